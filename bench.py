@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""Headline benchmark: gate-applies/s and HBM GB/s of the QubitCircuit statevector hot path.
+
+Workload (BASELINE.json configs[2]): QubitCircuit(28), seeded random H / Rx / CNOT
+circuit of depth 40 (1120 gates, seed 1234), complex64, batch = 16 with per-sample Rx angles (the
+``torch.vmap`` case of the reference), initial state |0...0>, no_grad forward.  One "step" = one
+forward pass of the whole circuit over the whole batch, inputs resident in HBM.
+
+N > 1 (launched by torchrun, one rank per GPU): weak scaling -- n = 28 + log2(N) qubits index-bit
+sharded over the N ranks, the same 2^28 amplitudes x 16 samples per GPU; the batch is processed as 16
+consecutive sharded circuits.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement), with two extra objects:
+``roofline`` for the dominant kernel (the fused pass) and ``cpu_baseline`` (the oracle = restatement of
+the reference's permute/reshape/matmul path, timed on this host's cores on a bounded sample).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--nqubit', type=int, default=28, help='qubits per GPU-sized shard (n = nqubit + log2 gpus)')
+    ap.add_argument('--depth', type=int, default=40)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--dtype', choices=['c64', 'c128'], default='c64')
+    ap.add_argument('--seed', type=int, default=1234)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--tile-bits', type=int, default=None, help='override fused tile size m')
+    ap.add_argument('--min-low', type=int, default=None)
+    ap.add_argument('--max-gates', type=int, default=None)
+    ap.add_argument('--no-fuse', action='store_true')
+    ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
+    return ap.parse_args()
+
+
+def build_circuit(dq, n, spec, batch, dtype, device, distributed=False):
+    """The generator's circuit; Rx angles are encoder inputs so each batch sample has its own."""
+    cir = dq.DistributedQubitCircuit(n) if distributed else dq.QubitCircuit(n)
+    angles = []
+    for op in spec:
+        if op[0] == 'h':
+            cir.h(op[1])
+        elif op[0] == 'rx':
+            cir.rx(op[1], encode=True)
+            angles.append(op[2])
+        else:
+            cir.cnot(op[1], op[2])
+    cir.observable(0)
+    cir.to(device)
+    if dtype == torch.complex128:
+        cir.to(torch.double)
+    real = torch.float64 if dtype == torch.complex128 else torch.float32
+    g = torch.Generator().manual_seed(1234)
+    data = torch.rand(batch, len(angles), generator=g, dtype=real) * 2 * math.pi
+    data[0] = torch.tensor(angles, dtype=real)  # sample 0 = the generator's own angles
+    return cir, data.to(device)
+
+
+def cpu_baseline(n, spec, dtype, budget_s):
+    """Oracle (port of the reference's evolve_state path) on this host: first gates of the same
+    workload, batch element 0, until ``budget_s`` seconds are spent."""
+    from oracle import statevec_oracle as oracle
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    real = torch.float32 if dtype == torch.complex64 else torch.float64
+    x = torch.zeros(1, 2**n, dtype=dtype)
+    x[0, 0] = 1
+    h = oracle.fixed_matrix('h').to(dtype)
+    cnot = (torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]]) + 0j).to(dtype)
+    done, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        for op in spec:
+            if op[0] == 'h':
+                x = oracle.apply_gate_wires(x, h, n, [op[1]])
+            elif op[0] == 'rx':
+                x = oracle.apply_gate_wires(x, oracle.rx_matrix(oracle.theta_tensor(op[2]).to(real)).to(dtype), n, [op[1]])
+            else:
+                x = oracle.apply_gate_wires(x, cnot, n, [op[1], op[2]])
+            done += 1
+            if time.perf_counter() - t0 > budget_s or done >= 64:
+                break
+    x = x.contiguous()
+    dt = time.perf_counter() - t0
+    return {
+        'value': done / dt,
+        'unit': 'gate-applies/s',
+        'cores': torch.get_num_threads(),
+        'kind': 'port',
+        'sample': f'first {done} gates of the same n={n} seed-1234 circuit, batch element 0 only, '
+                  f'{"c64" if dtype == torch.complex64 else "c128"}, {dt:.1f} s wall',
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    import deepquantum_amd as dq
+    from oracle.statevec_oracle import random_circuit_spec  # workload generator only
+
+    dtype = torch.complex64 if args.dtype == 'c64' else torch.complex128
+    amp_bytes = 8 if dtype == torch.complex64 else 16
+    distributed = world > 1
+    if distributed:
+        dq.setup_distributed('nccl')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    key = 'm_c64' if dtype == torch.complex64 else 'm_c128'
+    if args.tile_bits is not None:
+        dq.executor.CONFIG[key] = args.tile_bits
+    if args.min_low is not None:
+        dq.executor.CONFIG['min_low_c64' if dtype == torch.complex64 else 'min_low_c128'] = args.min_low
+    if args.max_gates is not None:
+        dq.executor.CONFIG['max_gates'] = args.max_gates
+    if args.no_fuse:
+        dq.executor.CONFIG['fuse'] = False
+
+    n = args.nqubit + int(math.log2(world))
+    spec = random_circuit_spec(n, args.depth, args.seed)
+    ngates = len(spec)
+    cir, data = build_circuit(dq, n, spec, args.batch, dtype, device, distributed)
+    # algorithmic bytes per gate: 2 * 2^(n - nc) * sizeof(amp) per batch sample
+    alg_bytes = sum(2 * (2 ** (n - (1 if op[0] == 'cnot' else 0))) * amp_bytes for op in spec) * args.batch
+
+    prof = dq.executor.PROFILE
+
+    def step():
+        with torch.no_grad():
+            if distributed:
+                ev = None
+                for b in range(args.batch):
+                    cir(data[b])
+                return ev
+            cir(data)
+            return cir.expectation()
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if distributed:
+            torch.distributed.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    prof['enabled'] = True
+    prof['events'].clear()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof['enabled'] = False
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # dominant kernel: the fused pass -- durations from HIP events recorded on the launch stream
+    kernel_ms = [a.elapsed_time(b) for a, b, _ in prof['events']]
+    launches = len(kernel_ms)
+    alg_per_launch = (alg_bytes * args.steps / launches) if launches else 0.0
+    avg_ms = (sum(kernel_ms) / launches) if launches else float('nan')
+    achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+    traffic = None
+    if args.traffic_json and os.path.exists(args.traffic_json):
+        traffic = json.load(open(args.traffic_json)).get('hbm_bytes_per_launch')
+    stats = dict(dq.executor.LAST_RUN)
+
+    if rank == 0:
+        total_gate_applies = ngates * args.batch * args.steps
+        value = total_gate_applies / elapsed
+        line = {
+            'metric': 'gate-applies/sec, 28q random circuit depth 40 (HBM GB/s in roofline)',
+            'value': value,
+            'unit': 'gate-applies/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'c64' if dtype == torch.complex64 else 'c128',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'QubitCircuit({n}) random H/Rx/CNOT depth {args.depth} ({ngates} gates, seed {args.seed}), '
+                            f'{"complex64" if dtype == torch.complex64 else "complex128"}, batch={args.batch} '
+                            f'(per-sample Rx angles), |0..0> start, no_grad forward'
+                            + (f', index-bit sharded over {world} GPUs' if distributed else ''),
+                'nqubit': n,
+                'depth': args.depth,
+                'batch': args.batch,
+                'parallelism': f'state-shard x{world}' if distributed else 'single GPU',
+                'fused_passes_per_step': stats.get('passes'),
+                'lds_round_trips_per_step': stats.get('transposes'),
+            },
+            'roofline': {
+                'bound': 'hbm',
+                'kernel': 'dq::fused_pass_kernel',
+                'achieved': achieved,
+                'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS,
+                'traffic': traffic,
+                'launches': launches,
+                'avg_launch_ms': avg_ms,
+                'algorithmic_bytes_per_launch': alg_per_launch,
+                'actual_state_bytes_per_launch': 2 * (2**n >> int(math.log2(world))) * amp_bytes * (1 if distributed else args.batch),
+                'note': 'achieved counts every fused gate as its own read+write of the state (SURVEY 8d), so it '
+                        'can exceed the HBM peak; actual_state_bytes_per_launch / avg_launch_ms is the physical rate',
+            },
+        }
+        line['roofline']['physical_GBs'] = (line['roofline']['actual_state_bytes_per_launch'] / (avg_ms * 1e-3) / 1e9
+                                            if launches else None)
+        if out is not None:
+            line['config']['expectation_Z0_sample0'] = float(out.reshape(-1)[0])
+        if not args.no_cpu_baseline and not distributed:
+            line['cpu_baseline'] = cpu_baseline(n, spec, dtype, args.cpu_seconds)
+        print(json.dumps(line))
+    if distributed:
+        dq.cleanup_distributed()
+
+
+if __name__ == '__main__':
+    main()

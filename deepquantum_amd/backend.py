@@ -1,0 +1,308 @@
+"""Tensor-level entry points of the statevector kernels.
+
+Every function takes PyTorch tensors (device memory owned by the caller), checks shapes on the host the
+way the reference asserts them (operation.py:91-107, 285-288), and enqueues the matching libdqhip call
+on ``torch.cuda.current_stream()``.  CUDA (= HIP on ROCm) tensors are required: a CPU tensor raises
+``RuntimeError`` -- there is no CPU fallback in the product.  The unit tests that exercise host logic
+without a GPU install an explicit test double with :func:`set_test_backend` (it lives under ``tests/``
+and is built on the oracle); the package itself never imports ``oracle/``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Sequence
+
+import torch
+
+from . import _lib
+
+_test_backend: Any = None
+
+
+def set_test_backend(obj: Any) -> None:
+    """Install (or clear with ``None``) a CPU test double.  For ``tests/`` only."""
+    global _test_backend
+    _test_backend = obj
+
+
+def get_test_backend() -> Any:
+    return _test_backend
+
+
+def _suffix(t: torch.Tensor) -> str:
+    if t.dtype == torch.complex64:
+        return 'c64'
+    if t.dtype == torch.complex128:
+        return 'c128'
+    raise TypeError(f'state must be complex64 or complex128, got {t.dtype}')
+
+
+def _use_hip(t: torch.Tensor) -> bool:
+    if t.is_cuda:
+        return True
+    if _test_backend is not None:
+        return False
+    raise RuntimeError(
+        'deepquantum_amd: statevector kernels run on MI355X only; got a tensor on '
+        f'{t.device}. Move the circuit/state to "cuda" (there is no CPU fallback).'
+    )
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _nqubit(state: torch.Tensor) -> int:
+    dim = state.shape[-1]
+    n = dim.bit_length() - 1
+    if state.ndim != 2 or (1 << n) != dim:
+        raise ValueError(f'state must have shape (batch, 2**n), got {tuple(state.shape)}')
+    return n
+
+
+def _check_mats(state: torch.Tensor, mats: torch.Tensor, k: int) -> tuple[torch.Tensor, int]:
+    """Return contiguous (Bm, D, D) matrices in the state's dtype/device and the batch stride."""
+    d = 1 << k
+    if mats.ndim == 2:
+        mats = mats.unsqueeze(0)
+    if mats.ndim != 3 or mats.shape[-1] != d or mats.shape[-2] != d:
+        raise ValueError(f'matrix must have shape (.., {d}, {d}), got {tuple(mats.shape)}')
+    if mats.shape[0] not in (1, state.shape[0]):
+        raise ValueError(f'matrix batch {mats.shape[0]} does not match state batch {state.shape[0]}')
+    if mats.dtype != state.dtype or mats.device != state.device:
+        mats = mats.to(device=state.device, dtype=state.dtype)
+    mats = mats.contiguous()
+    stride = 0 if mats.shape[0] == 1 else d * d
+    return mats, stride
+
+
+# ---------------------------------------------------------------------------------------------------
+def apply_gate(
+    state: torch.Tensor,
+    mats: torch.Tensor,
+    targets: Sequence[int],
+    controls: Sequence[int] = (),
+    out: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """psi' = (U on ``targets``, conditioned on all ``controls`` = 1) psi.
+
+    ``state``: (B, 2**n) contiguous complex; ``targets``/``controls``: bit positions (LSB = 0),
+    ``targets[0]`` is the matrix-index MSB.  ``out`` may be ``state`` itself (in place) for k <= 4.
+    Replaces qmath.evolve_state / Gate.op_state_control of the reference.
+    """
+    n = _nqubit(state)
+    targets, controls = [int(t) for t in targets], [int(c) for c in controls]
+    k = len(targets)
+    if not state.is_contiguous():
+        raise ValueError('state must be contiguous')
+    mats, stride = _check_mats(state, mats, k)
+    if out is None:
+        out = torch.empty_like(state)
+    if not _use_hip(state):
+        return _test_backend.apply_gate(state, mats, targets, controls, out)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_apply_gate_{_suffix(state)}')
+    rc = fn(_ptr(state), _ptr(out), _ptr(mats), stride, n, _lib.int_array(targets), k,
+            _lib.int_array(controls), len(controls), state.shape[0], _stream(state))
+    _lib.check(rc, 'dq_apply_gate')
+    return out
+
+
+def apply_fused(
+    state: torch.Tensor,
+    mats: torch.Tensor,
+    mat_batch_stride: int,
+    desc: _lib.DqFusedPass,
+    out: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """Run one fused pass (see fusion.py).  ``mats``: flat complex buffer (Bm * stride or stride)."""
+    n = _nqubit(state)
+    if out is None:
+        out = state
+    if mats.dtype != state.dtype or mats.device != state.device or not mats.is_contiguous():
+        raise ValueError('mats must be a contiguous buffer in the dtype/device of the state')
+    if not _use_hip(state):
+        return _test_backend.apply_fused(state, mats, mat_batch_stride, desc, out)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_apply_fused_{_suffix(state)}')
+    rc = fn(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, state.shape[0], C.byref(desc),
+            _stream(state))
+    _lib.check(rc, 'dq_apply_fused')
+    return out
+
+
+def fused_geometry(is_c128: bool, variant: int = 0) -> tuple[int, int, int]:
+    """(m, slots, threads) of a compiled fused-kernel variant."""
+    if _test_backend is not None and not torch.cuda.is_available():
+        return _test_backend.fused_geometry(is_c128, variant)
+    lib = _lib.load()
+    m, s, t = C.c_int(), C.c_int(), C.c_int()
+    _lib.check(lib.dq_fused_geometry(int(is_c128), variant, C.byref(m), C.byref(s), C.byref(t)),
+               'dq_fused_geometry')
+    return m.value, s.value, t.value
+
+
+_ws_cache: dict[tuple, torch.Tensor] = {}
+
+
+def _workspace(state: torch.Tensor) -> torch.Tensor:
+    key = (state.device, state.shape[0])
+    ws = _ws_cache.get(key)
+    if ws is None:
+        nbytes = _lib.load().dq_reduce_ws_bytes(state.shape[0])
+        ws = torch.empty(nbytes // 8, dtype=torch.float64, device=state.device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def expect_pauli(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
+    """Re <psi_b|P|psi_b> for the Pauli string (xmask, zmask); a Y sets its bit in both masks.
+    Returns float64 (B,)."""
+    n = _nqubit(state)
+    if not state.is_contiguous():
+        raise ValueError('state must be contiguous')
+    if not _use_hip(state):
+        return _test_backend.expect_pauli(state, xmask, zmask)
+    out = torch.empty(state.shape[0], dtype=torch.float64, device=state.device)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_expect_pauli_{_suffix(state)}')
+    rc = fn(_ptr(state), xmask, zmask, n, state.shape[0], _ptr(out), _ptr(_workspace(state)), _stream(state))
+    _lib.check(rc, 'dq_expect_pauli')
+    return out
+
+
+def inner(bra: torch.Tensor, ket: torch.Tensor) -> torch.Tensor:
+    """<bra_b|ket_b> as complex128 (B,).  Inputs (B, count) contiguous, same dtype."""
+    if bra.shape != ket.shape or bra.dtype != ket.dtype or bra.ndim != 2:
+        raise ValueError('bra/ket must be matching (B, count) tensors')
+    if not (bra.is_contiguous() and ket.is_contiguous()):
+        raise ValueError('bra/ket must be contiguous')
+    if not _use_hip(bra):
+        return _test_backend.inner(bra, ket)
+    out = torch.empty(bra.shape[0], 2, dtype=torch.float64, device=bra.device)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_inner_{_suffix(bra)}')
+    rc = fn(_ptr(bra), _ptr(ket), bra.shape[1], bra.shape[0], _ptr(out), _ptr(_workspace(bra)), _stream(bra))
+    _lib.check(rc, 'dq_inner')
+    return torch.view_as_complex(out)
+
+
+def probs(state: torch.Tensor) -> torch.Tensor:
+    """|psi|^2 elementwise in the state's real precision, same shape."""
+    if not state.is_contiguous():
+        raise ValueError('state must be contiguous')
+    if not _use_hip(state):
+        return _test_backend.probs(state)
+    out = torch.empty(state.shape, dtype=state.real.dtype, device=state.device)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_probs_{_suffix(state)}')
+    _lib.check(fn(_ptr(state), _ptr(out), state.numel(), _stream(state)), 'dq_probs')
+    return out
+
+
+def marginal(state: torch.Tensor, bits: Sequence[int]) -> torch.Tensor:
+    """Marginal distribution over ``bits`` (bits[0] = MSB of the outcome index), float64 (B, 2**nw)."""
+    n = _nqubit(state)
+    bits = [int(b) for b in bits]
+    if not _use_hip(state):
+        return _test_backend.marginal(state, bits)
+    nw = len(bits)
+    b = state.shape[0]
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_marginal_{_suffix(state)}')
+    max_b = max(1, 65535 >> nw)
+    if nw > 12:
+        raise NotImplementedError('marginal over more than 12 wires: measure all wires and reduce on the host')
+    out = torch.zeros(b, 1 << nw, dtype=torch.float64, device=state.device)
+    for lo in range(0, b, max_b):
+        hi = min(b, lo + max_b)
+        rc = fn(_ptr(state[lo:hi]), n, _lib.int_array(bits), nw, hi - lo, _ptr(out[lo:hi]), _stream(state))
+        _lib.check(rc, 'dq_marginal')
+    return out
+
+
+def gate_grad(
+    x: torch.Tensor, gy: torch.Tensor, targets: Sequence[int], controls: Sequence[int] = ()
+) -> torch.Tensor:
+    """gU[b] = sum over controlled amplitude groups of gy (outer) conj(x): complex128 (B, D, D)."""
+    n = _nqubit(x)
+    targets, controls = [int(t) for t in targets], [int(c) for c in controls]
+    k = len(targets)
+    if x.shape != gy.shape or x.dtype != gy.dtype:
+        raise ValueError('x/gy mismatch')
+    if not (x.is_contiguous() and gy.is_contiguous()):
+        raise ValueError('x/gy must be contiguous')
+    if not _use_hip(x):
+        return _test_backend.gate_grad(x, gy, targets, controls)
+    d = 1 << k
+    if k > 2:
+        # Dense blocks on > 2 wires with trainable entries (LatentGate on many wires) are rare; the
+        # contraction is a plain GEMM (gy_mat @ x_mat^H) and is left to rocBLAS through torch.
+        return _gate_grad_gemm(x, gy, n, targets, controls)
+    out = torch.zeros(x.shape[0], d, d, 2, dtype=torch.float64, device=x.device)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_gate_grad_{_suffix(x)}')
+    rc = fn(_ptr(x), _ptr(gy), n, _lib.int_array(targets), k, _lib.int_array(controls), len(controls),
+            x.shape[0], _ptr(out), _stream(x))
+    _lib.check(rc, 'dq_gate_grad')
+    return torch.view_as_complex(out)
+
+
+def _gate_grad_gemm(x, gy, n, targets, controls):
+    b = x.shape[0]
+    wires_t = [n - 1 - t + 1 for t in targets]
+    wires_c = [n - 1 - c + 1 for c in controls]
+    rest = [i for i in range(1, n + 1) if i not in wires_t and i not in wires_c]
+    perm = [0] + wires_t + rest + wires_c
+    d = 1 << len(targets)
+
+    def mat(t):
+        t = t.reshape([b] + [2] * n).permute(perm).reshape(b, d, -1, 1 << len(controls))
+        return t[..., -1]
+
+    return (mat(gy) @ mat(x).mH).to(torch.complex128)
+
+
+def pack(amps: torch.Tensor, mask: int, value: int) -> torch.Tensor:
+    """Gather the sub-cube of each shard whose bits under ``mask`` equal ``value`` into a contiguous
+    (B, 2**(nl - popcount(mask))) buffer."""
+    nl = _nqubit(amps)
+    if not _use_hip(amps):
+        return _test_backend.pack(amps, mask, value)
+    cnt = 1 << (nl - bin(mask).count('1'))
+    out = torch.empty(amps.shape[0], cnt, dtype=amps.dtype, device=amps.device)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_pack_{_suffix(amps)}')
+    _lib.check(fn(_ptr(amps), _ptr(out), nl, mask, value, amps.shape[0], _stream(amps)), 'dq_pack')
+    return out
+
+
+def unpack_axpby(
+    amps: torch.Tensor,
+    x: torch.Tensor,
+    y: torch.Tensor | None,
+    coef: torch.Tensor | None,
+    mask: int,
+    value: int,
+) -> torch.Tensor:
+    """amps[b, expand(c)] = coef[b,0] * x[b,c] + coef[b,1] * y[b,c] (or = x[b,c] when y is None), where
+    expand() re-inserts ``value`` at the ``mask`` bit positions.  In place on ``amps``."""
+    nl = _nqubit(amps)
+    if not _use_hip(amps):
+        return _test_backend.unpack_axpby(amps, x, y, coef, mask, value)
+    stride = 0
+    if y is not None:
+        coef = coef.to(device=amps.device, dtype=amps.dtype).reshape(-1, 2).contiguous()
+        if coef.shape[0] not in (1, amps.shape[0]):
+            raise ValueError('coef batch mismatch')
+        stride = 0 if coef.shape[0] == 1 else 2
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_unpack_axpby_{_suffix(amps)}')
+    rc = fn(_ptr(amps), _ptr(x), _ptr(y), _ptr(coef), stride, nl, mask, value, amps.shape[0], _stream(amps))
+    _lib.check(rc, 'dq_unpack_axpby')
+    return amps

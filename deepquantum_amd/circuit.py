@@ -1,0 +1,611 @@
+"""``QubitCircuit`` and ``DistributedQubitCircuit``: the circuit driver, API-compatible with the
+reference's circuit.py (:81-1623 and :1625-1770) for the statevector path.
+
+Differences that matter for performance, none for results:
+
+* ``forward`` does not loop over ``nn.Sequential(self.operators)`` gate by gate; it collects every
+  operator's kernel primitives and lets ``executor.run`` fuse them into HBM passes (no-grad) or run
+  one differentiable kernel per gate (autograd).
+* 2-D ``data`` is not ``torch.vmap``-ed over the circuit: encoders receive the whole (B, npara) slice
+  and produce batched (B, D, D) matrices; the kernels take a per-sample matrix stride.
+
+Out of scope here: density matrices, MPS, channels, MBQC patterns, circuit cutting,
+QASM, drawing -- the corresponding entry points raise ``NotImplementedError``.
+"""
+
+from __future__ import annotations
+
+from copy import copy
+from typing import Any
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import executor, qmath
+from .gate import (
+    CNOT, Barrier, Fredkin, Hadamard, HamiltonianGate, ImaginarySwap, LatentGate, PauliX, PauliY, PauliZ,
+    PhaseShift, ProjectionJ, ReconfigurableBeamSplitter, Rx, Rxx, Rxy, Ry, Ryy, Rz, Rzz, SDaggerGate, SGate, Swap,
+    TDaggerGate, TGate, Toffoli, U3Gate, UAnyGate,
+)
+from .layer import CnotLayer, CnotRing, HLayer, Observable, RxLayer, RyLayer, RzLayer, U3Layer, XLayer, YLayer, ZLayer
+from .operation import Gate, Layer, Operation
+from .qmath import amplitude_encoding, sample2expval, slice_state_vector
+from .state import DistributedQubitState, QubitState
+
+
+class QubitCircuit(Operation):
+    """A circuit on ``nqubit`` qubits: gate builders, ``cir(data, state)``, ``expectation()``,
+    ``measure()``, ``get_unitary()``."""
+
+    def __init__(
+        self,
+        nqubit: int,
+        init_state: Any = 'zeros',
+        name: str | None = None,
+        den_mat: bool = False,
+        reupload: bool = False,
+        mps: bool = False,
+        chi: int | None = None,
+        shots: int = 1024,
+    ) -> None:
+        if den_mat or mps:
+            raise NotImplementedError('deepquantum_amd: only the dense statevector path is implemented')
+        super().__init__(name=name, nqubit=nqubit, wires=None, den_mat=False)
+        self.reupload = reupload
+        self.mps = False
+        self.chi = chi
+        self.shots = shots
+        self.set_init_state(init_state)
+        self.operators = nn.Sequential()
+        self.encoders: list = []
+        self.observables = nn.ModuleList()
+        self.state = None
+        self.ndata = 0
+        self.depth = np.array([0] * nqubit)
+        self.wires_measure: list[int] = []
+        self.wires_condition: list[int] = []
+
+    # ---- state / bookkeeping ------------------------------------------------------------------------
+    def set_init_state(self, init_state: Any) -> None:
+        if isinstance(init_state, QubitState):
+            assert self.nqubit == init_state.nqubit
+            self.init_state = init_state
+        else:
+            self.init_state = QubitState(nqubit=self.nqubit, state=init_state)
+
+    def __add__(self, rhs: 'QubitCircuit') -> 'QubitCircuit':
+        assert self.nqubit == rhs.nqubit
+        cir = QubitCircuit(nqubit=self.nqubit, init_state=self.init_state, name=self.name, reupload=self.reupload)
+        cir.operators = self.operators + rhs.operators
+        cir.encoders = self.encoders + rhs.encoders
+        cir.observables = rhs.observables
+        cir.npara = self.npara + rhs.npara
+        cir.ndata = self.ndata + rhs.ndata
+        cir.depth = self.depth + rhs.depth
+        cir.wires_measure = rhs.wires_measure
+        cir.wires_condition = list(set(self.wires_condition + rhs.wires_condition))
+        return cir
+
+    def init_para(self) -> None:
+        for op in self.operators:
+            op.init_para()
+
+    def init_encoder(self) -> None:
+        """Re-draw the encoder parameters (scrubs batched buffers before ``state_dict()``)."""
+        for op in self.encoders:
+            op.init_para()
+
+    def reset_circuit(self, init_state: Any = 'zeros') -> None:
+        self.set_init_state(init_state)
+        self.operators = nn.Sequential()
+        self.encoders = []
+        self.observables = nn.ModuleList()
+        self.state = None
+        self.npara = 0
+        self.ndata = 0
+        self.depth = np.array([0] * self.nqubit)
+        self.wires_measure = []
+        self.wires_condition = []
+
+    def amplitude_encoding(self, data: Any) -> torch.Tensor:
+        return amplitude_encoding(data, self.nqubit)
+
+    def observable(self, wires: int | list[int] | None = None, basis: str = 'z') -> None:
+        self.observables.append(Observable(nqubit=self.nqubit, wires=wires, basis=basis, tsr_mode=False))
+
+    def reset_observable(self) -> None:
+        self.observables = nn.ModuleList()
+
+    @property
+    def max_depth(self) -> int:
+        return max(self.depth)
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def prims(self, decompose: bool = True) -> list:
+        out = []
+        for op in self.operators:
+            out.extend(op.prims(decompose))
+        return out
+
+    def forward(self, data: torch.Tensor | None = None, state: Any = None) -> torch.Tensor:
+        """Run the circuit.  ``data``: 1-D (one sample) or 2-D (batch) encoder inputs; ``state``:
+        (2**n, 1) or (B, 2**n, 1) initial state (default: the circuit's ``init_state``).  Returns the
+        final state with the leading batch dimension the reference would return
+        (reference: circuit.py:180-263)."""
+        if state is None:
+            state = self.init_state
+        if isinstance(state, QubitState):
+            state = state.state
+        if self.ndata == 0:
+            data = None
+        if data is None or data.ndim == 1:
+            out = self._forward_helper(data, state)
+            if out.ndim == 2:
+                out = out.unsqueeze(0)
+            if state.ndim == 2:
+                out = out.squeeze(0)
+            self.state = out
+        else:
+            assert data.ndim == 2
+            assert state.ndim in (2, 3)
+            out = self._forward_helper(data, state)
+            if out.ndim == 2:          # batch of one sample
+                out = out.unsqueeze(0)
+            self.state = out
+            self.encode(data[-1])
+        return self.state
+
+    def _forward_helper(self, data: torch.Tensor | None = None, state: Any = None) -> torch.Tensor:
+        self.encode(data)
+        if state is None:
+            state = self.init_state
+        if isinstance(state, QubitState):
+            state = state.state
+        dim = 2**self.nqubit
+        flat = state.reshape(-1, dim)
+        if data is not None and data.ndim == 2 and flat.shape[0] != data.shape[0]:
+            assert flat.shape[0] == 1, 'batch of data and batch of states differ'
+            flat = flat.expand(data.shape[0], dim)
+        x = executor.run(flat, self.prims())
+        if x is flat or x.data_ptr() == state.data_ptr():
+            x = x.clone()
+        return self.vector_rep(x).squeeze(0)
+
+    def encode(self, data: torch.Tensor | None) -> None:
+        """Feed ``data`` to the encoders in order; with ``reupload`` the data wraps around
+        (reference: circuit.py:265-293).  ``data`` may be (ndata,) or (B, ndata)."""
+        if data is None:
+            return
+        width = data.shape[-1]
+        if not self.reupload:
+            assert width >= self.ndata, 'The circuit needs more data, or consider data re-uploading'
+        count = 0
+        for op in self.encoders:
+            count_up = count + op.npara
+            if self.reupload and count_up > width:
+                reps = int(np.ceil(count_up / width))
+                op.init_para(torch.cat([data] * reps, dim=-1)[..., count:count_up])
+            else:
+                op.init_para(data[..., count:count_up])
+            count = count_up % width
+
+    # ---- read-out -----------------------------------------------------------------------------------
+    def measure(self, shots: int | None = None, with_prob: bool = False, wires: int | list[int] | None = None,
+                block_size: int = 2**24) -> dict | list[dict] | None:
+        if shots is None:
+            shots = self.shots
+        else:
+            self.shots = shots
+        if wires is None:
+            wires = list(range(self.nqubit))
+        self.wires_measure = self._convert_indices(wires)
+        if self.state is None:
+            return None
+        return qmath.measure(self.state, shots=shots, with_prob=with_prob, wires=self.wires_measure,
+                             block_size=block_size)
+
+    def expectation(self, shots: int | None = None) -> torch.Tensor:
+        """Expectation value of every registered observable, stacked on the last dimension
+        (reference: circuit.py:381-428)."""
+        assert len(self.observables) > 0, 'There is no observable'
+        assert isinstance(self.state, torch.Tensor), 'There is no final state'
+        assert self.wires_condition == [], 'Expectation with conditional measurement is NOT supported'
+        out = []
+        if shots is None:
+            for ob in self.observables:
+                out.append(qmath.expectation(self.state, observable=ob))
+        else:
+            self.shots = shots
+            dtype, device = self.state.real.dtype, self.state.device
+            for ob in self.observables:
+                basis_cir = QubitCircuit(nqubit=self.nqubit)
+                for wire, b in zip(ob.wires, ob.basis, strict=True):
+                    if b == 'x':
+                        basis_cir.h(wire)
+                    elif b == 'y':
+                        basis_cir.sdg(wire)
+                        basis_cir.h(wire)
+                basis_cir.to(device, dtype)
+                with torch.no_grad():
+                    basis_cir(state=self.state)
+                samples = basis_cir.measure(shots=shots, wires=sum(ob.wires, []))
+                if isinstance(samples, list):
+                    ev = torch.cat([sample2expval(s).to(device, dtype) for s in samples])
+                else:
+                    ev = sample2expval(samples).to(device, dtype)
+                    if self.state.ndim == 2:
+                        ev = ev.squeeze(0)
+                out.append(ev)
+        return torch.stack(out, dim=-1)
+
+    def defer_measure(self, with_prob: bool = False):
+        rst = self.measure(shots=1, with_prob=with_prob, wires=self.wires_condition)
+        if self.state.ndim == 2:
+            key = [*rst][0]
+            state = self._slice_state_vector(self.state, self.wires_condition, key)
+            return (state, key, rst[key][1]) if with_prob else state
+        states, keys, probs = [], [], []
+        for i, d in enumerate(rst):
+            key = [*d][0]
+            states.append(self._slice_state_vector(self.state[i], self.wires_condition, key))
+            if with_prob:
+                keys.append(key)
+                probs.append(d[key][1])
+        return (torch.stack(states), keys, probs) if with_prob else torch.stack(states)
+
+    def post_select(self, bits: str) -> torch.Tensor:
+        return self._slice_state_vector(self.state, self.wires_condition, bits)
+
+    def _slice_state_vector(self, state: torch.Tensor, wires: int | list[int], bits: str, normalize: bool = True):
+        return slice_state_vector(state, self.nqubit, self._convert_indices(wires), bits, normalize)
+
+    def get_unitary(self) -> torch.Tensor:
+        """2^n x 2^n matrix of the circuit: the gate kernels applied to all columns of the identity at
+        once (batch = 2^n), instead of the reference's chain of Kronecker-built dense GEMMs
+        (reference: circuit.py:467-477)."""
+        ops_ = [op for op in self.operators if not isinstance(op, Barrier)]
+        if not ops_:
+            return torch.eye(2**self.nqubit, dtype=torch.cfloat)
+        prims = self.prims(decompose=True)
+        if not prims:
+            return torch.eye(2**self.nqubit, dtype=torch.cfloat)
+        ref = prims[0].matrix
+        eye = torch.eye(2**self.nqubit, dtype=ref.dtype, device=ref.device)
+        cols = executor.run(eye, prims)
+        return cols.T.contiguous() if not cols.requires_grad else cols.T
+
+    def get_amplitude(self, bits: str) -> torch.Tensor:
+        assert len(bits) == self.nqubit
+        idx = int(bits, 2)
+        return self.state.reshape(-1, 2**self.nqubit)[:, idx].squeeze()
+
+    def get_prob(self, bits: str, wires: int | list[int] | None = None) -> torch.Tensor:
+        if wires is not None:
+            wires = self._convert_indices(wires)
+            if len(wires) != self.nqubit:
+                sub = slice_state_vector(self.state.reshape(1, -1) if self.state.ndim == 2 else self.state,
+                                         self.nqubit, wires, bits, False)
+                p = (torch.abs(sub) ** 2).sum(-1)
+                return p.squeeze(0) if self.state.ndim == 2 else p
+        return torch.abs(self.get_amplitude(bits)) ** 2
+
+    def inverse(self, encode: bool = False) -> 'QubitCircuit':
+        name = self.name + '_inverse' if isinstance(self.name, str) else self.name
+        cir = QubitCircuit(nqubit=self.nqubit, name=name, reupload=self.reupload)
+        for op in reversed(self.operators):
+            inv = op.inverse()
+            cir.add(inv)
+            if encode and op in self.encoders:
+                cir.encoders.append(inv)
+        cir.wires_condition = self.wires_condition
+        if encode:
+            cir.npara, cir.ndata = self.npara, self.ndata
+        else:
+            cir.npara, cir.ndata = self.npara + self.ndata, 0
+        return cir
+
+    # ---- construction -------------------------------------------------------------------------------
+    def add(self, op: Operation, encode: bool = False, wires: int | list[int] | None = None,
+            controls: int | list[int] | None = None) -> None:
+        """Append a gate, a layer or another circuit (reference: circuit.py:820-897)."""
+        assert isinstance(op, Operation)
+        if wires is not None:
+            assert isinstance(op, Gate)
+            wires = self._convert_indices(wires)
+            controls = self._convert_indices([] if controls is None else controls)
+            assert not set(wires) & set(controls), 'Use repeated wires'
+            assert len(wires) == len(op.wires), 'Invalid input'
+            op = copy(op)
+            op.wires = wires
+            op.controls = controls
+        if isinstance(op, QubitCircuit):
+            assert self.nqubit == op.nqubit
+            self.operators += op.operators
+            self.encoders += op.encoders
+            self.observables = op.observables
+            self.npara += op.npara
+            self.ndata += op.ndata
+            self.depth += op.depth
+            self.wires_measure = op.wires_measure
+            self.wires_condition = list(set(self.wires_condition + op.wires_condition))
+            return
+        op.tsr_mode = True
+        if isinstance(op, Gate):
+            self.operators.append(op)
+            for i in op.wires + op.controls:
+                self.depth[i] += 1
+            if op.condition:
+                self.wires_condition = list(set(self.wires_condition + op.controls))
+        elif isinstance(op, Layer):
+            self.operators.extend(op.gates)
+            for wire in op.wires:
+                for i in wire:
+                    self.depth[i] += 1
+        else:
+            raise NotImplementedError(f'{type(op).__name__} is outside the statevector path')
+        if encode:
+            assert not op.requires_grad, 'Please set requires_grad of the operation to be False'
+            self.encoders.append(op)
+            self.ndata += op.npara
+        else:
+            self.npara += op.npara
+
+    def _add_param(self, cls, wires, inputs, controls, condition, encode, **extra) -> None:
+        requires_grad = (not encode) and inputs is None
+        gate = cls(inputs=inputs, nqubit=self.nqubit, wires=wires, controls=controls, condition=condition,
+                   requires_grad=requires_grad, **extra)
+        self.add(gate, encode=encode)
+
+    def _add_fixed(self, cls, wires, controls=None, condition=False) -> None:
+        self.add(cls(nqubit=self.nqubit, wires=wires, controls=controls, condition=condition))
+
+    # single-qubit, parametric
+    def u3(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(U3Gate, wires, inputs, controls, condition, encode)
+
+    def cu(self, control, target, inputs=None, encode=False):
+        self._add_param(U3Gate, [target], inputs, [control], False, encode)
+
+    def p(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(PhaseShift, wires, inputs, controls, condition, encode)
+
+    def cp(self, control, target, inputs=None, encode=False):
+        self._add_param(PhaseShift, [target], inputs, [control], False, encode)
+
+    def rx(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(Rx, wires, inputs, controls, condition, encode)
+
+    def ry(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(Ry, wires, inputs, controls, condition, encode)
+
+    def rz(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(Rz, wires, inputs, controls, condition, encode)
+
+    def crx(self, control, target, inputs=None, encode=False):
+        self._add_param(Rx, [target], inputs, [control], False, encode)
+
+    def cry(self, control, target, inputs=None, encode=False):
+        self._add_param(Ry, [target], inputs, [control], False, encode)
+
+    def crz(self, control, target, inputs=None, encode=False):
+        self._add_param(Rz, [target], inputs, [control], False, encode)
+
+    def j(self, wires, inputs=None, plane='xy', controls=None, condition=False, encode=False):
+        self._add_param(ProjectionJ, wires, inputs, controls, condition, encode, plane=plane)
+
+    # single-qubit, fixed
+    def x(self, wires, controls=None, condition=False):
+        self._add_fixed(PauliX, wires, controls, condition)
+
+    def y(self, wires, controls=None, condition=False):
+        self._add_fixed(PauliY, wires, controls, condition)
+
+    def z(self, wires, controls=None, condition=False):
+        self._add_fixed(PauliZ, wires, controls, condition)
+
+    def h(self, wires, controls=None, condition=False):
+        self._add_fixed(Hadamard, wires, controls, condition)
+
+    def s(self, wires, controls=None, condition=False):
+        self._add_fixed(SGate, wires, controls, condition)
+
+    def sdg(self, wires, controls=None, condition=False):
+        self._add_fixed(SDaggerGate, wires, controls, condition)
+
+    def t(self, wires, controls=None, condition=False):
+        self._add_fixed(TGate, wires, controls, condition)
+
+    def tdg(self, wires, controls=None, condition=False):
+        self._add_fixed(TDaggerGate, wires, controls, condition)
+
+    def ch(self, control, target):
+        self._add_fixed(Hadamard, [target], [control])
+
+    def cs(self, control, target):
+        self._add_fixed(SGate, [target], [control])
+
+    def csdg(self, control, target):
+        self._add_fixed(SDaggerGate, [target], [control])
+
+    def ct(self, control, target):
+        self._add_fixed(TGate, [target], [control])
+
+    def ctdg(self, control, target):
+        self._add_fixed(TDaggerGate, [target], [control])
+
+    # two- and three-qubit
+    def cnot(self, control, target):
+        self.add(CNOT(nqubit=self.nqubit, wires=[control, target]))
+
+    def cx(self, control, target):
+        self._add_fixed(PauliX, [target], [control])
+
+    def cy(self, control, target):
+        self._add_fixed(PauliY, [target], [control])
+
+    def cz(self, control, target):
+        self._add_fixed(PauliZ, [target], [control])
+
+    def swap(self, wires, controls=None, condition=False):
+        self._add_fixed(Swap, wires, controls, condition)
+
+    def iswap(self, wires, controls=None, condition=False):
+        self._add_fixed(ImaginarySwap, wires, controls, condition)
+
+    def rxx(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(Rxx, wires, inputs, controls, condition, encode)
+
+    def ryy(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(Ryy, wires, inputs, controls, condition, encode)
+
+    def rzz(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(Rzz, wires, inputs, controls, condition, encode)
+
+    def rxy(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(Rxy, wires, inputs, controls, condition, encode)
+
+    def rbs(self, wires, inputs=None, controls=None, condition=False, encode=False):
+        self._add_param(ReconfigurableBeamSplitter, wires, inputs, controls, condition, encode)
+
+    def crxx(self, control, target1, target2, inputs=None, encode=False):
+        self._add_param(Rxx, [target1, target2], inputs, [control], False, encode)
+
+    def cryy(self, control, target1, target2, inputs=None, encode=False):
+        self._add_param(Ryy, [target1, target2], inputs, [control], False, encode)
+
+    def crzz(self, control, target1, target2, inputs=None, encode=False):
+        self._add_param(Rzz, [target1, target2], inputs, [control], False, encode)
+
+    def crxy(self, control, target1, target2, inputs=None, encode=False):
+        self._add_param(Rxy, [target1, target2], inputs, [control], False, encode)
+
+    def toffoli(self, control1, control2, target):
+        self.add(Toffoli(nqubit=self.nqubit, wires=[control1, control2, target]))
+
+    def ccx(self, control1, control2, target):
+        self._add_fixed(PauliX, [target], [control1, control2])
+
+    def fredkin(self, control, target1, target2):
+        self.add(Fredkin(nqubit=self.nqubit, wires=[control, target1, target2]))
+
+    def cswap(self, control, target1, target2):
+        self._add_fixed(Swap, [target1, target2], [control])
+
+    # arbitrary
+    def any(self, unitary, wires=None, minmax=None, controls=None, name='uany'):
+        self.add(UAnyGate(unitary=unitary, nqubit=self.nqubit, wires=wires, minmax=minmax, controls=controls, name=name))
+
+    def latent(self, wires=None, minmax=None, inputs=None, controls=None, encode=False, name='latent'):
+        requires_grad = (not encode) and inputs is None
+        self.add(LatentGate(inputs=inputs, nqubit=self.nqubit, wires=wires, minmax=minmax, controls=controls,
+                            name=name, requires_grad=requires_grad), encode=encode)
+
+    def hamiltonian(self, hamiltonian, t=None, wires=None, minmax=None, controls=None, encode=False,
+                    name='hamiltonian'):
+        requires_grad = (not encode) and t is None
+        self.add(HamiltonianGate(hamiltonian=hamiltonian, t=t, nqubit=self.nqubit, wires=wires, minmax=minmax,
+                                 controls=controls, name=name, requires_grad=requires_grad), encode=encode)
+
+    # layers
+    def xlayer(self, wires=None):
+        self.add(XLayer(nqubit=self.nqubit, wires=wires))
+
+    def ylayer(self, wires=None):
+        self.add(YLayer(nqubit=self.nqubit, wires=wires))
+
+    def zlayer(self, wires=None):
+        self.add(ZLayer(nqubit=self.nqubit, wires=wires))
+
+    def hlayer(self, wires=None):
+        self.add(HLayer(nqubit=self.nqubit, wires=wires))
+
+    def _add_param_layer(self, cls, wires, inputs, encode):
+        requires_grad = (not encode) and inputs is None
+        self.add(cls(nqubit=self.nqubit, wires=wires, inputs=inputs, requires_grad=requires_grad), encode=encode)
+
+    def rxlayer(self, wires=None, inputs=None, encode=False):
+        self._add_param_layer(RxLayer, wires, inputs, encode)
+
+    def rylayer(self, wires=None, inputs=None, encode=False):
+        self._add_param_layer(RyLayer, wires, inputs, encode)
+
+    def rzlayer(self, wires=None, inputs=None, encode=False):
+        self._add_param_layer(RzLayer, wires, inputs, encode)
+
+    def u3layer(self, wires=None, inputs=None, encode=False):
+        self._add_param_layer(U3Layer, wires, inputs, encode)
+
+    def cxlayer(self, wires=None):
+        self.add(CnotLayer(nqubit=self.nqubit, wires=wires))
+
+    def cnot_ring(self, minmax=None, step=1, reverse=False):
+        self.add(CnotRing(nqubit=self.nqubit, minmax=minmax, step=step, reverse=reverse))
+
+    def barrier(self, wires=None):
+        self.add(Barrier(nqubit=self.nqubit, wires=wires))
+
+    # explicitly out of scope -----------------------------------------------------------------------
+    def _out_of_scope(self, *a, **k):
+        raise NotImplementedError('outside the accelerated statevector path (SURVEY section 2, OUT OF SCOPE)')
+
+    qasm = pattern = draw = transform_cut2move = get_subexperiments = _out_of_scope
+    bit_flip = phase_flip = depolarizing = pauli = amp_damp = phase_damp = gen_amp_damp = _out_of_scope
+    reset = cut = move = _out_of_scope
+
+
+class DistributedQubitCircuit(QubitCircuit):
+    """Circuit on an index-bit-sharded state, one process per GPU (reference: circuit.py:1625-1770)."""
+
+    def __init__(self, nqubit: int, name: str | None = None, reupload: bool = False, shots: int = 1024) -> None:
+        super().__init__(nqubit=nqubit, init_state='zeros', name=name, reupload=reupload, shots=shots)
+
+    def set_init_state(self, init_state: Any = 'zeros') -> None:
+        if isinstance(init_state, DistributedQubitState):
+            self.init_state = init_state
+        elif init_state == 'zeros':
+            self.init_state = DistributedQubitState(self.nqubit)
+
+    @torch.no_grad()
+    def forward(self, data: torch.Tensor | None = None, state: DistributedQubitState | None = None):
+        from .distributed import dist_run
+
+        if state is None:
+            self.init_state.reset()
+        else:
+            self.init_state = state
+        with torch.enable_grad():
+            self.encode(data)
+        self.state = dist_run(self.init_state, self.operators)
+        return self.state
+
+    def measure(self, shots=None, with_prob=False, wires=None, block_size=2**24):
+        from .distributed import measure_dist
+
+        if shots is None:
+            shots = self.shots
+        else:
+            self.shots = shots
+        if wires is None:
+            wires = list(range(self.nqubit))
+        self.wires_measure = self._convert_indices(wires)
+        if self.state is None:
+            return None
+        return measure_dist(self.state, shots=shots, with_prob=with_prob, wires=self.wires_measure,
+                            block_size=block_size)
+
+    def expectation(self, shots: int | None = None) -> torch.Tensor:
+        from .adjoint import adjoint_expectation
+
+        assert len(self.observables) > 0, 'There is no observable'
+        assert isinstance(self.state, DistributedQubitState), 'There is no final state'
+        if shots is not None:
+            raise NotImplementedError('sampled expectation on the sharded state is not implemented yet')
+        out = [adjoint_expectation(self.state, self.operators, ob) for ob in self.observables]
+        return torch.stack(out, dim=-1)
+
+    def cnot(self, control: int, target: int) -> None:
+        super().cx(control, target)
+
+    def toffoli(self, control1: int, control2: int, target: int) -> None:
+        super().ccx(control1, control2, target)

@@ -1,0 +1,128 @@
+// Shard exchange helpers for the index-bit-partitioned state: gather the sub-cube of a shard that
+// has to travel to the partner rank into a contiguous send buffer, and combine/scatter what came
+// back.  Replaces the arange + boolean-mask gathers and the axpby on the received half in the
+// reference (distributed.py:70, 109-126, 150-157).  HBM-bound streams; the exchange itself is done
+// by the host through torch.distributed (RCCL over xGMI).
+#include "dq_common.hpp"
+
+namespace dq {
+
+struct MaskGeom {
+    BitList sorted;  // positions of the mask bits, ascending
+    uint64_t value;
+    int nl;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const cx<T>* __restrict__ amps, cx<T>* __restrict__ packed,
+                                                    MaskGeom g, uint64_t count) {
+    const int64_t b = blockIdx.y;
+    const cx<T>* src = amps + ((uint64_t)b << g.nl);
+    cx<T>* dst = packed + (uint64_t)b * count;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < count;
+         c += (uint64_t)gridDim.x * blockDim.x)
+        dst[c] = src[insert_zeros(c, g.sorted) | g.value];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_axpby_kernel(cx<T>* amps, const cx<T>* x,
+                                                            const cx<T>* y, const cx<T>* __restrict__ coef,
+                                                            int64_t coef_bstride, MaskGeom g, uint64_t count) {
+    const int64_t b = blockIdx.y;
+    cx<T>* dst = amps + ((uint64_t)b << g.nl);
+    const cx<T>* px = x + (uint64_t)b * count;
+    if (y == nullptr) {
+        for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < count;
+             c += (uint64_t)gridDim.x * blockDim.x)
+            dst[insert_zeros(c, g.sorted) | g.value] = px[c];
+        return;
+    }
+    const cx<T>* py = y + (uint64_t)b * count;
+    const cx<T> ca = coef[b * coef_bstride], cb = coef[b * coef_bstride + 1];
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < count;
+         c += (uint64_t)gridDim.x * blockDim.x) {
+        const cx<T> r = cfma(cb, py[c], cmul(ca, px[c]));
+        dst[insert_zeros(c, g.sorted) | g.value] = r;
+    }
+}
+
+static int make_geom(int nl, uint64_t mask, uint64_t value, MaskGeom& g, const char* who) {
+    if (nl < 0 || nl > 40) {
+        set_error("%s: nl=%d out of range", who, nl);
+        return DQ_ERR_ARG;
+    }
+    const uint64_t full = (1ull << nl) - 1ull;
+    if ((mask & ~full) || (value & ~mask)) {
+        set_error("%s: mask/value inconsistent with nl=%d", who, nl);
+        return DQ_ERR_ARG;
+    }
+    g.nl = nl;
+    g.value = value;
+    g.sorted.n = 0;
+    for (int p = 0; p < nl; ++p)
+        if ((mask >> p) & 1ull) {
+            if (g.sorted.n >= 16) {
+                set_error("%s: more than 16 mask bits", who);
+                return DQ_ERR_UNSUPPORTED;
+            }
+            g.sorted.pos[g.sorted.n++] = p;
+        }
+    return DQ_OK;
+}
+
+template <typename T>
+static int pack_impl(const void* amps, void* packed, int nl, uint64_t mask, uint64_t value, int64_t batch,
+                     dq_stream_t stream) {
+    if (!amps || !packed || batch < 1 || batch > 65535) {
+        set_error("dq_pack: bad argument");
+        return DQ_ERR_ARG;
+    }
+    MaskGeom g;
+    int rc = make_geom(nl, mask, value, g, "dq_pack");
+    if (rc) return rc;
+    const uint64_t count = 1ull << (nl - g.sorted.n);
+    uint64_t nb = (count + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(pack_kernel<T>, dim3((unsigned)nb, (unsigned)batch), dim3(256), 0, as_stream(stream),
+                       static_cast<const cx<T>*>(amps), static_cast<cx<T>*>(packed), g, count);
+    return check_launch("dq_pack");
+}
+
+template <typename T>
+static int unpack_impl(void* amps, const void* x, const void* y, const void* coef, int64_t coef_bstride, int nl,
+                       uint64_t mask, uint64_t value, int64_t batch, dq_stream_t stream) {
+    if (!amps || !x || (y && !coef) || batch < 1 || batch > 65535) {
+        set_error("dq_unpack_axpby: bad argument");
+        return DQ_ERR_ARG;
+    }
+    MaskGeom g;
+    int rc = make_geom(nl, mask, value, g, "dq_unpack_axpby");
+    if (rc) return rc;
+    const uint64_t count = 1ull << (nl - g.sorted.n);
+    uint64_t nb = (count + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(unpack_axpby_kernel<T>, dim3((unsigned)nb, (unsigned)batch), dim3(256), 0, as_stream(stream),
+                       static_cast<cx<T>*>(amps), static_cast<const cx<T>*>(x), static_cast<const cx<T>*>(y),
+                       static_cast<const cx<T>*>(coef), coef_bstride, g, count);
+    return check_launch("dq_unpack_axpby");
+}
+
+}  // namespace dq
+
+extern "C" int dq_pack_c64(const void* amps, void* packed, int nl, uint64_t mask, uint64_t value, int64_t batch,
+                           dq_stream_t stream) {
+    return dq::pack_impl<float>(amps, packed, nl, mask, value, batch, stream);
+}
+extern "C" int dq_pack_c128(const void* amps, void* packed, int nl, uint64_t mask, uint64_t value, int64_t batch,
+                            dq_stream_t stream) {
+    return dq::pack_impl<double>(amps, packed, nl, mask, value, batch, stream);
+}
+extern "C" int dq_unpack_axpby_c64(void* amps, const void* x, const void* y, const void* coef, int64_t coef_batch_stride,
+                                   int nl, uint64_t mask, uint64_t value, int64_t batch, dq_stream_t stream) {
+    return dq::unpack_impl<float>(amps, x, y, coef, coef_batch_stride, nl, mask, value, batch, stream);
+}
+extern "C" int dq_unpack_axpby_c128(void* amps, const void* x, const void* y, const void* coef,
+                                    int64_t coef_batch_stride, int nl, uint64_t mask, uint64_t value, int64_t batch,
+                                    dq_stream_t stream) {
+    return dq::unpack_impl<double>(amps, x, y, coef, coef_batch_stride, nl, mask, value, batch, stream);
+}

@@ -1,0 +1,505 @@
+// Fused gate pass for gfx950: one HBM read + one HBM write of the statevector applies a whole group
+// of 1- and 2-qubit gates.  Replaces a run of consecutive Gate.forward calls of the reference
+// (circuit.py:261 -> operation.py:274-289 -> qmath.py:485-506 / operation.py:203-219), each of which
+// costs the reference >= 2 full read+write passes.
+//
+// Geometry.  A workgroup of 2^LOGT threads owns one tile of 2^M amplitudes, M = R + LOGT: every
+// thread keeps 2^R amplitudes in VGPRs ("register slots").  The M tile bits are the low L index bits
+// (contiguous -> every wave-level load/store instruction moves >= 512 contiguous bytes) plus
+// h = M - L gathered high bits chosen per pass by the host scheduler.  A pass is a list of rounds; a
+// round names which R tile bits are register slots, and its gates act on register slots only, so a
+// gate costs VALU work but no memory traffic of any kind.  Between rounds the tile is re-distributed
+// through LDS (one write + one read, XOR-swizzled).  Control qubits never need to be slots: a
+// control on a thread bit is a per-lane predicate, a control outside the tile is a workgroup-uniform
+// branch.  Diagonal gates act wherever their qubit happens to be.
+//
+// The first and last layouts are the "canonical" one used for global I/O: c64 keeps tile bit 0 and
+// the top R-1 tile bits as slots (so a lane moves 16 B per instruction and a wave 1 KiB), c128 the
+// top R tile bits.  A pass whose gates only touch those bits runs with no LDS traffic at all.
+//
+// Roofline: HBM-bound by construction.  Algorithmic bytes per launch = sum over the gates of the
+// pass of 2 * 2^(n - nc) * sizeof(amp) * batch; actual traffic = 2 * 2^n * sizeof(amp) * batch.
+#include "dq_common.hpp"
+
+namespace dq {
+
+// ---- gate bodies on the register file ---------------------------------------------------------------
+template <typename T, int R, int Q>
+__device__ __forceinline__ void gen1_body(cx<T> (&a)[1 << R], const cx<T> m00, const cx<T> m01, const cx<T> m10,
+                                          const cx<T> m11, const unsigned reg_cmask, const bool thr_ok) {
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+        if ((j >> Q) & 1) continue;
+        if (thr_ok && ((j & reg_cmask) == reg_cmask)) {
+            const cx<T> x0 = a[j], x1 = a[j | (1 << Q)];
+            a[j] = cfma(m01, x1, cmul(m00, x0));
+            a[j | (1 << Q)] = cfma(m11, x1, cmul(m10, x0));
+        }
+    }
+}
+
+template <typename T, int R, int Q>
+__device__ __forceinline__ void x1_body(cx<T> (&a)[1 << R], const unsigned reg_cmask, const bool thr_ok) {
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+        if ((j >> Q) & 1) continue;
+        if (thr_ok && ((j & reg_cmask) == reg_cmask)) {
+            const cx<T> x0 = a[j];
+            a[j] = a[j | (1 << Q)];
+            a[j | (1 << Q)] = x0;
+        }
+    }
+}
+
+template <typename T, int R, int Q, int Q2>
+__device__ __forceinline__ void gen2_body(cx<T> (&a)[1 << R], const cx<T>* __restrict__ mp, const unsigned reg_cmask,
+                                          const bool thr_ok) {
+    cx<T> m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = mp[i];
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+        if (((j >> Q) & 1) || ((j >> Q2) & 1)) continue;
+        if (thr_ok && ((j & reg_cmask) == reg_cmask)) {
+            // matrix index = (bit of slot Q) * 2 + (bit of slot Q2)
+            const int i0 = j, i1 = j | (1 << Q2), i2 = j | (1 << Q), i3 = j | (1 << Q) | (1 << Q2);
+            const cx<T> x0 = a[i0], x1 = a[i1], x2 = a[i2], x3 = a[i3];
+            a[i0] = cfma(m[3], x3, cfma(m[2], x2, cfma(m[1], x1, cmul(m[0], x0))));
+            a[i1] = cfma(m[7], x3, cfma(m[6], x2, cfma(m[5], x1, cmul(m[4], x0))));
+            a[i2] = cfma(m[11], x3, cfma(m[10], x2, cfma(m[9], x1, cmul(m[8], x0))));
+            a[i3] = cfma(m[15], x3, cfma(m[14], x2, cfma(m[13], x1, cmul(m[12], x0))));
+        }
+    }
+}
+
+template <typename T, int R>
+__device__ __forceinline__ void dispatch_gen1(cx<T> (&a)[1 << R], int q, const cx<T>* __restrict__ mp,
+                                              unsigned reg_cmask, bool thr_ok) {
+    const cx<T> m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+    switch (q) {
+        case 0: gen1_body<T, R, 0>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
+        case 1: gen1_body<T, R, 1>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
+        case 2: gen1_body<T, R, 2>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
+        default:
+            if constexpr (R > 3) gen1_body<T, R, 3>(a, m00, m01, m10, m11, reg_cmask, thr_ok);
+            break;
+    }
+}
+
+template <typename T, int R>
+__device__ __forceinline__ void dispatch_x1(cx<T> (&a)[1 << R], int q, unsigned reg_cmask, bool thr_ok) {
+    switch (q) {
+        case 0: x1_body<T, R, 0>(a, reg_cmask, thr_ok); break;
+        case 1: x1_body<T, R, 1>(a, reg_cmask, thr_ok); break;
+        case 2: x1_body<T, R, 2>(a, reg_cmask, thr_ok); break;
+        default:
+            if constexpr (R > 3) x1_body<T, R, 3>(a, reg_cmask, thr_ok);
+            break;
+    }
+}
+
+template <typename T, int R, int Q>
+__device__ __forceinline__ void dispatch_gen2_q2(cx<T> (&a)[1 << R], int q2, const cx<T>* __restrict__ mp,
+                                                 unsigned reg_cmask, bool thr_ok) {
+    switch (q2) {
+        case 0:
+            if constexpr (Q != 0) gen2_body<T, R, Q, 0>(a, mp, reg_cmask, thr_ok);
+            break;
+        case 1:
+            if constexpr (Q != 1) gen2_body<T, R, Q, 1>(a, mp, reg_cmask, thr_ok);
+            break;
+        case 2:
+            if constexpr (Q != 2) gen2_body<T, R, Q, 2>(a, mp, reg_cmask, thr_ok);
+            break;
+        default:
+            if constexpr (R > 3 && Q != 3) gen2_body<T, R, Q, 3>(a, mp, reg_cmask, thr_ok);
+            break;
+    }
+}
+
+template <typename T, int R>
+__device__ __forceinline__ void dispatch_gen2(cx<T> (&a)[1 << R], int q, int q2, const cx<T>* __restrict__ mp,
+                                              unsigned reg_cmask, bool thr_ok) {
+    switch (q) {
+        case 0: dispatch_gen2_q2<T, R, 0>(a, q2, mp, reg_cmask, thr_ok); break;
+        case 1: dispatch_gen2_q2<T, R, 1>(a, q2, mp, reg_cmask, thr_ok); break;
+        case 2: dispatch_gen2_q2<T, R, 2>(a, q2, mp, reg_cmask, thr_ok); break;
+        default:
+            if constexpr (R > 3) dispatch_gen2_q2<T, R, 3>(a, q2, mp, reg_cmask, thr_ok);
+            break;
+    }
+}
+
+// XOR swizzle of the LDS element index: spreads power-of-two strides over the bank slots
+// (tools/lds_swizzle_eval.py).  Bijective on [0, 2^M).
+template <int ESZ> __device__ __forceinline__ unsigned lds_swz(unsigned e) {
+    if constexpr (ESZ == 8)
+        return e ^ ((e >> 5) & 31u);
+    else
+        return e ^ ((e >> 4) & 15u);
+}
+
+template <typename T, int R, int LOGT>
+__global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, cx<T>* out,
+                                                               const cx<T>* __restrict__ mats, int64_t mat_bstride,
+                                                               int n, const DqFusedPass p) {
+    constexpr int M = R + LOGT;
+    constexpr int NA = 1 << R;
+    constexpr int VB = (sizeof(T) == 4) ? 1 : 0;  // low slots of the canonical layout (16 B per lane)
+    using V = cx<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dq_smem[];
+    V* lds = reinterpret_cast<V*>(dq_smem);
+
+    const unsigned tid = threadIdx.x;
+    const int L = p.L, h = p.h;
+
+    // ---- tile base address (workgroup-uniform) ----
+    uint64_t tile = (uint64_t)blockIdx.x << L;
+    for (int i = 0; i < h; ++i) tile = insert_zero(tile, p.high_sorted[i]);
+    const uint64_t state_off = ((uint64_t)blockIdx.y << n) + tile;
+    const V* pin = in + state_off;
+    V* pout = out + state_off;
+    const V* mbase = mats + (int64_t)blockIdx.y * mat_bstride;
+
+    // tile-local index -> offset inside the state
+    auto glob = [&](unsigned e) __attribute__((always_inline)) -> uint64_t {
+        uint64_t g = e & ((1u << L) - 1u);
+        for (int i = 0; i < h; ++i) g |= (uint64_t)((e >> (L + i)) & 1u) << p.high_pos[i];
+        return g;
+    };
+
+    // ---- load layout: slots from the descriptor, thread bits = remaining tile bits ascending ----
+    unsigned rb[R];  // current register-slot tile bits (ascending)
+    unsigned tbase = tid;  // current thread base (tile-local)
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+        rb[s] = p.load_rb[s];
+        tbase = (unsigned)insert_zero(tbase, (int)rb[s]);
+    }
+
+    V a[NA];
+    {
+        const uint64_t gt = glob(tbase);
+        uint64_t gs[R];
+#pragma unroll
+        for (int s = 0; s < R; ++s) gs[s] = glob(1u << rb[s]);
+        if constexpr (VB == 1) {
+#pragma unroll
+            for (int j = 0; j < NA; j += 2) {
+                uint64_t o = gt;
+#pragma unroll
+                for (int s = 1; s < R; ++s)
+                    if ((j >> s) & 1) o += gs[s];
+                const float4 v = *reinterpret_cast<const float4*>(pin + o);
+                a[j] = mk<T>(v.x, v.y);
+                a[j + 1] = mk<T>(v.z, v.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                uint64_t o = gt;
+#pragma unroll
+                for (int s = 0; s < R; ++s)
+                    if ((j >> s) & 1) o += gs[s];
+                a[j] = pin[o];
+            }
+        }
+    }
+
+    auto transpose_to = [&](const unsigned (&nrb)[R], const unsigned ntbase) __attribute__((always_inline)) {
+        unsigned so[NA], sn[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            unsigned x = 0, y = 0;
+#pragma unroll
+            for (int s = 0; s < R; ++s)
+                if ((j >> s) & 1) {
+                    x |= 1u << rb[s];
+                    y |= 1u << nrb[s];
+                }
+            so[j] = x;
+            sn[j] = y;
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) lds[lds_swz<sizeof(V)>(tbase | so[j])] = a[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NA; ++j) a[j] = lds[lds_swz<sizeof(V)>(ntbase | sn[j])];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < R; ++s) rb[s] = nrb[s];
+        tbase = ntbase;
+    };
+
+    const uint64_t tile_global = tile;  // global index bits fixed for this workgroup (outside the tile)
+
+    for (int r = 0; r < p.nrounds; ++r) {
+        const DqFusedRound& rd = p.rounds[r];
+        unsigned nrb[R];
+        bool same = true;
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            nrb[s] = rd.rb[s];
+            same = same && (nrb[s] == rb[s]);
+        }
+        unsigned ntbase = 0;
+#pragma unroll
+        for (int i = 0; i < LOGT; ++i) ntbase |= ((tid >> i) & 1u) << rd.tb[i];
+        if (!same || ntbase != tbase) {
+            // NB: `same` is uniform; a differing thread order with identical slots also needs the trip.
+            transpose_to(nrb, ntbase);
+        }
+        for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
+            const DqFusedGate& g = p.gates[gi];
+            if ((tile_global & g.out_cmask) != g.out_cmask) continue;  // uniform: control outside tile is 0
+            const bool thr_ok = (tbase & g.thr_cmask) == g.thr_cmask;
+            const V* mp = mbase + g.mat;
+            switch (g.kind) {
+                case DQ_FG_GEN1: dispatch_gen1<T, R>(a, g.q, mp, g.reg_cmask, thr_ok); break;
+                case DQ_FG_X1: dispatch_x1<T, R>(a, g.q, g.reg_cmask, thr_ok); break;
+                case DQ_FG_GEN2: dispatch_gen2<T, R>(a, g.q, g.q2, mp, g.reg_cmask, thr_ok); break;
+                case DQ_FG_DIAG1: {
+                    const V d0 = mp[0], d1 = mp[3];
+                    int fixed = -1;  // target bit value when it is not a register slot
+                    if (g.loc == DQ_LOC_THR) fixed = (tbase >> g.q) & 1u;
+                    else if (g.loc == DQ_LOC_OUT) fixed = (int)((tile_global >> g.q) & 1ull);
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) {
+                        if (thr_ok && ((j & g.reg_cmask) == g.reg_cmask)) {
+                            const int bit = (fixed >= 0) ? fixed : ((j >> g.q) & 1);
+                            a[j] = cmul(bit ? d1 : d0, a[j]);
+                        }
+                    }
+                    break;
+                }
+                default: {  // DQ_FG_DIAG2: index = bit(target1) * 2 + bit(target2)
+                    const V d0 = mp[0], d1 = mp[5], d2 = mp[10], d3 = mp[15];
+                    int f1 = -1, f2 = -1;
+                    if (g.loc == DQ_LOC_THR) f1 = (tbase >> g.q) & 1u;
+                    else if (g.loc == DQ_LOC_OUT) f1 = (int)((tile_global >> g.q) & 1ull);
+                    if (g.loc2 == DQ_LOC_THR) f2 = (tbase >> g.q2) & 1u;
+                    else if (g.loc2 == DQ_LOC_OUT) f2 = (int)((tile_global >> g.q2) & 1ull);
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) {
+                        if (thr_ok && ((j & g.reg_cmask) == g.reg_cmask)) {
+                            const int b1 = (f1 >= 0) ? f1 : ((j >> g.q) & 1);
+                            const int b2 = (f2 >= 0) ? f2 : ((j >> g.q2) & 1);
+                            const V ph = b1 ? (b2 ? d3 : d2) : (b2 ? d1 : d0);
+                            a[j] = cmul(ph, a[j]);
+                        }
+                    }
+                    break;
+                }
+            }
+        }
+    }
+
+    {  // ---- store layout ----
+        unsigned srb[R];
+        unsigned stbase = tid;
+        bool same = true;
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            srb[s] = p.store_rb[s];
+            stbase = (unsigned)insert_zero(stbase, (int)srb[s]);
+            same = same && (srb[s] == rb[s]);
+        }
+        if (!same || stbase != tbase) transpose_to(srb, stbase);
+    }
+
+    {
+        const uint64_t gt = glob(tbase);
+        uint64_t gs[R];
+#pragma unroll
+        for (int s = 0; s < R; ++s) gs[s] = glob(1u << rb[s]);
+        if constexpr (VB == 1) {
+#pragma unroll
+            for (int j = 0; j < NA; j += 2) {
+                uint64_t o = gt;
+#pragma unroll
+                for (int s = 1; s < R; ++s)
+                    if ((j >> s) & 1) o += gs[s];
+                float4 v;
+                v.x = a[j].x;
+                v.y = a[j].y;
+                v.z = a[j + 1].x;
+                v.w = a[j + 1].y;
+                *reinterpret_cast<float4*>(pout + o) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                uint64_t o = gt;
+#pragma unroll
+                for (int s = 0; s < R; ++s)
+                    if ((j >> s) & 1) o += gs[s];
+                pout[o] = a[j];
+            }
+        }
+    }
+}
+
+struct FusedVariant {
+    int m, slots, logt;
+};
+// variant 0 is the default geometry of each precision
+static const FusedVariant kVariantsC64[] = {{12, 4, 8}, {13, 4, 9}};
+static const FusedVariant kVariantsC128[] = {{11, 3, 8}, {12, 4, 8}};
+static const int kNumVariants = 2;
+
+template <typename T>
+static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
+    const int m = slots + logt;
+    if (p->m != m || p->L + p->h != m || p->h > DQ_FUSED_MAX_HIGH || p->L < 1) {
+        set_error("dq_apply_fused: inconsistent geometry (m=%d L=%d h=%d)", p->m, p->L, p->h);
+        return DQ_ERR_ARG;
+    }
+    if (n < m) {
+        set_error("dq_apply_fused: n=%d smaller than tile m=%d", n, m);
+        return DQ_ERR_ARG;
+    }
+    if (p->nrounds > DQ_FUSED_MAX_ROUNDS) {
+        set_error("dq_apply_fused: too many rounds");
+        return DQ_ERR_ARG;
+    }
+    uint64_t seen = 0;
+    for (int i = 0; i < p->h; ++i) {
+        const int hp = p->high_pos[i];
+        if (hp < p->L || hp >= n || ((seen >> hp) & 1ull)) {
+            set_error("dq_apply_fused: bad high bit %d", hp);
+            return DQ_ERR_ARG;
+        }
+        seen |= 1ull << hp;
+        if (i > 0 && p->high_sorted[i] <= p->high_sorted[i - 1]) {
+            set_error("dq_apply_fused: high_sorted not ascending");
+            return DQ_ERR_ARG;
+        }
+    }
+    uint64_t seen2 = 0;
+    for (int i = 0; i < p->h; ++i) seen2 |= 1ull << p->high_sorted[i];
+    if (seen != seen2) {
+        set_error("dq_apply_fused: high_sorted is not a permutation of high_pos");
+        return DQ_ERR_ARG;
+    }
+    for (int io = 0; io < 2; ++io) {
+        const uint8_t* iorb = io ? p->store_rb : p->load_rb;
+        constexpr int vb = sizeof(T) == 4 ? 1 : 0;
+        for (int s = 0; s < slots; ++s) {
+            const bool ok = (s < vb) ? (iorb[s] == s) : (iorb[s] >= p->L && iorb[s] < m);
+            if (!ok || (s > 0 && iorb[s] <= iorb[s - 1])) {
+                set_error("dq_apply_fused: %s layout invalid at slot %d", io ? "store" : "load", s);
+                return DQ_ERR_ARG;
+            }
+        }
+    }
+    for (int r = 0; r < p->nrounds; ++r) {
+        const DqFusedRound& rd = p->rounds[r];
+        unsigned used = 0;
+        for (int s = 0; s < slots; ++s) {
+            if (rd.rb[s] >= m || (s > 0 && rd.rb[s] <= rd.rb[s - 1])) {
+                set_error("dq_apply_fused: round %d slot list invalid", r);
+                return DQ_ERR_ARG;
+            }
+            used |= 1u << rd.rb[s];
+        }
+        for (int i = 0; i < logt; ++i) {
+            if (rd.tb[i] >= m || ((used >> rd.tb[i]) & 1u)) {
+                set_error("dq_apply_fused: round %d thread-bit list invalid", r);
+                return DQ_ERR_ARG;
+            }
+            used |= 1u << rd.tb[i];
+        }
+        if (rd.gate_begin > rd.gate_end || rd.gate_end > DQ_FUSED_MAX_GATES) {
+            set_error("dq_apply_fused: round %d gate range invalid", r);
+            return DQ_ERR_ARG;
+        }
+        for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
+            const DqFusedGate& g = p->gates[gi];
+            const bool slot_kind = g.kind == DQ_FG_GEN1 || g.kind == DQ_FG_X1 || g.kind == DQ_FG_GEN2;
+            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) ||
+                (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
+                set_error("dq_apply_fused: gate %d malformed", gi);
+                return DQ_ERR_ARG;
+            }
+        }
+    }
+    return DQ_OK;
+}
+
+template <typename T, int R, int LOGT>
+static void launch_variant(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
+                           const DqFusedPass* pass, hipStream_t s) {
+    constexpr int M = R + LOGT;
+    const size_t lds_bytes = sizeof(cx<T>) << M;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_pass_kernel<T, R, LOGT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(1ull << (n - M)), (unsigned)batch);
+    hipLaunchKernelGGL((fused_pass_kernel<T, R, LOGT>), grid, dim3(1u << LOGT), lds_bytes, s,
+                       static_cast<const cx<T>*>(in), static_cast<cx<T>*>(out), static_cast<const cx<T>*>(mats),
+                       mat_bstride, n, *pass);
+}
+
+template <typename T>
+static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
+                      const DqFusedPass* pass, dq_stream_t stream) {
+    if (!in || !out || !mats || !pass) {
+        set_error("dq_apply_fused: null pointer");
+        return DQ_ERR_ARG;
+    }
+    if (batch < 1 || batch > 65535) {
+        set_error("dq_apply_fused: batch %lld out of range [1, 65535]", (long long)batch);
+        return DQ_ERR_ARG;
+    }
+    constexpr bool is128 = sizeof(T) == 8;
+    const FusedVariant* vars = is128 ? kVariantsC128 : kVariantsC64;
+    int vi = -1;
+    for (int i = 0; i < kNumVariants; ++i)
+        if (vars[i].m == pass->m) vi = i;
+    if (vi < 0) {
+        set_error("dq_apply_fused: no kernel variant with m=%d", pass->m);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    const FusedVariant v = vars[vi];
+    int rc = validate_pass<T>(pass, n, v.slots, v.logt);
+    if (rc) return rc;
+    if (n - v.m > 31) {
+        set_error("dq_apply_fused: grid too large (n=%d)", n);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = as_stream(stream);
+    if constexpr (!is128) {
+        if (v.m == 12) launch_variant<float, 4, 8>(in, out, mats, mat_bstride, n, batch, pass, s);
+        else launch_variant<float, 4, 9>(in, out, mats, mat_bstride, n, batch, pass, s);
+    } else {
+        if (v.m == 11) launch_variant<double, 3, 8>(in, out, mats, mat_bstride, n, batch, pass, s);
+        else launch_variant<double, 4, 8>(in, out, mats, mat_bstride, n, batch, pass, s);
+    }
+    return check_launch("dq_apply_fused");
+}
+
+}  // namespace dq
+
+extern "C" int dq_fused_geometry(int is_c128, int variant, int* m, int* slots, int* threads) {
+    if (variant < 0 || variant >= dq::kNumVariants) {
+        dq::set_error("dq_fused_geometry: variant %d out of range", variant);
+        return DQ_ERR_ARG;
+    }
+    const dq::FusedVariant v = is_c128 ? dq::kVariantsC128[variant] : dq::kVariantsC64[variant];
+    if (m) *m = v.m;
+    if (slots) *slots = v.slots;
+    if (threads) *threads = 1 << v.logt;
+    return DQ_OK;
+}
+
+extern "C" int dq_apply_fused_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                  int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
+    return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream);
+}
+extern "C" int dq_apply_fused_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                   int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
+    return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream);
+}

@@ -1,0 +1,399 @@
+// Reductions over the statevector: Pauli-string expectation, inner product, probabilities,
+// marginals and the gate-matrix gradient.  All are single-pass HBM-bound streams; accumulation is
+// in double precision regardless of the state's precision.
+//
+// Replaces (reference, src/deepquantum/): qmath.expectation (qmath.py:830-860) together with
+// Observable.forward (layer.py:127-165) -- there one full gate pass per Pauli factor plus a bmm;
+// here one read of the state -- the |psi|^2 / permute / sum of qmath.measure (qmath.py:624-626),
+// inner_product_dist's local part (distributed.py:288-291) and the matmul backward that autograd
+// derives for qmath.py:504.
+#include "dq_common.hpp"
+
+namespace dq {
+
+constexpr int RED_BLOCKS = 1024;  // partial sums per batch sample
+constexpr int RED_THREADS = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Sum (re, im) over the block; result valid in thread 0.
+__device__ __forceinline__ void block_sum2(double& re, double& im) {
+    __shared__ double sre[RED_THREADS / 64], sim[RED_THREADS / 64];
+    re = wave_sum(re);
+    im = wave_sum(im);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        sre[w] = re;
+        sim[w] = im;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+        for (int i = 0; i < RED_THREADS / 64; ++i) {
+            a += sre[i];
+            b += sim[i];
+        }
+        re = a;
+        im = b;
+    }
+}
+
+// ---- <psi|P|psi> ---------------------------------------------------------------------------------
+// P|j> = i^ny (-1)^{popc(j & zmask)} |j ^ xmask>.  For xmask != 0 amplitudes are visited in pairs
+// (i, k = i ^ xmask) so every amplitude is read exactly once:
+//   term(i) + term(k) = s_k conj(psi_i) psi_k + s_i conj(psi_k) psi_i,   s_j = (-1)^{popc(j & zmask)}.
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void expect_pauli_kernel(const cx<T>* __restrict__ psi, uint64_t xmask,
+                                                                    uint64_t zmask, int n, double* __restrict__ ws) {
+    const int64_t b = blockIdx.y;
+    const cx<T>* p = psi + ((uint64_t)b << n);
+    double re = 0, im = 0;
+    if (xmask == 0) {
+        const uint64_t dim = 1ull << n;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < dim;
+             i += (uint64_t)gridDim.x * blockDim.x) {
+            const cx<T> a = p[i];
+            const double pr = (double)a.x * a.x + (double)a.y * a.y;
+            re += (__popcll(i & zmask) & 1) ? -pr : pr;
+        }
+    } else {
+        const int low = __ffsll((long long)xmask) - 1;
+        const uint64_t half = 1ull << (n - 1);
+        for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < half;
+             g += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t i = insert_zero(g, low);
+            const uint64_t k = i ^ xmask;
+            const cx<T> a = p[i], c = p[k];
+            // conj(a) * c
+            const double cr = (double)a.x * c.x + (double)a.y * c.y;
+            const double ci = (double)a.x * c.y - (double)a.y * c.x;
+            const double sk = (__popcll(k & zmask) & 1) ? -1.0 : 1.0;
+            const double si = (__popcll(i & zmask) & 1) ? -1.0 : 1.0;
+            // s_k * (cr + i ci) + s_i * (cr - i ci)
+            re += (sk + si) * cr;
+            im += (sk - si) * ci;
+        }
+    }
+    block_sum2(re, im);
+    if (threadIdx.x == 0) {
+        double* w = ws + ((size_t)b * RED_BLOCKS + blockIdx.x) * 2;
+        w[0] = re;
+        w[1] = im;
+    }
+}
+
+// mode 0: out[b] = Re(i^ny * S); mode 1: out[2b], out[2b+1] = S
+__global__ __launch_bounds__(RED_THREADS) void finish_kernel(const double* __restrict__ ws, int nblocks, int ny,
+                                                              int mode, double* __restrict__ out) {
+    const int64_t b = blockIdx.x;
+    double re = 0, im = 0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        re += ws[((size_t)b * RED_BLOCKS + i) * 2];
+        im += ws[((size_t)b * RED_BLOCKS + i) * 2 + 1];
+    }
+    block_sum2(re, im);
+    if (threadIdx.x == 0) {
+        if (mode == 0) {
+            double r;
+            switch (ny & 3) {
+                case 0: r = re; break;
+                case 1: r = -im; break;  // Re(i (re + i im)) = -im
+                case 2: r = -re; break;
+                default: r = im; break;  // Re(-i (re + i im)) = im
+            }
+            out[b] = r;
+        } else {
+            out[2 * b] = re;
+            out[2 * b + 1] = im;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void inner_kernel(const cx<T>* __restrict__ bra, const cx<T>* __restrict__ ket,
+                                                             uint64_t count, double* __restrict__ ws) {
+    const int64_t b = blockIdx.y;
+    const cx<T>* pa = bra + (uint64_t)b * count;
+    const cx<T>* pb = ket + (uint64_t)b * count;
+    double re = 0, im = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const cx<T> a = pa[i], c = pb[i];
+        re += (double)a.x * c.x + (double)a.y * c.y;
+        im += (double)a.x * c.y - (double)a.y * c.x;
+    }
+    block_sum2(re, im);
+    if (threadIdx.x == 0) {
+        double* w = ws + ((size_t)b * RED_BLOCKS + blockIdx.x) * 2;
+        w[0] = re;
+        w[1] = im;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void probs_kernel(const cx<T>* __restrict__ psi, T* __restrict__ probs, uint64_t count) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const cx<T> a = psi[i];
+        probs[i] = a.x * a.x + a.y * a.y;
+    }
+}
+
+// One block = (batch sample, outcome o, chunk of the unmeasured bits).  Every amplitude is read once;
+// reads stay coalesced as long as the low index bits are unmeasured.
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void marginal_kernel(const cx<T>* __restrict__ psi, int n, BitList sorted,
+                                                                BitList order, int64_t batch, double* __restrict__ out) {
+    const int nw = order.n;
+    const uint64_t o = blockIdx.y % (1u << nw);
+    const int64_t b = blockIdx.y >> nw;
+    uint64_t value = 0;
+    for (int i = 0; i < nw; ++i) value |= ((o >> (nw - 1 - i)) & 1ull) << order.pos[i];
+    const cx<T>* p = psi + ((uint64_t)b << n);
+    const uint64_t rest = 1ull << (n - nw);
+    double acc = 0, dummy = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rest;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const cx<T> a = p[insert_zeros(r, sorted) | value];
+        acc += (double)a.x * a.x + (double)a.y * a.y;
+    }
+    block_sum2(acc, dummy);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out + ((size_t)b << nw) + o, acc);
+}
+
+struct GradGeom {
+    BitList sorted;
+    int tpos[2];
+    uint64_t cmask;
+    int n;
+};
+
+template <typename T, int K>
+__global__ __launch_bounds__(RED_THREADS) void gate_grad_kernel(const cx<T>* __restrict__ x, const cx<T>* __restrict__ gy,
+                                                                 GradGeom g, uint64_t groups, double* __restrict__ gU) {
+    constexpr int D = 1 << K;
+    const int64_t b = blockIdx.y;
+    const cx<T>* px = x + ((uint64_t)b << g.n);
+    const cx<T>* pg = gy + ((uint64_t)b << g.n);
+    uint64_t offs[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        uint64_t o = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) o |= (uint64_t)((j >> (K - 1 - i)) & 1) << g.tpos[i];
+        offs[j] = o;
+    }
+    double are[D * D], aim[D * D];
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) are[i] = aim[i] = 0;
+    for (uint64_t gi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < groups;
+         gi += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t base = insert_zeros(gi, g.sorted) | g.cmask;
+        cx<T> xv[D], gv[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            xv[j] = px[base | offs[j]];
+            gv[j] = pg[base | offs[j]];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {  // gy[i] * conj(x[j])
+                are[i * D + j] += (double)gv[i].x * xv[j].x + (double)gv[i].y * xv[j].y;
+                aim[i * D + j] += (double)gv[i].y * xv[j].x - (double)gv[i].x * xv[j].y;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) {
+        double re = are[i], im = aim[i];
+        block_sum2(re, im);
+        if (threadIdx.x == 0) {
+            double* dst = gU + ((size_t)b * D * D + i) * 2;
+            unsafeAtomicAdd(dst, re);
+            unsafeAtomicAdd(dst + 1, im);
+        }
+    }
+}
+
+static int sort_bits(const int* bits, int nb, BitList& out) {
+    out.n = nb;
+    for (int i = 0; i < nb; ++i) out.pos[i] = bits[i];
+    for (int i = 1; i < nb; ++i) {
+        int v = out.pos[i], j = i - 1;
+        while (j >= 0 && out.pos[j] > v) {
+            out.pos[j + 1] = out.pos[j];
+            --j;
+        }
+        out.pos[j + 1] = v;
+    }
+    return 0;
+}
+
+static unsigned red_blocks(uint64_t work) {
+    uint64_t nb = (work + RED_THREADS - 1) / RED_THREADS;
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+template <typename T>
+static int expect_impl(const void* psi, uint64_t xmask, uint64_t zmask, int n, int64_t batch, double* out, void* ws,
+                       dq_stream_t stream) {
+    if (!psi || !out || !ws || n < 1 || n > 40 || batch < 1 || batch > 65535) {
+        set_error("dq_expect_pauli: bad argument (n=%d batch=%lld)", n, (long long)batch);
+        return DQ_ERR_ARG;
+    }
+    const uint64_t full = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+    if ((xmask | zmask) & ~full) {
+        set_error("dq_expect_pauli: mask has bits >= n");
+        return DQ_ERR_ARG;
+    }
+    const uint64_t work = xmask ? (1ull << (n - 1)) : (1ull << n);
+    const unsigned nb = red_blocks(work);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(expect_pauli_kernel<T>, dim3(nb, (unsigned)batch), dim3(RED_THREADS), 0, s,
+                       static_cast<const cx<T>*>(psi), xmask, zmask, n, static_cast<double*>(ws));
+    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)batch), dim3(RED_THREADS), 0, s, static_cast<const double*>(ws),
+                       (int)nb, __builtin_popcountll(xmask & zmask), 0, out);
+    return check_launch("dq_expect_pauli");
+}
+
+template <typename T>
+static int inner_impl(const void* bra, const void* ket, int64_t count, int64_t batch, double* out, void* ws,
+                      dq_stream_t stream) {
+    if (!bra || !ket || !out || !ws || count < 1 || batch < 1 || batch > 65535) {
+        set_error("dq_inner: bad argument");
+        return DQ_ERR_ARG;
+    }
+    const unsigned nb = red_blocks((uint64_t)count);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(inner_kernel<T>, dim3(nb, (unsigned)batch), dim3(RED_THREADS), 0, s,
+                       static_cast<const cx<T>*>(bra), static_cast<const cx<T>*>(ket), (uint64_t)count,
+                       static_cast<double*>(ws));
+    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)batch), dim3(RED_THREADS), 0, s, static_cast<const double*>(ws),
+                       (int)nb, 0, 1, out);
+    return check_launch("dq_inner");
+}
+
+template <typename T>
+static int probs_impl(const void* psi, void* probs, int64_t count, dq_stream_t stream) {
+    if (!psi || !probs || count < 1) {
+        set_error("dq_probs: bad argument");
+        return DQ_ERR_ARG;
+    }
+    uint64_t nb = ((uint64_t)count + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(probs_kernel<T>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream),
+                       static_cast<const cx<T>*>(psi), static_cast<T*>(probs), (uint64_t)count);
+    return check_launch("dq_probs");
+}
+
+template <typename T>
+static int marginal_impl(const void* psi, int n, const int* bits, int nw, int64_t batch, double* out,
+                         dq_stream_t stream) {
+    if (!psi || !out || batch < 1) {
+        set_error("dq_marginal: bad argument");
+        return DQ_ERR_ARG;
+    }
+    if (nw < 1 || nw > 12) {
+        set_error("dq_marginal: nw=%d unsupported (1..12)", nw);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    int rc = validate_bits(n, bits, nw, nullptr, 0);
+    if (rc) return rc;
+    if (((uint64_t)batch << nw) > 65535) {
+        set_error("dq_marginal: batch * 2^nw = %llu exceeds 65535", (unsigned long long)((uint64_t)batch << nw));
+        return DQ_ERR_UNSUPPORTED;
+    }
+    BitList sorted, order;
+    sort_bits(bits, nw, sorted);
+    order.n = nw;
+    for (int i = 0; i < nw; ++i) order.pos[i] = bits[i];
+    const uint64_t rest = 1ull << (n - nw);
+    uint64_t nb = (rest + RED_THREADS - 1) / RED_THREADS;
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(marginal_kernel<T>, dim3((unsigned)nb, (unsigned)((uint64_t)batch << nw)), dim3(RED_THREADS), 0,
+                       as_stream(stream), static_cast<const cx<T>*>(psi), n, sorted, order, batch, out);
+    return check_launch("dq_marginal");
+}
+
+template <typename T>
+static int gate_grad_impl(const void* x, const void* gy, int n, const int* targets, int k, const int* controls, int nc,
+                          int64_t batch, double* gU, dq_stream_t stream) {
+    if (!x || !gy || !gU || batch < 1 || batch > 65535) {
+        set_error("dq_gate_grad: bad argument");
+        return DQ_ERR_ARG;
+    }
+    if (k < 1 || k > 2) {
+        set_error("dq_gate_grad: k=%d unsupported (1..2)", k);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    int rc = validate_bits(n, targets, k, controls, nc);
+    if (rc) return rc;
+    if (k + nc > 16) {
+        set_error("dq_gate_grad: k+nc > 16");
+        return DQ_ERR_UNSUPPORTED;
+    }
+    GradGeom g;
+    g.n = n;
+    g.cmask = 0;
+    int all[16];
+    for (int i = 0; i < k; ++i) {
+        g.tpos[i] = targets[i];
+        all[i] = targets[i];
+    }
+    for (int i = 0; i < nc; ++i) {
+        g.cmask |= 1ull << controls[i];
+        all[k + i] = controls[i];
+    }
+    sort_bits(all, k + nc, g.sorted);
+    const uint64_t groups = 1ull << (n - k - nc);
+    uint64_t nb = (groups + RED_THREADS - 1) / RED_THREADS;
+    if (nb > 512) nb = 512;
+    dim3 grid((unsigned)nb, (unsigned)batch);
+    hipStream_t s = as_stream(stream);
+    if (k == 1)
+        hipLaunchKernelGGL((gate_grad_kernel<T, 1>), grid, dim3(RED_THREADS), 0, s, static_cast<const cx<T>*>(x),
+                           static_cast<const cx<T>*>(gy), g, groups, gU);
+    else
+        hipLaunchKernelGGL((gate_grad_kernel<T, 2>), grid, dim3(RED_THREADS), 0, s, static_cast<const cx<T>*>(x),
+                           static_cast<const cx<T>*>(gy), g, groups, gU);
+    return check_launch("dq_gate_grad");
+}
+
+}  // namespace dq
+
+extern "C" int64_t dq_reduce_ws_bytes(int64_t batch) {
+    if (batch < 1) batch = 1;
+    return batch * (int64_t)dq::RED_BLOCKS * 2 * (int64_t)sizeof(double);
+}
+
+#define DQ_DEFINE(SUFFIX, T)                                                                                          \
+    extern "C" int dq_expect_pauli_##SUFFIX(const void* psi, uint64_t xmask, uint64_t zmask, int n, int64_t batch,    \
+                                            double* out, void* ws, dq_stream_t stream) {                              \
+        return dq::expect_impl<T>(psi, xmask, zmask, n, batch, out, ws, stream);                                      \
+    }                                                                                                                 \
+    extern "C" int dq_inner_##SUFFIX(const void* bra, const void* ket, int64_t count, int64_t batch, double* out,     \
+                                     void* ws, dq_stream_t stream) {                                                  \
+        return dq::inner_impl<T>(bra, ket, count, batch, out, ws, stream);                                            \
+    }                                                                                                                 \
+    extern "C" int dq_probs_##SUFFIX(const void* psi, void* probs, int64_t count, dq_stream_t stream) {               \
+        return dq::probs_impl<T>(psi, probs, count, stream);                                                          \
+    }                                                                                                                 \
+    extern "C" int dq_marginal_##SUFFIX(const void* psi, int n, const int* bits, int nw, int64_t batch, double* out,  \
+                                        dq_stream_t stream) {                                                         \
+        return dq::marginal_impl<T>(psi, n, bits, nw, batch, out, stream);                                            \
+    }                                                                                                                 \
+    extern "C" int dq_gate_grad_##SUFFIX(const void* x, const void* gy, int n, const int* targets, int k,             \
+                                         const int* controls, int nc, int64_t batch, double* gU,                      \
+                                         dq_stream_t stream) {                                                        \
+        return dq::gate_grad_impl<T>(x, gy, n, targets, k, controls, nc, batch, gU, stream);                          \
+    }
+
+DQ_DEFINE(c64, float)
+DQ_DEFINE(c128, double)

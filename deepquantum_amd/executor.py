@@ -1,0 +1,159 @@
+"""Circuit executor: runs a list of kernel-level gates on a (B, 2**n) state.
+
+Two modes, chosen per call:
+
+* fused (default when nothing requires grad): the gate list is scheduled once into fused passes
+  (``fusion.schedule``, cached by circuit structure) and each pass is one ``dq_apply_fused_*`` launch
+  working in place on a private copy of the state;
+* eager (autograd): one differentiable ``ops.apply_gate`` per gate, mirroring how the reference lets
+  autograd see every gate (circuit.py:261).
+
+This replaces the Python loop ``nn.Sequential(self.operators)(x)`` of the reference.
+"""
+
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Sequence
+
+import torch
+
+from . import backend, fusion, ops
+
+
+@dataclass
+class Prim:
+    """A kernel-level gate with its matrix tensor: (.., D, D), batch dim optional."""
+
+    kind: str                      # 'gen' | 'x' | 'diag'
+    matrix: torch.Tensor
+    targets: tuple[int, ...]       # bit positions, matrix MSB first
+    controls: tuple[int, ...] = ()
+
+
+@dataclass
+class Plan:
+    steps: list
+    prim_ops: list[fusion.PrimOp]
+    mat_total: int                 # complex numbers per batch sample in the flat matrix buffer
+    n_fused: int
+    n_single: int
+
+
+_PLAN_CACHE: OrderedDict = OrderedDict()
+_PLAN_CACHE_SIZE = 64
+
+# Tunables (debug / benchmarking): tile bits per precision; None = library default.
+CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
+          'max_gates': None}
+
+# When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
+# (start, stop, ngates) to report the kernel's average duration next to its algorithmic bytes.
+PROFILE = {'enabled': False, 'events': []}
+
+# Statistics of the most recent fused run (for bench.py and tests).
+LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0}
+
+
+def _geometry(is128: bool) -> fusion.Geometry:
+    g = fusion.default_geometry(is128, CONFIG['m_c128'] if is128 else CONFIG['m_c64'])
+    ml = CONFIG['min_low_c128'] if is128 else CONFIG['min_low_c64']
+    if ml is not None:
+        g.min_low = ml
+    if CONFIG['max_gates'] is not None:
+        g.max_gates = CONFIG['max_gates']
+    return g
+
+
+def make_plan(prims: Sequence[Prim], n: int, is128: bool) -> Plan:
+    geom = _geometry(is128)
+    key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, CONFIG['fuse'],
+           tuple((p.kind, p.targets, p.controls) for p in prims))
+    plan = _PLAN_CACHE.get(key)
+    if plan is not None:
+        _PLAN_CACHE.move_to_end(key)
+        return plan
+    prim_ops, off = [], 0
+    for p in prims:
+        prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off))
+        off += (1 << len(p.targets)) ** 2
+    steps = fusion.schedule(prim_ops, n, geom, fuse=CONFIG['fuse'])
+    plan = Plan(steps, prim_ops, off,
+                sum(isinstance(s, fusion.FusedStep) for s in steps),
+                sum(isinstance(s, fusion.SingleStep) for s in steps))
+    _PLAN_CACHE[key] = plan
+    if len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+        _PLAN_CACHE.popitem(last=False)
+    return plan
+
+
+def _flat_mats(prims: Sequence[Prim], batch: int, dtype: torch.dtype, device: torch.device) -> tuple[torch.Tensor, int]:
+    """Concatenate all gate matrices into one (Bm, total) buffer; Bm = batch if any is batched."""
+    batched = any(p.matrix.ndim == 3 and p.matrix.shape[0] > 1 for p in prims)
+    bm = batch if batched else 1
+    rows = []
+    for p in prims:
+        m = p.matrix
+        if m.ndim == 2:
+            m = m.unsqueeze(0)
+        m = m.reshape(m.shape[0], -1)
+        if m.shape[0] != bm:
+            m = m.expand(bm, -1)
+        rows.append(m)
+    flat = torch.cat(rows, dim=1).to(device=device, dtype=dtype).contiguous()
+    return flat, (flat.shape[1] if batched else 0)
+
+
+def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
+    if not torch.is_grad_enabled():
+        return False
+    return state.requires_grad or any(p.matrix.requires_grad for p in prims)
+
+
+def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> torch.Tensor:
+    """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state."""
+    if len(prims) == 0:
+        return state
+    if state.ndim != 2:
+        raise ValueError('state must be (batch, 2**n)')
+    n = state.shape[-1].bit_length() - 1
+    if needs_autograd(state, prims):
+        x = state
+        for p in prims:
+            x = ops.apply_gate(x, p.matrix, p.targets, p.controls)
+        return x
+    with torch.no_grad():
+        is128 = state.dtype == torch.complex128
+        x = state if (inplace and state.is_contiguous()) else state.detach().clone(memory_format=torch.contiguous_format)
+        plan = make_plan(prims, n, is128)
+        flat, stride = _flat_mats(prims, x.shape[0], x.dtype, x.device)
+        stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0}
+        scratch = None
+        for st in plan.steps:
+            if isinstance(st, fusion.FusedStep):
+                if PROFILE['enabled'] and x.is_cuda:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    backend.apply_fused(x, flat, stride, st.desc, out=x)
+                    e1.record()
+                    PROFILE['events'].append((e0, e1, len(st.ops)))
+                else:
+                    backend.apply_fused(x, flat, stride, st.desc, out=x)
+                stats['passes'] += 1
+                stats['rounds'] += st.nrounds
+                stats['transposes'] += st.ntranspose
+            else:
+                op = plan.prim_ops[st.op]
+                d = 1 << op.k
+                mat = flat[:, op.mat : op.mat + d * d].reshape(-1, d, d)
+                if op.k <= 4:
+                    backend.apply_gate(x, mat, op.targets, op.controls, out=x)
+                else:
+                    if scratch is None:
+                        scratch = torch.empty_like(x)
+                    backend.apply_gate(x, mat, op.targets, op.controls, out=scratch)
+                    x, scratch = scratch, x
+                stats['singles'] += 1
+        LAST_RUN.update(stats)
+        return x

@@ -1,0 +1,385 @@
+"""Host-side scheduler that turns a gate list into fused passes for ``dq_apply_fused_*``.
+
+The reference executes one gate per ``Gate.forward`` call (circuit.py:261, operation.py:274-289), i.e.
+at least two full read+write sweeps of the statevector per gate.  Here gates are grouped so that one
+HBM read + one HBM write applies a whole group ("pass").  The kernel side is described in
+``csrc/dq_fused.hip``; this module only decides *which* gates go together and emits the descriptor
+structs of ``include/dq_hip.h``.
+
+Vocabulary
+  bit      amplitude-index bit position, LSB = 0; wire w of an n-qubit circuit is bit n-1-w.
+  tile     the m index bits a workgroup owns in a pass: the low L bits plus h gathered high bits.
+  round    a stretch of a pass during which R chosen tile bits are "register slots"; a non-diagonal
+           gate needs its target bit(s) to be slots.  Changing rounds costs one LDS round trip.
+  action   how a gate acts on a qubit: 'D' if it is diagonal in that qubit (controls, targets of
+           diagonal gates), 'N' otherwise.  Two gates commute when every shared qubit is 'D' in both,
+           which is what lets the scheduler pull later gates forward.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Sequence
+
+from . import _lib
+
+
+@dataclass
+class PrimOp:
+    """One kernel-level gate: ``kind`` in {'gen', 'x', 'diag'}; ``targets`` in matrix order (MSB
+    first); ``mat`` = offset (in complex numbers) of its 2^k x 2^k matrix in the flat matrix buffer."""
+
+    kind: str
+    targets: tuple[int, ...]
+    controls: tuple[int, ...] = ()
+    mat: int = 0
+
+    @property
+    def k(self) -> int:
+        return len(self.targets)
+
+
+@dataclass
+class FusedStep:
+    desc: _lib.DqFusedPass
+    ops: list[int]            # indices into the PrimOp list, in execution order
+    nrounds: int
+    ntranspose: int           # LDS round trips the kernel will do (incl. back to canonical)
+
+
+@dataclass
+class SingleStep:
+    op: int
+
+
+@dataclass
+class Geometry:
+    m: int            # tile bits
+    slots: int        # register slots per thread (R)
+    vb: int           # canonical layout keeps tile bits [0, vb) as slots (1 for c64, 0 for c128)
+    min_low: int      # minimum contiguous low bits of a tile (coalescing floor)
+    max_gates: int = _lib.FUSED_MAX_GATES
+    max_rounds: int = _lib.FUSED_MAX_ROUNDS - 1  # one spare so a trailing round never overflows
+
+    @property
+    def logt(self) -> int:
+        return self.m - self.slots
+
+
+def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = None) -> Geometry:
+    if is_c128:
+        m = 11 if m is None else m
+        slots = {11: 3, 12: 4}[m] if slots is None else slots
+        return Geometry(m=m, slots=slots, vb=0, min_low=6)
+    m = 12 if m is None else m
+    slots = 4 if slots is None else slots
+    return Geometry(m=m, slots=slots, vb=1, min_low=7)
+
+
+# ---------------------------------------------------------------------------------------------------
+class _Dag:
+    """Dependency bookkeeping with the diagonal-commutation rule."""
+
+    def __init__(self, ops: Sequence[PrimOp], n: int):
+        self.ops = ops
+        self.n_ops = len(ops)
+        self.succ: list[list[int]] = [[] for _ in ops]
+        self.indeg = [0] * len(ops)
+        last_n = [-1] * n                 # last gate acting 'N' on the qubit
+        d_since: list[list[int]] = [[] for _ in range(n)]  # 'D' gates since then
+        for i, op in enumerate(ops):
+            deps = set()
+            d_bits = set(op.controls) | (set(op.targets) if op.kind == 'diag' else set())
+            n_bits = set() if op.kind == 'diag' else set(op.targets)
+            for q in d_bits:
+                if last_n[q] >= 0:
+                    deps.add(last_n[q])
+            for q in n_bits:
+                if last_n[q] >= 0:
+                    deps.add(last_n[q])
+                deps.update(d_since[q])
+            for d in deps:
+                self.succ[d].append(i)
+            self.indeg[i] = len(deps)
+            for q in d_bits:
+                d_since[q].append(i)
+            for q in n_bits:
+                last_n[q] = i
+                d_since[q] = []
+        self.ready = sorted(i for i in range(self.n_ops) if self.indeg[i] == 0)
+        self.done = 0
+
+    def retire(self, i: int) -> None:
+        self.ready.remove(i)
+        self.done += 1
+        new = []
+        for s in self.succ[i]:
+            self.indeg[s] -= 1
+            if self.indeg[s] == 0:
+                new.append(s)
+        if new:
+            self.ready = sorted(self.ready + new)
+
+
+@dataclass
+class _Round:
+    slots: list[int] = field(default_factory=list)  # global bits that must be register slots
+    ops: list[int] = field(default_factory=list)
+
+
+def _fusable(op: PrimOp) -> bool:
+    if op.kind == 'diag':
+        return op.k <= 2
+    return op.k <= 2
+
+
+def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True) -> list[FusedStep | SingleStep]:
+    """Greedy list scheduling over the commutation DAG.  Returns steps in execution order."""
+    if not fuse or n < geom.m:
+        return [SingleStep(i) for i in range(len(ops))]
+    dag = _Dag(ops, n)
+    steps: list[FusedStep | SingleStep] = []
+    low = set(range(geom.min_low))
+    hcap = geom.m - geom.min_low
+    # with a single low slot in the canonical layout only R - vb high bits fit a canonical round
+    while dag.done < dag.n_ops:
+        high: set[int] = set()          # tile bits beyond the guaranteed low ones
+        rounds: list[_Round] = [_Round()]
+        count = 0
+
+        def fits_tile(op: PrimOp) -> bool:
+            need = {t for t in op.targets if t not in low} - high
+            return len(high) + len(need) <= hcap and len(high | need) <= min(hcap, n - geom.min_low)
+
+        def round_accepts(cur: _Round, tset: set[int], first: bool) -> bool:
+            new = set(cur.slots) | tset
+            if len(new) > geom.slots:
+                return False
+            if first and cur.ops:
+                # keep the first round loadable straight from HBM: only bit 0 (c64) and gathered bits
+                # may be slots, and at most R - vb gathered ones
+                if any(geom.vb <= b < geom.min_low for b in new):
+                    return False
+                if sum(1 for b in new if b >= geom.min_low) > geom.slots - geom.vb:
+                    return False
+            return True
+
+        progressed = True
+        while progressed and count < geom.max_gates:
+            progressed = False
+            cur = rounds[-1]
+            pick = None
+            pick_rank = 99
+            for i in dag.ready:
+                op = ops[i]
+                if not _fusable(op):
+                    continue
+                if op.kind == 'diag':
+                    rank = 0
+                else:
+                    tset = set(op.targets)
+                    in_tile = all(t in low or t in high for t in tset)
+                    room = round_accepts(cur, tset, first=len(rounds) == 1)
+                    more_rounds = len(rounds) < geom.max_rounds and len(tset) <= geom.slots
+                    if tset <= set(cur.slots):
+                        rank = 0
+                    elif in_tile and room:
+                        rank = 1
+                    elif fits_tile(op) and room:
+                        rank = 2
+                    elif in_tile and more_rounds:
+                        rank = 3
+                    elif fits_tile(op) and more_rounds:
+                        rank = 4
+                    else:
+                        continue
+                if rank < pick_rank:
+                    pick, pick_rank = i, rank
+                    if rank == 0:
+                        break
+            if pick is None:
+                break
+            op = ops[pick]
+            if op.kind != 'diag':
+                tset = set(op.targets)
+                for t in tset:
+                    if t not in low:
+                        high.add(t)
+                if pick_rank in (3, 4):
+                    rounds.append(_Round())
+                    cur = rounds[-1]
+                for t in op.targets:
+                    if t not in cur.slots:
+                        cur.slots.append(t)
+            cur.ops.append(pick)
+            dag.retire(pick)
+            count += 1
+            progressed = True
+
+        if count == 0:
+            # nothing fusable is ready: run the lowest-index ready gate on its own
+            i = dag.ready[0]
+            steps.append(SingleStep(i))
+            dag.retire(i)
+            continue
+        steps.append(_finalize(ops, n, geom, high, rounds))
+    return steps
+
+
+def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rounds: list[_Round]) -> FusedStep:
+    m, R, vb = geom.m, geom.slots, geom.vb
+    rounds = [r for r in rounds if r.ops]
+    L = geom.min_low
+    h = m - L
+    # gathered bits: the ones gates need, then the lowest free bits above the contiguous part
+    highs = set(high)
+    p = L
+    while len(highs) < h:
+        if p not in highs:
+            highs.add(p)
+        p += 1
+    assert len(highs) == h and max(highs) < n and h <= _lib.FUSED_MAX_HIGH
+    order = sorted(highs)                  # tile bit L+i <-> order[i]
+    local = {b: b for b in range(L)}
+    for i, b in enumerate(order):
+        local[b] = L + i
+    tile = set(range(L)) | highs
+
+    def io_layout(need: list[int]) -> list[int] | None:
+        """Slots of an I/O-capable layout covering ``need`` (tile-local), or None."""
+        if any(vb <= q < L for q in need):
+            return None
+        hi = [q for q in need if q >= L]
+        if len(hi) > R - vb:
+            return None
+        pad = [q for q in range(m - 1, L - 1, -1) if q not in hi]
+        hi = hi + pad[: R - vb - len(hi)]
+        return sorted(list(range(vb)) + hi)
+
+    def ascending_tb(slots_l: list[int]) -> list[int]:
+        return [b for b in range(m) if b not in slots_l]
+
+    desc = _lib.DqFusedPass()
+    desc.m, desc.L, desc.h = m, L, h
+    for i, b in enumerate(order):
+        desc.high_pos[i] = b
+        desc.high_sorted[i] = b
+
+    layouts: list[tuple[tuple[int, ...], tuple[int, ...]]] = []
+    prev: tuple[tuple[int, ...], tuple[int, ...]] | None = None
+    for rd in rounds:
+        need = sorted(local[b] for b in rd.slots)
+        assert len(need) <= R
+        if prev is not None and set(need) <= set(prev[0]):
+            lay = prev
+        else:
+            io = io_layout(need)
+            if io is not None:
+                lay = (tuple(io), tuple(ascending_tb(io)))
+            else:
+                slots_l = list(need)
+                cand = (list(prev[0])[::-1] if prev else []) + list(range(m - 1, -1, -1))
+                for c in cand:
+                    if len(slots_l) >= R:
+                        break
+                    if c not in slots_l:
+                        slots_l.append(c)
+                slots_l.sort()
+                lay = (tuple(slots_l), tuple(_thread_bit_order(m, slots_l, geom)))
+        layouts.append(lay)
+        prev = lay
+
+    def is_io(lay) -> bool:
+        sl = list(lay[0])
+        return io_layout(sl) == sl and list(lay[1]) == ascending_tb(sl)
+
+    default_io = io_layout([])
+    load_rb = list(layouts[0][0]) if is_io(layouts[0]) else default_io
+    store_rb = list(layouts[-1][0]) if is_io(layouts[-1]) else default_io
+    for s in range(R):
+        desc.load_rb[s] = load_rb[s]
+        desc.store_rb[s] = store_rb[s]
+
+    exec_order: list[int] = []
+    gi = 0
+    ntrans = 0
+    cur = (tuple(load_rb), tuple(ascending_tb(load_rb)))
+    for ri, (rd, lay) in enumerate(zip(rounds, layouts)):
+        if lay != cur:
+            ntrans += 1
+            cur = lay
+        slot_of = {tl: s for s, tl in enumerate(lay[0])}
+        r = desc.rounds[ri]
+        for s in range(R):
+            r.rb[s] = lay[0][s]
+        for i, t in enumerate(lay[1]):
+            r.tb[i] = t
+        r.gate_begin = gi
+        for oi in rd.ops:
+            _encode_gate(desc.gates[gi], ops[oi], local, slot_of, tile)
+            exec_order.append(oi)
+            gi += 1
+        r.gate_end = gi
+    if cur != (tuple(store_rb), tuple(ascending_tb(store_rb))):
+        ntrans += 1
+    desc.nrounds = len(rounds)
+    return FusedStep(desc=desc, ops=exec_order, nrounds=len(rounds), ntranspose=ntrans)
+
+
+def _thread_bit_order(m: int, slots_l: list[int], geom: Geometry) -> list[int]:
+    """Order of the non-slot tile bits over the thread index (bit 0 = lane LSB).  The LDS index is
+    XOR-swizzled with period 32 (c64) / 16 (c128) elements (csrc/dq_fused.hip lds_swz), so lanes are
+    conflict-free when the low lane bits land in distinct residue classes of that period."""
+    free = [b for b in range(m) if b not in slots_l]
+    period = 5 if geom.vb == 1 else 4
+    chosen: list[int] = []
+    used_cls: set[int] = set()
+    for b in free:
+        if (b % period) not in used_cls and len(chosen) < period:
+            chosen.append(b)
+            used_cls.add(b % period)
+    restb = [b for b in free if b not in chosen]
+    return chosen + restb
+
+
+def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of: dict[int, int], tile: set[int]) -> None:
+    reg_c, thr_c, out_c = 0, 0, 0
+    for c in op.controls:
+        if c in tile:
+            tl = local[c]
+            if tl in slot_of:
+                reg_c |= 1 << slot_of[tl]
+            else:
+                thr_c |= 1 << tl
+        else:
+            out_c |= 1 << c
+    g.reg_cmask, g.thr_cmask, g.out_cmask = reg_c, thr_c, out_c
+    g.mat = op.mat
+    g.q = g.q2 = g.loc = g.loc2 = 0
+
+    def locate(b: int) -> tuple[int, int]:
+        if b in tile:
+            tl = local[b]
+            if tl in slot_of:
+                return _lib.LOC_REG, slot_of[tl]
+            return _lib.LOC_THR, tl
+        return _lib.LOC_OUT, b
+
+    if op.kind == 'diag':
+        g.kind = _lib.FG_DIAG1 if op.k == 1 else _lib.FG_DIAG2
+        g.loc, g.q = locate(op.targets[0])
+        if op.k == 2:
+            g.loc2, g.q2 = locate(op.targets[1])
+        return
+    slots = [slot_of[local[t]] for t in op.targets]
+    if op.k == 1:
+        g.kind = _lib.FG_X1 if op.kind == 'x' else _lib.FG_GEN1
+        g.q = slots[0]
+    else:
+        g.kind = _lib.FG_GEN2
+        g.q, g.q2 = slots
+
+
+def algorithmic_bytes(ops: Sequence[PrimOp], n: int, amp_bytes: int, batch: int) -> int:
+    """every touched amplitude read once and written once per gate."""
+    return sum(2 * (1 << (n - len(op.controls))) * amp_bytes * batch for op in ops)

@@ -1,0 +1,288 @@
+"""Base classes of the gate/layer hierarchy, API-compatible with the reference's operation.py
+(``Operation`` :16-108, ``Gate`` :110-409, ``Layer`` :412-522) for the statevector path.
+
+What differs from the reference is everything below ``Gate.forward``: instead of permute / reshape /
+matmul / cat on a (batch, 2, ..., 2) tensor, a gate describes itself as kernel-level primitives
+(:meth:`Gate.prims`) and the executor hands them to the HIP kernels.  Density matrices and MPS are not
+on this path and raise ``NotImplementedError``.
+"""
+
+from __future__ import annotations
+
+from copy import copy
+from typing import Any
+
+import torch
+from torch import nn
+
+from . import executor
+from .executor import Prim
+from .utils import complex_apply
+
+
+class Operation(nn.Module):
+    r"""A quantum operation on ``nqubit`` qubits acting on ``wires``.
+
+    ``tsr_mode=True`` means inputs/outputs are (batch, 2, ..., 2) tensors; otherwise (2**n, 1) /
+    (batch, 2**n, 1) column vectors (same contract as the reference)."""
+
+    def __init__(
+        self,
+        name: str | None = None,
+        nqubit: int = 1,
+        wires: int | list[int] | None = None,
+        den_mat: bool = False,
+        tsr_mode: bool = False,
+    ) -> None:
+        super().__init__()
+        self.name = name
+        self.nqubit = nqubit
+        self.wires = wires
+        self.den_mat = den_mat
+        self.tsr_mode = tsr_mode
+        self.npara = 0
+
+    # ---- representations ----------------------------------------------------------------------------
+    def tensor_rep(self, x: torch.Tensor) -> torch.Tensor:
+        if self.den_mat:
+            assert x.shape[-1] == x.shape[-2] == 2**self.nqubit
+            return x.reshape([-1] + [2] * 2 * self.nqubit)
+        if x.ndim == 1:
+            assert x.shape[-1] == 2**self.nqubit
+        else:
+            assert x.shape[-1] == 2**self.nqubit or x.shape[-2] == 2**self.nqubit
+        return x.reshape([-1] + [2] * self.nqubit)
+
+    def vector_rep(self, x: torch.Tensor) -> torch.Tensor:
+        return x.reshape(-1, 2**self.nqubit, 1)
+
+    def matrix_rep(self, x: torch.Tensor) -> torch.Tensor:
+        return x.reshape(-1, 2**self.nqubit, 2**self.nqubit)
+
+    def get_unitary(self) -> torch.Tensor:
+        raise NotImplementedError
+
+    def init_para(self) -> None:
+        pass
+
+    def set_nqubit(self, nqubit: int) -> None:
+        self.nqubit = nqubit
+
+    def set_wires(self, wires: int | list[int]) -> None:
+        self.wires = self._convert_indices(wires)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.tsr_mode:
+            return self.tensor_rep(x)
+        return self.matrix_rep(x) if self.den_mat else self.vector_rep(x)
+
+    def _convert_indices(self, indices: int | list[int]) -> list[int]:
+        if isinstance(indices, int):
+            indices = [indices]
+        assert isinstance(indices, list), 'Invalid input type'
+        assert all(isinstance(i, int) for i in indices), 'Invalid input type'
+        if indices:
+            assert min(indices) > -1 and max(indices) < self.nqubit, 'Invalid input'
+        assert len(set(indices)) == len(indices), 'Invalid input'
+        return indices
+
+    def _check_minmax(self, minmax: list[int]) -> None:
+        assert isinstance(minmax, list) and len(minmax) == 2
+        assert all(isinstance(i, int) for i in minmax)
+        assert -1 < minmax[0] <= minmax[1] < self.nqubit
+
+    def _flat_state(self, x: torch.Tensor) -> torch.Tensor:
+        """Any accepted state representation -> contiguous (batch, 2**n)."""
+        if self.den_mat:
+            raise NotImplementedError('deepquantum_amd: the density-matrix path is out of scope (SURVEY section 2)')
+        x = self.tensor_rep(x)
+        return x.reshape(x.shape[0], -1)
+
+
+class Gate(Operation):
+    r"""Base class of gates: a 2^k x 2^k ``matrix`` on ``wires``, optionally conditioned on ``controls``."""
+
+    _qasm_new_gate = ['c3x', 'c4x']
+    #: how the kernels may treat the matrix: 'gen' dense, 'diag' diagonal, 'x' bit-flip permutation
+    _kernel_kind = 'gen'
+
+    def __init__(
+        self,
+        name: str | None = None,
+        nqubit: int = 1,
+        wires: int | list[int] | None = None,
+        controls: int | list[int] | None = None,
+        condition: bool = False,
+        den_mat: bool = False,
+        tsr_mode: bool = False,
+    ) -> None:
+        self.nqubit = nqubit
+        wires = self._convert_indices([0] if wires is None else wires)
+        controls = self._convert_indices([] if controls is None else controls)
+        assert not set(wires) & set(controls), 'Use repeated wires'
+        if condition:
+            assert len(controls) > 0
+        super().__init__(name=name, nqubit=nqubit, wires=wires, den_mat=den_mat, tsr_mode=tsr_mode)
+        self.controls = controls
+        self.condition = condition
+        self.nodes = self.wires
+        self.nancilla = 1
+
+    def _apply(self, fn: Any, *args, **kwargs) -> 'Gate':
+        # .to(torch.double) must promote the complex64 matrix buffer to complex128 (utils.complex_apply)
+        if self.npara > 0:
+            return super()._apply(fn, *args, **kwargs)
+        held = {}
+        if 'matrix' in self._buffers and self._buffers['matrix'] is not None:
+            held['matrix'] = self._buffers.pop('matrix')
+        super()._apply(fn, *args, **kwargs)
+        for key, value in complex_apply(fn, held).items():
+            self.register_buffer(key, value)
+        return self
+
+    def set_controls(self, controls: int | list[int]) -> None:
+        self.controls = self._convert_indices(controls)
+
+    def get_matrix(self, inputs: Any) -> torch.Tensor:
+        return self.matrix
+
+    def update_matrix(self) -> torch.Tensor:
+        return self.matrix
+
+    def _real_wrapper(self, x: Any) -> torch.Tensor:
+        return torch.view_as_real(self.get_matrix(x))
+
+    def get_derivative(self, inputs: Any) -> torch.Tensor:
+        return torch.zeros_like(self.matrix)
+
+    # ---- kernel-level description -------------------------------------------------------------------
+    def _bits(self, wires: list[int]) -> tuple[int, ...]:
+        return tuple(self.nqubit - 1 - w for w in wires)
+
+    def prims(self, decompose: bool = True) -> list[Prim]:
+        """The gate as kernel primitives.  ``decompose=True`` may split permutation gates into
+        CNOT-like bit flips (exactly equal results, cheaper in the fused kernel)."""
+        return [Prim(self._kernel_kind, self.update_matrix(), self._bits(self.wires), self._bits(self.controls))]
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def op_state(self, x: torch.Tensor) -> torch.Tensor:
+        """(batch, 2, ..., 2) -> same; replaces op_state_base / op_state_control of the reference."""
+        shape = x.shape
+        out = executor.run(x.reshape(shape[0], -1), self.prims(decompose=False))
+        return out.reshape(shape)
+
+    def op_dist_state(self, x):
+        from .distributed import dist_gate
+
+        return dist_gate(x, self)
+
+    def forward(self, x):
+        from .state import DistributedQubitState
+
+        if isinstance(x, DistributedQubitState):
+            return self.op_dist_state(x)
+        if self.den_mat:
+            raise NotImplementedError('deepquantum_amd: the density-matrix path is out of scope (SURVEY section 2)')
+        if self.tsr_mode:
+            assert x.ndim == self.nqubit + 1
+            return self.op_state(x)
+        x = self.op_state(self.tensor_rep(x))
+        return self.vector_rep(x).squeeze(0)
+
+    def inverse(self) -> 'Gate':
+        return self
+
+    def qpd(self, label: int | None = None) -> 'Gate':
+        return self
+
+    def get_unitary(self) -> torch.Tensor:
+        """Global 2^n x 2^n matrix: the gate applied to the columns of the identity (the trick
+        ArbitraryGate.get_unitary already uses in the reference, gate.py:326-330)."""
+        matrix = self.update_matrix()
+        dim = 2**self.nqubit
+        eye = torch.eye(dim, dtype=matrix.dtype, device=matrix.device)
+        with torch.no_grad():
+            cols = executor.run(eye, self.prims(decompose=False))
+        return cols.T.contiguous()
+
+    def extra_repr(self) -> str:
+        s = f'wires={self.wires}'
+        return s if self.controls == [] else s + f', controls={self.controls}'
+
+
+class Layer(Operation):
+    r"""A group of gates added to a circuit at once; ``wires`` is a list of wire lists."""
+
+    def __init__(
+        self,
+        name: str | None = None,
+        nqubit: int = 1,
+        wires: int | list[int] | list[list[int]] | None = None,
+        den_mat: bool = False,
+        tsr_mode: bool = False,
+    ) -> None:
+        super().__init__(name=name, nqubit=nqubit, wires=None, den_mat=den_mat, tsr_mode=tsr_mode)
+        self.wires = self._convert_indices([[0]] if wires is None else wires)
+        self.gates = nn.Sequential()
+        self.nodes = copy(self.wires)
+
+    def get_unitary(self) -> torch.Tensor:
+        u = None
+        for gate in self.gates:
+            u = gate.get_unitary() if u is None else gate.get_unitary() @ u
+        return u
+
+    def init_para(self, inputs: Any = None) -> None:
+        count = 0
+        for gate in self.gates:
+            if inputs is None:
+                gate.init_para()
+            else:
+                gate.init_para(inputs[..., count : count + gate.npara])
+            count += gate.npara
+
+    def update_npara(self) -> None:
+        self.npara = sum(gate.npara for gate in self.gates)
+
+    def set_nqubit(self, nqubit: int) -> None:
+        self.nqubit = nqubit
+        for gate in self.gates:
+            gate.nqubit = nqubit
+
+    def set_wires(self, wires: int | list[int] | list[list[int]]) -> None:
+        self.wires = self._convert_indices(wires)
+        for i, gate in enumerate(self.gates):
+            gate.wires = self.wires[i]
+
+    def prims(self, decompose: bool = True) -> list[Prim]:
+        out: list[Prim] = []
+        for gate in self.gates:
+            out.extend(gate.prims(decompose))
+        return out
+
+    def forward(self, x):
+        from .state import DistributedQubitState
+
+        if isinstance(x, DistributedQubitState):
+            return self.gates(x)
+        flat = self._flat_state(x)
+        out = executor.run(flat, self.prims())
+        if self.tsr_mode:
+            return out.reshape([-1] + [2] * self.nqubit)
+        return self.vector_rep(out).squeeze(0)
+
+    def inverse(self) -> 'Layer':
+        return self
+
+    def _convert_indices(self, indices: int | list) -> list[list[int]]:
+        if isinstance(indices, int):
+            indices = [[indices]]
+        assert isinstance(indices, list), 'Invalid input type'
+        if all(isinstance(i, int) for i in indices):
+            indices = [[i] for i in indices]
+        assert all(isinstance(i, list) for i in indices), 'Invalid input type'
+        for idx in indices:
+            assert all(isinstance(i, int) for i in idx), 'Invalid input type'
+            assert min(idx) > -1 and max(idx) < self.nqubit, 'Invalid input'
+            assert len(set(idx)) == len(idx), 'Invalid input'
+        return indices

@@ -1,0 +1,110 @@
+"""Autograd-aware wrappers around the HIP kernels.
+
+The reference differentiates its dense path with stock autograd through permute/reshape/matmul/cat
+(SURVEY section 3C).  Here every gate application is one ``torch.autograd.Function`` whose backward is
+again a gate kernel (``U^dagger`` applied to the cotangent) plus a small reduction for the matrix
+gradient, so ``loss.backward()`` through ``QubitCircuit`` works unchanged while every sweep over the
+state stays a single HBM-bound HIP launch.
+"""
+
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+from . import backend
+
+
+class _ApplyGate(torch.autograd.Function):
+    """y = (U on targets | controls) x  for x: (B, 2**n), U: (Bm, D, D)."""
+
+    @staticmethod
+    def forward(ctx, state: torch.Tensor, mats: torch.Tensor, targets: tuple, controls: tuple) -> torch.Tensor:
+        ctx.targets, ctx.controls = targets, controls
+        ctx.save_for_backward(state, mats)
+        return backend.apply_gate(state, mats, targets, controls)
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        state, mats = ctx.saved_tensors
+        gy = gy.contiguous()
+        gstate = gmats = None
+        if ctx.needs_input_grad[0]:
+            # d/dx of y = U x  ->  U^H gy on the same targets / controls (other amplitudes: identity)
+            gstate = backend.apply_gate(gy, mats.mH.contiguous(), ctx.targets, ctx.controls)
+        if ctx.needs_input_grad[1]:
+            g = backend.gate_grad(state, gy, ctx.targets, ctx.controls)  # (B, D, D) complex128
+            if mats.shape[0] == 1 and g.shape[0] > 1:
+                g = g.sum(dim=0, keepdim=True)
+            gmats = g.to(mats.dtype)
+        return gstate, gmats, None, None
+
+
+def apply_gate(
+    state: torch.Tensor, mats: torch.Tensor, targets: Sequence[int], controls: Sequence[int] = ()
+) -> torch.Tensor:
+    """Differentiable single-gate application on a contiguous (B, 2**n) state.
+
+    ``mats`` is (D, D) or (Bm, D, D) with Bm in {1, B}; it is cast to the state's dtype (the reference
+    multiplies a matrix and a state of the same dtype because ``.to()`` converts both,
+    operation.py:156-169)."""
+    if mats.ndim == 2:
+        mats = mats.unsqueeze(0)
+    if mats.dtype != state.dtype:
+        mats = mats.to(state.dtype)
+    if not state.is_contiguous():
+        state = state.contiguous()
+    return _ApplyGate.apply(state, mats, tuple(int(t) for t in targets), tuple(int(c) for c in controls))
+
+
+class _ExpectPauli(torch.autograd.Function):
+    """Re <psi|P|psi> per batch sample, P a Pauli string given by bit masks."""
+
+    @staticmethod
+    def forward(ctx, state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
+        ctx.xmask, ctx.zmask = xmask, zmask
+        ctx.save_for_backward(state)
+        return backend.expect_pauli(state, xmask, zmask).to(state.real.dtype)
+
+    @staticmethod
+    def backward(ctx, g: torch.Tensor):
+        (state,) = ctx.saved_tensors
+        # L = psi^H P psi with P Hermitian: dL/d(conj psi) = P psi; PyTorch's convention for a real loss
+        # of a complex tensor is grad = 2 * dL/d(conj psi).
+        ppsi = apply_pauli(state, ctx.xmask, ctx.zmask)
+        return (2.0 * g).to(state.real.dtype).unsqueeze(-1) * ppsi, None, None
+
+
+_PAULI = {}
+
+
+def _pauli_mats(dtype: torch.dtype, device: torch.device) -> dict[str, torch.Tensor]:
+    key = (dtype, device)
+    if key not in _PAULI:
+        _PAULI[key] = {
+            'x': torch.tensor([[0, 1], [1, 0]], dtype=dtype, device=device),
+            'y': torch.tensor([[0, -1j], [1j, 0]], dtype=dtype, device=device),
+            'z': torch.tensor([[1, 0], [0, -1]], dtype=dtype, device=device),
+        }
+    return _PAULI[key]
+
+
+def apply_pauli(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
+    """P|psi> for a Pauli string (no autograd)."""
+    mats = _pauli_mats(state.dtype, state.device)
+    n = state.shape[-1].bit_length() - 1
+    out = state
+    for p in range(n):
+        xb, zb = (xmask >> p) & 1, (zmask >> p) & 1
+        if xb or zb:
+            m = mats['y'] if (xb and zb) else (mats['x'] if xb else mats['z'])
+            out = backend.apply_gate(out, m, [p], [])
+    return out if out is not state else state.clone()
+
+
+def expect_pauli(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
+    """Differentiable Re <psi_b|P|psi_b>, real (B,) in the state's real precision."""
+    if not state.is_contiguous():
+        state = state.contiguous()
+    return _ExpectPauli.apply(state, int(xmask), int(zmask))

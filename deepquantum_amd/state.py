@@ -1,0 +1,95 @@
+"""State containers: ``QubitState`` (dense) and ``DistributedQubitState`` (index-bit sharded),
+API-compatible with the reference's state.py:14-78 and :342-383."""
+
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+from torch import nn
+
+from .bitmath import is_power_of_2, log_base2, power_of_2
+from .communication import comm_get_rank, comm_get_world_size
+from .qmath import amplitude_encoding
+from .utils import complex_apply
+
+
+class _ComplexBuffers(nn.Module):
+    """nn.Module whose complex buffers follow ``.to(real dtype)`` to the matching complex dtype."""
+
+    _complex_names: tuple[str, ...] = ()
+
+    def _apply(self, fn: Any, *args, **kwargs):
+        held = {k: self._buffers.pop(k) for k in self._complex_names if self._buffers.get(k) is not None}
+        super()._apply(fn, *args, **kwargs)
+        for key, value in complex_apply(fn, held).items():
+            self.register_buffer(key, value)
+        return self
+
+
+class QubitState(_ComplexBuffers):
+    """|psi> of ``nqubit`` qubits as a complex64 (2**n, 1) buffer: ``'zeros'``, ``'equal'``,
+    ``'entangle'``/``'GHZ'``/``'ghz'`` or user amplitudes (amplitude-encoded)."""
+
+    _complex_names = ('state',)
+
+    def __init__(self, nqubit: int = 1, state: Any = 'zeros', den_mat: bool = False) -> None:
+        super().__init__()
+        if den_mat:
+            raise NotImplementedError('deepquantum_amd: the density-matrix path is out of scope (SURVEY section 2)')
+        self.nqubit = nqubit
+        self.den_mat = den_mat
+        dim = 2**nqubit
+        if isinstance(state, str):
+            if state == 'zeros':
+                vec = torch.zeros((dim, 1), dtype=torch.cfloat)
+                vec[0] = 1
+            elif state == 'equal':
+                vec = nn.functional.normalize(torch.ones((dim, 1), dtype=torch.cfloat), p=2, dim=-2)
+            elif state in ('entangle', 'GHZ', 'ghz'):
+                vec = torch.zeros((dim, 1), dtype=torch.cfloat)
+                vec[0] = 1 / 2**0.5
+                vec[-1] = 1 / 2**0.5
+            else:
+                raise ValueError(f'unknown state name {state!r}')
+        else:
+            if not isinstance(state, torch.Tensor):
+                state = torch.tensor(state, dtype=torch.cfloat)
+            ndim = state.ndim
+            vec = amplitude_encoding(data=state, nqubit=nqubit)
+            if vec.ndim > ndim:
+                vec = vec.squeeze(0)
+        self.register_buffer('state', vec)
+
+    def forward(self) -> None:
+        pass
+
+
+class DistributedQubitState(_ComplexBuffers):
+    """Shard of an n-qubit state: rank r owns global indices [r * 2^L, (r+1) * 2^L), L = n - log2(W),
+    i.e. wires 0..log2(W)-1 are the global qubits.  ``amps`` is the shard, ``buffer`` the receive
+    buffer of the pairwise exchanges (reference: state.py:342-383)."""
+
+    _complex_names = ('amps', 'buffer')
+
+    def __init__(self, nqubit: int) -> None:
+        super().__init__()
+        self.world_size = comm_get_world_size()
+        self.rank = comm_get_rank()
+        assert is_power_of_2(self.world_size)
+        assert power_of_2(nqubit) >= self.world_size
+        assert 0 <= self.rank < self.world_size
+        self.nqubit = nqubit
+        self.log_num_nodes = log_base2(self.world_size)
+        self.log_num_amps_per_node = nqubit - self.log_num_nodes
+        self.num_amps_per_node = power_of_2(self.log_num_amps_per_node)
+        amps = torch.zeros(self.num_amps_per_node) + 0j
+        self.register_buffer('amps', amps)
+        self.register_buffer('buffer', torch.zeros_like(amps))
+        self.reset()
+
+    def reset(self) -> None:
+        self.amps.zero_()
+        self.buffer.zero_()
+        if self.rank == 0:
+            self.amps[0] = 1.0

@@ -1,0 +1,200 @@
+/*
+ * dq_hip.h -- C ABI of libdqhip.so, the MI355X (gfx950) statevector backend.
+ *
+ * This is the drop-in boundary for the QubitCircuit hot path of TuringQ/deepquantum.  The
+ * reference has no FFI of its own (it is pure Python/PyTorch); every entry point below replaces
+ * one Python-level seam of the reference, cited as <file:line> relative to the reference tree
+ * (src/deepquantum/...).  The Python host (deepquantum_amd/_lib.py) binds these with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *   - All data pointers are DEVICE pointers unless the parameter is documented "host".
+ *   - A state is `batch` contiguous vectors of 2^n interleaved complex numbers
+ *     (c64 = 2 x float, c128 = 2 x double), index bit p <-> wire (n-1-p): wire 0 is the most
+ *     significant bit of the flat amplitude index (operation.py:45-55, qmath.py:497-505).
+ *   - `targets`/`controls` are bit positions (LSB = 0), host arrays.  targets[0] is the MOST
+ *     significant bit of the gate-matrix index (qmath.py:502-503, wires[0] = matrix MSB).
+ *   - Gate matrices are row-major 2^k x 2^k complex in the state's precision, DEVICE memory,
+ *     `mat_batch_stride` = elements (complex numbers) between the matrices of consecutive batch
+ *     samples (0 = one matrix shared by the whole batch; this is the vmap case of
+ *     circuit.py:232-240).
+ *   - Every call enqueues on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     returns without synchronising.  The library keeps no device memory and no global mutable
+ *     state besides a thread-local error string; it is re-entrant.
+ *   - Return value: DQ_OK (0) or a negative DqStatus; dq_last_error() describes the failure.
+ *     No exception crosses the ABI.
+ */
+#ifndef DQ_HIP_H
+#define DQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dq_stream_t; /* hipStream_t */
+
+typedef enum {
+    DQ_OK = 0,
+    DQ_ERR_ARG = -1,         /* invalid argument (bad bit index, overlap, null pointer, ...) */
+    DQ_ERR_LAUNCH = -2,      /* HIP runtime reported an error at launch */
+    DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
+} DqStatus;
+
+#define DQ_ABI_VERSION 1
+
+int dq_abi_version(void);
+/* Thread-local, never NULL. */
+const char* dq_last_error(void);
+/* Fills CU count, LDS bytes per workgroup, total global memory of the current device. */
+int dq_device_info(int* cu_count, int64_t* lds_per_block, int64_t* global_mem);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Single gate application.  Replaces qmath.evolve_state (qmath.py:485-506) and
+ *    Gate.op_state_control (operation.py:203-219): psi' = (U on targets, conditioned on all
+ *    controls = 1) psi.  in == out is allowed (each amplitude group is private to one thread)
+ *    when k <= 4; for k > 4, in and out must not alias.  k <= 10.
+ * ------------------------------------------------------------------------------------------ */
+int dq_apply_gate_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                      const int* targets, int k, const int* controls, int nc, int64_t batch,
+                      dq_stream_t stream);
+int dq_apply_gate_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                       const int* targets, int k, const int* controls, int nc, int64_t batch,
+                       dq_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Fused pass.  Replaces a run of consecutive Gate.forward calls inside
+ *    nn.Sequential(self.operators) (circuit.py:261, operation.py:274-289): one HBM read + one HBM
+ *    write of the state applies every gate of the pass.  A pass owns `m` "tile" index bits: the
+ *    low `L` bits (contiguous, for coalescing) plus `h = m - L` gathered high bits; each
+ *    workgroup stages one 2^m tile (registers + LDS) and walks the pass's rounds.  A round names
+ *    R register-slot bits (tile-local positions); gates of the round act on register slots.
+ *    The host scheduler (deepquantum_amd/fusion.py) builds these descriptors.
+ * ------------------------------------------------------------------------------------------ */
+#define DQ_FUSED_MAX_HIGH 8
+#define DQ_FUSED_MAX_ROUNDS 12
+#define DQ_FUSED_MAX_GATES 40
+#define DQ_FUSED_MAX_SLOTS 4
+
+typedef enum {
+    DQ_FG_GEN1 = 0,  /* general 2x2 on register slot q                       */
+    DQ_FG_X1 = 1,    /* Pauli-X / CNOT / Toffoli: swap the pair of slot q     */
+    DQ_FG_DIAG1 = 2, /* diagonal 2x2 (Z,S,T,Rz,P,CZ...) target anywhere      */
+    DQ_FG_GEN2 = 3,  /* general 4x4 on register slots q (matrix MSB) and q2   */
+    DQ_FG_DIAG2 = 4  /* diagonal 4x4 (Rzz...) both targets anywhere           */
+} DqFusedKind;
+
+typedef enum { DQ_LOC_REG = 0, DQ_LOC_THR = 1, DQ_LOC_OUT = 2 } DqBitLoc;
+
+typedef struct {
+    uint8_t kind;       /* DqFusedKind */
+    uint8_t q;          /* GEN/X: register slot of the (first) target; DIAG: position per loc */
+    uint8_t q2;         /* GEN2: slot of the second target (matrix LSB); DIAG2: position per loc2 */
+    uint8_t loc;        /* DIAG1/2: DqBitLoc of target 1 (REG: q = slot, THR: q = tile-local bit,
+                           OUT: q = global bit position) */
+    uint8_t loc2;       /* DIAG2: same for target 2 */
+    uint8_t reg_cmask;  /* controls that are register slots (bit s = slot s) */
+    uint16_t thr_cmask; /* controls that are thread bits (tile-local bit positions) */
+    uint32_t mat;       /* offset (in complex numbers) of this gate's matrix inside `mats` */
+    uint64_t out_cmask; /* controls outside the tile (global bit positions) */
+} DqFusedGate;          /* 24 bytes */
+
+#define DQ_FUSED_MAX_TBITS 10
+typedef struct {
+    uint8_t rb[DQ_FUSED_MAX_SLOTS]; /* tile-local bit positions of the register slots, ascending */
+    uint8_t tb[DQ_FUSED_MAX_TBITS]; /* tile-local bit position of thread-index bit i (the other m - slots
+                                       tile bits, in an order the host picks to avoid LDS bank conflicts) */
+    uint8_t gate_begin, gate_end;   /* [begin, end) into gates[] */
+} DqFusedRound;                     /* 16 bytes */
+
+typedef struct {
+    uint8_t m, L, h, nrounds;
+    uint8_t high_pos[DQ_FUSED_MAX_HIGH];        /* global bit of tile bit L+i, any order */
+    uint8_t high_sorted[DQ_FUSED_MAX_HIGH];     /* the same positions ascending (tile -> base) */
+    /* Register slots (tile-local, ascending) of the layouts used for the global load and the global
+     * store.  An I/O layout keeps tile bit 0 as slot 0 for c64 (16 B per lane) and otherwise only
+     * gathered bits (>= L) as slots; its thread bits are the remaining tile bits in ascending order,
+     * so a wave instruction always moves >= 2^L contiguous amplitudes. */
+    uint8_t load_rb[DQ_FUSED_MAX_SLOTS];
+    uint8_t store_rb[DQ_FUSED_MAX_SLOTS];
+    DqFusedRound rounds[DQ_FUSED_MAX_ROUNDS];
+    DqFusedGate gates[DQ_FUSED_MAX_GATES];
+} DqFusedPass;
+
+/* Tile geometries this build was compiled with (m = slots + log2(threads)); variant 0 is the
+ * default, DQ_ERR_ARG past the last one.  The kernel is selected by pass->m. */
+int dq_fused_geometry(int is_c128, int variant, int* m, int* slots, int* threads);
+/* `pass` is a HOST pointer; it is copied into the kernel argument segment.  in == out allowed.
+ * Requires n >= pass->m. */
+int dq_apply_fused_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                       int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
+int dq_apply_fused_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                        int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. Reductions.  Results are written to DEVICE memory in double precision.
+ *    `ws` is a caller-owned device workspace of at least dq_reduce_ws_bytes(batch) bytes.
+ * ------------------------------------------------------------------------------------------ */
+int64_t dq_reduce_ws_bytes(int64_t batch);
+
+/* out[b] = Re <psi_b| P |psi_b>, P = Pauli string given as bit masks (a Y sets its bit in both
+ * xmask and zmask).  Replaces qmath.expectation (qmath.py:830-860) + Observable.forward
+ * (layer.py:127-165): one read of the state instead of one gate pass per Pauli factor + bmm. */
+int dq_expect_pauli_c64(const void* psi, uint64_t xmask, uint64_t zmask, int n, int64_t batch,
+                        double* out, void* ws, dq_stream_t stream);
+int dq_expect_pauli_c128(const void* psi, uint64_t xmask, uint64_t zmask, int n, int64_t batch,
+                         double* out, void* ws, dq_stream_t stream);
+
+/* out[2b], out[2b+1] = Re, Im of <bra_b|ket_b> over `count` amplitudes.
+ * Replaces inner_product_dist's local part (distributed.py:288-291) and `state.mH @ x`. */
+int dq_inner_c64(const void* bra, const void* ket, int64_t count, int64_t batch, double* out, void* ws,
+                 dq_stream_t stream);
+int dq_inner_c128(const void* bra, const void* ket, int64_t count, int64_t batch, double* out, void* ws,
+                  dq_stream_t stream);
+
+/* probs[b, i] = |psi[b, i]|^2 in the state's real precision (qmath.py:624). */
+int dq_probs_c64(const void* psi, void* probs, int64_t count, dq_stream_t stream);
+int dq_probs_c128(const void* psi, void* probs, int64_t count, dq_stream_t stream);
+
+/* Marginal distribution over `nw` bit positions (host array, bits[0] = MSB of the outcome index):
+ * out[b, o] = sum over the other bits of |psi|^2, double precision, out must be zeroed by the
+ * caller.  nw <= 12.  Replaces the permute/reshape/sum of qmath.py:626. */
+int dq_marginal_c64(const void* psi, int n, const int* bits, int nw, int64_t batch, double* out,
+                    dq_stream_t stream);
+int dq_marginal_c128(const void* psi, int n, const int* bits, int nw, int64_t batch, double* out,
+                     dq_stream_t stream);
+
+/* Gradient of a gate matrix: gU[b, i, j] += sum_groups gy[i] * conj(x[j]) over the amplitude groups
+ * whose controls are all 1 (the matmul backward of qmath.py:504 / operation.py:216).  k <= 2.
+ * gU is DEVICE double-precision complex [batch, 2^k, 2^k], zeroed by the caller. */
+int dq_gate_grad_c64(const void* x, const void* gy, int n, const int* targets, int k, const int* controls,
+                     int nc, int64_t batch, double* gU, dq_stream_t stream);
+int dq_gate_grad_c128(const void* x, const void* gy, int n, const int* targets, int k, const int* controls,
+                      int nc, int64_t batch, double* gU, dq_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Shard exchange helpers for the index-bit-partitioned state (distributed.py:57-202).
+ *    `nl` = number of local qubits (shard = 2^nl amplitudes per batch sample).
+ * ------------------------------------------------------------------------------------------ */
+/* packed[b, c] = amps[b, expand(c)] where expand() inserts, at the bit positions set in `mask`,
+ * the corresponding bits of `value` (mask/value over local bit positions).  Replaces the
+ * arange/boolean-mask gather of distributed.py:109-117, 150-155. */
+int dq_pack_c64(const void* amps, void* packed, int nl, uint64_t mask, uint64_t value, int64_t batch,
+                dq_stream_t stream);
+int dq_pack_c128(const void* amps, void* packed, int nl, uint64_t mask, uint64_t value, int64_t batch,
+                 dq_stream_t stream);
+/* amps[b, expand(c)] = a * x[b, c] + bcoef * y[b, c]; coef = DEVICE pointer to 2 complex numbers
+ * {a, bcoef} per batch sample (coef_batch_stride in complex numbers, 0 = shared) in the state's
+ * precision.  With y == NULL: amps[b, expand(c)] = x[b, c] (pure scatter, SWAP local<->global).
+ * Replaces distributed.py:70, 126, 157. */
+int dq_unpack_axpby_c64(void* amps, const void* x, const void* y, const void* coef, int64_t coef_batch_stride,
+                        int nl, uint64_t mask, uint64_t value, int64_t batch, dq_stream_t stream);
+int dq_unpack_axpby_c128(void* amps, const void* x, const void* y, const void* coef, int64_t coef_batch_stride,
+                         int nl, uint64_t mask, uint64_t value, int64_t batch, dq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQ_HIP_H */

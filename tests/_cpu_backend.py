@@ -1,0 +1,216 @@
+"""CPU test double for ``deepquantum_amd.backend`` -- TEST INFRASTRUCTURE ONLY.
+
+Installed explicitly by tests (``backend.set_test_backend``) so that host logic -- the gate library,
+the circuit driver, the fusion scheduler and the distributed routines -- can be checked in a container
+without a GPU.  Gate application and reductions are delegated to the oracle; ``apply_fused`` is an
+independent interpreter of the ``DqFusedPass`` descriptor that follows the semantics documented in
+``include/dq_hip.h`` (tile = low L bits + gathered bits, rounds with register slots / thread bits,
+control masks split into reg / thread / outside-tile), so descriptor bugs show up here before a kernel
+ever runs.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import statevec_oracle as oracle  # noqa: E402
+
+from deepquantum_amd import _lib  # noqa: E402
+
+
+class CpuTestBackend:
+    def __init__(self):
+        self.fused_calls = 0
+        self.single_calls = 0
+
+    # ---- single gate -------------------------------------------------------------------------------
+    def apply_gate(self, state, mats, targets, controls, out):
+        self.single_calls += 1
+        res = oracle.apply_gate_bits(state, mats, targets, controls)
+        out.copy_(res)
+        return out
+
+    def fused_geometry(self, is_c128, variant):
+        table = {(False, 0): (12, 4, 256), (False, 1): (13, 4, 512), (True, 0): (11, 3, 256), (True, 1): (12, 4, 256)}
+        return table[(bool(is_c128), variant)]
+
+    # ---- fused pass interpreter --------------------------------------------------------------------
+    def apply_fused(self, state, mats, mat_batch_stride, desc, out):
+        self.fused_calls += 1
+        n = state.shape[-1].bit_length() - 1
+        bsz = state.shape[0]
+        is128 = state.dtype == torch.complex128
+        m, L, h = desc.m, desc.L, desc.h
+        geoms = {(False, 12): 4, (False, 13): 4, (True, 11): 3, (True, 12): 4}
+        R = geoms[(is128, m)]
+        vb = 0 if is128 else 1
+        logt = m - R
+        assert L + h == m and n >= m
+        high_pos = [desc.high_pos[i] for i in range(h)]
+        high_sorted = [desc.high_sorted[i] for i in range(h)]
+        assert sorted(high_pos) == high_sorted and all(L <= p < n for p in high_pos)
+        assert len(set(high_pos)) == h
+        for rbio in (desc.load_rb, desc.store_rb):
+            sl = [rbio[s] for s in range(R)]
+            assert sl == sorted(set(sl)), 'I/O slots must be ascending and distinct'
+            assert all((q == s) if s < vb else (L <= q < m) for s, q in enumerate(sl)), 'I/O layout not coalesced'
+
+        # tile-local index -> global offset, tile index -> base
+        e = np.arange(1 << m, dtype=np.int64)
+        glob = e & ((1 << L) - 1)
+        for i in range(h):
+            glob |= ((e >> (L + i)) & 1) << high_pos[i]
+        tiles = np.arange(1 << (n - m), dtype=np.int64) << L
+        for p in high_sorted:
+            tiles = ((tiles >> p) << (p + 1)) | (tiles & ((1 << p) - 1))
+        idx = tiles[:, None] | glob[None, :]            # (ntiles, 2^m) global amplitude indices
+        assert np.array_equal(np.sort(idx.reshape(-1)), np.arange(1 << n)), 'tiles do not partition the state'
+
+        x = state.detach().numpy().copy()
+        flat_m = mats.detach().numpy().reshape(-1)
+        for b in range(bsz):
+            t = x[b][idx]                               # (ntiles, 2^m)
+            mb = flat_m[b * mat_batch_stride :] if mat_batch_stride else flat_m
+            for r in range(desc.nrounds):
+                rd = desc.rounds[r]
+                rb = [rd.rb[s] for s in range(R)]
+                tb = [rd.tb[i] for i in range(logt)]
+                assert rb == sorted(set(rb)) and all(q < m for q in rb)
+                assert sorted(rb + tb) == list(range(m)), 'slots + thread bits must cover the tile exactly'
+                slotmask = sum(1 << q for q in rb)
+                for gi in range(rd.gate_begin, rd.gate_end):
+                    g = desc.gates[gi]
+                    assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
+                    assert (g.reg_cmask >> R) == 0
+                    cm = g.thr_cmask
+                    for s in range(R):
+                        if (g.reg_cmask >> s) & 1:
+                            cm |= 1 << rb[s]
+                    tile_ok = (tiles & g.out_cmask) == g.out_cmask          # (ntiles,)
+                    outside = g.out_cmask
+                    assert all(((outside >> p) & 1) == 0 for p in range(L)) and all(
+                        ((outside >> p) & 1) == 0 for p in high_pos
+                    ), 'outside-control on a tile bit'
+                    el_ok = (e & cm) == cm
+                    if g.kind in (_lib.FG_GEN1, _lib.FG_X1):
+                        tbit = rb[g.q]
+                        assert not (cm >> tbit) & 1
+                        mat = mb[g.mat : g.mat + 4].reshape(2, 2)
+                        if g.kind == _lib.FG_X1:
+                            mat = np.array([[0, 1], [1, 0]], dtype=mat.dtype)
+                        e0 = e[el_ok & (((e >> tbit) & 1) == 0)]
+                        e1 = e0 | (1 << tbit)
+                        a0, a1 = t[:, e0].copy(), t[:, e1].copy()
+                        n0 = mat[0, 0] * a0 + mat[0, 1] * a1
+                        n1 = mat[1, 0] * a0 + mat[1, 1] * a1
+                        t[:, e0] = np.where(tile_ok[:, None], n0, a0)
+                        t[:, e1] = np.where(tile_ok[:, None], n1, a1)
+                    elif g.kind == _lib.FG_GEN2:
+                        b1, b2 = rb[g.q], rb[g.q2]
+                        assert b1 != b2 and not (cm >> b1) & 1 and not (cm >> b2) & 1
+                        mat = mb[g.mat : g.mat + 16].reshape(4, 4)
+                        e00 = e[el_ok & (((e >> b1) & 1) == 0) & (((e >> b2) & 1) == 0)]
+                        es = [e00, e00 | (1 << b2), e00 | (1 << b1), e00 | (1 << b1) | (1 << b2)]
+                        a = [t[:, q].copy() for q in es]
+                        for i in range(4):
+                            ni = sum(mat[i, j] * a[j] for j in range(4))
+                            t[:, es[i]] = np.where(tile_ok[:, None], ni, a[i])
+                    else:
+                        two = g.kind == _lib.FG_DIAG2
+                        assert g.kind in (_lib.FG_DIAG1, _lib.FG_DIAG2)
+
+                        def bit_of(loc, q):
+                            if loc == _lib.LOC_REG:
+                                return ((e >> rb[q]) & 1)[None, :] * np.ones((len(tiles), 1), dtype=np.int64)
+                            if loc == _lib.LOC_THR:
+                                assert not (slotmask >> q) & 1 and q < m
+                                return ((e >> q) & 1)[None, :] * np.ones((len(tiles), 1), dtype=np.int64)
+                            assert loc == _lib.LOC_OUT
+                            return ((tiles >> q) & 1)[:, None] * np.ones((1, len(e)), dtype=np.int64)
+
+                        if two:
+                            d = mb[g.mat : g.mat + 16].reshape(4, 4).diagonal()
+                            sel = bit_of(g.loc, g.q) * 2 + bit_of(g.loc2, g.q2)
+                        else:
+                            d = mb[g.mat : g.mat + 4].reshape(2, 2).diagonal()
+                            sel = bit_of(g.loc, g.q)
+                        ph = d[sel]
+                        ok = tile_ok[:, None] & el_ok[None, :]
+                        t = np.where(ok, ph * t, t)
+            x[b][idx] = t
+        out.copy_(torch.from_numpy(x))
+        return out
+
+    # ---- reductions ---------------------------------------------------------------------------------
+    def expect_pauli(self, state, xmask, zmask):
+        n = state.shape[-1].bit_length() - 1
+        wires, basis = [], ''
+        for p in range(n):
+            xb, zb = (xmask >> p) & 1, (zmask >> p) & 1
+            if xb or zb:
+                wires.append(n - 1 - p)
+                basis += 'y' if (xb and zb) else ('x' if xb else 'z')
+        if not wires:
+            return (torch.abs(state) ** 2).sum(-1).to(torch.float64)
+        return oracle.expectation_pauli(state, wires, basis).to(torch.float64)
+
+    def inner(self, bra, ket):
+        return (bra.conj() * ket).sum(-1).to(torch.complex128)
+
+    def probs(self, state):
+        return torch.abs(state) ** 2
+
+    def marginal(self, state, bits):
+        n = state.shape[-1].bit_length() - 1
+        wires = [n - 1 - b for b in bits]
+        order = sorted(range(len(wires)), key=lambda i: wires[i])
+        p = oracle.probabilities(state, wires).reshape([state.shape[0]] + [2] * len(wires))
+        # oracle returns outcomes indexed by sorted wires; re-order axes to the requested bit order
+        inv = [order.index(i) + 1 for i in range(len(wires))]
+        return p.permute([0] + inv).reshape(state.shape[0], -1).to(torch.float64)
+
+    def gate_grad(self, x, gy, targets, controls):
+        n = x.shape[-1].bit_length() - 1
+        b = x.shape[0]
+        wt = [n - 1 - t + 1 for t in targets]
+        wc = [n - 1 - c + 1 for c in controls]
+        rest = [i for i in range(1, n + 1) if i not in wt and i not in wc]
+        perm = [0] + wt + rest + wc
+        d = 1 << len(targets)
+
+        def mat(t):
+            t = t.reshape([b] + [2] * n).permute(perm).reshape(b, d, -1, 1 << len(controls))
+            return t[..., -1]
+
+        return (mat(gy) @ mat(x).mH).to(torch.complex128)
+
+    # ---- shard helpers ------------------------------------------------------------------------------
+    @staticmethod
+    def _expand(nl, mask, value):
+        c = np.arange(1 << (nl - bin(mask).count('1')), dtype=np.int64)
+        out = np.zeros_like(c)
+        src = 0
+        for p in range(nl):
+            if not (mask >> p) & 1:
+                out |= ((c >> src) & 1) << p
+                src += 1
+        return torch.from_numpy(out | value)
+
+    def pack(self, amps, mask, value):
+        nl = amps.shape[-1].bit_length() - 1
+        return amps[:, self._expand(nl, mask, value)].contiguous()
+
+    def unpack_axpby(self, amps, x, y, coef, mask, value):
+        nl = amps.shape[-1].bit_length() - 1
+        idx = self._expand(nl, mask, value)
+        if y is None:
+            amps[:, idx] = x
+        else:
+            coef = coef.to(amps.dtype).reshape(-1, 2)
+            amps[:, idx] = coef[:, 0:1] * x + coef[:, 1:2] * y
+        return amps

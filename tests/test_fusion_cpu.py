@@ -1,0 +1,106 @@
+"""Host-side scheduler: legality of the reordering and of the emitted descriptors (no GPU).
+
+The descriptors are executed by the independent interpreter in tests/_cpu_backend.py and compared with
+the oracle applying the same gates one by one in program order."""
+
+import random
+
+import pytest
+import torch
+
+from deepquantum_amd import _lib, backend, fusion
+from oracle import statevec_oracle as oracle
+
+
+def random_ops(n, ngates, seed, kinds=('gen', 'x', 'diag', 'gen2', 'diag2', 'big')):
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(seed)
+    ops, mats, off = [], [], 0
+    for _ in range(ngates):
+        kind = rng.choice(kinds)
+        k = {'gen': 1, 'x': 1, 'diag': 1, 'gen2': 2, 'diag2': 2, 'big': 3}[kind]
+        nc = rng.choice([0, 0, 0, 1, 1, 2])
+        bits = rng.sample(range(n), k + nc)
+        d = 1 << k
+        if kind == 'x':
+            m = torch.tensor([[0, 1], [1, 0]], dtype=torch.complex128)
+        elif kind in ('diag', 'diag2'):
+            m = torch.diag(torch.exp(1j * torch.rand(d, generator=g, dtype=torch.float64) * 6.28))
+        else:
+            a = torch.randn(d, d, generator=g, dtype=torch.float64) + 1j * torch.randn(d, d, generator=g, dtype=torch.float64)
+            m, _ = torch.linalg.qr(a)
+        pk = {'gen': 'gen', 'x': 'x', 'diag': 'diag', 'gen2': 'gen', 'diag2': 'diag', 'big': 'gen'}[kind]
+        ops.append(fusion.PrimOp(pk, tuple(bits[:k]), tuple(bits[k:]), off))
+        mats.append(m.reshape(-1))
+        off += d * d
+    return ops, torch.cat(mats)
+
+
+def run_reference(state, ops, mats):
+    x = state
+    for op in ops:
+        d = 1 << op.k
+        m = mats[op.mat : op.mat + d * d].reshape(d, d)
+        x = oracle.apply_gate_bits(x, m, list(op.targets), list(op.controls))
+    return x
+
+
+def run_steps(state, ops, mats, steps):
+    x = state.clone()
+    for st in steps:
+        if isinstance(st, fusion.FusedStep):
+            backend.apply_fused(x, mats, 0, st.desc, out=x)
+        else:
+            op = ops[st.op]
+            d = 1 << op.k
+            x = backend.apply_gate(x, mats[op.mat : op.mat + d * d].reshape(d, d), op.targets, op.controls)
+    return x
+
+
+@pytest.mark.parametrize('is128,m,n', [(False, 12, 12), (False, 12, 14), (True, 11, 13), (False, 13, 14), (True, 12, 13)])
+@pytest.mark.parametrize('seed', [0, 1])
+def test_schedule_matches_program_order(cpu_backend, is128, m, n, seed):
+    dtype = torch.complex128 if is128 else torch.complex64
+    ops, mats = random_ops(n, 60, seed)
+    mats = mats.to(dtype)
+    geom = fusion.default_geometry(is128, m)
+    steps = fusion.schedule(ops, n, geom)
+    executed = sorted(i for st in steps for i in (st.ops if isinstance(st, fusion.FusedStep) else [st.op]))
+    assert executed == list(range(len(ops)))
+    assert any(isinstance(st, fusion.FusedStep) for st in steps)
+    g = torch.Generator().manual_seed(100 + seed)
+    state = torch.randn(2, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 1 << n, generator=g, dtype=torch.float64)
+    state = (state / state.norm(dim=-1, keepdim=True)).to(dtype)
+    ref = run_reference(state, ops, mats)
+    got = run_steps(state, ops, mats, steps)
+    tol = 1e-12 if is128 else 2e-5
+    assert torch.allclose(got, ref, atol=tol, rtol=0), (got - ref).abs().max()
+
+
+def test_benchmark_circuit_fuses_deeply():
+    n, depth = 28, 40
+    spec = oracle.random_circuit_spec(n, depth)
+    ops = []
+    for i, op in enumerate(spec):
+        if op[0] in ('h', 'rx'):
+            ops.append(fusion.PrimOp('gen', (n - 1 - op[1],), (), 4 * i))
+        else:
+            ops.append(fusion.PrimOp('x', (n - 1 - op[2],), (n - 1 - op[1],), 4 * i))
+    steps = fusion.schedule(ops, n, fusion.default_geometry(False))
+    assert all(isinstance(s, fusion.FusedStep) for s in steps)
+    assert sum(len(s.ops) for s in steps) == n * depth
+    assert len(steps) < n * depth / 8  # >= 8 gates per HBM pass on the headline workload
+
+
+def test_small_state_is_not_fused():
+    ops = [fusion.PrimOp('gen', (0,), (), 0)]
+    steps = fusion.schedule(ops, 5, fusion.default_geometry(False))
+    assert len(steps) == 1 and isinstance(steps[0], fusion.SingleStep)
+
+
+def test_descriptor_struct_sizes_match_header():
+    import ctypes
+
+    assert ctypes.sizeof(_lib.DqFusedGate) == 24
+    assert ctypes.sizeof(_lib.DqFusedRound) == 16
+    assert ctypes.sizeof(_lib.DqFusedPass) == 4 + 8 + 8 + 4 + 4 + 4 + 12 * 16 + 40 * 24

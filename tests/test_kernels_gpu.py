@@ -1,0 +1,186 @@
+"""Parity of the HIP kernels (through the C ABI / ctypes) against the CPU oracle on seeded inputs.
+
+Tolerances are the north-star ones: 1e-10 for complex128, 1e-4 for complex64 (absolute, on amplitudes of
+a normalised state and on expectation values); actual errors are ~1e-15 / ~1e-6."""
+
+import random
+
+import pytest
+import torch
+
+from deepquantum_amd import backend, fusion
+from oracle import statevec_oracle as oracle
+from test_fusion_cpu import random_ops, run_reference
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.complex64: 1e-4, torch.complex128: 1e-10}
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda', 0)
+
+
+def rand_state(b, n, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randn(b, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(b, 1 << n, generator=g, dtype=torch.float64)
+    return (s / s.norm(dim=-1, keepdim=True)).to(dtype)
+
+
+def rand_unitary(k, dtype, seed, batch=None):
+    g = torch.Generator().manual_seed(seed)
+    d = 1 << k
+    shape = (d, d) if batch is None else (batch, d, d)
+    a = torch.randn(*shape, generator=g, dtype=torch.float64) + 1j * torch.randn(*shape, generator=g, dtype=torch.float64)
+    q, _ = torch.linalg.qr(a)
+    return q.to(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+@pytest.mark.parametrize('k,nc', [(1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (3, 0), (3, 2), (4, 0), (5, 0), (6, 1)])
+def test_apply_gate_all_positions(dtype, k, nc):
+    n, b = 9, 3
+    rng = random.Random(1000 * k + nc)
+    x = rand_state(b, n, dtype, 7)
+    for trial in range(6):
+        bits = rng.sample(range(n), k + nc)
+        batched = trial % 2 == 1
+        m = rand_unitary(k, dtype, trial, batch=b if batched else None)
+        ref = oracle.apply_gate_bits(x, m, bits[:k], bits[k:])
+        got = backend.apply_gate(x.to(dev()), m.to(dev()), bits[:k], bits[k:]).cpu()
+        assert (got - ref).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+def test_apply_gate_in_place_and_edges(dtype):
+    n = 6
+    x = rand_state(2, n, dtype, 3)
+    m = rand_unitary(1, dtype, 5)
+    for t in (0, n - 1):
+        xd = x.to(dev())
+        ref = oracle.apply_gate_bits(x, m, [t], [])
+        backend.apply_gate(xd, m.to(dev()), [t], [], out=xd)
+        assert (xd.cpu() - ref).abs().max().item() < TOL[dtype]
+    # one-qubit state
+    x1 = rand_state(1, 1, dtype, 9)
+    got = backend.apply_gate(x1.to(dev()), m.to(dev()), [0], []).cpu()
+    assert (got - oracle.apply_gate_bits(x1, m, [0], [])).abs().max().item() < TOL[dtype]
+
+
+def test_apply_gate_rejects_bad_arguments():
+    x = rand_state(1, 4, torch.complex64, 1).to(dev())
+    m = rand_unitary(1, torch.complex64, 1).to(dev())
+    with pytest.raises(RuntimeError):
+        backend.apply_gate(x, m, [4], [])          # bit out of range
+    with pytest.raises(RuntimeError):
+        backend.apply_gate(x, m, [1], [1])         # target == control
+    with pytest.raises(RuntimeError):
+        backend.apply_gate(x.cpu(), m.cpu(), [1], [])  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize('is128,m,n', [(False, 12, 12), (False, 12, 15), (False, 13, 14), (True, 11, 11),
+                                       (True, 11, 14), (True, 12, 13)])
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_fused_passes_match_oracle(is128, m, n, seed):
+    dtype = torch.complex128 if is128 else torch.complex64
+    ops, mats = random_ops(n, 80, seed, kinds=('gen', 'x', 'diag', 'gen2', 'diag2'))
+    mats = mats.to(dtype)
+    steps = fusion.schedule(ops, n, fusion.default_geometry(is128, m))
+    assert all(isinstance(s, fusion.FusedStep) for s in steps)
+    x = rand_state(2, n, dtype, 50 + seed)
+    ref = run_reference(x, ops, mats)
+    xd, md = x.to(dev()), mats.to(dev())
+    for st in steps:
+        backend.apply_fused(xd, md, 0, st.desc, out=xd)
+    err = (xd.cpu() - ref).abs().max().item()
+    assert err < TOL[dtype], err
+
+
+@pytest.mark.parametrize('is128', [False, True])
+def test_fused_batched_matrices_and_out_of_place(is128):
+    dtype = torch.complex128 if is128 else torch.complex64
+    n, b = 13, 3
+    ops, mats0 = random_ops(n, 40, 11, kinds=('gen', 'x', 'diag', 'gen2'))
+    per_sample = []
+    for i in range(b):
+        _, mi = random_ops(n, 40, 11, kinds=('gen', 'x', 'diag', 'gen2'))
+        g = torch.Generator().manual_seed(i)
+        # same structure, different unitaries per sample: right-multiply each gate matrix by a phase
+        per_sample.append(mi * torch.exp(1j * torch.rand(1, generator=g, dtype=torch.float64) * 3))
+    mats = torch.stack(per_sample).to(dtype)
+    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+    x = rand_state(b, n, dtype, 5)
+    ref = torch.cat([run_reference(x[i : i + 1], ops, mats[i]) for i in range(b)])
+    xd, md = x.to(dev()), mats.to(dev()).contiguous()
+    cur = xd
+    for st in steps:
+        nxt = torch.empty_like(cur)
+        backend.apply_fused(cur, md, md.shape[1], st.desc, out=nxt)
+        cur = nxt
+    assert (cur.cpu() - ref).abs().max().item() < TOL[dtype]
+    assert torch.equal(xd.cpu(), x)  # input untouched
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+def test_reductions(dtype):
+    n, b = 10, 3
+    x = rand_state(b, n, dtype, 21)
+    xd = x.to(dev())
+    rng = random.Random(5)
+    for _ in range(8):
+        k = rng.randint(1, 4)
+        wires = rng.sample(range(n), k)
+        basis = ''.join(rng.choice('xyz') for _ in range(k))
+        xm = zm = 0
+        for w, p in zip(wires, basis):
+            bit = 1 << (n - 1 - w)
+            xm |= bit if p in 'xy' else 0
+            zm |= bit if p in 'zy' else 0
+        ref = oracle.expectation_pauli(x, wires, basis).to(torch.float64)
+        got = backend.expect_pauli(xd, xm, zm).cpu()
+        assert (got - ref).abs().max().item() < TOL[dtype]
+    y = rand_state(b, n, dtype, 22)
+    ref = (x.conj() * y).sum(-1).to(torch.complex128)
+    assert (backend.inner(xd, y.to(dev())).cpu() - ref).abs().max().item() < TOL[dtype]
+    assert (backend.probs(xd).cpu() - torch.abs(x) ** 2).abs().max().item() < TOL[dtype]
+    for wires in ([0], [3, 1], [9, 0, 4], list(range(n))[:7]):
+        ref = oracle.probabilities(x, wires).to(torch.float64)
+        got = backend.marginal(xd, [n - 1 - w for w in sorted(wires)]).cpu()
+        assert (got - ref).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+@pytest.mark.parametrize('k,nc', [(1, 0), (1, 2), (2, 0), (2, 1)])
+def test_gate_grad(dtype, k, nc):
+    from _cpu_backend import CpuTestBackend
+
+    n, b = 8, 2
+    x, gy = rand_state(b, n, dtype, 1), rand_state(b, n, dtype, 2)
+    bits = random.Random(k * 10 + nc).sample(range(n), k + nc)
+    ref = CpuTestBackend().gate_grad(x, gy, bits[:k], bits[k:])
+    got = backend.gate_grad(x.to(dev()), gy.to(dev()), bits[:k], bits[k:]).cpu()
+    assert (got - ref).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+def test_pack_unpack(dtype):
+    from _cpu_backend import CpuTestBackend
+
+    cpu = CpuTestBackend()
+    nl, b = 9, 2
+    x = rand_state(b, nl, dtype, 4)
+    for mask, value in ((0b100, 0b100), (0b100010, 0b000010), (0, 0), (0b1, 0)):
+        ref = cpu.pack(x, mask, value)
+        got = backend.pack(x.to(dev()), mask, value)
+        assert torch.equal(got.cpu(), ref)
+        y = rand_state(b, nl, dtype, 6)[:, : ref.shape[1]].contiguous()
+        coef = torch.tensor([[0.3 + 0.1j, -0.2 + 0.5j]], dtype=dtype)
+        a1, a2 = x.clone(), x.clone().to(dev())
+        cpu.unpack_axpby(a1, ref, y, coef, mask, value)
+        backend.unpack_axpby(a2, got, y.to(dev()), coef.to(dev()), mask, value)
+        assert (a2.cpu() - a1).abs().max().item() < TOL[dtype]
+        a1, a2 = x.clone(), x.clone().to(dev())
+        cpu.unpack_axpby(a1, y, None, None, mask, value)
+        backend.unpack_axpby(a2, y.to(dev()), None, None, mask, value)
+        assert torch.equal(a2.cpu(), a1)

@@ -1,0 +1,65 @@
+"""Evaluate LDS index swizzles for the fused kernel's layout transposes (host-side design aid).
+
+Model (MI355X_MICROARCH.md, LDS table): ds_read_b64 is served in two 32-lane groups over 64 4-byte
+banks, ds_write_b64 in four contiguous 16-lane groups over 32 banks; ds_read_b128 in four 16-lane
+groups (non-contiguous) over 64 banks, ds_write_b128 in eight contiguous 8-lane groups over 32 banks.
+Cost of a group = max number of distinct addresses that fall on one bank slot.
+"""
+import itertools, sys
+
+def deposit(tid, rb, m):
+    e = 0; src = 0
+    for p in range(m):
+        if p not in rb:
+            e |= ((tid >> src) & 1) << p; src += 1
+    return e
+
+R128 = [[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27],[4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31]]
+R128 = R128 + [[x+32 for x in g] for g in R128]
+
+def cost(addrs, groups, slots):
+    # addrs: element index per lane; slots: number of distinct element slots per bank row
+    tot = 0
+    for g in groups:
+        buckets = {}
+        for l in g:
+            buckets.setdefault(addrs[l] % slots, set()).add(addrs[l])
+        tot += max(len(v) for v in buckets.values())
+    return tot
+
+def evaluate(swz, m, R, elem_bytes):
+    nthreads = 1 << (m - R)
+    if elem_bytes == 8:
+        rgroups = [list(range(0,32)), list(range(32,64))]; rslots = 32
+        wgroups = [list(range(i,i+16)) for i in range(0,64,16)]; wslots = 16
+    else:
+        rgroups = R128; rslots = 16
+        wgroups = [list(range(i,i+8)) for i in range(0,64,8)]; wslots = 8
+    worst_r = worst_w = 0; sum_r = sum_w = 0; cnt = 0
+    for rb in itertools.combinations(range(m), R):
+        soffs = [sum(((j >> s) & 1) << rb[s] for s in range(R)) for j in range(1 << R)]
+        for w in range(min(nthreads // 64, 2)):
+            tb = [deposit(w*64 + l, rb, m) for l in range(64)]
+            for so in soffs[:4]:
+                addrs = [swz(t | so) for t in tb]
+                cr = cost(addrs, rgroups, rslots) / len(rgroups)
+                cw = cost(addrs, wgroups, wslots) / len(wgroups)
+                worst_r = max(worst_r, cr); worst_w = max(worst_w, cw); sum_r += cr; sum_w += cw; cnt += 1
+    return worst_r, sum_r / cnt, worst_w, sum_w / cnt
+
+if __name__ == '__main__':
+    cands = {
+        'identity': lambda e: e,
+        'pad e+(e>>5)': lambda e: e + (e >> 5),
+        'pad e+(e>>4)': lambda e: e + (e >> 4),
+        'xor (e>>5)&31': lambda e: e ^ ((e >> 5) & 31),
+        'xor (e>>4)&15': lambda e: e ^ ((e >> 4) & 15),
+        'xor (e>>5)&31 ^ (e>>10)&3': lambda e: e ^ ((e >> 5) & 31) ^ ((e >> 10) & 3),
+        'xor fold3': lambda e: e ^ ((e >> 4) & 15) ^ ((e >> 8) & 15),
+        'xor fold5': lambda e: e ^ ((e >> 5) & 31) ^ ((e >> 10) & 31),
+    }
+    for eb, m, R in ((8, 12, 4), (16, 11, 3), (16, 12, 4)):
+        print(f'elem {eb}B m={m} R={R}')
+        for name, f in cands.items():
+            wr, ar, ww, aw = evaluate(f, m, R, eb)
+            print(f'  {name:28s} read worst {wr:5.1f} avg {ar:5.2f} | write worst {ww:5.1f} avg {aw:5.2f}')
