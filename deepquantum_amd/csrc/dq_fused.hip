@@ -20,34 +20,98 @@
 // Roofline: HBM-bound by construction.  Algorithmic bytes per launch = sum over the gates of the
 // pass of 2 * 2^(n - nc) * sizeof(amp) * batch; actual traffic = 2 * 2^n * sizeof(amp) * batch.
 #include "dq_common.hpp"
+#include <stddef.h>
 
 namespace dq {
 
 // ---- gate bodies on the register file ---------------------------------------------------------------
-template <typename T, int R, int Q>
+// MODE 0: general complex 2x2.  MODE 1: all four entries real (H, Ry, X, ...).  MODE 2: real diagonal,
+// purely imaginary off-diagonal (Rx).  The mode is picked at run time from the (workgroup-uniform)
+// matrix values, so multiplications by exact zeros are skipped: half the VALU work for H / Rx / Ry.
+// Packed formulation: an amplitude (re, im) is one 2-vector, so every line below is one packed VALU op on
+// gfx950 (v_pk_mul_f32 / v_pk_fma_f32 with op_sel / neg modifiers for the swizzled operand); for double
+// the same source scalarises to v_fma_f64.
+template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
+
+template <typename T, int MODE>
+__device__ __forceinline__ void apply2x2(cx<T>& x0, cx<T>& x1, const cx<T> m00, const cx<T> m01, const cx<T> m10,
+                                         const cx<T> m11) {
+    using V2 = vec2<T>;
+    const V2 a = {x0.x, x0.y}, b = {x1.x, x1.y};
+    V2 r0, r1;
+    if constexpr (MODE == 1) {
+        // scalar source form: hipcc's SLP vectoriser turns each (x, y) pair into one packed op and keeps
+        // the matrix entries as SGPR operands (32 packed VALU ops per 16 amplitudes, measured)
+        cx<T> n0, n1;
+        n0.x = fma(m01.x, x1.x, m00.x * x0.x);
+        n0.y = fma(m01.x, x1.y, m00.x * x0.y);
+        n1.x = fma(m11.x, x1.x, m10.x * x0.x);
+        n1.y = fma(m11.x, x1.y, m10.x * x0.y);
+        x0 = n0;
+        x1 = n1;
+        return;
+    } else if constexpr (MODE == 2) {
+        // i*y*(b.x + i b.y) = (-y b.y) + i (y b.x)
+        cx<T> n0, n1;
+        n0.x = fma(-m01.y, x1.y, m00.x * x0.x);
+        n0.y = fma(m01.y, x1.x, m00.x * x0.y);
+        n1.x = fma(-m10.y, x0.y, m11.x * x1.x);
+        n1.y = fma(m10.y, x0.x, m11.x * x1.y);
+        x0 = n0;
+        x1 = n1;
+        return;
+    } else {
+        const V2 bs = {-b.y, b.x}, as = {-a.y, a.x};
+        V2 t = m01.x * b;
+        t = __builtin_elementwise_fma((V2)(m01.y), bs, t);
+        t = __builtin_elementwise_fma((V2)(m00.y), as, t);
+        r0 = __builtin_elementwise_fma((V2)(m00.x), a, t);
+        V2 u = m10.x * a;
+        u = __builtin_elementwise_fma((V2)(m10.y), as, u);
+        u = __builtin_elementwise_fma((V2)(m11.y), bs, u);
+        r1 = __builtin_elementwise_fma((V2)(m11.x), b, u);
+    }
+    x0.x = r0.x;
+    x0.y = r0.y;
+    x1.x = r1.x;
+    x1.y = r1.y;
+}
+
+template <typename T, int R, int Q, int MODE, bool PRED>
 __device__ __forceinline__ void gen1_body(cx<T> (&a)[1 << R], const cx<T> m00, const cx<T> m01, const cx<T> m10,
                                           const cx<T> m11, const unsigned reg_cmask, const bool thr_ok) {
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j) {
         if ((j >> Q) & 1) continue;
-        if (thr_ok && ((j & reg_cmask) == reg_cmask)) {
-            const cx<T> x0 = a[j], x1 = a[j | (1 << Q)];
-            a[j] = cfma(m01, x1, cmul(m00, x0));
-            a[j | (1 << Q)] = cfma(m11, x1, cmul(m10, x0));
+        if constexpr (PRED) {
+            if (thr_ok && ((j & reg_cmask) == reg_cmask)) apply2x2<T, MODE>(a[j], a[j | (1 << Q)], m00, m01, m10, m11);
+        } else {
+            apply2x2<T, MODE>(a[j], a[j | (1 << Q)], m00, m01, m10, m11);
         }
     }
 }
 
+// Register swap through v_swap_b32: one VALU op per dword, and -- being an asm statement -- it keeps the
+// enclosing per-lane control an exec-masked branch instead of being if-converted into v_cndmask chains.
+__device__ __forceinline__ void swap_dword(float& a, float& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_dword(double& a, double& b) {
+    int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    asm volatile("v_swap_b32 %0, %1" : "+v"(alo), "+v"(blo));
+    asm volatile("v_swap_b32 %0, %1" : "+v"(ahi), "+v"(bhi));
+    a = __hiloint2double(ahi, alo);
+    b = __hiloint2double(bhi, blo);
+}
+template <typename V> __device__ __forceinline__ void swap_amp(V& a, V& b) {
+    swap_dword(a.x, b.x);
+    swap_dword(a.y, b.y);
+}
+
 template <typename T, int R, int Q>
-__device__ __forceinline__ void x1_body(cx<T> (&a)[1 << R], const unsigned reg_cmask, const bool thr_ok) {
+__device__ __forceinline__ void x1_body(cx<T> (&a)[1 << R], const unsigned reg_cmask) {
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j) {
         if ((j >> Q) & 1) continue;
-        if (thr_ok && ((j & reg_cmask) == reg_cmask)) {
-            const cx<T> x0 = a[j];
-            a[j] = a[j | (1 << Q)];
-            a[j | (1 << Q)] = x0;
-        }
+        if ((j & reg_cmask) == reg_cmask) swap_amp(a[j], a[j | (1 << Q)]);
     }
 }
 
@@ -72,29 +136,58 @@ __device__ __forceinline__ void gen2_body(cx<T> (&a)[1 << R], const cx<T>* __res
     }
 }
 
-template <typename T, int R>
-__device__ __forceinline__ void dispatch_gen1(cx<T> (&a)[1 << R], int q, const cx<T>* __restrict__ mp,
-                                              unsigned reg_cmask, bool thr_ok) {
-    const cx<T> m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+template <typename T, int R, int MODE, bool PRED>
+__device__ __forceinline__ void dispatch_gen1_q(cx<T> (&a)[1 << R], int q, const cx<T> m00, const cx<T> m01,
+                                                const cx<T> m10, const cx<T> m11, unsigned reg_cmask, bool thr_ok) {
     switch (q) {
-        case 0: gen1_body<T, R, 0>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
-        case 1: gen1_body<T, R, 1>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
-        case 2: gen1_body<T, R, 2>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
+        case 0: gen1_body<T, R, 0, MODE, PRED>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
+        case 1: gen1_body<T, R, 1, MODE, PRED>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
+        case 2: gen1_body<T, R, 2, MODE, PRED>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
         default:
-            if constexpr (R > 3) gen1_body<T, R, 3>(a, m00, m01, m10, m11, reg_cmask, thr_ok);
+            if constexpr (R > 3) gen1_body<T, R, 3, MODE, PRED>(a, m00, m01, m10, m11, reg_cmask, thr_ok);
             break;
     }
 }
 
 template <typename T, int R>
-__device__ __forceinline__ void dispatch_x1(cx<T> (&a)[1 << R], int q, unsigned reg_cmask, bool thr_ok) {
-    switch (q) {
-        case 0: x1_body<T, R, 0>(a, reg_cmask, thr_ok); break;
-        case 1: x1_body<T, R, 1>(a, reg_cmask, thr_ok); break;
-        case 2: x1_body<T, R, 2>(a, reg_cmask, thr_ok); break;
-        default:
-            if constexpr (R > 3) x1_body<T, R, 3>(a, reg_cmask, thr_ok);
-            break;
+__device__ __forceinline__ void dispatch_gen1(cx<T> (&a)[1 << R], int q, const cx<T>* __restrict__ mp,
+                                              unsigned reg_cmask, bool pred, bool thr_ok) {
+    const cx<T> m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+    const bool all_real = (m00.y == 0) & (m01.y == 0) & (m10.y == 0) & (m11.y == 0);
+    const bool rx_like = (m00.y == 0) & (m11.y == 0) & (m01.x == 0) & (m10.x == 0);
+    if (pred) {  // controlled gate: one predicated general body (code size)
+        dispatch_gen1_q<T, R, 0, true>(a, q, m00, m01, m10, m11, reg_cmask, thr_ok);
+    } else if (all_real) {
+        dispatch_gen1_q<T, R, 1, false>(a, q, m00, m01, m10, m11, 0u, true);
+    } else if (rx_like) {
+        dispatch_gen1_q<T, R, 2, false>(a, q, m00, m01, m10, m11, 0u, true);
+    } else {
+        dispatch_gen1_q<T, R, 0, false>(a, q, m00, m01, m10, m11, 0u, true);
+    }
+}
+
+// X / CNOT / Toffoli.  Controls on register slots or outside the tile are uniform tests; only a control
+// on a thread bit makes the swap per-lane, and then it is one exec-masked region of v_swap_b32.
+template <typename T, int R>
+__device__ __forceinline__ void dispatch_x1(cx<T> (&a)[1 << R], int q, unsigned reg_cmask, bool lane_pred, bool thr_ok) {
+    if (!lane_pred) {
+        switch (q) {
+            case 0: x1_body<T, R, 0>(a, reg_cmask); break;
+            case 1: x1_body<T, R, 1>(a, reg_cmask); break;
+            case 2: x1_body<T, R, 2>(a, reg_cmask); break;
+            default:
+                if constexpr (R > 3) x1_body<T, R, 3>(a, reg_cmask);
+                break;
+        }
+    } else if (thr_ok) {
+        switch (q) {
+            case 0: x1_body<T, R, 0>(a, reg_cmask); break;
+            case 1: x1_body<T, R, 1>(a, reg_cmask); break;
+            case 2: x1_body<T, R, 2>(a, reg_cmask); break;
+            default:
+                if constexpr (R > 3) x1_body<T, R, 3>(a, reg_cmask);
+                break;
+        }
     }
 }
 
@@ -151,11 +244,16 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, 
     V* lds = reinterpret_cast<V*>(dq_smem);
 
     const unsigned tid = threadIdx.x;
-    const int L = p.L, h = p.h;
+    const uint32_t* hw = reinterpret_cast<const uint32_t*>(&p);
+    const uint32_t hw0 = hw[0], hp0 = hw[1], hp1 = hw[2], hs0 = hw[3], hs1 = hw[4], lrb = hw[5], srbw = hw[6];
+    const int L = (int)((hw0 >> 8) & 0xffu), h = (int)((hw0 >> 16) & 0xffu);
+    auto byte_of = [](uint32_t w0, uint32_t w1, int i) __attribute__((always_inline)) -> unsigned {
+        return ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
+    };
 
     // ---- tile base address (workgroup-uniform) ----
     uint64_t tile = (uint64_t)blockIdx.x << L;
-    for (int i = 0; i < h; ++i) tile = insert_zero(tile, p.high_sorted[i]);
+    for (int i = 0; i < h; ++i) tile = insert_zero(tile, (int)byte_of(hs0, hs1, i));
     const uint64_t state_off = ((uint64_t)blockIdx.y << n) + tile;
     const V* pin = in + state_off;
     V* pout = out + state_off;
@@ -164,7 +262,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, 
     // tile-local index -> offset inside the state
     auto glob = [&](unsigned e) __attribute__((always_inline)) -> uint64_t {
         uint64_t g = e & ((1u << L) - 1u);
-        for (int i = 0; i < h; ++i) g |= (uint64_t)((e >> (L + i)) & 1u) << p.high_pos[i];
+        for (int i = 0; i < h; ++i) g |= (uint64_t)((e >> (L + i)) & 1u) << byte_of(hp0, hp1, i);
         return g;
     };
 
@@ -173,7 +271,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, 
     unsigned tbase = tid;  // current thread base (tile-local)
 #pragma unroll
     for (int s = 0; s < R; ++s) {
-        rb[s] = p.load_rb[s];
+        rb[s] = (lrb >> (8 * s)) & 0xffu;
         tbase = (unsigned)insert_zero(tbase, (int)rb[s]);
     }
 
@@ -233,40 +331,52 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, 
 
     const uint64_t tile_global = tile;  // global index bits fixed for this workgroup (outside the tile)
 
-    for (int r = 0; r < p.nrounds; ++r) {
-        const DqFusedRound& rd = p.rounds[r];
+    // The descriptor is read as 32-bit words (scalar loads; gfx950 has no sub-dword s_load) and decoded
+    // with SALU bit ops, so no vector memory instruction is spent on it.
+    const uint32_t* pw = reinterpret_cast<const uint32_t*>(&p);
+    constexpr int ROUND_W0 = offsetof(DqFusedPass, rounds) / 4;
+    constexpr int GATE_W0 = offsetof(DqFusedPass, gates) / 4;
+    const int nrounds = (int)(pw[0] >> 24);
+    for (int r = 0; r < nrounds; ++r) {
+        const uint32_t rw0 = pw[ROUND_W0 + 4 * r], rw1 = pw[ROUND_W0 + 4 * r + 1], rw2 = pw[ROUND_W0 + 4 * r + 2],
+                       rw3 = pw[ROUND_W0 + 4 * r + 3];
         unsigned nrb[R];
         bool same = true;
 #pragma unroll
         for (int s = 0; s < R; ++s) {
-            nrb[s] = rd.rb[s];
+            nrb[s] = (rw0 >> (8 * s)) & 0xffu;
             same = same && (nrb[s] == rb[s]);
         }
         unsigned ntbase = 0;
 #pragma unroll
-        for (int i = 0; i < LOGT; ++i) ntbase |= ((tid >> i) & 1u) << rd.tb[i];
-        if (!same || ntbase != tbase) {
-            // NB: `same` is uniform; a differing thread order with identical slots also needs the trip.
-            transpose_to(nrb, ntbase);
+        for (int i = 0; i < LOGT; ++i) {
+            const uint32_t w = i < 4 ? rw1 : (i < 8 ? rw2 : rw3);
+            ntbase |= ((tid >> i) & 1u) << ((w >> (8 * (i & 3))) & 0xffu);
         }
-        for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
-            const DqFusedGate& g = p.gates[gi];
-            if ((tile_global & g.out_cmask) != g.out_cmask) continue;  // uniform: control outside tile is 0
-            const bool thr_ok = (tbase & g.thr_cmask) == g.thr_cmask;
-            const V* mp = mbase + g.mat;
-            switch (g.kind) {
-                case DQ_FG_GEN1: dispatch_gen1<T, R>(a, g.q, mp, g.reg_cmask, thr_ok); break;
-                case DQ_FG_X1: dispatch_x1<T, R>(a, g.q, g.reg_cmask, thr_ok); break;
-                case DQ_FG_GEN2: dispatch_gen2<T, R>(a, g.q, g.q2, mp, g.reg_cmask, thr_ok); break;
+        if (!same || ntbase != tbase) transpose_to(nrb, ntbase);
+        const int gbeg = (int)((rw3 >> 16) & 0xffu), gend = (int)(rw3 >> 24);
+        for (int gi = gbeg; gi < gend; ++gi) {
+            const uint32_t* gw = pw + GATE_W0 + 6 * gi;
+            const uint32_t g0 = gw[0], g1 = gw[1], gmat = gw[2];
+            const uint64_t out_cmask = (uint64_t)gw[4] | ((uint64_t)gw[5] << 32);
+            if ((tile_global & out_cmask) != out_cmask) continue;  // uniform: a control outside the tile is 0
+            const unsigned kind = g0 & 0xffu, q = (g0 >> 8) & 0xffu, q2 = (g0 >> 16) & 0xffu, loc = g0 >> 24;
+            const unsigned loc2 = g1 & 0xffu, reg_cmask = (g1 >> 8) & 0xffu, thr_cmask = g1 >> 16;
+            const bool thr_ok = (tbase & thr_cmask) == thr_cmask;
+            const V* mp = mbase + gmat;
+            switch (kind) {
+                case DQ_FG_GEN1: dispatch_gen1<T, R>(a, q, mp, reg_cmask, (reg_cmask | thr_cmask) != 0, thr_ok); break;
+                case DQ_FG_X1: dispatch_x1<T, R>(a, q, reg_cmask, thr_cmask != 0, thr_ok); break;
+                case DQ_FG_GEN2: dispatch_gen2<T, R>(a, q, q2, mp, reg_cmask, thr_ok); break;
                 case DQ_FG_DIAG1: {
                     const V d0 = mp[0], d1 = mp[3];
                     int fixed = -1;  // target bit value when it is not a register slot
-                    if (g.loc == DQ_LOC_THR) fixed = (tbase >> g.q) & 1u;
-                    else if (g.loc == DQ_LOC_OUT) fixed = (int)((tile_global >> g.q) & 1ull);
+                    if (loc == DQ_LOC_THR) fixed = (tbase >> q) & 1u;
+                    else if (loc == DQ_LOC_OUT) fixed = (int)((tile_global >> q) & 1ull);
 #pragma unroll
                     for (int j = 0; j < NA; ++j) {
-                        if (thr_ok && ((j & g.reg_cmask) == g.reg_cmask)) {
-                            const int bit = (fixed >= 0) ? fixed : ((j >> g.q) & 1);
+                        if (thr_ok && ((j & reg_cmask) == reg_cmask)) {
+                            const int bit = (fixed >= 0) ? fixed : ((j >> q) & 1);
                             a[j] = cmul(bit ? d1 : d0, a[j]);
                         }
                     }
@@ -275,15 +385,15 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, 
                 default: {  // DQ_FG_DIAG2: index = bit(target1) * 2 + bit(target2)
                     const V d0 = mp[0], d1 = mp[5], d2 = mp[10], d3 = mp[15];
                     int f1 = -1, f2 = -1;
-                    if (g.loc == DQ_LOC_THR) f1 = (tbase >> g.q) & 1u;
-                    else if (g.loc == DQ_LOC_OUT) f1 = (int)((tile_global >> g.q) & 1ull);
-                    if (g.loc2 == DQ_LOC_THR) f2 = (tbase >> g.q2) & 1u;
-                    else if (g.loc2 == DQ_LOC_OUT) f2 = (int)((tile_global >> g.q2) & 1ull);
+                    if (loc == DQ_LOC_THR) f1 = (tbase >> q) & 1u;
+                    else if (loc == DQ_LOC_OUT) f1 = (int)((tile_global >> q) & 1ull);
+                    if (loc2 == DQ_LOC_THR) f2 = (tbase >> q2) & 1u;
+                    else if (loc2 == DQ_LOC_OUT) f2 = (int)((tile_global >> q2) & 1ull);
 #pragma unroll
                     for (int j = 0; j < NA; ++j) {
-                        if (thr_ok && ((j & g.reg_cmask) == g.reg_cmask)) {
-                            const int b1 = (f1 >= 0) ? f1 : ((j >> g.q) & 1);
-                            const int b2 = (f2 >= 0) ? f2 : ((j >> g.q2) & 1);
+                        if (thr_ok && ((j & reg_cmask) == reg_cmask)) {
+                            const int b1 = (f1 >= 0) ? f1 : ((j >> q) & 1);
+                            const int b2 = (f2 >= 0) ? f2 : ((j >> q2) & 1);
                             const V ph = b1 ? (b2 ? d3 : d2) : (b2 ? d1 : d0);
                             a[j] = cmul(ph, a[j]);
                         }
@@ -300,7 +410,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, 
         bool same = true;
 #pragma unroll
         for (int s = 0; s < R; ++s) {
-            srb[s] = p.store_rb[s];
+            srb[s] = (srbw >> (8 * s)) & 0xffu;
             stbase = (unsigned)insert_zero(stbase, (int)srb[s]);
             same = same && (srb[s] == rb[s]);
         }

@@ -104,10 +104,14 @@ def test_fused_batched_matrices_and_out_of_place(is128):
     ops, mats0 = random_ops(n, 40, 11, kinds=('gen', 'x', 'diag', 'gen2'))
     per_sample = []
     for i in range(b):
-        _, mi = random_ops(n, 40, 11, kinds=('gen', 'x', 'diag', 'gen2'))
         g = torch.Generator().manual_seed(i)
-        # same structure, different unitaries per sample: right-multiply each gate matrix by a phase
-        per_sample.append(mi * torch.exp(1j * torch.rand(1, generator=g, dtype=torch.float64) * 3))
+        mi = mats0.clone()
+        # same structure, different unitaries per sample: scale every non-permutation matrix by a phase
+        for op in ops:
+            if op.kind != 'x':
+                d2 = (1 << op.k) ** 2
+                mi[op.mat : op.mat + d2] *= torch.exp(1j * torch.rand(1, generator=g, dtype=torch.float64) * 3)
+        per_sample.append(mi)
     mats = torch.stack(per_sample).to(dtype)
     steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
     x = rand_state(b, n, dtype, 5)

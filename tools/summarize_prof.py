@@ -1,0 +1,39 @@
+"""Summarise the rocprofv3 output of tools/profile.sh: per-kernel time from --stats, per-kernel counter
+averages from the --pmc passes, HBM bytes per launch (FETCH_SIZE doubled on gfx950, see
+MI355X_MICROARCH.md section HBM)."""
+import csv, glob, os, sys, collections
+
+root = sys.argv[1]
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(root, pattern), recursive=True))
+
+print('# kernel stats (rocprofv3 --kernel-trace --stats)')
+for f in find('trace/**/*kernel_stats.csv'):
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:8]:
+        print('  %-70s calls %6s  total %12s ns  avg %12s ns  %6s%%' % (r['Name'][:70], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage']))
+
+def counters(sub):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in find(sub + '/**/*counter_collection.csv'):
+        for r in csv.DictReader(open(f)):
+            acc[r['Kernel_Name'].split('(')[0][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
+    return acc
+
+for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq1', 'pmc_sq2'):
+    acc = counters(sub)
+    print('# counters:', sub)
+    for k, d in acc.items():
+        if 'fused' not in k:
+            continue
+        for c, v in d.items():
+            print('  %-55s %-22s launches %5d  mean/launch %.4g' % (k, c, len(v), sum(v) / len(v)))
+
+f = counters('pmc_fetch'); w = counters('pmc_write')
+for k in f:
+    if 'fused' in k and k in w:
+        fs = f[k]['FETCH_SIZE']; ws = w[k]['WRITE_SIZE']
+        fb = sum(fs) / len(fs) * 1024 * 2   # KiB -> bytes, x2 gfx950 correction for 16 B/lane streams
+        wb = sum(ws) / len(ws) * 1024
+        print('# HBM bytes per launch %s: read %.4g (FETCH_SIZE x2 corrected) + write %.4g = %.4g' % (k, fb, wb, fb + wb))
