@@ -18,7 +18,9 @@ import torch.distributed as dist
 from torch.autograd import Function
 
 from . import backend
-from .distributed import _one_target_global, _rank_controls_ok, dist_apply_prims, inner_product_dist
+from .distributed import (
+    _many_target_global, _one_target_global, _rank_controls_ok, dist_apply_prims, inner_product_dist,
+)
 from .executor import Prim
 from .gate import CombinedSingleGate
 from .state import DistributedQubitState
@@ -50,9 +52,25 @@ def _bracket(lam: DistributedQubitState, phi: DistributedQubitState, gate, dmat:
         else:
             val = torch.zeros((), dtype=torch.complex128, device=phi.amps.device)
     else:
-        assert len(targets) == 1, 'derivative of a multi-qubit gate on global qubits is not supported yet'
+        # a target lives on a global qubit: build mu = dU phi through the exchange path
         mu = deepcopy(phi)
-        _one_target_global(mu, Prim('gen', dmat.to(mu.amps.dtype), tuple(targets), tuple(controls)), derivative=True)
+        prim = Prim('gen', dmat.to(mu.amps.dtype), tuple(targets), tuple(controls))
+        if len(targets) == 1:
+            _one_target_global(mu, prim, derivative=True)
+        else:
+            _many_target_global(mu, prim)
+            # dU acts as ZERO (not identity) outside the controlled subspace
+            if not _rank_controls_ok(mu, controls):
+                mu.amps.zero_()
+            else:
+                mask = 0
+                for c in controls:
+                    if c < L:
+                        mask |= 1 << c
+                if mask:
+                    keep = backend.pack(mu.amps.view(1, -1), mask, mask)
+                    mu.amps.zero_()
+                    backend.unpack_axpby(mu.amps.view(1, -1), keep, None, None, mask, mask)
         val = backend.inner(lam.amps.view(1, -1), mu.amps.view(1, -1))[0]
     if phi.world_size > 1:
         buf = torch.view_as_real(val.clone())
@@ -83,7 +101,7 @@ class AdjointExpectation(Function):
                 dist_apply_prims(phi, inv_prims)
                 if gate.npara > 0:
                     p = params[-idx]
-                    if ctx.needs_input_grad[2 + len(params) - idx]:
+                    if ctx.needs_input_grad[3 + len(params) - idx]:
                         with torch.enable_grad():
                             du = gate.get_derivative(p.detach())
                         du = du.unsqueeze(0).flatten(0, -3)  # (npara, D, D)

@@ -1,0 +1,173 @@
+"""Circuit / gate specifications shared by the golden-vector generator (which drives the real reference)
+and by the tests (which drive deepquantum_amd).  A spec is a list of (builder method, args, kwargs)
+applied to a ``QubitCircuit``: both libraries expose the same builder API, which is the point."""
+
+import math
+import random
+
+import torch
+
+
+def random_spec(n, depth, seed):
+    """SURVEY.md section 8(d) generator: per layer, per qubit: 1/3 H, 1/3 Rx(U(0, 2pi)), 1/3 CNOT."""
+    rng = random.Random(seed)
+    spec = []
+    for _ in range(depth):
+        for q in range(n):
+            r = rng.random()
+            if r < 1 / 3:
+                spec.append(('h', [q], {}))
+            elif r < 2 / 3:
+                spec.append(('rx', [q, rng.uniform(0, 2 * math.pi)], {}))
+            else:
+                t = rng.randrange(n - 1)
+                t += t >= q
+                spec.append(('cnot', [q, t], {}))
+    return spec
+
+
+def build(dq, n, spec, **circuit_kwargs):
+    cir = dq.QubitCircuit(n, **circuit_kwargs)
+    for method, args, kwargs in spec:
+        getattr(cir, method)(*args, **kwargs)
+    return cir
+
+
+def _unitary(k, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(2**k, 2**k, generator=g, dtype=torch.float64) + 1j * torch.randn(2**k, 2**k, generator=g, dtype=torch.float64)
+    q, _ = torch.linalg.qr(a)
+    return q.to(torch.complex64)
+
+
+ZOO5 = [
+    ('hlayer', [], {}),
+    ('u3', [0, [0.3, 1.1, -0.4]], {}),
+    ('p', [1, 0.7], {}),
+    ('x', [2], {}), ('y', [3], {}), ('z', [4], {}),
+    ('s', [0], {}), ('sdg', [1], {}), ('t', [2], {}), ('tdg', [3], {}),
+    ('ry', [4, 0.9], {}), ('rz', [0, -1.3], {}), ('rx', [1, 2.2], {}),
+    ('cx', [0, 3], {}), ('cy', [4, 1], {}), ('cz', [2, 0], {}), ('cnot', [3, 4], {}),
+    ('swap', [[0, 4]], {}), ('iswap', [[1, 3]], {}),
+    ('rxx', [[0, 2], 0.6], {}), ('ryy', [[3, 1], -0.8], {}), ('rzz', [[4, 2], 1.7], {}),
+    ('rxy', [[2, 3], 0.45], {}), ('rbs', [[0, 1], 0.35], {}),
+    ('toffoli', [0, 1, 2], {}), ('ccx', [4, 2, 3], {}), ('fredkin', [2, 0, 4], {}), ('cswap', [1, 3, 0], {}),
+    ('crx', [0, 2, 0.5], {}), ('cry', [3, 1, 1.5], {}), ('crz', [4, 0, -0.6], {}),
+    ('ch', [1, 4], {}), ('cs', [2, 3], {}), ('ct', [0, 1], {}), ('cp', [3, 0, 0.9], {}), ('cu', [2, 4, [0.2, 0.4, 0.6]], {}),
+    ('crxx', [0, 1, 2, 0.3], {}), ('cryy', [4, 3, 2, 0.7], {}), ('crzz', [1, 0, 4, 1.1], {}), ('crxy', [2, 4, 3, 0.25], {}),
+    ('rx', [2, 0.8], {'controls': [0, 4]}), ('h', [3], {'controls': [1, 2]}), ('p', [4, 0.3], {'controls': [0, 1, 2]}),
+    ('swap', [[1, 2]], {'controls': [3, 4]}),
+    ('rxlayer', [], {'inputs': [0.1, 0.2, 0.3, 0.4, 0.5]}),
+    ('rylayer', [[0, 2, 4]], {'inputs': [1.0, 1.1, 1.2]}),
+    ('rzlayer', [[1, 3]], {'inputs': [-0.5, 0.5]}),
+    ('u3layer', [[0, 1]], {'inputs': [0.1, 0.2, 0.3, 0.4, 0.5, 0.6]}),
+    ('cnot_ring', [], {}), ('cnot_ring', [], {'minmax': [1, 4], 'step': 2, 'reverse': True}),
+    ('xlayer', [[0, 3]], {}), ('ylayer', [[1]], {}), ('zlayer', [[2, 4]], {}),
+    ('any', [_unitary(1, 1)], {'wires': [3]}),
+    ('any', [_unitary(2, 2)], {'wires': [4, 1]}),
+    ('any', [_unitary(3, 3)], {'wires': [2, 0, 3]}),
+    ('cxlayer', [[[0, 1], [2, 3]]], {}),
+]
+
+BATCHED10 = (
+    [('hlayer', [], {})]
+    + [('rx', [q], {'encode': True}) for q in range(0, 10, 2)]
+    + [('cnot', [q, (q + 3) % 10], {}) for q in range(10)]
+    + [('ry', [q], {'encode': True}) for q in range(1, 10, 3)]
+    + [('u3', [4], {'encode': True}), ('rzz', [[2, 7]], {'encode': True}), ('rz', [9], {'encode': True})]
+    + [('cz', [0, 9], {}), ('toffoli', [1, 5, 8], {}), ('rx', [6, 0.77], {})]
+    + [('crx', [3, 6], {'encode': True}), ('p', [0], {'encode': True})]
+)
+_NDATA10 = 5 + 3 + 3 + 1 + 1 + 1 + 1
+_g = torch.Generator().manual_seed(21)
+_DATA10 = (torch.rand(4, _NDATA10, generator=_g, dtype=torch.float64) * 6).tolist()
+
+CIRCUITS = {
+    'readme': {
+        'nqubit': 2,
+        'spec': [('h', [0], {}), ('cnot', [0, 1], {}), ('rx', [1, 0.2], {})],
+        'observables': [([0], 'z')],
+    },
+    'zoo5': {'nqubit': 5, 'spec': ZOO5, 'observables': [([0], 'z'), ([1, 2], 'xy'), ([4, 3, 0], 'zyx')],
+             'marginal': [0, 2], 'unitary': True},
+    'batched10': {'nqubit': 10, 'spec': BATCHED10, 'data': _DATA10,
+                  'observables': [([0], 'z'), ([3, 8], 'xx'), ([5], 'y')], 'marginal': [1, 4, 9]},
+}
+for _n in (4, 8, 12, 16):
+    CIRCUITS[f'rand{_n}'] = {
+        'nqubit': _n, 'spec': random_spec(_n, 20, 100 + _n),
+        'observables': [([0], 'z'), ([1, 2], 'xy')], 'marginal': [0, 2], 'unitary': _n <= 4,
+    }
+CIRCUITS['rand14_seed1234'] = {'nqubit': 14, 'spec': random_spec(14, 40, 1234), 'observables': [([0], 'z')]}
+
+# ---- F2: gate classes ------------------------------------------------------------------------------------
+GATE_CASES = []
+for cls in ('PauliX', 'PauliY', 'PauliZ', 'Hadamard', 'SGate', 'SDaggerGate', 'TGate', 'TDaggerGate'):
+    for w in range(3):
+        GATE_CASES.append({'cls': cls, 'nqubit': 3, 'kwargs': {'wires': [w]}})
+    GATE_CASES.append({'cls': cls, 'nqubit': 4, 'kwargs': {'wires': [2], 'controls': [0]}})
+    GATE_CASES.append({'cls': cls, 'nqubit': 4, 'kwargs': {'wires': [0], 'controls': [3, 1]}, 'inverse': True})
+for cls, val in (('Rx', 0.37), ('Ry', -1.2), ('Rz', 2.5), ('PhaseShift', 0.81)):
+    for w in range(3):
+        GATE_CASES.append({'cls': cls, 'nqubit': 3, 'kwargs': {'wires': [w], 'inputs': val}})
+    GATE_CASES.append({'cls': cls, 'nqubit': 4, 'kwargs': {'wires': [1], 'controls': [3], 'inputs': val}})
+    GATE_CASES.append({'cls': cls, 'nqubit': 4, 'kwargs': {'wires': [3], 'controls': [0, 2], 'inputs': val}, 'inverse': True})
+GATE_CASES.append({'cls': 'U3Gate', 'nqubit': 3, 'kwargs': {'wires': [1], 'inputs': [0.4, 1.3, -2.1]}})
+GATE_CASES.append({'cls': 'U3Gate', 'nqubit': 3, 'kwargs': {'wires': [2], 'controls': [0], 'inputs': [1.4, 0.3, 0.1]}, 'inverse': True})
+for plane in ('xy', 'yz', 'zx'):
+    GATE_CASES.append({'cls': 'ProjectionJ', 'nqubit': 2, 'kwargs': {'wires': [1], 'inputs': 0.6, 'plane': plane}})
+for cls in ('CNOT', 'Swap', 'ImaginarySwap'):
+    for wires in ([0, 1], [2, 0], [1, 3]):
+        GATE_CASES.append({'cls': cls, 'nqubit': 4, 'kwargs': {'wires': wires}})
+GATE_CASES.append({'cls': 'Swap', 'nqubit': 4, 'kwargs': {'wires': [3, 0], 'controls': [1]}})
+for cls, val in (('Rxx', 0.9), ('Ryy', -0.4), ('Rzz', 1.6), ('Rxy', 0.7), ('ReconfigurableBeamSplitter', 0.33)):
+    for wires in ([0, 1], [3, 1]):
+        GATE_CASES.append({'cls': cls, 'nqubit': 4, 'kwargs': {'wires': wires, 'inputs': val}})
+    GATE_CASES.append({'cls': cls, 'nqubit': 4, 'kwargs': {'wires': [2, 0], 'controls': [3], 'inputs': val}, 'inverse': True})
+for wires in ([0, 1, 2], [3, 0, 2], [2, 4, 1]):
+    GATE_CASES.append({'cls': 'Toffoli', 'nqubit': 5, 'kwargs': {'wires': wires}})
+    GATE_CASES.append({'cls': 'Fredkin', 'nqubit': 5, 'kwargs': {'wires': wires}})
+GATE_CASES.append({'cls': 'UAnyGate', 'nqubit': 4, 'kwargs': {'unitary': _unitary(2, 9), 'wires': [3, 1]}})
+GATE_CASES.append({'cls': 'UAnyGate', 'nqubit': 5, 'kwargs': {'unitary': _unitary(3, 10), 'minmax': [1, 3]}, 'inverse': True})
+GATE_CASES.append({'cls': 'UAnyGate', 'nqubit': 6, 'kwargs': {'unitary': _unitary(5, 11), 'wires': [5, 0, 3, 1, 4]}})
+GATE_CASES.append({'cls': 'UAnyGate', 'nqubit': 4, 'kwargs': {'unitary': _unitary(1, 12), 'wires': [2], 'controls': [0, 3]}})
+# NB: a controlled UAnyGate is checked through forward only -- the reference's ArbitraryGate.get_unitary
+# (gate.py:318-330) ignores `controls`, so its get_unitary disagrees with its own forward for such gates.
+GATE_CASES.append({'cls': 'UAnyGate', 'nqubit': 5, 'kwargs': {'unitary': _unitary(2, 4), 'minmax': [1, 2], 'controls': [4]}})
+
+
+# ---- F5: circuits with data inputs and trainable parameters ----------------------------------------------
+def grad_circuit_a(dq, n):
+    """Encoders (data) + trainable gates + controlled parametric gates + 2-qubit parametric gates."""
+    cir = dq.QubitCircuit(n)
+    cir.hlayer()
+    cir.rx(0, encode=True)
+    cir.ry(1, encode=True)
+    cir.rz(2, encode=True)
+    cir.cnot_ring()
+    cir.rxlayer()                      # trainable
+    cir.crx(0, 3, encode=True)
+    cir.rzz([1, 2], encode=True)
+    cir.u3(3)                          # trainable
+    cir.ryy([0, 2])                    # trainable
+    cir.toffoli(0, 1, 3)
+    cir.ry(2, controls=[0, 1])         # trainable, two controls
+    cir.observable(0)
+    cir.observable([1, 2], 'xy')
+    cir.observable([3], 'x')
+    return cir
+
+
+def qaoa_circuit(dq, n):
+    """Ring MaxCut QAOA layer in the style of the reference's examples/qaoa.py: data = (gamma, beta)."""
+    cir = dq.QubitCircuit(n, reupload=True)
+    cir.hlayer()
+    edges = [(i, (i + 1) % n) for i in range(n)]
+    for i, j in edges:
+        cir.cnot(i, j)
+        cir.rz(j, encode=True)
+        cir.cnot(i, j)
+    cir.rxlayer(encode=True)
+    for i, j in edges:
+        cir.observable([i, j], 'zz')
+    return cir

@@ -1,0 +1,172 @@
+"""Host-side API (gate library, layers, circuit driver, batching, autograd glue, dtype plumbing) against the
+golden vectors of the real reference, with the kernels replaced by the oracle-backed CPU test double.
+These tests validate everything above the C ABI without a GPU; tests/test_circuit_gpu.py repeats them
+through the HIP kernels."""
+
+import pytest
+import torch
+
+import deepquantum_amd as dq
+from _helpers import CDTYPE, TOL, check_circuit_against_golden, gold, specs
+
+
+@pytest.mark.parametrize('name', ['readme', 'zoo5', 'rand4', 'rand8', 'rand12', 'batched10'])
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+def test_circuits_match_reference(cpu_backend, name, prec):
+    check_circuit_against_golden(dq, name, prec)
+
+
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+def test_fused_path_used_for_large_states(cpu_backend, prec):
+    check_circuit_against_golden(dq, 'rand14_seed1234', prec)
+    assert cpu_backend.fused_calls > 0 and dq.executor.LAST_RUN['passes'] > 0
+    assert dq.executor.LAST_RUN['passes'] < dq.executor.LAST_RUN['gates'] / 8
+
+
+def test_gate_classes_match_reference(cpu_backend):
+    for i, case in enumerate(specs.GATE_CASES):
+        cls = getattr(dq, case['cls'])
+        gate = cls(nqubit=case['nqubit'], **case['kwargs'])
+        if case.get('inverse'):
+            gate = gate.inverse()
+        gate = gate.to(torch.double)
+        m = gate.update_matrix()
+        assert (m - gold(f'gate/{i}/matrix')).abs().max().item() == 0.0, (i, case['cls'])  # bit-identical matrices
+        with torch.no_grad():
+            out = gate(gold(f'gate/{i}/in'))
+        ref = gold(f'gate/{i}/out')
+        assert out.shape == ref.shape
+        assert (out - ref).abs().max().item() < 1e-12, (i, case['cls'])
+
+
+def _grad_check(builder, tag, nqubit):
+    cir = builder(dq, nqubit)
+    params = gold(f'grad/{tag}/params')
+    off = 0
+    with torch.no_grad():
+        for p in cir.parameters():
+            p.copy_(params[off : off + p.numel()].reshape(p.shape))
+            off += p.numel()
+    assert off == params.numel()
+    data = gold(f'grad/{tag}/data').clone().requires_grad_(True)
+    cir(data)
+    ev = cir.expectation()
+    assert (ev - gold(f'grad/{tag}/expectation')).abs().max().item() < 1e-5
+    ev.sum().backward()
+    assert (data.grad - gold(f'grad/{tag}/data_grad')).abs().max().item() < 1e-4
+    if params.numel():
+        pg = torch.cat([p.grad.reshape(-1) for p in cir.parameters()])
+        assert (pg - gold(f'grad/{tag}/param_grads')).abs().max().item() < 1e-4
+
+
+def test_autograd_mixed_circuit(cpu_backend):
+    _grad_check(specs.grad_circuit_a, 'mixed', 4)
+
+
+def test_autograd_qaoa(cpu_backend):
+    _grad_check(specs.qaoa_circuit, 'qaoa', 7)
+
+
+def test_forward_shapes_follow_reference(cpu_backend):
+    cir = dq.QubitCircuit(3)
+    cir.h(0)
+    cir.rx(1, encode=True)
+    cir.cnot(0, 2)
+    cir.observable(0)
+    cir.observable(1, 'x')
+    assert cir(torch.tensor([0.3])).shape == (8, 1)
+    assert cir.expectation().shape == (2,)
+    assert cir(torch.tensor([[0.3], [0.4]])).shape == (2, 8, 1)
+    assert cir.expectation().shape == (2, 2)
+    batch_state = torch.zeros(2, 8, 1, dtype=torch.cfloat)
+    batch_state[:, 0] = 1
+    assert cir(torch.tensor([0.3]), state=batch_state).shape == (2, 8, 1)
+    assert cir(torch.tensor([[0.3], [0.4]]), state=batch_state).shape == (2, 8, 1)
+    # after a batched call the encoders hold the last sample again (reference: circuit.py:241)
+    assert cir.encoders[0].theta.numel() == 1
+
+
+def test_gate_forward_representations(cpu_backend):
+    g = dq.Hadamard(nqubit=2, wires=[1])
+    x = torch.tensor([1, 0, 0, 0], dtype=torch.cfloat)
+    assert g(x).shape == (4, 1)
+    assert g(x.reshape(1, 4, 1).repeat(3, 1, 1)).shape == (3, 4, 1)
+    g.tsr_mode = True
+    assert g(x.reshape(1, 2, 2)).shape == (1, 2, 2)
+
+
+def test_to_double_promotes_complex_buffers(cpu_backend):
+    cir = dq.QubitCircuit(2)
+    cir.h(0)
+    cir.rx(1, 0.3)
+    cir.cnot(0, 1)
+    cir.to(torch.double)
+    assert cir.init_state.state.dtype == torch.complex128
+    assert cir.operators[0].matrix.dtype == torch.complex128
+    assert cir.operators[1].theta.dtype == torch.float64
+    assert cir().dtype == torch.complex128
+    # H keeps its float32-rounded entries (parity with the reference, SURVEY summary item 3)
+    assert cir.operators[0].matrix[0, 0].real.item() == 0.7071067690849304
+
+
+def test_inverse_circuit_returns_initial_state(cpu_backend):
+    c = specs.CIRCUITS['rand8']
+    cir = specs.build(dq, 8, c['spec'] + [('u3', [3, [0.3, 0.2, 0.1]], {}), ('rzz', [[1, 6], 0.4], {}), ('s', [2], {}), ('t', [5], {})])
+    cir.to(torch.double)
+    full = cir + cir.inverse()
+    out = full()
+    ref = torch.zeros(256, 1, dtype=torch.complex128)
+    ref[0] = 1
+    assert (out - ref).abs().max().item() < 1e-5  # float32-rounded constants are not exactly unitary
+
+
+def test_measure_and_amplitudes(cpu_backend):
+    cir = dq.QubitCircuit(3)
+    cir.h(0)
+    cir.cnot(0, 1)
+    cir.cnot(1, 2)
+    cir()
+    res = cir.measure(shots=200)
+    assert set(res) <= {'000', '111'} and sum(res.values()) == 200
+    assert abs(cir.get_prob('111').item() - 0.5) < 1e-6
+    assert abs(cir.get_prob('1', wires=[2]).item() - 0.5) < 1e-6
+    assert abs(cir.get_amplitude('000').abs().item() - 0.5**0.5) < 1e-6
+    res = cir.measure(shots=50, wires=[0, 2], with_prob=True)
+    assert set(res) <= {'00', '11'}
+
+
+def test_expectation_with_shots(cpu_backend):
+    cir = dq.QubitCircuit(2)
+    cir.x(0)
+    cir.observable(0)
+    cir.observable(1, 'z')
+    cir()
+    ev = cir.expectation(shots=100)
+    assert torch.allclose(ev, torch.tensor([-1.0, 1.0]))
+
+
+def test_cpu_tensors_without_test_backend_fail_loudly():
+    cir = dq.QubitCircuit(2)
+    cir.h(0)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        cir()
+
+
+def test_out_of_scope_paths_raise():
+    with pytest.raises(NotImplementedError):
+        dq.QubitCircuit(2, den_mat=True)
+    with pytest.raises(NotImplementedError):
+        dq.QubitCircuit(2, mps=True)
+    with pytest.raises(NotImplementedError):
+        dq.QubitCircuit(2).qasm()
+
+
+def test_reupload_encoding(cpu_backend):
+    cir = dq.QubitCircuit(2, reupload=True)
+    for _ in range(3):
+        cir.rx(0, encode=True)
+        cir.ry(1, encode=True)
+    data = torch.tensor([0.3, 0.5, 0.7, 0.9])
+    cir(data)
+    got = [g.theta.item() for g in cir.encoders]
+    assert got == pytest.approx([0.3, 0.5, 0.7, 0.9, 0.3, 0.5])
