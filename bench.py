@@ -186,9 +186,17 @@ def main():
     alg_per_launch = (alg_bytes * args.steps / launches) if launches else 0.0
     avg_ms = (sum(kernel_ms) / launches) if launches else float('nan')
     achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc runs of this same command,
+    # tools/profile.sh; committed under profiles/): only reported for the workload it was collected on.
     traffic = None
-    if args.traffic_json and os.path.exists(args.traffic_json):
-        traffic = json.load(open(args.traffic_json)).get('hbm_bytes_per_launch')
+    tj = args.traffic_json
+    if tj is None and not distributed:
+        import glob
+
+        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'traffic_n{n}_b{args.batch}_{args.dtype}.json')))
+        tj = cands[-1] if cands else None
+    if tj and os.path.exists(tj):
+        traffic = json.load(open(tj)).get('hbm_bytes_per_launch')
     stats = dict(dq.executor.LAST_RUN)
 
     if rank == 0:
