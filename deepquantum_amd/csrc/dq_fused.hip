@@ -22,7 +22,16 @@
 #include "dq_common.hpp"
 #include <stddef.h>
 
+#ifndef DQ_USE_ASM_BLOCKS
+#define DQ_USE_ASM_BLOCKS 1
+#endif
+
 namespace dq {
+
+// Amplitudes live in registers as 2-element native vectors: for complex64 that is one aligned 64-bit VGPR
+// pair, the operand shape of the packed VALU ops and of the tied inline-asm operands below.
+template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
+template <typename T> using amp = vec2<T>;
 
 // ---- gate bodies on the register file ---------------------------------------------------------------
 // MODE 0: general complex 2x2.  MODE 1: all four entries real (H, Ry, X, ...).  MODE 2: real diagonal,
@@ -31,18 +40,17 @@ namespace dq {
 // Packed formulation: an amplitude (re, im) is one 2-vector, so every line below is one packed VALU op on
 // gfx950 (v_pk_mul_f32 / v_pk_fma_f32 with op_sel / neg modifiers for the swizzled operand); for double
 // the same source scalarises to v_fma_f64.
-template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
 
 template <typename T, int MODE>
-__device__ __forceinline__ void apply2x2(cx<T>& x0, cx<T>& x1, const cx<T> m00, const cx<T> m01, const cx<T> m10,
-                                         const cx<T> m11) {
+__device__ __forceinline__ void apply2x2(amp<T>& x0, amp<T>& x1, const amp<T> m00, const amp<T> m01, const amp<T> m10,
+                                         const amp<T> m11) {
     using V2 = vec2<T>;
     const V2 a = {x0.x, x0.y}, b = {x1.x, x1.y};
     V2 r0, r1;
     if constexpr (MODE == 1) {
         // scalar source form: hipcc's SLP vectoriser turns each (x, y) pair into one packed op and keeps
         // the matrix entries as SGPR operands (32 packed VALU ops per 16 amplitudes, measured)
-        cx<T> n0, n1;
+        amp<T> n0, n1;
         n0.x = fma(m01.x, x1.x, m00.x * x0.x);
         n0.y = fma(m01.x, x1.y, m00.x * x0.y);
         n1.x = fma(m11.x, x1.x, m10.x * x0.x);
@@ -52,7 +60,7 @@ __device__ __forceinline__ void apply2x2(cx<T>& x0, cx<T>& x1, const cx<T> m00, 
         return;
     } else if constexpr (MODE == 2) {
         // i*y*(b.x + i b.y) = (-y b.y) + i (y b.x)
-        cx<T> n0, n1;
+        amp<T> n0, n1;
         n0.x = fma(-m01.y, x1.y, m00.x * x0.x);
         n0.y = fma(m01.y, x1.x, m00.x * x0.y);
         n1.x = fma(-m10.y, x0.y, m11.x * x1.x);
@@ -77,9 +85,32 @@ __device__ __forceinline__ void apply2x2(cx<T>& x0, cx<T>& x1, const cx<T> m00, 
     x1.y = r1.y;
 }
 
+// ---- complex64: straight-line inline-asm blocks (generated, csrc/dq_fused_asm.inc) -------------------
+// One asm statement per (matrix structure, target slot) updates all 16 register-resident amplitudes in
+// place: every amplitude is a tied "+v" 64-bit operand, matrix entries are SGPR pairs whose low half is
+// broadcast (op_sel_hi 0), the "times i" swizzle (-im, re) is op_sel:[1,..] op_sel_hi:[0,..] + neg_lo.
+// ms[] = {m00.re, m00.im, m01.re, m01.im, m10.re, m10.im, m11.re, m11.im} as 64-bit uniform values.
+template <int MODE, int Q> __device__ __forceinline__ void gen1_block_f32(vec2<float> (&a)[16], const uint64_t (&ms)[8]);
+template <int Q, int CMASK> __device__ __forceinline__ void x1_block_f32(vec2<float> (&a)[16]);
+#include "dq_fused_asm.inc"
+
+template <int MODE>
+__device__ __forceinline__ void dispatch_gen1_block_f32(vec2<float> (&a)[16], int q, const uint64_t (&ms)[8]) {
+    switch (q) {
+        case 0: gen1_block_f32<MODE, 0>(a, ms); break;
+        case 1: gen1_block_f32<MODE, 1>(a, ms); break;
+        case 2: gen1_block_f32<MODE, 2>(a, ms); break;
+        default: gen1_block_f32<MODE, 3>(a, ms); break;
+    }
+}
+
+__device__ __forceinline__ uint64_t uniform_f32(float v) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v));
+}
+
 template <typename T, int R, int Q, int MODE, bool PRED>
-__device__ __forceinline__ void gen1_body(cx<T> (&a)[1 << R], const cx<T> m00, const cx<T> m01, const cx<T> m10,
-                                          const cx<T> m11, const unsigned reg_cmask, const bool thr_ok) {
+__device__ __forceinline__ void gen1_body(amp<T> (&a)[1 << R], const amp<T> m00, const amp<T> m01, const amp<T> m10,
+                                          const amp<T> m11, const unsigned reg_cmask, const bool thr_ok) {
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j) {
         if ((j >> Q) & 1) continue;
@@ -91,23 +122,16 @@ __device__ __forceinline__ void gen1_body(cx<T> (&a)[1 << R], const cx<T> m00, c
     }
 }
 
-// Register swap through v_swap_b32: one VALU op per dword, and -- being an asm statement -- it keeps the
-// enclosing per-lane control an exec-masked branch instead of being if-converted into v_cndmask chains.
-__device__ __forceinline__ void swap_dword(float& a, float& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap_dword(double& a, double& b) {
-    int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
-    asm volatile("v_swap_b32 %0, %1" : "+v"(alo), "+v"(blo));
-    asm volatile("v_swap_b32 %0, %1" : "+v"(ahi), "+v"(bhi));
-    a = __hiloint2double(ahi, alo);
-    b = __hiloint2double(bhi, blo);
-}
+// Register swap (C++ path, used for complex128): plain moves; the enclosing control is uniform or an
+// exec-masked region.
 template <typename V> __device__ __forceinline__ void swap_amp(V& a, V& b) {
-    swap_dword(a.x, b.x);
-    swap_dword(a.y, b.y);
+    const V t = a;
+    a = b;
+    b = t;
 }
 
 template <typename T, int R, int Q>
-__device__ __forceinline__ void x1_body(cx<T> (&a)[1 << R], const unsigned reg_cmask) {
+__device__ __forceinline__ void x1_body(amp<T> (&a)[1 << R], const unsigned reg_cmask) {
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j) {
         if ((j >> Q) & 1) continue;
@@ -116,9 +140,9 @@ __device__ __forceinline__ void x1_body(cx<T> (&a)[1 << R], const unsigned reg_c
 }
 
 template <typename T, int R, int Q, int Q2>
-__device__ __forceinline__ void gen2_body(cx<T> (&a)[1 << R], const cx<T>* __restrict__ mp, const unsigned reg_cmask,
+__device__ __forceinline__ void gen2_body(amp<T> (&a)[1 << R], const amp<T>* __restrict__ mp, const unsigned reg_cmask,
                                           const bool thr_ok) {
-    cx<T> m[16];
+    amp<T> m[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) m[i] = mp[i];
 #pragma unroll
@@ -127,7 +151,7 @@ __device__ __forceinline__ void gen2_body(cx<T> (&a)[1 << R], const cx<T>* __res
         if (thr_ok && ((j & reg_cmask) == reg_cmask)) {
             // matrix index = (bit of slot Q) * 2 + (bit of slot Q2)
             const int i0 = j, i1 = j | (1 << Q2), i2 = j | (1 << Q), i3 = j | (1 << Q) | (1 << Q2);
-            const cx<T> x0 = a[i0], x1 = a[i1], x2 = a[i2], x3 = a[i3];
+            const amp<T> x0 = a[i0], x1 = a[i1], x2 = a[i2], x3 = a[i3];
             a[i0] = cfma(m[3], x3, cfma(m[2], x2, cfma(m[1], x1, cmul(m[0], x0))));
             a[i1] = cfma(m[7], x3, cfma(m[6], x2, cfma(m[5], x1, cmul(m[4], x0))));
             a[i2] = cfma(m[11], x3, cfma(m[10], x2, cfma(m[9], x1, cmul(m[8], x0))));
@@ -137,8 +161,8 @@ __device__ __forceinline__ void gen2_body(cx<T> (&a)[1 << R], const cx<T>* __res
 }
 
 template <typename T, int R, int MODE, bool PRED>
-__device__ __forceinline__ void dispatch_gen1_q(cx<T> (&a)[1 << R], int q, const cx<T> m00, const cx<T> m01,
-                                                const cx<T> m10, const cx<T> m11, unsigned reg_cmask, bool thr_ok) {
+__device__ __forceinline__ void dispatch_gen1_q(amp<T> (&a)[1 << R], int q, const amp<T> m00, const amp<T> m01,
+                                                const amp<T> m10, const amp<T> m11, unsigned reg_cmask, bool thr_ok) {
     switch (q) {
         case 0: gen1_body<T, R, 0, MODE, PRED>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
         case 1: gen1_body<T, R, 1, MODE, PRED>(a, m00, m01, m10, m11, reg_cmask, thr_ok); break;
@@ -150,36 +174,63 @@ __device__ __forceinline__ void dispatch_gen1_q(cx<T> (&a)[1 << R], int q, const
 }
 
 template <typename T, int R>
-__device__ __forceinline__ void dispatch_gen1(cx<T> (&a)[1 << R], int q, const cx<T>* __restrict__ mp,
-                                              unsigned reg_cmask, bool pred, bool thr_ok) {
-    const cx<T> m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+__device__ __forceinline__ void dispatch_gen1(amp<T> (&a)[1 << R], int q, const amp<T>* __restrict__ mp,
+                                              unsigned reg_cmask, bool lane_pred, bool thr_ok) {
+    const amp<T> m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
     const bool all_real = (m00.y == 0) & (m01.y == 0) & (m10.y == 0) & (m11.y == 0);
     const bool rx_like = (m00.y == 0) & (m11.y == 0) & (m01.x == 0) & (m10.x == 0);
-    if (pred) {  // controlled gate: one predicated general body (code size)
-        dispatch_gen1_q<T, R, 0, true>(a, q, m00, m01, m10, m11, reg_cmask, thr_ok);
-    } else if (all_real) {
-        dispatch_gen1_q<T, R, 1, false>(a, q, m00, m01, m10, m11, 0u, true);
-    } else if (rx_like) {
-        dispatch_gen1_q<T, R, 2, false>(a, q, m00, m01, m10, m11, 0u, true);
+    if constexpr (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS) {
+        if (reg_cmask == 0) {
+            // uncontrolled (or controlled only by thread / outside bits): straight-line asm block; a control
+            // on a thread bit is ONE exec-masked region around it (asm is never if-converted)
+            if (!lane_pred || thr_ok) {
+                const uint64_t ms[8] = {uniform_f32(m00.x), uniform_f32(m00.y), uniform_f32(m01.x), uniform_f32(m01.y),
+                                        uniform_f32(m10.x), uniform_f32(m10.y), uniform_f32(m11.x), uniform_f32(m11.y)};
+                if (all_real) dispatch_gen1_block_f32<1>(a, q, ms);
+                else if (rx_like) dispatch_gen1_block_f32<2>(a, q, ms);
+                else dispatch_gen1_block_f32<0>(a, q, ms);
+            }
+        } else {  // a control sits on a register slot: predicated C++ body (rare)
+            dispatch_gen1_q<T, R, 0, true>(a, q, m00, m01, m10, m11, reg_cmask, thr_ok);
+        }
     } else {
-        dispatch_gen1_q<T, R, 0, false>(a, q, m00, m01, m10, m11, 0u, true);
+        if (lane_pred || reg_cmask) {  // controlled gate: one predicated general body (code size)
+            dispatch_gen1_q<T, R, 0, true>(a, q, m00, m01, m10, m11, reg_cmask, thr_ok);
+        } else if (all_real) {
+            dispatch_gen1_q<T, R, 1, false>(a, q, m00, m01, m10, m11, 0u, true);
+        } else if (rx_like) {
+            dispatch_gen1_q<T, R, 2, false>(a, q, m00, m01, m10, m11, 0u, true);
+        } else {
+            dispatch_gen1_q<T, R, 0, false>(a, q, m00, m01, m10, m11, 0u, true);
+        }
     }
 }
 
 // X / CNOT / Toffoli.  Controls on register slots or outside the tile are uniform tests; only a control
 // on a thread bit makes the swap per-lane, and then it is one exec-masked region of v_swap_b32.
+template <int Q>
+__device__ __forceinline__ void dispatch_x1_block_f32(vec2<float> (&a)[16], unsigned cmask) {
+    switch (cmask) {  // cmask never contains bit Q (host guarantees target != control)
+        case 0: x1_block_f32<Q, 0>(a); break;
+#define DQ_X1_CASE(C) case C: if constexpr (!((C >> Q) & 1)) x1_block_f32<Q, C>(a); break;
+        DQ_X1_CASE(1) DQ_X1_CASE(2) DQ_X1_CASE(3) DQ_X1_CASE(4) DQ_X1_CASE(5) DQ_X1_CASE(6) DQ_X1_CASE(7)
+        DQ_X1_CASE(8) DQ_X1_CASE(9) DQ_X1_CASE(10) DQ_X1_CASE(11) DQ_X1_CASE(12) DQ_X1_CASE(13) DQ_X1_CASE(14)
+#undef DQ_X1_CASE
+        default: break;
+    }
+}
+
 template <typename T, int R>
-__device__ __forceinline__ void dispatch_x1(cx<T> (&a)[1 << R], int q, unsigned reg_cmask, bool lane_pred, bool thr_ok) {
-    if (!lane_pred) {
+__device__ __forceinline__ void dispatch_x1(amp<T> (&a)[1 << R], int q, unsigned reg_cmask, bool lane_pred, bool thr_ok) {
+    if (lane_pred && !thr_ok) return;  // per-lane control: exec-masked region around the swaps
+    if constexpr (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS) {
         switch (q) {
-            case 0: x1_body<T, R, 0>(a, reg_cmask); break;
-            case 1: x1_body<T, R, 1>(a, reg_cmask); break;
-            case 2: x1_body<T, R, 2>(a, reg_cmask); break;
-            default:
-                if constexpr (R > 3) x1_body<T, R, 3>(a, reg_cmask);
-                break;
+            case 0: dispatch_x1_block_f32<0>(a, reg_cmask); break;
+            case 1: dispatch_x1_block_f32<1>(a, reg_cmask); break;
+            case 2: dispatch_x1_block_f32<2>(a, reg_cmask); break;
+            default: dispatch_x1_block_f32<3>(a, reg_cmask); break;
         }
-    } else if (thr_ok) {
+    } else {
         switch (q) {
             case 0: x1_body<T, R, 0>(a, reg_cmask); break;
             case 1: x1_body<T, R, 1>(a, reg_cmask); break;
@@ -192,7 +243,7 @@ __device__ __forceinline__ void dispatch_x1(cx<T> (&a)[1 << R], int q, unsigned 
 }
 
 template <typename T, int R, int Q>
-__device__ __forceinline__ void dispatch_gen2_q2(cx<T> (&a)[1 << R], int q2, const cx<T>* __restrict__ mp,
+__device__ __forceinline__ void dispatch_gen2_q2(amp<T> (&a)[1 << R], int q2, const amp<T>* __restrict__ mp,
                                                  unsigned reg_cmask, bool thr_ok) {
     switch (q2) {
         case 0:
@@ -211,7 +262,7 @@ __device__ __forceinline__ void dispatch_gen2_q2(cx<T> (&a)[1 << R], int q2, con
 }
 
 template <typename T, int R>
-__device__ __forceinline__ void dispatch_gen2(cx<T> (&a)[1 << R], int q, int q2, const cx<T>* __restrict__ mp,
+__device__ __forceinline__ void dispatch_gen2(amp<T> (&a)[1 << R], int q, int q2, const amp<T>* __restrict__ mp,
                                               unsigned reg_cmask, bool thr_ok) {
     switch (q) {
         case 0: dispatch_gen2_q2<T, R, 0>(a, q2, mp, reg_cmask, thr_ok); break;
@@ -233,15 +284,14 @@ template <int ESZ> __device__ __forceinline__ unsigned lds_swz(unsigned e) {
 }
 
 template <typename T, int R, int LOGT>
-__global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, cx<T>* out,
-                                                               const cx<T>* __restrict__ mats, int64_t mat_bstride,
+__global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in, amp<T>* out,
+                                                               const amp<T>* __restrict__ mats, int64_t mat_bstride,
                                                                int n, const DqFusedPass p) {
     constexpr int M = R + LOGT;
     constexpr int NA = 1 << R;
     constexpr int VB = (sizeof(T) == 4) ? 1 : 0;  // low slots of the canonical layout (16 B per lane)
-    using V = cx<T>;
+    using V = amp<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char dq_smem[];
-    V* lds = reinterpret_cast<V*>(dq_smem);
 
     const unsigned tid = threadIdx.x;
     const uint32_t* hw = reinterpret_cast<const uint32_t*>(&p);
@@ -289,8 +339,8 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, 
                 for (int s = 1; s < R; ++s)
                     if ((j >> s) & 1) o += gs[s];
                 const float4 v = *reinterpret_cast<const float4*>(pin + o);
-                a[j] = mk<T>(v.x, v.y);
-                a[j + 1] = mk<T>(v.z, v.w);
+                a[j] = amp<T>{v.x, v.y};
+                a[j + 1] = amp<T>{v.z, v.w};
             }
         } else {
 #pragma unroll
@@ -304,6 +354,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, 
         }
     }
 
+    V* lds = reinterpret_cast<V*>(dq_smem);
     auto transpose_to = [&](const unsigned (&nrb)[R], const unsigned ntbase) __attribute__((always_inline)) {
         unsigned so[NA], sn[NA];
 #pragma unroll
@@ -365,7 +416,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const cx<T>* in, 
             const bool thr_ok = (tbase & thr_cmask) == thr_cmask;
             const V* mp = mbase + gmat;
             switch (kind) {
-                case DQ_FG_GEN1: dispatch_gen1<T, R>(a, q, mp, reg_cmask, (reg_cmask | thr_cmask) != 0, thr_ok); break;
+                case DQ_FG_GEN1: dispatch_gen1<T, R>(a, q, mp, reg_cmask, thr_cmask != 0, thr_ok); break;
                 case DQ_FG_X1: dispatch_x1<T, R>(a, q, reg_cmask, thr_cmask != 0, thr_ok); break;
                 case DQ_FG_GEN2: dispatch_gen2<T, R>(a, q, q2, mp, reg_cmask, thr_ok); break;
                 case DQ_FG_DIAG1: {
@@ -540,7 +591,7 @@ template <typename T, int R, int LOGT>
 static void launch_variant(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
                            const DqFusedPass* pass, hipStream_t s) {
     constexpr int M = R + LOGT;
-    const size_t lds_bytes = sizeof(cx<T>) << M;
+    const size_t lds_bytes = sizeof(amp<T>) << M;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_pass_kernel<T, R, LOGT>),
@@ -549,7 +600,7 @@ static void launch_variant(const void* in, void* out, const void* mats, int64_t 
     }
     dim3 grid((unsigned)(1ull << (n - M)), (unsigned)batch);
     hipLaunchKernelGGL((fused_pass_kernel<T, R, LOGT>), grid, dim3(1u << LOGT), lds_bytes, s,
-                       static_cast<const cx<T>*>(in), static_cast<cx<T>*>(out), static_cast<const cx<T>*>(mats),
+                       static_cast<const amp<T>*>(in), static_cast<amp<T>*>(out), static_cast<const amp<T>*>(mats),
                        mat_bstride, n, *pass);
 }
 
