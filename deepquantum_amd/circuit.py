@@ -128,6 +128,31 @@ class QubitCircuit(Operation):
             out.extend(op.prims(decompose))
         return out
 
+    def _precompute_matrices(self) -> list:
+        """Evaluate the matrices of all single-parameter gates of one class in ONE vectorised call
+        (identical element-wise arithmetic, hence bit-identical values) instead of a handful of tiny
+        device kernels per gate.  Returns the gates whose ``_precomputed`` must be cleared afterwards."""
+        groups: dict = {}
+        for op in self.operators:
+            if getattr(op, '_param_names', None) == ('theta',) and type(op).get_matrix is not None:
+                th = op.theta
+                key = (type(op), getattr(op, 'plane', None), th.dtype, th.device, th.numel())
+                groups.setdefault(key, []).append(op)
+        touched = []
+        for (cls, _plane, _dt, _dev, numel), gates in groups.items():
+            if len(gates) < 2:
+                continue
+            thetas = torch.stack([(-g.theta if g.inv_mode else g.theta).reshape(-1) for g in gates])  # (G, B)
+            mats = gates[0].get_matrix(thetas.reshape(-1))
+            d = mats.shape[-1]
+            mats = mats.reshape(len(gates), numel, d, d)
+            for i, g in enumerate(gates):
+                m = mats[i] if numel > 1 else mats[i, 0]
+                g.__dict__['_precomputed'] = m
+                g.__dict__['_matrix_cache'] = m.detach()
+                touched.append(g)
+        return touched
+
     def forward(self, data: torch.Tensor | None = None, state: Any = None) -> torch.Tensor:
         """Run the circuit.  ``data``: 1-D (one sample) or 2-D (batch) encoder inputs; ``state``:
         (2**n, 1) or (B, 2**n, 1) initial state (default: the circuit's ``init_state``).  Returns the
@@ -139,6 +164,7 @@ class QubitCircuit(Operation):
             state = state.state
         if self.ndata == 0:
             data = None
+        self.state = None  # release the previous result first: the caching allocator hands the block back
         if data is None or data.ndim == 1:
             out = self._forward_helper(data, state)
             if out.ndim == 2:
@@ -167,7 +193,12 @@ class QubitCircuit(Operation):
         if data is not None and data.ndim == 2 and flat.shape[0] != data.shape[0]:
             assert flat.shape[0] == 1, 'batch of data and batch of states differ'
             flat = flat.expand(data.shape[0], dim)
-        x = executor.run(flat, self.prims())
+        touched = self._precompute_matrices()
+        try:
+            x = executor.run(flat, self.prims())
+        finally:
+            for g in touched:
+                g.__dict__['_precomputed'] = None
         if x is flat or x.data_ptr() == state.data_ptr():
             x = x.clone()
         return self.vector_rep(x).squeeze(0)

@@ -142,19 +142,48 @@ class _Parametric:
             return torch.rand(1)[0] * 4 * torch.pi
         return _as_param_tensor(inputs)
 
+    # ``matrix`` is evaluated lazily: the reference recomputes it inside every ``init_para`` /
+    # ``update_matrix`` call (gate.py:395-415), i.e. a handful of tiny device kernels per gate per forward.
+    # Here ``init_para`` only stores the parameter; the circuit driver evaluates all gates of one class in
+    # a single vectorised call (``QubitCircuit._precompute_matrices``), and ``gate.matrix`` computes on
+    # demand when somebody reads it.
+    @property
+    def matrix(self) -> torch.Tensor:
+        m = self.__dict__.get('_matrix_cache')
+        if m is None:
+            self.update_matrix()
+            m = self.__dict__['_matrix_cache']
+        return m
+
+    @matrix.setter
+    def matrix(self, value: torch.Tensor) -> None:
+        self.__dict__['_matrix_cache'] = value
+
+    def _invalidate(self) -> None:
+        self.__dict__['_matrix_cache'] = None
+        self.__dict__['_precomputed'] = None
+
     def init_para(self, inputs: Any = None) -> None:
         theta = self.inputs_to_tensor(inputs)
         if self.requires_grad:
             self.theta = nn.Parameter(theta)
         else:
             self.register_buffer('theta', theta)
-        self.update_matrix()
+        self._invalidate()
 
     def update_matrix(self) -> torch.Tensor:
+        pre = self.__dict__.get('_precomputed')
+        if pre is not None:
+            return pre
         theta = -self.theta if self.inv_mode else self.theta
         matrix = self.get_matrix(theta)
         self.matrix = matrix.detach()
         return matrix
+
+    def _apply(self, fn: Any, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate()
+        return out
 
     def get_derivative(self, theta: Any) -> torch.Tensor:
         """dU/dtheta by differentiating the matrix builder (reference: gate.py:402-406)."""
@@ -165,6 +194,7 @@ class _Parametric:
     def inverse(self):
         gate = copy(self)
         gate.inv_mode = not self.inv_mode
+        gate._invalidate()
         return gate
 
     def extra_repr(self) -> str:
@@ -290,6 +320,9 @@ class U3Gate(ParametricSingleGate):
         return _mat([cos_t, -e_il * sin_t, e_ip * sin_t, e_ipl * cos_t], 2)
 
     def update_matrix(self) -> torch.Tensor:
+        pre = self.__dict__.get('_precomputed')
+        if pre is not None:
+            return pre
         if self.inv_mode:
             theta, phi, lambd = -self.theta, -self.lambd, -self.phi
         else:
@@ -314,7 +347,7 @@ class U3Gate(ParametricSingleGate):
                 setattr(self, name, nn.Parameter(val))
             else:
                 self.register_buffer(name, val)
-        self.update_matrix()
+        self._invalidate()
 
     def extra_repr(self) -> str:
         s = f'wires={self.wires}, npara=3'
