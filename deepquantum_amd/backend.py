@@ -306,3 +306,20 @@ def unpack_axpby(
     rc = fn(_ptr(amps), _ptr(x), _ptr(y), _ptr(coef), stride, nl, mask, value, amps.shape[0], _stream(amps))
     _lib.check(rc, 'dq_unpack_axpby')
     return amps
+
+
+def permute_bits(amps: torch.Tensor, src_of_dst: Sequence[int], out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[b, i] = amps[b, sigma(i)], sigma(i) = sum_p bit_p(i) << src_of_dst[p]: re-label the local qubits
+    (destination bit p takes the role of source bit src_of_dst[p]).  Out of place."""
+    nl = _nqubit(amps)
+    src_of_dst = [int(p) for p in src_of_dst]
+    if sorted(src_of_dst) != list(range(nl)):
+        raise ValueError('src_of_dst must be a permutation of the local bit positions')
+    if out is None:
+        out = torch.empty_like(amps)
+    if not _use_hip(amps):
+        return _test_backend.permute_bits(amps, src_of_dst, out)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_permute_bits_{_suffix(amps)}')
+    _lib.check(fn(_ptr(amps), _ptr(out), nl, _lib.int_array(src_of_dst), amps.shape[0], _stream(amps)), 'dq_permute_bits')
+    return out

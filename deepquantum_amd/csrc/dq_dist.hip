@@ -46,6 +46,58 @@ __global__ __launch_bounds__(256) void unpack_axpby_kernel(cx<T>* amps, const cx
     }
 }
 
+struct PermGeom {
+    int nl;
+    int src_of_dst[40];  // bit p of the destination index comes from bit src_of_dst[p] of the source index
+};
+
+// out[b, i] = in[b, sigma(i)], sigma(i) = sum_p bit_p(i) << src_of_dst[p]: a pure re-labelling of the
+// local qubits (one read + one write of the shard).  Used by the all-to-all qubit remap to move the bits
+// that are about to become rank bits to the top of the local index, so that every peer's chunk is one
+// contiguous slab, and to restore the canonical qubit order at the end.  Writes are fully coalesced;
+// reads are coalesced as long as the low bits map to low bits.
+template <typename T>
+__global__ __launch_bounds__(256) void permute_bits_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
+                                                            PermGeom g) {
+    const int64_t b = blockIdx.y;
+    const cx<T>* src = in + ((uint64_t)b << g.nl);
+    cx<T>* dst = out + ((uint64_t)b << g.nl);
+    const uint64_t count = 1ull << g.nl;
+    // identity prefix: the lowest bits that map to themselves can be copied as contiguous runs
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t sidx = 0;
+        for (int p = 0; p < g.nl; ++p) sidx |= ((i >> p) & 1ull) << g.src_of_dst[p];
+        dst[i] = src[sidx];
+    }
+}
+
+template <typename T>
+static int permute_impl(const void* in, void* out, int nl, const int* src_of_dst, int64_t batch, dq_stream_t stream) {
+    if (!in || !out || in == out || !src_of_dst || batch < 1 || batch > 65535 || nl < 0 || nl > 40) {
+        set_error("dq_permute_bits: bad argument (in == out is not allowed)");
+        return DQ_ERR_ARG;
+    }
+    PermGeom g;
+    g.nl = nl;
+    uint64_t seen = 0;
+    for (int p = 0; p < nl; ++p) {
+        const int sp = src_of_dst[p];
+        if (sp < 0 || sp >= nl || ((seen >> sp) & 1ull)) {
+            set_error("dq_permute_bits: src_of_dst is not a permutation of [0, %d)", nl);
+            return DQ_ERR_ARG;
+        }
+        seen |= 1ull << sp;
+        g.src_of_dst[p] = sp;
+    }
+    const uint64_t count = 1ull << nl;
+    uint64_t nb = (count + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(permute_bits_kernel<T>, dim3((unsigned)nb, (unsigned)batch), dim3(256), 0, as_stream(stream),
+                       static_cast<const cx<T>*>(in), static_cast<cx<T>*>(out), g);
+    return check_launch("dq_permute_bits");
+}
+
 static int make_geom(int nl, uint64_t mask, uint64_t value, MaskGeom& g, const char* who) {
     if (nl < 0 || nl > 40) {
         set_error("%s: nl=%d out of range", who, nl);
@@ -125,4 +177,12 @@ extern "C" int dq_unpack_axpby_c128(void* amps, const void* x, const void* y, co
                                     int64_t coef_batch_stride, int nl, uint64_t mask, uint64_t value, int64_t batch,
                                     dq_stream_t stream) {
     return dq::unpack_impl<double>(amps, x, y, coef, coef_batch_stride, nl, mask, value, batch, stream);
+}
+extern "C" int dq_permute_bits_c64(const void* in, void* out, int nl, const int* src_of_dst, int64_t batch,
+                                   dq_stream_t stream) {
+    return dq::permute_impl<float>(in, out, nl, src_of_dst, batch, stream);
+}
+extern "C" int dq_permute_bits_c128(const void* in, void* out, int nl, const int* src_of_dst, int64_t batch,
+                                    dq_stream_t stream) {
+    return dq::permute_impl<double>(in, out, nl, src_of_dst, batch, stream);
 }

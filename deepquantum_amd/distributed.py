@@ -18,6 +18,18 @@ p - L ("global").  Semantics follow arXiv:2311.01512 Alg. 6-10 as the reference 
 Every rank executes the same sequence of exchange steps (ranks with nothing to move take part with an
 empty message), which keeps the collective matched exactly like the reference does
 (distributed.py:89-96).
+
+Two execution modes (``CONFIG['mode']``):
+
+* ``'pairwise'`` -- reference semantics gate by gate: a non-diagonal gate on a global qubit costs one
+  pairwise exchange of (part of) the shard over ONE xGMI link (Alg. 6-10).  Used for short gate lists
+  (single ``Gate.forward`` calls, the adjoint sweep).
+* ``'remap'`` (default for whole circuits) -- the state carries a logical->physical qubit permutation.
+  When a stretch of gates needs a qubit that currently is a rank bit, ONE all-to-all swaps k global
+  qubits with the k local qubits whose next non-diagonal use lies farthest in the future (Belady),
+  each GPU sending 1/2^k of its shard to each of its 2^k - 1 group peers concurrently -- all xGMI links
+  at once -- and the following gates run as fused local passes until a rank bit is needed again.  The
+  canonical layout is restored before anything reads ``state.amps``.
 """
 
 from __future__ import annotations
@@ -34,6 +46,13 @@ from .communication import comm_exchange_arrays
 from .executor import Prim
 from .qmath import block_sample, measure
 from .state import DistributedQubitState
+
+
+#: 'remap' | 'pairwise'; gate lists shorter than ``remap_min_prims`` always run pairwise
+CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14}
+
+#: statistics of the last ``dist_apply_prims`` call (bench / tests)
+LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -89,6 +108,7 @@ def _flush(state: DistributedQubitState, pending: list[Prim]) -> None:
     if not pending:
         return
     view = _view(state)
+    LAST_RUN['local_flushes'] += 1
     out = executor.run(view, pending, inplace=True)
     if out.data_ptr() != state.amps.data_ptr():
         state.amps.copy_(out.reshape(-1))
@@ -190,6 +210,7 @@ def _many_target_global(state: DistributedQubitState, p: Prim) -> None:
 
 def _exchange_prim(state: DistributedQubitState, p: Prim) -> None:
     L = state.log_num_amps_per_node
+    LAST_RUN['pairwise_exchanges'] += 1
     if len(p.targets) == 1:
         _one_target_global(state, p)
     else:
@@ -199,20 +220,225 @@ def _exchange_prim(state: DistributedQubitState, p: Prim) -> None:
 
 
 # ---------------------------------------------------------------------------------------------------
-# public entry points
-def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim]) -> DistributedQubitState:
-    """Apply kernel primitives (global bit positions) to the sharded state, fusing local stretches."""
-    pending: list[Prim] = []
+# qubit remap: logical -> physical permutation + k-qubit all-to-all
+def _phys(state: DistributedQubitState) -> list[int]:
+    """phys[logical bit] = physical bit (physical bit p >= L is rank bit p - L)."""
+    ph = state.__dict__.get('_phys')
+    if ph is None:
+        ph = list(range(state.nqubit))
+        state.__dict__['_phys'] = ph
+    return ph
+
+
+def _is_canonical(state: DistributedQubitState) -> bool:
+    ph = state.__dict__.get('_phys')
+    return ph is None or all(p == q for q, p in enumerate(ph))
+
+
+def _translate(p: Prim, ph: list[int]) -> Prim:
+    return Prim(p.kind, p.matrix, tuple(ph[t] for t in p.targets), tuple(ph[c] for c in p.controls))
+
+
+def _permute_local(state: DistributedQubitState, src_of_dst: list[int]) -> None:
+    """Re-label the local qubits (one read + one write): destination bit d <- source bit src_of_dst[d]."""
+    if src_of_dst == list(range(len(src_of_dst))):
+        return
+    out = backend.permute_bits(_view(state), src_of_dst, out=state.buffer.view(1, -1))
+    state.amps, state.buffer = state.buffer, state.amps
+    del out
+    ph = _phys(state)
+    dst_of_src = {sp: d for d, sp in enumerate(src_of_dst)}
+    for q, p in enumerate(ph):
+        if p < state.log_num_amps_per_node:
+            ph[q] = dst_of_src[p]
+
+
+def _exchange_qubits(state: DistributedQubitState, pairs: list[tuple[int, int]]) -> None:
+    """Swap k global qubits with k local ones in one all-to-all.  ``pairs`` = [(leaving logical qubit,
+    entering logical qubit)]: the entering qubit takes over the rank bit of the leaving one."""
+    L, W = state.log_num_amps_per_node, state.world_size
+    ph = _phys(state)
+    pairs = sorted(pairs, key=lambda pr: ph[pr[0]])          # ascending rank bit -> ascending peer rank
+    k = len(pairs)
+    rbits = [ph[lq] - L for lq, _ in pairs]
+    assert all(0 <= r < state.log_num_nodes for r in rbits) and all(ph[eq] < L for _, eq in pairs)
+    # 1. move the entering qubits to the top k local bits (chunk index = their joint value)
+    ent_bits = [ph[eq] for _, eq in pairs]
+    rest = [b for b in range(L) if b not in ent_bits]
+    _permute_local(state, rest + ent_bits)
+    # 2. chunk c goes to the peer whose rank bits `rbits` spell c; what comes back from that peer lands in
+    #    the same chunk slot.  Peers outside the 2^k group get empty messages.
+    chunk = (1 << (L - k))
+    splits = [0] * W
+    for c in range(1 << k):
+        peer = state.rank
+        for i, r in enumerate(rbits):
+            peer = (peer & ~(1 << r)) | (((c >> i) & 1) << r)
+        splits[peer] = chunk * 2                                # complex -> interleaved reals
+    send = torch.view_as_real(state.amps).reshape(-1)
+    recv = torch.view_as_real(state.buffer).reshape(-1)
+    if W > 1 and dist.is_initialized():
+        dist.all_to_all_single(recv, send, output_split_sizes=splits, input_split_sizes=splits)
+        state.amps, state.buffer = state.buffer, state.amps
+    # 3. bookkeeping: entering qubit i now is rank bit rbits[i]; leaving qubit i is local bit L - k + i
+    for i, (lq, eq) in enumerate(pairs):
+        ph[eq] = L + rbits[i]
+        ph[lq] = L - k + i
+    LAST_RUN['remaps'] += 1
+
+
+def _next_use(prims: Sequence[Prim], start: int, n: int) -> list[int]:
+    """Index of the next gate (>= start) acting NON-diagonally on each logical qubit (inf if none soon)."""
+    inf = 1 << 60
+    nxt = [inf] * n
+    left = n
+    stop = min(len(prims), start + CONFIG['horizon'])
+    for j in range(start, stop):
+        p = prims[j]
+        if p.kind == 'diag':
+            continue
+        for t in p.targets:
+            if nxt[t] == inf:
+                nxt[t] = j
+                left -= 1
+        if left == 0:
+            break
+    return nxt
+
+
+def _plan_remap(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int) -> list[tuple[int, int]]:
+    """Which qubits trade places so that gate ``i`` becomes local: evict to the rank bits the qubits whose
+    next non-diagonal use is farthest away (Belady).  Pure function of the gate list: every rank computes
+    the same plan."""
+    g = n - L
+    nxt = _next_use(prims, i, n)
+    is_glob = [ph[q] >= L for q in range(n)]
+    # farthest next use first; ties: keep what already is global (less traffic), then canonical order
+    order = sorted(range(n), key=lambda q: (-nxt[q], 0 if is_glob[q] else 1, -q))
+    new_global = set(order[:g])
+    needed = {t for t in prims[i].targets} if prims[i].kind != 'diag' else set()
+    assert not (needed & new_global), 'gate needs more local qubits than a shard has'
+    leaving = [q for q in range(n) if is_glob[q] and q not in new_global]
+    entering = [q for q in new_global if not is_glob[q]]
+    assert len(leaving) == len(entering) and leaving, 'remap requested although the gate is local'
+    # a canonical global qubit (logical bit L + j) prefers its own rank bit j: cheaper to canonicalise later
+    pairs, free_enter = [], list(entering)
+    for lq in leaving:
+        own = ph[lq]                                   # physical rank bit being vacated
+        pick = next((eq for eq in free_enter if eq == own), free_enter[0])
+        free_enter.remove(pick)
+        pairs.append((lq, pick))
+    return pairs
+
+
+def _remap_for(state: DistributedQubitState, prims: Sequence[Prim], i: int) -> None:
+    pairs = _plan_remap(_phys(state), prims, i, state.nqubit, state.log_num_amps_per_node)
+    _exchange_qubits(state, pairs)
+
+
+def count_exchange_steps(prims: Sequence[Prim], n: int, g: int) -> dict:
+    """Dry run of both modes on a gate list (no data): number of exchange steps and the volume each rank
+    sends, in units of one shard.  Used by tests and to size the design."""
+    L = n - g
+    pw_steps, pw_vol = 0, 0.0
     for p in prims:
+        if p.kind != 'diag' and any(t >= L for t in p.targets):
+            nglob = sum(1 for t in p.targets if t >= L)
+            lc = sum(1 for c in p.controls if c < L)
+            if len(p.targets) == 1:
+                pw_steps += 1
+                pw_vol += 0.5**lc
+            else:
+                pw_steps += 2 * nglob
+                pw_vol += 2 * nglob * 0.5
+    ph = list(range(n))
+    rm_steps, rm_vol, i = 0, 0.0, 0
+    while i < len(prims):
+        p = prims[i]
+        if p.kind != 'diag' and any(ph[t] >= L for t in p.targets):
+            pairs = _plan_remap(ph, prims, i, n, L)
+            pairs = sorted(pairs, key=lambda pr: ph[pr[0]])
+            k = len(pairs)
+            rb = [ph[lq] for lq, _ in pairs]
+            ent = [ph[eq] for _, eq in pairs]
+            rest = [b for b in range(L) if b not in ent]
+            new_local = {sp: d for d, sp in enumerate(rest + ent)}
+            for q in range(n):
+                if ph[q] < L:
+                    ph[q] = new_local[ph[q]]
+            for j, (lq, eq) in enumerate(pairs):
+                ph[eq], ph[lq] = rb[j], L - k + j
+            rm_steps += 1
+            rm_vol += 1 - 0.5**k
+            continue
+        i += 1
+    return {'pairwise_steps': pw_steps, 'pairwise_volume': pw_vol, 'remap_steps': rm_steps, 'remap_volume': rm_vol}
+
+
+def canonicalize(state: DistributedQubitState) -> DistributedQubitState:
+    """Restore phys[q] == q: at most two all-to-all steps for the rank bits, then one local re-labelling."""
+    if _is_canonical(state):
+        return state
+    n, L = state.nqubit, state.log_num_amps_per_node
+    ph = _phys(state)
+    for _ in range(4):
+        glob = [q for q in range(n) if ph[q] >= L]
+        misplaced = [q for q in glob if ph[q] != q]
+        if not misplaced:
+            break
+        pairs, used = [], set()
+        for lq in misplaced:
+            owner = ph[lq]                              # logical qubit that belongs on this rank bit
+            if ph[owner] < L and owner not in used:
+                pick = owner
+            else:                                       # owner itself is on the move: park a filler there
+                pick = next(q for q in range(L) if ph[q] < L and q not in used)
+            used.add(pick)
+            pairs.append((lq, pick))
+        _exchange_qubits(state, pairs)
+    assert all(ph[q] == q for q in range(L, n)), 'rank bits not canonical after 4 exchange rounds'
+    src_of_dst = [0] * L
+    for q in range(L):
+        src_of_dst[q] = ph[q]                           # destination bit q must receive logical qubit q
+    _permute_local(state, src_of_dst)
+    assert _is_canonical(state)
+    return state
+
+
+# ---------------------------------------------------------------------------------------------------
+# public entry points
+def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None = None,
+                     keep_layout: bool = False) -> DistributedQubitState:
+    """Apply kernel primitives (logical bit positions) to the sharded state, fusing local stretches.
+    Unless ``keep_layout`` is set the canonical qubit order is restored before returning."""
+    for k in LAST_RUN:
+        LAST_RUN[k] = 0
+    mode = mode or CONFIG['mode']
+    if len(prims) < CONFIG['remap_min_prims'] or state.world_size == 1:
+        mode = 'pairwise'
+    if mode == 'pairwise' and not _is_canonical(state):
+        canonicalize(state)
+    pending: list[Prim] = []
+    i, nprims = 0, len(prims)
+    while i < nprims:
+        p = prims[i] if mode == 'pairwise' else _translate(prims[i], _phys(state))
         local = _localize(state, p)
         if local is None:
+            i += 1
             continue
         if isinstance(local, Prim):
             pending.append(local)
+            i += 1
             continue
         _flush(state, pending)
-        _exchange_prim(state, p)
+        if mode == 'pairwise':
+            _exchange_prim(state, p)
+            i += 1
+        else:
+            _remap_for(state, prims, i)     # then re-evaluate gate i under the new layout
     _flush(state, pending)
+    if not keep_layout:
+        canonicalize(state)
     return state
 
 

@@ -194,6 +194,16 @@ int dq_unpack_axpby_c64(void* amps, const void* x, const void* y, const void* co
 int dq_unpack_axpby_c128(void* amps, const void* x, const void* y, const void* coef, int64_t coef_batch_stride,
                          int nl, uint64_t mask, uint64_t value, int64_t batch, dq_stream_t stream);
 
+/* out[b, i] = in[b, sigma(i)] with sigma(i) = sum_p bit_p(i) << src_of_dst[p] (host array of nl entries, a
+ * permutation of 0..nl-1): re-labels the local qubits of a shard in one read + one write.  in != out.
+ * Used by the all-to-all qubit remap (swap k global qubits with k local ones in ONE exchange step over all
+ * xGMI links instead of the reference's one pairwise exchange per gate, distributed.py:57-202) and to restore
+ * the canonical order (the reshape/transpose copy of local_swap_gate, distributed.py:48-54). */
+int dq_permute_bits_c64(const void* in, void* out, int nl, const int* src_of_dst, int64_t batch,
+                        dq_stream_t stream);
+int dq_permute_bits_c128(const void* in, void* out, int nl, const int* src_of_dst, int64_t batch,
+                         dq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,12 @@ class CpuTestBackend:
             coef = coef.to(amps.dtype).reshape(-1, 2)
             amps[:, idx] = coef[:, 0:1] * x + coef[:, 1:2] * y
         return amps
+
+    def permute_bits(self, amps, src_of_dst, out):
+        nl = amps.shape[-1].bit_length() - 1
+        i = np.arange(1 << nl, dtype=np.int64)
+        sidx = np.zeros_like(i)
+        for p, sp in enumerate(src_of_dst):
+            sidx |= ((i >> p) & 1) << sp
+        out.copy_(amps[:, torch.from_numpy(sidx)])
+        return out

@@ -90,13 +90,45 @@ GLOBAL_HEAVY = [
 ]
 
 
+def _both_modes(dq, fn):
+    from deepquantum_amd import distributed as D
+
+    out = {}
+    for mode in ('pairwise', 'remap'):
+        D.CONFIG['mode'] = mode
+        fn()
+        out[mode] = dict(D.LAST_RUN)
+    D.CONFIG['mode'] = 'remap'
+    return out
+
+
 def _case_gates_w2(dq, rank, world):
-    _shard_check(dq, rank, world, 5, GLOBAL_HEAVY)
+    st = _both_modes(dq, lambda: _shard_check(dq, rank, world, 5, GLOBAL_HEAVY))
+    assert st['pairwise']['remaps'] == 0 and st['pairwise']['pairwise_exchanges'] > 0
+    assert st['remap']['remaps'] > 0 and st['remap']['pairwise_exchanges'] == 0
 
 
 def _case_gates_w4(dq, rank, world):
-    _shard_check(dq, rank, world, 5, GLOBAL_HEAVY)
-    _shard_check(dq, rank, world, 6, [(m, a, k) for m, a, k in GLOBAL_HEAVY] + [('cnot_ring', [], {}), ('hlayer', [], {})])
+    _both_modes(dq, lambda: _shard_check(dq, rank, world, 5, GLOBAL_HEAVY))
+    _both_modes(dq, lambda: _shard_check(dq, rank, world, 6, [(m, a, k) for m, a, k in GLOBAL_HEAVY]
+                                         + [('cnot_ring', [], {}), ('hlayer', [], {})]))
+
+
+def _case_random_remap_w4(dq, rank, world):
+    """The benchmark generator at n = 10 over 4 ranks: the all-to-all remap needs far fewer exchange steps
+    than one pairwise exchange per global-qubit gate, and both give the dense result."""
+    import specs
+
+    spec = specs.random_spec(10, 12, 4242)
+    st = _both_modes(dq, lambda: _shard_check(dq, rank, world, 10, spec, double=True, tol=1e-10))
+    assert 0 < st['remap']['remaps'] < st['pairwise']['pairwise_exchanges'] / 2, st
+
+
+def _case_remap_w8(dq, rank, world):
+    import specs
+
+    _shard_check(dq, rank, world, 9, specs.random_spec(9, 10, 77) + [('toffoli', [0, 1, 2], {}), ('rzz', [[0, 8], 0.3], {}),
+                                                                    ('rxx', [[1, 2], 0.4], {}), ('swap', [[0, 2]], {})])
 
 
 def _case_fused_local_w2(dq, rank, world):
@@ -161,6 +193,7 @@ def _case_measure_w2(dq, rank, world):
 
 
 @pytest.mark.parametrize('case,world', [('gates_w2', 2), ('gates_w4', 4), ('fused_local_w2', 2),
+                                        ('random_remap_w4', 4), ('remap_w8', 8),
                                         ('expectation_grad_w4', 4), ('measure_w2', 2)])
 def test_sharded_circuit(case, world):
     _run(case, world)
