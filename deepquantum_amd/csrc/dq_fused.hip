@@ -354,37 +354,26 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
     }
 
-    // Layout change through LDS.  Whether a change is needed is decided by the host (flag bits in the
-    // descriptor), so the slot list `rb` stays wave-uniform (SGPRs).  The XOR swizzle is GF(2)-linear and
-    // thread / slot bits are disjoint: swz(tbase | slot_off) = swz(tbase) ^ swz(slot_off), i.e. ONE v_xor
-    // per element with the slot part as a scalar operand.
+    V* lds = reinterpret_cast<V*>(dq_smem);
     auto transpose_to = [&](const unsigned (&nrb)[R], const unsigned ntbase) __attribute__((always_inline)) {
-        unsigned tsw_old = lds_swz<sizeof(V)>(tbase) * (unsigned)sizeof(V);
-        unsigned tsw_new = lds_swz<sizeof(V)>(ntbase) * (unsigned)sizeof(V);
-        // opaque to the optimiser: otherwise instcombine re-merges the two XOR halves and recomputes the
-        // whole swizzle per element (5 VALU ops instead of 1)
-        asm volatile("" : "+v"(tsw_old), "+v"(tsw_new));
+        unsigned so[NA], sn[NA];
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            unsigned x = 0;
+            unsigned x = 0, y = 0;
 #pragma unroll
             for (int s = 0; s < R; ++s)
-                if ((j >> s) & 1) x |= 1u << rb[s];
-            unsigned off = lds_swz<sizeof(V)>(x) * (unsigned)sizeof(V);  // uniform
-            asm volatile("" : "+s"(off));
-            *reinterpret_cast<V*>(dq_smem + (tsw_old ^ off)) = a[j];
+                if ((j >> s) & 1) {
+                    x |= 1u << rb[s];
+                    y |= 1u << nrb[s];
+                }
+            so[j] = x;
+            sn[j] = y;
         }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) lds[lds_swz<sizeof(V)>(tbase | so[j])] = a[j];
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            unsigned y = 0;
-#pragma unroll
-            for (int s = 0; s < R; ++s)
-                if ((j >> s) & 1) y |= 1u << nrb[s];
-            unsigned off = lds_swz<sizeof(V)>(y) * (unsigned)sizeof(V);  // uniform
-            asm volatile("" : "+s"(off));
-            a[j] = *reinterpret_cast<const V*>(dq_smem + (tsw_new ^ off));
-        }
+        for (int j = 0; j < NA; ++j) a[j] = lds[lds_swz<sizeof(V)>(ntbase | sn[j])];
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < R; ++s) rb[s] = nrb[s];
@@ -398,24 +387,25 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     const uint32_t* pw = reinterpret_cast<const uint32_t*>(&p);
     constexpr int ROUND_W0 = offsetof(DqFusedPass, rounds) / 4;
     constexpr int GATE_W0 = offsetof(DqFusedPass, gates) / 4;
-    const int nrounds = (int)((pw[0] >> 24) & 0x7fu);
-    const bool store_needs_trip = ((pw[0] >> 31) & 1u) != 0;  // host: last layout != store layout
+    const int nrounds = (int)(pw[0] >> 24);
     for (int r = 0; r < nrounds; ++r) {
         const uint32_t rw0 = pw[ROUND_W0 + 4 * r], rw1 = pw[ROUND_W0 + 4 * r + 1], rw2 = pw[ROUND_W0 + 4 * r + 2],
                        rw3 = pw[ROUND_W0 + 4 * r + 3];
-        if ((rw3 >> 23) & 1u) {  // host flag: this round's layout differs from the current one
-            unsigned nrb[R];
+        unsigned nrb[R];
+        bool same = true;
 #pragma unroll
-            for (int s = 0; s < R; ++s) nrb[s] = (rw0 >> (8 * s)) & 0xffu;
-            unsigned ntbase = 0;
-#pragma unroll
-            for (int i = 0; i < LOGT; ++i) {
-                const uint32_t w = i < 4 ? rw1 : (i < 8 ? rw2 : rw3);
-                ntbase |= ((tid >> i) & 1u) << ((w >> (8 * (i & 3))) & 0xffu);
-            }
-            transpose_to(nrb, ntbase);
+        for (int s = 0; s < R; ++s) {
+            nrb[s] = (rw0 >> (8 * s)) & 0xffu;
+            same = same && (nrb[s] == rb[s]);
         }
-        const int gbeg = (int)((rw3 >> 16) & 0x7fu), gend = (int)(rw3 >> 24);
+        unsigned ntbase = 0;
+#pragma unroll
+        for (int i = 0; i < LOGT; ++i) {
+            const uint32_t w = i < 4 ? rw1 : (i < 8 ? rw2 : rw3);
+            ntbase |= ((tid >> i) & 1u) << ((w >> (8 * (i & 3))) & 0xffu);
+        }
+        if (!same || ntbase != tbase) transpose_to(nrb, ntbase);
+        const int gbeg = (int)((rw3 >> 16) & 0xffu), gend = (int)(rw3 >> 24);
         for (int gi = gbeg; gi < gend; ++gi) {
             const uint32_t* gw = pw + GATE_W0 + 6 * gi;
             const uint32_t g0 = gw[0], g1 = gw[1], gmat = gw[2];
@@ -465,15 +455,17 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
     }
 
-    if (store_needs_trip) {  // ---- back to the store layout ----
+    {  // ---- store layout ----
         unsigned srb[R];
         unsigned stbase = tid;
+        bool same = true;
 #pragma unroll
         for (int s = 0; s < R; ++s) {
             srb[s] = (srbw >> (8 * s)) & 0xffu;
             stbase = (unsigned)insert_zero(stbase, (int)srb[s]);
+            same = same && (srb[s] == rb[s]);
         }
-        transpose_to(srb, stbase);
+        if (!same || stbase != tbase) transpose_to(srb, stbase);
     }
 
     {
@@ -527,7 +519,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
         set_error("dq_apply_fused: n=%d smaller than tile m=%d", n, m);
         return DQ_ERR_ARG;
     }
-    if ((p->nrounds & 0x7f) > DQ_FUSED_MAX_ROUNDS) {
+    if (p->nrounds > DQ_FUSED_MAX_ROUNDS) {
         set_error("dq_apply_fused: too many rounds");
         return DQ_ERR_ARG;
     }
@@ -561,7 +553,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
             }
         }
     }
-    for (int r = 0; r < (p->nrounds & 0x7f); ++r) {
+    for (int r = 0; r < p->nrounds; ++r) {
         const DqFusedRound& rd = p->rounds[r];
         unsigned used = 0;
         for (int s = 0; s < slots; ++s) {
@@ -578,11 +570,11 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
             }
             used |= 1u << rd.tb[i];
         }
-        if ((rd.gate_begin & 0x7f) > rd.gate_end || rd.gate_end > DQ_FUSED_MAX_GATES) {
+        if (rd.gate_begin > rd.gate_end || rd.gate_end > DQ_FUSED_MAX_GATES) {
             set_error("dq_apply_fused: round %d gate range invalid", r);
             return DQ_ERR_ARG;
         }
-        for (int gi = (rd.gate_begin & 0x7f); gi < rd.gate_end; ++gi) {
+        for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
             const bool slot_kind = g.kind == DQ_FG_GEN1 || g.kind == DQ_FG_X1 || g.kind == DQ_FG_GEN2;
             if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) ||

@@ -307,8 +307,7 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
     ntrans = 0
     cur = (tuple(load_rb), tuple(ascending_tb(load_rb)))
     for ri, (rd, lay) in enumerate(zip(rounds, layouts)):
-        trip = lay != cur
-        if trip:
+        if lay != cur:
             ntrans += 1
             cur = lay
         slot_of = {tl: s for s, tl in enumerate(lay[0])}
@@ -317,16 +316,15 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
             r.rb[s] = lay[0][s]
         for i, t in enumerate(lay[1]):
             r.tb[i] = t
-        r.gate_begin = gi | (0x80 if trip else 0)   # bit 7: layout change before this round
+        r.gate_begin = gi
         for oi in rd.ops:
             _encode_gate(desc.gates[gi], ops[oi], local, slot_of, tile)
             exec_order.append(oi)
             gi += 1
         r.gate_end = gi
-    final_trip = cur != (tuple(store_rb), tuple(ascending_tb(store_rb)))
-    if final_trip:
+    if cur != (tuple(store_rb), tuple(ascending_tb(store_rb))):
         ntrans += 1
-    desc.nrounds = len(rounds) | (0x80 if final_trip else 0)   # bit 7: layout change before the store
+    desc.nrounds = len(rounds)
     return FusedStep(desc=desc, ops=exec_order, nrounds=len(rounds), ntranspose=ntrans)
 
 

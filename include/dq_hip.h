@@ -106,12 +106,11 @@ typedef struct {
     uint8_t rb[DQ_FUSED_MAX_SLOTS]; /* tile-local bit positions of the register slots, ascending */
     uint8_t tb[DQ_FUSED_MAX_TBITS]; /* tile-local bit position of thread-index bit i (the other m - slots
                                        tile bits, in an order the host picks to avoid LDS bank conflicts) */
-    uint8_t gate_begin, gate_end;   /* [begin, end) into gates[]; bit 7 of gate_begin = "this round's layout differs
-                                       from the one in effect before it" (host-computed, keeps the decision uniform) */
+    uint8_t gate_begin, gate_end;   /* [begin, end) into gates[] */
 } DqFusedRound;                     /* 16 bytes */
 
 typedef struct {
-    uint8_t m, L, h, nrounds;                   /* bit 7 of nrounds = the last round's layout differs from the store layout */
+    uint8_t m, L, h, nrounds;
     uint8_t high_pos[DQ_FUSED_MAX_HIGH];        /* global bit of tile bit L+i, any order */
     uint8_t high_sorted[DQ_FUSED_MAX_HIGH];     /* the same positions ascending (tile -> base) */
     /* Register slots (tile-local, ascending) of the layouts used for the global load and the global

@@ -75,20 +75,15 @@ class CpuTestBackend:
         flat_m = mats.detach().numpy().reshape(-1)
         for b in range(bsz):
             t = x[b][idx]                               # (ntiles, 2^m)
-            io = lambda rbio: (tuple(rbio[s] for s in range(R)), tuple(q for q in range(m) if q not in [rbio[s] for s in range(R)]))  # noqa: E731
-            cur_layout = io(desc.load_rb)
             mb = flat_m[b * mat_batch_stride :] if mat_batch_stride else flat_m
-            for r in range(desc.nrounds & 0x7F):
+            for r in range(desc.nrounds):
                 rd = desc.rounds[r]
                 rb = [rd.rb[s] for s in range(R)]
                 tb = [rd.tb[i] for i in range(logt)]
                 assert rb == sorted(set(rb)) and all(q < m for q in rb)
                 assert sorted(rb + tb) == list(range(m)), 'slots + thread bits must cover the tile exactly'
                 slotmask = sum(1 << q for q in rb)
-                lay = (tuple(rb), tuple(tb))
-                assert bool(rd.gate_begin & 0x80) == (lay != cur_layout), 'layout-change flag wrong'
-                cur_layout = lay
-                for gi in range(rd.gate_begin & 0x7F, rd.gate_end):
+                for gi in range(rd.gate_begin, rd.gate_end):
                     g = desc.gates[gi]
                     assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
                     assert (g.reg_cmask >> R) == 0
@@ -147,7 +142,6 @@ class CpuTestBackend:
                         ph = d[sel]
                         ok = tile_ok[:, None] & el_ok[None, :]
                         t = np.where(ok, ph * t, t)
-            assert bool(desc.nrounds & 0x80) == (cur_layout != io(desc.store_rb)), 'store layout-change flag wrong'
             x[b][idx] = t
         out.copy_(torch.from_numpy(x))
         return out
