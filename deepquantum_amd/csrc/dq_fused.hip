@@ -89,23 +89,19 @@ __device__ __forceinline__ void apply2x2(amp<T>& x0, amp<T>& x1, const amp<T> m0
 // One asm statement per (matrix structure, target slot) updates all 16 register-resident amplitudes in
 // place: every amplitude is a tied "+v" 64-bit operand, matrix entries are SGPR pairs whose low half is
 // broadcast (op_sel_hi 0), the "times i" swizzle (-im, re) is op_sel:[1,..] op_sel_hi:[0,..] + neg_lo.
-// ms[] = {m00.re, m00.im, m01.re, m01.im, m10.re, m10.im, m11.re, m11.im} as 64-bit uniform values.
-template <int MODE, int Q> __device__ __forceinline__ void gen1_block_f32(vec2<float> (&a)[16], const uint64_t (&ms)[8]);
+// mq[] = the four matrix entries as raw 64-bit SGPR pairs (low half re, high half im).
+template <int MODE, int Q> __device__ __forceinline__ void gen1_block_f32(vec2<float> (&a)[16], const uint64_t (&mq)[4]);
 template <int Q, int CMASK> __device__ __forceinline__ void x1_block_f32(vec2<float> (&a)[16]);
 #include "dq_fused_asm.inc"
 
 template <int MODE>
-__device__ __forceinline__ void dispatch_gen1_block_f32(vec2<float> (&a)[16], int q, const uint64_t (&ms)[8]) {
+__device__ __forceinline__ void dispatch_gen1_block_f32(vec2<float> (&a)[16], int q, const uint64_t (&mq)[4]) {
     switch (q) {
-        case 0: gen1_block_f32<MODE, 0>(a, ms); break;
-        case 1: gen1_block_f32<MODE, 1>(a, ms); break;
-        case 2: gen1_block_f32<MODE, 2>(a, ms); break;
-        default: gen1_block_f32<MODE, 3>(a, ms); break;
+        case 0: gen1_block_f32<MODE, 0>(a, mq); break;
+        case 1: gen1_block_f32<MODE, 1>(a, mq); break;
+        case 2: gen1_block_f32<MODE, 2>(a, mq); break;
+        default: gen1_block_f32<MODE, 3>(a, mq); break;
     }
-}
-
-__device__ __forceinline__ uint64_t uniform_f32(float v) {
-    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v));
 }
 
 template <typename T, int R, int Q, int MODE, bool PRED>
@@ -173,41 +169,38 @@ __device__ __forceinline__ void dispatch_gen1_q(amp<T> (&a)[1 << R], int q, cons
     }
 }
 
+// `mode` = matrix structure promised by the host from the gate class (DqFusedMode): 0 general, 1 all
+// entries real (H, Ry, X...), 2 real diagonal + imaginary off-diagonal (Rx).  Multiplications by the exact
+// zeros are skipped: half the VALU work for the common gates.
 template <typename T, int R>
 __device__ __forceinline__ void dispatch_gen1(amp<T> (&a)[1 << R], int q, const amp<T>* __restrict__ mp,
-                                              unsigned reg_cmask, bool lane_pred, bool thr_ok) {
-    const amp<T> m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
-    const bool all_real = (m00.y == 0) & (m01.y == 0) & (m10.y == 0) & (m11.y == 0);
-    const bool rx_like = (m00.y == 0) & (m11.y == 0) & (m01.x == 0) & (m10.x == 0);
+                                              unsigned mode, unsigned reg_cmask, bool lane_pred, bool thr_ok) {
     if constexpr (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS) {
         if (reg_cmask == 0) {
             // uncontrolled (or controlled only by thread / outside bits): straight-line asm block; a control
             // on a thread bit is ONE exec-masked region around it (asm is never if-converted)
             if (!lane_pred || thr_ok) {
-                const uint64_t ms[8] = {uniform_f32(m00.x), uniform_f32(m00.y), uniform_f32(m01.x), uniform_f32(m01.y),
-                                        uniform_f32(m10.x), uniform_f32(m10.y), uniform_f32(m11.x), uniform_f32(m11.y)};
-                if (all_real) dispatch_gen1_block_f32<1>(a, q, ms);
-                else if (rx_like) dispatch_gen1_block_f32<2>(a, q, ms);
-                else dispatch_gen1_block_f32<0>(a, q, ms);
+                const uint64_t* mw = reinterpret_cast<const uint64_t*>(mp);
+                const uint64_t mq[4] = {mw[0], mw[1], mw[2], mw[3]};
+                if (mode == 1) dispatch_gen1_block_f32<1>(a, q, mq);
+                else if (mode == 2) dispatch_gen1_block_f32<2>(a, q, mq);
+                else dispatch_gen1_block_f32<0>(a, q, mq);
             }
-        } else {  // a control sits on a register slot: predicated C++ body (rare)
-            dispatch_gen1_q<T, R, 0, true>(a, q, m00, m01, m10, m11, reg_cmask, thr_ok);
+            return;
         }
+    }
+    const amp<T> m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+    if (lane_pred || reg_cmask) {  // controlled gate: one predicated general body (code size)
+        dispatch_gen1_q<T, R, 0, true>(a, q, m00, m01, m10, m11, reg_cmask, thr_ok);
+    } else if (mode == 1) {
+        dispatch_gen1_q<T, R, 1, false>(a, q, m00, m01, m10, m11, 0u, true);
+    } else if (mode == 2) {
+        dispatch_gen1_q<T, R, 2, false>(a, q, m00, m01, m10, m11, 0u, true);
     } else {
-        if (lane_pred || reg_cmask) {  // controlled gate: one predicated general body (code size)
-            dispatch_gen1_q<T, R, 0, true>(a, q, m00, m01, m10, m11, reg_cmask, thr_ok);
-        } else if (all_real) {
-            dispatch_gen1_q<T, R, 1, false>(a, q, m00, m01, m10, m11, 0u, true);
-        } else if (rx_like) {
-            dispatch_gen1_q<T, R, 2, false>(a, q, m00, m01, m10, m11, 0u, true);
-        } else {
-            dispatch_gen1_q<T, R, 0, false>(a, q, m00, m01, m10, m11, 0u, true);
-        }
+        dispatch_gen1_q<T, R, 0, false>(a, q, m00, m01, m10, m11, 0u, true);
     }
 }
 
-// X / CNOT / Toffoli.  Controls on register slots or outside the tile are uniform tests; only a control
-// on a thread bit makes the swap per-lane, and then it is one exec-masked region of v_swap_b32.
 template <int Q>
 __device__ __forceinline__ void dispatch_x1_block_f32(vec2<float> (&a)[16], unsigned cmask) {
     switch (cmask) {  // cmask never contains bit Q (host guarantees target != control)
@@ -416,7 +409,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             const bool thr_ok = (tbase & thr_cmask) == thr_cmask;
             const V* mp = mbase + gmat;
             switch (kind) {
-                case DQ_FG_GEN1: dispatch_gen1<T, R>(a, q, mp, reg_cmask, thr_cmask != 0, thr_ok); break;
+                case DQ_FG_GEN1: dispatch_gen1<T, R>(a, q, mp, loc, reg_cmask, thr_cmask != 0, thr_ok); break;
                 case DQ_FG_X1: dispatch_x1<T, R>(a, q, reg_cmask, thr_cmask != 0, thr_ok); break;
                 case DQ_FG_GEN2: dispatch_gen2<T, R>(a, q, q2, mp, reg_cmask, thr_ok); break;
                 case DQ_FG_DIAG1: {
@@ -577,7 +570,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
         for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
             const bool slot_kind = g.kind == DQ_FG_GEN1 || g.kind == DQ_FG_X1 || g.kind == DQ_FG_GEN2;
-            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) ||
+            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || (g.kind == DQ_FG_GEN1 && g.loc > 2) ||
                 (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
                 set_error("dq_apply_fused: gate %d malformed", gi);
                 return DQ_ERR_ARG;

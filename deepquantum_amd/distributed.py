@@ -78,7 +78,7 @@ def _localize(state: DistributedQubitState, p: Prim) -> Prim | None | str:
     if not _rank_controls_ok(state, p.controls):
         return None
     if p.kind != 'diag' or all(t < L for t in p.targets):
-        return Prim(p.kind, p.matrix, p.targets, lc)
+        return Prim(p.kind, p.matrix, p.targets, lc, p.mode)
     # diagonal gate with global target(s): the rank bits select a sub-block of the diagonal
     m = p.matrix.reshape(-1, 1 << len(p.targets), 1 << len(p.targets))[0] if p.matrix.ndim == 3 else p.matrix
     diag = m.diagonal()
@@ -236,7 +236,7 @@ def _is_canonical(state: DistributedQubitState) -> bool:
 
 
 def _translate(p: Prim, ph: list[int]) -> Prim:
-    return Prim(p.kind, p.matrix, tuple(ph[t] for t in p.targets), tuple(ph[c] for c in p.controls))
+    return Prim(p.kind, p.matrix, tuple(ph[t] for t in p.targets), tuple(ph[c] for c in p.controls), p.mode)
 
 
 def _permute_local(state: DistributedQubitState, src_of_dst: list[int]) -> None:

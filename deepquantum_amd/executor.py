@@ -30,6 +30,7 @@ class Prim:
     matrix: torch.Tensor
     targets: tuple[int, ...]       # bit positions, matrix MSB first
     controls: tuple[int, ...] = ()
+    mode: int = 0                  # 2x2 matrix structure known from the gate class: 0 general, 1 real, 2 Rx-like
 
 
 @dataclass
@@ -69,14 +70,14 @@ def _geometry(is128: bool) -> fusion.Geometry:
 def make_plan(prims: Sequence[Prim], n: int, is128: bool) -> Plan:
     geom = _geometry(is128)
     key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, CONFIG['fuse'],
-           tuple((p.kind, p.targets, p.controls) for p in prims))
+           tuple((p.kind, p.targets, p.controls, p.mode) for p in prims))
     plan = _PLAN_CACHE.get(key)
     if plan is not None:
         _PLAN_CACHE.move_to_end(key)
         return plan
     prim_ops, off = [], 0
     for p in prims:
-        prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off))
+        prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off, p.mode))
         off += (1 << len(p.targets)) ** 2
     steps = fusion.schedule(prim_ops, n, geom, fuse=CONFIG['fuse'])
     plan = Plan(steps, prim_ops, off,

@@ -33,6 +33,7 @@ class PrimOp:
     targets: tuple[int, ...]
     controls: tuple[int, ...] = ()
     mat: int = 0
+    mode: int = 0             # matrix structure promised by the gate class: 0 general, 1 real, 2 Rx-like
 
     @property
     def k(self) -> int:
@@ -377,6 +378,7 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
     if op.k == 1:
         g.kind = _lib.FG_X1 if op.kind == 'x' else _lib.FG_GEN1
         g.q = slots[0]
+        g.loc = op.mode if op.kind == 'gen' else 0
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots

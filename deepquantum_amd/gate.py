@@ -228,7 +228,7 @@ class ParametricDoubleGate(_Parametric, DoubleGate):
 # fixed single-qubit gates
 # ======================================================================================================
 def _fixed_single(cls_name: str, gate_name: str, build, kind: str = 'gen', inverse_name: str | None = None,
-                  nancilla: int | None = None, doc: str = ''):
+                  nancilla: int | None = None, doc: str = '', mode: int = 0):
     def __init__(self, nqubit=1, wires=None, controls=None, condition=False, den_mat=False, tsr_mode=False):
         SingleGate.__init__(self, name=gate_name, nqubit=nqubit, wires=wires, controls=controls,
                             condition=condition, den_mat=den_mat, tsr_mode=tsr_mode)
@@ -243,7 +243,8 @@ def _fixed_single(cls_name: str, gate_name: str, build, kind: str = 'gen', inver
         return other(nqubit=self.nqubit, wires=self.wires, controls=self.controls, condition=self.condition,
                      den_mat=self.den_mat, tsr_mode=self.tsr_mode).to(self.matrix.device, self.matrix.real.dtype)
 
-    return type(cls_name, (SingleGate,), {'__init__': __init__, 'inverse': inverse, '_kernel_kind': kind, '__doc__': doc})
+    return type(cls_name, (SingleGate,), {'__init__': __init__, 'inverse': inverse, '_kernel_kind': kind,
+                                          '_kernel_mode': mode, '__doc__': doc})
 
 
 PauliX = _fixed_single('PauliX', 'PauliX', lambda: torch.tensor([[0, 1], [1, 0]], dtype=torch.cfloat), kind='x',
@@ -253,7 +254,7 @@ PauliY = _fixed_single('PauliY', 'PauliY', lambda: torch.tensor([[0, -1j], [1j, 
 PauliZ = _fixed_single('PauliZ', 'PauliZ', lambda: torch.tensor([[1, 0], [0, -1]], dtype=torch.cfloat), kind='diag',
                        doc='Pauli-Z (reference: gate.py:954-1024, matrix :995).')
 Hadamard = _fixed_single('Hadamard', 'Hadamard',
-                         lambda: torch.tensor([[1, 1], [1, -1]], dtype=torch.cfloat) / 2**0.5, nancilla=1,
+                         lambda: torch.tensor([[1, 1], [1, -1]], dtype=torch.cfloat) / 2**0.5, nancilla=1, mode=1,
                          doc='Hadamard; note the float32-rounded 1/sqrt(2) (reference: gate.py:1027-1099, :1069).')
 SGate = _fixed_single('SGate', 'SGate', lambda: torch.tensor([[1, 0], [0, 1j]]), kind='diag',
                       inverse_name='SDaggerGate', doc='S (reference: gate.py:1102-1188, matrix :1143).')
@@ -373,6 +374,8 @@ class PhaseShift(ParametricSingleGate):
 class Rx(ParametricSingleGate):
     r"""exp(-i theta X / 2) (reference: gate.py:1389-1480, matrix :1443-1448)."""
 
+    _kernel_mode = 2  # cos + 0j on the diagonal, (0 -/+ i sin) off it: exact zeros by construction
+
     def __init__(self, inputs=None, nqubit=1, wires=None, controls=None, condition=False, den_mat=False,
                  tsr_mode=False, requires_grad=False):
         super().__init__(name='Rx', inputs=inputs, nqubit=nqubit, wires=wires, controls=controls,
@@ -387,6 +390,8 @@ class Rx(ParametricSingleGate):
 
 class Ry(ParametricSingleGate):
     r"""exp(-i theta Y / 2) (reference: gate.py:1483-1579, matrix :1538-1543)."""
+
+    _kernel_mode = 1  # real entries + 0j
 
     def __init__(self, inputs=None, nqubit=1, wires=None, controls=None, condition=False, den_mat=False,
                  tsr_mode=False, requires_grad=False):

@@ -105,6 +105,8 @@ class Gate(Operation):
     _qasm_new_gate = ['c3x', 'c4x']
     #: how the kernels may treat the matrix: 'gen' dense, 'diag' diagonal, 'x' bit-flip permutation
     _kernel_kind = 'gen'
+    #: structure of a 2x2 matrix known from the class: 0 general, 1 all real, 2 real diag + imaginary off-diag
+    _kernel_mode = 0
 
     def __init__(
         self,
@@ -162,7 +164,8 @@ class Gate(Operation):
     def prims(self, decompose: bool = True) -> list[Prim]:
         """The gate as kernel primitives.  ``decompose=True`` may split permutation gates into
         CNOT-like bit flips (exactly equal results, cheaper in the fused kernel)."""
-        return [Prim(self._kernel_kind, self.update_matrix(), self._bits(self.wires), self._bits(self.controls))]
+        mode = self._kernel_mode if len(self.wires) == 1 else 0
+        return [Prim(self._kernel_kind, self.update_matrix(), self._bits(self.wires), self._bits(self.controls), mode)]
 
     # ---- forward ------------------------------------------------------------------------------------
     def op_state(self, x: torch.Tensor) -> torch.Tensor:

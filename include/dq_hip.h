@@ -88,12 +88,20 @@ typedef enum {
 
 typedef enum { DQ_LOC_REG = 0, DQ_LOC_THR = 1, DQ_LOC_OUT = 2 } DqBitLoc;
 
+/* Structure of a GEN1 matrix, promised by the host from the gate class (never from values: that would
+ * need a device sync): the kernel skips the multiplications by the exact zeros. */
+typedef enum {
+    DQ_MODE_GENERAL = 0,
+    DQ_MODE_REAL = 1, /* all four entries real: H, Ry, X, Z ... */
+    DQ_MODE_RX = 2    /* real diagonal, purely imaginary off-diagonal: Rx */
+} DqFusedMode;
+
 typedef struct {
     uint8_t kind;       /* DqFusedKind */
     uint8_t q;          /* GEN/X: register slot of the (first) target; DIAG: position per loc */
     uint8_t q2;         /* GEN2: slot of the second target (matrix LSB); DIAG2: position per loc2 */
     uint8_t loc;        /* DIAG1/2: DqBitLoc of target 1 (REG: q = slot, THR: q = tile-local bit,
-                           OUT: q = global bit position) */
+                           OUT: q = global bit position); GEN1: DqFusedMode of the matrix */
     uint8_t loc2;       /* DIAG2: same for target 2 */
     uint8_t reg_cmask;  /* controls that are register slots (bit s = slot s) */
     uint16_t thr_cmask; /* controls that are thread bits (tile-local bit positions) */

@@ -101,6 +101,10 @@ class CpuTestBackend:
                         tbit = rb[g.q]
                         assert not (cm >> tbit) & 1
                         mat = mb[g.mat : g.mat + 4].reshape(2, 2)
+                        if g.kind == _lib.FG_GEN1 and g.loc == 1:
+                            assert np.all(mat.imag == 0), 'gate promised a real matrix'
+                        if g.kind == _lib.FG_GEN1 and g.loc == 2:
+                            assert mat[0, 0].imag == 0 and mat[1, 1].imag == 0 and mat[0, 1].real == 0 and mat[1, 0].real == 0
                         if g.kind == _lib.FG_X1:
                             mat = np.array([[0, 1], [1, 0]], dtype=mat.dtype)
                         e0 = e[el_ok & (((e >> tbit) & 1) == 0)]

@@ -43,7 +43,7 @@ def ops_seq(kind, count, targets, controls=()):
     for i in range(count):
         tb = targets[i % len(targets)]
         k = 'x' if kind == 'x' else 'gen'
-        out.append(fusion.PrimOp(k, (tb,), tuple(controls), OFF[kind]))
+        out.append(fusion.PrimOp(k, (tb,), tuple(controls), OFF[kind], {'h': 1, 'rx': 2}.get(kind, 0)))
     return out
 
 
