@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
@@ -39,6 +39,7 @@ class DqFusedGate(C.Structure):
         ('thr_cmask', C.c_uint16),
         ('mat', C.c_uint32),
         ('out_cmask', C.c_uint64),
+        ('reserved', C.c_uint64),
     ]
 
 
@@ -62,7 +63,10 @@ class DqFusedPass(C.Structure):
         ('load_rb', C.c_uint8 * FUSED_MAX_SLOTS),
         ('store_rb', C.c_uint8 * FUSED_MAX_SLOTS),
         ('rounds', DqFusedRound * FUSED_MAX_ROUNDS),
+        ('pad_', C.c_uint32),
         ('gates', DqFusedGate * FUSED_MAX_GATES),
+        ('load_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),
+        ('store_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),
     ]
 
 

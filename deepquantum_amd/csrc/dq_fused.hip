@@ -321,9 +321,10 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     V a[NA];
     {
         const uint64_t gt = glob(tbase);
+        const uint64_t* so = reinterpret_cast<const uint64_t*>(hw + offsetof(DqFusedPass, load_slot_off) / 4);
         uint64_t gs[R];
 #pragma unroll
-        for (int s = 0; s < R; ++s) gs[s] = glob(1u << rb[s]);
+        for (int s = 0; s < R; ++s) gs[s] = so[s];
         if constexpr (VB == 1) {
 #pragma unroll
             for (int j = 0; j < NA; j += 2) {
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         if (!same || ntbase != tbase) transpose_to(nrb, ntbase);
         const int gbeg = (int)((rw3 >> 16) & 0xffu), gend = (int)(rw3 >> 24);
         for (int gi = gbeg; gi < gend; ++gi) {
-            const uint32_t* gw = pw + GATE_W0 + 6 * gi;
+            const uint32_t* gw = pw + GATE_W0 + 8 * gi;
             const uint32_t g0 = gw[0], g1 = gw[1], gmat = gw[2];
             const uint64_t out_cmask = (uint64_t)gw[4] | ((uint64_t)gw[5] << 32);
             if ((tile_global & out_cmask) != out_cmask) continue;  // uniform: a control outside the tile is 0
@@ -463,9 +464,10 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
 
     {
         const uint64_t gt = glob(tbase);
+        const uint64_t* so = reinterpret_cast<const uint64_t*>(hw + offsetof(DqFusedPass, store_slot_off) / 4);
         uint64_t gs[R];
 #pragma unroll
-        for (int s = 0; s < R; ++s) gs[s] = glob(1u << rb[s]);
+        for (int s = 0; s < R; ++s) gs[s] = so[s];
         if constexpr (VB == 1) {
 #pragma unroll
             for (int j = 0; j < NA; j += 2) {

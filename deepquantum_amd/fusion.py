@@ -299,9 +299,14 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
     default_io = io_layout([])
     load_rb = list(layouts[0][0]) if is_io(layouts[0]) else default_io
     store_rb = list(layouts[-1][0]) if is_io(layouts[-1]) else default_io
+    def goff(tl: int) -> int:                      # tile-local bit -> offset inside the state
+        return 1 << (tl if tl < L else order[tl - L])
+
     for s in range(R):
         desc.load_rb[s] = load_rb[s]
         desc.store_rb[s] = store_rb[s]
+        desc.load_slot_off[s] = goff(load_rb[s])
+        desc.store_slot_off[s] = goff(store_rb[s])
 
     exec_order: list[int] = []
     gi = 0

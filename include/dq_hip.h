@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 1
+#define DQ_ABI_VERSION 2
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -107,7 +107,8 @@ typedef struct {
     uint16_t thr_cmask; /* controls that are thread bits (tile-local bit positions) */
     uint32_t mat;       /* offset (in complex numbers) of this gate's matrix inside `mats` */
     uint64_t out_cmask; /* controls outside the tile (global bit positions) */
-} DqFusedGate;          /* 24 bytes */
+    uint64_t reserved;  /* pads the record to 32 bytes: one s_load_dwordx8 per gate */
+} DqFusedGate;          /* 32 bytes */
 
 #define DQ_FUSED_MAX_TBITS 10
 typedef struct {
@@ -128,7 +129,13 @@ typedef struct {
     uint8_t load_rb[DQ_FUSED_MAX_SLOTS];
     uint8_t store_rb[DQ_FUSED_MAX_SLOTS];
     DqFusedRound rounds[DQ_FUSED_MAX_ROUNDS];
+    uint32_t pad_;                              /* aligns gates[] to 32 bytes */
     DqFusedGate gates[DQ_FUSED_MAX_GATES];
+    /* Host-precomputed addressing of the two I/O layouts: offset (in amplitudes, inside one state) that
+     * register slot s contributes, i.e. 2^(global bit of tile bit load_rb[s]); saves the kernel a scalar
+     * loop per slot per tile. */
+    uint64_t load_slot_off[DQ_FUSED_MAX_SLOTS];
+    uint64_t store_slot_off[DQ_FUSED_MAX_SLOTS];
 } DqFusedPass;
 
 /* Tile geometries this build was compiled with (m = slots + log2(threads)); variant 0 is the

@@ -60,6 +60,10 @@ class CpuTestBackend:
             assert sl == sorted(set(sl)), 'I/O slots must be ascending and distinct'
             assert all((q == s) if s < vb else (L <= q < m) for s, q in enumerate(sl)), 'I/O layout not coalesced'
 
+        for rbio, offs in ((desc.load_rb, desc.load_slot_off), (desc.store_rb, desc.store_slot_off)):
+            for sl in range(R):
+                tl = rbio[sl]
+                assert offs[sl] == 1 << (tl if tl < L else high_pos[tl - L]), 'slot offset table wrong'
         # tile-local index -> global offset, tile index -> base
         e = np.arange(1 << m, dtype=np.int64)
         glob = e & ((1 << L) - 1)

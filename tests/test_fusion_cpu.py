@@ -101,6 +101,6 @@ def test_small_state_is_not_fused():
 def test_descriptor_struct_sizes_match_header():
     import ctypes
 
-    assert ctypes.sizeof(_lib.DqFusedGate) == 24
+    assert ctypes.sizeof(_lib.DqFusedGate) == 32
     assert ctypes.sizeof(_lib.DqFusedRound) == 16
-    assert ctypes.sizeof(_lib.DqFusedPass) == 4 + 8 + 8 + 4 + 4 + 4 + 12 * 16 + 40 * 24
+    assert ctypes.sizeof(_lib.DqFusedPass) == 224 + 40 * 32 + 64
