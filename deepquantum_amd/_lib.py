@@ -22,8 +22,8 @@ FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
 LOC_REG, LOC_THR, LOC_OUT = range(3)
 
 FUSED_MAX_HIGH = 8
-FUSED_MAX_ROUNDS = 12
-FUSED_MAX_GATES = 40
+FUSED_MAX_ROUNDS = 24
+FUSED_MAX_GATES = 96
 FUSED_MAX_SLOTS = 4
 FUSED_MAX_TBITS = 10
 

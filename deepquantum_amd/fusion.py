@@ -74,9 +74,10 @@ def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = No
         return Geometry(m=m, slots=slots, vb=0, min_low=6)
     m = 12 if m is None else m
     slots = 4 if slots is None else slots
-    # min_low = 6: a wave-level 16 B/lane access still moves 512 contiguous bytes; measured best on the
-    # headline workload (tools/sweep2.sh: 760 ms/step vs 802 ms with min_low = 7)
-    return Geometry(m=m, slots=slots, vb=1, min_low=6)
+    # min_low = 5: every lane still moves 16 B and a wave instruction covers 256-byte runs (two 128-B
+    # lines); the extra gathered bit buys more fusion.  Measured on the headline workload (tools/sweep2.sh):
+    # min_low 7 / 6 / 5 / 4 -> 46 / 40 / 35 / 32 passes, 707 / 650 / 629 / 617 ms per step.
+    return Geometry(m=m, slots=slots, vb=1, min_low=5)
 
 
 # ---------------------------------------------------------------------------------------------------

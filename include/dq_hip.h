@@ -74,8 +74,8 @@ int dq_apply_gate_c128(const void* in, void* out, const void* mats, int64_t mat_
  *    The host scheduler (deepquantum_amd/fusion.py) builds these descriptors.
  * ------------------------------------------------------------------------------------------ */
 #define DQ_FUSED_MAX_HIGH 8
-#define DQ_FUSED_MAX_ROUNDS 12
-#define DQ_FUSED_MAX_GATES 40
+#define DQ_FUSED_MAX_ROUNDS 24
+#define DQ_FUSED_MAX_GATES 96
 #define DQ_FUSED_MAX_SLOTS 4
 
 typedef enum {

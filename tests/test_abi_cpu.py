@@ -37,7 +37,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.DqFusedGate) == 32
     assert ctypes.sizeof(_lib.DqFusedRound) == 16
     assert _lib.DqFusedPass.rounds.offset == 28
-    assert _lib.DqFusedPass.gates.offset == 224 and _lib.DqFusedPass.load_slot_off.offset == 224 + 40 * 32
+    assert _lib.DqFusedPass.gates.offset == 416 and _lib.DqFusedPass.load_slot_off.offset == 416 + 96 * 32
     assert _lib.DqFusedGate.out_cmask.offset == 16 and _lib.DqFusedGate.mat.offset == 8
 
 

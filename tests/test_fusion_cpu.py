@@ -103,4 +103,4 @@ def test_descriptor_struct_sizes_match_header():
 
     assert ctypes.sizeof(_lib.DqFusedGate) == 32
     assert ctypes.sizeof(_lib.DqFusedRound) == 16
-    assert ctypes.sizeof(_lib.DqFusedPass) == 224 + 40 * 32 + 64
+    assert ctypes.sizeof(_lib.DqFusedPass) == 28 + 24 * 16 + 4 + 96 * 32 + 64
