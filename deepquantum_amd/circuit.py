@@ -199,7 +199,8 @@ class QubitCircuit(Operation):
         finally:
             for g in touched:
                 g.__dict__['_precomputed'] = None
-        if x is flat or x.data_ptr() == state.data_ptr():
+        if x is flat or (not executor.ops._is_batched(x) and not executor.ops._is_batched(state)
+                         and x.data_ptr() == state.data_ptr()):
             x = x.clone()
         return self.vector_rep(x).squeeze(0)
 

@@ -107,6 +107,10 @@ def _flat_mats(prims: Sequence[Prim], batch: int, dtype: torch.dtype, device: to
 
 
 def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
+    """Eager per-gate path: when autograd must see every gate, or inside a ``torch.vmap`` transform (the
+    per-gate Function carries the vmap rule; raw pointers of BatchedTensors are not available)."""
+    if ops._is_batched(state) or any(ops._is_batched(p.matrix) for p in prims):
+        return True
     if not torch.is_grad_enabled():
         return False
     return state.requires_grad or any(p.matrix.requires_grad for p in prims)

@@ -16,14 +16,28 @@ import torch
 from . import backend
 
 
+def _is_batched(t: torch.Tensor) -> bool:
+    """True inside a ``torch.vmap`` transform (the tensor is a functorch BatchedTensor)."""
+    return torch._C._functorch.is_batchedtensor(t)
+
+
 class _ApplyGate(torch.autograd.Function):
-    """y = (U on targets | controls) x  for x: (B, 2**n), U: (Bm, D, D)."""
+    """y = (U on targets | controls) x  for x: (B, 2**n), U: (Bm, D, D).
+
+    Written in the ``setup_context`` style so that it composes with ``torch.func`` transforms; the
+    ``vmap`` rule folds the mapped dimension into the kernels' batch dimension (per-sample matrix stride),
+    which is what lets ``torch.vmap`` over a circuit -- the reference's batching mechanism,
+    circuit.py:232-240 -- run on the same kernels."""
 
     @staticmethod
-    def forward(ctx, state: torch.Tensor, mats: torch.Tensor, targets: tuple, controls: tuple) -> torch.Tensor:
+    def forward(state: torch.Tensor, mats: torch.Tensor, targets: tuple, controls: tuple) -> torch.Tensor:
+        return backend.apply_gate(state, mats, targets, controls)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        state, mats, targets, controls = inputs
         ctx.targets, ctx.controls = targets, controls
         ctx.save_for_backward(state, mats)
-        return backend.apply_gate(state, mats, targets, controls)
 
     @staticmethod
     def backward(ctx, gy: torch.Tensor):
@@ -32,13 +46,28 @@ class _ApplyGate(torch.autograd.Function):
         gstate = gmats = None
         if ctx.needs_input_grad[0]:
             # d/dx of y = U x  ->  U^H gy on the same targets / controls (other amplitudes: identity)
-            gstate = backend.apply_gate(gy, mats.mH.contiguous(), ctx.targets, ctx.controls)
+            gstate = apply_gate(gy, mats.mH.contiguous(), ctx.targets, ctx.controls)
         if ctx.needs_input_grad[1]:
             g = backend.gate_grad(state, gy, ctx.targets, ctx.controls)  # (B, D, D) complex128
             if mats.shape[0] == 1 and g.shape[0] > 1:
                 g = g.sum(dim=0, keepdim=True)
             gmats = g.to(mats.dtype)
         return gstate, gmats, None, None
+
+    @staticmethod
+    def vmap(info, in_dims, state, mats, targets, controls):
+        sd, md = in_dims[0], in_dims[1]
+        v = info.batch_size
+        state = state.movedim(sd, 0) if sd is not None else state.unsqueeze(0).expand(v, *state.shape)
+        b = state.shape[1]
+        if md is not None:
+            mats = mats.movedim(md, 0)
+            d = mats.shape[-1]
+            mats = mats.expand(v, b, d, d).reshape(v * b, d, d)
+        elif mats.shape[0] > 1:
+            mats = mats.unsqueeze(0).expand(v, *mats.shape).reshape(v * b, *mats.shape[1:])
+        out = _ApplyGate.apply(state.reshape(v * b, -1).contiguous(), mats.contiguous(), targets, controls)
+        return out.reshape(v, b, -1), 0
 
 
 def apply_gate(
@@ -53,7 +82,7 @@ def apply_gate(
         mats = mats.unsqueeze(0)
     if mats.dtype != state.dtype:
         mats = mats.to(state.dtype)
-    if not state.is_contiguous():
+    if not _is_batched(state) and not state.is_contiguous():
         state = state.contiguous()
     return _ApplyGate.apply(state, mats, tuple(int(t) for t in targets), tuple(int(c) for c in controls))
 
@@ -62,10 +91,13 @@ class _ExpectPauli(torch.autograd.Function):
     """Re <psi|P|psi> per batch sample, P a Pauli string given by bit masks."""
 
     @staticmethod
-    def forward(ctx, state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
-        ctx.xmask, ctx.zmask = xmask, zmask
-        ctx.save_for_backward(state)
+    def forward(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
         return backend.expect_pauli(state, xmask, zmask).to(state.real.dtype)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        state, ctx.xmask, ctx.zmask = inputs
+        ctx.save_for_backward(state)
 
     @staticmethod
     def backward(ctx, g: torch.Tensor):
@@ -74,6 +106,14 @@ class _ExpectPauli(torch.autograd.Function):
         # of a complex tensor is grad = 2 * dL/d(conj psi).
         ppsi = apply_pauli(state, ctx.xmask, ctx.zmask)
         return (2.0 * g).to(state.real.dtype).unsqueeze(-1) * ppsi, None, None
+
+    @staticmethod
+    def vmap(info, in_dims, state, xmask, zmask):
+        v = info.batch_size
+        state = state.movedim(in_dims[0], 0)
+        b = state.shape[1]
+        out = _ExpectPauli.apply(state.reshape(v * b, -1).contiguous(), xmask, zmask)
+        return out.reshape(v, b), 0
 
 
 _PAULI = {}
@@ -105,6 +145,6 @@ def apply_pauli(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
 
 def expect_pauli(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
     """Differentiable Re <psi_b|P|psi_b>, real (B,) in the state's real precision."""
-    if not state.is_contiguous():
+    if not _is_batched(state) and not state.is_contiguous():
         state = state.contiguous()
     return _ExpectPauli.apply(state, int(xmask), int(zmask))

@@ -170,3 +170,26 @@ def test_reupload_encoding(cpu_backend):
     cir(data)
     got = [g.theta.item() for g in cir.encoders]
     assert got == pytest.approx([0.3, 0.5, 0.7, 0.9, 0.3, 0.5])
+
+
+def test_torch_vmap_over_the_circuit_matches_native_batching(cpu_backend):
+    """The reference batches with torch.vmap over _forward_helper (circuit.py:232-240); the per-gate op has a
+    vmap rule, so the same call works here and equals the native batched path."""
+    cir = dq.QubitCircuit(4)
+    cir.hlayer()
+    cir.rx(0, encode=True)
+    cir.cnot(0, 2)
+    cir.ry(3, encode=True)
+    cir.crx(1, 2, encode=True)
+    cir.rzz([0, 3], encode=True)
+    g = torch.Generator().manual_seed(0)
+    data = torch.rand(5, 4, generator=g)
+    native = cir(data)
+    vm = torch.vmap(cir._forward_helper, in_dims=(0, None))(data, cir.init_state.state)
+    assert vm.shape == native.shape
+    assert (vm - native).abs().max().item() < 1e-6
+    cir.encode(data[-1])
+    # mapped initial states too
+    states = torch.stack([cir.init_state.state] * 5)
+    vm2 = torch.vmap(cir._forward_helper)(data, states)
+    assert (vm2 - native).abs().max().item() < 1e-6

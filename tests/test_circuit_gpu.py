@@ -186,3 +186,22 @@ def test_full_size_hlayer_uniform_n28():
     amp = 0.7071067690849304**n
     assert (state.real - amp).abs().max().item() < 1e-9 and state.imag.abs().max().item() == 0
     assert (ev - (2 * 0.7071067690849304**2) ** n).abs().max().item() < 1e-4
+
+
+def test_torch_vmap_over_the_circuit_on_gpu():
+    cir = dq.QubitCircuit(6)
+    cir.hlayer()
+    cir.rx(0, encode=True)
+    cir.cnot(0, 4)
+    cir.ry(3, encode=True)
+    cir.crx(1, 5, encode=True)
+    cir.rzz([0, 3], encode=True)
+    cir.observable([0, 3], 'zx')
+    cir.to(dev())
+    data = torch.rand(7, 4, generator=torch.Generator().manual_seed(0)).to(dev())
+    with torch.no_grad():
+        native = cir(data)
+        ev = cir.expectation()
+        vm = torch.vmap(cir._forward_helper, in_dims=(0, None))(data, cir.init_state.state)
+    assert (vm - native).abs().max().item() < 1e-6
+    assert ev.shape == (7, 1)
