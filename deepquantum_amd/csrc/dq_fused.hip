@@ -409,6 +409,28 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             const unsigned loc2 = g1 & 0xffu, reg_cmask = (g1 >> 8) & 0xffu, thr_cmask = g1 >> 16;
             const bool thr_ok = (tbase & thr_cmask) == thr_cmask;
             const V* mp = mbase + gmat;
+            if constexpr (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS) {
+                // Fast handlers (host-assigned id in the q2 byte of 1-target gates): 0..11 = uncontrolled-by-slot
+                // 2x2 gate with structure mode = id / 4 on slot id % 4; 12..15 = X on slot id - 12.  One flat
+                // switch instead of the kind / control / mode / slot decision chain (SALU is the scarce unit).
+                if (kind <= DQ_FG_X1 && q2 < 16) {
+                    if (thr_cmask == 0 || thr_ok) {
+                        const uint64_t* mw = reinterpret_cast<const uint64_t*>(mp);
+                        switch (q2) {
+#define DQ_GEN1_CASE(ID) case ID: { const uint64_t mq[4] = {mw[0], mw[1], mw[2], mw[3]}; gen1_block_f32<(ID) / 4, (ID) % 4>(a, mq); break; }
+                            DQ_GEN1_CASE(0) DQ_GEN1_CASE(1) DQ_GEN1_CASE(2) DQ_GEN1_CASE(3)
+                            DQ_GEN1_CASE(4) DQ_GEN1_CASE(5) DQ_GEN1_CASE(6) DQ_GEN1_CASE(7)
+                            DQ_GEN1_CASE(8) DQ_GEN1_CASE(9) DQ_GEN1_CASE(10) DQ_GEN1_CASE(11)
+#undef DQ_GEN1_CASE
+                            case 12: dispatch_x1_block_f32<0>(a, reg_cmask); break;
+                            case 13: dispatch_x1_block_f32<1>(a, reg_cmask); break;
+                            case 14: dispatch_x1_block_f32<2>(a, reg_cmask); break;
+                            default: dispatch_x1_block_f32<3>(a, reg_cmask); break;
+                        }
+                    }
+                    continue;
+                }
+            }
             switch (kind) {
                 case DQ_FG_GEN1: dispatch_gen1<T, R>(a, q, mp, loc, reg_cmask, thr_cmask != 0, thr_ok); break;
                 case DQ_FG_X1: dispatch_x1<T, R>(a, q, reg_cmask, thr_cmask != 0, thr_ok); break;

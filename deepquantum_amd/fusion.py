@@ -387,6 +387,13 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         g.kind = _lib.FG_X1 if op.kind == 'x' else _lib.FG_GEN1
         g.q = slots[0]
         g.loc = op.mode if op.kind == 'gen' else 0
+        # fast-handler id (one flat switch in the kernel): see include/dq_hip.h
+        if op.kind == 'x':
+            g.q2 = 12 + slots[0]
+        elif reg_c == 0:
+            g.q2 = 4 * g.loc + slots[0]
+        else:
+            g.q2 = 0xFF
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots

@@ -99,7 +99,9 @@ typedef enum {
 typedef struct {
     uint8_t kind;       /* DqFusedKind */
     uint8_t q;          /* GEN/X: register slot of the (first) target; DIAG: position per loc */
-    uint8_t q2;         /* GEN2: slot of the second target (matrix LSB); DIAG2: position per loc2 */
+    uint8_t q2;         /* GEN2: slot of the second target (matrix LSB); DIAG2: position per loc2;
+                           GEN1 / X1: fast-handler id (0..11 = mode * 4 + slot for a 2x2 gate without slot
+                           controls, 12..15 = 12 + slot for X), or 0xFF = none */
     uint8_t loc;        /* DIAG1/2: DqBitLoc of target 1 (REG: q = slot, THR: q = tile-local bit,
                            OUT: q = global bit position); GEN1: DqFusedMode of the matrix */
     uint8_t loc2;       /* DIAG2: same for target 2 */

@@ -104,6 +104,8 @@ class CpuTestBackend:
                     if g.kind in (_lib.FG_GEN1, _lib.FG_X1):
                         tbit = rb[g.q]
                         assert not (cm >> tbit) & 1
+                        want = 12 + g.q if g.kind == _lib.FG_X1 else (4 * g.loc + g.q if g.reg_cmask == 0 else 0xFF)
+                        assert g.q2 == want, 'fast-handler id wrong'
                         mat = mb[g.mat : g.mat + 4].reshape(2, 2)
                         if g.kind == _lib.FG_GEN1 and g.loc == 1:
                             assert np.all(mat.imag == 0), 'gate promised a real matrix'

@@ -1,0 +1,30 @@
+"""Per-pass breakdown of the headline workload: gates, rounds, LDS trips and measured duration."""
+import os, sys, math
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deepquantum_amd as dq
+import bench
+from oracle.statevec_oracle import random_circuit_spec
+n, depth, batch = 28, 40, int(os.environ.get('B', 4))
+dev = torch.device('cuda', 0)
+spec = random_circuit_spec(n, depth, 1234)
+cir, data = bench.build_circuit(dq, n, spec, batch, torch.complex64, dev)
+with torch.no_grad():
+    cir(data)
+    dq.executor.PROFILE['enabled'] = True
+    dq.executor.PROFILE['events'].clear()
+    cir(data)
+    torch.cuda.synchronize()
+plan = list(dq.executor._PLAN_CACHE.values())[-1]
+steps = [s for s in plan.steps if isinstance(s, dq.fusion.FusedStep)]
+ev = dq.executor.PROFILE['events']
+tot = 0
+for i, (s, (a, b, ng)) in enumerate(zip(steps, ev)):
+    ms = a.elapsed_time(b); tot += ms
+    kinds = {}
+    for oi in s.ops:
+        op = plan.prim_ops[oi]
+        k = 'x' if op.kind == 'x' else ('h' if op.mode == 1 else 'rx' if op.mode == 2 else 'g')
+        kinds[k] = kinds.get(k, 0) + 1
+    print(f'pass {i:2d}: gates {len(s.ops):3d} {kinds} rounds {s.nrounds} trips {s.ntranspose}  {ms:6.2f} ms')
+print('total', tot)
