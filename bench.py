@@ -149,12 +149,7 @@ def main():
 
     def step():
         with torch.no_grad():
-            if distributed:
-                ev = None
-                for b in range(args.batch):
-                    cir(data[b])
-                return ev
-            cir(data)
+            cir(data)      # N>1: (batch, 2^L) shards on every rank, one exchange schedule for the whole batch
             return cir.expectation()
 
     def sync():

@@ -600,15 +600,31 @@ class DistributedQubitCircuit(QubitCircuit):
 
     @torch.no_grad()
     def forward(self, data: torch.Tensor | None = None, state: DistributedQubitState | None = None):
+        """Run the circuit on the sharded state.  ``data`` may be 1-D (as in the reference) or 2-D: then every
+        rank holds one shard per sample, (B, 2^L), and the whole batch moves through the same kernels and
+        exchange steps (extension; the reference's sharded state has no batch dimension)."""
         from .distributed import dist_run
 
+        if self.ndata == 0:
+            data = None
+        batch = data.shape[0] if (data is not None and data.ndim == 2) else None
         if state is None:
+            if self.init_state.batch != batch:
+                old = self.init_state.amps
+                self.init_state = DistributedQubitState(self.nqubit, batch).to(old.device, old.real.dtype)
             self.init_state.reset()
         else:
             self.init_state = state
         with torch.enable_grad():
             self.encode(data)
-        self.state = dist_run(self.init_state, self.operators)
+        touched = self._precompute_matrices()
+        try:
+            self.state = dist_run(self.init_state, self.operators)
+        finally:
+            for g in touched:
+                g.__dict__['_precomputed'] = None
+        if batch is not None:
+            self.encode(data[-1])
         return self.state
 
     def measure(self, shots=None, with_prob=False, wires=None, block_size=2**24):
@@ -633,6 +649,11 @@ class DistributedQubitCircuit(QubitCircuit):
         assert isinstance(self.state, DistributedQubitState), 'There is no final state'
         if shots is not None:
             raise NotImplementedError('sampled expectation on the sharded state is not implemented yet')
+        if self.state.batch is not None or not torch.is_grad_enabled():
+            # forward-only evaluation (also the only one defined for batched shards)
+            from .distributed import expect_pauli_dist
+
+            return torch.stack([expect_pauli_dist(self.state, ob) for ob in self.observables], dim=-1)
         out = [adjoint_expectation(self.state, self.operators, ob) for ob in self.observables]
         return torch.stack(out, dim=-1)
 

@@ -46,6 +46,19 @@ def comm_get_world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def all_to_all_flat(recv: torch.Tensor, send: torch.Tensor, splits: list[int]) -> None:
+    """``all_to_all_single`` on flat real buffers with the same split table both ways.  RCCL moves GPU
+    memory directly; under the ``gloo`` backend (CPU tests, or several ranks sharing one GPU in the GPU
+    test-suite) device buffers are staged through host memory."""
+    if send.is_cuda and dist.get_backend() == 'gloo':
+        h_send = send.cpu()
+        h_recv = torch.empty_like(h_send)
+        dist.all_to_all_single(h_recv, h_send, output_split_sizes=splits, input_split_sizes=splits)
+        recv.copy_(h_recv)
+        return
+    dist.all_to_all_single(recv, send, output_split_sizes=splits, input_split_sizes=splits)
+
+
 def comm_exchange_arrays(send_data: torch.Tensor, recv_data: torch.Tensor, pair_rank: int | None) -> None:
     """Pairwise exchange with ``pair_rank``.  Every rank of the group must call it for every exchange
     step (ranks with nothing to move pass ``pair_rank=None``): it is expressed as one
@@ -67,4 +80,4 @@ def comm_exchange_arrays(send_data: torch.Tensor, recv_data: torch.Tensor, pair_
         real = send_data.real.dtype if send_data.is_complex() else send_data.dtype
         send_flat = torch.empty(0, dtype=real, device=send_data.device)
         recv_flat = torch.empty(0, dtype=real, device=send_data.device)
-    dist.all_to_all_single(recv_flat, send_flat, output_split_sizes=splits, input_split_sizes=splits)
+    all_to_all_flat(recv_flat, send_flat, splits)

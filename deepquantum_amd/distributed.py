@@ -42,7 +42,7 @@ import torch.distributed as dist
 
 from . import backend, executor
 from .bitmath import get_bit
-from .communication import comm_exchange_arrays
+from .communication import all_to_all_flat, comm_exchange_arrays
 from .executor import Prim
 from .qmath import block_sample, measure
 from .state import DistributedQubitState
@@ -58,7 +58,12 @@ LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0}
 # ---------------------------------------------------------------------------------------------------
 # helpers on one shard
 def _view(state: DistributedQubitState) -> torch.Tensor:
-    return state.amps.view(1, -1)
+    """(batch, 2^L) view of the shard(s)."""
+    return state.amps.view(-1, state.num_amps_per_node)
+
+
+def _bview(state: DistributedQubitState) -> torch.Tensor:
+    return state.buffer.view(-1, state.num_amps_per_node)
 
 
 def _rank_controls_ok(state: DistributedQubitState, controls: Sequence[int]) -> bool:
@@ -80,8 +85,7 @@ def _localize(state: DistributedQubitState, p: Prim) -> Prim | None | str:
     if p.kind != 'diag' or all(t < L for t in p.targets):
         return Prim(p.kind, p.matrix, p.targets, lc, p.mode)
     # diagonal gate with global target(s): the rank bits select a sub-block of the diagonal
-    m = p.matrix.reshape(-1, 1 << len(p.targets), 1 << len(p.targets))[0] if p.matrix.ndim == 3 else p.matrix
-    diag = m.diagonal()
+    diag = p.matrix.diagonal(dim1=-2, dim2=-1)             # (.., D); a leading dim = one matrix per sample
     k = len(p.targets)
     local_t = [t for t in p.targets if t < L]
     sel = []
@@ -94,14 +98,14 @@ def _localize(state: DistributedQubitState, p: Prim) -> Prim | None | str:
                 bit = (idx >> (len(local_t) - 1 - li)) & 1
                 li += 1
             full |= bit << (k - 1 - i)
-        sel.append(diag[full])
+        sel.append(diag[..., full])
     if local_t:
-        return Prim('diag', torch.diag(torch.stack(sel)), tuple(local_t), lc)
+        return Prim('diag', torch.stack(sel, dim=-1).diag_embed(), tuple(local_t), lc)
     phase = sel[0]
     if lc:  # phase on the controlled sub-cube = diag(1, phase) on one control bit, controlled by the rest
         one = torch.ones_like(phase)
-        return Prim('diag', torch.diag(torch.stack([one, phase])), (lc[0],), lc[1:])
-    return Prim('diag', torch.diag(torch.stack([phase, phase])), (0,), ())
+        return Prim('diag', torch.stack([one, phase], dim=-1).diag_embed(), (lc[0],), lc[1:])
+    return Prim('diag', torch.stack([phase, phase], dim=-1).diag_embed(), (0,), ())
 
 
 def _flush(state: DistributedQubitState, pending: list[Prim]) -> None:
@@ -111,7 +115,7 @@ def _flush(state: DistributedQubitState, pending: list[Prim]) -> None:
     LAST_RUN['local_flushes'] += 1
     out = executor.run(view, pending, inplace=True)
     if out.data_ptr() != state.amps.data_ptr():
-        state.amps.copy_(out.reshape(-1))
+        state.amps.copy_(out.reshape(state.amps.shape))
     pending.clear()
 
 
@@ -127,7 +131,7 @@ def _swap_local_global(state: DistributedQubitState, lbit: int, gbit: int) -> No
     mask = 1 << lbit
     value = (1 - b) << lbit
     send = backend.pack(_view(state), mask, value)
-    recv = state.buffer[: send.numel()].view(1, -1)
+    recv = state.buffer.view(-1)[: send.numel()].view(send.shape)
     comm_exchange_arrays(send, recv, pair)
     backend.unpack_axpby(_view(state), recv, None, None, mask, value)
 
@@ -158,19 +162,19 @@ def _one_target_global(state: DistributedQubitState, p: Prim, derivative: bool =
         return
     b = get_bit(state.rank, rb)
     pair = state.rank ^ (1 << rb)
-    m = p.matrix[0] if p.matrix.ndim == 3 else p.matrix
+    m = p.matrix
     if p.kind == 'x':
         m = m.new_tensor([[0, 1], [1, 0]])
-    coef = torch.stack([m[b, b], m[b, 1 - b]]).to(state.amps.dtype)
+    coef = torch.stack([m[..., b, b], m[..., b, 1 - b]], dim=-1).to(state.amps.dtype)   # (2,) or (B, 2)
     mask = 0
     for c in lc:
         mask |= 1 << c
     if mask == 0:
         comm_exchange_arrays(state.amps, state.buffer, pair)
-        backend.unpack_axpby(_view(state), _view(state), state.buffer.view(1, -1), coef, 0, 0)
+        backend.unpack_axpby(_view(state), _view(state), _bview(state), coef, 0, 0)
         return
     send = backend.pack(_view(state), mask, mask)
-    recv = state.buffer[: send.numel()].view(1, -1)
+    recv = state.buffer.view(-1)[: send.numel()].view(send.shape)
     comm_exchange_arrays(send, recv, pair)
     if derivative:
         state.amps.zero_()
@@ -243,9 +247,8 @@ def _permute_local(state: DistributedQubitState, src_of_dst: list[int]) -> None:
     """Re-label the local qubits (one read + one write): destination bit d <- source bit src_of_dst[d]."""
     if src_of_dst == list(range(len(src_of_dst))):
         return
-    out = backend.permute_bits(_view(state), src_of_dst, out=state.buffer.view(1, -1))
+    backend.permute_bits(_view(state), src_of_dst, out=_bview(state))
     state.amps, state.buffer = state.buffer, state.amps
-    del out
     ph = _phys(state)
     dst_of_src = {sp: d for d, sp in enumerate(src_of_dst)}
     for q, p in enumerate(ph):
@@ -275,10 +278,10 @@ def _exchange_qubits(state: DistributedQubitState, pairs: list[tuple[int, int]])
         for i, r in enumerate(rbits):
             peer = (peer & ~(1 << r)) | (((c >> i) & 1) << r)
         splits[peer] = chunk * 2                                # complex -> interleaved reals
-    send = torch.view_as_real(state.amps).reshape(-1)
-    recv = torch.view_as_real(state.buffer).reshape(-1)
     if W > 1 and dist.is_initialized():
-        dist.all_to_all_single(recv, send, output_split_sizes=splits, input_split_sizes=splits)
+        send, recv = torch.view_as_real(_view(state)), torch.view_as_real(_bview(state))   # (B, 2^L, 2)
+        for i in range(send.shape[0]):                          # one collective per sample: contiguous chunks
+            all_to_all_flat(recv[i].reshape(-1), send[i].reshape(-1), splits)
         state.amps, state.buffer = state.buffer, state.amps
     # 3. bookkeeping: entering qubit i now is rank bit rbits[i]; leaving qubit i is local bit L - k + i
     for i, (lq, eq) in enumerate(pairs):
@@ -473,20 +476,43 @@ def dist_swap_gate(state: DistributedQubitState, qb1: int, qb2: int) -> Distribu
     return state
 
 
+def expect_pauli_dist(state: DistributedQubitState, observable) -> torch.Tensor:
+    """Re <psi|P|psi> of a Pauli-string observable on the sharded state without autograd and without
+    a copy of the state when no X / Y factor sits on a global qubit: Z factors on global qubits are a
+    sign that depends on the rank only.  Otherwise P|psi> is built through the exchange path.
+    Works on batched shards; returns a 0-dim tensor (or (B,) for batched shards)."""
+    L = state.log_num_amps_per_node
+    xmask, zmask = observable.pauli_masks()
+    if xmask >> L == 0:
+        sign = -1.0 if bin((zmask >> L) & state.rank).count('1') & 1 else 1.0
+        val = backend.expect_pauli(_view(state), xmask, zmask & ((1 << L) - 1)) * sign     # (B,) float64
+        if state.world_size > 1:
+            dist.all_reduce(val, dist.ReduceOp.SUM)
+        val = val.to(state.amps.real.dtype)
+        return val[0] if state.batch is None else val
+    from copy import deepcopy
+
+    lam = deepcopy(state)
+    dist_apply_prims(lam, observable.prims())
+    return inner_product_dist(lam, state).real
+
+
 def inner_product_dist(bra: DistributedQubitState, ket: DistributedQubitState) -> torch.Tensor:
     """<bra|ket> over all shards (reference: distributed.py:288-294)."""
-    val = backend.inner(bra.amps.view(1, -1), ket.amps.view(1, -1))[0]
+    val = backend.inner(_view(bra), _view(ket))                       # (B,) complex128
     if bra.world_size > 1:
         buf = torch.view_as_real(val.clone())
         dist.all_reduce(buf, dist.ReduceOp.SUM)
         val = torch.view_as_complex(buf)
-    return val.to(bra.amps.dtype)
+    val = val.to(bra.amps.dtype)
+    return val[0] if bra.batch is None else val
 
 
 def measure_dist(state: DistributedQubitState, shots: int = 1024, with_prob: bool = False,
                  wires: int | list[int] | None = None, block_size: int = 2**24) -> dict:
     """Sample bit strings from the sharded state; the result lives on rank 0 (other ranks return {})
     (reference: distributed.py:205-285)."""
+    assert state.batch is None, 'measure_dist works on an un-batched sharded state'
     if state.world_size == 1:
         return measure(state.amps, shots, with_prob, wires, False, block_size)
     n, L, g = state.nqubit, state.log_num_amps_per_node, state.log_num_nodes

@@ -72,7 +72,7 @@ class DistributedQubitState(_ComplexBuffers):
 
     _complex_names = ('amps', 'buffer')
 
-    def __init__(self, nqubit: int) -> None:
+    def __init__(self, nqubit: int, batch: int | None = None) -> None:
         super().__init__()
         self.world_size = comm_get_world_size()
         self.rank = comm_get_rank()
@@ -80,10 +80,12 @@ class DistributedQubitState(_ComplexBuffers):
         assert power_of_2(nqubit) >= self.world_size
         assert 0 <= self.rank < self.world_size
         self.nqubit = nqubit
+        self.batch = batch          # None: 1-D shard as in the reference; B: (B, 2^L) shards, one per sample
         self.log_num_nodes = log_base2(self.world_size)
         self.log_num_amps_per_node = nqubit - self.log_num_nodes
         self.num_amps_per_node = power_of_2(self.log_num_amps_per_node)
-        amps = torch.zeros(self.num_amps_per_node) + 0j
+        shape = (self.num_amps_per_node,) if batch is None else (batch, self.num_amps_per_node)
+        amps = torch.zeros(shape) + 0j
         self.register_buffer('amps', amps)
         self.register_buffer('buffer', torch.zeros_like(amps))
         self.reset()
@@ -91,5 +93,6 @@ class DistributedQubitState(_ComplexBuffers):
     def reset(self) -> None:
         self.amps.zero_()
         self.buffer.zero_()
+        self.__dict__.pop('_phys', None)   # canonical qubit order
         if self.rank == 0:
-            self.amps[0] = 1.0
+            self.amps[..., 0] = 1.0

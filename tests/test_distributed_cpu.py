@@ -175,6 +175,49 @@ def _case_expectation_grad_w4(dq, rank, world):
     assert (d1.grad - d2.grad).abs().max().item() < 1e-4, (d1.grad, d2.grad)
 
 
+def _case_batched_w4(dq, rank, world):
+    """Extension over the reference: a batch of encoded samples on the sharded state -- (B, 2^L) shards,
+    per-sample matrices through global targets / controls, both exchange modes."""
+    import specs
+    from deepquantum_amd.distributed import inner_product_dist
+
+    n, B = 10, 3
+    def add_obs(c):
+        c.observable(0)                     # Z on a global qubit
+        c.observable([1, 5], 'zx')          # global Z, local X
+        c.observable([0, 9], 'yz')          # Y on a global qubit: exchange path
+        c.observable([4, 7], 'xy')          # local only
+
+    dense = specs.build(dq, n, specs.BATCHED10)
+    add_obs(dense)
+    data = torch.rand(B, dense.ndata, generator=torch.Generator().manual_seed(5)) * 6.28
+    with torch.no_grad():
+        ref = dense(data).reshape(B, -1)
+        ref_ev = dense.expectation()
+    per = 2**n // world
+
+    def run():
+        shard = dq.DistributedQubitCircuit(n)
+        _apply_spec(shard, specs.BATCHED10)
+        add_obs(shard)
+        st = shard(data)
+        assert st.amps.shape == (B, per)
+        ev = shard.expectation()
+        assert ev.shape == ref_ev.shape and (ev - ref_ev).abs().max().item() < 1e-5, (ev, ref_ev)
+        err = (st.amps - ref[:, rank * per : (rank + 1) * per]).abs().max().item()
+        assert err < 1e-5, f'rank {rank}: batched shard error {err}'
+        nrm = inner_product_dist(st, st)
+        assert nrm.shape == (B,) and (nrm - 1).abs().max().item() < 1e-5
+        # the same circuit object falls back to the reference's un-batched shard for 1-D data
+        st1 = shard(data[1])
+        assert st1.amps.shape == (per,)
+        assert (st1.amps - ref[1, rank * per : (rank + 1) * per]).abs().max().item() < 1e-5
+        with torch.no_grad():
+            assert (shard.expectation() - ref_ev[1]).abs().max().item() < 1e-5
+
+    _both_modes(dq, run)
+
+
 def _case_measure_w2(dq, rank, world):
     cir = dq.DistributedQubitCircuit(4)
     cir.h(0)
@@ -194,7 +237,7 @@ def _case_measure_w2(dq, rank, world):
 
 @pytest.mark.parametrize('case,world', [('gates_w2', 2), ('gates_w4', 4), ('fused_local_w2', 2),
                                         ('random_remap_w4', 4), ('remap_w8', 8),
-                                        ('expectation_grad_w4', 4), ('measure_w2', 2)])
+                                        ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4)])
 def test_sharded_circuit(case, world):
     _run(case, world)
 
