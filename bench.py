@@ -75,6 +75,21 @@ def build_circuit(dq, n, spec, batch, dtype, device, distributed=False):
     return cir, data.to(device)
 
 
+def device_copy_bandwidth(device, nbytes=1 << 32, reps=5):
+    """Read+write GB/s of a plain device-to-device copy of ``nbytes`` (the achievable-HBM yardstick)."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(n, spec, dtype, budget_s):
     """Oracle (port of the reference's evolve_state path) on this host: first gates of the same
     workload, batch element 0, until ``budget_s`` seconds are spent."""
@@ -178,7 +193,7 @@ def main():
     # dominant kernel: the fused pass -- durations from HIP events recorded on the launch stream
     kernel_ms = [a.elapsed_time(b) for a, b, _ in prof['events']]
     launches = len(kernel_ms)
-    alg_per_launch = (alg_bytes * args.steps / launches) if launches else 0.0
+    alg_per_launch = (alg_bytes / world * args.steps / launches) if launches else 0.0   # this rank's share
     avg_ms = (sum(kernel_ms) / launches) if launches else float('nan')
     achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc runs of this same command,
@@ -193,6 +208,7 @@ def main():
     if tj and os.path.exists(tj):
         traffic = json.load(open(tj)).get('hbm_bytes_per_launch')
     stats = dict(dq.executor.LAST_RUN)
+    copy_gbs = device_copy_bandwidth(device) if rank == 0 else None
 
     if rank == 0:
         total_gate_applies = ngates * args.batch * args.steps
@@ -233,13 +249,17 @@ def main():
                 'launches': launches,
                 'avg_launch_ms': avg_ms,
                 'algorithmic_bytes_per_launch': alg_per_launch,
-                'actual_state_bytes_per_launch': 2 * (2**n >> int(math.log2(world))) * amp_bytes * (1 if distributed else args.batch),
+                'actual_state_bytes_per_launch': 2 * (2**n >> int(math.log2(world))) * amp_bytes * args.batch,
                 'note': 'achieved counts every fused gate as its own read+write of the state (SURVEY 8d), so it '
                         'can exceed the HBM peak; actual_state_bytes_per_launch / avg_launch_ms is the physical rate',
             },
         }
         line['roofline']['physical_GBs'] = (line['roofline']['actual_state_bytes_per_launch'] / (avg_ms * 1e-3) / 1e9
                                             if launches else None)
+        # also quote the physical rate against an in-framework device copy measured on this box
+        line['roofline']['device_copy_GBs'] = copy_gbs
+        if launches and copy_gbs:
+            line['roofline']['physical_frac_of_copy'] = line['roofline']['physical_GBs'] / copy_gbs
         if out is not None:
             line['config']['expectation_Z0_sample0'] = float(out.reshape(-1)[0])
         if not args.no_cpu_baseline and not distributed:

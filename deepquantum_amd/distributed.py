@@ -181,23 +181,18 @@ def _one_target_global(state: DistributedQubitState, p: Prim, derivative: bool =
     backend.unpack_axpby(_view(state), send, recv, coef, mask, mask)
 
 
-def _free_local_bits(used: set[int], count: int) -> list[int]:
-    out, p = [], 0
-    while len(out) < count:
-        if p not in used:
-            out.append(p)
-        p += 1
-    return out
-
-
 def _many_target_global(state: DistributedQubitState, p: Prim) -> None:
     """Multi-qubit gate with global targets: swap each global target with a free local qubit, apply
     locally, swap back (Alg. 10; reference: distributed.py:162-202).  Controls stay where they are."""
     L = state.log_num_amps_per_node
     glob_t = [t for t in p.targets if t >= L]
-    used = set(t for t in p.targets if t < L) | set(c for c in p.controls if c < L)
-    subst = dict(zip(glob_t, _free_local_bits(used, len(glob_t))))
-    assert max(subst.values()) < L, 'not enough local qubits to host the gate'
+    loc_t = set(t for t in p.targets if t < L)
+    loc_c = set(c for c in p.controls if c < L)
+    # host qubits: local bits that are not targets, bits that are not controls either first (a control
+    # bit may host a target too: the control then sits on the global position for the duration)
+    hosts = [q for q in range(L) if q not in loc_t and q not in loc_c] + [q for q in range(L) if q in loc_c]
+    assert len(hosts) >= len(glob_t), 'not enough local qubits to host the gate'
+    subst = dict(zip(glob_t, hosts))
     for g, l in subst.items():
         _swap_local_global(state, l, g)
     # after the swaps the former local qubits l sit on the global positions: a control that used one

@@ -171,3 +171,75 @@ def qaoa_circuit(dq, n):
     for i, j in edges:
         cir.observable([i, j], 'zz')
     return cir
+
+
+# ---- F7: sharded semantics (the reference's own tests/test_circuit.py:45-139 circuit + scaled configs 4/5) -
+def dist_test_circuit(dq, cls, n=4, observables=False):
+    """The circuit of the reference's test_qubit_dist / test_qubit_expectation_and_differentiation_dist
+    (tests/test_circuit.py:45-139), rebuilt through the public builder API: 4 qubits, re-uploaded data.
+    With n > 4 the layers span all wires and the explicit gates stay on wires 0..3 (the global ones): the
+    reference treats a controlled multi-qubit gate as a dense gate on controls + targets and needs them all
+    to fit the local qubits (distributed.py:189), so n = 4 only runs un-sharded there."""
+    cir = cls(n, reupload=True)
+    cir.rxlayer(encode=True)
+    cir.rylayer(encode=True)
+    cir.rzlayer(encode=True)
+    cir.u3layer(encode=True)
+    cir.hlayer()
+    cir.cnot_ring()
+    cir.toffoli(0, 1, 2)
+    cir.fredkin(2, 1, 0)
+    cir.swap([2, 3])
+    cir.rx(0, controls=[1, 2, 3], encode=True)
+    cir.ry(1, controls=[0, 2, 3], encode=True)
+    cir.rz(2, controls=[0, 1, 3], encode=True)
+    cir.rxx([0, 1], controls=[2, 3], encode=True)
+    cir.ryy([1, 2], controls=[0, 3], encode=True)
+    cir.rzz([2, 3], controls=[0, 1], encode=True)
+    cir.rxy([3, 0], controls=[1, 2], encode=True)
+    if observables:
+        cir.observable(0)
+        cir.observable(1, 'x')
+        cir.observable([2, 3], 'xy')
+    return cir
+
+
+def config4_circuit(dq, cls, n, depth=6, seed=1234):
+    """BASELINE config 4 scaled down: the generator circuit plus a CNOT with a global control and one
+    with a global target."""
+    cir = cls(n)
+    for method, args, kwargs in random_spec(n, depth, seed):
+        getattr(cir, method)(*args, **kwargs)
+    cir.cx(0, n - 1)
+    cir.cx(n - 1, 0)
+    cir.observable(0)
+    return cir
+
+
+def config5_circuit(dq, cls, n, depth=3, seed=1234):
+    """BASELINE config 5 scaled down: generator circuit + one QAOA ring step with (gamma, beta) as data,
+    one ZZ observable per ring edge (after examples/qaoa.py:31-44)."""
+    cir = cls(n, reupload=True)
+    for method, args, kwargs in random_spec(n, depth, seed):
+        getattr(cir, method)(*args, **kwargs)
+    cir.hlayer()
+    edges = [(i, (i + 1) % n) for i in range(n)]
+    for i, j in edges:
+        cir.cnot(i, j)
+        cir.rz(j, encode=True)
+        cir.cnot(i, j)
+    cir.rxlayer(encode=True)
+    for i, j in edges:
+        cir.observable([i, j], 'zz')
+    return cir
+
+
+DIST_CASES = {
+    # name: (builder, kwargs, nqubit, data, world sizes)
+    'dist4': dict(builder='dist_test_circuit', kwargs={'observables': True}, nqubit=4,
+                  data=[0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0], worlds=(1,)),
+    'dist7': dict(builder='dist_test_circuit', kwargs={'n': 7, 'observables': True}, nqubit=7,
+                  data=[0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0], worlds=(1, 2, 4)),
+    'config4_n8': dict(builder='config4_circuit', kwargs={'n': 8}, nqubit=8, data=None, worlds=(1, 4)),
+    'config5_n9': dict(builder='config5_circuit', kwargs={'n': 9}, nqubit=9, data=[0.37, 1.21], worlds=(1, 8)),
+}

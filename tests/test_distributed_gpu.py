@@ -140,6 +140,26 @@ def _case_adjoint_grad(dq, rank, world):
     assert (d1.grad - d2.grad).abs().max().item() < 1e-4, (d1.grad, d2.grad)
 
 
-@pytest.mark.parametrize('case,world', [('random_c64', 2), ('random_c64', 4), ('batched_c128', 4), ('adjoint_grad', 2)])
+def _case_golden(dq, rank, world):
+    """Reference-made fixtures (real DistributedQubitCircuit under gloo) vs. the HIP kernels."""
+    from deepquantum_amd import distributed as D
+    from test_distributed_cpu import _golden_dist_check
+
+    names = {2: ['dist4', 'dist7'], 4: ['dist4', 'dist7', 'config4_n8'], 8: ['config5_n9']}[world]
+    for mode in ('pairwise', 'remap'):
+        D.CONFIG['mode'] = mode
+        _golden_dist_check(dq, rank, world, names, device='cuda')
+    D.CONFIG['mode'] = 'remap'
+
+
+def test_reference_dist_tests_on_gpu_world_of_one():
+    import deepquantum_amd as dq
+    from test_distributed_cpu import _golden_dist_check
+
+    sys.path.insert(0, os.path.join(HERE, 'golden'))
+    _golden_dist_check(dq, 0, 1, ['dist4', 'dist7', 'config4_n8', 'config5_n9'], device='cuda')
+
+
+@pytest.mark.parametrize('case,world', [('golden', 2), ('golden', 4), ('golden', 8), ('random_c64', 2), ('random_c64', 4), ('batched_c128', 4), ('adjoint_grad', 2)])
 def test_sharded_on_gpu(case, world):
     _run(case, world)
