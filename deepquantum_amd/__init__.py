@@ -19,7 +19,7 @@ from .communication import (
 from .gate import (
     CNOT, ArbitraryGate, Barrier, CombinedSingleGate, DoubleControlGate, DoubleGate, Fredkin, Hadamard,
     HamiltonianGate, Identity, ImaginarySwap, LatentGate, ParametricDoubleGate, ParametricSingleGate, PauliX, PauliY,
-    PauliZ, PhaseShift, ProjectionJ, ReconfigurableBeamSplitter, Rx, Rxx, Rxy, Ry, Ryy, Rz, Rzz, SDaggerGate, SGate,
+    PauliZ, PhaseShift, ProjectionJ, ReconfigurableBeamSplitter, Reset, Rx, Rxx, Rxy, Ry, Ryy, Rz, Rzz, SDaggerGate, SGate,
     SingleGate, Swap, TDaggerGate, TGate, Toffoli, TripleGate, U3Gate, UAnyGate,
 )
 from .layer import (

@@ -25,7 +25,7 @@ from torch import nn
 from . import executor, qmath
 from .gate import (
     CNOT, Barrier, Fredkin, Hadamard, HamiltonianGate, ImaginarySwap, LatentGate, PauliX, PauliY, PauliZ,
-    PhaseShift, ProjectionJ, ReconfigurableBeamSplitter, Rx, Rxx, Rxy, Ry, Ryy, Rz, Rzz, SDaggerGate, SGate, Swap,
+    PhaseShift, ProjectionJ, ReconfigurableBeamSplitter, Reset, Rx, Rxx, Rxy, Ry, Ryy, Rz, Rzz, SDaggerGate, SGate, Swap,
     TDaggerGate, TGate, Toffoli, U3Gate, UAnyGate,
 )
 from .layer import CnotLayer, CnotRing, HLayer, Observable, RxLayer, RyLayer, RzLayer, U3Layer, XLayer, YLayer, ZLayer
@@ -128,6 +128,21 @@ class QubitCircuit(Operation):
             out.extend(op.prims(decompose))
         return out
 
+    def _run_operators(self, flat: torch.Tensor) -> torch.Tensor:
+        """All operators on a (B, 2**n) state: maximal stretches of gates go to the executor (fused passes),
+        state-dependent operations (``Reset``) run between them."""
+        if not any(getattr(op, '_state_dependent', False) for op in self.operators):
+            return executor.run(flat, self.prims())
+        x, pending = flat, []
+        for op in self.operators:
+            if getattr(op, '_state_dependent', False):
+                if pending:
+                    x, pending = executor.run(x, pending), []
+                x = op.apply_flat(x)
+            else:
+                pending.extend(op.prims())
+        return executor.run(x, pending) if pending else x
+
     def _precompute_matrices(self) -> list:
         """Evaluate the matrices of all single-parameter gates of one class in ONE vectorised call
         (identical element-wise arithmetic, hence bit-identical values) instead of a handful of tiny
@@ -195,7 +210,7 @@ class QubitCircuit(Operation):
             flat = flat.expand(data.shape[0], dim)
         touched = self._precompute_matrices()
         try:
-            x = executor.run(flat, self.prims())
+            x = self._run_operators(flat)
         finally:
             for g in touched:
                 g.__dict__['_precomputed'] = None
@@ -577,13 +592,18 @@ class QubitCircuit(Operation):
     def barrier(self, wires=None):
         self.add(Barrier(nqubit=self.nqubit, wires=wires))
 
+    def reset(self, wires=None, postselect=0):
+        """Add a reset operation (reference: circuit.py:1603-1607)."""
+        assert not self.den_mat and not self.mps, 'Currently NOT supported'
+        self.add(Reset(nqubit=self.nqubit, wires=wires, postselect=postselect))
+
     # explicitly out of scope -----------------------------------------------------------------------
     def _out_of_scope(self, *a, **k):
         raise NotImplementedError('outside the accelerated statevector path (SURVEY section 2, OUT OF SCOPE)')
 
     qasm = pattern = draw = transform_cut2move = get_subexperiments = _out_of_scope
     bit_flip = phase_flip = depolarizing = pauli = amp_damp = phase_damp = gen_amp_damp = _out_of_scope
-    reset = cut = move = _out_of_scope
+    cut = move = _out_of_scope
 
 
 class DistributedQubitCircuit(QubitCircuit):

@@ -849,6 +849,71 @@ class HamiltonianGate(ArbitraryGate):
         self.update_matrix()
 
 
+class Reset(Gate):
+    r"""Reset qubits to :math:`|0\rangle` (reference: gate.py:3027-3094).
+
+    ``postselect`` in (0, 1): project every wire on that outcome (or on the other one if its probability
+    is exactly zero), renormalise and move the amplitude to :math:`|0\rangle` -- per wire one marginal
+    reduction and one (non-unitary, per-sample) 2x2 gate launch.  ``postselect=None``: sample the joint
+    outcome of the wires, project, renormalise, relabel to :math:`|0..0\rangle`.  The matrices depend on the
+    state, so a circuit containing a ``Reset`` runs as separate fused stretches around it."""
+
+    _state_dependent = True
+
+    def __init__(self, nqubit=1, wires=None, postselect=0, tsr_mode=False):
+        if wires is None:
+            wires = list(range(nqubit))
+        super().__init__(name='Reset', nqubit=nqubit, wires=wires, tsr_mode=tsr_mode)
+        self.postselect = postselect
+
+    def prims(self, decompose: bool = True) -> list[Prim]:
+        raise NotImplementedError('Reset depends on the state: it has no fixed matrix / unitary')
+
+    def apply_flat(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, 2**n) -> (B, 2**n)."""
+        from . import ops
+
+        n = self.nqubit
+        if len(self.wires) == n:
+            out = torch.zeros_like(x)
+            out[:, 0] = 1
+            return out
+        if self.postselect in (0, 1):
+            ps = self.postselect
+            for wire in self.wires:
+                bit = n - 1 - wire
+                probs = ops.marginal(x, [bit])                                  # (B, 2)
+                mask = 1 - torch.sign(probs[:, ps])
+                norm = torch.sqrt(probs[:, ps] + mask)
+                keep, other = (1 - mask) / norm, mask / norm
+                zero = torch.zeros_like(keep)
+                row0 = torch.stack([keep, other] if ps == 0 else [other, keep], dim=-1)
+                mats = torch.stack([row0, torch.stack([zero, zero], dim=-1)], dim=-2) + 0j   # (B, 2, 2)
+                x = ops.apply_gate(x, mats, [bit], [])
+            return x
+        assert self.postselect is None, 'postselect must be 0, 1 or None'
+        wires = sorted(self.wires)
+        bits = [n - 1 - w for w in wires]
+        probs = ops.marginal(x, bits)                                          # (B, 2**k)
+        sample = torch.multinomial(probs.detach().clamp_min(0), 1)             # (B, 1)
+        amp = torch.gather(probs, 1, sample) ** -0.5                           # (B, 1)
+        d = probs.shape[-1]
+        mats = torch.zeros(x.shape[0], d, d, dtype=probs.dtype, device=x.device)
+        mats = mats.index_put((torch.arange(x.shape[0], device=x.device), torch.zeros_like(sample[:, 0]),
+                               sample[:, 0]), amp[:, 0]) + 0j
+        return ops.apply_gate(x, mats, bits, [])
+
+    def op_state(self, x: torch.Tensor) -> torch.Tensor:
+        shape = x.shape
+        return self.apply_flat(x.reshape(shape[0], -1)).reshape(shape)
+
+    def op_dist_state(self, x):
+        raise NotImplementedError('Reset on a sharded state is not supported (nor is it in the reference)')
+
+    def get_unitary(self) -> torch.Tensor:
+        raise NotImplementedError('Reset is not unitary')
+
+
 class Barrier(Gate):
     """No-op separator (reference: gate.py:3097-3126)."""
 

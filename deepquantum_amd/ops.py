@@ -148,3 +148,31 @@ def expect_pauli(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
     if not _is_batched(state) and not state.is_contiguous():
         state = state.contiguous()
     return _ExpectPauli.apply(state, int(xmask), int(zmask))
+
+
+class _Marginal(torch.autograd.Function):
+    """p[b, k] = sum over amplitudes whose ``bits`` spell k of |psi_b|^2 (bits[0] = MSB of k)."""
+
+    @staticmethod
+    def forward(state: torch.Tensor, bits: tuple) -> torch.Tensor:
+        return backend.marginal(state, bits).to(state.real.dtype)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        state, ctx.bits = inputs
+        ctx.save_for_backward(state)
+
+    @staticmethod
+    def backward(ctx, g: torch.Tensor):
+        (state,) = ctx.saved_tensors
+        # d p_k / d conj(psi_i) = psi_i [bits(i) = k]; real loss of a complex tensor: grad = 2 * that,
+        # i.e. a diagonal "gate" diag(2 g[b, :]) on the measured bits
+        diag = (2.0 * g).to(state.dtype).diag_embed()
+        return backend.apply_gate(state, diag.contiguous(), ctx.bits, ()), None
+
+
+def marginal(state: torch.Tensor, bits: Sequence[int]) -> torch.Tensor:
+    """Differentiable marginal distribution over ``bits`` of a contiguous (B, 2**n) state."""
+    if not state.is_contiguous():
+        state = state.contiguous()
+    return _Marginal.apply(state, tuple(int(b) for b in bits))

@@ -171,6 +171,29 @@ def probabilities(state: torch.Tensor, wires: Sequence[int] | None = None) -> to
 
 # --------------------------------------------------------------------------------------------------
 # the seeded random H / Rx / CNOT generator of the benchmark configs.
+def reset_state(state: torch.Tensor, nqubit: int, wires: Sequence[int], postselect: int = 0) -> torch.Tensor:
+    """Reset.op_state for postselect in (0, 1) (gate.py:3047-3066) on a (B, 2**n) state: per wire, keep
+    the postselected branch (the other one if its probability is exactly 0), renormalise, relabel to |0>."""
+    b = state.shape[0]
+    if len(wires) == nqubit:
+        out = torch.zeros_like(state)
+        out[:, 0] = 1
+        return out
+    x = state.reshape([b] + [2] * nqubit)
+    for wire in wires:
+        pm_shape = list(range(1, nqubit + 1))
+        pm_shape.remove(wire + 1)
+        pm_shape = [wire + 1] + pm_shape + [0]
+        x = x.permute(pm_shape)
+        probs = (x.abs() ** 2).sum(list(range(1, nqubit)))
+        mask = 1 - torch.sign(probs[postselect])
+        norm = torch.sqrt(probs[postselect] + mask)
+        state0 = ((1 - mask) * x[postselect] + mask * x[1 - postselect]) / norm
+        x = torch.stack([state0, torch.zeros_like(state0)])
+        x = x.permute(inverse_permutation(pm_shape))
+    return x.reshape(b, -1)
+
+
 def random_circuit_spec(nqubit: int, depth: int, seed: int = 1234) -> list[tuple]:
     """Returns [('h', q), ('rx', q, theta), ('cnot', q, t), ...] -- n * depth gates."""
     rng = random.Random(seed)

@@ -28,6 +28,63 @@ def gold(key):
     return torch.from_numpy(golden()[key])
 
 
+_GOLDEN_EXTRA = None
+
+
+def gold_extra(key):
+    global _GOLDEN_EXTRA
+    if _GOLDEN_EXTRA is None:
+        _GOLDEN_EXTRA = np.load(os.path.join(HERE, 'golden', 'golden_extra.npz'))
+    return torch.from_numpy(_GOLDEN_EXTRA[key])
+
+
+def check_reset_against_golden(dq, device=None):
+    """Reset (gate.py:3027-3094): the reference's outputs for whole circuits, for the gate on given inputs,
+    and for a batched circuit with gradients through two resets (tests/golden/make_golden_extra.py)."""
+    for name, spec in specs.RESET_CASES.items():
+        for prec in ('c64', 'c128'):          # the reference cannot run these in c128; same numbers expected
+            cir = specs.build(dq, 5, spec)
+            cir.observable(0)
+            cir.observable([1, 2], 'xz')
+            if device is not None:
+                cir.to(device)
+            if prec == 'c128':
+                cir.to(torch.double)
+            with torch.no_grad():
+                st = cir().reshape(-1).cpu()
+                ev = cir.expectation().cpu()
+            assert (st - gold_extra(f'{name}/c64/state')).abs().max().item() < 1e-5, (name, prec)
+            assert (ev - gold_extra(f'{name}/c64/expectation')).abs().max().item() < 1e-5, (name, prec)
+    for i, (wires, ps, _kind) in enumerate(specs.RESET_GATE_CASES):
+        psi = gold_extra(f'resetgate/{i}/in')
+        gate = dq.Reset(nqubit=4, wires=wires, postselect=ps, tsr_mode=True)
+        x = psi.reshape([2] + [2] * 4)
+        out = gate(x.to(device) if device is not None else x).reshape(2, -1).cpu()
+        assert (out - gold_extra(f'resetgate/{i}/out')).abs().max().item() < 1e-5, (i, wires, ps)
+    cir = dq.QubitCircuit(4)
+    cir.hlayer()
+    cir.rx(0, encode=True)
+    cir.ry(1, encode=True)
+    cir.cnot(0, 2)
+    cir.cnot(1, 3)
+    cir.reset([2], postselect=0)
+    cir.crx(0, 2, encode=True)
+    cir.reset([3], postselect=1)
+    cir.observable(0)
+    cir.observable([1, 2], 'zx')
+    data = gold_extra('reset_batched/data').clone()
+    if device is not None:
+        cir.to(device)
+        data = data.to(device)
+    data.requires_grad_(True)
+    state = cir(data=data)
+    ev = cir.expectation()
+    ev.sum().backward()
+    assert (state.reshape(3, -1).detach().cpu() - gold_extra('reset_batched/state')).abs().max().item() < 1e-5
+    assert (ev.detach().cpu() - gold_extra('reset_batched/expectation')).abs().max().item() < 1e-5
+    assert (data.grad.cpu() - gold_extra('reset_batched/grad')).abs().max().item() < 1e-4
+
+
 def build_circuit(dq, name, prec, device=None):
     c = specs.CIRCUITS[name]
     cir = specs.build(dq, c['nqubit'], c['spec'])

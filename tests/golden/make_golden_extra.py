@@ -1,0 +1,67 @@
+"""Further golden fixtures made by running the REAL reference here (same mechanism as make_golden.py, kept in
+a separate file so the large n = 24 pin need not be regenerated): Reset cases (batched encoders included).
+
+usage: python tests/golden/make_golden_extra.py
+"""
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import specs  # noqa: E402
+from make_golden import import_reference, to_np  # noqa: E402
+
+
+def main():
+    dq = import_reference()
+    out = {}
+    for name, spec in specs.RESET_CASES.items():
+        for prec in ('c64',):   # Reset.to(torch.double) raises in the reference (operation.py:166), like Barrier
+            cir = specs.build(dq, 5, spec)
+            cir.observable(0)
+            cir.observable([1, 2], 'xz')
+            state = cir()
+            out[f'{name}/{prec}/state'] = to_np(state.reshape(-1))
+            out[f'{name}/{prec}/expectation'] = to_np(cir.expectation())
+    # the Reset gate on given inputs (batch of 2, 4 qubits, tensor representation in and out)
+    g = torch.Generator().manual_seed(77)
+    for i, (wires, ps, kind) in enumerate(specs.RESET_GATE_CASES):
+        psi = torch.randn(2, 16, generator=g) + 1j * torch.randn(2, 16, generator=g)
+        if kind != 'random':       # zero the branch with wire 2 = 0 (bit_set) or = 1 (bit_clear)
+            keep = 1 if kind == 'bit_set' else 0
+            idx = torch.arange(16)
+            psi[:, ((idx >> 1) & 1) != keep] = 0
+        psi = (psi / psi.norm(dim=-1, keepdim=True)).to(torch.cfloat)
+        gate = dq.gate.Reset(nqubit=4, wires=wires, postselect=ps, tsr_mode=True)
+        out[f'resetgate/{i}/in'] = to_np(psi)
+        out[f'resetgate/{i}/out'] = to_np(gate(psi.reshape([2] + [2] * 4)).reshape(2, -1))
+    # batched data through a reset, gradient w.r.t. the data
+    cir = dq.QubitCircuit(4)
+    cir.hlayer()
+    cir.rx(0, encode=True)
+    cir.ry(1, encode=True)
+    cir.cnot(0, 2)
+    cir.cnot(1, 3)
+    cir.reset([2], postselect=0)
+    cir.crx(0, 2, encode=True)
+    cir.reset([3], postselect=1)
+    cir.observable(0)
+    cir.observable([1, 2], 'zx')
+    data = torch.tensor([[0.3, 1.2, 0.5], [2.0, -0.7, 1.1], [0.0, 0.4, 3.0]], requires_grad=True)
+    state = cir(data=data)
+    ev = cir.expectation()
+    ev.sum().backward()
+    out['reset_batched/data'] = to_np(data)
+    out['reset_batched/state'] = to_np(state.reshape(3, -1))
+    out['reset_batched/expectation'] = to_np(ev)
+    out['reset_batched/grad'] = to_np(data.grad)
+    np.savez_compressed(os.path.join(HERE, 'golden_extra.npz'), **out)
+    print('wrote golden_extra.npz', os.path.getsize(os.path.join(HERE, 'golden_extra.npz')), 'bytes;', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()

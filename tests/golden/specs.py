@@ -243,3 +243,22 @@ DIST_CASES = {
     'config4_n8': dict(builder='config4_circuit', kwargs={'n': 8}, nqubit=8, data=None, worlds=(1, 4)),
     'config5_n9': dict(builder='config5_circuit', kwargs={'n': 9}, nqubit=9, data=[0.37, 1.21], worlds=(1, 8)),
 }
+
+
+# ---- Reset (gate.py:3027-3094): deterministic cases ------------------------------------------------------
+_RESET_PREFIX = [('hlayer', [], {}), ('rx', [0, 0.7], {}), ('ry', [2, 1.3], {}), ('cnot', [0, 1], {}),
+                 ('cnot', [2, 3], {}), ('rzz', [[1, 4], 0.9], {}), ('u3', [3, [0.4, 0.5, 0.6]], {})]
+RESET_CASES = {
+    'reset_ps0': _RESET_PREFIX + [('reset', [[1, 3]], {'postselect': 0}), ('h', [1], {}), ('cnot', [1, 2], {})],
+    'reset_ps1': _RESET_PREFIX + [('reset', [2], {'postselect': 1}), ('ry', [2, 0.3], {})],
+    # the postselected outcome has probability exactly 0 -> the other branch is taken (gate.py:3061-3063)
+    'reset_ps1_empty': [('h', [0], {}), ('cnot', [0, 1], {}), ('reset', [2], {'postselect': 1}), ('h', [2], {})],
+    'reset_all': _RESET_PREFIX + [('reset', [], {}), ('h', [0], {})],
+    # sampled reset whose outcome is certain: wires 1, 3 are in |1>, |0>
+    'reset_sampled_certain': [('h', [0], {}), ('x', [1], {}), ('cnot', [0, 2], {}),
+                              ('reset', [[3, 1]], {'postselect': None}), ('h', [1], {})],
+}
+
+# Reset applied to given input states (pins the oracle's restatement directly): (wires, postselect, kind of input)
+RESET_GATE_CASES = [([1], 0, 'random'), ([0, 3], 1, 'random'), ([2], 0, 'bit_set'), ([2], 1, 'bit_clear'),
+                    ([0, 1, 2, 3], 0, 'random'), ([3, 1], 1, 'random')]

@@ -193,3 +193,27 @@ def test_torch_vmap_over_the_circuit_matches_native_batching(cpu_backend):
     states = torch.stack([cir.init_state.state] * 5)
     vm2 = torch.vmap(cir._forward_helper)(data, states)
     assert (vm2 - native).abs().max().item() < 1e-6
+
+
+def test_reset_matches_reference(cpu_backend):
+    from _helpers import check_reset_against_golden
+
+    check_reset_against_golden(dq)
+
+
+def test_reset_sampled_is_a_valid_collapse(cpu_backend):
+    """postselect=None samples the outcome: whatever it is, the reset wires end in |0>, the state is
+    normalised, and the remaining wires carry one of the two conditional states."""
+    torch.manual_seed(3)
+    cir = dq.QubitCircuit(3)
+    cir.h(0)
+    cir.cnot(0, 1)
+    cir.ry(2, 0.4)
+    cir.reset([1], postselect=None)
+    seen = set()
+    for _ in range(20):
+        st = cir().reshape(2, 2, 2)
+        assert abs((st.abs() ** 2).sum().item() - 1) < 1e-5
+        assert st[:, 1, :].abs().max().item() == 0
+        seen.add(int(st[1, 0, :].abs().max().item() > 0.5))     # wire 0 collapsed with wire 1
+    assert seen == {0, 1}

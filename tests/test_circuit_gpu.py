@@ -205,3 +205,9 @@ def test_torch_vmap_over_the_circuit_on_gpu():
         vm = torch.vmap(cir._forward_helper, in_dims=(0, None))(data, cir.init_state.state)
     assert (vm - native).abs().max().item() < 1e-6
     assert ev.shape == (7, 1)
+
+
+def test_reset_matches_reference_on_gpu():
+    from _helpers import check_reset_against_golden
+
+    check_reset_against_golden(dq, device=dev())

@@ -5,7 +5,7 @@ agree to the last few ulps (bit-exact in practice; BLAS thread count may reorder
 import pytest
 import torch
 
-from _helpers import CDTYPE, gold, specs
+from _helpers import CDTYPE, gold, gold_extra, specs
 from oracle import statevec_oracle as oracle
 
 
@@ -88,3 +88,9 @@ def test_oracle_large_pin_n24():
     assert abs((state.abs() ** 2).sum().item() - gold('pin24/norm2').item()) < 1e-12
     ev = oracle.expectation_pauli(state.contiguous(), [0], 'z')
     assert abs(ev.item() - gold('pin24/expectation_z0').item()) < 1e-12
+
+
+def test_oracle_reset_matches_reference():
+    for i, (wires, ps, _kind) in enumerate(specs.RESET_GATE_CASES):
+        out = oracle.reset_state(gold_extra(f'resetgate/{i}/in'), 4, wires, ps)
+        assert (out - gold_extra(f'resetgate/{i}/out')).abs().max().item() < 1e-6, (i, wires, ps)
