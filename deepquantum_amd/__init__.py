@@ -16,6 +16,10 @@ from .circuit import DistributedQubitCircuit, QubitCircuit
 from .communication import (
     cleanup_distributed, comm_exchange_arrays, comm_get_rank, comm_get_world_size, setup_distributed,
 )
+from .ansatz import (
+    HHL, Ansatz, ControlledMultiplier, ControlledUa, NumberEncoder, PhiAdder, PhiModularAdder,
+    QuantumConvolutionalNeuralNetwork, QuantumFourierTransform, QuantumPhaseEstimationSingleQubit, RandomCircuitG3, ShorCircuit, ShorCircuitFor15,
+)
 from .gate import (
     CNOT, ArbitraryGate, Barrier, CombinedSingleGate, DoubleControlGate, DoubleGate, Fredkin, Hadamard,
     HamiltonianGate, Identity, ImaginarySwap, LatentGate, ParametricDoubleGate, ParametricSingleGate, PauliX, PauliY,

@@ -59,6 +59,17 @@ def main():
     out['reset_batched/state'] = to_np(state.reshape(3, -1))
     out['reset_batched/expectation'] = to_np(ev)
     out['reset_batched/grad'] = to_np(data.grad)
+    # ansatz library: final states (and the parameters of the QCNN, which are drawn at random)
+    for name, builder in specs.ANSATZ_CASES.items():
+        cir = builder(dq)
+        out[f'ansatz/{name}/state'] = to_np(cir().reshape(-1))
+        out[f'ansatz/{name}/ngate'] = np.array(len(cir.operators))
+    torch.manual_seed(11)
+    qcnn = dq.QuantumConvolutionalNeuralNetwork(8, 2)
+    for i, prm in enumerate(qcnn.parameters()):
+        out[f'ansatz/qcnn/param{i}'] = to_np(prm)
+    out['ansatz/qcnn/nparam'] = np.array(len(list(qcnn.parameters())))
+    out['ansatz/qcnn/state'] = to_np(qcnn().reshape(-1))
     np.savez_compressed(os.path.join(HERE, 'golden_extra.npz'), **out)
     print('wrote golden_extra.npz', os.path.getsize(os.path.join(HERE, 'golden_extra.npz')), 'bytes;', len(out), 'arrays')
 

@@ -262,3 +262,67 @@ RESET_CASES = {
 # Reset applied to given input states (pins the oracle's restatement directly): (wires, postselect, kind of input)
 RESET_GATE_CASES = [([1], 0, 'random'), ([0, 3], 1, 'random'), ([2], 0, 'bit_set'), ([2], 1, 'bit_clear'),
                     ([0, 1, 2, 3], 0, 'random'), ([3, 1], 1, 'random')]
+
+
+# ---- ansatz library (reference ansatz.py): name -> builder(dq) -> circuit ---------------
+def _enc_then(dq, nq, parts):
+    cir = parts[0]
+    for p in parts[1:]:
+        cir = cir + p
+    return cir
+
+
+def _hhl(dq):
+    return dq.HHL(3, [[1.0, -1 / 3], [-1 / 3, 1.0]], t0=0.75)
+
+
+def _qpe(dq):
+    return dq.ansatz.QuantumPhaseEstimation(5, 3, _unitary(2, 21))
+
+
+def _g3(dq):
+    random.seed(7)
+    return dq.RandomCircuitG3(6, 40)
+
+
+def _cua(dq):
+    nreg = 4
+    nq = 2 * nreg + 2
+    return dq.NumberEncoder(nq, 3, [0, nreg - 1]) + dq.ControlledUa(nq, 8, 15, [0, nreg - 1], list(range(nreg, 2 * nreg + 2)))
+
+
+def _cmult(dq):
+    nx, nb = 4, 5
+    nq = nx + nb + 1
+    return (dq.NumberEncoder(nq, 14, [0, nx - 1]) + dq.NumberEncoder(nq, 1, [nx, nq - 2])
+            + dq.ControlledMultiplier(nq, 2, 15, [0, nq - 2], nx, [nq - 1]))
+
+
+def _pma(dq):
+    nq = 6
+    mm = [0, nq - 2]
+    qft = dq.QuantumFourierTransform(nq, mm, reverse=True)
+    return dq.NumberEncoder(nq, 5, mm) + qft + dq.PhiModularAdder(nq, 1, 8, mm, [nq - 1]) + qft.inverse()
+
+
+ANSATZ_CASES = {
+    'qft5': lambda dq: dq.NumberEncoder(5, 11) + dq.QuantumFourierTransform(5),
+    'qft5_reverse_barrier': lambda dq: dq.NumberEncoder(5, 19) + dq.QuantumFourierTransform(5, reverse=True, show_barrier=True),
+    'qft_sub': lambda dq: dq.NumberEncoder(6, 5, [1, 4]) + dq.QuantumFourierTransform(6, [1, 4]),
+    'iqft5': lambda dq: dq.NumberEncoder(5, 6) + dq.QuantumFourierTransform(5).inverse(),
+    'qpe_single_exact': lambda dq: dq.QuantumPhaseEstimationSingleQubit(3, 1 / 8),
+    'qpe_single_inexact': lambda dq: dq.QuantumPhaseEstimationSingleQubit(4, 0.3),
+    'phi_adder': lambda dq: (dq.NumberEncoder(5, 1) + dq.QuantumFourierTransform(5, reverse=True) + dq.PhiAdder(5, 8)
+                             + dq.QuantumFourierTransform(5, reverse=True).inverse()),
+    'phi_adder_ctrl': lambda dq: (dq.NumberEncoder(6, 35) + dq.QuantumFourierTransform(6, [1, 5], reverse=True)
+                                  + dq.PhiAdder(6, 13, [1, 5], controls=[0])),
+    'phi_mod_adder': _pma,
+    'cmult': _cmult,
+    'cua': _cua,
+    'shor15_special_a7': lambda dq: dq.ShorCircuitFor15(4, 7),
+    'shor15_special_a11': lambda dq: dq.ShorCircuitFor15(3, 11),
+    'shor15_general': lambda dq: dq.ShorCircuit(15, 3, 7),
+    'hhl': _hhl,
+    'qpe': _qpe,
+    'g3': _g3,
+}

@@ -217,3 +217,16 @@ def test_reset_sampled_is_a_valid_collapse(cpu_backend):
         assert st[:, 1, :].abs().max().item() == 0
         seen.add(int(st[1, 0, :].abs().max().item() > 0.5))     # wire 0 collapsed with wire 1
     assert seen == {0, 1}
+
+
+def test_ansatz_states_match_reference(cpu_backend):
+    from _ansatz_checks import check_qcnn, check_states
+
+    check_states(dq)
+    check_qcnn(dq)
+
+
+def test_ansatz_known_answers(cpu_backend):
+    from _ansatz_checks import check_known_answers
+
+    check_known_answers(dq, shor_ncount=3)      # 18-qubit Shor (ncount = 8) runs in the GPU suite

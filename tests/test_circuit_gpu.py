@@ -211,3 +211,14 @@ def test_reset_matches_reference_on_gpu():
     from _helpers import check_reset_against_golden
 
     check_reset_against_golden(dq, device=dev())
+
+
+def test_ansatz_library_on_gpu():
+    """QFT / QPE / Beauregard arithmetic / Shor / HHL / QCNN built with the reference's
+    constructors: amplitudes equal to the reference's, known answers of its tests/test_ansatz.py (Shor with
+    8 counting qubits = 18 qubits, ~6000 multi-controlled phase gates through the fused passes)."""
+    from _ansatz_checks import check_known_answers, check_qcnn, check_states
+
+    check_states(dq, device=dev())
+    check_qcnn(dq, device=dev())
+    check_known_answers(dq, device=dev(), shor_ncount=8)
