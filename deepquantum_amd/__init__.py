@@ -20,6 +20,9 @@ from .ansatz import (
     HHL, Ansatz, ControlledMultiplier, ControlledUa, NumberEncoder, PhiAdder, PhiModularAdder,
     QuantumConvolutionalNeuralNetwork, QuantumFourierTransform, QuantumPhaseEstimationSingleQubit, RandomCircuitG3, ShorCircuit, ShorCircuitFor15,
 )
+from .channel import (
+    AmplitudeDamping, BitFlip, Depolarizing, GeneralizedAmplitudeDamping, Pauli, PhaseDamping, PhaseFlip,
+)
 from .gate import (
     CNOT, ArbitraryGate, Barrier, CombinedSingleGate, DoubleControlGate, DoubleGate, Fredkin, Hadamard,
     HamiltonianGate, Identity, ImaginarySwap, LatentGate, ParametricDoubleGate, ParametricSingleGate, PauliX, PauliY,
@@ -30,7 +33,7 @@ from .layer import (
     CnotLayer, CnotRing, DoubleLayer, HLayer, Observable, ParametricSingleLayer, RxLayer, RyLayer, RzLayer, SingleLayer,
     U3Layer, XLayer, YLayer, ZLayer,
 )
-from .operation import Gate, Layer, Operation
+from .operation import Channel, Gate, Layer, Operation
 from .qmath import amplitude_encoding, expectation, measure, multi_kron
 from .state import DistributedQubitState, QubitState
 from .utils import dtype_map

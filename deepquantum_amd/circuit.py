@@ -29,7 +29,10 @@ from .gate import (
     TDaggerGate, TGate, Toffoli, U3Gate, UAnyGate,
 )
 from .layer import CnotLayer, CnotRing, HLayer, Observable, RxLayer, RyLayer, RzLayer, U3Layer, XLayer, YLayer, ZLayer
-from .operation import Gate, Layer, Operation
+from .channel import (
+    AmplitudeDamping, BitFlip, Depolarizing, GeneralizedAmplitudeDamping, Pauli, PhaseDamping, PhaseFlip,
+)
+from .operation import Channel, Gate, Layer, Operation
 from .qmath import amplitude_encoding, sample2expval, slice_state_vector
 from .state import DistributedQubitState, QubitState
 
@@ -49,9 +52,9 @@ class QubitCircuit(Operation):
         chi: int | None = None,
         shots: int = 1024,
     ) -> None:
-        if den_mat or mps:
-            raise NotImplementedError('deepquantum_amd: only the dense statevector path is implemented')
-        super().__init__(name=name, nqubit=nqubit, wires=None, den_mat=False)
+        if mps:
+            raise NotImplementedError('deepquantum_amd: matrix product states are out of scope (SURVEY section 2)')
+        super().__init__(name=name, nqubit=nqubit, wires=None, den_mat=den_mat)
         self.reupload = reupload
         self.mps = False
         self.chi = chi
@@ -70,13 +73,15 @@ class QubitCircuit(Operation):
     def set_init_state(self, init_state: Any) -> None:
         if isinstance(init_state, QubitState):
             assert self.nqubit == init_state.nqubit
+            self.den_mat = init_state.den_mat
             self.init_state = init_state
         else:
-            self.init_state = QubitState(nqubit=self.nqubit, state=init_state)
+            self.init_state = QubitState(nqubit=self.nqubit, state=init_state, den_mat=self.den_mat)
 
     def __add__(self, rhs: 'QubitCircuit') -> 'QubitCircuit':
         assert self.nqubit == rhs.nqubit
-        cir = QubitCircuit(nqubit=self.nqubit, init_state=self.init_state, name=self.name, reupload=self.reupload)
+        cir = QubitCircuit(nqubit=self.nqubit, init_state=self.init_state, name=self.name, den_mat=self.den_mat,
+                           reupload=self.reupload)
         cir.operators = self.operators + rhs.operators
         cir.encoders = self.encoders + rhs.encoders
         cir.observables = rhs.observables
@@ -112,7 +117,8 @@ class QubitCircuit(Operation):
         return amplitude_encoding(data, self.nqubit)
 
     def observable(self, wires: int | list[int] | None = None, basis: str = 'z') -> None:
-        self.observables.append(Observable(nqubit=self.nqubit, wires=wires, basis=basis, tsr_mode=False))
+        self.observables.append(Observable(nqubit=self.nqubit, wires=wires, basis=basis, den_mat=self.den_mat,
+                                           tsr_mode=False))
 
     def reset_observable(self) -> None:
         self.observables = nn.ModuleList()
@@ -131,6 +137,11 @@ class QubitCircuit(Operation):
     def _run_operators(self, flat: torch.Tensor) -> torch.Tensor:
         """All operators on a (B, 2**n) state: maximal stretches of gates go to the executor (fused passes),
         state-dependent operations (``Reset``) run between them."""
+        if self.den_mat:
+            prims = []
+            for op in self.operators:
+                prims.extend(op.dm_prims())
+            return executor.run(flat, prims)
         if not any(getattr(op, '_state_dependent', False) for op in self.operators):
             return executor.run(flat, self.prims())
         x, pending = flat, []
@@ -203,7 +214,7 @@ class QubitCircuit(Operation):
             state = self.init_state
         if isinstance(state, QubitState):
             state = state.state
-        dim = 2**self.nqubit
+        dim = 4**self.nqubit if self.den_mat else 2**self.nqubit
         flat = state.reshape(-1, dim)
         if data is not None and data.ndim == 2 and flat.shape[0] != data.shape[0]:
             assert flat.shape[0] == 1, 'batch of data and batch of states differ'
@@ -217,7 +228,7 @@ class QubitCircuit(Operation):
         if x is flat or (not executor.ops._is_batched(x) and not executor.ops._is_batched(state)
                          and x.data_ptr() == state.data_ptr()):
             x = x.clone()
-        return self.vector_rep(x).squeeze(0)
+        return (self.matrix_rep(x) if self.den_mat else self.vector_rep(x)).squeeze(0)
 
     def encode(self, data: torch.Tensor | None) -> None:
         """Feed ``data`` to the encoders in order; with ``reupload`` the data wraps around
@@ -250,7 +261,7 @@ class QubitCircuit(Operation):
         if self.state is None:
             return None
         return qmath.measure(self.state, shots=shots, with_prob=with_prob, wires=self.wires_measure,
-                             block_size=block_size)
+                             den_mat=self.den_mat, block_size=block_size)
 
     def expectation(self, shots: int | None = None) -> torch.Tensor:
         """Expectation value of every registered observable, stacked on the last dimension
@@ -261,12 +272,12 @@ class QubitCircuit(Operation):
         out = []
         if shots is None:
             for ob in self.observables:
-                out.append(qmath.expectation(self.state, observable=ob))
+                out.append(qmath.expectation(self.state, observable=ob, den_mat=self.den_mat))
         else:
             self.shots = shots
             dtype, device = self.state.real.dtype, self.state.device
             for ob in self.observables:
-                basis_cir = QubitCircuit(nqubit=self.nqubit)
+                basis_cir = QubitCircuit(nqubit=self.nqubit, den_mat=self.den_mat)
                 for wire, b in zip(ob.wires, ob.basis, strict=True):
                     if b == 'x':
                         basis_cir.h(wire)
@@ -339,7 +350,7 @@ class QubitCircuit(Operation):
 
     def inverse(self, encode: bool = False) -> 'QubitCircuit':
         name = self.name + '_inverse' if isinstance(self.name, str) else self.name
-        cir = QubitCircuit(nqubit=self.nqubit, name=name, reupload=self.reupload)
+        cir = QubitCircuit(nqubit=self.nqubit, name=name, den_mat=self.den_mat, reupload=self.reupload)
         for op in reversed(self.operators):
             inv = op.inverse()
             cir.add(inv)
@@ -378,13 +389,20 @@ class QubitCircuit(Operation):
             self.wires_condition = list(set(self.wires_condition + op.wires_condition))
             return
         op.tsr_mode = True
-        if isinstance(op, Gate):
+        if isinstance(op, Channel):
+            assert self.den_mat, 'channels act on density matrices: QubitCircuit(..., den_mat=True)'
+            self.operators.append(op)
+            self.depth[op.wires[0]] += 1
+        elif isinstance(op, Gate):
+            op.den_mat = self.den_mat
             self.operators.append(op)
             for i in op.wires + op.controls:
                 self.depth[i] += 1
             if op.condition:
                 self.wires_condition = list(set(self.wires_condition + op.controls))
         elif isinstance(op, Layer):
+            for gate in op.gates:
+                gate.den_mat = self.den_mat
             self.operators.extend(op.gates)
             for wire in op.wires:
                 for i in wire:
@@ -602,7 +620,33 @@ class QubitCircuit(Operation):
         raise NotImplementedError('outside the accelerated statevector path (SURVEY section 2, OUT OF SCOPE)')
 
     qasm = pattern = draw = transform_cut2move = get_subexperiments = _out_of_scope
-    bit_flip = phase_flip = depolarizing = pauli = amp_damp = phase_damp = gen_amp_damp = _out_of_scope
+
+    # noise channels (density matrices only; reference: circuit.py:1540-1601) ---------------------------
+    def _add_channel(self, cls, wires, inputs, encode) -> None:
+        assert self.den_mat, 'channels act on density matrices: QubitCircuit(..., den_mat=True)'
+        requires_grad = not encode and inputs is None
+        self.add(cls(inputs=inputs, nqubit=self.nqubit, wires=wires, requires_grad=requires_grad), encode=encode)
+
+    def bit_flip(self, wires, inputs=None, encode=False):
+        self._add_channel(BitFlip, wires, inputs, encode)
+
+    def phase_flip(self, wires, inputs=None, encode=False):
+        self._add_channel(PhaseFlip, wires, inputs, encode)
+
+    def depolarizing(self, wires, inputs=None, encode=False):
+        self._add_channel(Depolarizing, wires, inputs, encode)
+
+    def pauli(self, wires, inputs=None, encode=False):
+        self._add_channel(Pauli, wires, inputs, encode)
+
+    def amp_damp(self, wires, inputs=None, encode=False):
+        self._add_channel(AmplitudeDamping, wires, inputs, encode)
+
+    def phase_damp(self, wires, inputs=None, encode=False):
+        self._add_channel(PhaseDamping, wires, inputs, encode)
+
+    def gen_amp_damp(self, wires, inputs=None, encode=False):
+        self._add_channel(GeneralizedAmplitudeDamping, wires, inputs, encode)
     cut = move = _out_of_scope
 
 

@@ -3,8 +3,13 @@
 
 What differs from the reference is everything below ``Gate.forward``: instead of permute / reshape /
 matmul / cat on a (batch, 2, ..., 2) tensor, a gate describes itself as kernel-level primitives
-(:meth:`Gate.prims`) and the executor hands them to the HIP kernels.  Density matrices and MPS are not
-on this path and raise ``NotImplementedError``.
+(:meth:`Gate.prims`) and the executor hands them to the HIP kernels.
+
+Density matrices (``den_mat=True``; reference ``evolve_den_mat`` qmath.py:509-540, ``op_den_mat_control``
+operation.py:233-263, ``Channel`` :525-600) ride the same kernels: rho of n qubits is a 2n-"qubit" vector
+whose high n index bits are the row and low n bits the column, a gate is U on the row bits and conj(U) on the
+column bits (:meth:`Gate.dm_prims`), a channel is the 4x4 superoperator sum_k K_k (x) conj(K_k) on one
+(row bit, column bit) pair.  MPS is not on this path and raises ``NotImplementedError``.
 """
 
 from __future__ import annotations
@@ -92,9 +97,7 @@ class Operation(nn.Module):
         assert -1 < minmax[0] <= minmax[1] < self.nqubit
 
     def _flat_state(self, x: torch.Tensor) -> torch.Tensor:
-        """Any accepted state representation -> contiguous (batch, 2**n)."""
-        if self.den_mat:
-            raise NotImplementedError('deepquantum_amd: the density-matrix path is out of scope (SURVEY section 2)')
+        """Any accepted state representation -> (batch, 2**n), or (batch, 4**n) for density matrices."""
         x = self.tensor_rep(x)
         return x.reshape(x.shape[0], -1)
 
@@ -167,7 +170,18 @@ class Gate(Operation):
         mode = self._kernel_mode if len(self.wires) == 1 else 0
         return [Prim(self._kernel_kind, self.update_matrix(), self._bits(self.wires), self._bits(self.controls), mode)]
 
+    def dm_prims(self, decompose: bool = True) -> list[Prim]:
+        """The gate acting on a vectorised density matrix (row bits n..2n-1, column bits 0..n-1):
+        every statevector primitive once on the row bits and once, complex-conjugated, on the column bits."""
+        return lift_to_density_matrix(self.prims(decompose), self.nqubit)
+
     # ---- forward ------------------------------------------------------------------------------------
+    def op_den_mat(self, x: torch.Tensor) -> torch.Tensor:
+        """(batch, 2, ..., 2) with 2n qubit axes -> same (reference: operation.py:221-263)."""
+        shape = x.shape
+        out = executor.run(x.reshape(shape[0], -1), self.dm_prims(decompose=False))
+        return out.reshape(shape)
+
     def op_state(self, x: torch.Tensor) -> torch.Tensor:
         """(batch, 2, ..., 2) -> same; replaces op_state_base / op_state_control of the reference."""
         shape = x.shape
@@ -185,7 +199,11 @@ class Gate(Operation):
         if isinstance(x, DistributedQubitState):
             return self.op_dist_state(x)
         if self.den_mat:
-            raise NotImplementedError('deepquantum_amd: the density-matrix path is out of scope (SURVEY section 2)')
+            if self.tsr_mode:
+                assert x.ndim == 2 * self.nqubit + 1
+                return self.op_den_mat(x)
+            x = self.op_den_mat(self.tensor_rep(x))
+            return self.matrix_rep(x).squeeze(0)
         if self.tsr_mode:
             assert x.ndim == self.nqubit + 1
             return self.op_state(x)
@@ -211,6 +229,97 @@ class Gate(Operation):
     def extra_repr(self) -> str:
         s = f'wires={self.wires}'
         return s if self.controls == [] else s + f', controls={self.controls}'
+
+
+def lift_to_density_matrix(prims: list[Prim], nqubit: int) -> list[Prim]:
+    """Statevector primitives on n qubits -> primitives on the 2n index bits of vec(rho):
+    rho -> U rho U^dagger is U on the row bits (bit + n) and conj(U) on the column bits."""
+    out: list[Prim] = []
+    for p in prims:
+        out.append(Prim(p.kind, p.matrix, tuple(t + nqubit for t in p.targets),
+                        tuple(c + nqubit for c in p.controls), p.mode))
+        conj = p.matrix if p.kind == 'x' else p.matrix.conj().resolve_conj()
+        out.append(Prim(p.kind, conj, p.targets, p.controls, p.mode))
+    return out
+
+
+class Channel(Operation):
+    r"""Base class of single-qubit noise channels :math:`\rho \to \sum_k K_k \rho K_k^\dagger` with the
+    Kraus operators a function of ``theta`` (error probability :math:`\sin^2\theta`); density matrices only
+    (reference: operation.py:525-600).  On the kernels a channel is ONE non-unitary two-"qubit" gate: the
+    superoperator :math:`\sum_k K_k \otimes \bar K_k` on the (row bit, column bit) pair of its wire."""
+
+    def __init__(self, inputs: Any = None, name: str | None = None, nqubit: int = 1,
+                 wires: int | list[int] | None = None, tsr_mode: bool = False, requires_grad: bool = False) -> None:
+        self.nqubit = nqubit
+        wires = self._convert_indices([0] if wires is None else wires)
+        super().__init__(name=name, nqubit=nqubit, wires=wires, den_mat=True, tsr_mode=tsr_mode)
+        self.npara = 1
+        self.requires_grad = requires_grad
+        self.init_para(inputs)
+
+    @property
+    def prob(self) -> torch.Tensor:
+        """The error probability."""
+        return torch.sin(self.theta) ** 2
+
+    def inputs_to_tensor(self, inputs: Any = None) -> torch.Tensor:
+        while isinstance(inputs, list):
+            inputs = inputs[0]
+        if inputs is None:
+            inputs = torch.rand(1)[0] * torch.pi
+        elif not isinstance(inputs, torch.Tensor):
+            inputs = torch.tensor(inputs, dtype=torch.float)
+        return inputs
+
+    def get_matrix(self, theta: Any) -> torch.Tensor:
+        """The Kraus operators, stacked: (K, 2, 2)."""
+        raise NotImplementedError
+
+    def update_matrix(self) -> torch.Tensor:
+        matrix = self.get_matrix(self.theta)
+        self.matrix = matrix.detach()
+        return matrix
+
+    def init_para(self, inputs: Any = None) -> None:
+        theta = self.inputs_to_tensor(inputs)
+        if 'theta' in self._parameters:
+            del self._parameters['theta']
+        if 'theta' in self._buffers:
+            del self._buffers['theta']
+        if self.requires_grad:
+            self.theta = nn.Parameter(theta)
+        else:
+            self.register_buffer('theta', theta)
+        self.update_matrix()
+
+    def superoperator(self) -> torch.Tensor:
+        """sum_k K_k (x) conj(K_k): 4x4, index = (row bit, column bit)."""
+        kraus = self.update_matrix()                       # (K, 2, 2) or (K, B, 2, 2)
+        sup = torch.einsum('k...ab,k...cd->...acbd', kraus, kraus.conj())
+        return sup.reshape(*sup.shape[:-4], 4, 4)
+
+    def dm_prims(self, decompose: bool = True) -> list[Prim]:
+        bit = self.nqubit - 1 - self.wires[0]
+        return [Prim('gen', self.superoperator(), (bit + self.nqubit, bit), (), 0)]
+
+    def prims(self, decompose: bool = True) -> list[Prim]:
+        raise NotImplementedError('a channel acts on density matrices only')
+
+    def op_den_mat(self, x: torch.Tensor) -> torch.Tensor:
+        shape = x.shape
+        out = executor.run(x.reshape(shape[0], -1), self.dm_prims())
+        return out.reshape(shape)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.tsr_mode:
+            x = self.tensor_rep(x)
+        assert x.ndim == 2 * self.nqubit + 1
+        x = self.op_den_mat(x)
+        return x if self.tsr_mode else self.matrix_rep(x).squeeze(0)
+
+    def extra_repr(self) -> str:
+        return f'wires={self.wires}, probability={self.prob.item()}'
 
 
 class Layer(Operation):
@@ -263,12 +372,20 @@ class Layer(Operation):
             out.extend(gate.prims(decompose))
         return out
 
+    def dm_prims(self, decompose: bool = True) -> list[Prim]:
+        return lift_to_density_matrix(self.prims(decompose), self.nqubit)
+
     def forward(self, x):
         from .state import DistributedQubitState
 
         if isinstance(x, DistributedQubitState):
             return self.gates(x)
         flat = self._flat_state(x)
+        if self.den_mat:
+            out = executor.run(flat, self.dm_prims())
+            if self.tsr_mode:
+                return out.reshape([-1] + [2] * (2 * self.nqubit))
+            return self.matrix_rep(out).squeeze(0)
         out = executor.run(flat, self.prims())
         if self.tsr_mode:
             return out.reshape([-1] + [2] * self.nqubit)

@@ -115,6 +115,62 @@ def block_sample(probs: torch.Tensor, shots: int = 1024, block_size: int = 2**24
     return samples
 
 
+def is_density_matrix(rho: torch.Tensor) -> bool:
+    """Hermitian, unit trace, positive semi-definite; 2-D or batched 3-D (reference: qmath.py:117-149).
+    The spectrum is computed on the host (Hermitian eigensolver) with a small tolerance for round-off."""
+    if not isinstance(rho, torch.Tensor) or rho.ndim not in (2, 3):
+        return False
+    if not is_power_of_two(rho.shape[-2]) or not is_power_of_two(rho.shape[-1]) or rho.shape[-1] != rho.shape[-2]:
+        return False
+    if rho.ndim == 2:
+        rho = rho.unsqueeze(0)
+    rho = rho.detach()
+    if not torch.allclose(rho, rho.mH):
+        return False
+    trace = rho.diagonal(dim1=-2, dim2=-1).sum(-1)
+    if not torch.allclose(trace, torch.ones_like(trace)):
+        return False
+    eig = torch.linalg.eigvalsh(rho.cpu())
+    return bool((eig >= -1e-6).all())
+
+
+def partial_trace(rho: torch.Tensor, nqudit: int, trace_lst: list[int], qudit: int = 2) -> torch.Tensor:
+    """Trace out the qudits in ``trace_lst`` of (batch, d^n, d^n) density matrices
+    (reference: qmath.py:408-436)."""
+    if rho.ndim == 2:
+        rho = rho.unsqueeze(0)
+    assert rho.ndim == 3 and rho.shape[1] == rho.shape[2] == qudit**nqudit
+    b = rho.shape[0]
+    keep = [i for i in range(nqudit) if i not in trace_lst]
+    letters = list(range(1, 2 * nqudit + 1))            # einsum index ids: rows 1..n, columns n+1..2n
+    for i in trace_lst:
+        letters[nqudit + i] = letters[i]                # repeated index = traced
+    out = [letters[i] for i in keep] + [letters[nqudit + i] for i in keep]
+    red = torch.einsum(rho.reshape([b] + [qudit] * 2 * nqudit), [0] + letters, [0] + out)
+    d = qudit ** len(keep)
+    return red.reshape(b, d, d).squeeze(0)
+
+
+def evolve_den_mat(state: torch.Tensor, matrix: torch.Tensor, nqudit: int, wires: list[int], qudit: int = 2) -> torch.Tensor:
+    """rho -> U rho U^dagger for U on ``wires`` of a (batch, 2, ..., 2) tensor with 2n qubit axes
+    (reference: qmath.py:509-540): the gate kernel on the row bits, its conjugate on the column bits."""
+    if qudit != 2:
+        raise NotImplementedError('deepquantum_amd: qudits with d != 2 belong to the photonic path')
+    from . import executor
+    from .operation import lift_to_density_matrix
+
+    shape = state.shape
+    prim = executor.Prim('gen', matrix, tuple(nqudit - 1 - w for w in wires), ())
+    out = executor.run(state.reshape(shape[0], -1), lift_to_density_matrix([prim], nqudit))
+    return out.reshape(shape)
+
+
+def _parity(x: torch.Tensor) -> torch.Tensor:
+    for shift in (32, 16, 8, 4, 2, 1):
+        x = x ^ (x >> shift)
+    return x & 1
+
+
 def measure(
     state: torch.Tensor,
     shots: int = 1024,
@@ -126,7 +182,8 @@ def measure(
     """Sample bit strings from |psi|^2 (reference: qmath.py:568-638).  Probabilities and marginals are
     computed by the HIP reduction kernels; sampling stays ``torch.multinomial`` on the device."""
     if den_mat:
-        raise NotImplementedError('density matrices are outside the accelerated path')
+        assert is_density_matrix(state), 'Please input density matrices'
+        state = state.diagonal(dim1=-2, dim2=-1)
     single = state.ndim == 1 or (state.ndim == 2 and state.shape[-1] == 1)
     batch = 1 if single else state.shape[0]
     flat = state.reshape(batch, -1)
@@ -141,7 +198,13 @@ def measure(
         wires = sorted(wires)
     nbits = len(wires) if wires else n
     with torch.no_grad():
-        if wires is None or len(wires) == n:
+        if den_mat:                                   # the diagonal of rho already holds the probabilities
+            all_probs = torch.abs(flat)
+            if wires is not None and len(wires) != n:
+                axes = [w + 1 for w in wires]
+                pm = [0] + axes + [i for i in range(1, n + 1) if i not in axes]
+                all_probs = all_probs.reshape([batch] + [2] * n).permute(pm).reshape(batch, 2 ** len(wires), -1).sum(-1)
+        elif wires is None or len(wires) == n:
             all_probs = backend.probs(flat)
         elif len(wires) <= 12:
             all_probs = backend.marginal(flat, [n - 1 - w for w in wires]).to(flat.real.dtype)
@@ -165,8 +228,21 @@ def measure(
 def expectation(state: torch.Tensor, observable: 'Observable', den_mat: bool = False, chi: int | None = None) -> torch.Tensor:
     """``Re <psi| O |psi>`` for a Pauli-string observable (reference: qmath.py:830-860), computed in a
     single pass over the state by the Pauli-expectation kernel."""
-    if den_mat or isinstance(state, list):
-        raise NotImplementedError('only state vectors are on the accelerated path')
+    if isinstance(state, list):
+        raise NotImplementedError('matrix product states are outside the accelerated path')
+    if den_mat:
+        # Tr(P rho) = sum_j P[j ^ x, j] rho[j, j ^ x]: only 2^n of the 4^n entries of rho are needed
+        # (the reference multiplies the full 2^n x 2^n observable into rho, qmath.py:855)
+        single = state.ndim == 2
+        rho = state.reshape(1 if single else state.shape[0], -1)
+        xmask, zmask = observable.pauli_masks()
+        dim = int(round(rho.shape[-1] ** 0.5))
+        j = torch.arange(dim, device=rho.device)
+        entries = rho[:, j * dim + (j ^ xmask)]
+        sign = (1 - 2 * _parity(j & zmask)).to(rho.real.dtype)
+        val = (entries * sign).sum(-1) * (1j) ** bin(xmask & zmask).count('1')
+        out = val.real
+        return out.squeeze(0) if single else out
     single = state.ndim == 2
     flat = state.reshape(1 if single else state.shape[0], -1)
     xmask, zmask = observable.pauli_masks()

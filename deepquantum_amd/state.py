@@ -10,7 +10,7 @@ from torch import nn
 
 from .bitmath import is_power_of_2, log_base2, power_of_2
 from .communication import comm_get_rank, comm_get_world_size
-from .qmath import amplitude_encoding
+from .qmath import amplitude_encoding, is_density_matrix
 from .utils import complex_apply
 
 
@@ -28,15 +28,13 @@ class _ComplexBuffers(nn.Module):
 
 
 class QubitState(_ComplexBuffers):
-    """|psi> of ``nqubit`` qubits as a complex64 (2**n, 1) buffer: ``'zeros'``, ``'equal'``,
+    """|psi> of ``nqubit`` qubits as a complex64 (2**n, 1) buffer (or rho, (2**n, 2**n), with ``den_mat``): ``'zeros'``, ``'equal'``,
     ``'entangle'``/``'GHZ'``/``'ghz'`` or user amplitudes (amplitude-encoded)."""
 
     _complex_names = ('state',)
 
     def __init__(self, nqubit: int = 1, state: Any = 'zeros', den_mat: bool = False) -> None:
         super().__init__()
-        if den_mat:
-            raise NotImplementedError('deepquantum_amd: the density-matrix path is out of scope (SURVEY section 2)')
         self.nqubit = nqubit
         self.den_mat = den_mat
         dim = 2**nqubit
@@ -55,10 +53,15 @@ class QubitState(_ComplexBuffers):
         else:
             if not isinstance(state, torch.Tensor):
                 state = torch.tensor(state, dtype=torch.cfloat)
+            if den_mat and state.shape[-1] == dim and is_density_matrix(state):
+                self.register_buffer('state', state)      # already a density matrix (reference: state.py:57-58)
+                return
             ndim = state.ndim
             vec = amplitude_encoding(data=state, nqubit=nqubit)
             if vec.ndim > ndim:
                 vec = vec.squeeze(0)
+        if den_mat:
+            vec = vec @ vec.mH
         self.register_buffer('state', vec)
 
     def forward(self) -> None:

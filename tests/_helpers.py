@@ -85,6 +85,68 @@ def check_reset_against_golden(dq, device=None):
     assert (data.grad.cpu() - gold_extra('reset_batched/grad')).abs().max().item() < 1e-4
 
 
+def check_density_matrix_against_golden(dq, device=None, tol=2e-5):
+    """Density-matrix circuits with every channel class, batched data with gradients, partial trace and a
+    user-supplied rho (reference outputs: tests/golden/make_golden_extra.py)."""
+    for name, c in specs.DM_CASES.items():
+        cir = dq.QubitCircuit(c['nqubit'], init_state=c['init'], den_mat=True)
+        for method, args, kwargs in c['spec']:
+            getattr(cir, method)(*args, **kwargs)
+        for wires, basis in c['observables']:
+            cir.observable(wires, basis)
+        if device is not None:
+            cir.to(device)
+        with torch.no_grad():
+            rho = cir()
+            ev = cir.expectation()
+        ref = gold_extra(f'dm/{name}/rho')
+        assert rho.shape == ref.shape, (rho.shape, ref.shape)
+        assert (rho.cpu() - ref).abs().max().item() < tol, name
+        assert (ev.cpu() - gold_extra(f'dm/{name}/expectation')).abs().max().item() < tol, name
+        probs = cir.measure(shots=200, with_prob=True)
+        diag = ref.diagonal().real
+        for key, (_cnt, p) in probs.items():
+            assert abs(float(p) - float(diag[int(key, 2)])) < tol
+    cir = dq.QubitCircuit(3, den_mat=True)
+    cir.hlayer()
+    cir.rx(0, encode=True)
+    cir.bit_flip(0, encode=True)
+    cir.cnot(0, 1)
+    cir.amp_damp(1)
+    cir.ry(2, encode=True)
+    cir.depolarizing(2, 0.3)
+    cir.crz(1, 2, encode=True)
+    cir.observable(0)
+    cir.observable([1, 2], 'zx')
+    prm = list(cir.parameters())
+    assert len(prm) == 1
+    with torch.no_grad():
+        prm[0].copy_(gold_extra('dm/batched/theta'))
+    data = gold_extra('dm/batched/data').clone()
+    if device is not None:
+        cir.to(device)
+        data = data.to(device)
+    data.requires_grad_(True)
+    rho = cir(data=data)
+    ev = cir.expectation()
+    ev.sum().backward()
+    assert (rho.detach().cpu() - gold_extra('dm/batched/rho')).abs().max().item() < tol
+    assert (ev.detach().cpu() - gold_extra('dm/batched/expectation')).abs().max().item() < tol
+    assert (data.grad.cpu() - gold_extra('dm/batched/data_grad')).abs().max().item() < 10 * tol
+    assert (list(cir.parameters())[0].grad.cpu() - gold_extra('dm/batched/theta_grad')).abs().max().item() < 10 * tol
+    rho0 = gold_extra('dm/user/rho0')
+    assert (dq.qmath.partial_trace(rho0, 3, [0, 2]) - gold_extra('dm/user/ptrace_02')).abs().max().item() < 1e-6
+    assert (dq.qmath.partial_trace(rho0, 3, [1]) - gold_extra('dm/user/ptrace_1')).abs().max().item() < 1e-6
+    cir = dq.QubitCircuit(3, init_state=rho0, den_mat=True)
+    cir.h(0)
+    cir.cnot(0, 2)
+    cir.phase_damp(1, 0.6)
+    if device is not None:
+        cir.to(device)
+    with torch.no_grad():
+        assert (cir().cpu() - gold_extra('dm/user/rho')).abs().max().item() < tol
+
+
 def build_circuit(dq, name, prec, device=None):
     c = specs.CIRCUITS[name]
     cir = specs.build(dq, c['nqubit'], c['spec'])

@@ -70,6 +70,53 @@ def main():
         out[f'ansatz/qcnn/param{i}'] = to_np(prm)
     out['ansatz/qcnn/nparam'] = np.array(len(list(qcnn.parameters())))
     out['ansatz/qcnn/state'] = to_np(qcnn().reshape(-1))
+    # density matrices and channels
+    for name, c in specs.DM_CASES.items():
+        cir = dq.QubitCircuit(c['nqubit'], init_state=c['init'], den_mat=True)
+        for method, args, kwargs in c['spec']:
+            getattr(cir, method)(*args, **kwargs)
+        for wires, basis in c['observables']:
+            cir.observable(wires, basis)
+        rho = cir()
+        out[f'dm/{name}/rho'] = to_np(rho)
+        out[f'dm/{name}/expectation'] = to_np(cir.expectation())
+    # batched data + a trainable channel, gradients w.r.t. the data and the channel parameter
+    torch.manual_seed(5)
+    cir = dq.QubitCircuit(3, den_mat=True)
+    cir.hlayer()
+    cir.rx(0, encode=True)
+    cir.bit_flip(0, encode=True)
+    cir.cnot(0, 1)
+    cir.amp_damp(1)                      # trainable
+    cir.ry(2, encode=True)
+    cir.depolarizing(2, 0.3)
+    cir.crz(1, 2, encode=True)
+    cir.observable(0)
+    cir.observable([1, 2], 'zx')
+    data = torch.tensor([[0.3, 0.5, 1.2, -0.4], [1.0, 0.2, 0.1, 0.9]], requires_grad=True)
+    rho = cir(data=data)
+    ev = cir.expectation()
+    ev.sum().backward()
+    prm = [p for p in cir.parameters()]
+    out['dm/batched/data'] = to_np(data)
+    out['dm/batched/theta'] = to_np(prm[0])
+    out['dm/batched/rho'] = to_np(rho)
+    out['dm/batched/expectation'] = to_np(ev)
+    out['dm/batched/data_grad'] = to_np(data.grad)
+    out['dm/batched/theta_grad'] = to_np(prm[0].grad)
+    # partial trace and a user-supplied density matrix as the initial state
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(8, 8, generator=g) + 1j * torch.randn(8, 8, generator=g)
+    rho0 = a @ a.mH
+    rho0 = (rho0 / rho0.diagonal().sum()).to(torch.cfloat)
+    out['dm/user/rho0'] = to_np(rho0)
+    out['dm/user/ptrace_02'] = to_np(dq.qmath.partial_trace(rho0, 3, [0, 2]))
+    out['dm/user/ptrace_1'] = to_np(dq.qmath.partial_trace(rho0, 3, [1]))
+    cir = dq.QubitCircuit(3, init_state=rho0, den_mat=True)
+    cir.h(0)
+    cir.cnot(0, 2)
+    cir.phase_damp(1, 0.6)
+    out['dm/user/rho'] = to_np(cir())
     np.savez_compressed(os.path.join(HERE, 'golden_extra.npz'), **out)
     print('wrote golden_extra.npz', os.path.getsize(os.path.join(HERE, 'golden_extra.npz')), 'bytes;', len(out), 'arrays')
 

@@ -326,3 +326,21 @@ ANSATZ_CASES = {
     'qpe': _qpe,
     'g3': _g3,
 }
+
+
+# ---- density matrices + channels -------------------------------------------------------
+DM_ZOO4 = [
+    ('hlayer', [], {}), ('rx', [0, 0.7], {}), ('bit_flip', [0, 0.3], {}), ('cnot', [0, 1], {}),
+    ('phase_flip', [1, 0.5], {}), ('ry', [2, 1.1], {}), ('depolarizing', [2, 0.4], {}), ('toffoli', [0, 1, 3], {}),
+    ('pauli', [3, [0.3, 0.9, 0.5, 1.2]], {}), ('rzz', [[1, 3], 0.8], {}), ('amp_damp', [1, 0.6], {}),
+    ('u3', [2, [0.2, 0.4, 0.6]], {}), ('phase_damp', [2, 0.45], {}), ('swap', [[0, 3]], {}),
+    ('gen_amp_damp', [0, [0.8, 0.35]], {}), ('crx', [3, 1, 0.9], {}), ('cz', [2, 0], {}), ('s', [1], {}), ('t', [3], {}),
+    ('rx', [2, 0.33], {'controls': [0, 1]}), ('fredkin', [1, 0, 2], {}), ('y', [0], {}), ('p', [1, 0.7], {}),
+]
+DM_CASES = {
+    'dm_zoo4': dict(nqubit=4, spec=DM_ZOO4, init='zeros', observables=[([0], 'z'), ([1, 2], 'xy'), ([3], 'y'), ([0, 3], 'zx')]),
+    'dm_ghz3': dict(nqubit=3, spec=[('ry', [0, 0.4], {}), ('amp_damp', [2, 0.5], {}), ('cnot', [2, 0], {})], init='ghz',
+                    observables=[([0, 1, 2], 'xxx'), ([1], 'z')]),
+    'dm_equal2': dict(nqubit=2, spec=[('depolarizing', [0, 0.7], {}), ('h', [1], {})], init='equal',
+                      observables=[([0], 'x'), ([1], 'z')]),
+}

@@ -154,9 +154,9 @@ def test_cpu_tensors_without_test_backend_fail_loudly():
 
 def test_out_of_scope_paths_raise():
     with pytest.raises(NotImplementedError):
-        dq.QubitCircuit(2, den_mat=True)
-    with pytest.raises(NotImplementedError):
         dq.QubitCircuit(2, mps=True)
+    with pytest.raises(AssertionError):
+        dq.QubitCircuit(2).bit_flip(0)          # channels need den_mat=True, as in the reference
     with pytest.raises(NotImplementedError):
         dq.QubitCircuit(2).qasm()
 
@@ -230,3 +230,9 @@ def test_ansatz_known_answers(cpu_backend):
     from _ansatz_checks import check_known_answers
 
     check_known_answers(dq, shor_ncount=3)      # 18-qubit Shor (ncount = 8) runs in the GPU suite
+
+
+def test_density_matrix_path_matches_reference(cpu_backend):
+    from _helpers import check_density_matrix_against_golden
+
+    check_density_matrix_against_golden(dq)

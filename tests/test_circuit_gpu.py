@@ -222,3 +222,9 @@ def test_ansatz_library_on_gpu():
     check_states(dq, device=dev())
     check_qcnn(dq, device=dev())
     check_known_answers(dq, device=dev(), shor_ncount=8)
+
+
+def test_density_matrix_path_on_gpu():
+    from _helpers import check_density_matrix_against_golden
+
+    check_density_matrix_against_golden(dq, device=dev())
