@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument('--min-low', type=int, default=None)
     ap.add_argument('--max-gates', type=int, default=None)
     ap.add_argument('--no-fuse', action='store_true')
+    ap.add_argument('--max-far', type=int, default=None, help='scheduler: max gathered bits >= far-bit per pass')
+    ap.add_argument('--far-bit', type=int, default=None)
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
     return ap.parse_args()
 
@@ -152,6 +154,8 @@ def main():
         dq.executor.CONFIG['max_gates'] = args.max_gates
     if args.no_fuse:
         dq.executor.CONFIG['fuse'] = False
+    dq.executor.CONFIG['max_far'] = args.max_far
+    dq.executor.CONFIG['far_bit'] = args.far_bit
 
     n = args.nqubit + int(math.log2(world))
     spec = random_circuit_spec(n, args.depth, args.seed)

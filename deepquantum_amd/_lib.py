@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
@@ -26,6 +26,8 @@ FUSED_MAX_ROUNDS = 24
 FUSED_MAX_GATES = 96
 FUSED_MAX_SLOTS = 4
 FUSED_MAX_TBITS = 10
+FAST_NONE = 0xFFFFFFFF
+MAT_PAD = 16
 
 
 class DqFusedGate(C.Structure):
@@ -38,8 +40,10 @@ class DqFusedGate(C.Structure):
         ('reg_cmask', C.c_uint8),
         ('thr_cmask', C.c_uint16),
         ('mat', C.c_uint32),
+        ('fast', C.c_uint32),
         ('out_cmask', C.c_uint64),
-        ('reserved', C.c_uint64),
+        ('mat_advance', C.c_uint32),
+        ('reserved', C.c_uint32),
     ]
 
 
@@ -63,7 +67,7 @@ class DqFusedPass(C.Structure):
         ('load_rb', C.c_uint8 * FUSED_MAX_SLOTS),
         ('store_rb', C.c_uint8 * FUSED_MAX_SLOTS),
         ('rounds', DqFusedRound * FUSED_MAX_ROUNDS),
-        ('pad_', C.c_uint32),
+        ('mat_base', C.c_uint32),
         ('gates', DqFusedGate * FUSED_MAX_GATES),
         ('load_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),
         ('store_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),

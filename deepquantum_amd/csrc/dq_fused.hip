@@ -276,6 +276,18 @@ template <int ESZ> __device__ __forceinline__ unsigned lds_swz(unsigned e) {
         return e ^ ((e >> 4) & 15u);
 }
 
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
+// Mirror of the kernel's argument list: where the by-value descriptor sits in the kernarg segment.
+struct FusedKernArgs {
+    const void* in;
+    void* out;
+    const void* mats;
+    int64_t mat_bstride;
+    int n;
+    DqFusedPass p;
+};
+
 template <typename T, int R, int LOGT>
 __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in, amp<T>* out,
                                                                const amp<T>* __restrict__ mats, int64_t mat_bstride,
@@ -375,6 +387,11 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     };
 
     const uint64_t tile_global = tile;  // global index bits fixed for this workgroup (outside the tile)
+    constexpr bool FAST = (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS);
+    // Gate records are fetched with explicit scalar loads from the kernel-argument segment (the descriptor
+    // is passed by value; its address must not be taken through `&p`, that would force a private copy).
+    const uint64_t kgates = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FusedKernArgs, p) +
+                            offsetof(DqFusedPass, gates);
 
     // The descriptor is read as 32-bit words (scalar loads; gfx950 has no sub-dword s_load) and decoded
     // with SALU bit ops, so no vector memory instruction is spent on it.
@@ -382,6 +399,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     constexpr int ROUND_W0 = offsetof(DqFusedPass, rounds) / 4;
     constexpr int GATE_W0 = offsetof(DqFusedPass, gates) / 4;
     const int nrounds = (int)(pw[0] >> 24);
+    uint64_t mrun = (uint64_t)(mbase + pw[offsetof(DqFusedPass, mat_base) / 4]);  // running matrix pointer
     for (int r = 0; r < nrounds; ++r) {
         const uint32_t rw0 = pw[ROUND_W0 + 4 * r], rw1 = pw[ROUND_W0 + 4 * r + 1], rw2 = pw[ROUND_W0 + 4 * r + 2],
                        rw3 = pw[ROUND_W0 + 4 * r + 3];
@@ -400,37 +418,66 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
         if (!same || ntbase != tbase) transpose_to(nrb, ntbase);
         const int gbeg = (int)((rw3 >> 16) & 0xffu), gend = (int)(rw3 >> 24);
+        uint64_t gaddr = kgates + 32ull * (unsigned)gbeg;   // kernarg address of the round's first gate record
         for (int gi = gbeg; gi < gend; ++gi) {
-            const uint32_t* gw = pw + GATE_W0 + 8 * gi;
-            const uint32_t g0 = gw[0], g1 = gw[1], gmat = gw[2];
-            const uint64_t out_cmask = (uint64_t)gw[4] | ((uint64_t)gw[5] << 32);
-            if ((tile_global & out_cmask) != out_cmask) continue;  // uniform: a control outside the tile is 0
-            const unsigned kind = g0 & 0xffu, q = (g0 >> 8) & 0xffu, q2 = (g0 >> 16) & 0xffu, loc = g0 >> 24;
-            const unsigned loc2 = g1 & 0xffu, reg_cmask = (g1 >> 8) & 0xffu, thr_cmask = g1 >> 16;
-            const bool thr_ok = (tbase & thr_cmask) == thr_cmask;
-            const V* mp = mbase + gmat;
-            if constexpr (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS) {
-                // Fast handlers (host-assigned id in the q2 byte of 1-target gates): 0..11 = uncontrolled-by-slot
-                // 2x2 gate with structure mode = id / 4 on slot id % 4; 12..15 = X on slot id - 12.  One flat
-                // switch instead of the kind / control / mode / slot decision chain (SALU is the scarce unit).
-                if (kind <= DQ_FG_X1 && q2 < 16) {
-                    if (thr_cmask == 0 || thr_ok) {
-                        const uint64_t* mw = reinterpret_cast<const uint64_t*>(mp);
-                        switch (q2) {
-#define DQ_GEN1_CASE(ID) case ID: { const uint64_t mq[4] = {mw[0], mw[1], mw[2], mw[3]}; gen1_block_f32<(ID) / 4, (ID) % 4>(a, mq); break; }
-                            DQ_GEN1_CASE(0) DQ_GEN1_CASE(1) DQ_GEN1_CASE(2) DQ_GEN1_CASE(3)
-                            DQ_GEN1_CASE(4) DQ_GEN1_CASE(5) DQ_GEN1_CASE(6) DQ_GEN1_CASE(7)
-                            DQ_GEN1_CASE(8) DQ_GEN1_CASE(9) DQ_GEN1_CASE(10) DQ_GEN1_CASE(11)
-#undef DQ_GEN1_CASE
+            // ONE scalar-memory round trip per gate: the 32-byte record and -- from the running pointer, no
+            // decode needed because the host lays the matrices of a pass out in gate order -- its matrix.
+            u32x8 rec, mqv;
+            if constexpr (FAST) {
+                asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(rec), "=&s"(mqv)
+                             : "s"(gaddr), "s"(mrun));
+            } else {
+                asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rec) : "s"(gaddr));
+            }
+            gaddr += 32;
+            mrun += (uint64_t)rec[6] * sizeof(V);
+            const uint32_t g0 = rec[0], g1 = rec[1], gmat = rec[2], fast = rec[3];
+            const uint64_t out_cmask = (uint64_t)rec[4] | ((uint64_t)rec[5] << 32);
+            const unsigned reg_cmask = (g1 >> 8) & 0xffu, thr_cmask = g1 >> 16;
+            if constexpr (FAST) {
+                // Straight-line handlers picked by the host (include/dq_hip.h, DqFusedGate::fast): one flat
+                // switch instead of the kind / control / mode / slot decision chain -- the scalar unit is the
+                // scarce resource of this kernel.  Ids < 16 have no control of any kind: no test at all.
+                if (fast < 32u) {
+                    const uint64_t mq[4] = {(uint64_t)mqv[0] | ((uint64_t)mqv[1] << 32),
+                                            (uint64_t)mqv[2] | ((uint64_t)mqv[3] << 32),
+                                            (uint64_t)mqv[4] | ((uint64_t)mqv[5] << 32),
+                                            (uint64_t)mqv[6] | ((uint64_t)mqv[7] << 32)};
+#define DQ_GEN1_CASE(ID) case ID: gen1_block_f32<(ID) / 4, (ID) % 4>(a, mq); break;
+#define DQ_GEN1_CASES                                                                           \
+    DQ_GEN1_CASE(0) DQ_GEN1_CASE(1) DQ_GEN1_CASE(2) DQ_GEN1_CASE(3) DQ_GEN1_CASE(4) DQ_GEN1_CASE(5) \
+    DQ_GEN1_CASE(6) DQ_GEN1_CASE(7) DQ_GEN1_CASE(8) DQ_GEN1_CASE(9) DQ_GEN1_CASE(10) DQ_GEN1_CASE(11)
+                    if (fast < 16u) {
+                        switch (fast) {
+                            DQ_GEN1_CASES
+                            case 12: x1_block_f32<0, 0>(a); break;
+                            case 13: x1_block_f32<1, 0>(a); break;
+                            case 14: x1_block_f32<2, 0>(a); break;
+                            default: x1_block_f32<3, 0>(a); break;
+                        }
+                        continue;
+                    }
+                    if ((tile_global & out_cmask) != out_cmask) continue;  // uniform: an outside control is 0
+                    if ((tbase & thr_cmask) == thr_cmask) {
+                        switch (fast - 16u) {
+                            DQ_GEN1_CASES
                             case 12: dispatch_x1_block_f32<0>(a, reg_cmask); break;
                             case 13: dispatch_x1_block_f32<1>(a, reg_cmask); break;
                             case 14: dispatch_x1_block_f32<2>(a, reg_cmask); break;
                             default: dispatch_x1_block_f32<3>(a, reg_cmask); break;
                         }
                     }
+#undef DQ_GEN1_CASES
+#undef DQ_GEN1_CASE
                     continue;
                 }
             }
+            if ((tile_global & out_cmask) != out_cmask) continue;  // uniform: a control outside the tile is 0
+            const unsigned kind = g0 & 0xffu, q = (g0 >> 8) & 0xffu, q2 = (g0 >> 16) & 0xffu, loc = g0 >> 24;
+            const unsigned loc2 = g1 & 0xffu;
+            const bool thr_ok = (tbase & thr_cmask) == thr_cmask;
+            const V* mp = mbase + gmat;
             switch (kind) {
                 case DQ_FG_GEN1: dispatch_gen1<T, R>(a, q, mp, loc, reg_cmask, thr_cmask != 0, thr_ok); break;
                 case DQ_FG_X1: dispatch_x1<T, R>(a, q, reg_cmask, thr_cmask != 0, thr_ok); break;
@@ -570,6 +617,8 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
             }
         }
     }
+    int next_gate = 0;
+    uint32_t next_mat = p->mat_base;
     for (int r = 0; r < p->nrounds; ++r) {
         const DqFusedRound& rd = p->rounds[r];
         unsigned used = 0;
@@ -591,6 +640,11 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
             set_error("dq_apply_fused: round %d gate range invalid", r);
             return DQ_ERR_ARG;
         }
+        if (rd.gate_begin != next_gate) {
+            set_error("dq_apply_fused: round %d does not continue the gate list", r);
+            return DQ_ERR_ARG;
+        }
+        next_gate = rd.gate_end;
         for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
             const bool slot_kind = g.kind == DQ_FG_GEN1 || g.kind == DQ_FG_X1 || g.kind == DQ_FG_GEN2;
@@ -598,6 +652,24 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
                 (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
                 set_error("dq_apply_fused: gate %d malformed", gi);
                 return DQ_ERR_ARG;
+            }
+            // the kernel walks the matrices with a running pointer: they must lie back to back in gate order
+            static const uint32_t kSize[5] = {4, 0, 4, 16, 16};
+            if (g.mat != next_mat || g.mat_advance != kSize[g.kind]) {
+                set_error("dq_apply_fused: gate %d breaks the sequential matrix layout (mat=%u, expected %u)", gi,
+                          g.mat, next_mat);
+                return DQ_ERR_ARG;
+            }
+            next_mat += g.mat_advance;
+            if (g.fast != DQ_FAST_NONE) {
+                const bool free_ = g.reg_cmask == 0 && g.thr_cmask == 0 && g.out_cmask == 0;
+                uint32_t want = DQ_FAST_NONE;
+                if (g.kind == DQ_FG_X1) want = (free_ ? 12u : 28u) + g.q;
+                else if (g.kind == DQ_FG_GEN1 && g.reg_cmask == 0) want = (free_ ? 0u : 16u) + 4u * g.loc + g.q;
+                if (g.fast != want) {
+                    set_error("dq_apply_fused: gate %d has fast-handler id %u, expected %u", gi, g.fast, want);
+                    return DQ_ERR_ARG;
+                }
             }
         }
     }

@@ -37,7 +37,8 @@ class Prim:
 class Plan:
     steps: list
     prim_ops: list[fusion.PrimOp]
-    mat_total: int                 # complex numbers per batch sample in the flat matrix buffer
+    mat_order: list[int]           # prim indices in the order their matrices lie in the kernel buffer
+    mat_total: int                 # complex numbers per batch sample in the flat matrix buffer (incl. tail pad)
     n_fused: int
     n_single: int
 
@@ -47,7 +48,7 @@ _PLAN_CACHE_SIZE = 64
 
 # Tunables (debug / benchmarking): tile bits per precision; None = library default.
 CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
-          'max_gates': None}
+          'max_gates': None, 'max_far': None, 'far_bit': None}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates) to report the kernel's average duration next to its algorithmic bytes.
@@ -64,12 +65,16 @@ def _geometry(is128: bool) -> fusion.Geometry:
         g.min_low = ml
     if CONFIG['max_gates'] is not None:
         g.max_gates = CONFIG['max_gates']
+    if CONFIG['max_far'] is not None:
+        g.max_far = CONFIG['max_far']
+    if CONFIG['far_bit'] is not None:
+        g.far_bit = CONFIG['far_bit']
     return g
 
 
 def make_plan(prims: Sequence[Prim], n: int, is128: bool) -> Plan:
     geom = _geometry(is128)
-    key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, CONFIG['fuse'],
+    key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, CONFIG['fuse'],
            tuple((p.kind, p.targets, p.controls, p.mode) for p in prims))
     plan = _PLAN_CACHE.get(key)
     if plan is not None:
@@ -80,7 +85,8 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool) -> Plan:
         prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off, p.mode))
         off += (1 << len(p.targets)) ** 2
     steps = fusion.schedule(prim_ops, n, geom, fuse=CONFIG['fuse'])
-    plan = Plan(steps, prim_ops, off,
+    order, total = fusion.layout_matrices(steps, prim_ops)
+    plan = Plan(steps, prim_ops, order, total,
                 sum(isinstance(s, fusion.FusedStep) for s in steps),
                 sum(isinstance(s, fusion.SingleStep) for s in steps))
     _PLAN_CACHE[key] = plan
@@ -89,12 +95,15 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool) -> Plan:
     return plan
 
 
-def _flat_mats(prims: Sequence[Prim], batch: int, dtype: torch.dtype, device: torch.device) -> tuple[torch.Tensor, int]:
-    """Concatenate all gate matrices into one (Bm, total) buffer; Bm = batch if any is batched."""
+def _flat_mats(prims: Sequence[Prim], order: Sequence[int], batch: int, dtype: torch.dtype,
+               device: torch.device) -> tuple[torch.Tensor, int]:
+    """Concatenate the gate matrices in the plan's buffer order (fusion.layout_matrices) into one
+    (Bm, total) buffer with the kernel's tail pad; Bm = batch if any matrix is batched."""
     batched = any(p.matrix.ndim == 3 and p.matrix.shape[0] > 1 for p in prims)
     bm = batch if batched else 1
     rows = []
-    for p in prims:
+    for i in order:
+        p = prims[i]
         m = p.matrix
         if m.ndim == 2:
             m = m.unsqueeze(0)
@@ -102,8 +111,15 @@ def _flat_mats(prims: Sequence[Prim], batch: int, dtype: torch.dtype, device: to
         if m.shape[0] != bm:
             m = m.expand(bm, -1)
         rows.append(m)
+    rows.append(rows[0].new_zeros(bm, _lib_pad()) if rows else torch.zeros(bm, _lib_pad(), dtype=dtype, device=device))
     flat = torch.cat(rows, dim=1).to(device=device, dtype=dtype).contiguous()
     return flat, (flat.shape[1] if batched else 0)
+
+
+def _lib_pad() -> int:
+    from . import _lib
+
+    return _lib.MAT_PAD
 
 
 def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
@@ -132,7 +148,7 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> to
         is128 = state.dtype == torch.complex128
         x = state if (inplace and state.is_contiguous()) else state.detach().clone(memory_format=torch.contiguous_format)
         plan = make_plan(prims, n, is128)
-        flat, stride = _flat_mats(prims, x.shape[0], x.dtype, x.device)
+        flat, stride = _flat_mats(prims, plan.mat_order, x.shape[0], x.dtype, x.device)
         stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0}
         scratch = None
         for st in plan.steps:
@@ -151,7 +167,7 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> to
             else:
                 op = plan.prim_ops[st.op]
                 d = 1 << op.k
-                mat = flat[:, op.mat : op.mat + d * d].reshape(-1, d, d)
+                mat = flat[:, op.pos : op.pos + d * d].reshape(-1, d, d)
                 if op.k <= 4:
                     backend.apply_gate(x, mat, op.targets, op.controls, out=x)
                 else:

@@ -32,8 +32,9 @@ class PrimOp:
     kind: str
     targets: tuple[int, ...]
     controls: tuple[int, ...] = ()
-    mat: int = 0
+    mat: int = 0              # offset in the CALLER's matrix buffer (source of gather_matrices)
     mode: int = 0             # matrix structure promised by the gate class: 0 general, 1 real, 2 Rx-like
+    pos: int = 0              # offset in the kernel's matrix buffer, assigned by layout_matrices
 
     @property
     def k(self) -> int:
@@ -61,6 +62,8 @@ class Geometry:
     min_low: int      # minimum contiguous low bits of a tile (coalescing floor)
     max_gates: int = _lib.FUSED_MAX_GATES
     max_rounds: int = _lib.FUSED_MAX_ROUNDS - 1  # one spare so a trailing round never overflows
+    far_bit: int = 19         # index bits >= far_bit are "far": every one gathered doubles the number of
+    max_far: int | None = None  # distant address streams of a tile; None = no limit (tools/sweep_tile_bits*.py)
 
     @property
     def logt(self) -> int:
@@ -155,6 +158,8 @@ def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True) -
 
         def fits_tile(op: PrimOp) -> bool:
             need = {t for t in op.targets if t not in low} - high
+            if geom.max_far is not None and sum(1 for b in high | need if b >= geom.far_bit) > geom.max_far:
+                return False    # too many far-apart address streams per tile (DRAM row conflicts)
             return len(high) + len(need) <= hcap and len(high | need) <= min(hcap, n - geom.min_low)
 
         def round_accepts(cur: _Round, tset: set[int], first: bool) -> bool:
@@ -367,6 +372,8 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
     g.reg_cmask, g.thr_cmask, g.out_cmask = reg_c, thr_c, out_c
     g.mat = op.mat
     g.q = g.q2 = g.loc = g.loc2 = 0
+    g.fast = _lib.FAST_NONE
+    g.mat_advance = 0
 
     def locate(b: int) -> tuple[int, int]:
         if b in tile:
@@ -387,16 +394,56 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         g.kind = _lib.FG_X1 if op.kind == 'x' else _lib.FG_GEN1
         g.q = slots[0]
         g.loc = op.mode if op.kind == 'gen' else 0
-        # fast-handler id (one flat switch in the kernel): see include/dq_hip.h
+        # straight-line handler id (one flat switch in the kernel): see include/dq_hip.h
+        free = reg_c == 0 and thr_c == 0 and out_c == 0
         if op.kind == 'x':
-            g.q2 = 12 + slots[0]
+            g.fast = (12 if free else 28) + slots[0]
         elif reg_c == 0:
-            g.q2 = 4 * g.loc + slots[0]
-        else:
-            g.q2 = 0xFF
+            g.fast = (0 if free else 16) + 4 * g.loc + slots[0]
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots
+
+
+def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], int]:
+    """Assign the kernel-side matrix layout: the matrices of a fused pass lie back to back in gate order
+    (the kernel fetches gate i's matrix from a running pointer, together with the gate record), single-gate
+    steps in between.  Patches ``mat`` / ``mat_advance`` / ``mat_base`` of every descriptor and ``pos`` of
+    every op; returns (op indices in buffer order, buffer length in complex numbers incl. the tail pad)."""
+    order: list[int] = []
+    off = 0
+    for st in steps:
+        if isinstance(st, FusedStep):
+            st.desc.mat_base = off
+            for gi, oi in enumerate(st.ops):
+                op, g = ops[oi], st.desc.gates[gi]
+                size = 0 if g.kind == _lib.FG_X1 else (1 << op.k) ** 2
+                g.mat, g.mat_advance, op.pos = off, size, off
+                if size:
+                    order.append(oi)
+                    off += size
+        else:
+            op = ops[st.op]
+            op.pos = off
+            order.append(st.op)
+            off += (1 << op.k) ** 2
+    return order, off + _lib.MAT_PAD
+
+
+def gather_matrices(src, ops: Sequence[PrimOp], order: Sequence[int]):
+    """Kernel-side matrix buffer (Bm, total) from a caller buffer ``src`` (Bm, *) indexed by ``op.mat``."""
+    import torch
+
+    segs = [src[:, ops[oi].mat : ops[oi].mat + (1 << ops[oi].k) ** 2] for oi in order]
+    segs.append(src.new_zeros(src.shape[0], _lib.MAT_PAD))
+    return torch.cat(segs, dim=1).contiguous()
+
+
+def kernel_matrices(steps: Sequence, ops: Sequence[PrimOp], src):
+    """layout_matrices + gather_matrices for callers that drive ``apply_fused`` themselves (tests, tools):
+    ``src`` is (Bm, *) or 1-D, indexed by ``op.mat``; returns the (Bm, total) buffer the descriptors expect."""
+    order, _total = layout_matrices(steps, ops)
+    return gather_matrices(src if src.ndim == 2 else src.reshape(1, -1), ops, order)
 
 
 def algorithmic_bytes(ops: Sequence[PrimOp], n: int, amp_bytes: int, batch: int) -> int:

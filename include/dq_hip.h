@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 2
+#define DQ_ABI_VERSION 3
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -99,18 +99,27 @@ typedef enum {
 typedef struct {
     uint8_t kind;       /* DqFusedKind */
     uint8_t q;          /* GEN/X: register slot of the (first) target; DIAG: position per loc */
-    uint8_t q2;         /* GEN2: slot of the second target (matrix LSB); DIAG2: position per loc2;
-                           GEN1 / X1: fast-handler id (0..11 = mode * 4 + slot for a 2x2 gate without slot
-                           controls, 12..15 = 12 + slot for X), or 0xFF = none */
+    uint8_t q2;         /* GEN2: slot of the second target (matrix LSB); DIAG2: position per loc2 */
     uint8_t loc;        /* DIAG1/2: DqBitLoc of target 1 (REG: q = slot, THR: q = tile-local bit,
                            OUT: q = global bit position); GEN1: DqFusedMode of the matrix */
     uint8_t loc2;       /* DIAG2: same for target 2 */
     uint8_t reg_cmask;  /* controls that are register slots (bit s = slot s) */
     uint16_t thr_cmask; /* controls that are thread bits (tile-local bit positions) */
     uint32_t mat;       /* offset (in complex numbers) of this gate's matrix inside `mats` */
+    uint32_t fast;      /* GEN1 / X1 straight-line handler, or DQ_FAST_NONE:
+                             0..11  2x2 gate, id = mode * 4 + slot, no control of any kind
+                            12..15  X on slot id - 12, no control of any kind
+                            16..27  2x2 gate, id - 16 = mode * 4 + slot, thread / outside controls only
+                            28..31  X on slot id - 28 with any controls (CNOT, Toffoli ...) */
     uint64_t out_cmask; /* controls outside the tile (global bit positions) */
-    uint64_t reserved;  /* pads the record to 32 bytes: one s_load_dwordx8 per gate */
+    uint32_t mat_advance; /* complex numbers this gate occupies in `mats` (0 for X1): the matrices of a pass
+                             lie back to back in gate order, mat(i+1) = mat(i) + mat_advance(i), so the kernel
+                             fetches gate i's matrix together with its record instead of after decoding it */
+    uint32_t reserved;  /* pads the record to 32 bytes: one s_load_dwordx8 per gate */
 } DqFusedGate;          /* 32 bytes */
+#define DQ_FAST_NONE 0xFFFFFFFFu
+/* `mats` must be readable for DQ_MAT_PAD complex numbers past the last matrix of a pass (prefetch). */
+#define DQ_MAT_PAD 16
 
 #define DQ_FUSED_MAX_TBITS 10
 typedef struct {
@@ -131,7 +140,7 @@ typedef struct {
     uint8_t load_rb[DQ_FUSED_MAX_SLOTS];
     uint8_t store_rb[DQ_FUSED_MAX_SLOTS];
     DqFusedRound rounds[DQ_FUSED_MAX_ROUNDS];
-    uint32_t pad_;                              /* aligns gates[] to 32 bytes */
+    uint32_t mat_base;                          /* = gates[0].mat (also aligns gates[] to 32 bytes) */
     DqFusedGate gates[DQ_FUSED_MAX_GATES];
     /* Host-precomputed addressing of the two I/O layouts: offset (in amplitudes, inside one state) that
      * register slot s contributes, i.e. 2^(global bit of tile bit load_rb[s]); saves the kernel a scalar

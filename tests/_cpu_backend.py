@@ -75,6 +75,18 @@ class CpuTestBackend:
         idx = tiles[:, None] | glob[None, :]            # (ntiles, 2^m) global amplitude indices
         assert np.array_equal(np.sort(idx.reshape(-1)), np.arange(1 << n)), 'tiles do not partition the state'
 
+        # matrices of the pass lie back to back in gate order, readable MAT_PAD entries past the end
+        run = desc.mat_base
+        ngates = desc.rounds[desc.nrounds - 1].gate_end if desc.nrounds else 0
+        for gi in range(ngates):
+            g = desc.gates[gi]
+            assert g.mat == run, 'matrix layout is not sequential'
+            size = {_lib.FG_GEN1: 4, _lib.FG_X1: 0, _lib.FG_DIAG1: 4, _lib.FG_GEN2: 16, _lib.FG_DIAG2: 16}[g.kind]
+            assert g.mat_advance == size
+            run += size
+        per_sample = mats.shape[-1] if mats.ndim == 2 else mats.numel()
+        assert run + _lib.MAT_PAD <= per_sample, 'matrix buffer lacks the prefetch pad'
+
         x = state.detach().numpy().copy()
         flat_m = mats.detach().numpy().reshape(-1)
         for b in range(bsz):
@@ -104,8 +116,14 @@ class CpuTestBackend:
                     if g.kind in (_lib.FG_GEN1, _lib.FG_X1):
                         tbit = rb[g.q]
                         assert not (cm >> tbit) & 1
-                        want = 12 + g.q if g.kind == _lib.FG_X1 else (4 * g.loc + g.q if g.reg_cmask == 0 else 0xFF)
-                        assert g.q2 == want, 'fast-handler id wrong'
+                        free = g.reg_cmask == 0 and g.thr_cmask == 0 and g.out_cmask == 0
+                        if g.kind == _lib.FG_X1:
+                            want = (12 if free else 28) + g.q
+                        elif g.reg_cmask == 0:
+                            want = (0 if free else 16) + 4 * g.loc + g.q
+                        else:
+                            want = _lib.FAST_NONE
+                        assert g.fast == want, 'fast-handler id wrong'
                         mat = mb[g.mat : g.mat + 4].reshape(2, 2)
                         if g.kind == _lib.FG_GEN1 and g.loc == 1:
                             assert np.all(mat.imag == 0), 'gate promised a real matrix'

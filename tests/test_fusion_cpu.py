@@ -47,9 +47,10 @@ def run_reference(state, ops, mats):
 
 def run_steps(state, ops, mats, steps):
     x = state.clone()
+    km = fusion.kernel_matrices(steps, ops, mats)      # matrices of a pass back to back, in gate order
     for st in steps:
         if isinstance(st, fusion.FusedStep):
-            backend.apply_fused(x, mats, 0, st.desc, out=x)
+            backend.apply_fused(x, km, 0, st.desc, out=x)
         else:
             op = ops[st.op]
             d = 1 << op.k

@@ -90,7 +90,7 @@ def test_fused_passes_match_oracle(is128, m, n, seed):
     assert all(isinstance(s, fusion.FusedStep) for s in steps)
     x = rand_state(2, n, dtype, 50 + seed)
     ref = run_reference(x, ops, mats)
-    xd, md = x.to(dev()), mats.to(dev())
+    xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
     for st in steps:
         backend.apply_fused(xd, md, 0, st.desc, out=xd)
     err = (xd.cpu() - ref).abs().max().item()
@@ -116,7 +116,7 @@ def test_fused_batched_matrices_and_out_of_place(is128):
     steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
     x = rand_state(b, n, dtype, 5)
     ref = torch.cat([run_reference(x[i : i + 1], ops, mats[i]) for i in range(b)])
-    xd, md = x.to(dev()), mats.to(dev()).contiguous()
+    xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev()).contiguous()
     cur = xd
     for st in steps:
         nxt = torch.empty_like(cur)

@@ -64,6 +64,11 @@ cases.append(('H x8 alternating gathered/low bit (8 rounds)', ops_seq('h', 8, [h
 cases.append(('H x16 alternating gathered/low bit (16 rounds?)', ops_seq('h', 16, [hi, 2])))
 cases.append(('H x12 on 12 different bits (3+ rounds)', ops_seq('h', 12, [hi, hi - 1, hi - 2, hi - 3, hi - 4, 0, 1, 2, 3, 4, 5, 6])))
 
+# memory side: the same 7 gates on scattered gathered bits (256-byte runs at L = 5) vs adjacent ones
+scat = [n - 1, n - 3, n - 6, n - 8, n - 11, n - 13, n - 15]
+cases.append(('H x7 on 7 scattered gathered bits', ops_seq('h', 7, scat)))
+cases.append(('H x28 on 7 scattered gathered bits', ops_seq('h', 28, scat)))
+cases.append(('H x7 on 7 adjacent bits just above L', ops_seq('h', 7, [5, 6, 7, 8, 9, 10, 11])))
 x = torch.zeros(args.batch, 1 << n, dtype=dtype, device=dev)
 x[:, 0] = 1
 state_bytes = 2 * x.numel() * x.element_size()
@@ -72,12 +77,13 @@ for name, ops in cases:
     steps = fusion.schedule(ops, n, geom)
     assert len(steps) == 1 and isinstance(steps[0], fusion.FusedStep), (name, len(steps))
     st = steps[0]
-    backend.apply_fused(x, mats, 0, st.desc, out=x)  # warm
+    km = fusion.kernel_matrices(steps, ops, mats)
+    backend.apply_fused(x, km, 0, st.desc, out=x)  # warm
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(args.reps):
-        backend.apply_fused(x, mats, 0, st.desc, out=x)
+        backend.apply_fused(x, km, 0, st.desc, out=x)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.reps
