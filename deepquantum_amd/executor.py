@@ -31,6 +31,7 @@ class Prim:
     targets: tuple[int, ...]       # bit positions, matrix MSB first
     controls: tuple[int, ...] = ()
     mode: int = 0                  # 2x2 matrix structure known from the gate class: 0 general, 1 real, 2 Rx-like
+    unitary: bool = True           # False for channel superoperators: not reversible, per-gate autograd only
 
 
 @dataclass
@@ -48,7 +49,10 @@ _PLAN_CACHE_SIZE = 64
 
 # Tunables (debug / benchmarking): tile bits per precision; None = library default.
 CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
-          'max_gates': None, 'max_far': None, 'far_bit': None}
+          'max_gates': None, 'max_far': None, 'far_bit': None,
+          # 'adjoint': fused forward + reverse sweep with recomputation (O(1) states of memory);
+          # 'per_gate': one autograd node per gate (saves every intermediate state; supports double backward)
+          'grad_mode': 'adjoint'}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates) to report the kernel's average duration next to its algorithmic bytes.
@@ -138,12 +142,20 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> to
         return state
     if state.ndim != 2:
         raise ValueError('state must be (batch, 2**n)')
-    n = state.shape[-1].bit_length() - 1
     if needs_autograd(state, prims):
+        vmapped = ops._is_batched(state) or any(ops._is_batched(p.matrix) for p in prims)
+        if CONFIG['grad_mode'] == 'adjoint' and not vmapped and all(p.unitary for p in prims):
+            meta = tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode) for p in prims)
+            return _AdjointCircuit.apply(state, meta, *[p.matrix for p in prims])
         x = state
         for p in prims:
             x = ops.apply_gate(x, p.matrix, p.targets, p.controls)
         return x
+    return _run_nograd(state, prims, inplace)
+
+
+def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> torch.Tensor:
+    n = state.shape[-1].bit_length() - 1
     with torch.no_grad():
         is128 = state.dtype == torch.complex128
         x = state if (inplace and state.is_contiguous()) else state.detach().clone(memory_format=torch.contiguous_format)
@@ -178,3 +190,68 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> to
                 stats['singles'] += 1
         LAST_RUN.update(stats)
         return x
+
+
+def _inverse(kind: str, m: torch.Tensor) -> torch.Tensor:
+    """Exact inverse of a (.., D, D) gate matrix (the reference's fixed matrices are float32-rounded, so
+    U^dagger is an inverse only to 1e-8: recomputation must not drift)."""
+    if kind == 'diag':
+        return torch.diag_embed(1.0 / m.diagonal(dim1=-2, dim2=-1))
+    if m.shape[-1] == 2:
+        a, b, c, d = m[..., 0, 0], m[..., 0, 1], m[..., 1, 0], m[..., 1, 1]
+        det = a * d - b * c
+        return torch.stack([torch.stack([d, -b], dim=-1), torch.stack([-c, a], dim=-1)], dim=-2) / det[..., None, None]
+    return torch.linalg.inv_ex(m)[0]
+
+
+class _AdjointCircuit(torch.autograd.Function):
+    """y = U_K ... U_1 x for reversible gates as ONE autograd node.  Forward: the fused passes.  Backward: a
+    reverse sweep over two states stacked as one batch -- psi_j recomputed with the exact inverses, the
+    cotangent lambda_j carried with the adjoints -- and, for every matrix that needs a gradient,
+    dL/dU_j = [sum lambda_j (x) conj(psi_j)] U_j^{-dagger} from the gate-gradient kernel.  Memory: two extra
+    states whatever the depth (stock autograd, as in the reference, keeps one state per gate); stretches of
+    gates between two trainable ones are undone by fused passes."""
+
+    @staticmethod
+    def forward(ctx, state, meta, *mats):
+        prims = [Prim(k, m, t, c, mode) for (k, t, c, mode), m in zip(meta, mats, strict=True)]
+        out = _run_nograd(state, prims)
+        ctx.meta = meta
+        ctx.save_for_backward(out, *mats)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        out, *mats = ctx.saved_tensors
+        meta = ctx.meta
+        b = out.shape[0]
+        work = torch.cat([out, gy.to(out.dtype)]).contiguous()        # rows [0, b): psi, rows [b, 2b): lambda
+        grads: list = [None] * len(mats)
+        pending: list[Prim] = []
+
+        def flush():
+            nonlocal work
+            if pending:
+                work = _run_nograd(work, pending, inplace=True)
+                pending.clear()
+
+        for j in range(len(mats) - 1, -1, -1):
+            kind, targets, controls, mode = meta[j]
+            u = mats[j] if mats[j].ndim == 3 else mats[j].unsqueeze(0)
+            u = u.to(out.dtype)
+            inv = u if kind == 'x' else _inverse(kind, u)
+            if ctx.needs_input_grad[2 + j]:
+                flush()
+                g = backend.gate_grad(work[:b], work[b:], targets, controls) @ inv.mH.to(torch.complex128)
+                if kind == 'diag':
+                    g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))   # the kernels ignore off-diagonal entries
+                if u.shape[0] == 1 and b > 1:
+                    g = g.sum(dim=0, keepdim=True)
+                grads[j] = g.to(mats[j].dtype).reshape(mats[j].shape)
+            d = u.shape[-1]
+            both = torch.cat([inv.expand(b, d, d), u.mH.expand(b, d, d)])   # per-sample matrices for the 2b rows
+            pending.append(Prim(kind, both, targets, controls, mode))
+        flush()
+        gstate = work[b:].clone() if ctx.needs_input_grad[0] else None
+        return (gstate, None, *grads)

@@ -301,7 +301,7 @@ class Channel(Operation):
 
     def dm_prims(self, decompose: bool = True) -> list[Prim]:
         bit = self.nqubit - 1 - self.wires[0]
-        return [Prim('gen', self.superoperator(), (bit + self.nqubit, bit), (), 0)]
+        return [Prim('gen', self.superoperator(), (bit + self.nqubit, bit), (), 0, unitary=False)]
 
     def prims(self, decompose: bool = True) -> list[Prim]:
         raise NotImplementedError('a channel acts on density matrices only')

@@ -189,3 +189,63 @@ def check_circuit_against_golden(dq, name, prec, device=None, check_unitary=True
             ref_u = gold(f'{name}/{prec}/unitary')
             assert (u.cpu() - ref_u).abs().max().item() < tol
     return err
+
+
+def check_adjoint_grad_mode(dq, device=None, dtype=torch.float64, n=6, tol=1e-10):
+    """The default autograd mode (one node per circuit: fused forward, reverse sweep with recomputation) against
+    the one-node-per-gate mode, on a circuit with fixed float32-rounded gates (exact inverses matter), diagonal,
+    controlled, two-qubit trainable gates, batched data and a state that itself requires grad."""
+    def build():
+        torch.manual_seed(3)
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        cir.rxlayer(encode=True)
+        cir.cnot_ring()
+        cir.rylayer()                         # trainable
+        cir.rz(0, encode=True)
+        cir.p(1)                              # trainable diagonal
+        cir.crx(0, 2, encode=True)
+        cir.rzz([1, 3])                       # trainable two-qubit diagonal
+        cir.rxx([2, 4])                       # trainable two-qubit dense
+        cir.toffoli(0, 1, 5)
+        cir.u3(3, controls=[0, 5])            # trainable, two controls
+        cir.s(2)
+        cir.t(4)
+        cir.swap([1, 5])
+        cir.hlayer()
+        cir.observable(0)
+        cir.observable([1, 2], 'xy')
+        cir.observable([3, 5], 'zz')
+        if device is not None:
+            cir.to(device)
+        if dtype == torch.float64:
+            cir.to(torch.double)
+        return cir
+
+    results = {}
+    for mode in ('per_gate', 'adjoint'):
+        dq.executor.CONFIG['grad_mode'] = mode
+        try:
+            cir = build()
+            g = torch.Generator().manual_seed(8)
+            data = torch.rand(3, cir.ndata, generator=g, dtype=dtype)
+            psi0 = torch.randn(3, 2**n, 1, generator=g, dtype=dtype) + 1j * torch.randn(3, 2**n, 1, generator=g, dtype=dtype)
+            psi0 = psi0 / psi0.norm(dim=1, keepdim=True)
+            if device is not None:
+                data, psi0 = data.to(device), psi0.to(device)
+            data.requires_grad_(True)
+            psi0.requires_grad_(True)
+            cir(data=data, state=psi0)
+            loss = (cir.expectation() * torch.tensor([1.0, -0.5, 0.25], dtype=dtype, device=data.device)).sum()
+            loss.backward()
+            results[mode] = (loss.detach().cpu(), data.grad.cpu(), psi0.grad.cpu(),
+                             [p.grad.cpu() for p in cir.parameters()])
+        finally:
+            dq.executor.CONFIG['grad_mode'] = 'adjoint'
+    a, b = results['per_gate'], results['adjoint']
+    assert abs(a[0] - b[0]).item() < tol
+    assert (a[1] - b[1]).abs().max().item() < tol, (a[1] - b[1]).abs().max()
+    assert (a[2] - b[2]).abs().max().item() < tol, (a[2] - b[2]).abs().max()
+    assert len(a[3]) == len(b[3]) and len(a[3]) > 0
+    for x, y in zip(a[3], b[3], strict=True):
+        assert (x - y).abs().max().item() < tol, (x - y).abs().max()

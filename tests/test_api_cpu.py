@@ -236,3 +236,10 @@ def test_density_matrix_path_matches_reference(cpu_backend):
     from _helpers import check_density_matrix_against_golden
 
     check_density_matrix_against_golden(dq)
+
+
+def test_adjoint_grad_mode_matches_per_gate_autograd(cpu_backend):
+    from _helpers import check_adjoint_grad_mode
+
+    check_adjoint_grad_mode(dq, dtype=torch.float64, tol=1e-10)
+    check_adjoint_grad_mode(dq, dtype=torch.float32, tol=2e-5)
