@@ -1,0 +1,62 @@
+"""Training step (forward + expectation + backward w.r.t. every Rx angle) of the benchmark generator circuit.
+usage: python tools/bench_train.py [--n 24] [--depth 20] [--modes adjoint,per_gate] [--dtype c64]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deepquantum_amd as dq  # noqa: E402
+from oracle.statevec_oracle import random_circuit_spec  # noqa: E402  (workload generator only)
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--n', type=int, default=24)
+ap.add_argument('--depth', type=int, default=20)
+ap.add_argument('--modes', default='adjoint,per_gate')
+ap.add_argument('--dtype', default='c64')
+ap.add_argument('--reps', type=int, default=2)
+args = ap.parse_args()
+
+for mode in args.modes.split(','):
+    dq.executor.CONFIG['grad_mode'] = mode
+    cir = dq.QubitCircuit(args.n)
+    nrx = 0
+    for op in random_circuit_spec(args.n, args.depth, 1234):
+        if op[0] == 'h':
+            cir.h(op[1])
+        elif op[0] == 'rx':
+            cir.rx(op[1])
+            nrx += 1
+        else:
+            cir.cnot(op[1], op[2])
+    cir.observable(0)
+    cir.to('cuda')
+    if args.dtype == 'c128':
+        cir.to(torch.double)
+
+    def step():
+        cir.zero_grad()
+        cir()
+        cir.expectation().sum().backward()
+
+    step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.reps
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        cir()
+        torch.cuda.synchronize()
+        fwd = time.perf_counter() - t0
+    sb = (8 if args.dtype == 'c64' else 16) * 2**args.n
+    print(f'{mode:9s} n={args.n} depth={args.depth} ({args.n * args.depth} gates, {nrx} trainable) {args.dtype}: '
+          f'step {dt * 1e3:8.1f} ms (no-grad forward {fwd * 1e3:6.1f} ms), peak {torch.cuda.max_memory_allocated() / sb:6.1f} states '
+          f'= {torch.cuda.max_memory_allocated() / 2**30:6.1f} GiB')
+    del cir
+    torch.cuda.empty_cache()
