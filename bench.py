@@ -54,6 +54,28 @@ def parse_args():
     return ap.parse_args()
 
 
+def random_circuit_spec(nqubit, depth, seed=1234):
+    """The workload generator of SURVEY section 8(d), stated here so that the measured path imports nothing from
+    ``oracle/`` (tests check that the oracle's and the fixtures' generators are this same one): per layer, per
+    qubit q: 1/3 H(q), 1/3 Rx(q, U(0, 2 pi)), 1/3 CNOT(q, random other qubit)."""
+    import random
+
+    rng = random.Random(seed)
+    spec = []
+    for _ in range(depth):
+        for q in range(nqubit):
+            r = rng.random()
+            if r < 1 / 3:
+                spec.append(('h', q))
+            elif r < 2 / 3:
+                spec.append(('rx', q, rng.uniform(0, 2 * math.pi)))
+            else:
+                t = rng.randrange(nqubit - 1)
+                t += t >= q
+                spec.append(('cnot', q, t))
+    return spec
+
+
 def build_circuit(dq, n, spec, batch, dtype, device, distributed=False):
     """The generator's circuit; Rx angles are encoder inputs so each batch sample has its own."""
     cir = dq.DistributedQubitCircuit(n) if distributed else dq.QubitCircuit(n)
@@ -135,7 +157,6 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     import deepquantum_amd as dq
-    from oracle.statevec_oracle import random_circuit_spec  # workload generator only
 
     dtype = torch.complex64 if args.dtype == 'c64' else torch.complex128
     amp_bytes = 8 if dtype == torch.complex64 else 16

@@ -45,6 +45,9 @@ def test_oracle_generator_is_the_survey_generator():
     a = to_oracle_spec(specs.random_spec(9, 7, 1234))
     b = oracle.random_circuit_spec(9, 7, 1234)
     assert a == b
+    import bench
+
+    assert bench.random_circuit_spec(9, 7, 1234) == b      # bench.py states the generator itself
 
 
 def test_oracle_gate_cases_match_reference():

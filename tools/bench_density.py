@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deepquantum_amd as dq  # noqa: E402
-from oracle.statevec_oracle import random_circuit_spec  # noqa: E402  (workload generator only)
+from bench import random_circuit_spec  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--n', type=int, default=14)

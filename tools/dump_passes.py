@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deepquantum_amd as dq
 import bench
-from oracle.statevec_oracle import random_circuit_spec
+from bench import random_circuit_spec
 n, depth, batch = 28, 40, int(os.environ.get('B', 4))
 dev = torch.device('cuda', 0)
 spec = random_circuit_spec(n, depth, 1234)
