@@ -62,6 +62,7 @@ class Geometry:
     min_low: int      # minimum contiguous low bits of a tile (coalescing floor)
     max_gates: int = _lib.FUSED_MAX_GATES
     max_rounds: int = _lib.FUSED_MAX_ROUNDS - 1  # one spare so a trailing round never overflows
+    lookahead: bool = False   # choose the gathered bits of a pass by look-ahead (_choose_high)
     far_bit: int = 19         # index bits >= far_bit are "far": every one gathered doubles the number of
     max_far: int | None = None  # distant address streams of a tile; None = no limit (tools/sweep_tile_bits*.py)
 
@@ -71,18 +72,18 @@ class Geometry:
 
 
 def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = None) -> Geometry:
+    """Tile geometry per precision.  ``min_low`` = contiguous low bits every tile keeps: fewer of them leave more
+    tile bits for the qubits the gates need (fewer passes) at the price of shorter contiguous runs (slower
+    passes).  Measured on the headline sizes (ms per step, passes): c64, n = 28, batch 16: min_low 6 / 5 / 4 ->
+    643 (40) / 614 (35) / 596 (32); c128, n = 28, batch 8: min_low 4 / 3 -> 703 (38) / 671 (33).  The optimum is
+    128-byte runs (one cache line per lane group) in both precisions."""
     if is_c128:
         m = 11 if m is None else m
         slots = {11: 3, 12: 4}[m] if slots is None else slots
-        # 16-byte amplitudes: 4 contiguous low bits = 256-byte runs (same as c64 with 5); measured at n = 28,
-        # batch 8: min_low 6 / 5 / 4 -> 803 / 738 / 716 ms per step
-        return Geometry(m=m, slots=slots, vb=0, min_low=4)
+        return Geometry(m=m, slots=slots, vb=0, min_low=max(3, m - _lib.FUSED_MAX_HIGH))
     m = 12 if m is None else m
     slots = 4 if slots is None else slots
-    # min_low = 5: every lane still moves 16 B and a wave instruction covers 256-byte runs (two 128-B
-    # lines); the extra gathered bit buys more fusion.  Measured on the headline workload (tools/sweep2.sh):
-    # min_low 7 / 6 / 5 / 4 -> 46 / 40 / 35 / 32 passes, 707 / 650 / 629 / 617 ms per step.
-    return Geometry(m=m, slots=slots, vb=1, min_low=5)
+    return Geometry(m=m, slots=slots, vb=1, min_low=max(4, m - _lib.FUSED_MAX_HIGH))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -130,6 +131,67 @@ class _Dag:
             self.ready = sorted(self.ready + new)
 
 
+def _closure(dag: '_Dag', tile: set[int], cap: int) -> int:
+    """How many gates a pass owning ``tile`` could retire from the current front (ignoring the round / slot
+    limits): every fusable diagonal gate, every other fusable gate whose targets lie in the tile."""
+    ops, indeg = dag.ops, {}
+    stack = list(dag.ready)
+    count = 0
+    while stack and count < cap:
+        i = stack.pop()
+        op = ops[i]
+        if not _fusable(op) or (op.kind != 'diag' and not all(t in tile for t in op.targets)):
+            continue
+        count += 1
+        for s_ in dag.succ[i]:
+            left = indeg.get(s_, dag.indeg[s_]) - 1
+            indeg[s_] = left
+            if left == 0:
+                stack.append(s_)
+    return count
+
+
+def _choose_high(dag: '_Dag', low: set[int], hcap: int, geom: 'Geometry', n: int) -> set[int]:
+    """Pick the gathered bits of the next pass by look-ahead: grow the set one bit at a time, always the bit
+    that lets the pass retire the most gates.  Experimental (Geometry.lookahead, off): on the headline circuit
+    it needs as many passes as the first-come rule (35) and more at other sizes -- maximising the gates of the
+    next pass scatters the front; what bounds a pass is how far 12 qubits can advance before a CNOT reaches
+    outside the tile (about 2.7 layers)."""
+    chosen: set[int] = set()
+    cap = geom.max_gates
+    while len(chosen) < hcap:
+        tile = low | chosen
+        # candidate bits: targets of gates that are ready or one step behind the front
+        cands: dict[int, int] = {}
+        front = list(dag.ready)
+        seen = set(front)
+        for i in list(front):
+            for s_ in dag.succ[i]:
+                if s_ not in seen:
+                    seen.add(s_)
+                    front.append(s_)
+        for i in front:
+            op = dag.ops[i]
+            if op.kind == 'diag' or not _fusable(op):
+                continue
+            for t in op.targets:
+                if t not in tile:
+                    cands[t] = cands.get(t, 0) + 1
+        if not cands:
+            break
+        base = _closure(dag, tile, cap)
+        if base >= cap:
+            break
+        best, best_key = None, None
+        for q, weight in cands.items():
+            gain = _closure(dag, tile | {q}, cap)
+            key = (gain, weight, -q)
+            if best_key is None or key > best_key:
+                best, best_key = q, key
+        chosen.add(best)
+    return chosen
+
+
 @dataclass
 class _Round:
     slots: list[int] = field(default_factory=list)  # global bits that must be register slots
@@ -155,9 +217,12 @@ def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True) -
         high: set[int] = set()          # tile bits beyond the guaranteed low ones
         rounds: list[_Round] = [_Round()]
         count = 0
+        allowed = _choose_high(dag, low, hcap, geom, n) if geom.lookahead else None
 
         def fits_tile(op: PrimOp) -> bool:
             need = {t for t in op.targets if t not in low} - high
+            if allowed is not None and not need <= allowed:
+                return False
             if geom.max_far is not None and sum(1 for b in high | need if b >= geom.far_bit) > geom.max_far:
                 return False    # too many far-apart address streams per tile (DRAM row conflicts)
             return len(high) + len(need) <= hcap and len(high | need) <= min(hcap, n - geom.min_low)
