@@ -20,6 +20,7 @@
 // Roofline: HBM-bound by construction.  Algorithmic bytes per launch = sum over the gates of the
 // pass of 2 * 2^(n - nc) * sizeof(amp) * batch; actual traffic = 2 * 2^n * sizeof(amp) * batch.
 #include "dq_common.hpp"
+#include <type_traits>
 #include <stddef.h>
 
 #ifndef DQ_USE_ASM_BLOCKS
@@ -92,6 +93,10 @@ __device__ __forceinline__ void apply2x2(amp<T>& x0, amp<T>& x1, const amp<T> m0
 // mq[] = the four matrix entries as raw 64-bit SGPR pairs (low half re, high half im).
 template <int MODE, int Q> __device__ __forceinline__ void gen1_block_f32(vec2<float> (&a)[16], const uint64_t (&mq)[4]);
 template <int Q, int CMASK> __device__ __forceinline__ void x1_block_f32(vec2<float> (&a)[16]);
+// ---- complex128 (3 register slots = 8 amplitudes per thread): v_mul_f64 / v_fma_f64 chains on the re / im
+// doubles, the 8 real numbers of the matrix as SGPR pairs; in-place final FMA, no register copies.
+template <int MODE, int Q> __device__ __forceinline__ void gen1_block_f64(vec2<double> (&a)[8], const double (&md)[8]);
+template <int Q, int CMASK> __device__ __forceinline__ void x1_block_f64(vec2<double> (&a)[8]);
 #include "dq_fused_asm.inc"
 
 template <int MODE>
@@ -213,6 +218,17 @@ __device__ __forceinline__ void dispatch_x1_block_f32(vec2<float> (&a)[16], unsi
     }
 }
 
+template <int Q>
+__device__ __forceinline__ void dispatch_x1_block_f64(vec2<double> (&a)[8], unsigned cmask) {
+    switch (cmask) {
+        case 0: x1_block_f64<Q, 0>(a); break;
+#define DQ_X1_CASE(C) case C: if constexpr (!((C >> Q) & 1)) x1_block_f64<Q, C>(a); break;
+        DQ_X1_CASE(1) DQ_X1_CASE(2) DQ_X1_CASE(3) DQ_X1_CASE(4) DQ_X1_CASE(5) DQ_X1_CASE(6)
+#undef DQ_X1_CASE
+        default: break;
+    }
+}
+
 template <typename T, int R>
 __device__ __forceinline__ void dispatch_x1(amp<T> (&a)[1 << R], int q, unsigned reg_cmask, bool lane_pred, bool thr_ok) {
     if (lane_pred && !thr_ok) return;  // per-lane control: exec-masked region around the swaps
@@ -277,6 +293,7 @@ template <int ESZ> __device__ __forceinline__ unsigned lds_swz(unsigned e) {
 }
 
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
 // Mirror of the kernel's argument list: where the by-value descriptor sits in the kernarg segment.
 struct FusedKernArgs {
@@ -387,7 +404,9 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     };
 
     const uint64_t tile_global = tile;  // global index bits fixed for this workgroup (outside the tile)
-    constexpr bool FAST = (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS);
+    constexpr bool FAST32 = (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS);
+    constexpr bool FAST64 = (sizeof(T) == 8 && R == 3 && DQ_USE_ASM_BLOCKS);
+    constexpr bool FAST = FAST32 || FAST64;
     // Gate records are fetched with explicit scalar loads from the kernel-argument segment (the descriptor
     // is passed by value; its address must not be taken through `&p`, that would force a private copy).
     const uint64_t kgates = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FusedKernArgs, p) +
@@ -422,9 +441,14 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         for (int gi = gbeg; gi < gend; ++gi) {
             // ONE scalar-memory round trip per gate: the 32-byte record and -- from the running pointer, no
             // decode needed because the host lays the matrices of a pass out in gate order -- its matrix.
-            u32x8 rec, mqv;
-            if constexpr (FAST) {
+            u32x8 rec;
+            typename std::conditional<FAST64, u32x16, u32x8>::type mqv;
+            if constexpr (FAST32) {
                 asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(rec), "=&s"(mqv)
+                             : "s"(gaddr), "s"(mrun));
+            } else if constexpr (FAST64) {
+                asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
                              : "=&s"(rec), "=&s"(mqv)
                              : "s"(gaddr), "s"(mrun));
             } else {
@@ -440,36 +464,66 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
                 // switch instead of the kind / control / mode / slot decision chain -- the scalar unit is the
                 // scarce resource of this kernel.  Ids < 16 have no control of any kind: no test at all.
                 if (fast < 32u) {
-                    const uint64_t mq[4] = {(uint64_t)mqv[0] | ((uint64_t)mqv[1] << 32),
-                                            (uint64_t)mqv[2] | ((uint64_t)mqv[3] << 32),
-                                            (uint64_t)mqv[4] | ((uint64_t)mqv[5] << 32),
-                                            (uint64_t)mqv[6] | ((uint64_t)mqv[7] << 32)};
+#define DQ_PAIR(I) ((uint64_t)mqv[2 * (I)] | ((uint64_t)mqv[2 * (I) + 1] << 32))
+                    if constexpr (FAST32) {
+                        const uint64_t mq[4] = {DQ_PAIR(0), DQ_PAIR(1), DQ_PAIR(2), DQ_PAIR(3)};
 #define DQ_GEN1_CASE(ID) case ID: gen1_block_f32<(ID) / 4, (ID) % 4>(a, mq); break;
 #define DQ_GEN1_CASES                                                                           \
     DQ_GEN1_CASE(0) DQ_GEN1_CASE(1) DQ_GEN1_CASE(2) DQ_GEN1_CASE(3) DQ_GEN1_CASE(4) DQ_GEN1_CASE(5) \
     DQ_GEN1_CASE(6) DQ_GEN1_CASE(7) DQ_GEN1_CASE(8) DQ_GEN1_CASE(9) DQ_GEN1_CASE(10) DQ_GEN1_CASE(11)
-                    if (fast < 16u) {
-                        switch (fast) {
-                            DQ_GEN1_CASES
-                            case 12: x1_block_f32<0, 0>(a); break;
-                            case 13: x1_block_f32<1, 0>(a); break;
-                            case 14: x1_block_f32<2, 0>(a); break;
-                            default: x1_block_f32<3, 0>(a); break;
+                        if (fast < 16u) {
+                            switch (fast) {
+                                DQ_GEN1_CASES
+                                case 12: x1_block_f32<0, 0>(a); break;
+                                case 13: x1_block_f32<1, 0>(a); break;
+                                case 14: x1_block_f32<2, 0>(a); break;
+                                default: x1_block_f32<3, 0>(a); break;
+                            }
+                            continue;
                         }
-                        continue;
-                    }
-                    if ((tile_global & out_cmask) != out_cmask) continue;  // uniform: an outside control is 0
-                    if ((tbase & thr_cmask) == thr_cmask) {
-                        switch (fast - 16u) {
-                            DQ_GEN1_CASES
-                            case 12: dispatch_x1_block_f32<0>(a, reg_cmask); break;
-                            case 13: dispatch_x1_block_f32<1>(a, reg_cmask); break;
-                            case 14: dispatch_x1_block_f32<2>(a, reg_cmask); break;
-                            default: dispatch_x1_block_f32<3>(a, reg_cmask); break;
+                        if ((tile_global & out_cmask) != out_cmask) continue;  // uniform: an outside control is 0
+                        if ((tbase & thr_cmask) == thr_cmask) {
+                            switch (fast - 16u) {
+                                DQ_GEN1_CASES
+                                case 12: dispatch_x1_block_f32<0>(a, reg_cmask); break;
+                                case 13: dispatch_x1_block_f32<1>(a, reg_cmask); break;
+                                case 14: dispatch_x1_block_f32<2>(a, reg_cmask); break;
+                                default: dispatch_x1_block_f32<3>(a, reg_cmask); break;
+                            }
                         }
-                    }
 #undef DQ_GEN1_CASES
 #undef DQ_GEN1_CASE
+                    } else {
+                        const double md[8] = {__longlong_as_double((long long)DQ_PAIR(0)), __longlong_as_double((long long)DQ_PAIR(1)),
+                                              __longlong_as_double((long long)DQ_PAIR(2)), __longlong_as_double((long long)DQ_PAIR(3)),
+                                              __longlong_as_double((long long)DQ_PAIR(4)), __longlong_as_double((long long)DQ_PAIR(5)),
+                                              __longlong_as_double((long long)DQ_PAIR(6)), __longlong_as_double((long long)DQ_PAIR(7))};
+#define DQ_GEN1_CASE(ID) case ID: gen1_block_f64<(ID) / 4, (ID) % 4>(a, md); break;
+#define DQ_GEN1_CASES                                                                           \
+    DQ_GEN1_CASE(0) DQ_GEN1_CASE(1) DQ_GEN1_CASE(2) DQ_GEN1_CASE(4) DQ_GEN1_CASE(5) DQ_GEN1_CASE(6) \
+    DQ_GEN1_CASE(8) DQ_GEN1_CASE(9) DQ_GEN1_CASE(10)
+                        if (fast < 16u) {
+                            switch (fast) {
+                                DQ_GEN1_CASES
+                                case 12: x1_block_f64<0, 0>(a); break;
+                                case 13: x1_block_f64<1, 0>(a); break;
+                                default: x1_block_f64<2, 0>(a); break;
+                            }
+                            continue;
+                        }
+                        if ((tile_global & out_cmask) != out_cmask) continue;
+                        if ((tbase & thr_cmask) == thr_cmask) {
+                            switch (fast - 16u) {
+                                DQ_GEN1_CASES
+                                case 12: dispatch_x1_block_f64<0>(a, reg_cmask); break;
+                                case 13: dispatch_x1_block_f64<1>(a, reg_cmask); break;
+                                default: dispatch_x1_block_f64<2>(a, reg_cmask); break;
+                            }
+                        }
+#undef DQ_GEN1_CASES
+#undef DQ_GEN1_CASE
+                    }
+#undef DQ_PAIR
                     continue;
                 }
             }
