@@ -52,7 +52,9 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
           'max_gates': None, 'max_far': None, 'far_bit': None,
           # 'adjoint': fused forward + reverse sweep with recomputation (O(1) states of memory);
           # 'per_gate': one autograd node per gate (saves every intermediate state; supports double backward)
-          'grad_mode': 'adjoint'}
+          'grad_mode': 'adjoint',
+          # states smaller than a tile: fuse (batch folded into the index, or zero-padded) from this many gates on
+          'small_fuse_min_gates': 6}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates) to report the kernel's average duration next to its algorithmic bytes.
@@ -154,10 +156,30 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> to
     return _run_nograd(state, prims, inplace)
 
 
+def _run_small(state: torch.Tensor, prims: Sequence[Prim], n: int, m: int) -> torch.Tensor | None:
+    """States smaller than a tile (n < m): run the fused passes anyway instead of one launch per gate.
+    Shared matrices and a power-of-two batch: the batch index is just more (idle) high qubits of one
+    (n + log2 B)-qubit state.  Otherwise every sample is embedded in an m-qubit state |0..0> (x) |psi>
+    (zero padding; the pad qubits are never touched), one workgroup per sample."""
+    b = state.shape[0]
+    batched_mats = any(p.matrix.ndim == 3 and p.matrix.shape[0] > 1 for p in prims)
+    if not batched_mats and b & (b - 1) == 0 and n + b.bit_length() - 1 >= m:
+        out = _run_nograd(state.detach().reshape(1, -1), prims, inplace=False)
+        return out.reshape(b, -1)
+    padded = state.new_zeros(b, 1 << m)
+    padded[:, : 1 << n] = state.detach()
+    out = _run_nograd(padded, prims, inplace=True)
+    return out[:, : 1 << n].contiguous()
+
+
 def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> torch.Tensor:
     n = state.shape[-1].bit_length() - 1
     with torch.no_grad():
         is128 = state.dtype == torch.complex128
+        m = _geometry(is128).m
+        if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
+                and all(len(p.targets) <= 2 for p in prims)):
+            return _run_small(state, prims, n, m)
         x = state if (inplace and state.is_contiguous()) else state.detach().clone(memory_format=torch.contiguous_format)
         plan = make_plan(prims, n, is128)
         flat, stride = _flat_mats(prims, plan.mat_order, x.shape[0], x.dtype, x.device)
