@@ -36,4 +36,4 @@ from .layer import (
 from .operation import Channel, Gate, Layer, Operation
 from .qmath import amplitude_encoding, expectation, measure, multi_kron
 from .state import DistributedQubitState, QubitState
-from .utils import dtype_map
+from .utils import CapturedGraph, dtype_map

@@ -270,3 +270,71 @@ def test_adjoint_backward_memory_is_independent_of_depth():
     assert len(grads) == nrx and all(g is not None and torch.isfinite(g).all() for g in grads)
     assert peak < 8 * state_bytes, f'peak {peak / state_bytes:.1f} states'
     print(f'n={n}: {nrx} trainable angles, peak memory {peak / state_bytes:.1f} states')
+
+
+def _qml_circuit(n, trainable, seed=1234):
+    import bench
+
+    cir = dq.QubitCircuit(n)
+    for op in bench.random_circuit_spec(n, 12, seed):
+        if op[0] == 'h':
+            cir.h(op[1])
+        elif op[0] == 'rx':
+            cir.rx(op[1]) if trainable else cir.rx(op[1], encode=True)
+        else:
+            cir.cnot(op[1], op[2])
+    cir.observable(0)
+    cir.observable([1, 2], 'zx')
+    return cir.to(dev())
+
+
+def test_hip_graph_capture_of_forward_and_training_step():
+    """Launch-bound sizes: the whole evaluation (and the whole forward + backward) replays as one HIP graph."""
+    n = 7
+    cir = _qml_circuit(n, trainable=False)
+    data = torch.zeros(16, cir.ndata, device=dev())
+    with torch.no_grad():
+        graph = dq.CapturedGraph(lambda: (cir(data), cir.expectation())[1])
+        for seed in (1, 2):
+            batch = torch.rand(16, cir.ndata, generator=torch.Generator().manual_seed(seed)).to(dev()) * 6.28
+            data.copy_(batch)
+            got = graph.replay().clone()
+            ref_cir = _qml_circuit(n, trainable=False)
+            ref_cir(batch)
+            assert (got - ref_cir.expectation()).abs().max().item() < 1e-5
+
+    for mode in ('adjoint', 'per_gate'):
+        dq.executor.CONFIG['grad_mode'] = mode
+        try:
+            torch.manual_seed(5)
+            train = _qml_circuit(n, trainable=True)
+            torch.manual_seed(5)
+            eager = _qml_circuit(n, trainable=True)
+            for p, q in zip(train.parameters(), eager.parameters(), strict=True):
+                assert torch.equal(p, q)
+
+            def step():
+                train()
+                loss = train.expectation().sum()
+                loss.backward()
+                return loss
+
+            train.zero_grad(set_to_none=True)
+            graph = dq.CapturedGraph(step)
+            for it in range(2):
+                for p in train.parameters():
+                    p.grad.zero_()
+                loss = graph.replay()
+                eager.zero_grad(set_to_none=True)
+                eager()
+                ref = eager.expectation().sum()
+                ref.backward()
+                assert abs(loss.item() - ref.item()) < 1e-5
+                for p, q in zip(train.parameters(), eager.parameters(), strict=True):
+                    assert (p.grad - q.grad).abs().max().item() < 1e-4, mode
+                with torch.no_grad():       # an SGD step on both, then replay again
+                    for p, q in zip(train.parameters(), eager.parameters(), strict=True):
+                        p.sub_(0.1 * p.grad)
+                        q.sub_(0.1 * q.grad)
+        finally:
+            dq.executor.CONFIG['grad_mode'] = 'adjoint'

@@ -57,5 +57,21 @@ for label, thresh in (('fused (small-state path)', 6), ('one launch per gate', 1
         cir2.expectation().sum().backward()
 
     tr = timeit(step)
+    # the same two jobs replayed as HIP graphs
+    with torch.no_grad():
+        gf = dq.CapturedGraph(lambda: (cir(data), cir.expectation())[1])
+    fwd_g = timeit(gf.replay)
+    cir3 = build(trainable=True)
+
+    def step3():
+        cir3()
+        loss = cir3.expectation().sum()
+        loss.backward()
+        return loss
+
+    cir3.zero_grad(set_to_none=True)
+    gt = dq.CapturedGraph(step3)
+    tr_g = timeit(gt.replay)
     print(f'{label:26s} n={args.n} depth={args.depth} ({args.n * args.depth} gates) batch={args.batch}: '
-          f'no-grad forward+<Z0> {fwd:7.2f} ms (per-sample angles); training step (batch 1, every Rx trainable) {tr:7.2f} ms')
+          f'no-grad forward+<Z0> {fwd:7.2f} ms eager / {fwd_g:6.3f} ms HIP graph (per-sample angles); '
+          f'training step (batch 1, every Rx trainable) {tr:7.2f} ms eager / {tr_g:6.3f} ms HIP graph')
