@@ -248,8 +248,27 @@ class _AdjointCircuit(torch.autograd.Function):
         out, *mats = ctx.saved_tensors
         meta = ctx.meta
         b = out.shape[0]
+        need = [ctx.needs_input_grad[2 + j] for j in range(len(mats))]
+        # Inverses / adjoints of ALL gates in a few vectorised calls (grouped by kind, size and batchness): at
+        # launch-bound sizes a handful of tiny kernels per gate would dominate the whole sweep.
+        groups: dict = {}
+        for j, ((kind, _t, _c, _mode), m) in enumerate(zip(meta, mats, strict=True)):
+            u = m if m.ndim == 3 else m.unsqueeze(0)
+            groups.setdefault((kind, u.shape[-1], u.shape[0]), []).append((j, u))
+        undo: list = [None] * len(mats)       # (2b, D, D): rows [0, b) the inverse, rows [b, 2b) the adjoint
+        inv_h: dict = {}                      # group key -> (positions, inverse^dagger stack) for the gradients
+        for key, members in groups.items():
+            kind, d, nb = key
+            us = torch.stack([u for _, u in members]).to(out.dtype)           # (K, nb, D, D)
+            inv = us if kind == 'x' else _inverse(kind, us)
+            both = torch.cat([inv.expand(-1, b, d, d), us.mH.expand(-1, b, d, d)], dim=1).contiguous()
+            for k, (j, _u) in enumerate(members):
+                undo[j] = both[k]
+            if any(need[j] for j, _ in members):
+                inv_h[key] = ({j: k for k, (j, _u) in enumerate(members)}, inv.mH.to(torch.complex128))
+
         work = torch.cat([out, gy.to(out.dtype)]).contiguous()        # rows [0, b): psi, rows [b, 2b): lambda
-        grads: list = [None] * len(mats)
+        raw: dict = {}                                                  # j -> sum lambda_j (x) conj(psi_j)
         pending: list[Prim] = []
 
         def flush():
@@ -260,20 +279,22 @@ class _AdjointCircuit(torch.autograd.Function):
 
         for j in range(len(mats) - 1, -1, -1):
             kind, targets, controls, mode = meta[j]
-            u = mats[j] if mats[j].ndim == 3 else mats[j].unsqueeze(0)
-            u = u.to(out.dtype)
-            inv = u if kind == 'x' else _inverse(kind, u)
-            if ctx.needs_input_grad[2 + j]:
+            if need[j]:
                 flush()
-                g = backend.gate_grad(work[:b], work[b:], targets, controls) @ inv.mH.to(torch.complex128)
-                if kind == 'diag':
-                    g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))   # the kernels ignore off-diagonal entries
-                if u.shape[0] == 1 and b > 1:
-                    g = g.sum(dim=0, keepdim=True)
-                grads[j] = g.to(mats[j].dtype).reshape(mats[j].shape)
-            d = u.shape[-1]
-            both = torch.cat([inv.expand(b, d, d), u.mH.expand(b, d, d)])   # per-sample matrices for the 2b rows
-            pending.append(Prim(kind, both, targets, controls, mode))
+                raw[j] = backend.gate_grad(work[:b], work[b:], targets, controls)
+            pending.append(Prim(kind, undo[j], targets, controls, mode))
         flush()
+
+        grads: list = [None] * len(mats)
+        for key, (pos, ih) in inv_h.items():
+            kind, d, nb = key
+            js = [j for j in pos if need[j]]
+            g = torch.stack([raw[j] for j in js]) @ ih[[pos[j] for j in js]]         # (K', b, D, D)
+            if kind == 'diag':
+                g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))      # the kernels ignore off-diagonal entries
+            if nb == 1 and b > 1:
+                g = g.sum(dim=1, keepdim=True)
+            for k, j in enumerate(js):
+                grads[j] = g[k].to(mats[j].dtype).reshape(mats[j].shape)
         gstate = work[b:].clone() if ctx.needs_input_grad[0] else None
         return (gstate, None, *grads)
