@@ -289,7 +289,9 @@ class _AdjointCircuit(torch.autograd.Function):
         for key, (pos, ih) in inv_h.items():
             kind, d, nb = key
             js = [j for j in pos if need[j]]
-            g = torch.stack([raw[j] for j in js]) @ ih[[pos[j] for j in js]]         # (K', b, D, D)
+            ks = [pos[j] for j in js]
+            ihs = ih if ks == list(range(ih.shape[0])) else torch.stack([ih[k] for k in ks])   # no host index tensors
+            g = torch.stack([raw[j] for j in js]) @ ihs                              # (K', b, D, D)
             if kind == 'diag':
                 g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))      # the kernels ignore off-diagonal entries
             if nb == 1 and b > 1:
