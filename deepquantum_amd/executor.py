@@ -270,19 +270,28 @@ class _AdjointCircuit(torch.autograd.Function):
         work = torch.cat([out, gy.to(out.dtype)]).contiguous()        # rows [0, b): psi, rows [b, 2b): lambda
         raw: dict = {}                                                  # j -> sum lambda_j (x) conj(psi_j)
         pending: list[Prim] = []
+        touched: set[int] = set()             # qubits the not-yet-undone gates act on
 
         def flush():
             nonlocal work
             if pending:
                 work = _run_nograd(work, pending, inplace=True)
                 pending.clear()
+                touched.clear()
 
         for j in range(len(mats) - 1, -1, -1):
             kind, targets, controls, mode = meta[j]
+            mine = set(targets) | set(controls)
             if need[j]:
-                flush()
+                # sum lambda (x) conj(psi) reduced to this gate's qubits does not change when BOTH states are
+                # pulled back through gates on other qubits (psi with U^-1, lambda with U^dagger: the partial
+                # trace sees U^dagger U^-dagger = 1 exactly), so the snapshot is stale only if a pending gate
+                # shares a qubit with this one.  On layered circuits this is one flush per layer, not per gate.
+                if mine & touched:
+                    flush()
                 raw[j] = backend.gate_grad(work[:b], work[b:], targets, controls)
             pending.append(Prim(kind, undo[j], targets, controls, mode))
+            touched |= mine
         flush()
 
         grads: list = [None] * len(mats)
