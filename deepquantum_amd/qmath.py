@@ -7,7 +7,6 @@ from __future__ import annotations
 from collections import Counter
 from typing import TYPE_CHECKING, Any
 
-import numpy as np
 import torch
 from torch import nn
 

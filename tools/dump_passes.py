@@ -1,5 +1,5 @@
 """Per-pass breakdown of the headline workload: gates, rounds, LDS trips and measured duration."""
-import os, sys, math
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deepquantum_amd as dq

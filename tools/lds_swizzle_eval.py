@@ -5,7 +5,7 @@ banks, ds_write_b64 in four contiguous 16-lane groups over 32 banks; ds_read_b12
 groups (non-contiguous) over 64 banks, ds_write_b128 in eight contiguous 8-lane groups over 32 banks.
 Cost of a group = max number of distinct addresses that fall on one bank slot.
 """
-import itertools, sys
+import itertools
 
 def deposit(tid, rb, m):
     e = 0; src = 0

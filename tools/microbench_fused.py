@@ -5,7 +5,6 @@ instruction counts per launch; every case is launched REPS times back to back.
 usage: python tools/microbench_fused.py [--n 28] [--batch 4] [--dtype c64] [--reps 3]
 """
 import argparse
-import math
 import os
 import sys
 

@@ -1,5 +1,5 @@
-import os, sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
+import sys
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from deepquantum_amd import backend, fusion
 n, dev = 28, torch.device('cuda', 0)
