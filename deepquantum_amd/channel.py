@@ -57,6 +57,7 @@ class BitFlip(_OneParameter):
 class PhaseFlip(_OneParameter):
     r""":math:`\rho \to (1-p)\rho + p Z\rho Z` (reference: channel.py:58-97)."""
     _name = 'PhaseFlip'
+    _kernel_kind = 'diag'
 
     def get_matrix(self, theta: Any) -> torch.Tensor:
         p = self._prob(theta)
@@ -90,6 +91,7 @@ class PhaseDamping(_OneParameter):
     r""":math:`K_0 = \mathrm{diag}(1, \sqrt{1-p})`, :math:`K_1 = \mathrm{diag}(0, \sqrt p)`
     (reference: channel.py:266-314)."""
     _name = 'PhaseDamping'
+    _kernel_kind = 'diag'
 
     def get_matrix(self, theta: Any) -> torch.Tensor:
         p = self._prob(theta)

@@ -161,6 +161,48 @@ __device__ __forceinline__ void gen2_body(amp<T> (&a)[1 << R], const amp<T>* __r
     }
 }
 
+// 4x4 matrix promised REAL by the host (DqFusedMode REAL on a GEN2 gate: the superoperators of the noise
+// channels): entry by entry, skipping the exact zeros with a uniform branch -- a depolarizing channel has 6
+// non-zero entries of 16, amplitude damping 5 -- and one real-times-complex FMA per entry and amplitude group.
+template <typename T, int R, int Q, int Q2>
+__device__ __forceinline__ void gen2_body_real(amp<T> (&a)[1 << R], const amp<T>* __restrict__ mp,
+                                               const unsigned reg_cmask, const bool thr_ok) {
+    constexpr int NG = (1 << R) / 4;
+    int base[NG];
+    {
+        int g = 0;
+#pragma unroll
+        for (int j = 0; j < (1 << R); ++j)
+            if (!((j >> Q) & 1) && !((j >> Q2) & 1)) base[g++] = j;
+    }
+    constexpr int off[4] = {0, 1 << Q2, 1 << Q, (1 << Q) | (1 << Q2)};
+    amp<T> y[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[g][r] = amp<T>{0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const T mr = mp[r * 4 + c].x;
+            if (mr != T(0)) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const amp<T> x = a[base[g] + off[c]];
+                    y[g][r].x = fma(mr, x.x, y[g][r].x);
+                    y[g][r].y = fma(mr, x.y, y[g][r].y);
+                }
+            }
+        }
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+        if (thr_ok && ((base[g] & reg_cmask) == reg_cmask)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[base[g] + off[r]] = y[g][r];
+        }
+}
+
 template <typename T, int R, int MODE, bool PRED>
 __device__ __forceinline__ void dispatch_gen1_q(amp<T> (&a)[1 << R], int q, const amp<T> m00, const amp<T> m01,
                                                 const amp<T> m10, const amp<T> m11, unsigned reg_cmask, bool thr_ok) {
@@ -251,34 +293,41 @@ __device__ __forceinline__ void dispatch_x1(amp<T> (&a)[1 << R], int q, unsigned
     }
 }
 
+template <typename T, int R, int Q, int Q2>
+__device__ __forceinline__ void gen2_any(amp<T> (&a)[1 << R], const amp<T>* __restrict__ mp, unsigned mode,
+                                         unsigned reg_cmask, bool thr_ok) {
+    if (mode == DQ_MODE_REAL) gen2_body_real<T, R, Q, Q2>(a, mp, reg_cmask, thr_ok);
+    else gen2_body<T, R, Q, Q2>(a, mp, reg_cmask, thr_ok);
+}
+
 template <typename T, int R, int Q>
 __device__ __forceinline__ void dispatch_gen2_q2(amp<T> (&a)[1 << R], int q2, const amp<T>* __restrict__ mp,
-                                                 unsigned reg_cmask, bool thr_ok) {
+                                                 unsigned mode, unsigned reg_cmask, bool thr_ok) {
     switch (q2) {
         case 0:
-            if constexpr (Q != 0) gen2_body<T, R, Q, 0>(a, mp, reg_cmask, thr_ok);
+            if constexpr (Q != 0) gen2_any<T, R, Q, 0>(a, mp, mode, reg_cmask, thr_ok);
             break;
         case 1:
-            if constexpr (Q != 1) gen2_body<T, R, Q, 1>(a, mp, reg_cmask, thr_ok);
+            if constexpr (Q != 1) gen2_any<T, R, Q, 1>(a, mp, mode, reg_cmask, thr_ok);
             break;
         case 2:
-            if constexpr (Q != 2) gen2_body<T, R, Q, 2>(a, mp, reg_cmask, thr_ok);
+            if constexpr (Q != 2) gen2_any<T, R, Q, 2>(a, mp, mode, reg_cmask, thr_ok);
             break;
         default:
-            if constexpr (R > 3 && Q != 3) gen2_body<T, R, Q, 3>(a, mp, reg_cmask, thr_ok);
+            if constexpr (R > 3 && Q != 3) gen2_any<T, R, Q, 3>(a, mp, mode, reg_cmask, thr_ok);
             break;
     }
 }
 
 template <typename T, int R>
 __device__ __forceinline__ void dispatch_gen2(amp<T> (&a)[1 << R], int q, int q2, const amp<T>* __restrict__ mp,
-                                              unsigned reg_cmask, bool thr_ok) {
+                                              unsigned mode, unsigned reg_cmask, bool thr_ok) {
     switch (q) {
-        case 0: dispatch_gen2_q2<T, R, 0>(a, q2, mp, reg_cmask, thr_ok); break;
-        case 1: dispatch_gen2_q2<T, R, 1>(a, q2, mp, reg_cmask, thr_ok); break;
-        case 2: dispatch_gen2_q2<T, R, 2>(a, q2, mp, reg_cmask, thr_ok); break;
+        case 0: dispatch_gen2_q2<T, R, 0>(a, q2, mp, mode, reg_cmask, thr_ok); break;
+        case 1: dispatch_gen2_q2<T, R, 1>(a, q2, mp, mode, reg_cmask, thr_ok); break;
+        case 2: dispatch_gen2_q2<T, R, 2>(a, q2, mp, mode, reg_cmask, thr_ok); break;
         default:
-            if constexpr (R > 3) dispatch_gen2_q2<T, R, 3>(a, q2, mp, reg_cmask, thr_ok);
+            if constexpr (R > 3) dispatch_gen2_q2<T, R, 3>(a, q2, mp, mode, reg_cmask, thr_ok);
             break;
     }
 }
@@ -535,7 +584,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             switch (kind) {
                 case DQ_FG_GEN1: dispatch_gen1<T, R>(a, q, mp, loc, reg_cmask, thr_cmask != 0, thr_ok); break;
                 case DQ_FG_X1: dispatch_x1<T, R>(a, q, reg_cmask, thr_cmask != 0, thr_ok); break;
-                case DQ_FG_GEN2: dispatch_gen2<T, R>(a, q, q2, mp, reg_cmask, thr_ok); break;
+                case DQ_FG_GEN2: dispatch_gen2<T, R>(a, q, q2, mp, loc, reg_cmask, thr_ok); break;
                 case DQ_FG_DIAG1: {
                     const V d0 = mp[0], d1 = mp[3];
                     int fixed = -1;  // target bit value when it is not a register slot
@@ -702,7 +751,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
         for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
             const bool slot_kind = g.kind == DQ_FG_GEN1 || g.kind == DQ_FG_X1 || g.kind == DQ_FG_GEN2;
-            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || (g.kind == DQ_FG_GEN1 && g.loc > 2) ||
+            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 2) || (g.kind == DQ_FG_GEN2 && g.loc > 1)) ||
                 (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
                 set_error("dq_apply_fused: gate %d malformed", gi);
                 return DQ_ERR_ARG;

@@ -468,6 +468,7 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots
+        g.loc = 1 if op.mode == 1 else 0      # promised real (and usually sparse): channel superoperators
 
 
 def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], int]:

@@ -299,9 +299,14 @@ class Channel(Operation):
         sup = torch.einsum('k...ab,k...cd->...acbd', kraus, kraus.conj())
         return sup.reshape(*sup.shape[:-4], 4, 4)
 
+    #: 'gen': dense real superoperator (the kernels skip its exact zeros); 'diag' for channels whose Kraus
+    #: operators are all diagonal (phase flip, phase damping): a diagonal two-"qubit" gate, no tile constraint
+    _kernel_kind = 'gen'
+
     def dm_prims(self, decompose: bool = True) -> list[Prim]:
         bit = self.nqubit - 1 - self.wires[0]
-        return [Prim('gen', self.superoperator(), (bit + self.nqubit, bit), (), 0, unitary=False)]
+        # every channel of channel.py has a REAL superoperator (K (x) conj(K) of Pauli / damping operators)
+        return [Prim(self._kernel_kind, self.superoperator(), (bit + self.nqubit, bit), (), 1, unitary=False)]
 
     def prims(self, decompose: bool = True) -> list[Prim]:
         raise NotImplementedError('a channel acts on density matrices only')

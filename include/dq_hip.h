@@ -101,7 +101,8 @@ typedef struct {
     uint8_t q;          /* GEN/X: register slot of the (first) target; DIAG: position per loc */
     uint8_t q2;         /* GEN2: slot of the second target (matrix LSB); DIAG2: position per loc2 */
     uint8_t loc;        /* DIAG1/2: DqBitLoc of target 1 (REG: q = slot, THR: q = tile-local bit,
-                           OUT: q = global bit position); GEN1: DqFusedMode of the matrix */
+                           OUT: q = global bit position); GEN1: DqFusedMode of the matrix; GEN2: GENERAL or
+                           REAL (real 4x4, exact zeros skipped: channel superoperators) */
     uint8_t loc2;       /* DIAG2: same for target 2 */
     uint8_t reg_cmask;  /* controls that are register slots (bit s = slot s) */
     uint16_t thr_cmask; /* controls that are thread bits (tile-local bit positions) */
