@@ -295,9 +295,17 @@ class Channel(Operation):
 
     def superoperator(self) -> torch.Tensor:
         """sum_k K_k (x) conj(K_k): 4x4, index = (row bit, column bit)."""
+        theta = self.theta
+        key = (id(theta), theta._version, theta.dtype, theta.device)
+        cached = self.__dict__.get('_sup_cache')
+        if cached is not None and cached[0] == key and not theta.requires_grad:
+            return cached[1]                                # fixed noise strength: built once, not per forward
         kraus = self.update_matrix()                       # (K, 2, 2) or (K, B, 2, 2)
         sup = torch.einsum('k...ab,k...cd->...acbd', kraus, kraus.conj())
-        return sup.reshape(*sup.shape[:-4], 4, 4)
+        sup = sup.reshape(*sup.shape[:-4], 4, 4)
+        if not theta.requires_grad:
+            self.__dict__['_sup_cache'] = (key, sup)
+        return sup
 
     #: 'gen': dense real superoperator (the kernels skip its exact zeros); 'diag' for channels whose Kraus
     #: operators are all diagonal (phase flip, phase damping): a diagonal two-"qubit" gate, no tile constraint
