@@ -468,6 +468,8 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     constexpr int GATE_W0 = offsetof(DqFusedPass, gates) / 4;
     const int nrounds = (int)(pw[0] >> 24);
     uint64_t mrun = (uint64_t)(mbase + pw[offsetof(DqFusedPass, mat_base) / 4]);  // running matrix pointer
+    T hscale = T(1);   // product of the deferred Hadamard factors of this pass (uniform)
+    bool had = false;
     for (int r = 0; r < nrounds; ++r) {
         const uint32_t rw0 = pw[ROUND_W0 + 4 * r], rw1 = pw[ROUND_W0 + 4 * r + 1], rw2 = pw[ROUND_W0 + 4 * r + 2],
                        rw3 = pw[ROUND_W0 + 4 * r + 3];
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
                 // Straight-line handlers picked by the host (include/dq_hip.h, DqFusedGate::fast): one flat
                 // switch instead of the kind / control / mode / slot decision chain -- the scalar unit is the
                 // scarce resource of this kernel.  Ids < 16 have no control of any kind: no test at all.
-                if (fast < 32u) {
+                if (fast < 64u) {
 #define DQ_PAIR(I) ((uint64_t)mqv[2 * (I)] | ((uint64_t)mqv[2 * (I) + 1] << 32))
                     if constexpr (FAST32) {
                         const uint64_t mq[4] = {DQ_PAIR(0), DQ_PAIR(1), DQ_PAIR(2), DQ_PAIR(3)};
@@ -520,26 +522,38 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
 #define DQ_GEN1_CASES                                                                           \
     DQ_GEN1_CASE(0) DQ_GEN1_CASE(1) DQ_GEN1_CASE(2) DQ_GEN1_CASE(3) DQ_GEN1_CASE(4) DQ_GEN1_CASE(5) \
     DQ_GEN1_CASE(6) DQ_GEN1_CASE(7) DQ_GEN1_CASE(8) DQ_GEN1_CASE(9) DQ_GEN1_CASE(10) DQ_GEN1_CASE(11)
-                        if (fast < 16u) {
+// Hadamard-like matrix s [[1, 1], [1, -1]]: sums and differences only, the factor s is collected in `hscale`
+// and applied once at the end of the pass (linear, so it commutes with everything that follows)
+#define DQ_HAD_CASE(ID)                                                                     \
+    case ID: {                                                                              \
+        const uint64_t mh[4] = {0xC0000000C0000000ull, mq[1], mq[2], mq[3]}; /* (-2.0f, -2.0f) */ \
+        gen1_block_f32<3, (ID) % 4>(a, mh);                                                 \
+        hscale *= __uint_as_float(mqv[0]);                                                  \
+        had = true;                                                                         \
+        break;                                                                              \
+    }
+                        if (fast < 32u) {
                             switch (fast) {
                                 DQ_GEN1_CASES
-                                case 12: x1_block_f32<0, 0>(a); break;
-                                case 13: x1_block_f32<1, 0>(a); break;
-                                case 14: x1_block_f32<2, 0>(a); break;
+                                DQ_HAD_CASE(12) DQ_HAD_CASE(13) DQ_HAD_CASE(14) DQ_HAD_CASE(15)
+                                case 16: x1_block_f32<0, 0>(a); break;
+                                case 17: x1_block_f32<1, 0>(a); break;
+                                case 18: x1_block_f32<2, 0>(a); break;
                                 default: x1_block_f32<3, 0>(a); break;
                             }
                             continue;
                         }
                         if ((tile_global & out_cmask) != out_cmask) continue;  // uniform: an outside control is 0
                         if ((tbase & thr_cmask) == thr_cmask) {
-                            switch (fast - 16u) {
+                            switch (fast - 32u) {
                                 DQ_GEN1_CASES
-                                case 12: dispatch_x1_block_f32<0>(a, reg_cmask); break;
-                                case 13: dispatch_x1_block_f32<1>(a, reg_cmask); break;
-                                case 14: dispatch_x1_block_f32<2>(a, reg_cmask); break;
+                                case 16: dispatch_x1_block_f32<0>(a, reg_cmask); break;
+                                case 17: dispatch_x1_block_f32<1>(a, reg_cmask); break;
+                                case 18: dispatch_x1_block_f32<2>(a, reg_cmask); break;
                                 default: dispatch_x1_block_f32<3>(a, reg_cmask); break;
                             }
                         }
+#undef DQ_HAD_CASE
 #undef DQ_GEN1_CASES
 #undef DQ_GEN1_CASE
                     } else {
@@ -551,24 +565,34 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
 #define DQ_GEN1_CASES                                                                           \
     DQ_GEN1_CASE(0) DQ_GEN1_CASE(1) DQ_GEN1_CASE(2) DQ_GEN1_CASE(4) DQ_GEN1_CASE(5) DQ_GEN1_CASE(6) \
     DQ_GEN1_CASE(8) DQ_GEN1_CASE(9) DQ_GEN1_CASE(10)
-                        if (fast < 16u) {
+#define DQ_HAD_CASE(ID)                                                  \
+    case ID: {                                                           \
+        const double mh[8] = {-2.0, md[1], md[2], md[3], md[4], md[5], md[6], md[7]}; \
+        gen1_block_f64<3, (ID) % 4>(a, mh);                              \
+        hscale *= md[0];                                                 \
+        had = true;                                                      \
+        break;                                                           \
+    }
+                        if (fast < 32u) {
                             switch (fast) {
                                 DQ_GEN1_CASES
-                                case 12: x1_block_f64<0, 0>(a); break;
-                                case 13: x1_block_f64<1, 0>(a); break;
+                                DQ_HAD_CASE(12) DQ_HAD_CASE(13) DQ_HAD_CASE(14)
+                                case 16: x1_block_f64<0, 0>(a); break;
+                                case 17: x1_block_f64<1, 0>(a); break;
                                 default: x1_block_f64<2, 0>(a); break;
                             }
                             continue;
                         }
                         if ((tile_global & out_cmask) != out_cmask) continue;
                         if ((tbase & thr_cmask) == thr_cmask) {
-                            switch (fast - 16u) {
+                            switch (fast - 32u) {
                                 DQ_GEN1_CASES
-                                case 12: dispatch_x1_block_f64<0>(a, reg_cmask); break;
-                                case 13: dispatch_x1_block_f64<1>(a, reg_cmask); break;
+                                case 16: dispatch_x1_block_f64<0>(a, reg_cmask); break;
+                                case 17: dispatch_x1_block_f64<1>(a, reg_cmask); break;
                                 default: dispatch_x1_block_f64<2>(a, reg_cmask); break;
                             }
                         }
+#undef DQ_HAD_CASE
 #undef DQ_GEN1_CASES
 #undef DQ_GEN1_CASE
                     }
@@ -582,7 +606,9 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             const bool thr_ok = (tbase & thr_cmask) == thr_cmask;
             const V* mp = mbase + gmat;
             switch (kind) {
-                case DQ_FG_GEN1: dispatch_gen1<T, R>(a, q, mp, loc, reg_cmask, thr_cmask != 0, thr_ok); break;
+                case DQ_FG_GEN1:  // (a Hadamard that is not on a straight-line handler is just a real matrix)
+                    dispatch_gen1<T, R>(a, q, mp, loc == DQ_MODE_HAD ? (unsigned)DQ_MODE_REAL : loc, reg_cmask, thr_cmask != 0, thr_ok);
+                    break;
                 case DQ_FG_X1: dispatch_x1<T, R>(a, q, reg_cmask, thr_cmask != 0, thr_ok); break;
                 case DQ_FG_GEN2: dispatch_gen2<T, R>(a, q, q2, mp, loc, reg_cmask, thr_ok); break;
                 case DQ_FG_DIAG1: {
@@ -618,6 +644,14 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
                     break;
                 }
             }
+        }
+    }
+
+    if (had) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            a[j].x *= hscale;
+            a[j].y *= hscale;
         }
     }
 
@@ -751,7 +785,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
         for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
             const bool slot_kind = g.kind == DQ_FG_GEN1 || g.kind == DQ_FG_X1 || g.kind == DQ_FG_GEN2;
-            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 2) || (g.kind == DQ_FG_GEN2 && g.loc > 1)) ||
+            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 3) || (g.kind == DQ_FG_GEN2 && g.loc > 1)) ||
                 (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
                 set_error("dq_apply_fused: gate %d malformed", gi);
                 return DQ_ERR_ARG;
@@ -767,8 +801,9 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
             if (g.fast != DQ_FAST_NONE) {
                 const bool free_ = g.reg_cmask == 0 && g.thr_cmask == 0 && g.out_cmask == 0;
                 uint32_t want = DQ_FAST_NONE;
-                if (g.kind == DQ_FG_X1) want = (free_ ? 12u : 28u) + g.q;
-                else if (g.kind == DQ_FG_GEN1 && g.reg_cmask == 0) want = (free_ ? 0u : 16u) + 4u * g.loc + g.q;
+                if (g.kind == DQ_FG_X1) want = (free_ ? 16u : 48u) + g.q;
+                else if (g.kind == DQ_FG_GEN1 && g.reg_cmask == 0)
+                    want = free_ ? 4u * g.loc + g.q : 32u + 4u * (g.loc == DQ_MODE_HAD ? (unsigned)DQ_MODE_REAL : g.loc) + g.q;
                 if (g.fast != want) {
                     set_error("dq_apply_fused: gate %d has fast-handler id %u, expected %u", gi, g.fast, want);
                     return DQ_ERR_ARG;

@@ -462,9 +462,9 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         # straight-line handler id (one flat switch in the kernel): see include/dq_hip.h
         free = reg_c == 0 and thr_c == 0 and out_c == 0
         if op.kind == 'x':
-            g.fast = (12 if free else 28) + slots[0]
+            g.fast = (16 if free else 48) + slots[0]
         elif reg_c == 0:
-            g.fast = (0 if free else 16) + 4 * g.loc + slots[0]
+            g.fast = 4 * g.loc + slots[0] if free else 32 + 4 * (1 if g.loc == 3 else g.loc) + slots[0]
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots

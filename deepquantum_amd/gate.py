@@ -254,7 +254,7 @@ PauliY = _fixed_single('PauliY', 'PauliY', lambda: torch.tensor([[0, -1j], [1j, 
 PauliZ = _fixed_single('PauliZ', 'PauliZ', lambda: torch.tensor([[1, 0], [0, -1]], dtype=torch.cfloat), kind='diag',
                        doc='Pauli-Z (reference: gate.py:954-1024, matrix :995).')
 Hadamard = _fixed_single('Hadamard', 'Hadamard',
-                         lambda: torch.tensor([[1, 1], [1, -1]], dtype=torch.cfloat) / 2**0.5, nancilla=1, mode=1,
+                         lambda: torch.tensor([[1, 1], [1, -1]], dtype=torch.cfloat) / 2**0.5, nancilla=1, mode=3,
                          doc='Hadamard; note the float32-rounded 1/sqrt(2) (reference: gate.py:1027-1099, :1069).')
 SGate = _fixed_single('SGate', 'SGate', lambda: torch.tensor([[1, 0], [0, 1j]]), kind='diag',
                       inverse_name='SDaggerGate', doc='S (reference: gate.py:1102-1188, matrix :1143).')

@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 3
+#define DQ_ABI_VERSION 4
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -93,7 +93,9 @@ typedef enum { DQ_LOC_REG = 0, DQ_LOC_THR = 1, DQ_LOC_OUT = 2 } DqBitLoc;
 typedef enum {
     DQ_MODE_GENERAL = 0,
     DQ_MODE_REAL = 1, /* all four entries real: H, Ry, X, Z ... */
-    DQ_MODE_RX = 2    /* real diagonal, purely imaginary off-diagonal: Rx */
+    DQ_MODE_RX = 2,   /* real diagonal, purely imaginary off-diagonal: Rx */
+    DQ_MODE_HAD = 3   /* s * [[1, 1], [1, -1]], s real: Hadamard.  The kernel takes sums and differences and
+                         applies the product of the factors s of a pass once, at its end */
 } DqFusedMode;
 
 typedef struct {
@@ -108,10 +110,11 @@ typedef struct {
     uint16_t thr_cmask; /* controls that are thread bits (tile-local bit positions) */
     uint32_t mat;       /* offset (in complex numbers) of this gate's matrix inside `mats` */
     uint32_t fast;      /* GEN1 / X1 straight-line handler, or DQ_FAST_NONE:
-                             0..11  2x2 gate, id = mode * 4 + slot, no control of any kind
-                            12..15  X on slot id - 12, no control of any kind
-                            16..27  2x2 gate, id - 16 = mode * 4 + slot, thread / outside controls only
-                            28..31  X on slot id - 28 with any controls (CNOT, Toffoli ...) */
+                             0..15  2x2 gate, id = mode * 4 + slot, no control of any kind
+                            16..19  X on slot id - 16, no control of any kind
+                            32..43  2x2 gate, id - 32 = mode * 4 + slot (HAD counts as REAL), thread / outside
+                                    controls only
+                            48..51  X on slot id - 48 with any controls (CNOT, Toffoli ...) */
     uint64_t out_cmask; /* controls outside the tile (global bit positions) */
     uint32_t mat_advance; /* complex numbers this gate occupies in `mats` (0 for X1): the matrices of a pass
                              lie back to back in gate order, mat(i+1) = mat(i) + mat_advance(i), so the kernel

@@ -118,15 +118,18 @@ class CpuTestBackend:
                         assert not (cm >> tbit) & 1
                         free = g.reg_cmask == 0 and g.thr_cmask == 0 and g.out_cmask == 0
                         if g.kind == _lib.FG_X1:
-                            want = (12 if free else 28) + g.q
+                            want = (16 if free else 48) + g.q
                         elif g.reg_cmask == 0:
-                            want = (0 if free else 16) + 4 * g.loc + g.q
+                            want = 4 * g.loc + g.q if free else 32 + 4 * (1 if g.loc == 3 else g.loc) + g.q
                         else:
                             want = _lib.FAST_NONE
                         assert g.fast == want, 'fast-handler id wrong'
                         mat = mb[g.mat : g.mat + 4].reshape(2, 2)
                         if g.kind == _lib.FG_GEN1 and g.loc == 1:
                             assert np.all(mat.imag == 0), 'gate promised a real matrix'
+                        if g.kind == _lib.FG_GEN1 and g.loc == 3:
+                            assert np.all(mat.imag == 0) and mat[0, 0] == mat[0, 1] == mat[1, 0] == -mat[1, 1], \
+                                'gate promised a Hadamard-like matrix'
                         if g.kind == _lib.FG_GEN1 and g.loc == 2:
                             assert mat[0, 0].imag == 0 and mat[1, 1].imag == 0 and mat[0, 1].real == 0 and mat[1, 0].real == 0
                         if g.kind == _lib.FG_X1:

@@ -34,7 +34,7 @@ RX = torch.stack([torch.cos(t / 2) + 0j, -1j * torch.sin(t / 2), -1j * torch.sin
 G = torch.linalg.qr(torch.randn(2, 2, dtype=torch.complex128))[0].to(dtype)
 X = torch.tensor([[0, 1], [1, 0]], dtype=dtype)
 mats = torch.cat([H.reshape(-1), RX.reshape(-1), G.reshape(-1), X.reshape(-1)]).to(dev)
-OFF = {'h': 0, 'rx': 4, 'g': 8, 'x': 12}
+OFF = {'h': 0, 'rx': 4, 'g': 8, 'x': 12, 'ry': 0}   # 'ry': the H matrix handled as a plain real matrix
 
 
 def ops_seq(kind, count, targets, controls=()):
@@ -42,7 +42,7 @@ def ops_seq(kind, count, targets, controls=()):
     for i in range(count):
         tb = targets[i % len(targets)]
         k = 'x' if kind == 'x' else 'gen'
-        out.append(fusion.PrimOp(k, (tb,), tuple(controls), OFF[kind], {'h': 1, 'rx': 2}.get(kind, 0)))
+        out.append(fusion.PrimOp(k, (tb,), tuple(controls), OFF[kind], {'h': 3, 'rx': 2, 'ry': 1}.get(kind, 0)))
     return out
 
 
@@ -52,6 +52,7 @@ for cnt in (1, 9, 17, 33):
     cases.append((f'H x{cnt} on one gathered bit', ops_seq('h', cnt, [hi])))
 for cnt in (9, 33):
     cases.append((f'Rx x{cnt} on one gathered bit', ops_seq('rx', cnt, [hi])))
+    cases.append((f'real 2x2 x{cnt} on one gathered bit', ops_seq('ry', cnt, [hi])))
     cases.append((f'general 2x2 x{cnt} on one gathered bit', ops_seq('g', cnt, [hi])))
 for cnt in (9, 33):
     cases.append((f'CNOT x{cnt} target gathered, control outside tile', ops_seq('x', cnt, [hi], [hi - 8])))
