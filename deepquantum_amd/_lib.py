@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
@@ -23,7 +23,7 @@ LOC_REG, LOC_THR, LOC_OUT = range(3)
 
 FUSED_MAX_HIGH = 8
 FUSED_MAX_ROUNDS = 24
-FUSED_MAX_GATES = 96
+FUSED_MAX_GATES = 80
 FUSED_MAX_SLOTS = 4
 FUSED_MAX_TBITS = 10
 FAST_NONE = 0xFFFFFFFF
@@ -71,6 +71,7 @@ class DqFusedPass(C.Structure):
         ('gates', DqFusedGate * FUSED_MAX_GATES),
         ('load_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),
         ('store_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),
+        ('lds_tab', (C.c_uint16 * 16) * (FUSED_MAX_ROUNDS + 2)),
     ]
 
 

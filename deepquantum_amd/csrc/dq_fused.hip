@@ -426,29 +426,33 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
     }
 
-    V* lds = reinterpret_cast<V*>(dq_smem);
-    auto transpose_to = [&](const unsigned (&nrb)[R], const unsigned ntbase) __attribute__((always_inline)) {
-        unsigned so[NA], sn[NA];
+    // LDS staging: a thread's byte address = swizzle(its base) * sizeof(V)  XOR  the host-made table entry of the
+    // register-slot pattern (the swizzle is XOR-linear; include/dq_hip.h, lds_tab).  `ctab` = table of the layout
+    // the registers are in right now.
+    constexpr int TAB_W0 = offsetof(DqFusedPass, lds_tab) / 4;   // 8 words = 16 entries per table
+    constexpr int TAB_WORDS = (NA + 1) / 2;
+    uint32_t ctab[TAB_WORDS];
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            unsigned x = 0, y = 0;
+    for (int w = 0; w < TAB_WORDS; ++w) ctab[w] = hw[TAB_W0 + w];
+    auto tab_entry = [](const uint32_t (&tab)[TAB_WORDS], int j) __attribute__((always_inline)) -> unsigned {
+        return (tab[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+    };
+    auto transpose_to = [&](const unsigned (&nrb)[R], const unsigned ntbase, const int table) __attribute__((always_inline)) {
+        uint32_t ntab[TAB_WORDS];
 #pragma unroll
-            for (int s = 0; s < R; ++s)
-                if ((j >> s) & 1) {
-                    x |= 1u << rb[s];
-                    y |= 1u << nrb[s];
-                }
-            so[j] = x;
-            sn[j] = y;
-        }
+        for (int w = 0; w < TAB_WORDS; ++w) ntab[w] = hw[TAB_W0 + 8 * table + w];
+        const unsigned vw = lds_swz<sizeof(V)>(tbase) * (unsigned)sizeof(V);
+        const unsigned vr = lds_swz<sizeof(V)>(ntbase) * (unsigned)sizeof(V);
 #pragma unroll
-        for (int j = 0; j < NA; ++j) lds[lds_swz<sizeof(V)>(tbase | so[j])] = a[j];
+        for (int j = 0; j < NA; ++j) *reinterpret_cast<V*>(dq_smem + (vw ^ tab_entry(ctab, j))) = a[j];
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NA; ++j) a[j] = lds[lds_swz<sizeof(V)>(ntbase | sn[j])];
+        for (int j = 0; j < NA; ++j) a[j] = *reinterpret_cast<const V*>(dq_smem + (vr ^ tab_entry(ntab, j)));
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < R; ++s) rb[s] = nrb[s];
+#pragma unroll
+        for (int w = 0; w < TAB_WORDS; ++w) ctab[w] = ntab[w];
         tbase = ntbase;
     };
 
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             const uint32_t w = i < 4 ? rw1 : (i < 8 ? rw2 : rw3);
             ntbase |= ((tid >> i) & 1u) << ((w >> (8 * (i & 3))) & 0xffu);
         }
-        if (!same || ntbase != tbase) transpose_to(nrb, ntbase);
+        if (!same || ntbase != tbase) transpose_to(nrb, ntbase, 1 + r);
         const int gbeg = (int)((rw3 >> 16) & 0xffu), gend = (int)(rw3 >> 24);
         uint64_t gaddr = kgates + 32ull * (unsigned)gbeg;   // kernarg address of the round's first gate record
         for (int gi = gbeg; gi < gend; ++gi) {
@@ -665,7 +669,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             stbase = (unsigned)insert_zero(stbase, (int)srb[s]);
             same = same && (srb[s] == rb[s]);
         }
-        if (!same || stbase != tbase) transpose_to(srb, stbase);
+        if (!same || stbase != tbase) transpose_to(srb, stbase, DQ_FUSED_MAX_ROUNDS + 1);
     }
 
     {

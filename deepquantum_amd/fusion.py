@@ -381,6 +381,18 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         desc.load_slot_off[s] = goff(load_rb[s])
         desc.store_slot_off[s] = goff(store_rb[s])
 
+    esz_log = 3 if vb == 1 else 4           # complex64: 8-byte amplitudes; complex128: 16
+
+    def fill_table(index: int, slots_l) -> None:
+        period = 5 if vb == 1 else 4
+        for j in range(1 << R):
+            e = sum(1 << slots_l[s_] for s_ in range(R) if (j >> s_) & 1)
+            e ^= (e >> period) & ((1 << period) - 1)
+            desc.lds_tab[index][j] = e << esz_log
+
+    fill_table(0, load_rb)
+    fill_table(_lib.FUSED_MAX_ROUNDS + 1, store_rb)
+
     exec_order: list[int] = []
     gi = 0
     ntrans = 0
@@ -395,6 +407,7 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
             r.rb[s] = lay[0][s]
         for i, t in enumerate(lay[1]):
             r.tb[i] = t
+        fill_table(1 + ri, lay[0])
         r.gate_begin = gi
         for oi in rd.ops:
             _encode_gate(desc.gates[gi], ops[oi], local, slot_of, tile)

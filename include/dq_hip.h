@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 4
+#define DQ_ABI_VERSION 5
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -75,7 +75,7 @@ int dq_apply_gate_c128(const void* in, void* out, const void* mats, int64_t mat_
  * ------------------------------------------------------------------------------------------ */
 #define DQ_FUSED_MAX_HIGH 8
 #define DQ_FUSED_MAX_ROUNDS 24
-#define DQ_FUSED_MAX_GATES 96
+#define DQ_FUSED_MAX_GATES 80
 #define DQ_FUSED_MAX_SLOTS 4
 
 typedef enum {
@@ -151,6 +151,12 @@ typedef struct {
      * loop per slot per tile. */
     uint64_t load_slot_off[DQ_FUSED_MAX_SLOTS];
     uint64_t store_slot_off[DQ_FUSED_MAX_SLOTS];
+    /* LDS addressing of every layout the pass uses: table 0 = load layout, table 1 + r = round r, table
+     * DQ_FUSED_MAX_ROUNDS + 1 = store layout.  Entry j (j = pattern of register-slot bits) = BYTE offset of
+     * swizzle(sum over the set bits s of j of 2^rb[s]) in the staging tile, swizzle(e) = e ^ ((e >> 5) & 31) for
+     * 8-byte amplitudes, e ^ ((e >> 4) & 15) for 16-byte ones.  The swizzle is XOR-linear, so a thread's address
+     * is swizzle(its base) * size XOR the table entry: one VALU op per access instead of five. */
+    uint16_t lds_tab[DQ_FUSED_MAX_ROUNDS + 2][16];
 } DqFusedPass;
 
 /* Tile geometries this build was compiled with (m = slots + log2(threads)); variant 0 is the

@@ -64,6 +64,20 @@ class CpuTestBackend:
             for sl in range(R):
                 tl = rbio[sl]
                 assert offs[sl] == 1 << (tl if tl < L else high_pos[tl - L]), 'slot offset table wrong'
+        def want_table(slots_l):
+            period, esz = (4, 16) if is128 else (5, 8)
+            out = []
+            for j in range(1 << R):
+                e_ = sum(1 << slots_l[s_] for s_ in range(R) if (j >> s_) & 1)
+                out.append((e_ ^ ((e_ >> period) & ((1 << period) - 1))) * esz)
+            return out
+
+        assert [desc.lds_tab[0][j] for j in range(1 << R)] == want_table([desc.load_rb[s] for s in range(R)])
+        assert [desc.lds_tab[_lib.FUSED_MAX_ROUNDS + 1][j] for j in range(1 << R)] == \
+            want_table([desc.store_rb[s] for s in range(R)])
+        for r_ in range(desc.nrounds):
+            assert [desc.lds_tab[1 + r_][j] for j in range(1 << R)] == \
+                want_table([desc.rounds[r_].rb[s] for s in range(R)]), 'LDS offset table wrong'
         # tile-local index -> global offset, tile index -> base
         e = np.arange(1 << m, dtype=np.int64)
         glob = e & ((1 << L) - 1)
