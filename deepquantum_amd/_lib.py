@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
@@ -87,6 +87,7 @@ _SIGNATURES = {
     'dq_reduce_ws_bytes': (_i64, [_i64]),
     'dq_apply_gate_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _ip, _i, _ip, _i, _i64, _vp]),
     'dq_apply_fused_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp]),
+    'dq_apply_fused_bcast_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp]),
     'dq_expect_pauli_{s}': (_i, [_vp, _u64, _u64, _i, _i64, _vp, _vp, _vp]),
     'dq_inner_{s}': (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'dq_probs_{s}': (_i, [_vp, _vp, _i64, _vp]),

@@ -120,17 +120,20 @@ def apply_fused(
     desc: _lib.DqFusedPass,
     out: torch.Tensor | None = None,
 ) -> torch.Tensor:
-    """Run one fused pass (see fusion.py).  ``mats``: flat complex buffer (Bm * stride or stride)."""
+    """Run one fused pass (see fusion.py).  ``mats``: flat complex buffer (Bm * stride or stride).
+    ``state`` with ONE row and ``out`` with B rows: the single input state is shared by all outputs."""
     n = _nqubit(state)
     if out is None:
         out = state
+    broadcast = state.shape[0] == 1 and out.shape[0] > 1
     if mats.dtype != state.dtype or mats.device != state.device or not mats.is_contiguous():
         raise ValueError('mats must be a contiguous buffer in the dtype/device of the state')
     if not _use_hip(state):
-        return _test_backend.apply_fused(state, mats, mat_batch_stride, desc, out)
+        src = state.expand(out.shape[0], -1) if broadcast else state
+        return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out)
     lib = _lib.load()
-    fn = getattr(lib, f'dq_apply_fused_{_suffix(state)}')
-    rc = fn(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, state.shape[0], C.byref(desc),
+    fn = getattr(lib, f'dq_apply_fused_{"bcast_" if broadcast else ""}{_suffix(state)}')
+    rc = fn(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0], C.byref(desc),
             _stream(state))
     _lib.check(rc, 'dq_apply_fused')
     return out

@@ -350,6 +350,7 @@ struct FusedKernArgs {
     void* out;
     const void* mats;
     int64_t mat_bstride;
+    int64_t in_bstride;
     int n;
     DqFusedPass p;
 };
@@ -357,7 +358,7 @@ struct FusedKernArgs {
 template <typename T, int R, int LOGT>
 __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in, amp<T>* out,
                                                                const amp<T>* __restrict__ mats, int64_t mat_bstride,
-                                                               int n, const DqFusedPass p) {
+                                                               int64_t in_bstride, int n, const DqFusedPass p) {
     constexpr int M = R + LOGT;
     constexpr int NA = 1 << R;
     constexpr int VB = (sizeof(T) == 4) ? 1 : 0;  // low slots of the canonical layout (16 B per lane)
@@ -375,9 +376,9 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     // ---- tile base address (workgroup-uniform) ----
     uint64_t tile = (uint64_t)blockIdx.x << L;
     for (int i = 0; i < h; ++i) tile = insert_zero(tile, (int)byte_of(hs0, hs1, i));
-    const uint64_t state_off = ((uint64_t)blockIdx.y << n) + tile;
-    const V* pin = in + state_off;
-    V* pout = out + state_off;
+    // in_bstride = 2^n normally; 0 when every batch element starts from the same (single) input state
+    const V* pin = in + (uint64_t)blockIdx.y * (uint64_t)in_bstride + tile;
+    V* pout = out + ((uint64_t)blockIdx.y << n) + tile;
     const V* mbase = mats + (int64_t)blockIdx.y * mat_bstride;
 
     // tile-local index -> offset inside the state
@@ -819,8 +820,8 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
 }
 
 template <typename T, int R, int LOGT>
-static void launch_variant(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
-                           const DqFusedPass* pass, hipStream_t s) {
+static void launch_variant(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n,
+                           int64_t batch, const DqFusedPass* pass, hipStream_t s) {
     constexpr int M = R + LOGT;
     const size_t lds_bytes = sizeof(amp<T>) << M;
     static bool attr_set = false;
@@ -832,12 +833,17 @@ static void launch_variant(const void* in, void* out, const void* mats, int64_t 
     dim3 grid((unsigned)(1ull << (n - M)), (unsigned)batch);
     hipLaunchKernelGGL((fused_pass_kernel<T, R, LOGT>), grid, dim3(1u << LOGT), lds_bytes, s,
                        static_cast<const amp<T>*>(in), static_cast<amp<T>*>(out), static_cast<const amp<T>*>(mats),
-                       mat_bstride, n, *pass);
+                       mat_bstride, in_bstride, n, *pass);
 }
 
 template <typename T>
 static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
-                      const DqFusedPass* pass, dq_stream_t stream) {
+                      const DqFusedPass* pass, dq_stream_t stream, bool broadcast_in = false) {
+    const int64_t in_bstride = broadcast_in ? 0 : (int64_t)1 << n;
+    if (broadcast_in && in == out) {
+        set_error("dq_apply_fused_bcast: the shared input state cannot be the output buffer");
+        return DQ_ERR_ARG;
+    }
     if (!in || !out || !mats || !pass) {
         set_error("dq_apply_fused: null pointer");
         return DQ_ERR_ARG;
@@ -864,11 +870,11 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     }
     hipStream_t s = as_stream(stream);
     if constexpr (!is128) {
-        if (v.m == 12) launch_variant<float, 4, 8>(in, out, mats, mat_bstride, n, batch, pass, s);
-        else launch_variant<float, 4, 9>(in, out, mats, mat_bstride, n, batch, pass, s);
+        if (v.m == 12) launch_variant<float, 4, 8>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+        else launch_variant<float, 4, 9>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
     } else {
-        if (v.m == 11) launch_variant<double, 3, 8>(in, out, mats, mat_bstride, n, batch, pass, s);
-        else launch_variant<double, 4, 8>(in, out, mats, mat_bstride, n, batch, pass, s);
+        if (v.m == 11) launch_variant<double, 3, 8>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+        else launch_variant<double, 4, 8>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
     }
     return check_launch("dq_apply_fused");
 }
@@ -894,4 +900,15 @@ extern "C" int dq_apply_fused_c64(const void* in, void* out, const void* mats, i
 extern "C" int dq_apply_fused_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
                                    int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
     return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream);
+}
+
+// Same pass, but `in` is ONE state (2^n amplitudes) shared by all `batch` outputs: the first pass of a batched
+// circuit reads the circuit's initial state directly instead of `batch` materialised copies of it.
+extern "C" int dq_apply_fused_bcast_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                        int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
+    return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream, true);
+}
+extern "C" int dq_apply_fused_bcast_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                         int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
+    return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, true);
 }

@@ -180,21 +180,32 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):
             return _run_small(state, prims, n, m)
-        x = state if (inplace and state.is_contiguous()) else state.detach().clone(memory_format=torch.contiguous_format)
         plan = make_plan(prims, n, is128)
+        # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
+        # state directly and writes the B results -- no B materialised copies
+        shared_in = None
+        if (state.shape[0] > 1 and state.stride(0) == 0 and state.stride(1) == 1 and plan.steps
+                and isinstance(plan.steps[0], fusion.FusedStep)):
+            shared_in = state.detach()[:1]
+            x = torch.empty(state.shape, dtype=state.dtype, device=state.device)
+        elif inplace and state.is_contiguous():
+            x = state
+        else:
+            x = state.detach().clone(memory_format=torch.contiguous_format)
         flat, stride = _flat_mats(prims, plan.mat_order, x.shape[0], x.dtype, x.device)
         stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0}
         scratch = None
         for st in plan.steps:
             if isinstance(st, fusion.FusedStep):
+                src, shared_in = (shared_in, None) if shared_in is not None else (x, None)
                 if PROFILE['enabled'] and x.is_cuda:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    backend.apply_fused(x, flat, stride, st.desc, out=x)
+                    backend.apply_fused(src, flat, stride, st.desc, out=x)
                     e1.record()
                     PROFILE['events'].append((e0, e1, len(st.ops)))
                 else:
-                    backend.apply_fused(x, flat, stride, st.desc, out=x)
+                    backend.apply_fused(src, flat, stride, st.desc, out=x)
                 stats['passes'] += 1
                 stats['rounds'] += st.nrounds
                 stats['transposes'] += st.ntranspose

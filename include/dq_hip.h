@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 5
+#define DQ_ABI_VERSION 6
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -168,6 +168,13 @@ int dq_apply_fused_c64(const void* in, void* out, const void* mats, int64_t mat_
                        int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
 int dq_apply_fused_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
                         int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
+/* Same, with `in` = ONE state of 2^n amplitudes shared by all `batch` outputs (in != out): the first pass of a
+ * batched circuit reads the initial state directly, where the reference's vmap (circuit.py:238) materialises a
+ * copy per sample. */
+int dq_apply_fused_bcast_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                             int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
+int dq_apply_fused_bcast_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                              int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Reductions.  Results are written to DEVICE memory in double precision.
