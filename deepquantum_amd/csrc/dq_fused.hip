@@ -373,13 +373,26 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         return ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
     };
 
-    // ---- tile base address (workgroup-uniform) ----
-    uint64_t tile = (uint64_t)blockIdx.x << L;
+    // ---- which tile / which batch element (workgroup-uniform) ----
+    // Normally blockIdx.x = tile, blockIdx.y = sample.  When all samples read ONE input state (in_bstride == 0)
+    // the B workgroups of a tile are instead made neighbours in dispatch order AND placed on the same XCD
+    // (workgroups go round-robin over the 8 XCDs), so the tile is fetched from HBM once and served to the other
+    // B - 1 from that XCD's L2.
+    unsigned tile_id = blockIdx.x, sample = blockIdx.y;
+#ifndef DQ_NO_XCD_REMAP
+    if (in_bstride == 0 && (gridDim.x & 7u) == 0) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.y;
+        const unsigned group = lin / (8u * nb), r = lin % (8u * nb);
+        sample = r >> 3;
+        tile_id = group * 8u + (r & 7u);
+    }
+#endif
+    uint64_t tile = (uint64_t)tile_id << L;
     for (int i = 0; i < h; ++i) tile = insert_zero(tile, (int)byte_of(hs0, hs1, i));
     // in_bstride = 2^n normally; 0 when every batch element starts from the same (single) input state
-    const V* pin = in + (uint64_t)blockIdx.y * (uint64_t)in_bstride + tile;
-    V* pout = out + ((uint64_t)blockIdx.y << n) + tile;
-    const V* mbase = mats + (int64_t)blockIdx.y * mat_bstride;
+    const V* pin = in + (uint64_t)sample * (uint64_t)in_bstride + tile;
+    V* pout = out + ((uint64_t)sample << n) + tile;
+    const V* mbase = mats + (int64_t)sample * mat_bstride;
 
     // tile-local index -> offset inside the state
     auto glob = [&](unsigned e) __attribute__((always_inline)) -> uint64_t {

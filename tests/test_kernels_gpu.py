@@ -126,6 +126,36 @@ def test_fused_batched_matrices_and_out_of_place(is128):
     assert torch.equal(xd.cpu(), x)  # input untouched
 
 
+@pytest.mark.parametrize('is128,n,b', [(False, 15, 3), (False, 16, 16), (True, 14, 5), (False, 12, 4)])
+def test_fused_pass_with_one_shared_input_state(is128, n, b):
+    """dq_apply_fused_bcast_*: every sample reads the same input state (the first pass of a batched circuit),
+    with its own matrices; workgroups of one tile are remapped to neighbours on one XCD."""
+    dtype = torch.complex128 if is128 else torch.complex64
+    ops, mats0 = random_ops(n, 30, 21, kinds=('gen', 'x', 'diag', 'gen2'))
+    per_sample = []
+    for i in range(b):
+        g = torch.Generator().manual_seed(100 + i)
+        mi = mats0.clone()
+        for op in ops:
+            if op.kind != 'x':
+                d2 = (1 << op.k) ** 2
+                mi[op.mat : op.mat + d2] *= torch.exp(1j * torch.rand(1, generator=g, dtype=torch.float64) * 3)
+        per_sample.append(mi)
+    mats = torch.stack(per_sample).to(dtype)
+    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+    assert all(isinstance(s_, fusion.FusedStep) for s_ in steps)
+    x = rand_state(1, n, dtype, 77)
+    ref = torch.cat([run_reference(x, ops, mats[i]) for i in range(b)])
+    xd = x.to(dev())
+    md = fusion.kernel_matrices(steps, ops, mats).to(dev()).contiguous()
+    out = torch.empty(b, 1 << n, dtype=dtype, device=dev())
+    backend.apply_fused(xd, md, md.shape[1], steps[0].desc, out=out)      # broadcast read
+    for st in steps[1:]:
+        backend.apply_fused(out, md, md.shape[1], st.desc, out=out)
+    assert (out.cpu() - ref).abs().max().item() < TOL[dtype]
+    assert torch.equal(xd.cpu(), x)
+
+
 @pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
 def test_reductions(dtype):
     n, b = 10, 3
