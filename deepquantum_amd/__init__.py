@@ -37,3 +37,5 @@ from .operation import Channel, Gate, Layer, Operation
 from .qmath import amplitude_encoding, expectation, measure, multi_kron
 from .state import DistributedQubitState, QubitState
 from .utils import CapturedGraph, dtype_map
+from . import qasm3  # noqa: E402  (after the circuit classes it builds on)
+from .qasm3 import cir_to_qasm3, qasm3_to_cir

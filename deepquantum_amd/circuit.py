@@ -619,7 +619,13 @@ class QubitCircuit(Operation):
     def _out_of_scope(self, *a, **k):
         raise NotImplementedError('outside the accelerated statevector path (SURVEY section 2, OUT OF SCOPE)')
 
-    qasm = pattern = draw = transform_cut2move = get_subexperiments = _out_of_scope
+    pattern = draw = transform_cut2move = get_subexperiments = _out_of_scope
+
+    def qasm(self) -> str:
+        """OpenQASM 2.0 text of the circuit (reference: circuit.py:570-627)."""
+        from .qasm3 import cir_to_qasm2
+
+        return cir_to_qasm2(self)
 
     # noise channels (density matrices only; reference: circuit.py:1540-1601) ---------------------------
     def _add_channel(self, cls, wires, inputs, encode) -> None:

@@ -344,3 +344,65 @@ DM_CASES = {
     'dm_equal2': dict(nqubit=2, spec=[('depolarizing', [0, 0.7], {}), ('h', [1], {})], init='equal',
                       observables=[([0], 'x'), ([1], 'z')]),
 }
+
+
+# ---- OpenQASM --------------------------------------------------------------------------
+QASM_EXPORT = {
+    'zoo': dict(nqubit=5, measure=[0, 3], spec=[
+        ('h', [0], {}), ('x', [1], {}), ('y', [2], {}), ('z', [3], {}), ('s', [4], {}), ('sdg', [0], {}), ('t', [1], {}),
+        ('tdg', [2], {}), ('rx', [3, 0.3], {}), ('ry', [4, -1.2], {}), ('rz', [0, 2.5], {}), ('p', [1, 0.7], {}),
+        ('u3', [2, [0.1, 0.2, 0.3]], {}), ('cnot', [0, 1], {}), ('cx', [2, 3], {}), ('cy', [4, 0], {}), ('cz', [1, 2], {}),
+        ('ch', [3, 4], {}), ('cs', [0, 2], {}), ('cs', [1, 3], {}), ('crx', [0, 1, 0.4], {}), ('cry', [2, 4, 0.5], {}),
+        ('crz', [3, 0, 0.6], {}), ('cp', [4, 1, 0.8], {}), ('cu', [0, 3, [0.4, 0.5, 0.6]], {}), ('swap', [[1, 4]], {}),
+        ('swap', [[0, 2]], {'controls': [3]}), ('rxx', [[0, 1], 0.9], {}), ('ryy', [[2, 3], 1.0], {}),
+        ('ryy', [[1, 4], 1.1], {}), ('rzz', [[0, 4], 1.2], {}), ('toffoli', [0, 1, 2], {}), ('fredkin', [3, 4, 0], {}),
+        ('x', [4], {'controls': [0, 1]}), ('x', [3], {'controls': [0, 1, 2]}), ('x', [2], {'controls': [0, 1, 3, 4]}),
+        ('sdg', [1], {'controls': [2]}), ('barrier', [[0, 1, 2]], {}), ('hlayer', [], {}), ('rxlayer', [[0, 2]], {'inputs': [0.1, 0.2]}),
+    ]),
+    'no_measure': dict(nqubit=2, measure=[], spec=[('h', [0], {}), ('cnot', [0, 1], {}), ('rz', [1, 0.25], {})]),
+}
+QASM3_PROGRAMS = {
+    'defs_ctrl_pow': '''OPENQASM 3.0;
+include "stdgates.inc";
+qubit[4] q;
+bit[2] c;
+def bell a, b {
+  h a;
+  cx a, b;
+}
+def rot(theta, phi) a {
+  rx(theta) a;
+  rz(phi) a;
+}
+h q[0];
+bell q[0], q[1];
+rot(pi/3, 0.25) q[2];
+rot(2*pi/5 - 0.1, -0.5) q[3];
+ctrl @ rot(0.4, 0.9) q[0], q[2];
+ctrl @ bell q[3], q[1], q[2];
+ctrl @ ctrl @ x q[0], q[1], q[3];
+pow(2) @ t q[1];
+pow(3) @ rot(0.2, 0.1) q[0];
+pow(0.5) @ x q[2];
+ctrl @ pow(0.25) @ z q[1], q[3];
+pow(-1) @ s q[3];
+pow(-2) @ rx(0.3) q[0];
+cz q[0], q[3];
+ccx q[0], q[1], q[2];
+cswap q[3], q[0], q[1];
+swap q[1], q[2];
+u(0.1, 0.2, 0.3) q[0];
+p(0.5) q[1];
+rxx(0.3) q[0], q[1];
+ryy(0.2) q[1], q[2];
+rzz(0.6) q[2], q[3];
+ctrl @ ry(1.1) q[2], q[0];
+y q[3];
+sdg q[0];
+tdg q[1];
+barrier q[0], q[1];
+c[0] = measure q[0];
+c[1] = measure q[3];
+''',
+    'roundtrip': None,   # the QASM3 text the reference writes for QASM_EXPORT['zoo'], read back
+}
