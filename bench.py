@@ -6,9 +6,12 @@ circuit of depth 40 (1120 gates, seed 1234), complex64, batch = 16 with per-samp
 ``torch.vmap`` case of the reference), initial state |0...0>, no_grad forward.  One "step" = one
 forward pass of the whole circuit over the whole batch, inputs resident in HBM.
 
-N > 1 (launched by torchrun, one rank per GPU): weak scaling -- n = 28 + log2(N) qubits index-bit
-sharded over the N ranks, the same 2^28 amplitudes x 16 samples per GPU; the batch is processed as 16
-consecutive sharded circuits.
+N > 1 (launched by torchrun, one rank per GPU): weak scaling.  The samples of a batch are independent
+circuits, so the default shards THEM: every rank runs the same 28-qubit circuit on its own 16 samples (global
+batch 16 N), no collective in the data path -- the process group only carries the barrier and the max over
+ranks of the elapsed time.  ``--sharded-state`` instead measures the index-bit-sharded state (BASELINE configs
+4/5 style): n = 28 + log2(N) qubits over the N ranks, the same 2^28 amplitudes x 16 samples per GPU, qubit
+remapping by RCCL all-to-all (what a state that does not fit one GPU needs; link-bound on xGMI).
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement), with two extra objects:
 ``roofline`` for the dominant kernel (the fused pass) and ``cpu_baseline`` (the oracle = restatement of
@@ -48,6 +51,10 @@ def parse_args():
     ap.add_argument('--min-low', type=int, default=None)
     ap.add_argument('--max-gates', type=int, default=None)
     ap.add_argument('--no-fuse', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="process-group backend for N > 1 ('nccl' = RCCL; 'gloo' lets "
+                    'several ranks share one GPU for a functional check)')
+    ap.add_argument('--sharded-state', action='store_true',
+                    help='N > 1: index-bit-sharded state of 28 + log2(N) qubits instead of sharding the batch')
     ap.add_argument('--max-far', type=int, default=None, help='scheduler: max gathered bits >= far-bit per pass')
     ap.add_argument('--far-bit', type=int, default=None)
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
@@ -76,8 +83,9 @@ def random_circuit_spec(nqubit, depth, seed=1234):
     return spec
 
 
-def build_circuit(dq, n, spec, batch, dtype, device, distributed=False):
-    """The generator's circuit; Rx angles are encoder inputs so each batch sample has its own."""
+def build_circuit(dq, n, spec, batch, dtype, device, distributed=False, shard=0):
+    """The generator's circuit; Rx angles are encoder inputs so each batch sample has its own.  ``shard`` = which
+    slice of a batch sharded over ranks this is (its samples get their own angles)."""
     cir = dq.DistributedQubitCircuit(n) if distributed else dq.QubitCircuit(n)
     angles = []
     for op in spec:
@@ -93,9 +101,10 @@ def build_circuit(dq, n, spec, batch, dtype, device, distributed=False):
     if dtype == torch.complex128:
         cir.to(torch.double)
     real = torch.float64 if dtype == torch.complex128 else torch.float32
-    g = torch.Generator().manual_seed(1234)
+    g = torch.Generator().manual_seed(1234 + shard)
     data = torch.rand(batch, len(angles), generator=g, dtype=real) * 2 * math.pi
-    data[0] = torch.tensor(angles, dtype=real)  # sample 0 = the generator's own angles
+    if shard == 0:
+        data[0] = torch.tensor(angles, dtype=real)  # sample 0 = the generator's own angles
     return cir, data.to(device)
 
 
@@ -160,9 +169,10 @@ def main():
 
     dtype = torch.complex64 if args.dtype == 'c64' else torch.complex128
     amp_bytes = 8 if dtype == torch.complex64 else 16
-    distributed = world > 1
-    if distributed:
-        dq.setup_distributed('nccl')
+    multi = world > 1
+    distributed = multi and args.sharded_state          # index-bit-sharded state; otherwise the batch is sharded
+    if multi:
+        dq.setup_distributed(args.backend)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
@@ -178,10 +188,10 @@ def main():
     dq.executor.CONFIG['max_far'] = args.max_far
     dq.executor.CONFIG['far_bit'] = args.far_bit
 
-    n = args.nqubit + int(math.log2(world))
+    n = args.nqubit + (int(math.log2(world)) if distributed else 0)
     spec = random_circuit_spec(n, args.depth, args.seed)
     ngates = len(spec)
-    cir, data = build_circuit(dq, n, spec, args.batch, dtype, device, distributed)
+    cir, data = build_circuit(dq, n, spec, args.batch, dtype, device, distributed, rank if multi and not distributed else 0)
     # algorithmic bytes per gate: 2 * 2^(n - nc) * sizeof(amp) per batch sample
     alg_bytes = sum(2 * (2 ** (n - (1 if op[0] == 'cnot' else 0))) * amp_bytes for op in spec) * args.batch
 
@@ -194,7 +204,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if distributed:
+        if multi:
             torch.distributed.barrier()
             torch.cuda.synchronize(device)
 
@@ -210,7 +220,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     prof['enabled'] = False
-    if distributed:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
@@ -218,14 +228,14 @@ def main():
     # dominant kernel: the fused pass -- durations from HIP events recorded on the launch stream
     kernel_ms = [a.elapsed_time(b) for a, b, _ in prof['events']]
     launches = len(kernel_ms)
-    alg_per_launch = (alg_bytes / world * args.steps / launches) if launches else 0.0   # this rank's share
+    alg_per_launch = (alg_bytes / (world if distributed else 1) * args.steps / launches) if launches else 0.0   # this rank's share
     avg_ms = (sum(kernel_ms) / launches) if launches else float('nan')
     achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc runs of this same command,
     # tools/profile.sh; committed under profiles/): only reported for the workload it was collected on.
     traffic = None
     tj = args.traffic_json
-    if tj is None and not distributed:
+    if tj is None and not distributed:   # (batch-sharded ranks run the single-GPU workload: same traffic)
         import glob
 
         cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'traffic_n{n}_b{args.batch}_{args.dtype}.json')))
@@ -236,7 +246,7 @@ def main():
     copy_gbs = device_copy_bandwidth(device) if rank == 0 else None
 
     if rank == 0:
-        total_gate_applies = ngates * args.batch * args.steps
+        total_gate_applies = ngates * args.batch * args.steps * (world if multi and not distributed else 1)
         value = total_gate_applies / elapsed
         line = {
             'metric': 'gate-applies/sec, 28q random circuit depth 40 (HBM GB/s in roofline)',
@@ -255,11 +265,15 @@ def main():
                 'workload': f'QubitCircuit({n}) random H/Rx/CNOT depth {args.depth} ({ngates} gates, seed {args.seed}), '
                             f'{"complex64" if dtype == torch.complex64 else "complex128"}, batch={args.batch} '
                             f'(per-sample Rx angles), |0..0> start, no_grad forward'
-                            + (f', index-bit sharded over {world} GPUs' if distributed else ''),
+                            + (f', index-bit sharded over {world} GPUs' if distributed else '')
+                            + (f'; {world} ranks x {args.batch} samples (global batch {world * args.batch})'
+                               if multi and not distributed else ''),
                 'nqubit': n,
                 'depth': args.depth,
                 'batch': args.batch,
-                'parallelism': f'state-shard x{world}' if distributed else 'single GPU',
+                'parallelism': (f'state-shard x{world} (RCCL all-to-all qubit remap)' if distributed else
+                                f'batch-shard x{world} (independent samples, no collective in the data path)' if multi
+                                else 'single GPU'),
                 'fused_passes_per_step': stats.get('passes'),
                 'lds_round_trips_per_step': stats.get('transposes'),
             },
@@ -274,7 +288,7 @@ def main():
                 'launches': launches,
                 'avg_launch_ms': avg_ms,
                 'algorithmic_bytes_per_launch': alg_per_launch,
-                'actual_state_bytes_per_launch': 2 * (2**n >> int(math.log2(world))) * amp_bytes * args.batch,
+                'actual_state_bytes_per_launch': 2 * (2**n >> (int(math.log2(world)) if distributed else 0)) * amp_bytes * args.batch,
                 'note': 'achieved counts every fused gate as its own read+write of the state (SURVEY 8d), so it '
                         'can exceed the HBM peak; actual_state_bytes_per_launch / avg_launch_ms is the physical rate',
             },
@@ -287,10 +301,10 @@ def main():
             line['roofline']['physical_frac_of_copy'] = line['roofline']['physical_GBs'] / copy_gbs
         if out is not None:
             line['config']['expectation_Z0_sample0'] = float(out.reshape(-1)[0])
-        if not args.no_cpu_baseline and not distributed:
+        if not args.no_cpu_baseline and not multi:
             line['cpu_baseline'] = cpu_baseline(n, spec, dtype, args.cpu_seconds)
         print(json.dumps(line))
-    if distributed:
+    if multi:
         dq.cleanup_distributed()
 
 
