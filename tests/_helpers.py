@@ -249,3 +249,54 @@ def check_adjoint_grad_mode(dq, device=None, dtype=torch.float64, n=6, tol=1e-10
     assert len(a[3]) == len(b[3]) and len(a[3]) > 0
     for x, y in zip(a[3], b[3], strict=True):
         assert (x - y).abs().max().item() < tol, (x - y).abs().max()
+
+
+def check_edge_cases(dq, device=None):
+    """Degenerate and extreme inputs of the circuit driver: no gates, one qubit, a batch of one, only diagonal
+    gates, many controls, gates on the first and last wire, repeated forward calls on the same object."""
+    def dev_(cir):
+        return cir.to(device) if device is not None else cir
+
+    # empty circuit: the initial state comes back, in the reference's shapes
+    cir = dev_(dq.QubitCircuit(3))
+    out = cir()
+    assert out.shape == (8, 1) and out[0, 0] == 1 and out.abs().sum() == 1
+    cir = dev_(dq.QubitCircuit(3, init_state='equal'))
+    assert (cir().abs() - 8 ** -0.5).abs().max().item() < 1e-6
+    # one qubit
+    cir = dq.QubitCircuit(1)
+    cir.h(0)
+    cir.rz(0, 0.5)
+    cir.observable(0, 'x')
+    dev_(cir)
+    st = cir().reshape(-1)
+    assert abs(st[0].abs().item() - 0.7071068) < 1e-6 and abs(cir.expectation().item() - 0.8775826) < 1e-5
+    # batch of one through 2-D data keeps the batch dimension
+    cir = dq.QubitCircuit(2)
+    cir.rx(0, encode=True)
+    cir.cnot(0, 1)
+    dev_(cir)
+    data = torch.tensor([[1.2]])
+    data = data.to(device) if device is not None else data
+    assert cir(data).shape == (1, 4, 1)
+    assert cir(data[0]).shape == (4, 1)
+    # only diagonal gates, and many controls (9 controls on a 10-qubit register)
+    n = 10
+    cir = dq.QubitCircuit(n)
+    cir.hlayer()
+    cir.z(9, controls=list(range(9)))
+    cir.p(0, 0.3, controls=list(range(1, 10)))
+    cir.x(4, controls=[0, 1, 2, 3, 5, 6, 7, 8, 9])
+    cir.rzz([0, 9], 0.7)
+    cir.observable(list(range(n)), 'z' * n)
+    dev_(cir)
+    st = cir().reshape(-1).cpu()
+    amp = 0.7071067690849304 ** n
+    phase_rzz = torch.exp(torch.tensor(-0.35j))
+    # all-ones amplitude: sign from CZ, phase from CP, swapped with |1111011111> (equal amplitude) by the CX
+    assert abs(st[0] - amp * phase_rzz) < 1e-6
+    assert abs(abs(st[-1]) - amp) < 1e-6 and abs((st.abs() ** 2).sum().item() - (2 * 0.7071067690849304**2) ** n) < 1e-5
+    # the same circuit object can be called again and again (plan cache, lazy matrices)
+    a = cir().clone()
+    b = cir()
+    assert torch.equal(a, b)

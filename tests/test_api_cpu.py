@@ -243,3 +243,9 @@ def test_adjoint_grad_mode_matches_per_gate_autograd(cpu_backend):
 
     check_adjoint_grad_mode(dq, dtype=torch.float64, tol=1e-10)
     check_adjoint_grad_mode(dq, dtype=torch.float32, tol=2e-5)
+
+
+def test_edge_cases(cpu_backend):
+    from _helpers import check_edge_cases
+
+    check_edge_cases(dq)

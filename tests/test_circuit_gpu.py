@@ -338,3 +338,42 @@ def test_hip_graph_capture_of_forward_and_training_step():
                         q.sub_(0.1 * q.grad)
         finally:
             dq.executor.CONFIG['grad_mode'] = 'adjoint'
+
+
+def test_edge_cases_on_gpu():
+    from _helpers import check_edge_cases
+
+    check_edge_cases(dq, device=dev())
+
+
+@pytest.mark.parametrize('n,dtype', [(32, torch.float32), (31, torch.float64)])
+def test_largest_single_gpu_states(n, dtype):
+    """Maximum sizes (no oracle can hold these): a 32-qubit complex64 state is 32 GiB, a 31-qubit
+    complex128 one too.  Known answers: GHZ, then a layer of parametrised gates and its inverse on top."""
+    cir = dq.QubitCircuit(n)
+    cir.h(0)
+    for q in range(1, n):
+        cir.cnot(q - 1, q)
+    layer = dq.QubitCircuit(n)
+    for q in range(0, n, 3):
+        layer.rx(q, 0.1 + 0.05 * q)
+        layer.ry((q + 1) % n, 0.2 + 0.03 * q)
+    layer.cz(0, n - 1)
+    layer.rzz([1, n - 2], 0.4)
+    full = cir + layer + layer.inverse()
+    full.observable([0, n - 1], 'zz')
+    full.observable(n // 2, 'x')
+    full.to(dev())
+    if dtype == torch.float64:
+        full.to(torch.double)
+    with torch.no_grad():
+        state = full().reshape(-1)
+        ev = full.expectation()
+    assert state.numel() == 2**n and dq.executor.LAST_RUN['passes'] > 0
+    s = 0.7071067690849304
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    assert abs(state[0].item() - s) < tol and abs(state[-1].item() - s) < tol
+    assert abs((state.abs() ** 2).sum().item() - 2 * s * s) < 10 * tol
+    assert abs(ev[0].item() - 2 * s * s) < 10 * tol and abs(ev[1].item()) < 10 * tol
+    del state
+    torch.cuda.empty_cache()
