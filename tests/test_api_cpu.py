@@ -158,7 +158,7 @@ def test_out_of_scope_paths_raise():
     with pytest.raises(AssertionError):
         dq.QubitCircuit(2).bit_flip(0)          # channels need den_mat=True, as in the reference
     with pytest.raises(NotImplementedError):
-        dq.QubitCircuit(2).qasm()
+        dq.QubitCircuit(2).pattern()            # MBQC transpilation: out of scope
 
 
 def test_reupload_encoding(cpu_backend):
