@@ -322,6 +322,179 @@ static int marginal_impl(const void* psi, int n, const int* bits, int nw, int64_
     return check_launch("dq_marginal");
 }
 
+
+// ---- gate gradients of SEVERAL single-target gates from one read of both states -------------------------
+// The reverse sweep of the adjoint autograd node (executor._AdjointCircuit) needs, for every trainable gate g of a
+// layer,  G_g[a][b] = sum over the groups where g's controls are 1 of  gy[.. a ..] conj(x[.. b ..])  on the SAME
+// pair of states.  One launch of gate_grad_kernel per gate reads both states once per gate; here a workgroup stages
+// a tile of x and of gy in LDS -- the low L index bits plus up to GM_HIGH gathered bits, chosen so that every
+// listed target is a tile bit and therefore every amplitude pair sits in the tile -- and accumulates all the G_g.
+// Workgroups stride over the tiles and keep their partial sums in registers; one block reduction and one set of
+// atomics per workgroup at the end.
+constexpr int GM_HIGH = 7;
+struct GradMultiDesc {
+    int n, L, h, ngates;
+    uint8_t high_sorted[8];  // gathered global bit positions, ascending; tile bit L + i
+    uint8_t tbit[8];         // tile-local target bit per gate
+    uint16_t cin[8];         // tile-local control mask per gate
+    uint64_t cout[8];        // controls outside the tile per gate (global positions)
+};
+
+template <typename T> __device__ __forceinline__ unsigned gm_swz(unsigned e) {
+    if constexpr (sizeof(T) == 4) return e ^ ((e >> 5) & 31u);
+    else return e ^ ((e >> 4) & 15u);
+}
+
+template <typename T, int M, int GM>
+__global__ __launch_bounds__(RED_THREADS) void gate_grad_multi_kernel(const cx<T>* __restrict__ x,
+                                                                       const cx<T>* __restrict__ gy, GradMultiDesc d,
+                                                                       uint64_t ntiles, double* __restrict__ out) {
+    using V = cx<T>;
+    __shared__ V sx[1 << M], sy[1 << M];
+    const unsigned tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const V* px = x + ((uint64_t)b << d.n);
+    const V* py = gy + ((uint64_t)b << d.n);
+    T acc[GM][8];
+#pragma unroll
+    for (int g = 0; g < GM; ++g)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[g][i] = 0;
+
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint64_t base = t << d.L;
+        for (int i = 0; i < d.h; ++i) base = insert_zero(base, d.high_sorted[i]);
+        // stage the tile: consecutive lanes read consecutive amplitudes of the contiguous low run
+#pragma unroll
+        for (unsigned e = tid; e < (1u << M); e += RED_THREADS) {
+            uint64_t off = e & ((1u << d.L) - 1u);
+            for (int i = 0; i < d.h; ++i) off |= (uint64_t)((e >> (d.L + i)) & 1u) << d.high_sorted[i];
+            sx[gm_swz<T>(e)] = px[base | off];
+            sy[gm_swz<T>(e)] = py[base | off];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < GM; ++g) {
+            if (g < d.ngates && (base & d.cout[g]) == d.cout[g]) {   // uniform
+                const unsigned tb = d.tbit[g], cm = d.cin[g];
+                for (unsigned p = tid; p < (1u << (M - 1)); p += RED_THREADS) {
+                    const unsigned e0 = (unsigned)insert_zero(p, (int)tb), e1 = e0 | (1u << tb);
+                    if ((e0 & cm) == cm) {
+                        const V x0 = sx[gm_swz<T>(e0)], x1 = sx[gm_swz<T>(e1)];
+                        const V y0 = sy[gm_swz<T>(e0)], y1 = sy[gm_swz<T>(e1)];
+                        // gy[a] * conj(x[b])
+                        acc[g][0] += y0.x * x0.x + y0.y * x0.y;
+                        acc[g][1] += y0.y * x0.x - y0.x * x0.y;
+                        acc[g][2] += y0.x * x1.x + y0.y * x1.y;
+                        acc[g][3] += y0.y * x1.x - y0.x * x1.y;
+                        acc[g][4] += y1.x * x0.x + y1.y * x0.y;
+                        acc[g][5] += y1.y * x0.x - y1.x * x0.y;
+                        acc[g][6] += y1.x * x1.x + y1.y * x1.y;
+                        acc[g][7] += y1.y * x1.x - y1.x * x1.y;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < GM; ++g) {
+        if (g < d.ngates) {
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                double re = (double)acc[g][i], im = (double)acc[g][i + 1];
+                block_sum2(re, im);
+                if (threadIdx.x == 0) {
+                    double* dst = out + (((size_t)b * d.ngates + g) * 4 + i / 2) * 2;
+                    unsafeAtomicAdd(dst, re);
+                    unsafeAtomicAdd(dst + 1, im);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+static int gate_grad_multi_impl(const void* x, const void* gy, int n, int ngates, const int* targets,
+                                const int* ctrl_begin, const int* ctrl_bits, int64_t batch, double* out,
+                                dq_stream_t stream) {
+    constexpr bool is128 = sizeof(T) == 8;
+    constexpr int M = is128 ? 10 : 11, GM = is128 ? 4 : 8, L = is128 ? 3 : 4;
+    if (!x || !gy || !out || !targets || !ctrl_begin || batch < 1 || batch > 65535) {
+        set_error("dq_gate_grad_multi: bad argument");
+        return DQ_ERR_ARG;
+    }
+    if (ngates < 1 || ngates > GM) {
+        set_error("dq_gate_grad_multi: %d gates per call, supported 1..%d", ngates, GM);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    if (n < M) {
+        set_error("dq_gate_grad_multi: n=%d smaller than the tile (%d bits)", n, M);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    GradMultiDesc d;
+    d.n = n;
+    d.L = L;
+    d.h = M - L;
+    d.ngates = ngates;
+    // gathered bits: the high targets, then the lowest free bits above L
+    uint64_t high = 0;
+    int nh = 0;
+    for (int g = 0; g < ngates; ++g) {
+        const int t = targets[g];
+        if (t < 0 || t >= n) {
+            set_error("dq_gate_grad_multi: target %d out of range", t);
+            return DQ_ERR_ARG;
+        }
+        if (t >= L && !((high >> t) & 1ull)) {
+            high |= 1ull << t;
+            ++nh;
+        }
+    }
+    if (nh > d.h) {
+        set_error("dq_gate_grad_multi: %d distinct targets above bit %d, the tile gathers %d", nh, L, d.h);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    for (int p = L; nh < d.h; ++p)
+        if (!((high >> p) & 1ull)) {
+            high |= 1ull << p;
+            ++nh;
+        }
+    int local[64];
+    for (int p = 0; p < L; ++p) local[p] = p;
+    {
+        int i = 0;
+        for (int p = L; p < n; ++p)
+            if ((high >> p) & 1ull) {
+                d.high_sorted[i] = (uint8_t)p;
+                local[p] = L + i;
+                ++i;
+            } else {
+                local[p] = -1;
+            }
+    }
+    for (int g = 0; g < ngates; ++g) {
+        d.tbit[g] = (uint8_t)local[targets[g]];
+        d.cin[g] = 0;
+        d.cout[g] = 0;
+        for (int c = ctrl_begin[g]; c < ctrl_begin[g + 1]; ++c) {
+            const int q = ctrl_bits[c];
+            if (q < 0 || q >= n || q == targets[g]) {
+                set_error("dq_gate_grad_multi: bad control %d of gate %d", q, g);
+                return DQ_ERR_ARG;
+            }
+            if (local[q] >= 0) d.cin[g] |= (uint16_t)(1u << local[q]);
+            else d.cout[g] |= 1ull << q;
+        }
+    }
+    const uint64_t ntiles = 1ull << (n - M);
+    uint64_t nb = ntiles < 2560 ? ntiles : 2560;       // ~2 waves of 5 workgroups per CU, striding over the tiles
+    dim3 grid((unsigned)nb, (unsigned)batch);
+    hipLaunchKernelGGL((gate_grad_multi_kernel<T, M, GM>), grid, dim3(RED_THREADS), 0, as_stream(stream),
+                       static_cast<const cx<T>*>(x), static_cast<const cx<T>*>(gy), d, ntiles, out);
+    return check_launch("dq_gate_grad_multi");
+}
+
 template <typename T>
 static int gate_grad_impl(const void* x, const void* gy, int n, const int* targets, int k, const int* controls, int nc,
                           int64_t batch, double* gU, dq_stream_t stream) {
@@ -394,6 +567,17 @@ extern "C" int64_t dq_reduce_ws_bytes(int64_t batch) {
                                          dq_stream_t stream) {                                                        \
         return dq::gate_grad_impl<T>(x, gy, n, targets, k, controls, nc, batch, gU, stream);                          \
     }
+
+extern "C" int dq_gate_grad_multi_c64(const void* x, const void* gy, int n, int ngates, const int* targets,
+                                      const int* ctrl_begin, const int* ctrl_bits, int64_t batch, double* out,
+                                      dq_stream_t stream) {
+    return dq::gate_grad_multi_impl<float>(x, gy, n, ngates, targets, ctrl_begin, ctrl_bits, batch, out, stream);
+}
+extern "C" int dq_gate_grad_multi_c128(const void* x, const void* gy, int n, int ngates, const int* targets,
+                                       const int* ctrl_begin, const int* ctrl_bits, int64_t batch, double* out,
+                                       dq_stream_t stream) {
+    return dq::gate_grad_multi_impl<double>(x, gy, n, ngates, targets, ctrl_begin, ctrl_bits, batch, out, stream);
+}
 
 DQ_DEFINE(c64, float)
 DQ_DEFINE(c128, double)

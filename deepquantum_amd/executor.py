@@ -290,6 +290,16 @@ class _AdjointCircuit(torch.autograd.Function):
                 pending.clear()
                 touched.clear()
 
+        waiting: list[int] = []               # single-target trainable gates whose snapshot is the current `work`
+
+        def reduce_waiting():
+            # all of them in as few reads of the two states as the multi-gate kernel allows
+            if waiting:
+                g = backend.gate_grad_multi(work[:b], work[b:], [(meta[j][1][0], meta[j][2]) for j in waiting])
+                for k, j in enumerate(waiting):
+                    raw[j] = g[:, k]
+                waiting.clear()
+
         for j in range(len(mats) - 1, -1, -1):
             kind, targets, controls, mode = meta[j]
             mine = set(targets) | set(controls)
@@ -299,10 +309,15 @@ class _AdjointCircuit(torch.autograd.Function):
                 # trace sees U^dagger U^-dagger = 1 exactly), so the snapshot is stale only if a pending gate
                 # shares a qubit with this one.  On layered circuits this is one flush per layer, not per gate.
                 if mine & touched:
+                    reduce_waiting()
                     flush()
-                raw[j] = backend.gate_grad(work[:b], work[b:], targets, controls)
+                if len(targets) == 1:
+                    waiting.append(j)
+                else:
+                    raw[j] = backend.gate_grad(work[:b], work[b:], targets, controls)
             pending.append(Prim(kind, undo[j], targets, controls, mode))
             touched |= mine
+        reduce_waiting()
         flush()
 
         grads: list = [None] * len(mats)

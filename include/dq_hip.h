@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 6
+#define DQ_ABI_VERSION 7
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -216,6 +216,17 @@ int dq_gate_grad_c64(const void* x, const void* gy, int n, const int* targets, i
                      int nc, int64_t batch, double* gU, dq_stream_t stream);
 int dq_gate_grad_c128(const void* x, const void* gy, int n, const int* targets, int k, const int* controls,
                       int nc, int64_t batch, double* gU, dq_stream_t stream);
+
+/* The same quantity for SEVERAL single-target gates on one pair of states, in one read of both (the reverse sweep of
+ * the adjoint autograd node asks for all trainable gates of a circuit layer at once): gate g has target
+ * targets[g] and controls ctrl_bits[ctrl_begin[g] .. ctrl_begin[g+1]).  Per call at most 8 gates (c64) / 4 (c128)
+ * whose targets above bit 3 (c64) / 2 (c128) number at most 7, and n >= 11 (c64) / 10 (c128): DQ_ERR_UNSUPPORTED
+ * otherwise (callers fall back to dq_gate_grad_*).  out = DEVICE double complex [batch, ngates, 2, 2], zeroed by
+ * the caller. */
+int dq_gate_grad_multi_c64(const void* x, const void* gy, int n, int ngates, const int* targets, const int* ctrl_begin,
+                           const int* ctrl_bits, int64_t batch, double* out, dq_stream_t stream);
+int dq_gate_grad_multi_c128(const void* x, const void* gy, int n, int ngates, const int* targets, const int* ctrl_begin,
+                            const int* ctrl_bits, int64_t batch, double* out, dq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Shard exchange helpers for the index-bit-partitioned state (distributed.py:57-202).

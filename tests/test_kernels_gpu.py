@@ -156,6 +156,28 @@ def test_fused_pass_with_one_shared_input_state(is128, n, b):
     assert torch.equal(xd.cpu(), x)
 
 
+@pytest.mark.parametrize('dtype,n', [(torch.complex64, 15), (torch.complex64, 11), (torch.complex128, 13),
+                                     (torch.complex128, 10), (torch.complex64, 9)])
+def test_gate_grad_multi_equals_gate_by_gate(dtype, n):
+    """Several single-target gate gradients from one read of both states (dq_gate_grad_multi_*) against one
+    dq_gate_grad_* launch per gate: targets below / above the contiguous run, repeated targets, controls inside
+    and outside the tile, more gates and more distinct high targets than one launch holds, a batch."""
+    b = 3
+    x, gy = rand_state(b, n, dtype, 31).to(dev()), rand_state(b, n, dtype, 32).to(dev())
+    rng = random.Random(n)
+    gates = []
+    for t in list(range(n)) + [0, n - 1, n // 2]:
+        others = [q for q in range(n) if q != t]
+        nc = rng.choice([0, 0, 1, 2])
+        gates.append((t, rng.sample(others, nc)))
+    got = backend.gate_grad_multi(x, gy, gates)
+    assert got.shape == (b, len(gates), 2, 2)
+    tol = 1e-4 if dtype == torch.complex64 else 1e-12
+    for k, (t, c) in enumerate(gates):
+        ref = backend.gate_grad(x, gy, [t], c)
+        assert (got[:, k] - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item()), (k, t, c)
+
+
 @pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
 def test_reductions(dtype):
     n, b = 10, 3
