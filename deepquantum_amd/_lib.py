@@ -93,7 +93,7 @@ _SIGNATURES = {
     'dq_probs_{s}': (_i, [_vp, _vp, _i64, _vp]),
     'dq_marginal_{s}': (_i, [_vp, _i, _ip, _i, _i64, _vp, _vp]),
     'dq_gate_grad_{s}': (_i, [_vp, _vp, _i, _ip, _i, _ip, _i, _i64, _vp, _vp]),
-    'dq_gate_grad_multi_{s}': (_i, [_vp, _vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i64, _vp, _vp]),
+    'dq_gate_grad_multi_{s}': (_i, [_vp, _vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i64, _vp, _i, _vp]),
     'dq_pack_{s}': (_i, [_vp, _vp, _i, _u64, _u64, _i64, _vp]),
     'dq_unpack_axpby_{s}': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _u64, _u64, _i64, _vp]),
     'dq_permute_bits_{s}': (_i, [_vp, _vp, _i, _ip, _i64, _vp]),

@@ -268,7 +268,8 @@ def gate_grad_multi(x: torch.Tensor, gy: torch.Tensor, gates: Sequence[tuple[int
     tile, per_call, low = (10, 4, 3) if is128 else (11, 8, 4)
     if not _use_hip(x) or n < tile:
         return torch.stack([gate_grad(x, gy, [t], list(c)) for t, c in gates], dim=1)
-    out = torch.zeros(x.shape[0], len(gates), 2, 2, 2, dtype=torch.float64, device=x.device)
+    nblocks = min(1 << (n - tile), 1536)          # ~6 workgroups per CU striding over the tiles
+    parts = []
     lib = _lib.load()
     fn = getattr(lib, f'dq_gate_grad_multi_{_suffix(x)}')
     start = 0
@@ -286,14 +287,14 @@ def gate_grad_multi(x: torch.Tensor, gy: torch.Tensor, gates: Sequence[tuple[int
         for _t, c in grp:
             bits += [int(q) for q in c]
             begin.append(len(bits))
-        part = out[:, start:stop].contiguous() if (start, stop) != (0, len(gates)) else out
+        part = torch.empty(x.shape[0], nblocks, len(grp), 2, 2, 2, dtype=torch.float64, device=x.device)
         rc = fn(_ptr(x), _ptr(gy), n, len(grp), _lib.int_array([int(t) for t, _ in grp]), _lib.int_array(begin),
-                _lib.int_array(bits), x.shape[0], _ptr(part), _stream(x))
+                _lib.int_array(bits), x.shape[0], _ptr(part), nblocks, _stream(x))
         _lib.check(rc, 'dq_gate_grad_multi')
-        if part is not out:
-            out[:, start:stop] = part
+        parts.append(part.sum(dim=1))
         start = stop
-    return torch.view_as_complex(out)
+    out = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+    return torch.view_as_complex(out.contiguous())
 
 
 def _gate_grad_gemm(x, gy, n, targets, controls):

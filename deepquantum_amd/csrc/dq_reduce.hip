@@ -329,8 +329,8 @@ static int marginal_impl(const void* psi, int n, const int* bits, int nw, int64_
 // pair of states.  One launch of gate_grad_kernel per gate reads both states once per gate; here a workgroup stages
 // a tile of x and of gy in LDS -- the low L index bits plus up to GM_HIGH gathered bits, chosen so that every
 // listed target is a tile bit and therefore every amplitude pair sits in the tile -- and accumulates all the G_g.
-// Workgroups stride over the tiles and keep their partial sums in registers; one block reduction and one set of
-// atomics per workgroup at the end.
+// Workgroups stride over the tiles and keep their partial sums in registers; one block reduction per workgroup at
+// the end writes its row of partial sums, the caller adds the rows up.
 constexpr int GM_HIGH = 7;
 struct GradMultiDesc {
     int n, L, h, ngates;
@@ -364,13 +364,28 @@ __global__ __launch_bounds__(RED_THREADS) void gate_grad_multi_kernel(const cx<T
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint64_t base = t << d.L;
         for (int i = 0; i < d.h; ++i) base = insert_zero(base, d.high_sorted[i]);
-        // stage the tile: consecutive lanes read consecutive amplitudes of the contiguous low run
+        // stage the tile: 16 bytes per lane (two complex64 / one complex128), consecutive lanes on consecutive
+        // amplitudes of the contiguous low run; all loads of a thread are issued before the first LDS write
+        constexpr int PER = sizeof(T) == 4 ? 2 : 1;                 // amplitudes per 16-byte load
+        constexpr int NLD = (1 << M) / (RED_THREADS * PER);
+        struct alignas(16) Q { V v[PER]; };
+        Q qx[NLD], qy[NLD];
 #pragma unroll
-        for (unsigned e = tid; e < (1u << M); e += RED_THREADS) {
+        for (int j = 0; j < NLD; ++j) {
+            const unsigned e = (unsigned)(j * RED_THREADS + tid) * PER;
             uint64_t off = e & ((1u << d.L) - 1u);
             for (int i = 0; i < d.h; ++i) off |= (uint64_t)((e >> (d.L + i)) & 1u) << d.high_sorted[i];
-            sx[gm_swz<T>(e)] = px[base | off];
-            sy[gm_swz<T>(e)] = py[base | off];
+            qx[j] = *reinterpret_cast<const Q*>(px + (base | off));
+            qy[j] = *reinterpret_cast<const Q*>(py + (base | off));
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const unsigned e = (unsigned)(j * RED_THREADS + tid) * PER;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                sx[gm_swz<T>(e + k)] = qx[j].v[k];
+                sy[gm_swz<T>(e + k)] = qy[j].v[k];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -404,10 +419,10 @@ __global__ __launch_bounds__(RED_THREADS) void gate_grad_multi_kernel(const cx<T
             for (int i = 0; i < 8; i += 2) {
                 double re = (double)acc[g][i], im = (double)acc[g][i + 1];
                 block_sum2(re, im);
-                if (threadIdx.x == 0) {
-                    double* dst = out + (((size_t)b * d.ngates + g) * 4 + i / 2) * 2;
-                    unsafeAtomicAdd(dst, re);
-                    unsafeAtomicAdd(dst + 1, im);
+                if (threadIdx.x == 0) {   // one partial row per workgroup: no atomics, the caller sums the rows
+                    double* dst = out + ((((size_t)b * gridDim.x + blockIdx.x) * d.ngates + g) * 4 + i / 2) * 2;
+                    dst[0] = re;
+                    dst[1] = im;
                 }
             }
         }
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(RED_THREADS) void gate_grad_multi_kernel(const cx<T
 
 template <typename T>
 static int gate_grad_multi_impl(const void* x, const void* gy, int n, int ngates, const int* targets,
-                                const int* ctrl_begin, const int* ctrl_bits, int64_t batch, double* out,
+                                const int* ctrl_begin, const int* ctrl_bits, int64_t batch, double* out, int nblocks,
                                 dq_stream_t stream) {
     constexpr bool is128 = sizeof(T) == 8;
     constexpr int M = is128 ? 10 : 11, GM = is128 ? 4 : 8, L = is128 ? 3 : 4;
@@ -488,8 +503,11 @@ static int gate_grad_multi_impl(const void* x, const void* gy, int n, int ngates
         }
     }
     const uint64_t ntiles = 1ull << (n - M);
-    uint64_t nb = ntiles < 2560 ? ntiles : 2560;       // ~2 waves of 5 workgroups per CU, striding over the tiles
-    dim3 grid((unsigned)nb, (unsigned)batch);
+    if (nblocks < 1 || (uint64_t)nblocks > ntiles) {
+        set_error("dq_gate_grad_multi: nblocks=%d outside [1, %llu tiles]", nblocks, (unsigned long long)ntiles);
+        return DQ_ERR_ARG;
+    }
+    dim3 grid((unsigned)nblocks, (unsigned)batch);       // workgroups stride over the tiles
     hipLaunchKernelGGL((gate_grad_multi_kernel<T, M, GM>), grid, dim3(RED_THREADS), 0, as_stream(stream),
                        static_cast<const cx<T>*>(x), static_cast<const cx<T>*>(gy), d, ntiles, out);
     return check_launch("dq_gate_grad_multi");
@@ -570,13 +588,13 @@ extern "C" int64_t dq_reduce_ws_bytes(int64_t batch) {
 
 extern "C" int dq_gate_grad_multi_c64(const void* x, const void* gy, int n, int ngates, const int* targets,
                                       const int* ctrl_begin, const int* ctrl_bits, int64_t batch, double* out,
-                                      dq_stream_t stream) {
-    return dq::gate_grad_multi_impl<float>(x, gy, n, ngates, targets, ctrl_begin, ctrl_bits, batch, out, stream);
+                                      int nblocks, dq_stream_t stream) {
+    return dq::gate_grad_multi_impl<float>(x, gy, n, ngates, targets, ctrl_begin, ctrl_bits, batch, out, nblocks, stream);
 }
 extern "C" int dq_gate_grad_multi_c128(const void* x, const void* gy, int n, int ngates, const int* targets,
                                        const int* ctrl_begin, const int* ctrl_bits, int64_t batch, double* out,
-                                       dq_stream_t stream) {
-    return dq::gate_grad_multi_impl<double>(x, gy, n, ngates, targets, ctrl_begin, ctrl_bits, batch, out, stream);
+                                       int nblocks, dq_stream_t stream) {
+    return dq::gate_grad_multi_impl<double>(x, gy, n, ngates, targets, ctrl_begin, ctrl_bits, batch, out, nblocks, stream);
 }
 
 DQ_DEFINE(c64, float)

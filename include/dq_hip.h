@@ -221,12 +221,13 @@ int dq_gate_grad_c128(const void* x, const void* gy, int n, const int* targets, 
  * the adjoint autograd node asks for all trainable gates of a circuit layer at once): gate g has target
  * targets[g] and controls ctrl_bits[ctrl_begin[g] .. ctrl_begin[g+1]).  Per call at most 8 gates (c64) / 4 (c128)
  * whose targets above bit 3 (c64) / 2 (c128) number at most 7, and n >= 11 (c64) / 10 (c128): DQ_ERR_UNSUPPORTED
- * otherwise (callers fall back to dq_gate_grad_*).  out = DEVICE double complex [batch, ngates, 2, 2], zeroed by
- * the caller. */
+ * otherwise (callers fall back to dq_gate_grad_*).  `nblocks` workgroups stride over the 2^(n-11) (c64) / 2^(n-10)
+ * (c128) tiles; each writes ONE row of partial sums: out = DEVICE double complex [batch, nblocks, ngates, 2, 2], fully
+ * overwritten; the caller adds the nblocks rows. */
 int dq_gate_grad_multi_c64(const void* x, const void* gy, int n, int ngates, const int* targets, const int* ctrl_begin,
-                           const int* ctrl_bits, int64_t batch, double* out, dq_stream_t stream);
+                           const int* ctrl_bits, int64_t batch, double* out, int nblocks, dq_stream_t stream);
 int dq_gate_grad_multi_c128(const void* x, const void* gy, int n, int ngates, const int* targets, const int* ctrl_begin,
-                            const int* ctrl_bits, int64_t batch, double* out, dq_stream_t stream);
+                            const int* ctrl_bits, int64_t batch, double* out, int nblocks, dq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Shard exchange helpers for the index-bit-partitioned state (distributed.py:57-202).
