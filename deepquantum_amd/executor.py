@@ -1,12 +1,13 @@
 """Circuit executor: runs a list of kernel-level gates on a (B, 2**n) state.
 
-Two modes, chosen per call:
-
-* fused (default when nothing requires grad): the gate list is scheduled once into fused passes
-  (``fusion.schedule``, cached by circuit structure) and each pass is one ``dq_apply_fused_*`` launch
-  working in place on a private copy of the state;
-* eager (autograd): one differentiable ``ops.apply_gate`` per gate, mirroring how the reference lets
-  autograd see every gate (circuit.py:261).
+* No gradient needed: the gate list is scheduled once into fused passes (``fusion.schedule``, cached by circuit
+  structure) and each pass is one ``dq_apply_fused_*`` launch working in place on a private copy of the state (the
+  first pass of a batched circuit reads the one shared initial state directly).  States smaller than a tile are
+  folded into / padded to one tile so that they run the same passes (``_run_small``).
+* Gradient needed: the whole list is ONE autograd node (``_AdjointCircuit``): fused forward, reverse sweep with
+  recomputation -- O(1) states of memory instead of the one-state-per-gate of stock autograd, which is how the
+  reference differentiates (circuit.py:261).  ``CONFIG['grad_mode'] = 'per_gate'`` keeps one differentiable
+  ``ops.apply_gate`` per gate (non-reversible primitives -- channels -- and ``torch.vmap`` always use it).
 
 This replaces the Python loop ``nn.Sequential(self.operators)(x)`` of the reference.
 """
