@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
@@ -92,6 +92,8 @@ _SIGNATURES = {
     'dq_inner_{s}': (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'dq_probs_{s}': (_i, [_vp, _vp, _i64, _vp]),
     'dq_marginal_{s}': (_i, [_vp, _i, _ip, _i, _i64, _vp, _vp]),
+    'dq_expect_zmulti_{s}': (_i, [_vp, C.POINTER(C.c_uint64), _i, _i, _i64, _vp, _i, _vp]),
+    'dq_scale_zsigns_{s}': (_i, [_vp, _vp, C.POINTER(C.c_uint64), _i, _vp, _i, _i64, _vp]),
     'dq_gate_grad_{s}': (_i, [_vp, _vp, _i, _ip, _i, _ip, _i, _i64, _vp, _vp]),
     'dq_gate_grad_multi_{s}': (_i, [_vp, _vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i64, _vp, _i, _vp]),
     'dq_pack_{s}': (_i, [_vp, _vp, _i, _u64, _u64, _i64, _vp]),

@@ -179,6 +179,58 @@ def expect_pauli(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
     return out
 
 
+def _u64_array(values: Sequence[int]):
+    return (C.c_uint64 * max(len(values), 1))(*[int(v) for v in values])
+
+
+def expect_z_multi(state: torch.Tensor, zmasks: Sequence[int]) -> torch.Tensor:
+    """<psi_b| Z-string_k |psi_b> for several Z-type strings in one read of the state per 32 strings:
+    float64 (B, K)."""
+    n = _nqubit(state)
+    if not state.is_contiguous():
+        raise ValueError('state must be contiguous')
+    if not _use_hip(state):
+        return torch.stack([_test_backend.expect_pauli(state, 0, z) for z in zmasks], dim=1)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_expect_zmulti_{_suffix(state)}')
+    nblocks = max(1, min(1024, (1 << n) // 1024))
+    parts = []
+    for lo in range(0, len(zmasks), 32):
+        grp = zmasks[lo:lo + 32]
+        part = torch.empty(state.shape[0], nblocks, len(grp), dtype=torch.float64, device=state.device)
+        rc = fn(_ptr(state), _u64_array(grp), len(grp), n, state.shape[0], _ptr(part), nblocks, _stream(state))
+        _lib.check(rc, 'dq_expect_zmulti')
+        parts.append(part.sum(dim=1))
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
+
+def scale_z_signs(state: torch.Tensor, zmasks: Sequence[int], coef: torch.Tensor) -> torch.Tensor:
+    """(sum_k coef[b, k] Z-string_k) |psi_b>: (B, 2**n) in the state's dtype; coef real (B, K)."""
+    n = _nqubit(state)
+    if not _use_hip(state):
+        i = torch.arange(1 << n)
+        w = torch.zeros(state.shape[0], 1 << n, dtype=torch.float64)
+        for k, z in enumerate(zmasks):
+            par = torch.zeros_like(i)
+            for p in range(n):
+                if (z >> p) & 1:
+                    par ^= (i >> p) & 1
+            w += coef[:, k : k + 1].to(torch.float64) * (1 - 2 * par).to(torch.float64)
+        return (state * w.to(state.real.dtype)).contiguous()
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_scale_zsigns_{_suffix(state)}')
+    coef = coef.to(torch.float64).contiguous()
+    out = None
+    for lo in range(0, len(zmasks), 32):
+        grp = zmasks[lo:lo + 32]
+        part = torch.empty_like(state)
+        rc = fn(_ptr(state), _ptr(part), _u64_array(grp), len(grp), _ptr(coef[:, lo:lo + 32].contiguous()), n,
+                state.shape[0], _stream(state))
+        _lib.check(rc, 'dq_scale_zsigns')
+        out = part if out is None else out.add_(part)
+    return out
+
+
 def inner(bra: torch.Tensor, ket: torch.Tensor) -> torch.Tensor:
     """<bra_b|ket_b> as complex128 (B,).  Inputs (B, count) contiguous, same dtype."""
     if bra.shape != ket.shape or bra.dtype != ket.dtype or bra.ndim != 2:

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import executor, qmath
+from . import executor, ops, qmath
 from .gate import (
     CNOT, Barrier, Fredkin, Hadamard, HamiltonianGate, ImaginarySwap, LatentGate, PauliX, PauliY, PauliZ,
     PhaseShift, ProjectionJ, ReconfigurableBeamSplitter, Reset, Rx, Rxx, Rxy, Ry, Ryy, Rz, Rzz, SDaggerGate, SGate, Swap,
@@ -271,8 +271,20 @@ class QubitCircuit(Operation):
         assert self.wires_condition == [], 'Expectation with conditional measurement is NOT supported'
         out = []
         if shots is None:
-            for ob in self.observables:
-                out.append(qmath.expectation(self.state, observable=ob, den_mat=self.den_mat))
+            done = {}
+            if not self.den_mat and not ops._is_batched(self.state):
+                # all Z-type strings (the ZZ terms of a cost Hamiltonian, examples/qaoa.py:31-44) in one read of
+                # the state instead of one pass each
+                ztype = [(i, ob.pauli_masks()[1]) for i, ob in enumerate(self.observables) if ob.pauli_masks()[0] == 0]
+                if len(ztype) >= 2:
+                    single = self.state.ndim == 2
+                    flat = self.state.reshape(1 if single else self.state.shape[0], -1)
+                    vals = ops.expect_z_multi(flat, [z for _, z in ztype])
+                    for k, (i, _z) in enumerate(ztype):
+                        done[i] = vals[0, k] if single else vals[:, k]
+            for i, ob in enumerate(self.observables):
+                out.append(done[i] if i in done else
+                           qmath.expectation(self.state, observable=ob, den_mat=self.den_mat))
         else:
             self.shots = shots
             dtype, device = self.state.real.dtype, self.state.device

@@ -263,6 +263,115 @@ static int expect_impl(const void* psi, uint64_t xmask, uint64_t zmask, int n, i
     return check_launch("dq_expect_pauli");
 }
 
+
+// ---- several Z-type Pauli expectations from one read of the state ----------------------------------------
+// <psi| Z..Z |psi> = sum_i |psi_i|^2 (-1)^{popc(i & zmask)}: a Hamiltonian made of many such strings (MaxCut /
+// Ising cost functions: one ZZ term per edge) costs ONE pass instead of one per term.  Workgroups stride over the
+// state and write one row of partial sums each; the caller adds the rows.
+constexpr int ZM_MAX = 32;
+struct ZMasks {
+    int k;
+    uint64_t m[ZM_MAX];
+};
+
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void expect_zmulti_kernel(const cx<T>* __restrict__ psi, ZMasks z, int n,
+                                                                     double* __restrict__ out) {
+    const int64_t b = blockIdx.y;
+    const cx<T>* p = psi + ((uint64_t)b << n);
+    double acc[ZM_MAX];
+#pragma unroll
+    for (int k = 0; k < ZM_MAX; ++k) acc[k] = 0;
+    const uint64_t dim = 1ull << n;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += (uint64_t)gridDim.x * blockDim.x) {
+        const cx<T> a = p[i];
+        const double pr = (double)a.x * a.x + (double)a.y * a.y;
+#pragma unroll
+        for (int k = 0; k < ZM_MAX; ++k)
+            if (k < z.k) acc[k] += (__popcll(i & z.m[k]) & 1) ? -pr : pr;
+    }
+#pragma unroll
+    for (int k = 0; k < ZM_MAX; k += 2) {
+        if (k < z.k) {
+            double u = acc[k], v = (k + 1 < ZM_MAX) ? acc[k + 1] : 0.0;
+            block_sum2(u, v);
+            if (threadIdx.x == 0) {
+                double* dst = out + ((size_t)b * gridDim.x + blockIdx.x) * z.k;
+                dst[k] = u;
+                if (k + 1 < z.k) dst[k + 1] = v;
+            }
+        }
+    }
+}
+
+// out_i = psi_i * sum_k coef[b][k] (-1)^{popc(i & zmask_k)}: the backward of the above (and sum_k c_k Z-string |psi>)
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void scale_zsigns_kernel(const cx<T>* __restrict__ psi, cx<T>* __restrict__ out,
+                                                                    ZMasks z, const double* __restrict__ coef, int n) {
+    const int64_t b = blockIdx.y;
+    const cx<T>* p = psi + ((uint64_t)b << n);
+    cx<T>* q = out + ((uint64_t)b << n);
+    double c[ZM_MAX];
+#pragma unroll
+    for (int k = 0; k < ZM_MAX; ++k) c[k] = (k < z.k) ? coef[(size_t)b * z.k + k] : 0.0;
+    const uint64_t dim = 1ull << n;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += (uint64_t)gridDim.x * blockDim.x) {
+        double w = 0;
+#pragma unroll
+        for (int k = 0; k < ZM_MAX; ++k)
+            if (k < z.k) w += (__popcll(i & z.m[k]) & 1) ? -c[k] : c[k];
+        const cx<T> a = p[i];
+        q[i] = mk<T>((T)(a.x * w), (T)(a.y * w));
+    }
+}
+
+static int fill_zmasks(ZMasks& z, const uint64_t* zmasks, int k, int n, const char* who) {
+    if (!zmasks || k < 1 || k > ZM_MAX) {
+        set_error("%s: %d masks per call, supported 1..%d", who, k, ZM_MAX);
+        return DQ_ERR_ARG;
+    }
+    const uint64_t full = (1ull << n) - 1ull;
+    z.k = k;
+    for (int i = 0; i < ZM_MAX; ++i) z.m[i] = i < k ? zmasks[i] : 0;
+    for (int i = 0; i < k; ++i)
+        if (zmasks[i] & ~full) {
+            set_error("%s: mask %d has bits >= n", who, i);
+            return DQ_ERR_ARG;
+        }
+    return DQ_OK;
+}
+
+template <typename T>
+static int expect_zmulti_impl(const void* psi, const uint64_t* zmasks, int k, int n, int64_t batch, double* out,
+                              int nblocks, dq_stream_t stream) {
+    if (!psi || !out || n < 1 || n > 40 || batch < 1 || batch > 65535 || nblocks < 1 || nblocks > 65535) {
+        set_error("dq_expect_zmulti: bad argument");
+        return DQ_ERR_ARG;
+    }
+    ZMasks z;
+    int rc = fill_zmasks(z, zmasks, k, n, "dq_expect_zmulti");
+    if (rc) return rc;
+    hipLaunchKernelGGL(expect_zmulti_kernel<T>, dim3((unsigned)nblocks, (unsigned)batch), dim3(RED_THREADS), 0,
+                       as_stream(stream), static_cast<const cx<T>*>(psi), z, n, out);
+    return check_launch("dq_expect_zmulti");
+}
+
+template <typename T>
+static int scale_zsigns_impl(const void* psi, void* out, const uint64_t* zmasks, int k, const double* coef, int n,
+                             int64_t batch, dq_stream_t stream) {
+    if (!psi || !out || !coef || n < 1 || n > 40 || batch < 1 || batch > 65535) {
+        set_error("dq_scale_zsigns: bad argument");
+        return DQ_ERR_ARG;
+    }
+    ZMasks z;
+    int rc = fill_zmasks(z, zmasks, k, n, "dq_scale_zsigns");
+    if (rc) return rc;
+    const unsigned nb = red_blocks(1ull << n);
+    hipLaunchKernelGGL(scale_zsigns_kernel<T>, dim3(nb, (unsigned)batch), dim3(RED_THREADS), 0, as_stream(stream),
+                       static_cast<const cx<T>*>(psi), static_cast<cx<T>*>(out), z, coef, n);
+    return check_launch("dq_scale_zsigns");
+}
+
 template <typename T>
 static int inner_impl(const void* bra, const void* ket, int64_t count, int64_t batch, double* out, void* ws,
                       dq_stream_t stream) {
@@ -585,6 +694,18 @@ extern "C" int64_t dq_reduce_ws_bytes(int64_t batch) {
                                          dq_stream_t stream) {                                                        \
         return dq::gate_grad_impl<T>(x, gy, n, targets, k, controls, nc, batch, gU, stream);                          \
     }
+
+#define DQ_DEFINE_Z(SUFFIX, T)                                                                                        \
+    extern "C" int dq_expect_zmulti_##SUFFIX(const void* psi, const uint64_t* zmasks, int k, int n, int64_t batch,    \
+                                             double* out, int nblocks, dq_stream_t stream) {                          \
+        return dq::expect_zmulti_impl<T>(psi, zmasks, k, n, batch, out, nblocks, stream);                             \
+    }                                                                                                                 \
+    extern "C" int dq_scale_zsigns_##SUFFIX(const void* psi, void* out, const uint64_t* zmasks, int k,                \
+                                            const double* coef, int n, int64_t batch, dq_stream_t stream) {          \
+        return dq::scale_zsigns_impl<T>(psi, out, zmasks, k, coef, n, batch, stream);                                 \
+    }
+DQ_DEFINE_Z(c64, float)
+DQ_DEFINE_Z(c128, double)
 
 extern "C" int dq_gate_grad_multi_c64(const void* x, const void* gy, int n, int ngates, const int* targets,
                                       const int* ctrl_begin, const int* ctrl_bits, int64_t batch, double* out,

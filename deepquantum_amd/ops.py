@@ -176,3 +176,29 @@ def marginal(state: torch.Tensor, bits: Sequence[int]) -> torch.Tensor:
     if not state.is_contiguous():
         state = state.contiguous()
     return _Marginal.apply(state, tuple(int(b) for b in bits))
+
+
+class _ExpectZMulti(torch.autograd.Function):
+    """Re <psi_b| Z-string_k |psi_b> for K Z-type strings: (B, K), one read of the state per 32 strings."""
+
+    @staticmethod
+    def forward(state: torch.Tensor, zmasks: tuple) -> torch.Tensor:
+        return backend.expect_z_multi(state, zmasks).to(state.real.dtype)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        state, ctx.zmasks = inputs
+        ctx.save_for_backward(state)
+
+    @staticmethod
+    def backward(ctx, g: torch.Tensor):
+        (state,) = ctx.saved_tensors
+        # L = sum_k g_k psi^H P_k psi with P_k diagonal: grad = 2 (sum_k g_k P_k) psi, one read + one write
+        return backend.scale_z_signs(state, ctx.zmasks, 2.0 * g), None
+
+
+def expect_z_multi(state: torch.Tensor, zmasks: Sequence[int]) -> torch.Tensor:
+    """Differentiable expectation values of several Z-type Pauli strings at once: real (B, K)."""
+    if not state.is_contiguous():
+        state = state.contiguous()
+    return _ExpectZMulti.apply(state, tuple(int(z) for z in zmasks))

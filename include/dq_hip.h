@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 7
+#define DQ_ABI_VERSION 8
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -189,6 +189,21 @@ int dq_expect_pauli_c64(const void* psi, uint64_t xmask, uint64_t zmask, int n, 
                         double* out, void* ws, dq_stream_t stream);
 int dq_expect_pauli_c128(const void* psi, uint64_t xmask, uint64_t zmask, int n, int64_t batch,
                          double* out, void* ws, dq_stream_t stream);
+
+/* k <= 32 Z-type strings (xmask = 0) in ONE read of the state: `zmasks` is a HOST array; `nblocks` workgroups stride
+ * over the state and each writes one row of partial sums: out = DEVICE double [batch, nblocks, k], fully overwritten;
+ * the caller adds the nblocks rows.  A Hamiltonian of many ZZ terms (examples/qaoa.py:31-44: one observable per
+ * edge, each a separate pass in qmath.expectation) costs one pass. */
+int dq_expect_zmulti_c64(const void* psi, const uint64_t* zmasks, int k, int n, int64_t batch, double* out, int nblocks,
+                         dq_stream_t stream);
+int dq_expect_zmulti_c128(const void* psi, const uint64_t* zmasks, int k, int n, int64_t batch, double* out, int nblocks,
+                          dq_stream_t stream);
+/* out[b, i] = psi[b, i] * sum_j coef[b, j] (-1)^{popc(i & zmasks[j])}  (coef: DEVICE double [batch, k]): the
+ * gradient of the above, i.e. (sum_j coef_j Z-string_j) |psi>, in one read + one write.  out may be psi. */
+int dq_scale_zsigns_c64(const void* psi, void* out, const uint64_t* zmasks, int k, const double* coef, int n,
+                        int64_t batch, dq_stream_t stream);
+int dq_scale_zsigns_c128(const void* psi, void* out, const uint64_t* zmasks, int k, const double* coef, int n,
+                         int64_t batch, dq_stream_t stream);
 
 /* out[2b], out[2b+1] = Re, Im of <bra_b|ket_b> over `count` amplitudes.
  * Replaces inner_product_dist's local part (distributed.py:288-291) and `state.mH @ x`. */

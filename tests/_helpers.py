@@ -300,3 +300,50 @@ def check_edge_cases(dq, device=None):
     a = cir().clone()
     b = cir()
     assert torch.equal(a, b)
+
+
+def check_many_z_observables(dq, device=None, dtype=torch.float32, n=9):
+    """A ring of ZZ terms plus single Z, mixed with X / Y strings (the QAOA read-out, examples/qaoa.py:31-44): the
+    Z-type strings are evaluated together in one read of the state; values and gradients must equal the
+    observable-by-observable evaluation."""
+    def build():
+        torch.manual_seed(2)
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        cir.rylayer(encode=True)
+        cir.cnot_ring()
+        cir.rxlayer()
+        for q in range(n):
+            cir.observable([q, (q + 1) % n], 'zz')
+        cir.observable(0)
+        cir.observable([1, 2], 'xy')
+        cir.observable([3, 4, 5], 'zzz')
+        cir.observable(2, 'x')
+        if device is not None:
+            cir.to(device)
+        if dtype == torch.float64:
+            cir.to(torch.double)
+        return cir
+
+    g = torch.Generator().manual_seed(4)
+    data = torch.rand(3, n, generator=g, dtype=dtype)
+    data = data.to(device) if device is not None else data
+    tol = 1e-10 if dtype == torch.float64 else 2e-5
+    res = {}
+    for together in (True, False):
+        cir = build()
+        d = data.clone().requires_grad_(True)
+        cir(d)
+        if together:
+            ev = cir.expectation()
+        else:
+            ev = torch.stack([dq.qmath.expectation(cir.state, ob) for ob in cir.observables], dim=-1)
+        w = torch.linspace(0.5, 1.5, ev.shape[-1], dtype=dtype, device=ev.device)
+        (ev * w).sum().backward()
+        res[together] = (ev.detach().cpu(), d.grad.cpu(), [p.grad.cpu() for p in cir.parameters()])
+    a, b = res[True], res[False]
+    assert a[0].shape == (3, n + 4)
+    assert (a[0] - b[0]).abs().max().item() < tol
+    assert (a[1] - b[1]).abs().max().item() < 10 * tol
+    for x, y in zip(a[2], b[2], strict=True):
+        assert (x - y).abs().max().item() < 10 * tol

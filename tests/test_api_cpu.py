@@ -249,3 +249,10 @@ def test_edge_cases(cpu_backend):
     from _helpers import check_edge_cases
 
     check_edge_cases(dq)
+
+
+def test_many_z_observables_in_one_pass(cpu_backend):
+    from _helpers import check_many_z_observables
+
+    check_many_z_observables(dq, dtype=torch.float64)
+    check_many_z_observables(dq, dtype=torch.float32)

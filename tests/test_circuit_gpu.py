@@ -377,3 +377,11 @@ def test_largest_single_gpu_states(n, dtype):
     assert abs(ev[0].item() - 2 * s * s) < 10 * tol and abs(ev[1].item()) < 10 * tol
     del state
     torch.cuda.empty_cache()
+
+
+def test_many_z_observables_in_one_pass_on_gpu():
+    from _helpers import check_many_z_observables
+
+    check_many_z_observables(dq, device=dev(), dtype=torch.float64)
+    check_many_z_observables(dq, device=dev(), dtype=torch.float32)
+    check_many_z_observables(dq, device=dev(), dtype=torch.float32, n=14)     # fused passes + 16 Z-type strings

@@ -179,6 +179,33 @@ def test_gate_grad_multi_equals_gate_by_gate(dtype, n):
 
 
 @pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+def test_many_z_strings_in_one_read(dtype):
+    """dq_expect_zmulti_* / dq_scale_zsigns_*: 40 random Z-type strings (two launches of <= 32) against the
+    single-string kernel and against the diagonal operator applied amplitude by amplitude."""
+    n, b = 13, 3
+    x = rand_state(b, n, dtype, 41)
+    xd = x.to(dev())
+    rng = random.Random(9)
+    masks = [rng.randrange(1, 1 << n) for _ in range(40)]
+    got = backend.expect_z_multi(xd, masks)
+    assert got.shape == (b, 40)
+    for k, z in enumerate(masks):
+        assert (got[:, k] - backend.expect_pauli(xd, 0, z)).abs().max().item() < 1e-12
+    coef = torch.randn(b, 40, dtype=torch.float64)
+    out = backend.scale_z_signs(xd, masks, coef.to(dev())).cpu()
+    i = torch.arange(1 << n)
+    w = torch.zeros(b, 1 << n, dtype=torch.float64)
+    for k, z in enumerate(masks):
+        par = torch.zeros_like(i)
+        for p in range(n):
+            if (z >> p) & 1:
+                par ^= (i >> p) & 1
+        w += coef[:, k:k + 1] * (1 - 2 * par)
+    ref = x.to(torch.complex128) * w
+    assert (out.to(torch.complex128) - ref).abs().max().item() < (1e-5 if dtype == torch.complex64 else 1e-12)
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
 def test_reductions(dtype):
     n, b = 10, 3
     x = rand_state(b, n, dtype, 21)
