@@ -123,6 +123,29 @@ def device_copy_bandwidth(device, nbytes=1 << 32, reps=5):
     return 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def single_gate_bandwidth(dq, n, batch, dtype, device, reps=3):
+    """Physical read+write GB/s of ONE gate application (H on the top qubit) over a resident (batch, 2^n) state:
+    the un-fused figure the north star's ">= 60 % of the HBM roofline" refers to."""
+    from deepquantum_amd import backend, fusion
+
+    is128 = dtype == torch.complex128
+    mat = (torch.tensor([[1, 1], [1, -1]], dtype=torch.cfloat) / 2**0.5).to(dtype).reshape(-1).to(device)
+    ops = [fusion.PrimOp('gen', (n - 1,), (), 0, 3)]
+    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+    km = fusion.kernel_matrices(steps, ops, mat)
+    x = torch.zeros(batch, 1 << n, dtype=dtype, device=device)
+    x[:, 0] = 1
+    backend.apply_fused(x, km, 0, steps[0].desc, out=x)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        backend.apply_fused(x, km, 0, steps[0].desc, out=x)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return 2 * x.numel() * x.element_size() * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(n, spec, dtype, budget_s):
     """Oracle (port of the reference's evolve_state path) on this host: first gates of the same
     workload, batch element 0, until ``budget_s`` seconds are spent."""
@@ -243,7 +266,14 @@ def main():
     if tj and os.path.exists(tj):
         traffic = json.load(open(tj)).get('hbm_bytes_per_launch')
     stats = dict(dq.executor.LAST_RUN)
+    z0 = float(out.reshape(-1)[0]) if out is not None else None
     copy_gbs = device_copy_bandwidth(device) if rank == 0 else None
+    single_gbs = None
+    if rank == 0 and not distributed and n >= 12:
+        out = None
+        cir.state = None
+        torch.cuda.empty_cache()
+        single_gbs = single_gate_bandwidth(dq, n, args.batch, dtype, device)
 
     if rank == 0:
         total_gate_applies = ngates * args.batch * args.steps * (world if multi and not distributed else 1)
@@ -297,10 +327,13 @@ def main():
                                             if launches else None)
         # also quote the physical rate against an in-framework device copy measured on this box
         line['roofline']['device_copy_GBs'] = copy_gbs
+        if single_gbs is not None:
+            line['roofline']['single_gate_GBs'] = single_gbs
+            line['roofline']['single_gate_frac_of_peak'] = single_gbs / HBM_PEAK_GBS
         if launches and copy_gbs:
             line['roofline']['physical_frac_of_copy'] = line['roofline']['physical_GBs'] / copy_gbs
-        if out is not None:
-            line['config']['expectation_Z0_sample0'] = float(out.reshape(-1)[0])
+        if z0 is not None:
+            line['config']['expectation_Z0_sample0'] = z0
         if not args.no_cpu_baseline and not multi:
             line['cpu_baseline'] = cpu_baseline(n, spec, dtype, args.cpu_seconds)
         print(json.dumps(line))
