@@ -81,6 +81,9 @@ def _check_mats(state: torch.Tensor, mats: torch.Tensor, k: int) -> tuple[torch.
     return mats, stride
 
 
+MAX_BATCH = 32768     # slices of a batch wider than the 65535 a grid dimension can hold
+
+
 # ---------------------------------------------------------------------------------------------------
 def apply_gate(
     state: torch.Tensor,
@@ -105,6 +108,11 @@ def apply_gate(
         out = torch.empty_like(state)
     if not _use_hip(state):
         return _test_backend.apply_gate(state, mats, targets, controls, out)
+    if state.shape[0] > MAX_BATCH:       # the batch is a grid dimension (<= 65535): very wide batches go in slices
+        for lo in range(0, state.shape[0], MAX_BATCH):
+            hi = min(lo + MAX_BATCH, state.shape[0])
+            apply_gate(state[lo:hi], mats[lo:hi] if stride else mats, targets, controls, out[lo:hi])
+        return out
     lib = _lib.load()
     fn = getattr(lib, f'dq_apply_gate_{_suffix(state)}')
     rc = fn(_ptr(state), _ptr(out), _ptr(mats), stride, n, _lib.int_array(targets), k,
@@ -131,6 +139,13 @@ def apply_fused(
     if not _use_hip(state):
         src = state.expand(out.shape[0], -1) if broadcast else state
         return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out)
+    if out.shape[0] > MAX_BATCH:
+        rows = mats.reshape(-1, mat_batch_stride) if mat_batch_stride else None
+        for lo in range(0, out.shape[0], MAX_BATCH):
+            hi = min(lo + MAX_BATCH, out.shape[0])
+            apply_fused(state if broadcast else state[lo:hi], rows[lo:hi].reshape(-1) if rows is not None else mats,
+                        mat_batch_stride, desc, out[lo:hi])
+        return out
     lib = _lib.load()
     fn = getattr(lib, f'dq_apply_fused_{"bcast_" if broadcast else ""}{_suffix(state)}')
     rc = fn(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0], C.byref(desc),

@@ -178,6 +178,35 @@ def test_gate_grad_multi_equals_gate_by_gate(dtype, n):
         assert (got[:, k] - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item()), (k, t, c)
 
 
+def test_batches_wider_than_a_grid_dimension_go_in_slices(monkeypatch):
+    """The batch is a grid dimension (<= 65535); get_unitary of a 16-qubit circuit has 65536 columns.  The slicing
+    in backend.apply_gate / apply_fused is exercised here with a small limit."""
+    monkeypatch.setattr(backend, 'MAX_BATCH', 3)
+    dtype, n, b = torch.complex64, 13, 8
+    ops, mats0 = random_ops(n, 25, 5, kinds=('gen', 'x', 'diag'))
+    mats = torch.stack([mats0 * torch.exp(torch.tensor(0.1j * i)) for i in range(b)]).to(dtype)
+    for op in ops:      # X-type matrices are not read by the kernels: keep the per-sample phase off them
+        if op.kind == 'x':
+            mats[:, op.mat:op.mat + 4] = mats0[op.mat:op.mat + 4].to(dtype)
+    steps = fusion.schedule(ops, n, fusion.default_geometry(False))
+    x = rand_state(b, n, dtype, 3)
+    ref = torch.cat([run_reference(x[i:i + 1], ops, mats[i]) for i in range(b)])
+    xd = x.to(dev())
+    md = fusion.kernel_matrices(steps, ops, mats).to(dev()).contiguous()
+    for st in steps:
+        backend.apply_fused(xd, md, md.shape[1], st.desc, out=xd)
+    assert (xd.cpu() - ref).abs().max().item() < TOL[dtype]
+    # single-gate kernel with per-sample matrices, and the shared-input fused entry
+    m = torch.stack([rand_unitary(1, dtype, 20 + i) for i in range(b)]).to(dev())
+    got = backend.apply_gate(x.to(dev()), m, [5], [2]).cpu()
+    want = torch.cat([oracle.apply_gate_bits(x[i:i + 1], m[i].cpu(), [5], [2]) for i in range(b)])
+    assert (got - want).abs().max().item() < TOL[dtype]
+    out = torch.empty(b, 1 << n, dtype=dtype, device=dev())
+    backend.apply_fused(x[:1].to(dev()), md, md.shape[1], steps[0].desc, out=out)
+    one = torch.cat([run_reference(x[:1], [ops[i] for i in steps[0].ops], mats[j]) for j in range(b)])
+    assert (out.cpu() - one).abs().max().item() < TOL[dtype]
+
+
 @pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
 def test_many_z_strings_in_one_read(dtype):
     """dq_expect_zmulti_* / dq_scale_zsigns_*: 40 random Z-type strings (two launches of <= 32) against the
