@@ -15,13 +15,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
 LOC_REG, LOC_THR, LOC_OUT = range(3)
 
-FUSED_MAX_HIGH = 8
+FUSED_MAX_HIGH = 12
 FUSED_MAX_ROUNDS = 24
 FUSED_MAX_GATES = 80
 FUSED_MAX_SLOTS = 4

@@ -367,10 +367,14 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
 
     const unsigned tid = threadIdx.x;
     const uint32_t* hw = reinterpret_cast<const uint32_t*>(&p);
-    const uint32_t hw0 = hw[0], hp0 = hw[1], hp1 = hw[2], hs0 = hw[3], hs1 = hw[4], lrb = hw[5], srbw = hw[6];
+    static_assert(DQ_FUSED_MAX_HIGH == 12 && offsetof(DqFusedPass, high_pos) == 4 && offsetof(DqFusedPass, high_sorted) == 16 &&
+                      offsetof(DqFusedPass, load_rb) == 28 && offsetof(DqFusedPass, store_rb) == 32,
+                  "header word layout");
+    const uint32_t hw0 = hw[0], hp0 = hw[1], hp1 = hw[2], hp2 = hw[3], hs0 = hw[4], hs1 = hw[5], hs2 = hw[6], lrb = hw[7],
+                   srbw = hw[8];
     const int L = (int)((hw0 >> 8) & 0xffu), h = (int)((hw0 >> 16) & 0xffu);
-    auto byte_of = [](uint32_t w0, uint32_t w1, int i) __attribute__((always_inline)) -> unsigned {
-        return ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
+    auto byte_of = [](uint32_t w0, uint32_t w1, uint32_t w2, int i) __attribute__((always_inline)) -> unsigned {
+        return ((i < 4 ? w0 : (i < 8 ? w1 : w2)) >> (8 * (i & 3))) & 0xffu;
     };
 
     // ---- which tile / which batch element (workgroup-uniform) ----
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     }
 #endif
     uint64_t tile = (uint64_t)tile_id << L;
-    for (int i = 0; i < h; ++i) tile = insert_zero(tile, (int)byte_of(hs0, hs1, i));
+    for (int i = 0; i < h; ++i) tile = insert_zero(tile, (int)byte_of(hs0, hs1, hs2, i));
     // in_bstride = 2^n normally; 0 when every batch element starts from the same (single) input state
     const V* pin = in + (uint64_t)sample * (uint64_t)in_bstride + tile;
     V* pout = out + ((uint64_t)sample << n) + tile;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     // tile-local index -> offset inside the state
     auto glob = [&](unsigned e) __attribute__((always_inline)) -> uint64_t {
         uint64_t g = e & ((1u << L) - 1u);
-        for (int i = 0; i < h; ++i) g |= (uint64_t)((e >> (L + i)) & 1u) << byte_of(hp0, hp1, i);
+        for (int i = 0; i < h; ++i) g |= (uint64_t)((e >> (L + i)) & 1u) << byte_of(hp0, hp1, hp2, i);
         return g;
     };
 

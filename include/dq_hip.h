@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 8
+#define DQ_ABI_VERSION 9
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -73,7 +73,7 @@ int dq_apply_gate_c128(const void* in, void* out, const void* mats, int64_t mat_
  *    R register-slot bits (tile-local positions); gates of the round act on register slots.
  *    The host scheduler (deepquantum_amd/fusion.py) builds these descriptors.
  * ------------------------------------------------------------------------------------------ */
-#define DQ_FUSED_MAX_HIGH 8
+#define DQ_FUSED_MAX_HIGH 12
 #define DQ_FUSED_MAX_ROUNDS 24
 #define DQ_FUSED_MAX_GATES 80
 #define DQ_FUSED_MAX_SLOTS 4

@@ -36,10 +36,10 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.DqFusedGate) == 32
     assert ctypes.sizeof(_lib.DqFusedRound) == 16
-    assert _lib.DqFusedPass.rounds.offset == 28
+    assert _lib.DqFusedPass.rounds.offset == 36
     ng = _lib.FUSED_MAX_GATES
-    assert _lib.DqFusedPass.gates.offset == 416 and _lib.DqFusedPass.load_slot_off.offset == 416 + ng * 32
-    assert _lib.DqFusedPass.lds_tab.offset == 416 + ng * 32 + 64
+    assert _lib.DqFusedPass.gates.offset == 424 and _lib.DqFusedPass.load_slot_off.offset == 424 + ng * 32
+    assert _lib.DqFusedPass.lds_tab.offset == 424 + ng * 32 + 64
     assert _lib.DqFusedGate.fast.offset == 12 and _lib.DqFusedGate.mat_advance.offset == 24
     assert _lib.DqFusedGate.out_cmask.offset == 16 and _lib.DqFusedGate.mat.offset == 8
 

@@ -104,5 +104,5 @@ def test_descriptor_struct_sizes_match_header():
 
     assert ctypes.sizeof(_lib.DqFusedGate) == 32
     assert ctypes.sizeof(_lib.DqFusedRound) == 16
-    assert ctypes.sizeof(_lib.DqFusedPass) == 28 + 24 * 16 + 4 + 80 * 32 + 64 + 26 * 32
+    assert ctypes.sizeof(_lib.DqFusedPass) == 36 + 24 * 16 + 4 + 80 * 32 + 64 + 26 * 32
     assert ctypes.sizeof(_lib.DqFusedPass) + 40 <= 4096      # the descriptor travels in the kernel-argument segment

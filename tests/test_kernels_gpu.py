@@ -126,7 +126,7 @@ def test_fused_batched_matrices_and_out_of_place(is128):
     assert torch.equal(xd.cpu(), x)  # input untouched
 
 
-@pytest.mark.parametrize('is128,n,b', [(False, 15, 3), (False, 16, 16), (True, 14, 5), (False, 12, 4)])
+@pytest.mark.parametrize('is128,n,b', [(False, 15, 3), (False, 16, 16), (True, 14, 5), (False, 13, 4), (True, 11, 2)])
 def test_fused_pass_with_one_shared_input_state(is128, n, b):
     """dq_apply_fused_bcast_*: every sample reads the same input state (the first pass of a batched circuit),
     with its own matrices; workgroups of one tile are remapped to neighbours on one XCD."""
