@@ -70,6 +70,7 @@ def _geometry(is128: bool) -> fusion.Geometry:
     ml = CONFIG['min_low_c128'] if is128 else CONFIG['min_low_c64']
     if ml is not None:
         g.min_low = ml
+        g.fallback = None
     if CONFIG['max_gates'] is not None:
         g.max_gates = CONFIG['max_gates']
     if CONFIG['max_far'] is not None:
@@ -177,7 +178,8 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
     n = state.shape[-1].bit_length() - 1
     with torch.no_grad():
         is128 = state.dtype == torch.complex128
-        m = _geometry(is128).m
+        g_ = _geometry(is128)
+        m = g_.fallback.m if g_.fallback is not None else g_.m     # smallest tile a fused pass can run on
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):
             return _run_small(state, prims, n, m)
