@@ -728,7 +728,7 @@ struct FusedVariant {
 };
 // variant 0 is the default geometry of each precision
 static const FusedVariant kVariantsC64[] = {{12, 4, 8}, {13, 4, 9}};
-static const FusedVariant kVariantsC128[] = {{11, 3, 8}, {12, 4, 8}};
+static const FusedVariant kVariantsC128[] = {{11, 3, 8}, {12, 3, 9}};
 static const int kNumVariants = 2;
 
 template <typename T>
@@ -891,7 +891,7 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
         else launch_variant<float, 4, 9>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
     } else {
         if (v.m == 11) launch_variant<double, 3, 8>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
-        else launch_variant<double, 4, 8>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+        else launch_variant<double, 3, 9>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
     }
     return check_launch("dq_apply_fused");
 }

@@ -79,9 +79,13 @@ def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = No
     643 (40) / 614 (35) / 596 (32); c128, n = 28, batch 8: min_low 4 / 3 -> 703 (38) / 671 (33).  The optimum is
     128-byte runs (one cache line per lane group) in both precisions."""
     if is_c128:
-        m = 11 if m is None else m
-        slots = {11: 3, 12: 4}[m] if slots is None else slots
-        return Geometry(m=m, slots=slots, vb=0, min_low=max(3, m - _lib.FUSED_MAX_HIGH))
+        explicit = m is not None
+        m = 12 if m is None else m
+        slots = 3 if slots is None else slots
+        geom = Geometry(m=m, slots=slots, vb=0, min_low=max(3, m - _lib.FUSED_MAX_HIGH))
+        if not explicit:       # same trade as complex64: 12-bit tiles of 512 threads, 11-bit ones when 8 gathered bits do
+            geom.fallback = Geometry(m=11, slots=slots, vb=0, min_low=3)
+        return geom
     # complex64: 13-bit tiles (512 threads, 64 KiB of LDS, two workgroups per CU) with 9 gathered bits: a pass costs
     # ~14 % more than with 12-bit tiles but there are 15-20 % fewer of them (n = 28, depth 40, batch 16; seeds 1234 /
     # 7 / 99: 548 -> 528, 593 -> 544, 539 -> 525 ms per step)

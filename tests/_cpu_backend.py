@@ -36,7 +36,7 @@ class CpuTestBackend:
         return out
 
     def fused_geometry(self, is_c128, variant):
-        table = {(False, 0): (12, 4, 256), (False, 1): (13, 4, 512), (True, 0): (11, 3, 256), (True, 1): (12, 4, 256)}
+        table = {(False, 0): (12, 4, 256), (False, 1): (13, 4, 512), (True, 0): (11, 3, 256), (True, 1): (12, 3, 512)}
         return table[(bool(is_c128), variant)]
 
     # ---- fused pass interpreter --------------------------------------------------------------------
@@ -46,7 +46,7 @@ class CpuTestBackend:
         bsz = state.shape[0]
         is128 = state.dtype == torch.complex128
         m, L, h = desc.m, desc.L, desc.h
-        geoms = {(False, 12): 4, (False, 13): 4, (True, 11): 3, (True, 12): 4}
+        geoms = {(False, 12): 4, (False, 13): 4, (True, 11): 3, (True, 12): 3}
         R = geoms[(is128, m)]
         vb = 0 if is128 else 1
         logt = m - R
