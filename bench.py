@@ -338,6 +338,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(n, spec, dtype, args.cpu_seconds)
         print(json.dumps(line))
     if multi:
+        torch.distributed.barrier()      # rank 0 measured a few extras; leave together
         dq.cleanup_distributed()
 
 
