@@ -347,3 +347,55 @@ def check_many_z_observables(dq, device=None, dtype=torch.float32, n=9):
     assert (a[1] - b[1]).abs().max().item() < 10 * tol
     for x, y in zip(a[2], b[2], strict=True):
         assert (x - y).abs().max().item() < 10 * tol
+
+
+def check_readout_against_golden(dq, device=None, tol=2e-5):
+    """Conditional (measurement-controlled) gates, post-selection, deferred measurement, amplitudes / probabilities,
+    measurement probabilities, custom initial states: against the reference's outputs (make_golden_extra.py)."""
+    def build(init_state='zeros'):
+        cir = dq.QubitCircuit(4, init_state=init_state)
+        cir.h(0)
+        cir.ry(1, encode=True)
+        cir.cnot(0, 2)
+        cir.x(3, controls=[0], condition=True)
+        cir.rz(2, controls=[1], condition=True, encode=True)
+        cir.h(2)
+        return cir.to(device) if device is not None else cir
+
+    def close(a, key, t=tol):
+        ref = gold_extra(key)
+        a = a.detach().cpu()
+        assert a.shape == ref.shape, (key, a.shape, ref.shape)
+        assert (a - ref).abs().max().item() < t, key
+
+    data = gold_extra('readout/data')
+    data = data.to(device) if device is not None else data
+    with torch.no_grad():
+        cir = build()
+        close(cir(data), 'readout/state')
+        assert sorted(cir.wires_condition) == gold_extra('readout/wires_condition').tolist()
+        for bits in ('00', '01', '10', '11'):
+            close(cir.post_select(bits), f'readout/post_select_{bits}')
+        close(cir.get_amplitude('0110'), 'readout/amp_0110')
+        close(cir.get_prob('1011'), 'readout/prob_1011')
+        states, keys, probs = cir.defer_measure(with_prob=True)        # sampled: consistent with post-selection
+        for i, key in enumerate(keys):
+            assert (states[i].cpu() - gold_extra(f'readout/post_select_{key}')[i]).abs().max().item() < tol
+            assert 0 < float(probs[i]) <= 1 + 1e-6
+        cir1 = build()
+        close(cir1(data[1]), 'readout/single_state')
+        close(cir1.post_select('10'), 'readout/single_post_select_10')
+        close(cir1.get_prob('01', wires=[1, 3]), 'readout/single_prob_wires')
+        close(cir1.get_amplitude('1001'), 'readout/single_amp_1001')
+        for wires, tag in ((None, 'measure'), ([0, 2], 'measure02')):
+            res = cir1.measure(shots=20000, with_prob=True, wires=wires)
+            want = dict(zip(gold_extra(f'readout/{tag}_keys').tolist(), gold_extra(f'readout/{tag}_probs').tolist()))
+            for key, (count, prob) in res.items():
+                assert abs(float(prob) - want[int(key, 2)]) < tol
+                assert abs(count / 20000 - float(prob)) < 0.02
+        close(build(init_state=gold_extra('readout/init_vec'))(data[0]), 'readout/state_from_vec')
+        batch = gold_extra('readout/init_batch')
+        st = dq.QubitState(4, batch).state
+        st = st.to(device) if device is not None else st
+        close(build()(data[:2], state=st), 'readout/state_from_batch')
+        close(dq.amplitude_encoding(torch.arange(1.0, 11.0), 4), 'readout/amplitude_encoding', 1e-6)

@@ -70,6 +70,52 @@ def main():
         out[f'ansatz/qcnn/param{i}'] = to_np(prm)
     out['ansatz/qcnn/nparam'] = np.array(len(list(qcnn.parameters())))
     out['ansatz/qcnn/state'] = to_np(qcnn().reshape(-1))
+    # read-out functions: conditional gates, post-selection, amplitudes / probabilities, custom
+    # initial states given as amplitude vectors (single and batched)
+    def readout_circuit(lib, init_state='zeros'):
+        cir = lib.QubitCircuit(4, init_state=init_state)
+        cir.h(0)
+        cir.ry(1, encode=True)
+        cir.cnot(0, 2)
+        cir.x(3, controls=[0], condition=True)        # measurement-conditioned X on wire 3
+        cir.rz(2, controls=[1], condition=True, encode=True)
+        cir.h(2)
+        return cir
+
+    cir = readout_circuit(dq)
+    data = torch.tensor([[0.7, 0.3], [2.1, -0.9], [1.3, 1.7]])
+    state = cir(data)
+    out['readout/data'] = to_np(data)
+    out['readout/state'] = to_np(state)
+    out['readout/wires_condition'] = np.array(sorted(cir.wires_condition))
+    for bits in ('00', '01', '10', '11'):
+        out[f'readout/post_select_{bits}'] = to_np(cir.post_select(bits))
+    out['readout/amp_0110'] = to_np(cir.get_amplitude('0110'))
+    out['readout/prob_1011'] = to_np(cir.get_prob('1011'))
+    cir1 = readout_circuit(dq)
+    st1 = cir1(data[1])
+    out['readout/single_state'] = to_np(st1)
+    out['readout/single_post_select_10'] = to_np(cir1.post_select('10'))
+    out['readout/single_prob_wires'] = to_np(cir1.get_prob('01', wires=[1, 3]))
+    out['readout/single_amp_1001'] = to_np(cir1.get_amplitude('1001'))
+    res = cir1.measure(shots=20000, with_prob=True)
+    keys = sorted(res)
+    out['readout/measure_keys'] = np.array([int(k, 2) for k in keys])
+    out['readout/measure_probs'] = np.array([float(res[k][1]) for k in keys])
+    res2 = cir1.measure(shots=20000, with_prob=True, wires=[0, 2])
+    keys2 = sorted(res2)
+    out['readout/measure02_keys'] = np.array([int(k, 2) for k in keys2])
+    out['readout/measure02_probs'] = np.array([float(res2[k][1]) for k in keys2])
+    g = torch.Generator().manual_seed(12)
+    vec = torch.randn(16, generator=g) + 1j * torch.randn(16, generator=g)
+    batch = torch.randn(2, 16, generator=g) + 1j * torch.randn(2, 16, generator=g)
+    out['readout/init_vec'] = to_np(vec)
+    out['readout/init_batch'] = to_np(batch)
+    out['readout/state_from_vec'] = to_np(readout_circuit(dq, init_state=vec)(data[0]))
+    cirb = readout_circuit(dq)
+    out['readout/state_from_batch'] = to_np(cirb(data[:2], state=dq.QubitState(4, batch).state))
+    out['readout/amplitude_encoding'] = to_np(dq.amplitude_encoding(torch.arange(1.0, 11.0), 4))
+
     # density matrices and channels
     for name, c in specs.DM_CASES.items():
         cir = dq.QubitCircuit(c['nqubit'], init_state=c['init'], den_mat=True)

@@ -256,3 +256,9 @@ def test_many_z_observables_in_one_pass(cpu_backend):
 
     check_many_z_observables(dq, dtype=torch.float64)
     check_many_z_observables(dq, dtype=torch.float32)
+
+
+def test_readout_functions_match_reference(cpu_backend):
+    from _helpers import check_readout_against_golden
+
+    check_readout_against_golden(dq)

@@ -385,3 +385,9 @@ def test_many_z_observables_in_one_pass_on_gpu():
     check_many_z_observables(dq, device=dev(), dtype=torch.float64)
     check_many_z_observables(dq, device=dev(), dtype=torch.float32)
     check_many_z_observables(dq, device=dev(), dtype=torch.float32, n=14)     # fused passes + 16 Z-type strings
+
+
+def test_readout_functions_match_reference_on_gpu():
+    from _helpers import check_readout_against_golden
+
+    check_readout_against_golden(dq, device=dev())
