@@ -116,6 +116,11 @@ def main():
     out['readout/state_from_batch'] = to_np(cirb(data[:2], state=dq.QubitState(4, batch).state))
     out['readout/amplitude_encoding'] = to_np(dq.amplitude_encoding(torch.arange(1.0, 11.0), 4))
 
+    cir = specs.extra_gates_circuit(dq)
+    out['extra_gates/state'] = to_np(cir().reshape(-1))
+    out['extra_gates/expectation'] = to_np(cir.expectation())
+    out['extra_gates/unitary'] = to_np(cir.get_unitary())
+
     # density matrices and channels
     for name, c in specs.DM_CASES.items():
         cir = dq.QubitCircuit(c['nqubit'], init_state=c['init'], den_mat=True)

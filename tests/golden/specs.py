@@ -406,3 +406,26 @@ c[1] = measure q[3];
 ''',
     'roundtrip': None,   # the QASM3 text the reference writes for QASM_EXPORT['zoo'], read back
 }
+
+
+# ---- gate classes the zoo does not reach: ProjectionJ planes, HamiltonianGate, LatentGate, CombinedSingleGate,
+# Identity ----------------------------------------------------------------------------------------------------
+def extra_gates_circuit(dq):
+    g = torch.Generator().manual_seed(17)
+    cir = dq.QubitCircuit(4)
+    cir.hlayer()
+    cir.j(0, 0.4, plane='xy')
+    cir.j(1, -0.9, plane='yz')
+    cir.j(2, 1.3, plane='zx', controls=[3])
+    cir.hamiltonian([[0.7, 'x0'], [-0.4, 'z1y2'], [0.25, 'y3']], t=0.8)
+    cir.hamiltonian([[1.0, 'z1z2'], [0.5, 'x2']], t=0.35, controls=[0])
+    herm = torch.randn(4, 4, generator=g) + 1j * torch.randn(4, 4, generator=g)
+    cir.hamiltonian((herm + herm.mH).to(torch.cfloat), t=0.2, wires=[3, 1])
+    cir.latent(wires=[2], inputs=torch.randn(2, 2, generator=g))
+    cir.latent(wires=[0, 3], inputs=torch.randn(4, 4, generator=g), controls=[1])
+    cir.add(dq.gate.CombinedSingleGate([dq.gate.Rx(0.3), dq.gate.SGate(), dq.gate.Ry(-0.6)], nqubit=4, wires=[1]))
+    cir.add(dq.gate.CombinedSingleGate([dq.gate.Hadamard(), dq.gate.PhaseShift(0.9)], nqubit=4, wires=[3], controls=[0, 2]))
+    cir.add(dq.gate.Identity(nqubit=4, wires=[0, 1]))
+    cir.observable([0, 1], 'xz')
+    cir.observable(3, 'y')
+    return cir

@@ -262,3 +262,9 @@ def test_readout_functions_match_reference(cpu_backend):
     from _helpers import check_readout_against_golden
 
     check_readout_against_golden(dq)
+
+
+def test_remaining_gate_classes_match_reference(cpu_backend):
+    from _helpers import check_extra_gates_against_golden
+
+    check_extra_gates_against_golden(dq)

@@ -391,3 +391,9 @@ def test_readout_functions_match_reference_on_gpu():
     from _helpers import check_readout_against_golden
 
     check_readout_against_golden(dq, device=dev())
+
+
+def test_remaining_gate_classes_match_reference_on_gpu():
+    from _helpers import check_extra_gates_against_golden
+
+    check_extra_gates_against_golden(dq, device=dev())
