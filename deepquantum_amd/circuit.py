@@ -161,6 +161,8 @@ class QubitCircuit(Operation):
         groups: dict = {}
         for op in self.operators:
             if getattr(op, '_param_names', None) == ('theta',) and type(op).get_matrix is not None:
+                if op._fixed_matrix() is not None:   # fixed angle, unchanged since the last evaluation
+                    continue
                 th = op.theta
                 key = (type(op), getattr(op, 'plane', None), th.dtype, th.device, th.numel())
                 groups.setdefault(key, []).append(op)
@@ -176,6 +178,7 @@ class QubitCircuit(Operation):
                 m = mats[i] if numel > 1 else mats[i, 0]
                 g.__dict__['_precomputed'] = m
                 g.__dict__['_matrix_cache'] = m.detach()
+                g._stamp()
                 touched.append(g)
         return touched
 

@@ -162,6 +162,27 @@ class _Parametric:
     def _invalidate(self) -> None:
         self.__dict__['_matrix_cache'] = None
         self.__dict__['_precomputed'] = None
+        self.__dict__['_matrix_key'] = None
+
+    def _param_key(self) -> tuple:
+        """Identity and version of every parameter tensor (+ the inverse flag): what the cached matrix belongs to."""
+        return tuple((t, t._version) for t in (getattr(self, n) for n in self._param_names)) + (self.inv_mode,)
+
+    def _stamp(self) -> None:
+        self.__dict__['_matrix_key'] = self._param_key()
+
+    def _fixed_matrix(self) -> torch.Tensor | None:
+        """The cached matrix, if it is still the matrix of the current parameters and no autograd graph has to be
+        built: a gate with fixed angles is evaluated once, not once per forward."""
+        m, key = self.__dict__.get('_matrix_cache'), self.__dict__.get('_matrix_key')
+        if m is None or key is None or key[-1] != self.inv_mode:
+            return None
+        grad = torch.is_grad_enabled()
+        for (t, version), name in zip(key[:-1], self._param_names):
+            cur = getattr(self, name)
+            if cur is not t or cur._version != version or (grad and cur.requires_grad):
+                return None
+        return m
 
     def init_para(self, inputs: Any = None) -> None:
         theta = self.inputs_to_tensor(inputs)
@@ -175,9 +196,13 @@ class _Parametric:
         pre = self.__dict__.get('_precomputed')
         if pre is not None:
             return pre
+        fixed = self._fixed_matrix()
+        if fixed is not None:
+            return fixed
         theta = -self.theta if self.inv_mode else self.theta
         matrix = self.get_matrix(theta)
         self.matrix = matrix.detach()
+        self._stamp()
         return matrix
 
     def _apply(self, fn: Any, *args, **kwargs):
@@ -324,12 +349,16 @@ class U3Gate(ParametricSingleGate):
         pre = self.__dict__.get('_precomputed')
         if pre is not None:
             return pre
+        fixed = self._fixed_matrix()
+        if fixed is not None:
+            return fixed
         if self.inv_mode:
             theta, phi, lambd = -self.theta, -self.lambd, -self.phi
         else:
             theta, phi, lambd = self.theta, self.phi, self.lambd
         matrix = self.get_matrix(theta, phi, lambd)
         self.matrix = matrix.detach()
+        self._stamp()
         return matrix
 
     def _real_wrapper(self, x: torch.Tensor) -> torch.Tensor:

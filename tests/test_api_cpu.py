@@ -268,3 +268,36 @@ def test_remaining_gate_classes_match_reference(cpu_backend):
     from _helpers import check_extra_gates_against_golden
 
     check_extra_gates_against_golden(dq)
+
+
+def test_fixed_angle_matrices_are_reused_and_invalidated(cpu_backend):
+    """A gate with a fixed angle evaluates its matrix once; an in-place change of the angle, a new angle, the
+    inverse flag and a parameter that needs a graph all force a fresh evaluation."""
+    g = dq.Rx(0.3, nqubit=2, wires=0)
+    g.update_matrix()
+    m0 = g.update_matrix()
+    assert g.update_matrix() is m0                       # reused
+    with torch.no_grad():
+        g.theta.mul_(2.0)                                # in-place edit bumps the version counter
+    m1 = g.update_matrix()
+    assert m1 is not m0 and torch.allclose(m1, g.get_matrix(torch.tensor(0.6)))
+    g.init_para(0.9)
+    assert torch.allclose(g.update_matrix(), g.get_matrix(torch.tensor(0.9)))
+    g.inv_mode = True
+    assert torch.allclose(g.update_matrix(), g.get_matrix(torch.tensor(-0.9)))
+    t = dq.U3Gate([0.1, 0.2, 0.3], nqubit=1, requires_grad=True)
+    a = t.update_matrix()
+    assert a.requires_grad and t.update_matrix() is not a  # trainable: a graph per evaluation
+    with torch.no_grad():
+        b = t.update_matrix()
+        assert not b.requires_grad and t.update_matrix() is b and torch.equal(a.detach(), b)
+    # a circuit of fixed gates gives the same state on every call, also after an angle edit
+    cir = dq.QubitCircuit(3)
+    cir.rxlayer(inputs=[0.1, 0.2, 0.3]); cir.cnot_ring(); cir.rylayer(inputs=[0.4, 0.5, 0.6])
+    s0 = cir().clone()
+    assert torch.equal(cir(), s0)
+    with torch.no_grad():
+        cir.operators[1].theta.add_(0.5)
+    ref = dq.QubitCircuit(3)
+    ref.rxlayer(inputs=[0.1, 0.7, 0.3]); ref.cnot_ring(); ref.rylayer(inputs=[0.4, 0.5, 0.6])
+    assert torch.allclose(cir(), ref(), atol=1e-6)
