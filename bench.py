@@ -57,6 +57,9 @@ def parse_args():
                     help='N > 1: index-bit-sharded state of 28 + log2(N) qubits instead of sharding the batch')
     ap.add_argument('--max-far', type=int, default=None, help='scheduler: max gathered bits >= far-bit per pass')
     ap.add_argument('--far-bit', type=int, default=None)
+    ap.add_argument('--plan-width', type=int, default=None,
+                    help='pass planner beam width (0 = first-come tiles, 1 = greedy; default: library)')
+    ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
     return ap.parse_args()
 
@@ -210,6 +213,8 @@ def main():
         dq.executor.CONFIG['fuse'] = False
     dq.executor.CONFIG['max_far'] = args.max_far
     dq.executor.CONFIG['far_bit'] = args.far_bit
+    dq.executor.CONFIG['plan_width'] = args.plan_width
+    dq.executor.CONFIG['plan_branch'] = args.plan_branch
 
     n = args.nqubit + (int(math.log2(world)) if distributed else 0)
     spec = random_circuit_spec(n, args.depth, args.seed)

@@ -63,7 +63,9 @@ class Geometry:
     max_gates: int = _lib.FUSED_MAX_GATES
     max_rounds: int = _lib.FUSED_MAX_ROUNDS - 1  # one spare so a trailing round never overflows
     fallback: 'Geometry | None' = None   # smaller (faster per byte) tile for passes that do not need all gathered bits
-    lookahead: bool = False   # choose the gathered bits of a pass by look-ahead (_choose_high)
+    plan_width: int = 4       # gathered bits of every pass from dry runs of the pass (_plan_tiles): beam width
+    plan_branch: int = 3      # ... and tiles tried per beam state; plan_width = 0: first-come tiles (no dry runs)
+    plan_min_bits: int = 20   # states below 2^plan_min_bits amplitudes: greedy (width 1) -- planning time matters there
     far_bit: int = 19         # index bits >= far_bit are "far": every one gathered doubles the number of
     max_far: int | None = None  # distant address streams of a tile; None = no limit (tools/sweep_tile_bits*.py)
 
@@ -101,35 +103,53 @@ def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = No
 
 
 # ---------------------------------------------------------------------------------------------------
-class _Dag:
-    """Dependency bookkeeping with the diagonal-commutation rule."""
+def _action(op: PrimOp) -> dict[int, str]:
+    """How ``op`` acts on each of its qubits: 'D' = as a function of Z (controls, targets of diagonal gates),
+    'X' = as a function of X (target of an X or of an Rx-like matrix a*I + i*b*X, controlled or not),
+    'N' = anything else."""
+    act = {q: 'D' for q in op.controls}
+    if op.kind == 'diag':
+        t_act = 'D'
+    elif op.k == 1 and (op.kind == 'x' or (op.kind == 'gen' and op.mode == 2)):
+        t_act = 'X'
+    else:
+        t_act = 'N'
+    for q in op.targets:
+        act[q] = t_act
+    return act
 
-    def __init__(self, ops: Sequence[PrimOp], n: int):
+
+class _Dag:
+    """Dependency bookkeeping with the commutation rule: two gates commute when on every shared qubit both are
+    'D' or both are 'X' (each is then a polynomial in the same commuting Paulis on the shared qubits).  Per qubit
+    the gate list therefore splits into groups -- maximal runs of one type, every 'N' gate a group of its own --
+    and a gate depends on all members of the group before its own."""
+
+    def __init__(self, ops: Sequence[PrimOp], n: int, x_commute: bool = True):
         self.ops = ops
         self.n_ops = len(ops)
         self.succ: list[list[int]] = [[] for _ in ops]
         self.indeg = [0] * len(ops)
-        last_n = [-1] * n                 # last gate acting 'N' on the qubit
-        d_since: list[list[int]] = [[] for _ in range(n)]  # 'D' gates since then
+        prev: list[list[int]] = [[] for _ in range(n)]   # the group every member of the current one waits for
+        cur: list[list[int]] = [[] for _ in range(n)]    # the current group ...
+        cur_t: list[str] = ['N'] * n                     # ... and its type
         for i, op in enumerate(ops):
-            deps = set()
-            d_bits = set(op.controls) | (set(op.targets) if op.kind == 'diag' else set())
-            n_bits = set() if op.kind == 'diag' else set(op.targets)
-            for q in d_bits:
-                if last_n[q] >= 0:
-                    deps.add(last_n[q])
-            for q in n_bits:
-                if last_n[q] >= 0:
-                    deps.add(last_n[q])
-                deps.update(d_since[q])
+            deps: set[int] = set()
+            for q, t in _action(op).items():
+                if t == 'X' and not x_commute:
+                    t = 'N'
+                if t == 'N' or t != cur_t[q]:
+                    if cur[q]:
+                        prev[q] = cur[q]
+                    cur[q] = []
+                    cur_t[q] = t
+                deps.update(prev[q])
+                cur[q].append(i)
+                if t == 'N':                             # closes its own group at once
+                    prev[q], cur[q] = cur[q], []
             for d in deps:
                 self.succ[d].append(i)
             self.indeg[i] = len(deps)
-            for q in d_bits:
-                d_since[q].append(i)
-            for q in n_bits:
-                last_n[q] = i
-                d_since[q] = []
         self.ready = sorted(i for i in range(self.n_ops) if self.indeg[i] == 0)
         self.done = 0
 
@@ -145,65 +165,103 @@ class _Dag:
             self.ready = sorted(self.ready + new)
 
 
-def _closure(dag: '_Dag', tile: set[int], cap: int) -> int:
-    """How many gates a pass owning ``tile`` could retire from the current front (ignoring the round / slot
-    limits): every fusable diagonal gate, every other fusable gate whose targets lie in the tile."""
-    ops, indeg = dag.ops, {}
-    stack = list(dag.ready)
+def _closure(dag: '_Dag', tile: set[int], cap: int, indeg: list[int] | None = None,
+             ready: list[int] | None = None) -> tuple[int, list[int], dict[int, int]]:
+    """Dry run of a pass that owns ``tile`` from the front (``indeg``, ``ready``; default: the DAG's current one),
+    ignoring the round / slot limits: retires every fusable diagonal gate and every other fusable gate whose
+    targets lie in the tile, up to ``cap`` gates.  Returns (gates retired, the gates left ready but stuck,
+    the in-degrees it changed)."""
+    ops = dag.ops
+    base = dag.indeg if indeg is None else indeg
+    changed: dict[int, int] = {}
+    stack = list(dag.ready if ready is None else ready)
+    stuck: list[int] = []
     count = 0
-    while stack and count < cap:
+    while stack:
         i = stack.pop()
         op = ops[i]
-        if not _fusable(op) or (op.kind != 'diag' and not all(t in tile for t in op.targets)):
+        if count >= cap or not _fusable(op) or (op.kind != 'diag' and not all(t in tile for t in op.targets)):
+            stuck.append(i)
             continue
         count += 1
         for s_ in dag.succ[i]:
-            left = indeg.get(s_, dag.indeg[s_]) - 1
-            indeg[s_] = left
+            left = changed.get(s_, base[s_]) - 1
+            changed[s_] = left
             if left == 0:
                 stack.append(s_)
-    return count
+    return count, stuck, changed
 
 
-def _choose_high(dag: '_Dag', low: set[int], hcap: int, geom: 'Geometry', n: int) -> set[int]:
-    """Pick the gathered bits of the next pass by look-ahead: grow the set one bit at a time, always the bit
-    that lets the pass retire the most gates.  Experimental (Geometry.lookahead, off): on the headline circuit
-    it needs as many passes as the first-come rule (35) and more at other sizes -- maximising the gates of the
-    next pass scatters the front; what bounds a pass is how far 12 qubits can advance before a CNOT reaches
-    outside the tile (about 2.7 layers)."""
+def _grow_tile(dag: '_Dag', low: set[int], hcap: int, cap: int, indeg: list[int] | None = None,
+               ready: list[int] | None = None, pick=None) -> set[int]:
+    """Gathered bits of one pass, grown one bit at a time: dry-run the pass with the bits chosen so far, look at
+    the gates it leaves stuck at the front, and add the missing target bit that lets the pass retire the most
+    gates (ties: the bit most stuck gates wait for, then the lowest).  ``pick(ranked)`` may choose another of the
+    ranked candidates (the beam search's branching)."""
     chosen: set[int] = set()
-    cap = geom.max_gates
     while len(chosen) < hcap:
         tile = low | chosen
-        # candidate bits: targets of gates that are ready or one step behind the front
+        base, stuck, _ = _closure(dag, tile, cap, indeg, ready)
+        if base >= cap:
+            break
         cands: dict[int, int] = {}
-        front = list(dag.ready)
-        seen = set(front)
-        for i in list(front):
-            for s_ in dag.succ[i]:
-                if s_ not in seen:
-                    seen.add(s_)
-                    front.append(s_)
-        for i in front:
+        for i in stuck:
             op = dag.ops[i]
-            if op.kind == 'diag' or not _fusable(op):
+            if not _fusable(op):
                 continue
             for t in op.targets:
                 if t not in tile:
                     cands[t] = cands.get(t, 0) + 1
         if not cands:
             break
-        base = _closure(dag, tile, cap)
-        if base >= cap:
-            break
-        best, best_key = None, None
-        for q, weight in cands.items():
-            gain = _closure(dag, tile | {q}, cap)
-            key = (gain, weight, -q)
-            if best_key is None or key > best_key:
-                best, best_key = q, key
-        chosen.add(best)
+        ranked = sorted(((_closure(dag, tile | {q}, cap, indeg, ready)[0], w, -q) for q, w in cands.items()),
+                        reverse=True)
+        best = ranked[0] if pick is None else pick(ranked)
+        chosen.add(-best[2])
     return chosen
+
+
+def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, branch: int) -> list[set[int] | None]:
+    """Gathered-bit sets for ALL passes of a circuit by beam search over dry runs (`_closure`): every beam state
+    (a front of the DAG) is extended by the greedy tile and by ``branch - 1`` randomised ones (one of the three best
+    candidates at each growth step, fixed seed), the ``width`` states that have retired the most gates survive.
+    ``None`` entries stand for a gate that cannot be fused and runs on its own.  width = 1: plain greedy."""
+    import random
+
+    rng = random.Random(20250929)
+
+    def jitter(ranked):
+        return ranked[rng.randrange(min(3, len(ranked)))]
+
+    beam = [(0, list(dag.indeg), list(dag.ready), [])]
+    while True:
+        nxt = []
+        for done, indeg, ready, hist in beam:
+            if done >= dag.n_ops:
+                return hist
+            seen = set()
+            for b_ in range(branch if width > 1 else 1):
+                tile_bits = _grow_tile(dag, low, hcap, cap, indeg, ready, jitter if b_ else None)
+                key = frozenset(tile_bits)
+                if key in seen:
+                    continue
+                seen.add(key)
+                count, stuck, changed = _closure(dag, low | tile_bits, cap, indeg, ready)
+                nindeg = list(indeg)
+                for k_, v in changed.items():
+                    nindeg[k_] = v
+                if count == 0:       # nothing fusable at the front: the lowest ready gate runs on its own
+                    i = min(stuck)
+                    stuck.remove(i)
+                    for s_ in dag.succ[i]:
+                        nindeg[s_] -= 1
+                        if nindeg[s_] == 0:
+                            stuck.append(s_)
+                    nxt.append((done + 1, nindeg, stuck, hist + [None]))
+                    break
+                nxt.append((done + count, nindeg, stuck, hist + [tile_bits]))
+        nxt.sort(key=lambda t: -t[0])
+        beam = nxt[:width]
 
 
 @dataclass
@@ -219,26 +277,54 @@ def _fusable(op: PrimOp) -> bool:
 
 
 def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True) -> list[FusedStep | SingleStep]:
-    """Greedy list scheduling over the commutation DAG.  Returns steps in execution order."""
+    """List scheduling over the commutation DAG.  Returns steps in execution order.  The gathered bits of the
+    passes come from the dry-run planner and, for comparison, from the first-come rule (a gate claims its bits while
+    the tile has room) -- on circuits whose passes are bounded by the gate cap rather than by the tile the cheap
+    rule can win; the schedule with fewer passes (then fewer LDS trips) is kept."""
     if fuse and n < geom.m and geom.fallback is not None and n >= geom.fallback.m:
         geom = geom.fallback                  # the state is smaller than the big tile but fits the small one
     if not fuse or n < geom.m:
         return [SingleStep(i) for i in range(len(ops))]
+    width = geom.plan_width if n >= geom.plan_min_bits else min(geom.plan_width, 1)
+    best = _schedule(ops, n, geom, 0)
+    if width and sum(isinstance(s_, FusedStep) for s_ in best) > 1:
+        def cost(steps):
+            return (len(steps), sum(s_.ntranspose for s_ in steps if isinstance(s_, FusedStep)))
+        cand = _schedule(ops, n, geom, width)
+        if cost(cand) < cost(best):
+            best = cand
+    return best
+
+
+def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int) -> list[FusedStep | SingleStep]:
     dag = _Dag(ops, n)
     steps: list[FusedStep | SingleStep] = []
     low = set(range(geom.min_low))
     hcap = geom.m - geom.min_low
-    # with a single low slot in the canonical layout only R - vb high bits fit a canonical round
+    planned = _plan_tiles(dag, low, hcap, geom.max_gates, width, geom.plan_branch) if width else []
+    planned.reverse()                   # consumed from the end
     while dag.done < dag.n_ops:
         high: set[int] = set()          # tile bits beyond the guaranteed low ones
         rounds: list[_Round] = [_Round()]
         count = 0
-        allowed = _choose_high(dag, low, hcap, geom, n) if geom.lookahead else None
+        if width == 0:
+            allowed = None              # first come, first served: a gate claims its bits while the tile has room
+        elif planned:
+            allowed = planned.pop()
+            if allowed is None:         # a gate the fused kernel does not take
+                i = dag.ready[0]
+                if not _fusable(ops[i]):
+                    steps.append(SingleStep(i))
+                    dag.retire(i)
+                    continue
+                allowed = _grow_tile(dag, low, hcap, geom.max_gates)
+        else:                           # the passes ran out of step with the dry runs (round / gate caps)
+            allowed = _grow_tile(dag, low, hcap, geom.max_gates)
 
         def fits_tile(op: PrimOp) -> bool:
             need = {t for t in op.targets if t not in low} - high
-            if allowed is not None and not need <= allowed:
-                return False
+            if allowed is not None and len(high | need | allowed) > hcap:
+                return False    # room is kept for the planned bits; spare room goes first come, first served
             if geom.max_far is not None and sum(1 for b in high | need if b >= geom.far_bit) > geom.max_far:
                 return False    # too many far-apart address streams per tile (DRAM row conflicts)
             return len(high) + len(need) <= hcap and len(high | need) <= min(hcap, n - geom.min_low)

@@ -8,6 +8,7 @@ import random
 import pytest
 import torch
 
+import deepquantum_amd as dq
 from deepquantum_amd import _lib, backend, fusion
 from oracle import statevec_oracle as oracle
 
@@ -106,3 +107,60 @@ def test_descriptor_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.DqFusedRound) == 16
     assert ctypes.sizeof(_lib.DqFusedPass) == 36 + 24 * 16 + 4 + 80 * 32 + 64 + 26 * 32
     assert ctypes.sizeof(_lib.DqFusedPass) + 40 <= 4096      # the descriptor travels in the kernel-argument segment
+
+
+def test_x_type_gates_commute_in_the_dag():
+    """Gates that act on a shared qubit as functions of X (X, Rx-like matrices, CNOT targets) commute, like gates that
+    act as functions of Z (controls, diagonal gates): the DAG must not order them, and must order everything else."""
+    P = fusion.PrimOp
+    rx = lambda q: P('gen', (q,), (), 0, 2)           # noqa: E731
+    h = lambda q: P('gen', (q,), (), 0, 3)            # noqa: E731
+    cx = lambda c, t: P('x', (t,), (c,), 0, 0)        # noqa: E731
+    ops = [rx(0), cx(1, 0), rx(0), cx(2, 0), h(0), rx(0), cx(0, 1), P('diag', (0,), (), 0, 0), h(1)]
+    dag = fusion._Dag(ops, 3)
+    succ = {i: set(s) for i, s in enumerate(dag.succ)}
+    assert dag.ready == [0, 1, 2, 3]                  # the four X-type gates on qubit 0 are mutually free
+    assert all(4 in succ[i] for i in range(4))        # ... and all precede the Hadamard
+    assert succ[4] == {5}                             # H -> Rx (a new X group of one)
+    assert succ[5] == {6, 7}                          # Rx -> the two gates diagonal in qubit 0
+    assert 8 in succ[6] and 8 not in succ[7]          # CNOT(0 -> 1) acts as X on qubit 1: before H(1)
+    strict = fusion._Dag(ops, 3, x_commute=False)
+    assert strict.ready == [0]
+
+
+def test_planned_tiles_need_fewer_passes_and_keep_the_result(cpu_backend):
+    """The dry-run planner (fusion._plan_tiles) against first-come tiles on a random H / Rx / CNOT circuit: fewer
+    passes, same state."""
+    import random
+    n, rng = 20, random.Random(5)
+    spec = []
+    for _ in range(10):
+        for q in range(n):
+            r = rng.random()
+            if r < 1 / 3:
+                spec.append(('h', q))
+            elif r < 2 / 3:
+                spec.append(('rx', q, rng.uniform(0, 6.28)))
+            else:
+                t = rng.randrange(n - 1)
+                spec.append(('cnot', q, t + (t >= q)))
+
+    def run(width):
+        dq.executor.CONFIG['plan_width'] = width
+        dq.executor._PLAN_CACHE.clear()
+        try:
+            cir = dq.QubitCircuit(n)
+            for op in spec:
+                getattr(cir, op[0])(*op[1:]) if op[0] != 'rx' else cir.rx(op[1], inputs=op[2])
+            with torch.no_grad():
+                out = cir().clone()
+            return out, dq.executor.LAST_RUN['passes']
+        finally:
+            dq.executor.CONFIG['plan_width'] = None
+            dq.executor._PLAN_CACHE.clear()
+
+    s0, p0 = run(0)
+    s1, p1 = run(1)
+    s4, p4 = run(4)
+    assert p4 <= p1 <= p0 and p4 < p0, (p0, p1, p4)
+    assert torch.allclose(s0, s1, atol=1e-5) and torch.allclose(s0, s4, atol=1e-5)
