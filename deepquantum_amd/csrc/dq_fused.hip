@@ -367,6 +367,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
 
     const unsigned tid = threadIdx.x;
     const uint32_t* hw = reinterpret_cast<const uint32_t*>(&p);
+    static_assert(DQ_FAST32_IDS == DQ_FAST_IDS, "tools/gen_fused_asm.py and include/dq_hip.h disagree on the handler ids");
     static_assert(DQ_FUSED_MAX_HIGH == 12 && offsetof(DqFusedPass, high_pos) == 4 && offsetof(DqFusedPass, high_sorted) == 16 &&
                       offsetof(DqFusedPass, load_rb) == 28 && offsetof(DqFusedPass, store_rb) == 32,
                   "header word layout");
@@ -489,7 +490,9 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     constexpr int ROUND_W0 = offsetof(DqFusedPass, rounds) / 4;
     constexpr int GATE_W0 = offsetof(DqFusedPass, gates) / 4;
     const int nrounds = (int)(pw[0] >> 24);
-    uint64_t mrun = (uint64_t)(mbase + pw[offsetof(DqFusedPass, mat_base) / 4]);  // running matrix pointer
+    // running byte offset of the current gate's matrix from `mbase` (32 bits: SMEM takes base pair + SGPR offset)
+    uint32_t moff = pw[offsetof(DqFusedPass, mat_base) / 4] * (uint32_t)sizeof(V);
+    const uint64_t mbase_u = (uint64_t)mbase;
     T hscale = T(1);   // product of the deferred Hadamard factors of this pass (uniform)
     bool had = false;
     for (int r = 0; r < nrounds; ++r) {
@@ -510,25 +513,26 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
         if (!same || ntbase != tbase) transpose_to(nrb, ntbase, 1 + r);
         const int gbeg = (int)((rw3 >> 16) & 0xffu), gend = (int)(rw3 >> 24);
-        uint64_t gaddr = kgates + 32ull * (unsigned)gbeg;   // kernarg address of the round's first gate record
-        for (int gi = gbeg; gi < gend; ++gi) {
-            // ONE scalar-memory round trip per gate: the 32-byte record and -- from the running pointer, no
+        // byte offsets of the round's gate records from `kgates`; the loop runs on the offset (one add, one compare)
+        const uint32_t goff_end = 32u * (unsigned)gend;
+        for (uint32_t goff = 32u * (unsigned)gbeg; goff < goff_end; goff += 32u) {
+            // ONE scalar-memory round trip per gate: the 32-byte record and -- from the running offset, no
             // decode needed because the host lays the matrices of a pass out in gate order -- its matrix.
             u32x8 rec;
             typename std::conditional<FAST64, u32x16, u32x8>::type mqv;
             if constexpr (FAST32) {
-                asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx8 %1, %4, %5\n\ts_waitcnt lgkmcnt(0)"
                              : "=&s"(rec), "=&s"(mqv)
-                             : "s"(gaddr), "s"(mrun));
+                             : "s"(kgates), "s"(goff), "s"(mbase_u), "s"(moff));
             } else if constexpr (FAST64) {
-                asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx16 %1, %4, %5\n\ts_waitcnt lgkmcnt(0)"
                              : "=&s"(rec), "=&s"(mqv)
-                             : "s"(gaddr), "s"(mrun));
+                             : "s"(kgates), "s"(goff), "s"(mbase_u), "s"(moff));
             } else {
-                asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rec) : "s"(gaddr));
+                asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rec) : "s"(kgates), "s"(goff));
             }
-            gaddr += 32;
-            mrun += (uint64_t)rec[6] * sizeof(V);
+            if constexpr (sizeof(V) == 8) asm volatile("s_lshl3_add_u32 %0, %1, %0" : "+s"(moff) : "s"(rec[6]) : "scc");
+            else asm volatile("s_lshl4_add_u32 %0, %1, %0" : "+s"(moff) : "s"(rec[6]) : "scc");
             const uint32_t g0 = rec[0], g1 = rec[1], gmat = rec[2], fast = rec[3];
             const uint64_t out_cmask = (uint64_t)rec[4] | ((uint64_t)rec[5] << 32);
             const unsigned reg_cmask = (g1 >> 8) & 0xffu, thr_cmask = g1 >> 16;
@@ -536,48 +540,14 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
                 // Straight-line handlers picked by the host (include/dq_hip.h, DqFusedGate::fast): one flat
                 // switch instead of the kind / control / mode / slot decision chain -- the scalar unit is the
                 // scarce resource of this kernel.  Ids < 16 have no control of any kind: no test at all.
-                if (fast < 64u) {
+                if (__builtin_expect(fast < (uint32_t)DQ_FAST_IDS, 1)) {
 #define DQ_PAIR(I) ((uint64_t)mqv[2 * (I)] | ((uint64_t)mqv[2 * (I) + 1] << 32))
                     if constexpr (FAST32) {
+                        // every straight-line handler sits behind ONE jump table (dq_fused_asm.inc, fast_dispatch_f32):
+                        // the cost of reaching it does not depend on which one it is; handlers of controlled gates test
+                        // the outside and thread controls themselves.
                         const uint64_t mq[4] = {DQ_PAIR(0), DQ_PAIR(1), DQ_PAIR(2), DQ_PAIR(3)};
-#define DQ_GEN1_CASE(ID) case ID: gen1_block_f32<(ID) / 4, (ID) % 4>(a, mq); break;
-#define DQ_GEN1_CASES                                                                           \
-    DQ_GEN1_CASE(0) DQ_GEN1_CASE(1) DQ_GEN1_CASE(2) DQ_GEN1_CASE(3) DQ_GEN1_CASE(4) DQ_GEN1_CASE(5) \
-    DQ_GEN1_CASE(6) DQ_GEN1_CASE(7) DQ_GEN1_CASE(8) DQ_GEN1_CASE(9) DQ_GEN1_CASE(10) DQ_GEN1_CASE(11)
-// Hadamard-like matrix s [[1, 1], [1, -1]]: sums and differences only, the factor s is collected in `hscale`
-// and applied once at the end of the pass (linear, so it commutes with everything that follows)
-#define DQ_HAD_CASE(ID)                                                                     \
-    case ID: {                                                                              \
-        const uint64_t mh[4] = {0xC0000000C0000000ull, mq[1], mq[2], mq[3]}; /* (-2.0f, -2.0f) */ \
-        gen1_block_f32<3, (ID) % 4>(a, mh);                                                 \
-        hscale *= __uint_as_float(mqv[0]);                                                  \
-        had = true;                                                                         \
-        break;                                                                              \
-    }
-                        if (fast < 32u) {
-                            switch (fast) {
-                                DQ_GEN1_CASES
-                                DQ_HAD_CASE(12) DQ_HAD_CASE(13) DQ_HAD_CASE(14) DQ_HAD_CASE(15)
-                                case 16: x1_block_f32<0, 0>(a); break;
-                                case 17: x1_block_f32<1, 0>(a); break;
-                                case 18: x1_block_f32<2, 0>(a); break;
-                                default: x1_block_f32<3, 0>(a); break;
-                            }
-                            continue;
-                        }
-                        if ((tile_global & out_cmask) != out_cmask) continue;  // uniform: an outside control is 0
-                        if ((tbase & thr_cmask) == thr_cmask) {
-                            switch (fast - 32u) {
-                                DQ_GEN1_CASES
-                                case 16: dispatch_x1_block_f32<0>(a, reg_cmask); break;
-                                case 17: dispatch_x1_block_f32<1>(a, reg_cmask); break;
-                                case 18: dispatch_x1_block_f32<2>(a, reg_cmask); break;
-                                default: dispatch_x1_block_f32<3>(a, reg_cmask); break;
-                            }
-                        }
-#undef DQ_HAD_CASE
-#undef DQ_GEN1_CASES
-#undef DQ_GEN1_CASE
+                        fast_dispatch_f32(a, mq, mqv[0], fast, g1, out_cmask, tile_global, tbase, hscale);
                     } else {
                         const double md[8] = {__longlong_as_double((long long)DQ_PAIR(0)), __longlong_as_double((long long)DQ_PAIR(1)),
                                               __longlong_as_double((long long)DQ_PAIR(2)), __longlong_as_double((long long)DQ_PAIR(3)),
@@ -595,7 +565,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         had = true;                                                      \
         break;                                                           \
     }
-                        if (fast < 32u) {
+                        if (fast < 20u) {
                             switch (fast) {
                                 DQ_GEN1_CASES
                                 DQ_HAD_CASE(12) DQ_HAD_CASE(13) DQ_HAD_CASE(14)
@@ -607,11 +577,15 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
                         }
                         if ((tile_global & out_cmask) != out_cmask) continue;
                         if ((tbase & thr_cmask) == thr_cmask) {
-                            switch (fast - 32u) {
-                                DQ_GEN1_CASES
-                                case 16: dispatch_x1_block_f64<0>(a, reg_cmask); break;
-                                case 17: dispatch_x1_block_f64<1>(a, reg_cmask); break;
-                                default: dispatch_x1_block_f64<2>(a, reg_cmask); break;
+                            if (fast < 32u) {
+                                switch (fast - 20u) { DQ_GEN1_CASES default: break; }
+                            } else {   // X: 32 + slot (no register control) or 36 + 4 * slot + control slot
+                                const unsigned xq = fast < 36u ? fast - 32u : (fast - 36u) >> 2;
+                                switch (xq) {
+                                    case 0: dispatch_x1_block_f64<0>(a, reg_cmask); break;
+                                    case 1: dispatch_x1_block_f64<1>(a, reg_cmask); break;
+                                    default: dispatch_x1_block_f64<2>(a, reg_cmask); break;
+                                }
                             }
                         }
 #undef DQ_HAD_CASE
@@ -669,7 +643,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
     }
 
-    if (had) {
+    if (had || FAST32) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             a[j].x *= hscale;
@@ -823,9 +797,12 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
             if (g.fast != DQ_FAST_NONE) {
                 const bool free_ = g.reg_cmask == 0 && g.thr_cmask == 0 && g.out_cmask == 0;
                 uint32_t want = DQ_FAST_NONE;
-                if (g.kind == DQ_FG_X1) want = (free_ ? 16u : 48u) + g.q;
-                else if (g.kind == DQ_FG_GEN1 && g.reg_cmask == 0)
-                    want = free_ ? 4u * g.loc + g.q : 32u + 4u * (g.loc == DQ_MODE_HAD ? (unsigned)DQ_MODE_REAL : g.loc) + g.q;
+                if (g.kind == DQ_FG_X1) {
+                    if (g.reg_cmask == 0) want = (free_ ? 16u : 32u) + g.q;
+                    else if ((g.reg_cmask & (g.reg_cmask - 1)) == 0) want = 36u + 4u * g.q + (unsigned)__builtin_ctz(g.reg_cmask);
+                } else if (g.kind == DQ_FG_GEN1 && g.reg_cmask == 0) {
+                    want = free_ ? 4u * g.loc + g.q : 20u + 4u * (g.loc == DQ_MODE_HAD ? (unsigned)DQ_MODE_REAL : g.loc) + g.q;
+                }
                 if (g.fast != want) {
                     set_error("dq_apply_fused: gate %d has fast-handler id %u, expected %u", gi, g.fast, want);
                     return DQ_ERR_ARG;

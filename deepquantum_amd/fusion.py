@@ -580,14 +580,25 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         g.loc = op.mode if op.kind == 'gen' else 0
         # straight-line handler id (one flat switch in the kernel): see include/dq_hip.h
         free = reg_c == 0 and thr_c == 0 and out_c == 0
-        if op.kind == 'x':
-            g.fast = (16 if free else 48) + slots[0]
-        elif reg_c == 0:
-            g.fast = 4 * g.loc + slots[0] if free else 32 + 4 * (1 if g.loc == 3 else g.loc) + slots[0]
+        g.fast = fast_id(g.kind, g.loc, slots[0], reg_c, thr_c, out_c)
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots
         g.loc = 1 if op.mode == 1 else 0      # promised real (and usually sparse): channel superoperators
+
+
+def fast_id(kind: int, mode: int, slot: int, reg_c: int, thr_c: int, out_c: int) -> int:
+    """Index of the kernel's straight-line handler for a one-target gate (include/dq_hip.h, DqFusedGate::fast)."""
+    free = reg_c == 0 and thr_c == 0 and out_c == 0
+    if kind == _lib.FG_X1:
+        if reg_c == 0:
+            return (16 if free else 32) + slot
+        if reg_c & (reg_c - 1) == 0:
+            return 36 + 4 * slot + reg_c.bit_length() - 1
+        return _lib.FAST_NONE
+    if kind == _lib.FG_GEN1 and reg_c == 0:
+        return 4 * mode + slot if free else 20 + 4 * (1 if mode == 3 else mode) + slot
+    return _lib.FAST_NONE
 
 
 def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], int]:

@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 9
+#define DQ_ABI_VERSION 10
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -109,12 +109,15 @@ typedef struct {
     uint8_t reg_cmask;  /* controls that are register slots (bit s = slot s) */
     uint16_t thr_cmask; /* controls that are thread bits (tile-local bit positions) */
     uint32_t mat;       /* offset (in complex numbers) of this gate's matrix inside `mats` */
-    uint32_t fast;      /* GEN1 / X1 straight-line handler, or DQ_FAST_NONE:
+    uint32_t fast;      /* GEN1 / X1 straight-line handler (index of the kernel's jump table), or DQ_FAST_NONE:
                              0..15  2x2 gate, id = mode * 4 + slot, no control of any kind
                             16..19  X on slot id - 16, no control of any kind
-                            32..43  2x2 gate, id - 32 = mode * 4 + slot (HAD counts as REAL), thread / outside
-                                    controls only
-                            48..51  X on slot id - 48 with any controls (CNOT, Toffoli ...) */
+                            20..31  2x2 gate, id - 20 = mode * 4 + slot (GENERAL / REAL / RX; HAD counts as REAL),
+                                    thread / outside controls only
+                            32..35  X on slot id - 32, thread / outside controls only
+                            36..51  X on slot q with ONE register-slot control c (plus any thread / outside
+                                    controls): id = 36 + 4 * q + c, c != q  (CNOT with both bits in registers)
+                           anything else (register-controlled 2x2 gates, X with two register controls, ...): NONE */
     uint64_t out_cmask; /* controls outside the tile (global bit positions) */
     uint32_t mat_advance; /* complex numbers this gate occupies in `mats` (0 for X1): the matrices of a pass
                              lie back to back in gate order, mat(i+1) = mat(i) + mat_advance(i), so the kernel
@@ -122,6 +125,7 @@ typedef struct {
     uint32_t reserved;  /* pads the record to 32 bytes: one s_load_dwordx8 per gate */
 } DqFusedGate;          /* 32 bytes */
 #define DQ_FAST_NONE 0xFFFFFFFFu
+#define DQ_FAST_IDS 52   /* handler ids are < DQ_FAST_IDS */
 /* `mats` must be readable for DQ_MAT_PAD complex numbers past the last matrix of a pass (prefetch). */
 #define DQ_MAT_PAD 16
 

@@ -130,13 +130,16 @@ class CpuTestBackend:
                     if g.kind in (_lib.FG_GEN1, _lib.FG_X1):
                         tbit = rb[g.q]
                         assert not (cm >> tbit) & 1
+                        # restated from include/dq_hip.h (DqFusedGate::fast), independently of fusion.fast_id
                         free = g.reg_cmask == 0 and g.thr_cmask == 0 and g.out_cmask == 0
+                        want = _lib.FAST_NONE
                         if g.kind == _lib.FG_X1:
-                            want = (16 if free else 48) + g.q
+                            if g.reg_cmask == 0:
+                                want = (16 if free else 32) + g.q
+                            elif bin(g.reg_cmask).count('1') == 1:
+                                want = 36 + 4 * g.q + [1, 2, 4, 8].index(g.reg_cmask)
                         elif g.reg_cmask == 0:
-                            want = 4 * g.loc + g.q if free else 32 + 4 * (1 if g.loc == 3 else g.loc) + g.q
-                        else:
-                            want = _lib.FAST_NONE
+                            want = 4 * g.loc + g.q if free else 20 + 4 * (1 if g.loc == 3 else g.loc) + g.q
                         assert g.fast == want, 'fast-handler id wrong'
                         mat = mb[g.mat : g.mat + 4].reshape(2, 2)
                         if g.kind == _lib.FG_GEN1 and g.loc == 1:
