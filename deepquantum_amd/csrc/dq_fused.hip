@@ -553,44 +553,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
                                               __longlong_as_double((long long)DQ_PAIR(2)), __longlong_as_double((long long)DQ_PAIR(3)),
                                               __longlong_as_double((long long)DQ_PAIR(4)), __longlong_as_double((long long)DQ_PAIR(5)),
                                               __longlong_as_double((long long)DQ_PAIR(6)), __longlong_as_double((long long)DQ_PAIR(7))};
-#define DQ_GEN1_CASE(ID) case ID: gen1_block_f64<(ID) / 4, (ID) % 4>(a, md); break;
-#define DQ_GEN1_CASES                                                                           \
-    DQ_GEN1_CASE(0) DQ_GEN1_CASE(1) DQ_GEN1_CASE(2) DQ_GEN1_CASE(4) DQ_GEN1_CASE(5) DQ_GEN1_CASE(6) \
-    DQ_GEN1_CASE(8) DQ_GEN1_CASE(9) DQ_GEN1_CASE(10)
-#define DQ_HAD_CASE(ID)                                                  \
-    case ID: {                                                           \
-        const double mh[8] = {-2.0, md[1], md[2], md[3], md[4], md[5], md[6], md[7]}; \
-        gen1_block_f64<3, (ID) % 4>(a, mh);                              \
-        hscale *= md[0];                                                 \
-        had = true;                                                      \
-        break;                                                           \
-    }
-                        if (fast < 20u) {
-                            switch (fast) {
-                                DQ_GEN1_CASES
-                                DQ_HAD_CASE(12) DQ_HAD_CASE(13) DQ_HAD_CASE(14)
-                                case 16: x1_block_f64<0, 0>(a); break;
-                                case 17: x1_block_f64<1, 0>(a); break;
-                                default: x1_block_f64<2, 0>(a); break;
-                            }
-                            continue;
-                        }
-                        if ((tile_global & out_cmask) != out_cmask) continue;
-                        if ((tbase & thr_cmask) == thr_cmask) {
-                            if (fast < 32u) {
-                                switch (fast - 20u) { DQ_GEN1_CASES default: break; }
-                            } else {   // X: 32 + slot (no register control) or 36 + 4 * slot + control slot
-                                const unsigned xq = fast < 36u ? fast - 32u : (fast - 36u) >> 2;
-                                switch (xq) {
-                                    case 0: dispatch_x1_block_f64<0>(a, reg_cmask); break;
-                                    case 1: dispatch_x1_block_f64<1>(a, reg_cmask); break;
-                                    default: dispatch_x1_block_f64<2>(a, reg_cmask); break;
-                                }
-                            }
-                        }
-#undef DQ_HAD_CASE
-#undef DQ_GEN1_CASES
-#undef DQ_GEN1_CASE
+                        fast_dispatch_f64(a, md, fast, g1, out_cmask, tile_global, tbase, hscale);
                     }
 #undef DQ_PAIR
                     continue;
@@ -643,7 +606,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
     }
 
-    if (had || FAST32) {
+    if (had || FAST) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             a[j].x *= hscale;
