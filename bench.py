@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument('--plan-width', type=int, default=None,
                     help='pass planner beam width (0 = first-come tiles, 1 = greedy; default: library)')
     ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
+    ap.add_argument('--no-asm-loop', action='store_true', help='A/B: gate loop in C++ around the jump table')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
     return ap.parse_args()
 
@@ -215,6 +216,8 @@ def main():
     dq.executor.CONFIG['far_bit'] = args.far_bit
     dq.executor.CONFIG['plan_width'] = args.plan_width
     dq.executor.CONFIG['plan_branch'] = args.plan_branch
+    if args.no_asm_loop:
+        dq.executor.CONFIG['asm_loop'] = False
 
     n = args.nqubit + (int(math.log2(world)) if distributed else 0)
     spec = random_circuit_spec(n, args.depth, args.seed)

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
@@ -26,6 +26,7 @@ FUSED_MAX_ROUNDS = 24
 FUSED_MAX_GATES = 80
 FUSED_MAX_SLOTS = 4
 FUSED_MAX_TBITS = 10
+ROUND_ALL_FAST = 0x80
 FAST_NONE = 0xFFFFFFFF
 MAT_PAD = 16
 

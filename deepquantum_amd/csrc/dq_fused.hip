@@ -512,7 +512,14 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             ntbase |= ((tid >> i) & 1u) << ((w >> (8 * (i & 3))) & 0xffu);
         }
         if (!same || ntbase != tbase) transpose_to(nrb, ntbase, 1 + r);
-        const int gbeg = (int)((rw3 >> 16) & 0xffu), gend = (int)(rw3 >> 24);
+        const int gbeg = (int)((rw3 >> 16) & 0x7fu), gend = (int)(rw3 >> 24);
+        if constexpr (FAST32) {
+            if (rw3 & (DQ_ROUND_ALL_FAST << 16)) {   // the whole gate loop of the round in assembly (dq_fused_asm.inc)
+                uint32_t goff = 32u * (unsigned)gbeg;
+                fast_gate_loop_f32(a, kgates, goff, 32u * (unsigned)gend, mbase_u, moff, tile_global, tbase, hscale);
+                continue;
+            }
+        }
         // byte offsets of the round's gate records from `kgates`; the loop runs on the offset (one add, one compare)
         const uint32_t goff_end = 32u * (unsigned)gend;
         for (uint32_t goff = 32u * (unsigned)gbeg; goff < goff_end; goff += 32u) {
@@ -732,17 +739,23 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
             }
             used |= 1u << rd.tb[i];
         }
-        if (rd.gate_begin > rd.gate_end || rd.gate_end > DQ_FUSED_MAX_GATES) {
+        const int gate_begin = rd.gate_begin & 0x7f;
+        const bool all_fast = (rd.gate_begin & DQ_ROUND_ALL_FAST) != 0;
+        if (gate_begin > rd.gate_end || rd.gate_end > DQ_FUSED_MAX_GATES || (all_fast && gate_begin == rd.gate_end)) {
             set_error("dq_apply_fused: round %d gate range invalid", r);
             return DQ_ERR_ARG;
         }
-        if (rd.gate_begin != next_gate) {
+        if (gate_begin != next_gate) {
             set_error("dq_apply_fused: round %d does not continue the gate list", r);
             return DQ_ERR_ARG;
         }
         next_gate = rd.gate_end;
-        for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
+        for (int gi = gate_begin; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
+            if (all_fast && g.fast == DQ_FAST_NONE) {
+                set_error("dq_apply_fused: round %d is marked all-fast but gate %d has no handler id", r, gi);
+                return DQ_ERR_ARG;
+            }
             const bool slot_kind = g.kind == DQ_FG_GEN1 || g.kind == DQ_FG_X1 || g.kind == DQ_FG_GEN2;
             if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 3) || (g.kind == DQ_FG_GEN2 && g.loc > 1)) ||
                 (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {

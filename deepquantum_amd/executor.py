@@ -52,7 +52,7 @@ _PLAN_CACHE_SIZE = 64
 CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
           'max_gates': None, 'max_far': None, 'far_bit': None,
           # pass planner (fusion._plan_tiles): beam width / tiles tried per state; 0 = first-come tiles, 1 = greedy
-          'plan_width': None, 'plan_branch': None,
+          'plan_width': None, 'plan_branch': None, 'asm_loop': None,
           # 'adjoint': fused forward + reverse sweep with recomputation (O(1) states of memory);
           # 'per_gate': one autograd node per gate (saves every intermediate state; supports double backward)
           'grad_mode': 'adjoint',
@@ -83,13 +83,17 @@ def _geometry(is128: bool) -> fusion.Geometry:
         g.plan_width = CONFIG['plan_width']
     if CONFIG['plan_branch'] is not None:
         g.plan_branch = CONFIG['plan_branch']
+    if CONFIG['asm_loop'] is not None:
+        g.asm_loop = CONFIG['asm_loop']
+        if g.fallback is not None:
+            g.fallback.asm_loop = CONFIG['asm_loop']
     return g
 
 
 def make_plan(prims: Sequence[Prim], n: int, is128: bool) -> Plan:
     geom = _geometry(is128)
     key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
-           geom.plan_branch, CONFIG['fuse'],
+           geom.plan_branch, geom.asm_loop, CONFIG['fuse'],
            tuple((p.kind, p.targets, p.controls, p.mode) for p in prims))
     plan = _PLAN_CACHE.get(key)
     if plan is not None:

@@ -65,6 +65,7 @@ class Geometry:
     fallback: 'Geometry | None' = None   # smaller (faster per byte) tile for passes that do not need all gathered bits
     plan_width: int = 4       # gathered bits of every pass from dry runs of the pass (_plan_tiles): beam width
     plan_branch: int = 3      # ... and tiles tried per beam state; plan_width = 0: first-come tiles (no dry runs)
+    asm_loop: bool = True     # mark rounds whose gates all have handler ids (DQ_ROUND_ALL_FAST); off: A/B measurements
     plan_min_bits: int = 20   # states below 2^plan_min_bits amplitudes: greedy (width 1) -- planning time matters there
     far_bit: int = 19         # index bits >= far_bit are "far": every one gathered doubles the number of
     max_far: int | None = None  # distant address streams of a tile; None = no limit (tools/sweep_tile_bits*.py)
@@ -514,11 +515,13 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         for i, t in enumerate(lay[1]):
             r.tb[i] = t
         fill_table(1 + ri, lay[0])
-        r.gate_begin = gi
+        first = gi
         for oi in rd.ops:
             _encode_gate(desc.gates[gi], ops[oi], local, slot_of, tile)
             exec_order.append(oi)
             gi += 1
+        all_fast = all(desc.gates[k].fast != _lib.FAST_NONE for k in range(first, gi))
+        r.gate_begin = first | (_lib.ROUND_ALL_FAST if all_fast and geom.asm_loop else 0)
         r.gate_end = gi
     if cur != (tuple(store_rb), tuple(ascending_tb(store_rb))):
         ntrans += 1

@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 10
+#define DQ_ABI_VERSION 11
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -134,8 +134,11 @@ typedef struct {
     uint8_t rb[DQ_FUSED_MAX_SLOTS]; /* tile-local bit positions of the register slots, ascending */
     uint8_t tb[DQ_FUSED_MAX_TBITS]; /* tile-local bit position of thread-index bit i (the other m - slots
                                        tile bits, in an order the host picks to avoid LDS bank conflicts) */
-    uint8_t gate_begin, gate_end;   /* [begin, end) into gates[] */
+    uint8_t gate_begin, gate_end;   /* [begin & 0x7f, end) into gates[]; DQ_ROUND_ALL_FAST in gate_begin promises
+                                       that every gate of the round has a handler id (fast != DQ_FAST_NONE): the
+                                       kernel then runs the round's gate loop without leaving its assembly block */
 } DqFusedRound;                     /* 16 bytes */
+#define DQ_ROUND_ALL_FAST 0x80u
 
 typedef struct {
     uint8_t m, L, h, nrounds;

@@ -113,7 +113,11 @@ class CpuTestBackend:
                 assert rb == sorted(set(rb)) and all(q < m for q in rb)
                 assert sorted(rb + tb) == list(range(m)), 'slots + thread bits must cover the tile exactly'
                 slotmask = sum(1 << q for q in rb)
-                for gi in range(rd.gate_begin, rd.gate_end):
+                first = rd.gate_begin & 0x7F
+                if rd.gate_begin & _lib.ROUND_ALL_FAST:
+                    assert all(desc.gates[k].fast != _lib.FAST_NONE for k in range(first, rd.gate_end)), \
+                        'round promises handler ids for all gates'
+                for gi in range(first, rd.gate_end):
                     g = desc.gates[gi]
                     assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
                     assert (g.reg_cmask >> R) == 0
