@@ -363,7 +363,14 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     constexpr int NA = 1 << R;
     constexpr int VB = (sizeof(T) == 4) ? 1 : 0;  // low slots of the canonical layout (16 B per lane)
     using V = amp<T>;
+    // The tile buffer is the kernel's only LDS (dynamic, no static LDS anywhere in this file), so it starts at LDS
+    // address 0: forming the pointer from the byte offset alone saves the "+ base" VALU add the compiler would emit
+    // per access for a relocatable symbol.  `dq_smem` stays declared so the launch's dynamic size has an owner.
     extern __shared__ __attribute__((aligned(16))) unsigned char dq_smem[];
+    auto lds_at = [](unsigned byte_off) __attribute__((always_inline)) {
+        return (__attribute__((address_space(3))) V*)(uintptr_t)byte_off;
+    };
+    (void)dq_smem;
 
     const unsigned tid = threadIdx.x;
     const uint32_t* hw = reinterpret_cast<const uint32_t*>(&p);
@@ -463,10 +470,10 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         const unsigned vw = lds_swz<sizeof(V)>(tbase) * (unsigned)sizeof(V);
         const unsigned vr = lds_swz<sizeof(V)>(ntbase) * (unsigned)sizeof(V);
 #pragma unroll
-        for (int j = 0; j < NA; ++j) *reinterpret_cast<V*>(dq_smem + (vw ^ tab_entry(ctab, j))) = a[j];
+        for (int j = 0; j < NA; ++j) *lds_at(vw ^ tab_entry(ctab, j)) = a[j];
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NA; ++j) a[j] = *reinterpret_cast<const V*>(dq_smem + (vr ^ tab_entry(ntab, j)));
+        for (int j = 0; j < NA; ++j) a[j] = *lds_at(vr ^ tab_entry(ntab, j));
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < R; ++s) rb[s] = nrb[s];
