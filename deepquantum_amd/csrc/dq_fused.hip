@@ -520,10 +520,13 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
         if (!same || ntbase != tbase) transpose_to(nrb, ntbase, 1 + r);
         const int gbeg = (int)((rw3 >> 16) & 0x7fu), gend = (int)(rw3 >> 24);
-        if constexpr (FAST32) {
+        if constexpr (FAST) {
             if (rw3 & (DQ_ROUND_ALL_FAST << 16)) {   // the whole gate loop of the round in assembly (dq_fused_asm.inc)
                 uint32_t goff = 32u * (unsigned)gbeg;
-                fast_gate_loop_f32(a, kgates, goff, 32u * (unsigned)gend, mbase_u, moff, tile_global, tbase, hscale);
+                if constexpr (FAST32)
+                    fast_gate_loop_f32(a, kgates, goff, 32u * (unsigned)gend, mbase_u, moff, tile_global, tbase, hscale);
+                else
+                    fast_gate_loop_f64(a, kgates, goff, 32u * (unsigned)gend, mbase_u, moff, tile_global, tbase, hscale);
                 continue;
             }
         }
