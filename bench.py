@@ -61,6 +61,8 @@ def parse_args():
                     help='pass planner beam width (0 = first-come tiles, 1 = greedy; default: library)')
     ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
     ap.add_argument('--no-asm-loop', action='store_true', help='A/B: gate loop in C++ around the jump table')
+    ap.add_argument('--no-merge', action='store_true',
+                    help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
     return ap.parse_args()
 
@@ -218,6 +220,8 @@ def main():
     dq.executor.CONFIG['plan_branch'] = args.plan_branch
     if args.no_asm_loop:
         dq.executor.CONFIG['asm_loop'] = False
+    if args.no_merge:
+        dq.executor.CONFIG['merge_min_amps'] = None
 
     n = args.nqubit + (int(math.log2(world)) if distributed else 0)
     spec = random_circuit_spec(n, args.depth, args.seed)
@@ -314,6 +318,9 @@ def main():
                                 else 'single GPU'),
                 'fused_passes_per_step': stats.get('passes'),
                 'lds_round_trips_per_step': stats.get('transposes'),
+                # 2x2 matrices the kernel applies per sample after runs of one-qubit gates on the same qubit were
+                # multiplied together (executor.merge_one_qubit_runs; `--no-merge` applies all `ngates` one by one)
+                'kernel_gates_per_step': stats.get('gates'),
             },
             'roofline': {
                 'bound': 'hbm',

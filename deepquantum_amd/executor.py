@@ -57,7 +57,10 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
           # 'per_gate': one autograd node per gate (saves every intermediate state; supports double backward)
           'grad_mode': 'adjoint',
           # states smaller than a tile: fuse (batch folded into the index, or zero-padded) from this many gates on
-          'small_fuse_min_gates': 6}
+          'small_fuse_min_gates': 6,
+          # no-grad runs on states of at least this many amplitudes (batch included) multiply runs of one-qubit gates
+          # on the same qubit into one matrix before planning (merge_one_qubit_runs); None = never
+          'merge_min_amps': 1 << 24}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates) to report the kernel's average duration next to its algorithmic bytes.
@@ -166,7 +169,91 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> to
         for p in prims:
             x = ops.apply_gate(x, p.matrix, p.targets, p.controls)
         return x
+    if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']
+            and not ops._is_batched(state)):
+        prims = merge_one_qubit_runs(prims)
     return _run_nograd(state, prims, inplace)
+
+
+_MERGE_COST = {3: 30, 2: 45, 1: 45, 0: 79}    # issue slots of a wave per one-qubit gate, by matrix structure
+
+
+def merge_one_qubit_runs(prims: Sequence[Prim]) -> list[Prim]:
+    """Multiply runs of uncontrolled one-qubit gates on the same qubit into one 2x2 matrix (what qsim / Aer call
+    gate fusion, at its smallest): gates with nothing else on the qubit in between, and -- because functions of X
+    commute -- all Rx-like gates of a stretch in which the qubit only sees X-type actions (CNOT targets, X).  A
+    merge happens only when the product is cheaper for the kernel than its factors (two Hadamards -> one real
+    matrix, two Rx -> one Rx-like matrix, anything into a general matrix; NOT Hadamard + Rx -> general).  The
+    product matrix is always applied, also when it is (numerically almost) the identity.  The matrices of all
+    groups are multiplied level by level in stacked matmuls: a handful of launches whatever the circuit."""
+    groups: list[list] = []            # [members (prim indices, in order of application), mode]
+    order: list[tuple[str, int]] = []  # ('g', group) | ('p', prim)
+    last: dict[int, int] = {}          # qubit -> open group
+    nothing: dict[int, bool] = {}      # no gate has touched the qubit since the group's last member
+    only_x: dict[int, bool] = {}       # ... only X-type actions have
+    for i, p in enumerate(prims):
+        if p.kind == 'gen' and len(p.targets) == 1 and not p.controls and p.unitary:
+            q = p.targets[0]
+            g = last.get(q)
+            if g is not None:
+                mode = groups[g][1]
+                if nothing[q] or (only_x[q] and mode == 2 and p.mode == 2):
+                    new = 2 if (mode == 2 and p.mode == 2) else 1 if (mode in (1, 3) and p.mode in (1, 3)) else 0
+                    if _MERGE_COST[new] <= _MERGE_COST[mode] + _MERGE_COST[p.mode] - 5:
+                        groups[g][0].append(i)
+                        groups[g][1] = new
+                        continue
+            groups.append([[i], p.mode])
+            order.append(('g', len(groups) - 1))
+            last[q], nothing[q], only_x[q] = len(groups) - 1, True, True
+            continue
+        order.append(('p', i))
+        x_target = p.kind == 'x' or (p.kind == 'gen' and len(p.targets) == 1 and p.mode == 2)
+        for q in p.controls:
+            last.pop(q, None)
+        for q in p.targets:
+            if x_target and q in last:
+                nothing[q] = False
+            else:
+                last.pop(q, None)
+    if all(len(g[0]) == 1 for g in groups):
+        return list(prims)
+    multi = [g for g in groups if len(g[0]) > 1]
+    bm = max(prims[i].matrix.shape[0] if prims[i].matrix.ndim == 3 else 1 for g in multi for i in g[0])
+
+    def mat(i: int) -> torch.Tensor:
+        m = prims[i].matrix
+        return (m if m.ndim == 3 else m.unsqueeze(0)).expand(bm, 2, 2)
+
+    acc = torch.stack([mat(g[0][0]) for g in multi])                    # (G, bm, 2, 2)
+    live = list(range(len(multi)))
+    level = 1
+    while live:
+        live = [k for k in live if len(multi[k][0]) > level]
+        if not live:
+            break
+        nxt = torch.stack([mat(multi[k][0][level]) for k in live])
+        prod = torch.matmul(nxt, acc[live] if len(live) < len(multi) else acc)   # the later gate multiplies from the left
+        if len(live) < len(multi):
+            acc = acc.index_copy(0, torch.tensor(live, device=acc.device), prod)
+        else:
+            acc = prod
+        level += 1
+    def batched(g) -> bool:
+        return any(prims[i].matrix.ndim == 3 and prims[i].matrix.shape[0] > 1 for i in g[0])
+
+    merged = {id(g): acc[k] if batched(g) else acc[k, 0] for k, g in enumerate(multi)}
+    out: list[Prim] = []
+    for kind, idx in order:
+        if kind == 'p':
+            out.append(prims[idx])
+        else:
+            g = groups[idx]
+            if len(g[0]) == 1:
+                out.append(prims[g[0][0]])
+            else:
+                out.append(Prim('gen', merged[id(g)], prims[g[0][0]].targets, (), g[1]))
+    return out
 
 
 def _run_small(state: torch.Tensor, prims: Sequence[Prim], n: int, m: int) -> torch.Tensor | None:

@@ -66,6 +66,8 @@ class Geometry:
     plan_width: int = 4       # gathered bits of every pass from dry runs of the pass (_plan_tiles): beam width
     plan_branch: int = 3      # ... and tiles tried per beam state; plan_width = 0: first-come tiles (no dry runs)
     asm_loop: bool = True     # mark rounds whose gates all have handler ids (DQ_ROUND_ALL_FAST); off: A/B measurements
+    plan_restarts: int = 3    # beam searches with different random branches (states of >= 2^plan_restart_bits amplitudes)
+    plan_restart_bits: int = 26
     plan_min_bits: int = 20   # states below 2^plan_min_bits amplitudes: greedy (width 1) -- planning time matters there
     far_bit: int = 19         # index bits >= far_bit are "far": every one gathered doubles the number of
     max_far: int | None = None  # distant address streams of a tile; None = no limit (tools/sweep_tile_bits*.py)
@@ -222,14 +224,15 @@ def _grow_tile(dag: '_Dag', low: set[int], hcap: int, cap: int, indeg: list[int]
     return chosen
 
 
-def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, branch: int) -> list[set[int] | None]:
+def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, branch: int,
+                seed: int = 20250929) -> list[set[int] | None]:
     """Gathered-bit sets for ALL passes of a circuit by beam search over dry runs (`_closure`): every beam state
     (a front of the DAG) is extended by the greedy tile and by ``branch - 1`` randomised ones (one of the three best
     candidates at each growth step, fixed seed), the ``width`` states that have retired the most gates survive.
     ``None`` entries stand for a gate that cannot be fused and runs on its own.  width = 1: plain greedy."""
     import random
 
-    rng = random.Random(20250929)
+    rng = random.Random(seed)
 
     def jitter(ranked):
         return ranked[rng.randrange(min(3, len(ranked)))]
@@ -302,7 +305,10 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int) -> list
     steps: list[FusedStep | SingleStep] = []
     low = set(range(geom.min_low))
     hcap = geom.m - geom.min_low
-    planned = _plan_tiles(dag, low, hcap, geom.max_gates, width, geom.plan_branch) if width else []
+    # the randomised branches make the pass count vary by one or two: on big states a few restarts are worth it
+    restarts = geom.plan_restarts if width > 1 and n >= geom.plan_restart_bits else 1
+    planned = min((_plan_tiles(dag, low, hcap, geom.max_gates, width, geom.plan_branch, 20250929 + r)
+                   for r in range(restarts)), key=len) if width else []
     planned.reverse()                   # consumed from the end
     while dag.done < dag.n_ops:
         high: set[int] = set()          # tile bits beyond the guaranteed low ones

@@ -164,3 +164,62 @@ def test_planned_tiles_need_fewer_passes_and_keep_the_result(cpu_backend):
     s4, p4 = run(4)
     assert p4 <= p1 <= p0 and p4 < p0, (p0, p1, p4)
     assert torch.allclose(s0, s1, atol=1e-5) and torch.allclose(s0, s4, atol=1e-5)
+
+
+def test_one_qubit_runs_are_merged_and_the_state_is_unchanged(cpu_backend):
+    """executor.merge_one_qubit_runs: which gates merge (by structure and commutation), and that a circuit gives the
+    same state with and without merging (per-sample angles included)."""
+    from deepquantum_amd.executor import Prim, merge_one_qubit_runs
+    h = torch.tensor([[1, 1], [1, -1]], dtype=torch.cfloat) / 2 ** 0.5
+    x = torch.tensor([[0, 1], [1, 0]], dtype=torch.cfloat)
+
+    def rx(t):
+        t = torch.as_tensor(t, dtype=torch.float)
+        c, s_ = torch.cos(t / 2) + 0j, -1j * torch.sin(t / 2)
+        return torch.stack([torch.stack([c, s_], -1), torch.stack([s_, c], -1)], -2)
+
+    P = lambda m, q, mode: Prim('gen', m, (q,), (), mode)           # noqa: E731
+    cx = lambda c, t: Prim('x', x, (t,), (c,), 0)                   # noqa: E731
+    prims = [P(h, 0, 3), P(h, 0, 3),                                 # H H          -> one real matrix
+             P(rx(0.3), 1, 2), cx(2, 1), P(rx([0.1, 0.2]), 1, 2),    # Rx . CX-target . Rx (batched) -> one Rx-like
+             P(h, 2, 3), P(rx(0.5), 2, 2),                           # H Rx         -> stays two gates
+             P(rx(0.4), 0, 2), cx(0, 1), P(rx(0.6), 0, 2)]           # Rx . control . Rx -> stays (Z-type in between)
+    out = merge_one_qubit_runs(prims)
+    kinds = [(p.kind, p.targets, p.mode, tuple(p.matrix.shape)) for p in out]
+    assert kinds == [('gen', (0,), 0, (2, 2)),          # (H H) then Rx(0.4) on qubit 0: nothing in between -> general
+                     ('gen', (1,), 2, (2, 2, 2)), ('x', (1,), 0, (2, 2)),
+                     ('gen', (2,), 3, (2, 2)), ('gen', (2,), 2, (2, 2)),
+                     ('x', (1,), 0, (2, 2)), ('gen', (0,), 2, (2, 2))]
+    assert torch.allclose(out[0].matrix, rx(0.4) @ h @ h, atol=1e-6)
+    assert torch.allclose(out[1].matrix, rx([0.1, 0.2]) @ rx(0.3), atol=1e-6)
+    assert bool((out[1].matrix[..., 0, 0].imag == 0).all()) and bool((out[1].matrix[..., 0, 1].real == 0).all())
+
+    import random
+    n, rng = 13, random.Random(11)
+    cir = dq.QubitCircuit(n)
+    for _ in range(8):
+        for q in range(n):
+            r = rng.random()
+            if r < 0.4:
+                cir.h(q)
+            elif r < 0.75:
+                cir.rx(q, encode=True)
+            elif r < 0.85:
+                cir.ry(q, inputs=rng.uniform(0, 6))
+            else:
+                t = rng.randrange(n - 1)
+                cir.cnot(q, t + (t >= q))
+    data = torch.rand(3, cir.ndata) * 6.28
+    keep = dq.executor.CONFIG['merge_min_amps']
+    try:
+        with torch.no_grad():
+            dq.executor.CONFIG['merge_min_amps'] = None
+            ref = cir(data).clone()
+            plain = dq.executor.LAST_RUN['gates']
+            dq.executor.CONFIG['merge_min_amps'] = 0
+            got = cir(data).clone()
+            merged = dq.executor.LAST_RUN['gates']
+    finally:
+        dq.executor.CONFIG['merge_min_amps'] = keep
+    assert merged < plain
+    assert torch.allclose(got, ref, atol=2e-6)
