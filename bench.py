@@ -279,6 +279,19 @@ def main():
         traffic = json.load(open(tj)).get('hbm_bytes_per_launch')
     stats = dict(dq.executor.LAST_RUN)
     z0 = float(out.reshape(-1)[0]) if out is not None else None
+    # the same circuit with every gate applied on its own (no products of one-qubit runs), for comparison: N = 1 only
+    unmerged_ms = None
+    if not multi and not args.no_merge and dq.executor.CONFIG['merge_min_amps'] is not None:
+        keep = dq.executor.CONFIG['merge_min_amps']
+        dq.executor.CONFIG['merge_min_amps'] = None
+        step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(min(args.steps, 2)):
+            step()
+        sync()
+        unmerged_ms = (time.perf_counter() - t0) / min(args.steps, 2) * 1e3
+        dq.executor.CONFIG['merge_min_amps'] = keep
     copy_gbs = device_copy_bandwidth(device) if rank == 0 else None
     single_gbs = None
     if rank == 0 and not distributed and n >= 12:
@@ -321,6 +334,7 @@ def main():
                 # 2x2 matrices the kernel applies per sample after runs of one-qubit gates on the same qubit were
                 # multiplied together (executor.merge_one_qubit_runs; `--no-merge` applies all `ngates` one by one)
                 'kernel_gates_per_step': stats.get('gates'),
+                'unmerged_ms_per_step': unmerged_ms,
             },
             'roofline': {
                 'bound': 'hbm',

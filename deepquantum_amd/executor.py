@@ -60,7 +60,7 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
           'small_fuse_min_gates': 6,
           # no-grad runs on states of at least this many amplitudes (batch included) multiply runs of one-qubit gates
           # on the same qubit into one matrix before planning (merge_one_qubit_runs); None = never
-          'merge_min_amps': 1 << 24}
+          'merge_min_amps': 1 << 27}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates) to report the kernel's average duration next to its algorithmic bytes.

@@ -50,6 +50,8 @@ for mode in args.modes.split(','):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.reps
     with torch.no_grad():
+        cir()                       # (its own plan when one-qubit runs are merged: planned once, outside the timing)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         cir()
         torch.cuda.synchronize()
