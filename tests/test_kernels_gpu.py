@@ -8,7 +8,7 @@ import random
 import pytest
 import torch
 
-from deepquantum_amd import backend, fusion
+from deepquantum_amd import _lib, backend, fusion
 from oracle import statevec_oracle as oracle
 from test_fusion_cpu import random_ops, run_reference
 
@@ -296,3 +296,85 @@ def test_pack_unpack(dtype):
         cpu.unpack_axpby(a1, y, None, None, mask, value)
         backend.unpack_axpby(a2, y.to(dev()), None, None, mask, value)
         assert torch.equal(a2.cpu(), a1)
+
+
+@pytest.mark.parametrize('is128', [False, True])
+def test_all_handler_round_flag(is128):
+    """DQ_ROUND_ALL_FAST: rounds of handler-only gates run the assembly gate loop, mixed rounds the per-gate path (both
+    in one schedule, results checked by test_fused_passes_match_oracle); a round that carries the flag but holds a
+    gate without a handler id is refused by the C ABI."""
+    import copy
+    dtype = torch.complex128 if is128 else torch.complex64
+    n = 14
+    flagged = plain = 0
+    victim = None
+    for kinds in (('gen', 'x'), ('gen', 'x', 'diag', 'gen2')):
+        ops, mats = random_ops(n, 80, 3, kinds=kinds)
+        steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+        for st in steps:
+            for r in range(st.desc.nrounds):
+                rd = st.desc.rounds[r]
+                gates = [st.desc.gates[k] for k in range(rd.gate_begin & 0x7F, rd.gate_end)]
+                all_fast = all(g.fast != _lib.FAST_NONE for g in gates)
+                assert bool(rd.gate_begin & _lib.ROUND_ALL_FAST) == all_fast
+                flagged += all_fast
+                plain += not all_fast
+                if not all_fast and victim is None:
+                    victim = (st, r)
+    assert flagged > 0 and plain > 0 and victim is not None
+    st, r = victim
+    bad = copy.deepcopy(st.desc)
+    bad.rounds[r].gate_begin |= _lib.ROUND_ALL_FAST
+    x = rand_state(1, n, dtype, 1).to(dev())
+    md = fusion.kernel_matrices(steps, ops, mats.to(dtype)).to(dev())
+    with pytest.raises(RuntimeError, match='all-fast'):
+        backend.apply_fused(x, md, 0, bad, out=x)
+
+
+def handler_ops(n, ngates, seed):
+    """Gates that all have straight-line handlers: 2x2 gates of every promised structure (general, real, Rx-like,
+    Hadamard) mostly uncontrolled, X with up to one control -- so most rounds carry DQ_ROUND_ALL_FAST."""
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(seed)
+    ops, mats, off = [], [], 0
+    for _ in range(ngates):
+        mode = rng.choice([0, 1, 2, 3, 'x', 'x'])
+        nc = rng.choice([0, 1]) if mode == 'x' else int(rng.random() < 0.1)   # (a slot-controlled 2x2 has no handler)
+        bits = rng.sample(range(n), 1 + nc)
+        th = float(torch.rand(1, generator=g, dtype=torch.float64)) * 6.28
+        c, s_ = torch.cos(torch.tensor(th / 2, dtype=torch.float64)), torch.sin(torch.tensor(th / 2, dtype=torch.float64))
+        if mode == 'x':
+            m = torch.tensor([[0, 1], [1, 0]], dtype=torch.complex128)
+        elif mode == 0:
+            a = torch.randn(2, 2, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 2, generator=g, dtype=torch.float64)
+            m, _ = torch.linalg.qr(a)
+        elif mode == 1:
+            m = torch.stack([torch.stack([c, -s_]), torch.stack([s_, c])]).to(torch.complex128)
+        elif mode == 2:
+            m = torch.stack([torch.stack([c + 0j, -1j * s_]), torch.stack([-1j * s_, c + 0j])])
+        else:
+            m = torch.tensor([[1, 1], [1, -1]], dtype=torch.complex128) * float(torch.tensor(0.5, dtype=torch.float32).sqrt())
+        ops.append(fusion.PrimOp('x' if mode == 'x' else 'gen', (bits[0],), tuple(bits[1:]), off,
+                                 0 if mode == 'x' else (1 if (mode == 3 and nc) else mode)))
+        mats.append(m.reshape(-1))
+        off += 4
+    return ops, torch.cat(mats)
+
+
+@pytest.mark.parametrize('is128,n', [(False, 13), (False, 16), (True, 12), (True, 15)])
+@pytest.mark.parametrize('seed', [0, 1])
+def test_assembly_gate_loop_matches_oracle(is128, n, seed):
+    dtype = torch.complex128 if is128 else torch.complex64
+    ops, mats = handler_ops(n, 150, seed)
+    mats = mats.to(dtype)
+    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+    rounds = [st.desc.rounds[r] for st in steps for r in range(st.desc.nrounds)]
+    flagged = sum(bool(rd.gate_begin & _lib.ROUND_ALL_FAST) for rd in rounds)
+    assert flagged >= 0.5 * len(rounds), (flagged, len(rounds))
+    x = rand_state(2, n, dtype, 70 + seed)
+    ref = run_reference(x, ops, mats)
+    xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
+    for st in steps:
+        backend.apply_fused(xd, md, 0, st.desc, out=xd)
+    err = (xd.cpu() - ref).abs().max().item()
+    assert err < TOL[dtype], err
