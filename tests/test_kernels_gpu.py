@@ -320,13 +320,13 @@ def test_all_handler_round_flag(is128):
                 flagged += all_fast
                 plain += not all_fast
                 if not all_fast and victim is None:
-                    victim = (st, r)
+                    victim = (st, r, steps, ops, mats)
     assert flagged > 0 and plain > 0 and victim is not None
-    st, r = victim
+    st, r, steps, ops, mats = victim
+    md = fusion.kernel_matrices(steps, ops, mats.to(dtype)).to(dev())   # (assigns the matrix offsets of st.desc)
     bad = copy.deepcopy(st.desc)
     bad.rounds[r].gate_begin |= _lib.ROUND_ALL_FAST
     x = rand_state(1, n, dtype, 1).to(dev())
-    md = fusion.kernel_matrices(steps, ops, mats.to(dtype)).to(dev())
     with pytest.raises(RuntimeError, match='all-fast'):
         backend.apply_fused(x, md, 0, bad, out=x)
 
