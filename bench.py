@@ -361,6 +361,7 @@ def main():
             line['roofline']['single_gate_frac_of_peak'] = single_gbs / HBM_PEAK_GBS
         if launches and copy_gbs:
             line['roofline']['physical_frac_of_copy'] = line['roofline']['physical_GBs'] / copy_gbs
+            line['roofline']['physical_frac_of_peak'] = line['roofline']['physical_GBs'] / HBM_PEAK_GBS
         if z0 is not None:
             line['config']['expectation_Z0_sample0'] = z0
         if not args.no_cpu_baseline and not multi:
