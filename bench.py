@@ -61,6 +61,9 @@ def parse_args():
                     help='pass planner beam width (0 = first-come tiles, 1 = greedy; default: library)')
     ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
     ap.add_argument('--no-asm-loop', action='store_true', help='A/B: gate loop in C++ around the jump table')
+    ap.add_argument('--no-compare', action='store_true',
+                    help='skip the extra untimed-for-value runs with merging off (config.unmerged_ms_per_step): '
+                         'tools/profile.sh uses it so that the profiled launches are the timed ones only')
     ap.add_argument('--no-merge', action='store_true',
                     help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
@@ -281,7 +284,7 @@ def main():
     z0 = float(out.reshape(-1)[0]) if out is not None else None
     # the same circuit with every gate applied on its own (no products of one-qubit runs), for comparison: N = 1 only
     unmerged_ms = None
-    if not multi and not args.no_merge and dq.executor.CONFIG['merge_min_amps'] is not None:
+    if not multi and not args.no_merge and not args.no_compare and dq.executor.CONFIG['merge_min_amps'] is not None:
         keep = dq.executor.CONFIG['merge_min_amps']
         dq.executor.CONFIG['merge_min_amps'] = None
         step()

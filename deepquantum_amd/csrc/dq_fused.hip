@@ -554,9 +554,9 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             const uint64_t out_cmask = (uint64_t)rec[4] | ((uint64_t)rec[5] << 32);
             const unsigned reg_cmask = (g1 >> 8) & 0xffu, thr_cmask = g1 >> 16;
             if constexpr (FAST) {
-                // Straight-line handlers picked by the host (include/dq_hip.h, DqFusedGate::fast): one flat
-                // switch instead of the kind / control / mode / slot decision chain -- the scalar unit is the
-                // scarce resource of this kernel.  Ids < 16 have no control of any kind: no test at all.
+                // Straight-line handlers picked by the host (include/dq_hip.h, DqFusedGate::fast), reached through the
+                // jump table of fast_dispatch_f32 / _f64 (rounds that are not marked DQ_ROUND_ALL_FAST come here gate by
+                // gate; marked rounds never leave the assembly loop above).
                 if (__builtin_expect(fast < (uint32_t)DQ_FAST_IDS, 1)) {
 #define DQ_PAIR(I) ((uint64_t)mqv[2 * (I)] | ((uint64_t)mqv[2 * (I) + 1] << 32))
                     if constexpr (FAST32) {

@@ -587,7 +587,7 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         g.kind = _lib.FG_X1 if op.kind == 'x' else _lib.FG_GEN1
         g.q = slots[0]
         g.loc = op.mode if op.kind == 'gen' else 0
-        # straight-line handler id (one flat switch in the kernel): see include/dq_hip.h
+        # straight-line handler id (index of the kernel's jump table): see include/dq_hip.h
         free = reg_c == 0 and thr_c == 0 and out_c == 0
         g.fast = fast_id(g.kind, g.loc, slots[0], reg_c, thr_c, out_c)
     else:

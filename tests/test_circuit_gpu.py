@@ -397,3 +397,32 @@ def test_remaining_gate_classes_match_reference_on_gpu():
     from _helpers import check_extra_gates_against_golden
 
     check_extra_gates_against_golden(dq, device=dev())
+
+
+def test_bench_prints_one_contract_line():
+    """`python bench.py` (small workload) prints exactly one JSON line carrying the driver's contract keys plus the
+    `roofline` and `cpu_baseline` objects."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--nqubit', '16', '--batch', '4', '--depth', '6',
+                          '--steps', '2', '--warmup', '1', '--cpu-seconds', '1'],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['unit'] == 'gate-applies/s' and d['dtype'] == 'c64' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 16 * 6 * 4 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and r['launches'] > 0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 'traffic' in r
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'gate-applies/s' and c['sample']

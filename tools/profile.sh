@@ -6,7 +6,7 @@ tag=${1:-r01}; shift
 export TMPDIR=/tmp
 root=$PWD/gpurun_out/prof/$tag
 rm -rf "$root"; mkdir -p "$root"
-BENCH="python $PWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline $*"
+BENCH="python $PWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-compare $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$root/trace" -o trace -- $BENCH > "$root/bench_trace.json" 2> "$root/trace.err"
 rocprofv3 --kernel-trace --output-format csv --kernel-include-regex "fused_pass" --pmc FETCH_SIZE -d "$root/pmc_fetch" -o pmc -- $BENCH > /dev/null 2> "$root/pmc_fetch.err"
