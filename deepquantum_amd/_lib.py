@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
@@ -25,8 +25,10 @@ FUSED_MAX_HIGH = 12
 FUSED_MAX_ROUNDS = 24
 FUSED_MAX_GATES = 80
 FUSED_MAX_SLOTS = 4
-FUSED_MAX_TBITS = 10
+FUSED_MAX_TBITS = 9
 ROUND_ALL_FAST = 0x80
+ROUND_TRANSPOSE = 0x01
+ROUND_TRANSPOSE_AFTER = 0x02
 FAST_NONE = 0xFFFFFFFF
 MAT_PAD = 16
 
@@ -52,6 +54,7 @@ class DqFusedRound(C.Structure):
     _fields_ = [
         ('rb', C.c_uint8 * FUSED_MAX_SLOTS),
         ('tb', C.c_uint8 * FUSED_MAX_TBITS),
+        ('flags', C.c_uint8),
         ('gate_begin', C.c_uint8),
         ('gate_end', C.c_uint8),
     ]

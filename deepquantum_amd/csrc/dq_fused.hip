@@ -414,13 +414,9 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     };
 
     // ---- load layout: slots from the descriptor, thread bits = remaining tile bits ascending ----
-    unsigned rb[R];  // current register-slot tile bits (ascending)
     unsigned tbase = tid;  // current thread base (tile-local)
 #pragma unroll
-    for (int s = 0; s < R; ++s) {
-        rb[s] = (lrb >> (8 * s)) & 0xffu;
-        tbase = (unsigned)insert_zero(tbase, (int)rb[s]);
-    }
+    for (int s = 0; s < R; ++s) tbase = (unsigned)insert_zero(tbase, (int)((lrb >> (8 * s)) & 0xffu));
 
     V a[NA];
     {
@@ -457,16 +453,20 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     // the registers are in right now.
     constexpr int TAB_W0 = offsetof(DqFusedPass, lds_tab) / 4;   // 8 words = 16 entries per table
     constexpr int TAB_WORDS = (NA + 1) / 2;
-    uint32_t ctab[TAB_WORDS];
-#pragma unroll
-    for (int w = 0; w < TAB_WORDS; ++w) ctab[w] = hw[TAB_W0 + w];
+    int cur_tab = 0;   // table of the layout the registers are in right now (0 = load layout, 1 + r = round r)
     auto tab_entry = [](const uint32_t (&tab)[TAB_WORDS], int j) __attribute__((always_inline)) -> unsigned {
         return (tab[j >> 1] >> (16 * (j & 1))) & 0xffffu;
     };
-    auto transpose_to = [&](const unsigned (&nrb)[R], const unsigned ntbase, const int table) __attribute__((always_inline)) {
-        uint32_t ntab[TAB_WORDS];
+    // Whether a trip is needed is the host's decision (DqFusedRound::flags, checked by dq_apply_fused): a comparison
+    // of layouts here would be per lane (the thread base is a VGPR) and cost an exec-masked region per round.  Both
+    // offset tables are (re)loaded from the descriptor -- scalar loads -- instead of being carried across the gates.
+    auto transpose_to = [&](const unsigned ntbase, const int table) __attribute__((always_inline)) {
+        uint32_t ctab[TAB_WORDS], ntab[TAB_WORDS];
 #pragma unroll
-        for (int w = 0; w < TAB_WORDS; ++w) ntab[w] = hw[TAB_W0 + 8 * table + w];
+        for (int w = 0; w < TAB_WORDS; ++w) {
+            ctab[w] = hw[TAB_W0 + 8 * cur_tab + w];
+            ntab[w] = hw[TAB_W0 + 8 * table + w];
+        }
         const unsigned vw = lds_swz<sizeof(V)>(tbase) * (unsigned)sizeof(V);
         const unsigned vr = lds_swz<sizeof(V)>(ntbase) * (unsigned)sizeof(V);
 #pragma unroll
@@ -475,10 +475,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
 #pragma unroll
         for (int j = 0; j < NA; ++j) a[j] = *lds_at(vr ^ tab_entry(ntab, j));
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < R; ++s) rb[s] = nrb[s];
-#pragma unroll
-        for (int w = 0; w < TAB_WORDS; ++w) ctab[w] = ntab[w];
+        cur_tab = table;
         tbase = ntbase;
     };
 
@@ -502,23 +499,20 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     const uint64_t mbase_u = (uint64_t)mbase;
     T hscale = T(1);   // product of the deferred Hadamard factors of this pass (uniform)
     bool had = false;
+    unsigned last_flags = 0;
     for (int r = 0; r < nrounds; ++r) {
-        const uint32_t rw0 = pw[ROUND_W0 + 4 * r], rw1 = pw[ROUND_W0 + 4 * r + 1], rw2 = pw[ROUND_W0 + 4 * r + 2],
+        const uint32_t rw1 = pw[ROUND_W0 + 4 * r + 1], rw2 = pw[ROUND_W0 + 4 * r + 2],
                        rw3 = pw[ROUND_W0 + 4 * r + 3];
-        unsigned nrb[R];
-        bool same = true;
+        last_flags = (rw3 >> 8) & 0xffu;
+        if (last_flags & DQ_ROUND_TRANSPOSE) {
+            unsigned ntbase = 0;
 #pragma unroll
-        for (int s = 0; s < R; ++s) {
-            nrb[s] = (rw0 >> (8 * s)) & 0xffu;
-            same = same && (nrb[s] == rb[s]);
+            for (int i = 0; i < LOGT; ++i) {
+                const uint32_t w = i < 4 ? rw1 : (i < 8 ? rw2 : rw3);
+                ntbase |= ((tid >> i) & 1u) << ((w >> (8 * (i & 3))) & 0xffu);
+            }
+            transpose_to(ntbase, 1 + r);
         }
-        unsigned ntbase = 0;
-#pragma unroll
-        for (int i = 0; i < LOGT; ++i) {
-            const uint32_t w = i < 4 ? rw1 : (i < 8 ? rw2 : rw3);
-            ntbase |= ((tid >> i) & 1u) << ((w >> (8 * (i & 3))) & 0xffu);
-        }
-        if (!same || ntbase != tbase) transpose_to(nrb, ntbase, 1 + r);
         const int gbeg = (int)((rw3 >> 16) & 0x7fu), gend = (int)(rw3 >> 24);
         if constexpr (FAST) {
             if (rw3 & (DQ_ROUND_ALL_FAST << 16)) {   // the whole gate loop of the round in assembly (dq_fused_asm.inc)
@@ -631,17 +625,11 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
     }
 
-    {  // ---- store layout ----
-        unsigned srb[R];
+    if (last_flags & DQ_ROUND_TRANSPOSE_AFTER) {  // ---- into the store layout ----
         unsigned stbase = tid;
-        bool same = true;
 #pragma unroll
-        for (int s = 0; s < R; ++s) {
-            srb[s] = (srbw >> (8 * s)) & 0xffu;
-            stbase = (unsigned)insert_zero(stbase, (int)srb[s]);
-            same = same && (srb[s] == rb[s]);
-        }
-        if (!same || stbase != tbase) transpose_to(srb, stbase, DQ_FUSED_MAX_ROUNDS + 1);
+        for (int s = 0; s < R; ++s) stbase = (unsigned)insert_zero(stbase, (int)((srbw >> (8 * s)) & 0xffu));
+        transpose_to(stbase, DQ_FUSED_MAX_ROUNDS + 1);
     }
 
     {
@@ -696,8 +684,8 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
         set_error("dq_apply_fused: n=%d smaller than tile m=%d", n, m);
         return DQ_ERR_ARG;
     }
-    if (p->nrounds > DQ_FUSED_MAX_ROUNDS) {
-        set_error("dq_apply_fused: too many rounds");
+    if (p->nrounds == 0 || p->nrounds > DQ_FUSED_MAX_ROUNDS) {
+        set_error("dq_apply_fused: a pass has 1..%d rounds", DQ_FUSED_MAX_ROUNDS);
         return DQ_ERR_ARG;
     }
     uint64_t seen = 0;
@@ -748,6 +736,38 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
                 return DQ_ERR_ARG;
             }
             used |= 1u << rd.tb[i];
+        }
+        {   // the kernel trusts the transposition flags: recompute them from the layouts
+            const uint8_t* prb = r == 0 ? p->load_rb : p->rounds[r - 1].rb;
+            bool differs = false;
+            for (int s = 0; s < slots; ++s) differs = differs || prb[s] != rd.rb[s];
+            if (r == 0) {   // thread bits of an I/O layout: the tile bits that are not slots, ascending
+                unsigned slotmask = 0;
+                for (int s = 0; s < slots; ++s) slotmask |= 1u << p->load_rb[s];
+                for (int i = 0, q = 0; i < logt; ++i, ++q) {
+                    while ((slotmask >> q) & 1u) ++q;
+                    differs = differs || rd.tb[i] != q;
+                }
+            } else {
+                for (int i = 0; i < logt; ++i) differs = differs || p->rounds[r - 1].tb[i] != rd.tb[i];
+            }
+            bool after = false;
+            if (r == p->nrounds - 1) {
+                unsigned slotmask = 0;
+                for (int s = 0; s < slots; ++s) {
+                    slotmask |= 1u << p->store_rb[s];
+                    after = after || p->store_rb[s] != rd.rb[s];
+                }
+                for (int i = 0, q = 0; i < logt; ++i, ++q) {
+                    while ((slotmask >> q) & 1u) ++q;
+                    after = after || rd.tb[i] != q;
+                }
+            }
+            const unsigned want = (differs ? DQ_ROUND_TRANSPOSE : 0u) | (after ? DQ_ROUND_TRANSPOSE_AFTER : 0u);
+            if (rd.flags != want) {
+                set_error("dq_apply_fused: round %d has layout flags %u, expected %u", r, rd.flags, want);
+                return DQ_ERR_ARG;
+            }
         }
         const int gate_begin = rd.gate_begin & 0x7f;
         const bool all_fast = (rd.gate_begin & DQ_ROUND_ALL_FAST) != 0;

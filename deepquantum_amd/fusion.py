@@ -511,11 +511,13 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
     ntrans = 0
     cur = (tuple(load_rb), tuple(ascending_tb(load_rb)))
     for ri, (rd, lay) in enumerate(zip(rounds, layouts)):
+        r = desc.rounds[ri]
+        r.flags = 0
         if lay != cur:
             ntrans += 1
             cur = lay
+            r.flags |= _lib.ROUND_TRANSPOSE
         slot_of = {tl: s for s, tl in enumerate(lay[0])}
-        r = desc.rounds[ri]
         for s in range(R):
             r.rb[s] = lay[0][s]
         for i, t in enumerate(lay[1]):
@@ -531,6 +533,7 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         r.gate_end = gi
     if cur != (tuple(store_rb), tuple(ascending_tb(store_rb))):
         ntrans += 1
+        desc.rounds[len(rounds) - 1].flags |= _lib.ROUND_TRANSPOSE_AFTER
     desc.nrounds = len(rounds)
     return FusedStep(desc=desc, ops=exec_order, nrounds=len(rounds), ntranspose=ntrans)
 

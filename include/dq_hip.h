@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 11
+#define DQ_ABI_VERSION 12
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -129,16 +129,24 @@ typedef struct {
 /* `mats` must be readable for DQ_MAT_PAD complex numbers past the last matrix of a pass (prefetch). */
 #define DQ_MAT_PAD 16
 
-#define DQ_FUSED_MAX_TBITS 10
+#define DQ_FUSED_MAX_TBITS 9
 typedef struct {
     uint8_t rb[DQ_FUSED_MAX_SLOTS]; /* tile-local bit positions of the register slots, ascending */
     uint8_t tb[DQ_FUSED_MAX_TBITS]; /* tile-local bit position of thread-index bit i (the other m - slots
                                        tile bits, in an order the host picks to avoid LDS bank conflicts) */
+    uint8_t flags;                  /* DQ_ROUND_TRANSPOSE: the layout (rb, tb) differs from the one the registers are in
+                                       when the round starts (the previous round's, or the load layout for round 0) ->
+                                       one LDS round trip first; DQ_ROUND_TRANSPOSE_AFTER (last round only): the
+                                       layout differs from the store layout -> one LDS round trip before the store.
+                                       The kernel trusts these flags (it no longer compares layouts per lane);
+                                       dq_apply_fused_* recomputes and checks them. */
     uint8_t gate_begin, gate_end;   /* [begin & 0x7f, end) into gates[]; DQ_ROUND_ALL_FAST in gate_begin promises
                                        that every gate of the round has a handler id (fast != DQ_FAST_NONE): the
                                        kernel then runs the round's gate loop without leaving its assembly block */
 } DqFusedRound;                     /* 16 bytes */
 #define DQ_ROUND_ALL_FAST 0x80u
+#define DQ_ROUND_TRANSPOSE 0x01u
+#define DQ_ROUND_TRANSPOSE_AFTER 0x02u
 
 typedef struct {
     uint8_t m, L, h, nrounds;

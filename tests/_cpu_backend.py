@@ -106,11 +106,19 @@ class CpuTestBackend:
         for b in range(bsz):
             t = x[b][idx]                               # (ntiles, 2^m)
             mb = flat_m[b * mat_batch_stride :] if mat_batch_stride else flat_m
+            # layout the registers are in: (slots, thread bits); the load layout has ascending thread bits
+            lay = ([desc.load_rb[s] for s in range(R)],
+                   [q for q in range(m) if q not in [desc.load_rb[s] for s in range(R)]])
             for r in range(desc.nrounds):
                 rd = desc.rounds[r]
                 rb = [rd.rb[s] for s in range(R)]
                 tb = [rd.tb[i] for i in range(logt)]
                 assert rb == sorted(set(rb)) and all(q < m for q in rb)
+                assert bool(rd.flags & _lib.ROUND_TRANSPOSE) == ((rb, tb) != lay), 'transposition flag wrong'
+                lay = (rb, tb)
+                store = [desc.store_rb[s] for s in range(R)]
+                after = r == desc.nrounds - 1 and lay != (store, [q for q in range(m) if q not in store])
+                assert bool(rd.flags & _lib.ROUND_TRANSPOSE_AFTER) == after, 'final transposition flag wrong'
                 assert sorted(rb + tb) == list(range(m)), 'slots + thread bits must cover the tile exactly'
                 slotmask = sum(1 << q for q in rb)
                 first = rd.gate_begin & 0x7F
