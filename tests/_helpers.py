@@ -419,3 +419,76 @@ def check_extra_gates_against_golden(dq, device=None, tol=2e-5):
     assert (u @ u.mH - torch.eye(16)).abs().max().item() < 10 * tol
     ref_u = gold_extra('extra_gates/unitary')
     assert (ref_u[:, 0] - gold_extra('extra_gates/state')).abs().max().item() > 0.5     # (documents the divergence)
+
+
+def check_fuzz_against_oracle(dq, device=None, n=13, seeds=(0, 1, 2), depth=6, batch=2, double=False):
+    """Random circuits over the whole gate vocabulary (fixed, parametric with per-sample data, controlled, two- and
+    three-qubit) through the product path under every scheduler / merging configuration, against the oracle applying
+    the same gate matrices one by one.  Exercises the planner, the one-qubit-run products, the handler dispatch and
+    the per-gate fallbacks on structures the golden circuits do not contain."""
+    import random
+
+    from oracle import statevec_oracle as oracle
+    one = ['h', 'x', 'y', 'z', 's', 't', 'sdg', 'tdg']
+    par = ['rx', 'ry', 'rz', 'p']
+    for seed in seeds:
+        rng = random.Random(seed)
+        cir = dq.QubitCircuit(n)
+        for _ in range(depth):
+            for q in range(n):
+                r = rng.random()
+                others = [w for w in range(n) if w != q]
+                if r < 0.3:
+                    getattr(cir, rng.choice(one))(q)
+                elif r < 0.5:
+                    getattr(cir, rng.choice(par))(q, encode=True)
+                elif r < 0.6:
+                    getattr(cir, rng.choice(par))(q, inputs=rng.uniform(0, 6.28))
+                elif r < 0.75:
+                    cir.cnot(q, rng.choice(others))
+                elif r < 0.8:
+                    cir.cz(q, rng.choice(others))
+                elif r < 0.85:
+                    cir.swap([q, rng.choice(others)])
+                elif r < 0.9:
+                    c1, c2 = rng.sample(others, 2)
+                    cir.toffoli(c1, c2, q)
+                elif r < 0.95:
+                    cir.rxx([q, rng.choice(others)], inputs=rng.uniform(0, 6.28))
+                else:
+                    cir.rx(q, inputs=rng.uniform(0, 6.28), controls=[rng.choice(others)])
+        if double:
+            cir.to(torch.double)
+        if device is not None:
+            cir.to(device)
+        gen = torch.Generator().manual_seed(100 + seed)
+        data = torch.rand(batch, cir.ndata, generator=gen, dtype=torch.double if double else torch.float) * 6.28
+        data = data.to(device) if device is not None else data
+        keep = dict(dq.executor.CONFIG)
+        outs = []
+        try:
+            for cfg in ({'merge_min_amps': None, 'plan_width': 0}, {'merge_min_amps': 0, 'plan_width': 1},
+                        {'merge_min_amps': 0, 'plan_width': 4}, {'merge_min_amps': 0, 'asm_loop': False}):
+                dq.executor.CONFIG.update(keep)
+                dq.executor.CONFIG.update(cfg)
+                dq.executor._PLAN_CACHE.clear()
+                with torch.no_grad():
+                    outs.append(cir(data).detach().cpu().reshape(batch, -1).clone())
+            # the reference: the same matrices (encoded with the last sample by forward()) applied by the oracle
+            ref = []
+            for b in range(batch):
+                cir.encode(data[b])
+                x = torch.zeros(1, 1 << n, dtype=outs[0].dtype)
+                x[0, 0] = 1
+                for op in cir.operators:
+                    m = op.update_matrix().detach().cpu().to(outs[0].dtype)
+                    x = oracle.apply_gate_wires(x, m, n, list(op.wires), list(op.controls))
+                ref.append(x)
+            ref = torch.cat(ref)
+        finally:
+            dq.executor.CONFIG.clear()
+            dq.executor.CONFIG.update(keep)
+            dq.executor._PLAN_CACHE.clear()
+        for k, o in enumerate(outs):
+            err = (o - ref).abs().max().item()
+            assert err < (1e-12 if double else 5e-6), (seed, k, err)

@@ -301,3 +301,9 @@ def test_fixed_angle_matrices_are_reused_and_invalidated(cpu_backend):
     ref = dq.QubitCircuit(3)
     ref.rxlayer(inputs=[0.1, 0.7, 0.3]); ref.cnot_ring(); ref.rylayer(inputs=[0.4, 0.5, 0.6])
     assert torch.allclose(cir(), ref(), atol=1e-6)
+
+
+def test_random_circuits_under_every_scheduler_configuration(cpu_backend):
+    from _helpers import check_fuzz_against_oracle
+    check_fuzz_against_oracle(dq, n=13, seeds=(0, 1), depth=5)
+    check_fuzz_against_oracle(dq, n=12, seeds=(2,), depth=5, double=True)

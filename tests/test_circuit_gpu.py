@@ -426,3 +426,11 @@ def test_bench_prints_one_contract_line():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 'traffic' in r
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'gate-applies/s' and c['sample']
+
+
+def test_random_circuits_under_every_scheduler_configuration_on_gpu():
+    from _helpers import check_fuzz_against_oracle
+    check_fuzz_against_oracle(dq, device=dev(), n=13, seeds=(0, 1, 2, 3), depth=6)
+    check_fuzz_against_oracle(dq, device=dev(), n=16, seeds=(4, 5), depth=5, batch=3)
+    check_fuzz_against_oracle(dq, device=dev(), n=12, seeds=(6, 7, 8), depth=6, double=True)
+    check_fuzz_against_oracle(dq, device=dev(), n=15, seeds=(9,), depth=5, double=True)
