@@ -196,7 +196,7 @@ def _closure(dag: '_Dag', tile: set[int], cap: int, indeg: list[int] | None = No
 
 
 def _grow_tile(dag: '_Dag', low: set[int], hcap: int, cap: int, indeg: list[int] | None = None,
-               ready: list[int] | None = None, pick=None) -> set[int]:
+               ready: list[int] | None = None, pick=None, far: tuple[int, int] | None = None) -> set[int]:
     """Gathered bits of one pass, grown one bit at a time: dry-run the pass with the bits chosen so far, look at
     the gates it leaves stuck at the front, and add the missing target bit that lets the pass retire the most
     gates (ties: the bit most stuck gates wait for, then the lowest).  ``pick(ranked)`` may choose another of the
@@ -215,6 +215,8 @@ def _grow_tile(dag: '_Dag', low: set[int], hcap: int, cap: int, indeg: list[int]
             for t in op.targets:
                 if t not in tile:
                     cands[t] = cands.get(t, 0) + 1
+        if far is not None and sum(1 for b_ in chosen if b_ >= far[0]) >= far[1]:
+            cands = {q: w for q, w in cands.items() if q < far[0]}     # the budget of far-apart bits is spent
         if not cands:
             break
         ranked = sorted(((_closure(dag, tile | {q}, cap, indeg, ready)[0], w, -q) for q, w in cands.items()),
@@ -225,7 +227,7 @@ def _grow_tile(dag: '_Dag', low: set[int], hcap: int, cap: int, indeg: list[int]
 
 
 def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, branch: int,
-                seed: int = 20250929) -> list[set[int] | None]:
+                seed: int = 20250929, far: tuple[int, int] | None = None) -> list[set[int] | None]:
     """Gathered-bit sets for ALL passes of a circuit by beam search over dry runs (`_closure`): every beam state
     (a front of the DAG) is extended by the greedy tile and by ``branch - 1`` randomised ones (one of the three best
     candidates at each growth step, fixed seed), the ``width`` states that have retired the most gates survive.
@@ -245,7 +247,7 @@ def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, bra
                 return hist
             seen = set()
             for b_ in range(branch if width > 1 else 1):
-                tile_bits = _grow_tile(dag, low, hcap, cap, indeg, ready, jitter if b_ else None)
+                tile_bits = _grow_tile(dag, low, hcap, cap, indeg, ready, jitter if b_ else None, far)
                 key = frozenset(tile_bits)
                 if key in seen:
                     continue
@@ -307,7 +309,8 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int) -> list
     hcap = geom.m - geom.min_low
     # the randomised branches make the pass count vary by one or two: on big states a few restarts are worth it
     restarts = geom.plan_restarts if width > 1 and n >= geom.plan_restart_bits else 1
-    planned = min((_plan_tiles(dag, low, hcap, geom.max_gates, width, geom.plan_branch, 20250929 + r)
+    far = (geom.far_bit, geom.max_far) if geom.max_far is not None else None
+    planned = min((_plan_tiles(dag, low, hcap, geom.max_gates, width, geom.plan_branch, 20250929 + r, far)
                    for r in range(restarts)), key=len) if width else []
     planned.reverse()                   # consumed from the end
     while dag.done < dag.n_ops:
@@ -324,9 +327,9 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int) -> list
                     steps.append(SingleStep(i))
                     dag.retire(i)
                     continue
-                allowed = _grow_tile(dag, low, hcap, geom.max_gates)
+                allowed = _grow_tile(dag, low, hcap, geom.max_gates, far=far)
         else:                           # the passes ran out of step with the dry runs (round / gate caps)
-            allowed = _grow_tile(dag, low, hcap, geom.max_gates)
+            allowed = _grow_tile(dag, low, hcap, geom.max_gates, far=far)
 
         def fits_tile(op: PrimOp) -> bool:
             need = {t for t in op.targets if t not in low} - high
