@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument('--no-compare', action='store_true',
                     help='skip the extra untimed-for-value runs with merging off (config.unmerged_ms_per_step): '
                          'tools/profile.sh uses it so that the profiled launches are the timed ones only')
+    ap.add_argument('--no-permute-store', action='store_true',
+                    help='A/B: in-place passes (every pass gathers its qubits where they canonically live)')
     ap.add_argument('--no-merge', action='store_true',
                     help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
@@ -225,6 +227,8 @@ def main():
         dq.executor.CONFIG['asm_loop'] = False
     if args.no_merge:
         dq.executor.CONFIG['merge_min_amps'] = None
+    if args.no_permute_store:
+        dq.executor.CONFIG['permute_store'] = False
 
     n = args.nqubit + (int(math.log2(world)) if distributed else 0)
     spec = random_circuit_spec(n, args.depth, args.seed)

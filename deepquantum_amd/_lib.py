@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
@@ -26,6 +26,7 @@ FUSED_MAX_ROUNDS = 24
 FUSED_MAX_GATES = 80
 FUSED_MAX_SLOTS = 4
 FUSED_MAX_TBITS = 9
+FUSED_MAX_BLK = 24
 ROUND_ALL_FAST = 0x80
 ROUND_TRANSPOSE = 0x01
 ROUND_TRANSPOSE_AFTER = 0x02
@@ -76,6 +77,8 @@ class DqFusedPass(C.Structure):
         ('load_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),
         ('store_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),
         ('lds_tab', (C.c_uint16 * 16) * (FUSED_MAX_ROUNDS + 2)),
+        ('store_high_pos', C.c_uint8 * FUSED_MAX_HIGH),
+        ('store_blk_pos', C.c_uint8 * FUSED_MAX_BLK),
     ]
 
 

@@ -403,7 +403,25 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     for (int i = 0; i < h; ++i) tile = insert_zero(tile, (int)byte_of(hs0, hs1, hs2, i));
     // in_bstride = 2^n normally; 0 when every batch element starts from the same (single) input state
     const V* pin = in + (uint64_t)sample * (uint64_t)in_bstride + tile;
-    V* pout = out + ((uint64_t)sample << n) + tile;
+    // write side: block-index bit j goes to global bit store_blk_pos[j], tile bit L + i to store_high_pos[i]
+    // (both equal to the read positions for an in-place pass; include/dq_hip.h)
+    constexpr int SHP_W0 = offsetof(DqFusedPass, store_high_pos) / 4, SBP_W0 = offsetof(DqFusedPass, store_blk_pos) / 4;
+    static_assert(offsetof(DqFusedPass, store_high_pos) % 4 == 0 && offsetof(DqFusedPass, store_blk_pos) % 4 == 0, "");
+    uint64_t tile_w = 0;
+    {
+        const int nblk = n - L - h;
+        for (int j = 0; j < nblk; ++j) {
+            const unsigned pos = (hw[SBP_W0 + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
+            tile_w |= (uint64_t)((tile_id >> j) & 1u) << pos;
+        }
+    }
+    V* pout = out + ((uint64_t)sample << n) + tile_w;
+    auto glob_w = [&](unsigned e) __attribute__((always_inline)) -> uint64_t {
+        uint64_t g = e & ((1u << L) - 1u);
+        for (int i = 0; i < h; ++i)
+            g |= (uint64_t)((e >> (L + i)) & 1u) << ((hw[SHP_W0 + (i >> 2)] >> (8 * (i & 3))) & 0xffu);
+        return g;
+    };
     const V* mbase = mats + (int64_t)sample * mat_bstride;
 
     // tile-local index -> offset inside the state
@@ -633,7 +651,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     }
 
     {
-        const uint64_t gt = glob(tbase);
+        const uint64_t gt = glob_w(tbase);
         const uint64_t* so = reinterpret_cast<const uint64_t*>(hw + offsetof(DqFusedPass, store_slot_off) / 4);
         uint64_t gs[R];
 #pragma unroll
@@ -716,6 +734,22 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
                 set_error("dq_apply_fused: %s layout invalid at slot %d", io ? "store" : "load", s);
                 return DQ_ERR_ARG;
             }
+        }
+    }
+    {   // write positions: a permutation of [L, n)
+        const int nblk = n - m;
+        if (nblk > DQ_FUSED_MAX_BLK) {
+            set_error("dq_apply_fused: n - m = %d block bits, at most %d", nblk, DQ_FUSED_MAX_BLK);
+            return DQ_ERR_UNSUPPORTED;
+        }
+        uint64_t wseen = 0;
+        for (int i = 0; i < p->h + nblk; ++i) {
+            const int pos = i < p->h ? p->store_high_pos[i] : p->store_blk_pos[i - p->h];
+            if (pos < p->L || pos >= n || ((wseen >> pos) & 1ull)) {
+                set_error("dq_apply_fused: write positions are not a permutation of [L, n) (entry %d = %d)", i, pos);
+                return DQ_ERR_ARG;
+            }
+            wseen |= 1ull << pos;
         }
     }
     int next_gate = 0;
@@ -864,6 +898,20 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     const FusedVariant v = vars[vi];
     int rc = validate_pass<T>(pass, n, v.slots, v.logt);
     if (rc) return rc;
+    if (in == out) {   // in place: every amplitude must be written where it was read
+        bool same = true;
+        for (int i = 0; i < pass->h; ++i) same = same && pass->store_high_pos[i] == pass->high_pos[i];
+        uint64_t tilemask = 0;
+        for (int i = 0; i < pass->h; ++i) tilemask |= 1ull << pass->high_pos[i];
+        for (int j = 0, q = pass->L; j < n - v.m; ++j, ++q) {
+            while ((tilemask >> q) & 1ull) ++q;
+            same = same && pass->store_blk_pos[j] == q;
+        }
+        if (!same) {
+            set_error("dq_apply_fused: a pass that writes to other index bits than it reads needs in != out");
+            return DQ_ERR_ARG;
+        }
+    }
     if (n - v.m > 31) {
         set_error("dq_apply_fused: grid too large (n=%d)", n);
         return DQ_ERR_UNSUPPORTED;

@@ -53,6 +53,9 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
           'max_gates': None, 'max_far': None, 'far_bit': None,
           # pass planner (fusion._plan_tiles): beam width / tiles tried per state; 0 = first-come tiles, 1 = greedy
           'plan_width': None, 'plan_branch': None, 'asm_loop': None,
+          # out-of-place passes that write the next pass's qubits to cheap index bits (fusion._place_writes): needs a
+          # second state buffer; used when both fit in `permute_mem_frac` of the device memory
+          'permute_store': True, 'permute_mem_frac': 0.45, 'permute_min_bits': 20,
           # 'adjoint': fused forward + reverse sweep with recomputation (O(1) states of memory);
           # 'per_gate': one autograd node per gate (saves every intermediate state; supports double backward)
           'grad_mode': 'adjoint',
@@ -93,10 +96,13 @@ def _geometry(is128: bool) -> fusion.Geometry:
     return g
 
 
-def make_plan(prims: Sequence[Prim], n: int, is128: bool) -> Plan:
+def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False) -> Plan:
     geom = _geometry(is128)
+    geom.permute_store = permute
+    if geom.fallback is not None:
+        geom.fallback.permute_store = permute
     key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
-           geom.plan_branch, geom.asm_loop, CONFIG['fuse'],
+           geom.plan_branch, geom.asm_loop, permute, CONFIG['fuse'],
            tuple((p.kind, p.targets, p.controls, p.mode) for p in prims))
     plan = _PLAN_CACHE.get(key)
     if plan is not None:
@@ -281,7 +287,13 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):
             return _run_small(state, prims, n, m)
-        plan = make_plan(prims, n, is128)
+        permute = False
+        if CONFIG['permute_store'] and not inplace and n >= CONFIG['permute_min_bits']:
+            permute = True
+            if state.is_cuda:
+                total = torch.cuda.get_device_properties(state.device).total_memory
+                permute = 2 * state.numel() * state.element_size() <= CONFIG['permute_mem_frac'] * total
+        plan = make_plan(prims, n, is128, permute)
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies
         shared_in = None
@@ -295,18 +307,25 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
             x = state.detach().clone(memory_format=torch.contiguous_format)
         flat, stride = _flat_mats(prims, plan.mat_order, x.shape[0], x.dtype, x.device)
         stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0}
-        scratch = None
+        scratch = other = None
         for st in plan.steps:
             if isinstance(st, fusion.FusedStep):
                 src, shared_in = (shared_in, None) if shared_in is not None else (x, None)
+                dst = x
+                if st.permutes and src is x:     # writes to other index bits than it reads: the other buffer
+                    if other is None:
+                        other = torch.empty_like(x)
+                    dst = other
                 if PROFILE['enabled'] and x.is_cuda:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    backend.apply_fused(src, flat, stride, st.desc, out=x)
+                    backend.apply_fused(src, flat, stride, st.desc, out=dst)
                     e1.record()
                     PROFILE['events'].append((e0, e1, len(st.ops)))
                 else:
-                    backend.apply_fused(src, flat, stride, st.desc, out=x)
+                    backend.apply_fused(src, flat, stride, st.desc, out=dst)
+                if dst is not x:
+                    x, other = dst, x
                 stats['passes'] += 1
                 stats['rounds'] += st.nrounds
                 stats['transposes'] += st.ntranspose

@@ -47,6 +47,7 @@ class FusedStep:
     ops: list[int]            # indices into the PrimOp list, in execution order
     nrounds: int
     ntranspose: int           # LDS round trips the kernel will do (incl. back to canonical)
+    permutes: bool = False    # writes to other index bits than it reads (needs in != out)
 
 
 @dataclass
@@ -65,6 +66,7 @@ class Geometry:
     fallback: 'Geometry | None' = None   # smaller (faster per byte) tile for passes that do not need all gathered bits
     plan_width: int = 4       # gathered bits of every pass from dry runs of the pass (_plan_tiles): beam width
     plan_branch: int = 3      # ... and tiles tried per beam state; plan_width = 0: first-come tiles (no dry runs)
+    permute_store: bool = False   # passes may write to other index bits than they read (out-of-place; _place_writes)
     asm_loop: bool = True     # mark rounds whose gates all have handler ids (DQ_ROUND_ALL_FAST); off: A/B measurements
     plan_restarts: int = 3    # beam searches with different random branches (states of >= 2^plan_restart_bits amplitudes)
     plan_restart_bits: int = 26
@@ -304,7 +306,7 @@ def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True) -
 
 def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int) -> list[FusedStep | SingleStep]:
     dag = _Dag(ops, n)
-    steps: list[FusedStep | SingleStep] = []
+    steps: list = []                    # SingleStep | (geometry, gathered bits, rounds) of a fused pass, finalised below
     low = set(range(geom.min_low))
     hcap = geom.m - geom.min_low
     # the randomised branches make the pass count vary by one or two: on big states a few restarts are worth it
@@ -412,10 +414,78 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int) -> list
             continue
         small = geom.fallback
         if small is not None and n >= small.m and len(high) <= small.m - small.min_low and small.min_low == geom.min_low:
-            steps.append(_finalize(ops, n, small, high, rounds))
+            steps.append((small, high, rounds))
         else:
-            steps.append(_finalize(ops, n, geom, high, rounds))
-    return steps
+            steps.append((geom, high, rounds))
+    return _place_writes(ops, n, steps, geom.permute_store)
+
+
+def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool) -> list[FusedStep | SingleStep]:
+    """Finalise the passes.  With ``permute`` a pass writes the qubits the NEXT pass gathers to the cheapest index
+    bits (right above the contiguous run) and everybody else above them, in their current order -- gathered reads
+    from far-apart addresses are what a pass pays for, scattered writes are nearly free (mb_scatter) --
+    so from the second pass on every tile is read as one contiguous block.  ``phys`` maps a qubit's index bit
+    (logical) to where it currently lives; the last pass, and any pass followed by a gate that runs on its own,
+    writes the canonical order back."""
+    phys = list(range(n))
+    out: list[FusedStep | SingleStep] = []
+    for k, item in enumerate(pending):
+        if isinstance(item, SingleStep):
+            assert phys == list(range(n))
+            out.append(item)
+            continue
+        geom, high, rounds = item
+        if phys == list(range(n)):
+            tops, thigh, trounds = ops, high, rounds
+        else:                               # the pass sees physical bits
+            def tr(bits):
+                return tuple(phys[b] for b in bits)
+            tops = list(ops)
+            trounds = []
+            for rd in rounds:
+                for oi in rd.ops:
+                    tops[oi] = PrimOp(ops[oi].kind, tr(ops[oi].targets), tr(ops[oi].controls), ops[oi].mat, ops[oi].mode,
+                                      ops[oi].pos)
+                trounds.append(_Round(slots=[phys[b] for b in rd.slots], ops=list(rd.ops)))
+            thigh = {phys[b] for b in high}
+        step = _finalize(tops, n, geom, thigh, trounds)
+        desc, L, h = step.desc, geom.min_low, geom.m - geom.min_low
+        nxt = pending[k + 1] if permute and k + 1 < len(pending) and not isinstance(pending[k + 1], SingleStep) else None
+        if nxt is None:
+            wphys = list(range(n))
+        else:
+            ngeom, nhigh, _ = nxt
+            near = list(range(ngeom.min_low, ngeom.min_low + len(nhigh)))
+            wphys = [None] * n
+            for b in range(L):
+                wphys[b] = b
+            keep = [b for b in nhigh if phys[b] in near]             # already cheap: stay
+            for b in keep:
+                wphys[b] = phys[b]
+            free = [p_ for p_ in near if p_ not in {phys[b] for b in keep}]
+            for b in sorted(nhigh - set(keep), key=lambda b: phys[b]):
+                wphys[b] = free.pop(0)
+            taken = {w for w in wphys if w is not None}
+            rest = [p_ for p_ in range(L, n) if p_ not in taken]
+            for b in sorted((b for b in range(L, n) if wphys[b] is None), key=lambda b: phys[b]):
+                wphys[b] = rest.pop(0)
+        inv = {phys[b]: b for b in range(n)}                          # physical (read side) -> logical
+        tile_pos = [desc.high_sorted[i] for i in range(h)]            # read position of tile bit L + i
+        for i, pos in enumerate(tile_pos):
+            desc.store_high_pos[i] = wphys[inv[pos]]
+        tileset = set(tile_pos)
+        blk = [p_ for p_ in range(L, n) if p_ not in tileset]         # read position of block-index bit j
+        assert len(blk) <= _lib.FUSED_MAX_BLK
+        for j, pos in enumerate(blk):
+            desc.store_blk_pos[j] = wphys[inv[pos]]
+        for s_ in range(geom.slots):
+            tl = desc.store_rb[s_]
+            desc.store_slot_off[s_] = 1 << (tl if tl < L else desc.store_high_pos[tl - L])
+        step.permutes = wphys != phys
+        phys = wphys
+        out.append(step)
+    assert phys == list(range(n))
+    return out
 
 
 def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rounds: list[_Round]) -> FusedStep:

@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 12
+#define DQ_ABI_VERSION 13
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -130,6 +130,7 @@ typedef struct {
 #define DQ_MAT_PAD 16
 
 #define DQ_FUSED_MAX_TBITS 9
+#define DQ_FUSED_MAX_BLK 24      /* block-index bits: n - m <= 24 */
 typedef struct {
     uint8_t rb[DQ_FUSED_MAX_SLOTS]; /* tile-local bit positions of the register slots, ascending */
     uint8_t tb[DQ_FUSED_MAX_TBITS]; /* tile-local bit position of thread-index bit i (the other m - slots
@@ -172,6 +173,16 @@ typedef struct {
      * 8-byte amplitudes, e ^ ((e >> 4) & 15) for 16-byte ones.  The swizzle is XOR-linear, so a thread's address
      * is swizzle(its base) * size XOR the table entry: one VALU op per access instead of five. */
     uint16_t lds_tab[DQ_FUSED_MAX_ROUNDS + 2][16];
+    /* Where the pass WRITES.  A pass may store its tile -- and its block index -- to other index bits (>= L) than
+     * it read them from: a bit permutation of the state on the way out, so that the qubits of the NEXT pass already
+     * sit in cheap (near) positions when that pass gathers them (scattered writes are nearly free on this memory
+     * system, gathered reads are not: DESIGN.md).  store_high_pos[i] = global bit that tile bit L + i is written
+     * to; store_blk_pos[j] = global bit that bit j of the block index (= the j-th lowest non-tile bit on the READ
+     * side) is written to.  Together a permutation of [L, n).  In-place passes (in == out) must use the read
+     * positions (store_high_pos == high_pos, store_blk_pos ascending): anything else needs in != out.
+     * store_slot_off is in write positions. */
+    uint8_t store_high_pos[DQ_FUSED_MAX_HIGH];
+    uint8_t store_blk_pos[DQ_FUSED_MAX_BLK];
 } DqFusedPass;
 
 /* Tile geometries this build was compiled with (m = slots + log2(threads)); variant 0 is the

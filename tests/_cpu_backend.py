@@ -60,10 +60,13 @@ class CpuTestBackend:
             assert sl == sorted(set(sl)), 'I/O slots must be ascending and distinct'
             assert all((q == s) if s < vb else (L <= q < m) for s, q in enumerate(sl)), 'I/O layout not coalesced'
 
-        for rbio, offs in ((desc.load_rb, desc.load_slot_off), (desc.store_rb, desc.store_slot_off)):
+        store_high = [desc.store_high_pos[i] for i in range(h)]
+        store_blk = [desc.store_blk_pos[j] for j in range(n - m)]
+        assert sorted(store_high + store_blk) == list(range(L, n)), 'write positions are not a permutation of [L, n)'
+        for rbio, offs, pos in ((desc.load_rb, desc.load_slot_off, high_pos), (desc.store_rb, desc.store_slot_off, store_high)):
             for sl in range(R):
                 tl = rbio[sl]
-                assert offs[sl] == 1 << (tl if tl < L else high_pos[tl - L]), 'slot offset table wrong'
+                assert offs[sl] == 1 << (tl if tl < L else pos[tl - L]), 'slot offset table wrong'
         def want_table(slots_l):
             period, esz = (4, 16) if is128 else (5, 8)
             out = []
@@ -88,6 +91,18 @@ class CpuTestBackend:
             tiles = ((tiles >> p) << (p + 1)) | (tiles & ((1 << p) - 1))
         idx = tiles[:, None] | glob[None, :]            # (ntiles, 2^m) global amplitude indices
         assert np.array_equal(np.sort(idx.reshape(-1)), np.arange(1 << n)), 'tiles do not partition the state'
+        # write side: tile bit L + i -> store_high_pos[i], block-index bit j -> store_blk_pos[j]
+        globw = e & ((1 << L) - 1)
+        for i in range(h):
+            globw |= ((e >> (L + i)) & 1) << store_high[i]
+        blk = np.arange(1 << (n - m), dtype=np.int64)
+        tilesw = np.zeros_like(blk)
+        for j in range(n - m):
+            tilesw |= ((blk >> j) & 1) << store_blk[j]
+        idxw = tilesw[:, None] | globw[None, :]
+        assert np.array_equal(np.sort(idxw.reshape(-1)), np.arange(1 << n)), 'written tiles do not partition the state'
+        if not np.array_equal(idx, idxw):
+            assert out.data_ptr() != state.data_ptr(), 'a permuting pass needs in != out'
 
         # matrices of the pass lie back to back in gate order, readable MAT_PAD entries past the end
         run = desc.mat_base
@@ -204,7 +219,7 @@ class CpuTestBackend:
                         ph = d[sel]
                         ok = tile_ok[:, None] & el_ok[None, :]
                         t = np.where(ok, ph * t, t)
-            x[b][idx] = t
+            x[b][idxw] = t          # (every index is written exactly once: idxw partitions the state)
         out.copy_(torch.from_numpy(x))
         return out
 

@@ -307,3 +307,4 @@ def test_random_circuits_under_every_scheduler_configuration(cpu_backend):
     from _helpers import check_fuzz_against_oracle
     check_fuzz_against_oracle(dq, n=13, seeds=(0, 1), depth=5)
     check_fuzz_against_oracle(dq, n=12, seeds=(2,), depth=5, double=True)
+    check_fuzz_against_oracle(dq, n=15, seeds=(3,), depth=8, batch=1)     # several passes: permuted stores matter

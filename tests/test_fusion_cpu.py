@@ -105,8 +105,8 @@ def test_descriptor_struct_sizes_match_header():
 
     assert ctypes.sizeof(_lib.DqFusedGate) == 32
     assert ctypes.sizeof(_lib.DqFusedRound) == 16
-    assert ctypes.sizeof(_lib.DqFusedPass) == 36 + 24 * 16 + 4 + 80 * 32 + 64 + 26 * 32
-    assert ctypes.sizeof(_lib.DqFusedPass) + 40 <= 4096      # the descriptor travels in the kernel-argument segment
+    assert ctypes.sizeof(_lib.DqFusedPass) == 36 + 24 * 16 + 4 + 80 * 32 + 64 + 26 * 32 + 12 + 24 + 4   # (+ 4 pad to 8)
+    assert ctypes.sizeof(_lib.DqFusedPass) + 48 <= 4096      # the descriptor travels in the kernel-argument segment
 
 
 def test_x_type_gates_commute_in_the_dag():
