@@ -50,7 +50,8 @@ for mode in args.modes.split(','):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.reps
     with torch.no_grad():
-        cir()                       # (its own plan when one-qubit runs are merged: planned once, outside the timing)
+        for _ in range(2):          # its own plan (merged one-qubit runs) and its second state buffer (permuted
+            cir()                   # stores) are made once, outside the timing
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cir()
