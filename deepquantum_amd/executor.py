@@ -290,9 +290,11 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         permute = False
         if CONFIG['permute_store'] and not inplace and n >= CONFIG['permute_min_bits']:
             permute = True
-            if state.is_cuda:
-                total = torch.cuda.get_device_properties(state.device).total_memory
-                permute = 2 * state.numel() * state.element_size() <= CONFIG['permute_mem_frac'] * total
+            if state.is_cuda:     # the second buffer must fit: a share of the device, and what is free right now
+                nbytes = state.numel() * state.element_size()
+                free, total = torch.cuda.mem_get_info(state.device)
+                free += torch.cuda.memory_reserved(state.device) - torch.cuda.memory_allocated(state.device)
+                permute = 2 * nbytes <= CONFIG['permute_mem_frac'] * total and 1.05 * nbytes <= free
         plan = make_plan(prims, n, is128, permute)
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies
