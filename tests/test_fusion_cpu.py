@@ -223,3 +223,48 @@ def test_one_qubit_runs_are_merged_and_the_state_is_unchanged(cpu_backend):
         dq.executor.CONFIG['merge_min_amps'] = keep
     assert merged < plain
     assert torch.allclose(got, ref, atol=2e-6)
+
+
+def test_permuted_stores_make_every_later_tile_contiguous(cpu_backend):
+    """fusion._place_writes: with permuted stores every pass after the first gathers exactly the bits right above
+    the contiguous run, the write positions of every pass are a permutation of [L, n), the composition of all passes
+    is the identity (the state comes back in canonical order) -- and the result equals the in-place schedule's."""
+    n = 18
+    ops, mats = random_ops(n, 200, 5, kinds=('gen', 'x', 'diag', 'gen2'))
+    mats = mats.to(torch.complex64)
+    geom = fusion.default_geometry(False)
+    geom.permute_store = True
+    geom.fallback.permute_store = True
+    steps = fusion.schedule(ops, n, geom)
+    fused = [s for s in steps if isinstance(s, fusion.FusedStep)]
+    assert len(fused) >= 3 and any(s.permutes for s in fused)
+    where = list(range(n))                      # where[p] = which canonical bit currently lives at physical bit p
+    for k, st in enumerate(fused):
+        d, L, h = st.desc, st.desc.L, st.desc.h
+        read = [d.high_sorted[i] for i in range(h)]
+        if k > 0 and fused[k - 1].permutes:
+            assert read == list(range(L, L + h)), 'tile not contiguous after a permuting pass'
+        blk = [p for p in range(L, n) if p not in read]
+        wr = {read[i]: d.store_high_pos[i] for i in range(h)}
+        wr.update({p: d.store_blk_pos[j] for j, p in enumerate(blk)})
+        assert sorted(wr.values()) == list(range(L, n))
+        assert st.permutes == any(a != b for a, b in wr.items())
+        new = list(where)
+        for src, dst in wr.items():
+            new[dst] = where[src]
+        where = new
+    assert where == list(range(n)), 'the passes do not compose to the canonical order'
+    x = torch.randn(2, 1 << n, dtype=torch.complex64)
+    km = fusion.kernel_matrices(steps, ops, mats)
+    cur = x.clone()
+    for st in steps:
+        if isinstance(st, fusion.FusedStep):
+            nxt = torch.empty_like(cur)
+            backend.apply_fused(cur, km, 0, st.desc, out=nxt)
+            cur = nxt
+        else:
+            op = ops[st.op]
+            d2 = 1 << op.k
+            cur = backend.apply_gate(cur, mats[op.mat : op.mat + d2 * d2].reshape(d2, d2), op.targets, op.controls)
+    ref = run_reference(x, ops, mats)
+    assert (cur - ref).abs().max().item() < 2e-5
