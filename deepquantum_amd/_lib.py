@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
@@ -91,6 +91,7 @@ _SIGNATURES = {
     'dq_last_error': (C.c_char_p, []),
     'dq_device_info': (_i, [_ip, C.POINTER(_i64), C.POINTER(_i64)]),
     'dq_fused_geometry': (_i, [_i, _i, _ip, _ip, _ip]),
+    'dq_fused_set_tiles_per_wg': (_i, [_i]),
     'dq_reduce_ws_bytes': (_i64, [_i64]),
     'dq_apply_gate_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _ip, _i, _ip, _i, _i64, _vp]),
     'dq_apply_fused_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp]),

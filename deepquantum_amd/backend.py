@@ -169,7 +169,9 @@ _ws_cache: dict[tuple, torch.Tensor] = {}
 
 
 def _workspace(state: torch.Tensor) -> torch.Tensor:
-    key = (state.device, state.shape[0])
+    # one workspace per (device, batch, stream): reductions enqueued on two streams must not share scratch
+    stream = torch.cuda.current_stream(state.device).cuda_stream if state.is_cuda else 0
+    key = (state.device, state.shape[0], stream)
     ws = _ws_cache.get(key)
     if ws is None:
         nbytes = _lib.load().dq_reduce_ws_bytes(state.shape[0])

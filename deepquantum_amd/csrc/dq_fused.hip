@@ -33,6 +33,12 @@ namespace dq {
 // pair, the operand shape of the packed VALU ops and of the tied inline-asm operands below.
 template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
 template <typename T> using amp = vec2<T>;
+// Gate matrices are read through the CONSTANT address space: nothing in a pass writes them, and a constant pointer with
+// a workgroup-uniform address is read by scalar loads (lgkmcnt).  As plain global pointers hipcc reads them with vector
+// loads, whose s_waitcnt vmcnt(..) would also wait for the next tile's prefetch (one in-order counter).
+template <typename T> using cmat = const __attribute__((address_space(4))) amp<T>*;
+__device__ __forceinline__ uint64_t as_u64(const vec2<float> v) { return __builtin_bit_cast(uint64_t, v); }
+__device__ __forceinline__ uint64_t as_u64(const vec2<double>) { return 0; }   // (never used: the f32 blocks only)
 
 // ---- gate bodies on the register file ---------------------------------------------------------------
 // MODE 0: general complex 2x2.  MODE 1: all four entries real (H, Ry, X, ...).  MODE 2: real diagonal,
@@ -140,8 +146,8 @@ __device__ __forceinline__ void x1_body(amp<T> (&a)[1 << R], const unsigned reg_
     }
 }
 
-template <typename T, int R, int Q, int Q2>
-__device__ __forceinline__ void gen2_body(amp<T> (&a)[1 << R], const amp<T>* __restrict__ mp, const unsigned reg_cmask,
+template <typename T, int R, int Q, int Q2, typename MP>
+__device__ __forceinline__ void gen2_body(amp<T> (&a)[1 << R], MP mp, const unsigned reg_cmask,
                                           const bool thr_ok) {
     amp<T> m[16];
 #pragma unroll
@@ -164,8 +170,8 @@ __device__ __forceinline__ void gen2_body(amp<T> (&a)[1 << R], const amp<T>* __r
 // 4x4 matrix promised REAL by the host (DqFusedMode REAL on a GEN2 gate: the superoperators of the noise
 // channels): entry by entry, skipping the exact zeros with a uniform branch -- a depolarizing channel has 6
 // non-zero entries of 16, amplitude damping 5 -- and one real-times-complex FMA per entry and amplitude group.
-template <typename T, int R, int Q, int Q2>
-__device__ __forceinline__ void gen2_body_real(amp<T> (&a)[1 << R], const amp<T>* __restrict__ mp,
+template <typename T, int R, int Q, int Q2, typename MP>
+__device__ __forceinline__ void gen2_body_real(amp<T> (&a)[1 << R], MP mp,
                                                const unsigned reg_cmask, const bool thr_ok) {
     constexpr int NG = (1 << R) / 4;
     int base[NG];
@@ -219,16 +225,15 @@ __device__ __forceinline__ void dispatch_gen1_q(amp<T> (&a)[1 << R], int q, cons
 // `mode` = matrix structure promised by the host from the gate class (DqFusedMode): 0 general, 1 all
 // entries real (H, Ry, X...), 2 real diagonal + imaginary off-diagonal (Rx).  Multiplications by the exact
 // zeros are skipped: half the VALU work for the common gates.
-template <typename T, int R>
-__device__ __forceinline__ void dispatch_gen1(amp<T> (&a)[1 << R], int q, const amp<T>* __restrict__ mp,
+template <typename T, int R, typename MP>
+__device__ __forceinline__ void dispatch_gen1(amp<T> (&a)[1 << R], int q, MP mp,
                                               unsigned mode, unsigned reg_cmask, bool lane_pred, bool thr_ok) {
     if constexpr (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS) {
         if (reg_cmask == 0) {
             // uncontrolled (or controlled only by thread / outside bits): straight-line asm block; a control
             // on a thread bit is ONE exec-masked region around it (asm is never if-converted)
             if (!lane_pred || thr_ok) {
-                const uint64_t* mw = reinterpret_cast<const uint64_t*>(mp);
-                const uint64_t mq[4] = {mw[0], mw[1], mw[2], mw[3]};
+                const uint64_t mq[4] = {as_u64(mp[0]), as_u64(mp[1]), as_u64(mp[2]), as_u64(mp[3])};
                 if (mode == 1) dispatch_gen1_block_f32<1>(a, q, mq);
                 else if (mode == 2) dispatch_gen1_block_f32<2>(a, q, mq);
                 else dispatch_gen1_block_f32<0>(a, q, mq);
@@ -293,15 +298,15 @@ __device__ __forceinline__ void dispatch_x1(amp<T> (&a)[1 << R], int q, unsigned
     }
 }
 
-template <typename T, int R, int Q, int Q2>
-__device__ __forceinline__ void gen2_any(amp<T> (&a)[1 << R], const amp<T>* __restrict__ mp, unsigned mode,
+template <typename T, int R, int Q, int Q2, typename MP>
+__device__ __forceinline__ void gen2_any(amp<T> (&a)[1 << R], MP mp, unsigned mode,
                                          unsigned reg_cmask, bool thr_ok) {
     if (mode == DQ_MODE_REAL) gen2_body_real<T, R, Q, Q2>(a, mp, reg_cmask, thr_ok);
     else gen2_body<T, R, Q, Q2>(a, mp, reg_cmask, thr_ok);
 }
 
-template <typename T, int R, int Q>
-__device__ __forceinline__ void dispatch_gen2_q2(amp<T> (&a)[1 << R], int q2, const amp<T>* __restrict__ mp,
+template <typename T, int R, int Q, typename MP>
+__device__ __forceinline__ void dispatch_gen2_q2(amp<T> (&a)[1 << R], int q2, MP mp,
                                                  unsigned mode, unsigned reg_cmask, bool thr_ok) {
     switch (q2) {
         case 0:
@@ -319,8 +324,8 @@ __device__ __forceinline__ void dispatch_gen2_q2(amp<T> (&a)[1 << R], int q2, co
     }
 }
 
-template <typename T, int R>
-__device__ __forceinline__ void dispatch_gen2(amp<T> (&a)[1 << R], int q, int q2, const amp<T>* __restrict__ mp,
+template <typename T, int R, typename MP>
+__device__ __forceinline__ void dispatch_gen2(amp<T> (&a)[1 << R], int q, int q2, MP mp,
                                               unsigned mode, unsigned reg_cmask, bool thr_ok) {
     switch (q) {
         case 0: dispatch_gen2_q2<T, R, 0>(a, q2, mp, mode, reg_cmask, thr_ok); break;
@@ -352,13 +357,18 @@ struct FusedKernArgs {
     int64_t mat_bstride;
     int64_t in_bstride;
     int n;
+    int tpw;
     DqFusedPass p;
 };
 
-template <typename T, int R, int LOGT>
+// PF: a workgroup walks `tpw` consecutive tiles and requests tile t + 1 from HBM (into spare VGPRs) before it starts
+// the rounds of tile t, so the load latency of every tile but the first hides under the gates of its predecessor and
+// the stores of tile t drain under the gates of tile t + 1.  Two 64-KiB workgroups per CU (what the tile buffer allows)
+// cannot keep enough bytes in flight on their own: load -> gates -> store is strictly serial inside one workgroup.
+template <typename T, int R, int LOGT, bool PF>
 __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in, amp<T>* out,
                                                                const amp<T>* __restrict__ mats, int64_t mat_bstride,
-                                                               int64_t in_bstride, int n, const DqFusedPass p) {
+                                                               int64_t in_bstride, int n, int tpw, const DqFusedPass p) {
     constexpr int M = R + LOGT;
     constexpr int NA = 1 << R;
     constexpr int VB = (sizeof(T) == 4) ? 1 : 0;  // low slots of the canonical layout (16 B per lane)
@@ -372,8 +382,36 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     };
     (void)dq_smem;
 
-    const unsigned tid = threadIdx.x;
-    const uint32_t* hw = reinterpret_cast<const uint32_t*>(&p);
+    // ---- which tiles / which batch element (workgroup-uniform) ----
+    // Normally blockIdx.x = group of `tpw` consecutive tiles, blockIdx.y = sample.  When all samples read ONE input
+    // state (in_bstride == 0; the host launches that pass with tpw = 1) the B workgroups of a tile are instead made
+    // neighbours in dispatch order AND placed on the same XCD (workgroups go round-robin over the 8 XCDs), so the
+    // tile is fetched from HBM once and served to the other B - 1 from that XCD's L2.
+    unsigned tile_id = blockIdx.x * (unsigned)tpw, sample = blockIdx.y;
+#ifndef DQ_NO_XCD_REMAP
+    if (in_bstride == 0 && (gridDim.x & 7u) == 0) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.y;
+        const unsigned group = lin / (8u * nb), r = lin % (8u * nb);
+        sample = r >> 3;
+        tile_id = group * 8u + (r & 7u);
+    }
+#endif
+    // the raw 16-byte pieces of a tile as they come from memory: NP pieces per thread
+    using Piece = typename std::conditional<VB == 1, float4, V>::type;
+    constexpr int NP = VB == 1 ? NA / 2 : NA;
+    V a[NA];
+  for (int tile_no = 0; tile_no < tpw; ++tile_no, ++tile_id) {
+    // Everything a tile needs is derived INSIDE the loop from two laundered values (the kernel-argument pointer and the
+    // thread id): hoisted out as loop invariants, the decoded header and the per-thread offsets would stay live across
+    // the gate loop -- whose assembly block owns s[80:99] -- and spill (measured: 50 SGPR spills, 142 VGPRs).
+    uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(karg));
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    // (address space 4 = constant: keeps the descriptor reads scalar loads; a plain pointer made from an integer is
+    // a flat one and would be read per lane)
+    typedef const __attribute__((address_space(4))) uint32_t* KArgWords;
+    const KArgWords hw = (KArgWords)(karg + offsetof(FusedKernArgs, p));
     static_assert(DQ_FAST32_IDS == DQ_FAST_IDS, "tools/gen_fused_asm.py and include/dq_hip.h disagree on the handler ids");
     static_assert(DQ_FUSED_MAX_HIGH == 12 && offsetof(DqFusedPass, high_pos) == 4 && offsetof(DqFusedPass, high_sorted) == 16 &&
                       offsetof(DqFusedPass, load_rb) == 28 && offsetof(DqFusedPass, store_rb) == 32,
@@ -385,20 +423,6 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         return ((i < 4 ? w0 : (i < 8 ? w1 : w2)) >> (8 * (i & 3))) & 0xffu;
     };
 
-    // ---- which tile / which batch element (workgroup-uniform) ----
-    // Normally blockIdx.x = tile, blockIdx.y = sample.  When all samples read ONE input state (in_bstride == 0)
-    // the B workgroups of a tile are instead made neighbours in dispatch order AND placed on the same XCD
-    // (workgroups go round-robin over the 8 XCDs), so the tile is fetched from HBM once and served to the other
-    // B - 1 from that XCD's L2.
-    unsigned tile_id = blockIdx.x, sample = blockIdx.y;
-#ifndef DQ_NO_XCD_REMAP
-    if (in_bstride == 0 && (gridDim.x & 7u) == 0) {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.y;
-        const unsigned group = lin / (8u * nb), r = lin % (8u * nb);
-        sample = r >> 3;
-        tile_id = group * 8u + (r & 7u);
-    }
-#endif
     // Are the gathered bits simply the bits right above the contiguous run, in order (high_pos[i] == L + i)?  With
     // permuted stores that is every pass but the first: the tile is one contiguous block, its base is a shift and a
     // tile-local index IS the offset.  (Three masked word compares; the general path deposits bit by bit.)
@@ -412,22 +436,23 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         };
         contig = same(hp0, 0) && same(hp1, 1) && same(hp2, 2);
     }
-    uint64_t tile;
-    if (contig) {
-        tile = (uint64_t)tile_id << (L + h);
-    } else {
-        tile = (uint64_t)tile_id << L;
-        for (int i = 0; i < h; ++i) tile = insert_zero(tile, (int)byte_of(hs0, hs1, hs2, i));
-    }
+    // global index bits a tile fixes (= offset of its first amplitude inside the state)
+    auto tile_of = [&](unsigned id) __attribute__((always_inline)) -> uint64_t {
+        if (contig) return (uint64_t)id << (L + h);
+        uint64_t tl = (uint64_t)id << L;
+        for (int i = 0; i < h; ++i) tl = insert_zero(tl, (int)byte_of(hs0, hs1, hs2, i));
+        return tl;
+    };
     // in_bstride = 2^n normally; 0 when every batch element starts from the same (single) input state
-    const V* pin = in + (uint64_t)sample * (uint64_t)in_bstride + tile;
+    const V* const pin0 = in + (uint64_t)sample * (uint64_t)in_bstride;
     // write side: block-index bit j goes to global bit store_blk_pos[j], tile bit L + i to store_high_pos[i]
     // (both equal to the read positions for an in-place pass; include/dq_hip.h)
     constexpr int SHP_W0 = offsetof(DqFusedPass, store_high_pos) / 4, SBP_W0 = offsetof(DqFusedPass, store_blk_pos) / 4;
     static_assert(offsetof(DqFusedPass, store_high_pos) % 4 == 0 && offsetof(DqFusedPass, store_blk_pos) % 4 == 0, "");
-    uint64_t tile_w = 0;
-    {   // position bytes fetched once (six words), the loop unrolled with constant byte positions: no scalar load per
+    auto tile_w_of = [&](unsigned id) __attribute__((always_inline)) -> uint64_t {
+        // position bytes fetched once (six words), the loop unrolled with constant byte positions: no scalar load per
         // bit.  Block-index bits above n - m are zero, so whatever their position bytes hold contributes nothing.
+        uint64_t tw = 0;
         const int nblk = n - L - h;
         uint32_t bw[DQ_FUSED_MAX_BLK / 4];
 #pragma unroll
@@ -437,11 +462,12 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             if (4 * w < nblk) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    tile_w |= (uint64_t)((tile_id >> (4 * w + k)) & 1u) << ((bw[w] >> (8 * k)) & 0x3fu);
+                    tw |= (uint64_t)((id >> (4 * w + k)) & 1u) << ((bw[w] >> (8 * k)) & 0x3fu);
             }
         }
-    }
-    V* pout = out + ((uint64_t)sample << n) + tile_w;
+        return tw;
+    };
+    V* const pout0 = out + ((uint64_t)sample << n);
     auto glob_w = [&](unsigned e) __attribute__((always_inline)) -> uint64_t {
         uint64_t g = e & ((1u << L) - 1u);
         for (int i = 0; i < h; ++i)
@@ -459,37 +485,51 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     };
 
     // ---- load layout: slots from the descriptor, thread bits = remaining tile bits ascending ----
-    unsigned tbase = tid;  // current thread base (tile-local)
+    unsigned tbase0 = tid;  // thread base (tile-local) in the load layout
 #pragma unroll
-    for (int s = 0; s < R; ++s) tbase = (unsigned)insert_zero(tbase, (int)((lrb >> (8 * s)) & 0xffu));
+    for (int s = 0; s < R; ++s) tbase0 = (unsigned)insert_zero(tbase0, (int)((lrb >> (8 * s)) & 0xffu));
+    unsigned tbase = tbase0;  // current thread base
 
-    V a[NA];
+    // per-thread offset of the load layout inside a tile, and what each register slot adds to it
+    const uint64_t gt_load = glob(tbase0);
+    uint64_t gs_load[R];
     {
-        const uint64_t gt = glob(tbase);
-        const uint64_t* so = reinterpret_cast<const uint64_t*>(hw + offsetof(DqFusedPass, load_slot_off) / 4);
-        uint64_t gs[R];
+        const __attribute__((address_space(4))) uint64_t* so = (const __attribute__((address_space(4))) uint64_t*)(hw + offsetof(DqFusedPass, load_slot_off) / 4);
 #pragma unroll
-        for (int s = 0; s < R; ++s) gs[s] = so[s];
-        if constexpr (VB == 1) {
+        for (int s = 0; s < R; ++s) gs_load[s] = so[s];
+    }
+    auto request = [&](Piece (&dst)[NP], const V* pin) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NA; j += 2) {
-                uint64_t o = gt;
+        for (int i = 0; i < NP; ++i) {
+            const int j = VB == 1 ? 2 * i : i;
+            uint64_t o = gt_load;
 #pragma unroll
-                for (int s = 1; s < R; ++s)
-                    if ((j >> s) & 1) o += gs[s];
-                const float4 v = *reinterpret_cast<const float4*>(pin + o);
-                a[j] = amp<T>{v.x, v.y};
-                a[j + 1] = amp<T>{v.z, v.w};
+            for (int s = VB; s < R; ++s)
+                if ((j >> s) & 1) o += gs_load[s];
+            dst[i] = *reinterpret_cast<const Piece*>(pin + o);
+        }
+    };
+    auto unpack = [&](const Piece (&src)[NP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if constexpr (VB == 1) {
+                a[2 * i] = amp<T>{src[i].x, src[i].y};
+                a[2 * i + 1] = amp<T>{src[i].z, src[i].w};
+            } else {
+                a[i] = src[i];
             }
-        } else {
+        }
+    };
+    if (tile_no == 0) {
+        Piece first[NP];
+        request(first, pin0 + tile_of(tile_id));
+        unpack(first);
+        // complete HERE: were the first tile still in flight where this path joins the loop, hipcc's wait-count
+        // bookkeeping would merge the two paths into an s_waitcnt vmcnt(0) in front of the gate loop, which every
+        // later tile would then spend waiting for its successor's prefetch
+        if constexpr (PF) {
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                uint64_t o = gt;
-#pragma unroll
-                for (int s = 0; s < R; ++s)
-                    if ((j >> s) & 1) o += gs[s];
-                a[j] = pin[o];
-            }
+            for (int j = 0; j < NA; ++j) asm volatile("" : "+v"(a[j]));
         }
     }
 
@@ -524,24 +564,31 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         tbase = ntbase;
     };
 
-    const uint64_t tile_global = tile;  // global index bits fixed for this workgroup (outside the tile)
     constexpr bool FAST32 = (sizeof(T) == 4 && R == 4 && DQ_USE_ASM_BLOCKS);
     constexpr bool FAST64 = (sizeof(T) == 8 && R == 3 && DQ_USE_ASM_BLOCKS);
     constexpr bool FAST = FAST32 || FAST64;
     // Gate records are fetched with explicit scalar loads from the kernel-argument segment (the descriptor
     // is passed by value; its address must not be taken through `&p`, that would force a private copy).
-    const uint64_t kgates = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FusedKernArgs, p) +
-                            offsetof(DqFusedPass, gates);
+    const uint64_t kgates = karg + offsetof(FusedKernArgs, p) + offsetof(DqFusedPass, gates);
 
     // The descriptor is read as 32-bit words (scalar loads; gfx950 has no sub-dword s_load) and decoded
     // with SALU bit ops, so no vector memory instruction is spent on it.
-    const uint32_t* pw = reinterpret_cast<const uint32_t*>(&p);
+    const KArgWords pw = hw;
     constexpr int ROUND_W0 = offsetof(DqFusedPass, rounds) / 4;
     constexpr int GATE_W0 = offsetof(DqFusedPass, gates) / 4;
     const int nrounds = (int)(pw[0] >> 24);
+    const uint64_t mbase_u = (uint64_t)mbase;
+    const uint64_t tile_global = tile_of(tile_id);  // global index bits fixed for this tile (outside the tile)
+    // tile t + 1 is requested now and consumed after the store of tile t
+    Piece nx[NP];
+    const bool more = PF && tile_no + 1 < tpw;
+    if constexpr (PF) {
+        if (more) request(nx, pin0 + tile_of(tile_id + 1u));
+    }
+    tbase = tbase0;
+    cur_tab = 0;
     // running byte offset of the current gate's matrix from `mbase` (32 bits: SMEM takes base pair + SGPR offset)
     uint32_t moff = pw[offsetof(DqFusedPass, mat_base) / 4] * (uint32_t)sizeof(V);
-    const uint64_t mbase_u = (uint64_t)mbase;
     T hscale = T(1);   // product of the deferred Hadamard factors of this pass (uniform)
     bool had = false;
     unsigned last_flags = 0;
@@ -619,7 +666,10 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             const unsigned kind = g0 & 0xffu, q = (g0 >> 8) & 0xffu, q2 = (g0 >> 16) & 0xffu, loc = g0 >> 24;
             const unsigned loc2 = g1 & 0xffu;
             const bool thr_ok = (tbase & thr_cmask) == thr_cmask;
-            const V* mp = mbase + gmat;
+            // (the complex128 kernels keep plain global reads: sixteen 16-byte entries of a two-qubit matrix do not fit
+            // the scalar registers, and they do not prefetch)
+            using MatPtr = typename std::conditional<PF, cmat<T>, const V*>::type;
+            const MatPtr mp = (MatPtr)mbase_u + gmat;
             switch (kind) {
                 case DQ_FG_GEN1:  // (a Hadamard that is not on a straight-line handler is just a real matrix)
                     dispatch_gen1<T, R>(a, q, mp, loc == DQ_MODE_HAD ? (unsigned)DQ_MODE_REAL : loc, reg_cmask, thr_cmask != 0, thr_ok);
@@ -678,8 +728,9 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     }
 
     {
+        V* const pout = pout0 + tile_w_of(tile_id);
         const uint64_t gt = glob_w(tbase);
-        const uint64_t* so = reinterpret_cast<const uint64_t*>(hw + offsetof(DqFusedPass, store_slot_off) / 4);
+        const __attribute__((address_space(4))) uint64_t* so = (const __attribute__((address_space(4))) uint64_t*)(hw + offsetof(DqFusedPass, store_slot_off) / 4);
         uint64_t gs[R];
 #pragma unroll
         for (int s = 0; s < R; ++s) gs[s] = so[s];
@@ -708,6 +759,16 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             }
         }
     }
+    if constexpr (PF) {
+        if (more) unpack(nx);
+    } else {
+        if (tile_no + 1 < tpw) {
+            Piece nxt[NP];
+            request(nxt, pin0 + tile_of(tile_id + 1u));
+            unpack(nxt);
+        }
+    }
+  }
 }
 
 struct FusedVariant {
@@ -880,21 +941,31 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
     return DQ_OK;
 }
 
-template <typename T, int R, int LOGT>
+// Tiles per workgroup of the prefetching variants (complex64): 0 = pick by size.  dq_fused_set_tiles_per_wg() is a
+// tuning / A-B knob, not part of the data path's contract.
+static int g_tiles_per_wg = 0;
+
+template <typename T, int R, int LOGT, bool PF>
 static void launch_variant(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n,
                            int64_t batch, const DqFusedPass* pass, hipStream_t s) {
     constexpr int M = R + LOGT;
     const size_t lds_bytes = sizeof(amp<T>) << M;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_pass_kernel<T, R, LOGT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
+    // (cheap; not cached: a process may drive several devices, and the attribute is per device)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_pass_kernel<T, R, LOGT, PF>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    // tiles per workgroup: enough workgroups must remain to fill the chip several times over (256 CUs x 2..5
+    // resident workgroups), and the pass that reads one shared input state keeps its XCD-aware order (one tile each)
+    int tpw_log = 0;
+    if (PF && in_bstride != 0) {
+        const int want = g_tiles_per_wg > 0 ? g_tiles_per_wg : 4;
+        while ((2 << tpw_log) <= want && n - M - (tpw_log + 1) >= 0 &&
+               ((int64_t)batch << (n - M - (tpw_log + 1))) >= 8192)
+            ++tpw_log;
     }
-    dim3 grid((unsigned)(1ull << (n - M)), (unsigned)batch);
-    hipLaunchKernelGGL((fused_pass_kernel<T, R, LOGT>), grid, dim3(1u << LOGT), lds_bytes, s,
+    dim3 grid((unsigned)(1ull << (n - M - tpw_log)), (unsigned)batch);
+    hipLaunchKernelGGL((fused_pass_kernel<T, R, LOGT, PF>), grid, dim3(1u << LOGT), lds_bytes, s,
                        static_cast<const amp<T>*>(in), static_cast<amp<T>*>(out), static_cast<const amp<T>*>(mats),
-                       mat_bstride, in_bstride, n, *pass);
+                       mat_bstride, in_bstride, n, 1 << tpw_log, *pass);
 }
 
 template <typename T>
@@ -945,16 +1016,25 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     }
     hipStream_t s = as_stream(stream);
     if constexpr (!is128) {
-        if (v.m == 12) launch_variant<float, 4, 8>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
-        else launch_variant<float, 4, 9>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+        if (v.m == 12) launch_variant<float, 4, 8, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+        else launch_variant<float, 4, 9, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
     } else {
-        if (v.m == 11) launch_variant<double, 3, 8>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
-        else launch_variant<double, 3, 9>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+        if (v.m == 11) launch_variant<double, 3, 8, false>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+        else launch_variant<double, 3, 9, false>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
     }
     return check_launch("dq_apply_fused");
 }
 
 }  // namespace dq
+
+extern "C" int dq_fused_set_tiles_per_wg(int tiles) {
+    if (tiles < 0 || tiles > 64 || (tiles & (tiles - 1))) {
+        dq::set_error("dq_fused_set_tiles_per_wg: %d is not 0 (automatic) or a power of two <= 64", tiles);
+        return DQ_ERR_ARG;
+    }
+    dq::g_tiles_per_wg = tiles;
+    return DQ_OK;
+}
 
 extern "C" int dq_fused_geometry(int is_c128, int variant, int* m, int* slots, int* threads) {
     if (variant < 0 || variant >= dq::kNumVariants) {

@@ -294,7 +294,9 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 nbytes = state.numel() * state.element_size()
                 free, total = torch.cuda.mem_get_info(state.device)
                 free += torch.cuda.memory_reserved(state.device) - torch.cuda.memory_allocated(state.device)
-                permute = 2 * nbytes <= CONFIG['permute_mem_frac'] * total and 1.05 * nbytes <= free
+                # what still has to be allocated: the second buffer, and the private working copy unless the caller's
+                # state is updated in place (never here: `inplace` runs do not permute)
+                permute = 2 * nbytes <= CONFIG['permute_mem_frac'] * total and 2.05 * nbytes <= free
         plan = make_plan(prims, n, is128, permute)
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies

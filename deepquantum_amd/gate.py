@@ -546,12 +546,12 @@ class CombinedSingleGate(SingleGate):
         self.update_matrix()
 
     def inverse(self) -> 'CombinedSingleGate':
-        gates = nn.ModuleList([g.inverse() for g in reversed(self.gates)])
+        # a NEW gate, as the reference builds one (gate.py:1883-1900): a shallow copy would share ``_modules`` with
+        # ``self``, so assigning ``inv.gates`` would also replace the original's factors
         name = self.name + '_dagger' if isinstance(self.name, str) else self.name
-        inv = copy(self)
-        inv.gates = gates
-        inv.name = name
-        return inv
+        return CombinedSingleGate(gates=[g.inverse() for g in reversed(self.gates)], name=name, nqubit=self.nqubit,
+                                  wires=self.wires, controls=self.controls, condition=self.condition,
+                                  den_mat=self.den_mat, tsr_mode=self.tsr_mode)
 
 
 # ======================================================================================================
@@ -714,8 +714,20 @@ class UAnyGate(ArbitraryGate):
         eye = torch.eye(unitary.shape[-1], dtype=unitary.dtype, device=unitary.device)
         assert torch.allclose(unitary @ unitary.mH, eye, rtol=1e-5, atol=1e-4), 'Please check the unitary matrix'
         self.register_buffer('matrix', unitary)
-        off = unitary - torch.diag(unitary.diagonal())
-        self._kernel_kind = 'diag' if (len(self.wires) <= 2 and bool((off == 0).all())) else 'gen'
+        self._kind_cache: tuple | None = None
+
+    @property
+    def _kernel_kind(self) -> str:
+        """'diag' when the CURRENT matrix is exactly diagonal (the diagonal kernels ignore off-diagonal entries),
+        re-derived whenever the buffer is replaced or written in place (``load_state_dict``, ``.to``): the test
+        reads the matrix values, so its result is cached on the buffer's identity and version counter."""
+        m = self.matrix
+        key = (m.data_ptr(), m._version, m.device, m.dtype)
+        if self._kind_cache is None or self._kind_cache[0] != key:
+            diag_only = m.ndim == 2 and len(self.wires) <= 2 and bool(
+                (m == torch.diag_embed(m.diagonal(dim1=-2, dim2=-1))).all())
+            self._kind_cache = (key, 'diag' if diag_only else 'gen')
+        return self._kind_cache[1]
 
     def update_matrix(self) -> torch.Tensor:
         return self.matrix.mH if self.inv_mode else self.matrix

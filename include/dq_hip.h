@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 13
+#define DQ_ABI_VERSION 14
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -188,6 +188,10 @@ typedef struct {
 /* Tile geometries this build was compiled with (m = slots + log2(threads)); variant 0 is the
  * default, DQ_ERR_ARG past the last one.  The kernel is selected by pass->m. */
 int dq_fused_geometry(int is_c128, int variant, int* m, int* slots, int* threads);
+/* Tuning knob (A/B measurements; not part of the data path's contract): a complex64 workgroup walks `tiles`
+ * consecutive tiles of a pass and requests tile t + 1 from HBM while the gates of tile t run.  0 = automatic (4 where
+ * the grid stays large enough), 1 = one tile per workgroup (no prefetch), otherwise a power of two <= 64. */
+int dq_fused_set_tiles_per_wg(int tiles);
 /* `pass` is a HOST pointer; it is copied into the kernel argument segment.  in == out allowed.
  * Requires n >= pass->m. */
 int dq_apply_fused_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,

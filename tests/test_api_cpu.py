@@ -308,3 +308,29 @@ def test_random_circuits_under_every_scheduler_configuration(cpu_backend):
     check_fuzz_against_oracle(dq, n=13, seeds=(0, 1), depth=5)
     check_fuzz_against_oracle(dq, n=12, seeds=(2,), depth=5, double=True)
     check_fuzz_against_oracle(dq, n=15, seeds=(3,), depth=8, batch=1)     # several passes: permuted stores matter
+
+
+def test_combined_gate_inverse_leaves_the_original_alone():
+    """inverse() builds a new gate (reference gate.py:1883-1900); the original's factors and matrix stay."""
+    g = dq.gate.CombinedSingleGate([dq.gate.Rx(inputs=0.3), dq.gate.Hadamard(), dq.gate.Rz(inputs=0.7)], nqubit=2, wires=[1])
+    before = g.update_matrix().clone()
+    factors = list(g.gates)
+    inv = g.inverse()
+    assert list(g.gates) == factors and inv.gates is not g.gates
+    assert (g.update_matrix() - before).abs().max().item() == 0.0
+    assert (inv.update_matrix() @ before - torch.eye(2)).abs().max().item() < 1e-6
+    cir = dq.QubitCircuit(2)
+    cir.add(g)
+    cir.inverse()
+    assert (g.update_matrix() - before).abs().max().item() == 0.0
+
+
+def test_uany_kernel_kind_follows_the_matrix():
+    """A diagonal user matrix takes the diagonal kernels only while it IS diagonal (state_dict reload, in-place writes)."""
+    u = dq.gate.UAnyGate(torch.diag(torch.tensor([1, 1j], dtype=torch.cfloat)), nqubit=2, wires=[0])
+    assert u._kernel_kind == 'diag' and u.prims()[0].kind == 'diag'
+    x = dq.gate.UAnyGate(torch.tensor([[0, 1], [1, 0]], dtype=torch.cfloat), nqubit=2, wires=[0])
+    u.load_state_dict(x.state_dict())
+    assert u._kernel_kind == 'gen' and u.prims()[0].kind == 'gen'
+    u.matrix = torch.diag(torch.tensor([1, -1], dtype=torch.cfloat))
+    assert u._kernel_kind == 'diag'
