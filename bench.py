@@ -70,6 +70,8 @@ def parse_args():
                     help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
     ap.add_argument('--tiles-per-wg', type=int, default=None,
                     help='A/B: tiles a complex64 workgroup walks with next-tile prefetch (1 = off; default: library)')
+    ap.add_argument('--tiles-per-wg', type=int, default=None,
+                    help='A/B: tiles a complex64 workgroup walks with next-tile prefetch (1 = off; default: library)')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
     return ap.parse_args()
 
@@ -232,6 +234,10 @@ def main():
     if args.no_permute_store:
         dq.executor.CONFIG['permute_store'] = False
 
+    if args.tiles_per_wg is not None:
+        from deepquantum_amd import _lib
+
+        _lib.check(_lib.load().dq_fused_set_tiles_per_wg(args.tiles_per_wg), 'dq_fused_set_tiles_per_wg')
     if args.tiles_per_wg is not None:
         from deepquantum_amd import _lib
 

@@ -12,7 +12,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdqhip.so')
+# (DQHIP_LIBRARY: tools/ablate.sh points it at experimental builds of the same ABI)
+LIB_PATH = os.environ.get('DQHIP_LIBRARY') or os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
 ABI_VERSION = 14

@@ -22,6 +22,7 @@
 #include "dq_common.hpp"
 #include <type_traits>
 #include <stddef.h>
+#include <stdlib.h>
 
 #ifndef DQ_USE_ASM_BLOCKS
 #define DQ_USE_ASM_BLOCKS 1
@@ -103,7 +104,11 @@ template <int Q, int CMASK> __device__ __forceinline__ void x1_block_f32(vec2<fl
 // doubles, the 8 real numbers of the matrix as SGPR pairs; in-place final FMA, no register copies.
 template <int MODE, int Q> __device__ __forceinline__ void gen1_block_f64(vec2<double> (&a)[8], const double (&md)[8]);
 template <int Q, int CMASK> __device__ __forceinline__ void x1_block_f64(vec2<double> (&a)[8]);
+#ifdef DQ_ASM_INC          // timing experiments (tools/ablate.sh): an alternative generated file
+#include DQ_ASM_INC
+#else
 #include "dq_fused_asm.inc"
+#endif
 
 template <int MODE>
 __device__ __forceinline__ void dispatch_gen1_block_f32(vec2<float> (&a)[16], int q, const uint64_t (&mq)[4]) {
@@ -337,13 +342,15 @@ __device__ __forceinline__ void dispatch_gen2(amp<T> (&a)[1 << R], int q, int q2
     }
 }
 
-// XOR swizzle of the LDS element index: spreads power-of-two strides over the bank slots
-// (tools/lds_swizzle_eval.py).  Bijective on [0, 2^M).
+// XOR swizzle of the LDS element index (fusion.lds_swizzle is the same function; tools/lds_conflicts.py counts the
+// bank conflicts of a schedule under it): every higher group of 5 (8-byte elements: 32 slots per LDS row) / 4 index
+// bits is folded onto the low group, so every tile bit moves the bank; for 8-byte elements bit 4 also toggles bit 0,
+// which spreads the lanes of the global-I/O layout over the 16 slots a store group sees.  Bijective on [0, 2^M).
 template <int ESZ> __device__ __forceinline__ unsigned lds_swz(unsigned e) {
     if constexpr (ESZ == 8)
-        return e ^ ((e >> 5) & 31u);
+        return e ^ ((e >> 5) & 31u) ^ ((e >> 10) & 31u) ^ ((e >> 4) & 1u);
     else
-        return e ^ ((e >> 4) & 15u);
+        return e ^ ((e >> 4) & 15u) ^ ((e >> 8) & 15u) ^ ((e >> 12) & 15u);
 }
 
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
@@ -546,6 +553,11 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     // of layouts here would be per lane (the thread base is a VGPR) and cost an exec-masked region per round.  Both
     // offset tables are (re)loaded from the descriptor -- scalar loads -- instead of being carried across the gates.
     auto transpose_to = [&](const unsigned ntbase, const int table) __attribute__((always_inline)) {
+#ifdef DQ_ABLATE_LDS       // timing experiments only: wrong results, no LDS trip
+        cur_tab = table;
+        tbase = ntbase;
+        return;
+#endif
         uint32_t ctab[TAB_WORDS], ntab[TAB_WORDS];
 #pragma unroll
         for (int w = 0; w < TAB_WORDS; ++w) {
@@ -556,10 +568,14 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         const unsigned vr = lds_swz<sizeof(V)>(ntbase) * (unsigned)sizeof(V);
 #pragma unroll
         for (int j = 0; j < NA; ++j) *lds_at(vw ^ tab_entry(ctab, j)) = a[j];
+#ifndef DQ_ABLATE_BARRIER   // timing experiments only (tools/ablate.sh)
         __syncthreads();
+#endif
 #pragma unroll
         for (int j = 0; j < NA; ++j) a[j] = *lds_at(vr ^ tab_entry(ntab, j));
+#ifndef DQ_ABLATE_BARRIER
         __syncthreads();
+#endif
         cur_tab = table;
         tbase = ntbase;
     };
@@ -859,30 +875,29 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
             }
             used |= 1u << rd.tb[i];
         }
-        {   // the kernel trusts the transposition flags: recompute them from the layouts
+        {   // the kernel trusts the layout flags: recompute them from the layouts
             const uint8_t* prb = r == 0 ? p->load_rb : p->rounds[r - 1].rb;
+            // thread bits of an I/O layout: the tile bits that are not slots, ascending
+            auto io_tb = [&](const uint8_t* iorb, uint8_t* tbo) {
+                unsigned slotmask = 0;
+                for (int s = 0; s < slots; ++s) slotmask |= 1u << iorb[s];
+                for (int i = 0, q = 0; i < logt; ++i, ++q) {
+                    while ((slotmask >> q) & 1u) ++q;
+                    tbo[i] = (uint8_t)q;
+                }
+            };
+            uint8_t ptb[DQ_FUSED_MAX_TBITS], stb[DQ_FUSED_MAX_TBITS];
+            if (r == 0) io_tb(p->load_rb, ptb);
+            else for (int i = 0; i < logt; ++i) ptb[i] = p->rounds[r - 1].tb[i];
             bool differs = false;
             for (int s = 0; s < slots; ++s) differs = differs || prb[s] != rd.rb[s];
-            if (r == 0) {   // thread bits of an I/O layout: the tile bits that are not slots, ascending
-                unsigned slotmask = 0;
-                for (int s = 0; s < slots; ++s) slotmask |= 1u << p->load_rb[s];
-                for (int i = 0, q = 0; i < logt; ++i, ++q) {
-                    while ((slotmask >> q) & 1u) ++q;
-                    differs = differs || rd.tb[i] != q;
-                }
-            } else {
-                for (int i = 0; i < logt; ++i) differs = differs || p->rounds[r - 1].tb[i] != rd.tb[i];
-            }
+            for (int i = 0; i < logt; ++i) differs = differs || ptb[i] != rd.tb[i];
             bool after = false;
             if (r == p->nrounds - 1) {
-                unsigned slotmask = 0;
-                for (int s = 0; s < slots; ++s) {
-                    slotmask |= 1u << p->store_rb[s];
-                    after = after || p->store_rb[s] != rd.rb[s];
-                }
-                for (int i = 0, q = 0; i < logt; ++i, ++q) {
-                    while ((slotmask >> q) & 1u) ++q;
-                    after = after || rd.tb[i] != q;
+                io_tb(p->store_rb, stb);
+                for (int s = 0; s < slots; ++s) after = after || p->store_rb[s] != rd.rb[s];
+                for (int i = 0; i < logt; ++i) {
+                    after = after || rd.tb[i] != stb[i];
                 }
             }
             const unsigned want = (differs ? DQ_ROUND_TRANSPOSE : 0u) | (after ? DQ_ROUND_TRANSPOSE_AFTER : 0u);
@@ -949,7 +964,8 @@ template <typename T, int R, int LOGT, bool PF>
 static void launch_variant(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n,
                            int64_t batch, const DqFusedPass* pass, hipStream_t s) {
     constexpr int M = R + LOGT;
-    const size_t lds_bytes = sizeof(amp<T>) << M;
+    size_t lds_bytes = sizeof(amp<T>) << M;
+    if (const char* pad = getenv("DQ_LDS_PAD_KB")) lds_bytes += (size_t)atoi(pad) << 10;   // occupancy experiments
     // (cheap; not cached: a process may drive several devices, and the attribute is per device)
     hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_pass_kernel<T, R, LOGT, PF>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

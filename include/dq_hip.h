@@ -169,9 +169,10 @@ typedef struct {
     uint64_t store_slot_off[DQ_FUSED_MAX_SLOTS];
     /* LDS addressing of every layout the pass uses: table 0 = load layout, table 1 + r = round r, table
      * DQ_FUSED_MAX_ROUNDS + 1 = store layout.  Entry j (j = pattern of register-slot bits) = BYTE offset of
-     * swizzle(sum over the set bits s of j of 2^rb[s]) in the staging tile, swizzle(e) = e ^ ((e >> 5) & 31) for
-     * 8-byte amplitudes, e ^ ((e >> 4) & 15) for 16-byte ones.  The swizzle is XOR-linear, so a thread's address
-     * is swizzle(its base) * size XOR the table entry: one VALU op per access instead of five. */
+     * swizzle(sum over the set bits s of j of 2^rb[s]) in the staging tile; swizzle(e) folds every higher group of
+     * 5 (8-byte amplitudes) / 4 (16-byte) index bits onto the low group by XOR -- e ^ ((e >> 5) & 31) ^ ((e >> 10) & 31)
+     * ^ ((e >> 4) & 1) resp. e ^ ((e >> 4) & 15) ^ ((e >> 8) & 15) ^ ((e >> 12) & 15).  It is XOR-linear, so a thread's
+     * address is swizzle(its base) * size XOR the table entry: one VALU op per access instead of five. */
     uint16_t lds_tab[DQ_FUSED_MAX_ROUNDS + 2][16];
     /* Where the pass WRITES.  A pass may store its tile -- and its block index -- to other index bits (>= L) than
      * it read them from: a bit permutation of the state on the way out, so that the qubits of the NEXT pass already

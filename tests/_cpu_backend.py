@@ -68,11 +68,13 @@ class CpuTestBackend:
                 tl = rbio[sl]
                 assert offs[sl] == 1 << (tl if tl < L else pos[tl - L]), 'slot offset table wrong'
         def want_table(slots_l):
-            period, esz = (4, 16) if is128 else (5, 8)
-            out = []
+            out = []       # the kernel's lds_swz (csrc/dq_fused.hip), restated
             for j in range(1 << R):
                 e_ = sum(1 << slots_l[s_] for s_ in range(R) if (j >> s_) & 1)
-                out.append((e_ ^ ((e_ >> period) & ((1 << period) - 1))) * esz)
+                if is128:
+                    out.append((e_ ^ ((e_ >> 4) & 15) ^ ((e_ >> 8) & 15) ^ ((e_ >> 12) & 15)) * 16)
+                else:
+                    out.append((e_ ^ ((e_ >> 5) & 31) ^ ((e_ >> 10) & 31) ^ ((e_ >> 4) & 1)) * 8)
             return out
 
         assert [desc.lds_tab[0][j] for j in range(1 << R)] == want_table([desc.load_rb[s] for s in range(R)])
@@ -132,7 +134,8 @@ class CpuTestBackend:
                 assert bool(rd.flags & _lib.ROUND_TRANSPOSE) == ((rb, tb) != lay), 'transposition flag wrong'
                 lay = (rb, tb)
                 store = [desc.store_rb[s] for s in range(R)]
-                after = r == desc.nrounds - 1 and lay != (store, [q for q in range(m) if q not in store])
+                store_tb = [q for q in range(m) if q not in store]
+                after = r == desc.nrounds - 1 and lay != (store, store_tb)
                 assert bool(rd.flags & _lib.ROUND_TRANSPOSE_AFTER) == after, 'final transposition flag wrong'
                 assert sorted(rb + tb) == list(range(m)), 'slots + thread bits must cover the tile exactly'
                 slotmask = sum(1 << q for q in rb)
