@@ -46,17 +46,21 @@ def comm_get_world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
-def all_to_all_flat(recv: torch.Tensor, send: torch.Tensor, splits: list[int]) -> None:
+def all_to_all_flat(recv: torch.Tensor, send: torch.Tensor, splits: list[int], async_op: bool = False):
     """``all_to_all_single`` on flat real buffers with the same split table both ways.  RCCL moves GPU
-    memory directly; under the ``gloo`` backend (CPU tests, or several ranks sharing one GPU in the GPU
-    test-suite) device buffers are staged through host memory."""
+    memory directly (``async_op``: returns the work handle; ``wait()`` orders it before the current stream's next
+    kernel without blocking the host); under the ``gloo`` backend (CPU tests, or several ranks sharing one GPU in the
+    GPU test-suite) device buffers are staged through host memory, synchronously."""
     if send.is_cuda and dist.get_backend() == 'gloo':
         h_send = send.cpu()
         h_recv = torch.empty_like(h_send)
         dist.all_to_all_single(h_recv, h_send, output_split_sizes=splits, input_split_sizes=splits)
         recv.copy_(h_recv)
-        return
+        return None
+    if async_op and send.is_cuda:
+        return dist.all_to_all_single(recv, send, output_split_sizes=splits, input_split_sizes=splits, async_op=True)
     dist.all_to_all_single(recv, send, output_split_sizes=splits, input_split_sizes=splits)
+    return None
 
 
 def comm_exchange_arrays(send_data: torch.Tensor, recv_data: torch.Tensor, pair_rank: int | None) -> None:

@@ -49,10 +49,14 @@ from .state import DistributedQubitState
 
 
 #: 'remap' | 'pairwise'; gate lists shorter than ``remap_min_prims`` always run pairwise
-CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14}
+#: ``overlap_groups``: a batched shard is cut into this many groups of samples; group g's exchange (RCCL, its own
+#: HIP stream) runs while group g + 1 still computes its local passes.  ``fold_permute``: the re-labelling of the
+#: local qubits that an exchange needs is written by the last fused pass before it instead of a pass of its own.
+CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_groups': 4, 'fold_permute': True}
 
 #: statistics of the last ``dist_apply_prims`` call (bench / tests)
-LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0}
+LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_permutes': 0, 'permute_passes': 0,
+            'wire_bytes': 0, 'groups': 1}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -108,14 +112,107 @@ def _localize(state: DistributedQubitState, p: Prim) -> Prim | None | str:
     return Prim('diag', torch.stack([phase, phase], dim=-1).diag_embed(), (0,), ())
 
 
+def _row_groups(state: DistributedQubitState) -> list[slice]:
+    """Groups of samples that move through a remap independently (each on its own stream when the shards are on a
+    GPU): equal sizes, so that every group takes the same plan."""
+    rows = _view(state).shape[0]
+    g = max(1, min(int(CONFIG['overlap_groups']), rows))
+    while rows % g:
+        g -= 1
+    if state.world_size == 1:
+        g = 1
+    step = rows // g
+    return [slice(i * step, (i + 1) * step) for i in range(g)]
+
+
+_STREAMS: dict = {}
+
+
+def _group_streams(state: DistributedQubitState, ngroups: int) -> list:
+    """One side stream per group (GPU shards with more than one group; None otherwise = the current stream)."""
+    if ngroups == 1 or not state.amps.is_cuda:
+        return [None] * ngroups
+    key = (state.amps.device, ngroups)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=state.amps.device) for _ in range(ngroups)]
+    return _STREAMS[key]
+
+
+class _on:
+    """``with _on(stream):`` -- run on a side stream that first waits for everything enqueued so far on the current
+    one; ``None`` = stay on the current stream."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.ctx = None
+
+    def __enter__(self):
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
+def _settle(state: DistributedQubitState) -> None:
+    """Join the group streams: everything in flight for this state (exchanges included) is ordered before whatever the
+    current stream does next."""
+    for stream, works in state.__dict__.pop('_inflight', []):
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                for w in works:
+                    w.wait()
+            torch.cuda.current_stream(stream.device).wait_stream(stream)
+        else:
+            for w in works:
+                w.wait()
+
+
+def _rows_of(pending: Sequence[Prim], rows: slice, total: int) -> list[Prim]:
+    """The primitives as group ``rows`` of the batch sees them (per-sample matrices are sliced)."""
+    if rows.start == 0 and rows.stop == total:
+        return list(pending)
+    out = []
+    for p in pending:
+        m = p.matrix
+        if m.ndim == 3 and m.shape[0] == total and total > 1:
+            m = m[rows]
+        out.append(Prim(p.kind, m, p.targets, p.controls, p.mode))
+    return out
+
+
+def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: slice,
+              out_perm: Sequence[int] | None = None) -> bool:
+    """Fused local passes on rows ``rows`` of the shard ``a`` with the receive buffer ``b`` as the second buffer of the
+    permuted stores; afterwards local bit q sits at position out_perm[q].  Returns True if the result lives in ``b``."""
+    total = a.shape[0]
+    x, y = a[rows], b[rows]
+    if CONFIG['fold_permute'] or out_perm is None:
+        out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm)
+    else:                                         # A/B: the re-labelling as a pass of its own
+        out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y)
+        if out.data_ptr() not in (x.data_ptr(), y.data_ptr()):
+            x.copy_(out)
+            out = x
+        out = executor.run(out, [], inplace=True, scratch=y if out.data_ptr() == x.data_ptr() else x, out_perm=out_perm)
+    if out.data_ptr() == y.data_ptr():
+        return True
+    if out.data_ptr() != x.data_ptr():        # (states smaller than a tile come back in a fresh tensor)
+        x.copy_(out)
+    return False
+
+
 def _flush(state: DistributedQubitState, pending: list[Prim]) -> None:
+    _settle(state)
     if not pending:
         return
-    view = _view(state)
     LAST_RUN['local_flushes'] += 1
-    out = executor.run(view, pending, inplace=True)
-    if out.data_ptr() != state.amps.data_ptr():
-        state.amps.copy_(out.reshape(state.amps.shape))
+    a, b = _view(state), _bview(state)
+    if _run_rows(a, b, pending, slice(0, a.shape[0])):
+        state.amps, state.buffer = state.buffer, state.amps
     pending.clear()
 
 
@@ -240,6 +337,7 @@ def _translate(p: Prim, ph: list[int]) -> Prim:
 
 def _permute_local(state: DistributedQubitState, src_of_dst: list[int]) -> None:
     """Re-label the local qubits (one read + one write): destination bit d <- source bit src_of_dst[d]."""
+    _settle(state)
     if src_of_dst == list(range(len(src_of_dst))):
         return
     backend.permute_bits(_view(state), src_of_dst, out=_bview(state))
@@ -254,16 +352,31 @@ def _permute_local(state: DistributedQubitState, src_of_dst: list[int]) -> None:
 def _exchange_qubits(state: DistributedQubitState, pairs: list[tuple[int, int]]) -> None:
     """Swap k global qubits with k local ones in one all-to-all.  ``pairs`` = [(leaving logical qubit,
     entering logical qubit)]: the entering qubit takes over the rank bit of the leaving one."""
+    _remap(state, pairs, [])
+    _settle(state)
+
+
+def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: list[Prim]) -> None:
+    """The local gates ``pending`` (physical positions), then the exchange ``pairs``.  Per group of samples
+    (CONFIG['overlap_groups']; each on its own stream): fused passes whose LAST one also moves the entering qubits to
+    the top k local bits (executor ``out_perm``), then one all-to-all per sample among the 2^k ranks of the group --
+    chunk c of the shard goes to the peer whose rank bits spell c -- issued asynchronously, so that the next group's
+    passes run while this group's amplitudes are on the links.  Nothing waits here: ``_settle`` (or the next remap of
+    the same group) does."""
     L, W = state.log_num_amps_per_node, state.world_size
     ph = _phys(state)
     pairs = sorted(pairs, key=lambda pr: ph[pr[0]])          # ascending rank bit -> ascending peer rank
     k = len(pairs)
     rbits = [ph[lq] - L for lq, _ in pairs]
     assert all(0 <= r < state.log_num_nodes for r in rbits) and all(ph[eq] < L for _, eq in pairs)
-    # 1. move the entering qubits to the top k local bits (chunk index = their joint value)
+    # 1. the entering qubits go to the top k local bits (chunk index = their joint value): destination bit d takes
+    #    source bit src_of_dst[d]
     ent_bits = [ph[eq] for _, eq in pairs]
-    rest = [b for b in range(L) if b not in ent_bits]
-    _permute_local(state, rest + ent_bits)
+    src_of_dst = [b for b in range(L) if b not in ent_bits] + ent_bits
+    out_perm = [0] * L
+    for d, sp in enumerate(src_of_dst):
+        out_perm[sp] = d
+    identity = out_perm == list(range(L))
     # 2. chunk c goes to the peer whose rank bits `rbits` spell c; what comes back from that peer lands in
     #    the same chunk slot.  Peers outside the 2^k group get empty messages.
     chunk = (1 << (L - k))
@@ -273,12 +386,50 @@ def _exchange_qubits(state: DistributedQubitState, pairs: list[tuple[int, int]])
         for i, r in enumerate(rbits):
             peer = (peer & ~(1 << r)) | (((c >> i) & 1) << r)
         splits[peer] = chunk * 2                                # complex -> interleaved reals
-    if W > 1 and dist.is_initialized():
-        send, recv = torch.view_as_real(_view(state)), torch.view_as_real(_bview(state))   # (B, 2^L, 2)
-        for i in range(send.shape[0]):                          # one collective per sample: contiguous chunks
-            all_to_all_flat(recv[i].reshape(-1), send[i].reshape(-1), splits)
+    a, b = _view(state), _bview(state)
+    groups = _row_groups(state)
+    streams = _group_streams(state, len(groups))
+    inflight_prev = {id(st): (st, works) for st, works in state.__dict__.pop('_inflight', [])}
+    inflight, landed_in_a = [], []
+    if pending:
+        LAST_RUN['local_flushes'] += 1
+    for rows, stream in zip(groups, streams):
+        with _on(stream):
+            for w in inflight_prev.pop(id(stream), (None, []))[1]:    # this group's previous exchange
+                w.wait()
+            in_b = _run_rows(a, b, pending, rows, None if identity else out_perm) if (pending or not identity) else False
+            src, dst = (b, a) if in_b else (a, b)
+            works = []
+            if W > 1 and dist.is_initialized():
+                send, recv = torch.view_as_real(src[rows]), torch.view_as_real(dst[rows])     # (rows, 2^L, 2)
+                for i in range(send.shape[0]):                      # one collective per sample: contiguous chunks
+                    w = all_to_all_flat(recv[i].reshape(-1), send[i].reshape(-1), splits, async_op=stream is not None)
+                    if w is not None:
+                        works.append(w)
+                LAST_RUN['wire_bytes'] += send.shape[0] * ((1 << k) - 1) * chunk * send.element_size() * 2
+            else:
+                dst[rows].copy_(src[rows])
+            landed_in_a.append(in_b)
+            inflight.append((stream, works))
+    for st, works in inflight_prev.values():                          # (streams of another grouping: join them)
+        inflight.append((st, works))
+    state.__dict__['_inflight'] = inflight
+    if not all(landed_in_a):
+        if any(landed_in_a):         # groups disagree on the buffer they ended in (never with equal group sizes)
+            _settle(state)
+            for rows, in_a in zip(groups, landed_in_a):
+                if in_a:
+                    b[rows].copy_(a[rows])
         state.amps, state.buffer = state.buffer, state.amps
-    # 3. bookkeeping: entering qubit i now is rank bit rbits[i]; leaving qubit i is local bit L - k + i
+    pending.clear()
+    if not identity:
+        LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
+    LAST_RUN['groups'] = len(groups)
+    # 3. bookkeeping: local qubits moved with the permutation; entering qubit i now is rank bit rbits[i]; leaving
+    #    qubit i is local bit L - k + i
+    for q, p_ in enumerate(ph):
+        if p_ < L:
+            ph[q] = out_perm[p_]
     for i, (lq, eq) in enumerate(pairs):
         ph[eq] = L + rbits[i]
         ph[lq] = L - k + i
@@ -329,9 +480,9 @@ def _plan_remap(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int) ->
     return pairs
 
 
-def _remap_for(state: DistributedQubitState, prims: Sequence[Prim], i: int) -> None:
+def _remap_for(state: DistributedQubitState, prims: Sequence[Prim], i: int, pending: list[Prim]) -> None:
     pairs = _plan_remap(_phys(state), prims, i, state.nqubit, state.log_num_amps_per_node)
-    _exchange_qubits(state, pairs)
+    _remap(state, pairs, pending)
 
 
 def count_exchange_steps(prims: Sequence[Prim], n: int, g: int) -> dict:
@@ -428,13 +579,14 @@ def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: 
             pending.append(local)
             i += 1
             continue
-        _flush(state, pending)
         if mode == 'pairwise':
+            _flush(state, pending)
             _exchange_prim(state, p)
             i += 1
         else:
-            _remap_for(state, prims, i)     # then re-evaluate gate i under the new layout
+            _remap_for(state, prims, i, pending)     # local gates so far + exchange; then gate i under the new layout
     _flush(state, pending)
+    _settle(state)
     if not keep_layout:
         canonicalize(state)
     return state

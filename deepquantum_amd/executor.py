@@ -37,7 +37,7 @@ class Prim:
 
 @dataclass
 class Plan:
-    steps: list
+    steps: list                    # fusion.Steps
     prim_ops: list[fusion.PrimOp]
     mat_order: list[int]           # prim indices in the order their matrices lie in the kernel buffer
     mat_total: int                 # complex numbers per batch sample in the flat matrix buffer (incl. tail pad)
@@ -70,7 +70,7 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
 PROFILE = {'enabled': False, 'events': []}
 
 # Statistics of the most recent fused run (for bench.py and tests).
-LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0}
+LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'permute_folded': False}
 
 
 def _geometry(is128: bool) -> fusion.Geometry:
@@ -96,13 +96,14 @@ def _geometry(is128: bool) -> fusion.Geometry:
     return g
 
 
-def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False) -> Plan:
+def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
+              out_perm: Sequence[int] | None = None) -> Plan:
     geom = _geometry(is128)
     geom.permute_store = permute
     if geom.fallback is not None:
         geom.fallback.permute_store = permute
     key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
-           geom.plan_branch, geom.asm_loop, permute, CONFIG['fuse'],
+           geom.plan_branch, geom.asm_loop, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
            tuple((p.kind, p.targets, p.controls, p.mode) for p in prims))
     plan = _PLAN_CACHE.get(key)
     if plan is not None:
@@ -112,7 +113,7 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False)
     for p in prims:
         prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off, p.mode))
         off += (1 << len(p.targets)) ** 2
-    steps = fusion.schedule(prim_ops, n, geom, fuse=CONFIG['fuse'])
+    steps = fusion.schedule(prim_ops, n, geom, fuse=CONFIG['fuse'], final_perm=out_perm)
     order, total = fusion.layout_matrices(steps, prim_ops)
     plan = Plan(steps, prim_ops, order, total,
                 sum(isinstance(s, fusion.FusedStep) for s in steps),
@@ -160,13 +161,20 @@ def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
     return state.requires_grad or any(p.matrix.requires_grad for p in prims)
 
 
-def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> torch.Tensor:
-    """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state."""
-    if len(prims) == 0:
+def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
+        out_perm: Sequence[int] | None = None) -> torch.Tensor:
+    """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state.
+
+    ``scratch`` (no-grad runs): a second buffer like ``state`` that the passes may ping-pong with (permuted stores
+    without an allocation; the sharded state passes its receive buffer) -- the result then lives in ``state`` OR in
+    ``scratch``, whichever the last pass wrote.  ``out_perm``: afterwards index bit b sits at position out_perm[b]
+    (the re-labelling a shard exchange needs); the last pass writes it if it can, else one extra permute pass."""
+    if len(prims) == 0 and out_perm is None:
         return state
     if state.ndim != 2:
         raise ValueError('state must be (batch, 2**n)')
     if needs_autograd(state, prims):
+        assert scratch is None and out_perm is None, 'scratch / out_perm are for no-grad runs'
         vmapped = ops._is_batched(state) or any(ops._is_batched(p.matrix) for p in prims)
         if CONFIG['grad_mode'] == 'adjoint' and not vmapped and all(p.unitary for p in prims):
             meta = tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode) for p in prims)
@@ -178,7 +186,7 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> to
     if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']
             and not ops._is_batched(state)):
         prims = merge_one_qubit_runs(prims)
-    return _run_nograd(state, prims, inplace)
+    return _run_nograd(state, prims, inplace, scratch, out_perm)
 
 
 _MERGE_COST = {3: 30, 2: 45, 1: 45, 0: 79}    # issue slots of a wave per one-qubit gate, by matrix structure
@@ -278,17 +286,36 @@ def _run_small(state: torch.Tensor, prims: Sequence[Prim], n: int, m: int) -> to
     return out[:, : 1 << n].contiguous()
 
 
-def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False) -> torch.Tensor:
+def _permute_after(x: torch.Tensor, out_perm: Sequence[int], scratch: torch.Tensor | None) -> torch.Tensor:
+    """Index bit b -> position out_perm[b] as a pass of its own (destination bit d takes source bit src_of_dst[d])."""
+    if list(out_perm) == list(range(len(out_perm))):
+        return x
+    src_of_dst = [0] * len(out_perm)
+    for b, d in enumerate(out_perm):
+        src_of_dst[d] = b
+    dst = scratch if scratch is not None and scratch.data_ptr() != x.data_ptr() else torch.empty_like(x)
+    return backend.permute_bits(x, src_of_dst, out=dst)
+
+
+def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
+                out_perm: Sequence[int] | None = None) -> torch.Tensor:
     n = state.shape[-1].bit_length() - 1
     with torch.no_grad():
         is128 = state.dtype == torch.complex128
         g_ = _geometry(is128)
         m = g_.fallback.m if g_.fallback is not None else g_.m     # smallest tile a fused pass can run on
+        if len(prims) == 0:
+            LAST_RUN['permute_folded'] = False
+            return _permute_after(state, out_perm, scratch)
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):
-            return _run_small(state, prims, n, m)
+            out = _run_small(state, prims, n, m)
+            return out if out_perm is None else _permute_after(out, out_perm, scratch)
         permute = False
-        if CONFIG['permute_store'] and not inplace and n >= CONFIG['permute_min_bits']:
+        if scratch is not None:
+            assert scratch.shape == state.shape and scratch.dtype == state.dtype and scratch.is_contiguous()
+            permute = CONFIG['permute_store'] and n >= CONFIG['permute_min_bits'] and state.is_contiguous()
+        elif CONFIG['permute_store'] and not inplace and n >= CONFIG['permute_min_bits']:
             permute = True
             if state.is_cuda:     # the second buffer must fit: a share of the device, and what is free right now
                 nbytes = state.numel() * state.element_size()
@@ -297,7 +324,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 # what still has to be allocated: the second buffer, and the private working copy unless the caller's
                 # state is updated in place (never here: `inplace` runs do not permute)
                 permute = 2 * nbytes <= CONFIG['permute_mem_frac'] * total and 2.05 * nbytes <= free
-        plan = make_plan(prims, n, is128, permute)
+        plan = make_plan(prims, n, is128, permute, out_perm if permute else None)
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies
         shared_in = None
@@ -311,7 +338,9 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
             x = state.detach().clone(memory_format=torch.contiguous_format)
         flat, stride = _flat_mats(prims, plan.mat_order, x.shape[0], x.dtype, x.device)
         stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0}
-        scratch = other = None
+        spare = scratch                      # the caller's second buffer (if any)
+        other = spare if permute else None
+        scratch = None
         for st in plan.steps:
             if isinstance(st, fusion.FusedStep):
                 src, shared_in = (shared_in, None) if shared_in is not None else (x, None)
@@ -345,7 +374,10 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                     backend.apply_gate(x, mat, op.targets, op.controls, out=scratch)
                     x, scratch = scratch, x
                 stats['singles'] += 1
+        stats['permute_folded'] = out_perm is not None and permute and plan.steps.applied_final_perm
         LAST_RUN.update(stats)
+        if out_perm is not None and not (permute and plan.steps.applied_final_perm):
+            x = _permute_after(x, out_perm, other if other is not None else spare)
         return x
 
 

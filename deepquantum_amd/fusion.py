@@ -284,27 +284,41 @@ def _fusable(op: PrimOp) -> bool:
     return op.k <= 2
 
 
-def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True) -> list[FusedStep | SingleStep]:
+def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True,
+             final_perm: Sequence[int] | None = None) -> list[FusedStep | SingleStep]:
     """List scheduling over the commutation DAG.  Returns steps in execution order.  The gathered bits of the
     passes come from the dry-run planner and, for comparison, from the first-come rule (a gate claims its bits while
     the tile has room) -- on circuits whose passes are bounded by the gate cap rather than by the tile the cheap
-    rule can win; the schedule with fewer passes (then fewer LDS trips) is kept."""
+    rule can win; the schedule with fewer passes (then fewer LDS trips) is kept.
+
+    ``final_perm`` (needs ``geom.permute_store``): the LAST pass leaves index bit b at position final_perm[b] instead
+    of restoring the canonical order -- the re-labelling of the local qubits that a shard exchange needs
+    (distributed._exchange_qubits) rides on a pass that has to be made anyway.  Callers check ``applied_final_perm``
+    on the result: False when no pass could take it (last step not fused, or the permutation moves a bit below the
+    contiguous run), and they then permute on their own."""
     if fuse and n < geom.m and geom.fallback is not None and n >= geom.fallback.m:
         geom = geom.fallback                  # the state is smaller than the big tile but fits the small one
     if not fuse or n < geom.m:
-        return [SingleStep(i) for i in range(len(ops))]
+        return Steps(SingleStep(i) for i in range(len(ops)))
     width = geom.plan_width if n >= geom.plan_min_bits else min(geom.plan_width, 1)
-    best = _schedule(ops, n, geom, 0)
+    best = _schedule(ops, n, geom, 0, final_perm)
     if width and sum(isinstance(s_, FusedStep) for s_ in best) > 1:
         def cost(steps):
-            return (len(steps), sum(s_.ntranspose for s_ in steps if isinstance(s_, FusedStep)))
-        cand = _schedule(ops, n, geom, width)
+            return (not steps.applied_final_perm, len(steps), sum(s_.ntranspose for s_ in steps if isinstance(s_, FusedStep)))
+        cand = _schedule(ops, n, geom, width, final_perm)
         if cost(cand) < cost(best):
             best = cand
     return best
 
 
-def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int) -> list[FusedStep | SingleStep]:
+class Steps(list):
+    """The steps of a schedule; ``applied_final_perm`` = the last pass writes the requested final permutation."""
+
+    applied_final_perm = False
+
+
+def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
+              final_perm: Sequence[int] | None = None) -> 'Steps':
     dag = _Dag(ops, n)
     steps: list = []                    # SingleStep | (geometry, gathered bits, rounds) of a fused pass, finalised below
     low = set(range(geom.min_low))
@@ -417,10 +431,11 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int) -> list
             steps.append((small, high, rounds))
         else:
             steps.append((geom, high, rounds))
-    return _place_writes(ops, n, steps, geom.permute_store)
+    return _place_writes(ops, n, steps, geom.permute_store, final_perm)
 
 
-def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool) -> list[FusedStep | SingleStep]:
+def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
+                  final_perm: Sequence[int] | None = None) -> 'Steps':
     """Finalise the passes.  With ``permute`` a pass writes the qubits the NEXT pass gathers to the cheapest index
     bits (right above the contiguous run) and everybody else above them, in their current order -- gathered reads
     from far-apart addresses are what a pass pays for, scattered writes are nearly free (mb_scatter) --
@@ -428,7 +443,12 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool) -
     (logical) to where it currently lives; the last pass, and any pass followed by a gate that runs on its own,
     writes the canonical order back."""
     phys = list(range(n))
-    out: list[FusedStep | SingleStep] = []
+    out = Steps()
+    final = list(range(n))
+    if (permute and final_perm is not None and pending and not isinstance(pending[-1], SingleStep)
+            and all(final_perm[b] == b for b in range(pending[-1][0].min_low))):
+        final = list(final_perm)
+        out.applied_final_perm = True
     for k, item in enumerate(pending):
         if isinstance(item, SingleStep):
             assert phys == list(range(n))
@@ -452,7 +472,7 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool) -
         desc, L, h = step.desc, geom.min_low, geom.m - geom.min_low
         nxt = pending[k + 1] if permute and k + 1 < len(pending) and not isinstance(pending[k + 1], SingleStep) else None
         if nxt is None:
-            wphys = list(range(n))
+            wphys = final if k == len(pending) - 1 else list(range(n))
         else:
             ngeom, nhigh, _ = nxt
             near = list(range(ngeom.min_low, ngeom.min_low + len(nhigh)))
@@ -484,7 +504,7 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool) -
         step.permutes = wphys != phys
         phys = wphys
         out.append(step)
-    assert phys == list(range(n))
+    assert phys == final
     return out
 
 

@@ -261,6 +261,42 @@ def _case_golden_w8(dq, rank, world):
     _both_modes(dq, lambda: _golden_dist_check(dq, rank, world, ['config5_n9']))
 
 
+def _case_folded_permute_w2(dq, rank, world):
+    """The remap's re-labelling of the local qubits rides on the last fused pass before the exchange (permuted store
+    into the receive buffer), the batch moves in groups of samples: same amplitudes as the dense circuit, as a pass of
+    its own (fold off), and with one group."""
+    import specs
+    from deepquantum_amd import distributed as D
+
+    n, B = 15, 4                                    # 14 local qubits: the shards take the 13-bit tile
+    spec = specs.random_spec(n, 6, 321)
+    spec = [(m_, [a[0]], {'encode': True}) if m_ == 'rx' else (m_, a, k) for m_, a, k in spec]
+    dense = specs.build(dq, n, spec)
+    data = torch.rand(B, dense.ndata, generator=torch.Generator().manual_seed(8)) * 6.28
+    with torch.no_grad():
+        ref = dense(data).reshape(B, -1)
+    per = 2**n // world
+    keep = dq.executor.CONFIG['permute_min_bits']
+    dq.executor.CONFIG['permute_min_bits'] = 12
+    try:
+        for fold, groups in ((True, 4), (False, 4), (True, 1), (True, 2)):
+            D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'] = fold, groups
+            shard = dq.DistributedQubitCircuit(n)
+            _apply_spec(shard, spec)
+            st = shard(data)
+            err = (st.amps - ref[:, rank * per : (rank + 1) * per]).abs().max().item()
+            assert err < 1e-5, f'rank {rank} fold={fold} groups={groups}: {err}'
+            assert D.LAST_RUN['remaps'] > 0 and D.LAST_RUN['groups'] in (groups, 1)
+            if fold:
+                assert D.LAST_RUN['folded_permutes'] > 0, D.LAST_RUN
+            else:
+                assert D.LAST_RUN['folded_permutes'] == 0 and D.LAST_RUN['permute_passes'] > 0, D.LAST_RUN
+            assert D.LAST_RUN['wire_bytes'] > 0
+    finally:
+        dq.executor.CONFIG['permute_min_bits'] = keep
+        D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'] = True, 4
+
+
 def _case_measure_w2(dq, rank, world):
     cir = dq.DistributedQubitCircuit(4)
     cir.h(0)
@@ -280,7 +316,7 @@ def _case_measure_w2(dq, rank, world):
 
 @pytest.mark.parametrize('case,world', [('gates_w2', 2), ('gates_w4', 4), ('fused_local_w2', 2),
                                         ('random_remap_w4', 4), ('remap_w8', 8),
-                                        ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4),
+                                        ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4), ('folded_permute_w2', 2),
                                         ('golden_w2', 2), ('golden_w4', 4), ('golden_w8', 8)])
 def test_sharded_circuit(case, world):
     _run(case, world)

@@ -152,6 +152,74 @@ def _case_golden(dq, rank, world):
     D.CONFIG['mode'] = 'remap'
 
 
+def _case_folded_permute(dq, rank, world):
+    """Remap with the real kernels at a size where the shards run permuted stores (>= 2^20 amplitudes): the last fused
+    pass before every exchange writes the re-labelled shard into the receive buffer; groups of samples on their own
+    streams.  Against the dense circuit, fold on / off, 1 / 2 / 4 groups."""
+    import specs
+    from deepquantum_amd import distributed as D
+
+    n, B = 21 + (world.bit_length() - 1), 4
+    spec = specs.random_spec(n, 4, 99)
+    spec = [(m_, [a[0]], {'encode': True}) if m_ == 'rx' else (m_, a, k) for m_, a, k in spec]
+    dense = _build(dq, dq.QubitCircuit, n, spec)
+    data = (torch.rand(B, dense.ndata, generator=torch.Generator().manual_seed(8)) * 6.28).cuda()
+    per = 2**n // world
+    with torch.no_grad():
+        ref = dense(data).reshape(B, -1)[:, rank * per:(rank + 1) * per].clone()
+        ref_ev = dense.expectation()
+    del dense
+    torch.cuda.empty_cache()
+    try:
+        for fold, groups in ((True, 4), (False, 2), (True, 1)):
+            D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'] = fold, groups
+            shard = _build(dq, dq.DistributedQubitCircuit, n, spec)
+            with torch.no_grad():
+                st = shard(data)
+                ev = shard.expectation()
+            assert (st.amps - ref).abs().max().item() < 1e-5, (fold, groups)
+            assert (ev - ref_ev).abs().max().item() < 1e-5
+            assert D.LAST_RUN['remaps'] > 0
+            assert (D.LAST_RUN['folded_permutes'] > 0) == fold, D.LAST_RUN
+    finally:
+        D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'] = True, 4
+
+
+def _case_measure(dq, rank, world):
+    """measure_dist on the HIP kernels (reference: distributed.py:205-285): the probabilities it reports are the
+    dense circuit's marginals, measured global wires select the rank's slot, the dict lives on rank 0 only."""
+    import specs
+    from deepquantum_amd import distributed as D
+
+    n = 12
+    spec = specs.random_spec(n, 5, 77)
+    dense = _build(dq, dq.QubitCircuit, n, spec, obs=False)
+    shard = _build(dq, dq.DistributedQubitCircuit, n, spec, obs=False)
+    with torch.no_grad():
+        psi = dense().reshape(-1)
+        st = shard()
+    p = (psi.abs() ** 2).double().reshape([2] * n).cpu()
+    for wires in (None, [0, 3], [1], [2, 5, n - 1], list(range(2, n)), [0, 1]):
+        res = D.measure_dist(st, shots=4000, with_prob=True, wires=wires)
+        if rank != 0:
+            assert res == {}
+            continue
+        w = sorted(wires) if wires is not None else list(range(n))
+        marg = p.permute(w + [q for q in range(n) if q not in w]).reshape(2 ** len(w), -1).sum(-1)
+        assert sum(v[0] for v in res.values()) == 4000
+        for bits, (_count, prob) in res.items():
+            assert len(bits) == len(w)
+            assert abs(prob - marg[int(bits, 2)].item()) < 1e-6, (wires, bits, prob, marg[int(bits, 2)].item())
+        if len(w) <= 2:   # every outcome with noticeable weight shows up, with about the right frequency
+            for o in range(2 ** len(w)):
+                if marg[o] > 0.05:
+                    got = res.get(format(o, f'0{len(w)}b'), (0, 0))[0] / 4000
+                    assert abs(got - marg[o].item()) < 0.05
+    # the circuit-level entry point (DistributedQubitCircuit.measure) takes the same path
+    res = shard.measure(shots=64, wires=[0, n - 1])
+    assert (rank == 0) == bool(res)
+
+
 def test_reference_dist_tests_on_gpu_world_of_one():
     import deepquantum_amd as dq
     from test_distributed_cpu import _golden_dist_check
@@ -160,6 +228,7 @@ def test_reference_dist_tests_on_gpu_world_of_one():
     _golden_dist_check(dq, 0, 1, ['dist4', 'dist7', 'config4_n8', 'config5_n9'], device='cuda')
 
 
-@pytest.mark.parametrize('case,world', [('golden', 2), ('golden', 4), ('golden', 8), ('random_c64', 2), ('random_c64', 4), ('batched_c128', 4), ('adjoint_grad', 2)])
+@pytest.mark.parametrize('case,world', [('golden', 2), ('golden', 4), ('golden', 8), ('random_c64', 2), ('random_c64', 4), ('batched_c128', 4), ('adjoint_grad', 2),
+                                        ('measure', 2), ('measure', 4), ('folded_permute', 2), ('folded_permute', 4)])
 def test_sharded_on_gpu(case, world):
     _run(case, world)
