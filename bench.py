@@ -1,21 +1,25 @@
 #!/usr/bin/env python
 """Headline benchmark: gate-applies/s and HBM GB/s of the QubitCircuit statevector hot path.
 
-Workload (BASELINE.json configs[2]): QubitCircuit(28), seeded random H / Rx / CNOT
-circuit of depth 40 (1120 gates, seed 1234), complex64, batch = 16 with per-sample Rx angles (the
-``torch.vmap`` case of the reference), initial state |0...0>, no_grad forward.  One "step" = one
-forward pass of the whole circuit over the whole batch, inputs resident in HBM.
+Workloads (BASELINE.json configs; generator = seeded random H / Rx / CNOT, seed 1234):
 
-N > 1 (launched by torchrun, one rank per GPU): weak scaling.  The samples of a batch are independent
-circuits, so the default shards THEM: every rank runs the same 28-qubit circuit on its own 16 samples (global
-batch 16 N), no collective in the data path -- the process group only carries the barrier and the max over
-ranks of the elapsed time.  ``--sharded-state`` instead measures the index-bit-sharded state (BASELINE configs
-4/5 style): n = 28 + log2(N) qubits over the N ranks, the same 2^28 amplitudes x 16 samples per GPU, qubit
-remapping by RCCL all-to-all (what a state that does not fit one GPU needs; link-bound on xGMI).
+* default, N = 1 -- config 3: QubitCircuit(28), depth 40 (1120 gates), complex64, batch = 16 with per-sample Rx
+  angles (the ``torch.vmap`` case of the reference), |0...0> start, no_grad forward + <Z0>.
+* default, N > 1 (one rank per GPU, torchrun) -- the SAME per-GPU state as N = 1 with the index bits sharded: the
+  section-8d weak series n = 28 + log2(N) (29 / 30 / 31 qubits on 2 / 4 / 8 GPUs), batch 16: every rank holds a
+  (16, 2^28) shard, global qubits are exchanged by the all-to-all qubit remap over RCCL / xGMI
+  (deepquantum_amd/distributed.py).  ``--batch-shard`` measures independent replicas instead (every rank its own 16
+  samples of the 28-qubit circuit, no collective in the data path).
+* ``--strong`` -- the section-8d pair "31 qubits on one GPU vs 34 qubits on eight": n = 31 + log2(N), batch 1.
+* ``--config 4`` / ``--config 5`` -- the sharded configs at full size (n = 30 / 31 qubits PER GPU + log2(N): 32 qubits
+  on 4 GPUs, 34 on 8): generator circuit plus the explicit global-control / global-target ``cx``; config 5 adds the
+  QAOA ring with the gradient of sum <Z_i Z_j> through the adjoint sweep.  They run on any N (n = 31 on one GPU).
 
-Prints ONE JSON line on rank 0 (see the contract in the task statement), with two extra objects:
-``roofline`` for the dominant kernel (the fused pass) and ``cpu_baseline`` (the oracle = restatement of
-the reference's permute/reshape/matmul path, timed on this host's cores on a bounded sample).
+One "step" = one forward pass of the whole circuit over the whole batch (+ the expectation), inputs resident in HBM.
+``value`` = gate-applies of all ranks / wall time of the K timed steps (barrier + synchronize on both sides, max over
+ranks).  Rank 0 prints ONE JSON line with two extra objects: ``roofline`` for the dominant kernel (the fused pass;
+``frac`` is the PHYSICAL fraction of the HBM peak) and ``cpu_baseline`` (the oracle = restatement of the reference's
+permute / reshape / matmul path on this host's cores, on a bounded sample of the same workload).
 """
 
 from __future__ import annotations
@@ -24,6 +28,7 @@ import argparse
 import json
 import math
 import os
+import statistics
 import sys
 import time
 
@@ -32,29 +37,35 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+XGMI_LINK_GBS = 153.0       # per link, 7 links per GPU (task statement); a k-qubit remap keeps 2^k - 1 of them busy
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--nqubit', type=int, default=28, help='qubits per GPU-sized shard (n = nqubit + log2 gpus)')
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', type=int, default=3, choices=[3, 4, 5], help='BASELINE config (3 = headline)')
+    ap.add_argument('--strong', action='store_true', help='n = 31 + log2(N), batch 1 (31 qubits x 1 GPU vs 34 x 8)')
+    ap.add_argument('--batch-shard', action='store_true',
+                    help='N > 1: independent replicas (every rank its own samples of the 28-qubit circuit)')
+    ap.add_argument('--sharded-state', action='store_true', help='(the default for N > 1; kept for old command lines)')
+    ap.add_argument('--nqubit', type=int, default=None, help='qubits PER GPU-sized shard (n = nqubit + log2 gpus)')
     ap.add_argument('--depth', type=int, default=40)
-    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--batch', type=int, default=None, help='samples (0 = un-batched 1-D data)')
     ap.add_argument('--dtype', choices=['c64', 'c128'], default='c64')
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--cpu-seconds', type=float, default=25.0)
+    ap.add_argument('--no-sweep', action='store_true', help='skip the single-gate sweep over all targets')
+    ap.add_argument('--backend', default='nccl', help="process-group backend for N > 1 ('nccl' = RCCL; 'gloo' lets "
+                    'several ranks share one GPU for a functional check)')
+    # A/B knobs
     ap.add_argument('--tile-bits', type=int, default=None, help='override fused tile size m')
     ap.add_argument('--min-low', type=int, default=None)
     ap.add_argument('--max-gates', type=int, default=None)
     ap.add_argument('--no-fuse', action='store_true')
-    ap.add_argument('--backend', default='nccl', help="process-group backend for N > 1 ('nccl' = RCCL; 'gloo' lets "
-                    'several ranks share one GPU for a functional check)')
-    ap.add_argument('--sharded-state', action='store_true',
-                    help='N > 1: index-bit-sharded state of 28 + log2(N) qubits instead of sharding the batch')
     ap.add_argument('--max-far', type=int, default=None, help='scheduler: max gathered bits >= far-bit per pass')
     ap.add_argument('--far-bit', type=int, default=None)
     ap.add_argument('--plan-width', type=int, default=None,
@@ -62,16 +73,17 @@ def parse_args():
     ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
     ap.add_argument('--no-asm-loop', action='store_true', help='A/B: gate loop in C++ around the jump table')
     ap.add_argument('--no-compare', action='store_true',
-                    help='skip the extra untimed-for-value runs with merging off (config.unmerged_ms_per_step): '
-                         'tools/profile.sh uses it so that the profiled launches are the timed ones only')
+                    help='skip the extra runs (merging off, single-gate sweep): tools/profile.sh uses it so that the '
+                         'profiled launches are the timed ones only')
     ap.add_argument('--no-permute-store', action='store_true',
                     help='A/B: in-place passes (every pass gathers its qubits where they canonically live)')
     ap.add_argument('--no-merge', action='store_true',
                     help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
     ap.add_argument('--tiles-per-wg', type=int, default=None,
                     help='A/B: tiles a complex64 workgroup walks with next-tile prefetch (1 = off; default: library)')
-    ap.add_argument('--tiles-per-wg', type=int, default=None,
-                    help='A/B: tiles a complex64 workgroup walks with next-tile prefetch (1 = off; default: library)')
+    ap.add_argument('--overlap-groups', type=int, default=None, help='N > 1: sample groups of the overlapped remap')
+    ap.add_argument('--no-fold-permute', action='store_true',
+                    help='N > 1, A/B: the re-labelling before an exchange as a pass of its own')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
     return ap.parse_args()
 
@@ -100,7 +112,8 @@ def random_circuit_spec(nqubit, depth, seed=1234):
 
 def build_circuit(dq, n, spec, batch, dtype, device, distributed=False, shard=0):
     """The generator's circuit; Rx angles are encoder inputs so each batch sample has its own.  ``shard`` = which
-    slice of a batch sharded over ranks this is (its samples get their own angles)."""
+    slice of a batch sharded over ranks this is (its samples get their own angles).  ``batch`` None: 1-D data (the
+    reference's un-batched call)."""
     cir = dq.DistributedQubitCircuit(n) if distributed else dq.QubitCircuit(n)
     angles = []
     for op in spec:
@@ -116,6 +129,8 @@ def build_circuit(dq, n, spec, batch, dtype, device, distributed=False, shard=0)
     if dtype == torch.complex128:
         cir.to(torch.double)
     real = torch.float64 if dtype == torch.complex128 else torch.float32
+    if batch is None:
+        return cir, torch.tensor(angles, dtype=real).to(device)
     g = torch.Generator().manual_seed(1234 + shard)
     data = torch.rand(batch, len(angles), generator=g, dtype=real) * 2 * math.pi
     if shard == 0:
@@ -138,32 +153,54 @@ def device_copy_bandwidth(device, nbytes=1 << 32, reps=5):
     return 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def single_gate_bandwidth(dq, n, batch, dtype, device, reps=3):
-    """Physical read+write GB/s of ONE gate application (H on the top qubit) over a resident (batch, 2^n) state:
-    the un-fused figure the north star's ">= 60 % of the HBM roofline" refers to."""
+def single_gate_sweep(dq, n, batch, dtype, device, reps=2):
+    """Physical read+write GB/s of ONE gate application over a resident (batch, 2^n) state -- the un-fused figure the
+    north star's ">= 60 % of the HBM roofline" refers to -- for H on EVERY target bit and for CNOT pairs (near / far,
+    control above / below the target).  Returns {'h': {bit: GB/s}, 'cnot': {'c->t': GB/s}}; a CNOT launch is charged
+    the whole state (it reads and writes the tiles it visits; whether it may skip a tile depends on where the control
+    sits), so its figure is a lower bound of the rate on the bytes it really touched."""
     from deepquantum_amd import backend, fusion
 
     is128 = dtype == torch.complex128
-    mat = (torch.tensor([[1, 1], [1, -1]], dtype=torch.cfloat) / 2**0.5).to(dtype).reshape(-1).to(device)
-    ops = [fusion.PrimOp('gen', (n - 1,), (), 0, 3)]
-    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
-    km = fusion.kernel_matrices(steps, ops, mat)
+    h = (torch.tensor([[1, 1], [1, -1]], dtype=torch.cfloat) / 2**0.5).to(dtype).reshape(-1).to(device)
     x = torch.zeros(batch, 1 << n, dtype=dtype, device=device)
     x[:, 0] = 1
-    backend.apply_fused(x, km, 0, steps[0].desc, out=x)
-    torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
+    nbytes = 2 * x.numel() * x.element_size()
+
+    def time_ops(ops, mat):
+        steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+        km = fusion.kernel_matrices(steps, ops, mat)
+        assert len(steps) == 1
         backend.apply_fused(x, km, 0, steps[0].desc, out=x)
-    e1.record()
-    torch.cuda.synchronize(device)
-    return 2 * x.numel() * x.element_size() * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            backend.apply_fused(x, km, 0, steps[0].desc, out=x)
+        e1.record()
+        torch.cuda.synchronize(device)
+        return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    out = {'h': {}, 'cnot': {}}
+    for t in range(n):
+        out['h'][t] = time_ops([fusion.PrimOp('gen', (t,), (), 0, 3)], h)
+    pairs = [(0, 1), (1, 0), (0, n - 1), (n - 1, 0), (n // 2, n // 2 + 1), (n // 2 + 1, n // 2), (3, n - 2), (n - 2, 3),
+             (n - 1, n - 2), (5, 17)]
+    pairs = [(c, t) for c, t in dict.fromkeys(pairs) if 0 <= c < n and 0 <= t < n and c != t]
+    for c, t in pairs:
+        out['cnot'][f'{c}->{t}'] = time_ops([fusion.PrimOp('x', (t,), (c,), 0, 0)], h)
+    return out
 
 
-def cpu_baseline(n, spec, dtype, budget_s):
-    """Oracle (port of the reference's evolve_state path) on this host: first gates of the same
-    workload, batch element 0, until ``budget_s`` seconds are spent."""
+def _stats(values):
+    v = sorted(values)
+    return {'min': v[0], 'median': statistics.median(v), 'max': v[-1], 'n': len(v)}
+
+
+def cpu_baseline(n, dtype, budget_s):
+    """Oracle (port of the reference's evolve_state / op_state_control path) on this host's cores, batch element 0:
+    the sample SURVEY 8(d) prescribes -- H and Rx on low / mid / high wires, near and far CNOTs in both directions --
+    extrapolated to a gate rate (the full circuit is n * depth such gates)."""
     from oracle import statevec_oracle as oracle
 
     torch.set_num_threads(os.cpu_count() or 1)
@@ -172,28 +209,79 @@ def cpu_baseline(n, spec, dtype, budget_s):
     x[0, 0] = 1
     h = oracle.fixed_matrix('h').to(dtype)
     cnot = (torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]]) + 0j).to(dtype)
-    done, t0 = 0, time.perf_counter()
+    rx = oracle.rx_matrix(oracle.theta_tensor(0.7).to(real)).to(dtype)
+    lo, mid, hi = 0, n // 2, n - 1
+    sample = [('h', lo), ('h', mid), ('h', hi), ('rx', lo + 1), ('rx', mid + 1), ('rx', hi - 1),
+              ('cnot', lo, lo + 1), ('cnot', lo, hi), ('cnot', hi, lo), ('cnot', mid, mid + 1), ('cnot', hi, hi - 1)]
+    per_gate, done, t0 = [], 0, time.perf_counter()
     with torch.no_grad():
-        for op in spec:
+        for op in sample:
+            t1 = time.perf_counter()
             if op[0] == 'h':
                 x = oracle.apply_gate_wires(x, h, n, [op[1]])
             elif op[0] == 'rx':
-                x = oracle.apply_gate_wires(x, oracle.rx_matrix(oracle.theta_tensor(op[2]).to(real)).to(dtype), n, [op[1]])
+                x = oracle.apply_gate_wires(x, rx, n, [op[1]])
             else:
                 x = oracle.apply_gate_wires(x, cnot, n, [op[1], op[2]])
+            per_gate.append(time.perf_counter() - t1)
             done += 1
-            if time.perf_counter() - t0 > budget_s or done >= 64:
+            if time.perf_counter() - t0 > budget_s and done >= 8:
                 break
-    x = x.contiguous()
     dt = time.perf_counter() - t0
+    names = ', '.join(f'{op[0]}{list(op[1:])}' for op in sample[:done])
     return {
         'value': done / dt,
         'unit': 'gate-applies/s',
         'cores': torch.get_num_threads(),
         'kind': 'port',
-        'sample': f'first {done} gates of the same n={n} seed-1234 circuit, batch element 0 only, '
-                  f'{"c64" if dtype == torch.complex64 else "c128"}, {dt:.1f} s wall',
+        'extrapolated': True,
+        'seconds_per_gate': {'min': min(per_gate), 'max': max(per_gate)},
+        'sample': f'{done} gates on wires low / mid / high of an n={n} state (wire 0 = MSB): {names}; batch element 0 '
+                  f'only, {"c64" if dtype == torch.complex64 else "c128"}, {dt:.1f} s wall; the rate extrapolates to the '
+                  f'n * depth gates of the circuit',
     }
+
+
+def check_pin(cir, n, depth, seed, dtype):
+    """Parity of the TIMED workload: sample 0 of config 3 against what the real reference computed for it
+    (tests/golden/pin28.npz, made by tests/golden/make_golden_pin28.py): 4096 amplitudes, the squared norm and <Z_q>
+    of every wire, at the north star's complex64 tolerance 1e-4."""
+    import numpy as np
+
+    from deepquantum_amd import backend
+
+    path = os.path.join(ROOT, 'tests', 'golden', 'pin28.npz')
+    if not (n == 28 and depth == 40 and seed == 1234 and dtype == torch.complex64 and os.path.exists(path)):
+        return False, {'reason': 'no reference pin for this workload (the pin is config 3: n=28, depth 40, seed 1234, c64)'}
+    pin = np.load(path)
+    state = cir.state.reshape(-1, 1 << n)[:1].contiguous()        # sample 0 = the generator's own angles
+    idx = torch.from_numpy(pin['indices']).to(state.device)
+    amp = state[0, idx].cpu().numpy()
+    amp_err = float(np.abs(amp - pin['amplitudes']).max())
+    norm2 = float(backend.expect_pauli(state, 0, 0)[0])
+    ez = [float(backend.expect_pauli(state, 0, 1 << (n - 1 - q))[0]) for q in range(n)]
+    z_err = float(np.abs(np.array(ez) - pin['expectation_z']).max())
+    ok = amp_err < 1e-4 and z_err < 1e-4 and abs(norm2 - float(pin['norm2'])) < 1e-4
+    return ok, {'source': 'tests/golden/pin28.npz (real reference, batch element 0)', 'amplitudes_checked': int(idx.numel()),
+                'max_amplitude_error': amp_err, 'max_expectation_z_error': z_err, 'norm2': norm2,
+                'norm2_reference': float(pin['norm2']), 'tolerance': 1e-4}
+
+
+def qaoa_ring(dq, n, device, distributed):
+    """Config 5's second half (examples/qaoa.py:21-64 on a ring, one step): hlayer; per edge cnot . rz . cnot; rx layer;
+    one <Z_i Z_j> observable per edge."""
+    cir = dq.DistributedQubitCircuit(n) if distributed else dq.QubitCircuit(n)
+    pairs = [(i, (i + 1) % n) for i in range(n)]
+    cir.hlayer()
+    for i, j in pairs:
+        cir.cnot(i, j)
+        cir.rz(j, encode=True)
+        cir.cnot(i, j)
+    for i in range(n):
+        cir.rx(i, encode=True)
+    for i, j in pairs:
+        cir.observable([i, j])
+    return cir.to(device), pairs
 
 
 def main():
@@ -208,11 +296,23 @@ def main():
     dtype = torch.complex64 if args.dtype == 'c64' else torch.complex128
     amp_bytes = 8 if dtype == torch.complex64 else 16
     multi = world > 1
-    distributed = multi and args.sharded_state          # index-bit-sharded state; otherwise the batch is sharded
+    distributed = multi and not args.batch_shard      # index-bit-sharded state; otherwise the batch is sharded
     if multi:
         dq.setup_distributed(args.backend)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+
+    # ---- which workload -------------------------------------------------------------------------------------
+    per_gpu = {3: 28, 4: 30, 5: 31}[args.config]
+    batch = 16 if args.config == 3 else None
+    if args.strong:
+        per_gpu, batch = 31, None
+    if args.nqubit is not None:
+        per_gpu = args.nqubit
+    if args.batch is not None:
+        batch = args.batch if args.batch > 0 else None
+    n = per_gpu + (int(math.log2(world)) if distributed else 0)
+    nbatch = batch or 1
 
     key = 'm_c64' if dtype == torch.complex64 else 'm_c128'
     if args.tile_bits is not None:
@@ -233,27 +333,31 @@ def main():
         dq.executor.CONFIG['merge_min_amps'] = None
     if args.no_permute_store:
         dq.executor.CONFIG['permute_store'] = False
-
+    if args.overlap_groups is not None:
+        dq.distributed.CONFIG['overlap_groups'] = args.overlap_groups
+    if args.no_fold_permute:
+        dq.distributed.CONFIG['fold_permute'] = False
     if args.tiles_per_wg is not None:
         from deepquantum_amd import _lib
 
         _lib.check(_lib.load().dq_fused_set_tiles_per_wg(args.tiles_per_wg), 'dq_fused_set_tiles_per_wg')
-    if args.tiles_per_wg is not None:
-        from deepquantum_amd import _lib
 
-        _lib.check(_lib.load().dq_fused_set_tiles_per_wg(args.tiles_per_wg), 'dq_fused_set_tiles_per_wg')
-    n = args.nqubit + (int(math.log2(world)) if distributed else 0)
     spec = random_circuit_spec(n, args.depth, args.seed)
-    ngates = len(spec)
-    cir, data = build_circuit(dq, n, spec, args.batch, dtype, device, distributed, rank if multi and not distributed else 0)
+    extra = []
+    if args.config in (4, 5):       # global control / local target, and local control / GLOBAL target
+        extra = [('cnot', 0, n - 1), ('cnot', n - 1, 0)]
+    full_spec = spec + extra
+    ngates = len(full_spec)
+    cir, data = build_circuit(dq, n, full_spec, batch, dtype, device, distributed,
+                              rank if multi and not distributed else 0)
     # algorithmic bytes per gate: 2 * 2^(n - nc) * sizeof(amp) per batch sample
-    alg_bytes = sum(2 * (2 ** (n - (1 if op[0] == 'cnot' else 0))) * amp_bytes for op in spec) * args.batch
+    alg_bytes = sum(2 * (2 ** (n - (1 if op[0] == 'cnot' else 0))) * amp_bytes for op in full_spec) * nbatch
 
     prof = dq.executor.PROFILE
 
     def step():
         with torch.no_grad():
-            cir(data)      # N>1: (batch, 2^L) shards on every rank, one exchange schedule for the whole batch
+            cir(data)      # N > 1: (batch, 2^L) shards on every rank, one exchange schedule for the whole batch
             return cir.expectation()
 
     def sync():
@@ -267,10 +371,15 @@ def main():
     sync()
     prof['enabled'] = True
     prof['events'].clear()
+    step_events = []
     t0 = time.perf_counter()
     out = None
     for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         out = step()
+        e1.record()
+        step_events.append((e0, e1))
     sync()
     elapsed = time.perf_counter() - t0
     prof['enabled'] = False
@@ -278,49 +387,87 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
+    step_ms = [a.elapsed_time(b) for a, b in step_events]      # HIP events around every step (this rank)
 
-    # dominant kernel: the fused pass -- durations from HIP events recorded on the launch stream
-    kernel_ms = [a.elapsed_time(b) for a, b, _ in prof['events']]
+    # dominant kernel: the fused pass -- durations from HIP events recorded on the stream it is launched on, and the
+    # bytes each launch physically moves (one read + one write of the rows it works on)
+    kernel_ms = [ev[0].elapsed_time(ev[1]) for ev in prof['events']]
+    kernel_bytes = [ev[3] for ev in prof['events']]
     launches = len(kernel_ms)
-    alg_per_launch = (alg_bytes / (world if distributed else 1) * args.steps / launches) if launches else 0.0   # this rank's share
+    shard_bytes = (2**n >> (int(math.log2(world)) if distributed else 0)) * amp_bytes * nbatch
     avg_ms = (sum(kernel_ms) / launches) if launches else float('nan')
-    achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc runs of this same command,
-    # tools/profile.sh; committed under profiles/): only reported for the workload it was collected on.
-    traffic = None
+    physical = (sum(kernel_bytes) / (sum(kernel_ms) * 1e-3) / 1e9) if launches else 0.0
+    alg_per_launch = (alg_bytes / (world if distributed else 1) * args.steps / launches) if launches else 0.0
+    effective = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+    # HBM bytes per launch from the PMC counters: measured by separate rocprofv3 --pmc runs of this same command
+    # (tools/profile.sh; summaries committed under profiles/), NOT during this run -- reported with its source, and
+    # only for the workload it was collected on
+    traffic, traffic_src = None, None
     tj = args.traffic_json
     if tj is None and not distributed:   # (batch-sharded ranks run the single-GPU workload: same traffic)
         import glob
 
-        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'traffic_n{n}_b{args.batch}_{args.dtype}.json')))
+        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'traffic_n{n}_b{nbatch}_{args.dtype}.json')))
         tj = cands[-1] if cands else None
     if tj and os.path.exists(tj):
         traffic = json.load(open(tj)).get('hbm_bytes_per_launch')
+        traffic_src = (os.path.relpath(tj, ROOT) + ': rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command by '
+                       'the builder (tools/profile.sh), not measured during this run')
     stats = dict(dq.executor.LAST_RUN)
+    dstats = dict(dq.distributed.LAST_RUN) if distributed else None
     z0 = float(out.reshape(-1)[0]) if out is not None else None
+
+    parity_ok, parity = None, None
+    if rank == 0 and not multi:
+        parity_ok, parity = check_pin(cir, n, args.depth, args.seed, dtype)
+    norm2 = None
+    if distributed:
+        from deepquantum_amd.distributed import inner_product_dist
+
+        norm2 = inner_product_dist(cir.state, cir.state).real.reshape(-1)[0].item()
+
+    extras = rank == 0 and not multi and not args.no_compare
     # the same circuit with every gate applied on its own (no products of one-qubit runs), for comparison: N = 1 only
     unmerged_ms = None
-    if not multi and not args.no_merge and not args.no_compare and dq.executor.CONFIG['merge_min_amps'] is not None:
+    if extras and not args.no_merge and dq.executor.CONFIG['merge_min_amps'] is not None:
         keep = dq.executor.CONFIG['merge_min_amps']
         dq.executor.CONFIG['merge_min_amps'] = None
         step()
         sync()
         t0 = time.perf_counter()
-        for _ in range(min(args.steps, 2)):
+        for _ in range(2):
             step()
         sync()
-        unmerged_ms = (time.perf_counter() - t0) / min(args.steps, 2) * 1e3
+        unmerged_ms = (time.perf_counter() - t0) / 2 * 1e3
         dq.executor.CONFIG['merge_min_amps'] = keep
     copy_gbs = device_copy_bandwidth(device) if rank == 0 else None
-    single_gbs = None
-    if rank == 0 and not distributed and n >= 12:
+    sweep = None
+    if extras and not args.no_sweep and n >= 13:
         out = None
         cir.state = None
         torch.cuda.empty_cache()
-        single_gbs = single_gate_bandwidth(dq, n, args.batch, dtype, device)
+        sweep = single_gate_sweep(dq, n, nbatch, dtype, device)
+
+    qaoa = None
+    if args.config == 5:            # QAOA ring, one step: gradient of sum <Z_i Z_j> w.r.t. (gamma, beta)
+        cir.state = None
+        out = None
+        torch.cuda.empty_cache()
+        qc, pairs = qaoa_ring(dq, n, device, distributed)
+        gamma = torch.tensor(0.1, device=device, requires_grad=True)
+        beta = torch.tensor(1.0, device=device, requires_grad=True)
+        params = torch.cat([(2 * gamma).repeat(len(pairs)), (2 * beta).repeat(n)])
+        sync()
+        t0 = time.perf_counter()
+        qc(params)
+        cost = qc.expectation().sum()
+        cost.backward()
+        sync()
+        qaoa = {'edges': len(pairs), 'gates': len(qc.operators), 'cost': float(cost.detach()), 'dcost_dgamma': float(gamma.grad),
+                'dcost_dbeta': float(beta.grad), 'seconds_forward_backward': time.perf_counter() - t0}
 
     if rank == 0:
-        total_gate_applies = ngates * args.batch * args.steps * (world if multi and not distributed else 1)
+        total_gate_applies = ngates * nbatch * args.steps * (world if multi and not distributed else 1)
         value = total_gate_applies / elapsed
         line = {
             'metric': 'gate-applies/sec, 28q random circuit depth 40 (HBM GB/s in roofline)',
@@ -335,56 +482,89 @@ def main():
             'vs_baseline': None,
             'dtype': 'c64' if dtype == torch.complex64 else 'c128',
             'data': 'synthetic',
+            'parity_checked': bool(parity_ok) if parity_ok is not None else False,
             'config': {
                 'workload': f'QubitCircuit({n}) random H/Rx/CNOT depth {args.depth} ({ngates} gates, seed {args.seed}), '
-                            f'{"complex64" if dtype == torch.complex64 else "complex128"}, batch={args.batch} '
-                            f'(per-sample Rx angles), |0..0> start, no_grad forward'
-                            + (f', index-bit sharded over {world} GPUs' if distributed else '')
-                            + (f'; {world} ranks x {args.batch} samples (global batch {world * args.batch})'
-                               if multi and not distributed else ''),
+                            f'{"complex64" if dtype == torch.complex64 else "complex128"}, batch={nbatch}'
+                            + (' (per-sample Rx angles)' if batch else ' (un-batched)') + ', |0..0> start, no_grad forward + <Z0>'
+                            + (f', index bits sharded over {world} GPUs ({per_gpu} local qubits each)' if distributed else '')
+                            + (f'; {world} ranks x {nbatch} samples (global batch {world * nbatch})'
+                               if multi and not distributed else '')
+                            + ('; + cx(0, n-1), cx(n-1, 0)' if extra else ''),
+                'baseline_config': args.config,
                 'nqubit': n,
                 'depth': args.depth,
-                'batch': args.batch,
-                'parallelism': (f'state-shard x{world} (RCCL all-to-all qubit remap)' if distributed else
+                'batch': nbatch,
+                'parallelism': (f'state-shard x{world}: index-bit partition, k-qubit all-to-all remap over RCCL, re-labelling '
+                                f'folded into the last local pass, {dstats.get("groups")} sample groups overlapped'
+                                if distributed else
                                 f'batch-shard x{world} (independent samples, no collective in the data path)' if multi
                                 else 'single GPU'),
-                'fused_passes_per_step': stats.get('passes'),
-                'lds_round_trips_per_step': stats.get('transposes'),
+                'fused_passes_per_step': stats.get('passes') if not distributed else launches / args.steps,
+                'lds_round_trips_per_step': stats.get('transposes') if not distributed else None,
                 # 2x2 matrices the kernel applies per sample after runs of one-qubit gates on the same qubit were
-                # multiplied together (executor.merge_one_qubit_runs; `--no-merge` applies all `ngates` one by one)
-                'kernel_gates_per_step': stats.get('gates'),
+                # multiplied together (executor.merge_one_qubit_runs; `--no-merge` applies all `ngates` one by one);
+                # `value` counts the circuit's gates, `unmerged_ms_per_step` times them one by one
+                'kernel_gates_per_step': stats.get('gates') if not distributed else None,
                 'unmerged_ms_per_step': unmerged_ms,
+                'ms_per_step_hip_events_median': statistics.median(step_ms) if step_ms else None,
+                'ms_per_step_hip_events_min': min(step_ms) if step_ms else None,
             },
             'roofline': {
                 'bound': 'hbm',
                 'kernel': 'dq::fused_pass_kernel',
-                'achieved': achieved,
+                # PHYSICAL rate of the dominant kernel: bytes its launches read + wrote / their summed duration
+                'achieved': physical,
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS,
+                'frac': physical / HBM_PEAK_GBS,
                 'traffic': traffic,
+                'traffic_source': traffic_src,
                 'launches': launches,
                 'avg_launch_ms': avg_ms,
+                'physical_bytes_per_launch': (sum(kernel_bytes) / launches) if launches else None,
+                # SURVEY 8(d) accounting: every fused gate counted as its own read + write of the state.  NOT a
+                # fraction of anything physical: effective / achieved = how many gate-passes one physical pass replaces
                 'algorithmic_bytes_per_launch': alg_per_launch,
-                'actual_state_bytes_per_launch': 2 * (2**n >> (int(math.log2(world)) if distributed else 0)) * amp_bytes * args.batch,
-                'note': 'achieved counts every fused gate as its own read+write of the state (SURVEY 8d), so it '
-                        'can exceed the HBM peak; actual_state_bytes_per_launch / avg_launch_ms is the physical rate',
+                'effective_GBs': effective,
+                'fusion_factor': (effective / physical) if physical else None,
+                'device_copy_GBs': copy_gbs,
+                'frac_of_device_copy': (physical / copy_gbs) if copy_gbs else None,
             },
         }
-        line['roofline']['physical_GBs'] = (line['roofline']['actual_state_bytes_per_launch'] / (avg_ms * 1e-3) / 1e9
-                                            if launches else None)
-        # also quote the physical rate against an in-framework device copy measured on this box
-        line['roofline']['device_copy_GBs'] = copy_gbs
-        if single_gbs is not None:
-            line['roofline']['single_gate_GBs'] = single_gbs
-            line['roofline']['single_gate_frac_of_peak'] = single_gbs / HBM_PEAK_GBS
-        if launches and copy_gbs:
-            line['roofline']['physical_frac_of_copy'] = line['roofline']['physical_GBs'] / copy_gbs
-            line['roofline']['physical_frac_of_peak'] = line['roofline']['physical_GBs'] / HBM_PEAK_GBS
+        if sweep is not None:
+            hs, cs = list(sweep['h'].values()), list(sweep['cnot'].values())
+            line['roofline']['single_gate'] = {
+                'what': 'one un-fused gate per pass over the same resident state, physical GB/s: H on every target bit; '
+                        'CNOT pairs near / far, control above / below the target (charged the whole state)',
+                'h_GBs': _stats(hs), 'h_frac_of_peak': {k: v / HBM_PEAK_GBS for k, v in _stats(hs).items() if k != 'n'},
+                'h_slowest_bits': sorted(sweep['h'], key=sweep['h'].get)[:3],
+                'cnot_GBs': _stats(cs), 'cnot_frac_of_peak': {k: v / HBM_PEAK_GBS for k, v in _stats(cs).items() if k != 'n'},
+            }
+        if parity is not None:
+            line['parity'] = parity
         if z0 is not None:
             line['config']['expectation_Z0_sample0'] = z0
+        if distributed:
+            per_step = {k: dstats[k] for k in ('remaps', 'folded_permutes', 'permute_passes', 'pairwise_exchanges')}
+            wire = dstats['wire_bytes']
+            links = min(7, world - 1)
+            line['config']['exchange_per_step'] = per_step
+            line['config']['norm2_sample0'] = norm2
+            line['xgmi'] = {
+                'wire_bytes_per_rank_per_step': wire,
+                'links_used': links,
+                'peak_GBs_per_link': XGMI_LINK_GBS,
+                # lower bound of the link rate: the whole step time is charged to the exchange (compute overlaps it)
+                'achieved_GBs_per_rank_lower_bound': wire / (elapsed / args.steps) / 1e9,
+                'frac_lower_bound': (wire / (elapsed / args.steps) / 1e9 / (links * XGMI_LINK_GBS)) if links else None,
+                'shard_volumes_sent_per_step': wire / shard_bytes if shard_bytes else None,
+                'global_qubits': int(math.log2(world)),
+            }
+        if qaoa is not None:
+            line['config']['qaoa_ring'] = qaoa
         if not args.no_cpu_baseline and not multi:
-            line['cpu_baseline'] = cpu_baseline(n, spec, dtype, args.cpu_seconds)
+            line['cpu_baseline'] = cpu_baseline(min(n, 28), dtype, args.cpu_seconds)
         print(json.dumps(line))
     if multi:
         torch.distributed.barrier()      # rank 0 measured a few extras; leave together

@@ -462,8 +462,9 @@ def _plan_remap(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int) ->
     g = n - L
     nxt = _next_use(prims, i, n)
     is_glob = [ph[q] >= L for q in range(n)]
-    # farthest next use first; ties: keep what already is global (less traffic), then canonical order
-    order = sorted(range(n), key=lambda q: (-nxt[q], 0 if is_glob[q] else 1, -q))
+    # farthest next use first; ties: keep what already is global (less traffic), then qubits above the contiguous run
+    # of a tile (moving a lower bit cannot ride on a fused pass's permuted store), then canonical order
+    order = sorted(range(n), key=lambda q: (-nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
     new_global = set(order[:g])
     needed = {t for t in prims[i].targets} if prims[i].kind != 'diag' else set()
     assert not (needed & new_global), 'gate needs more local qubits than a shard has'

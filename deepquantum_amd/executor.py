@@ -66,7 +66,7 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
           'merge_min_amps': 1 << 27}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
-# (start, stop, ngates) to report the kernel's average duration next to its algorithmic bytes.
+# (start, stop, ngates, bytes read + written) to report the kernel's average duration next to its algorithmic bytes.
 PROFILE = {'enabled': False, 'events': []}
 
 # Statistics of the most recent fused run (for bench.py and tests).
@@ -354,7 +354,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                     e0.record()
                     backend.apply_fused(src, flat, stride, st.desc, out=dst)
                     e1.record()
-                    PROFILE['events'].append((e0, e1, len(st.ops)))
+                    PROFILE['events'].append((e0, e1, len(st.ops), (src.numel() + dst.numel()) * x.element_size()))
                 else:
                     backend.apply_fused(src, flat, stride, st.desc, out=dst)
                 if dst is not x:

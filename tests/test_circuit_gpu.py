@@ -463,3 +463,48 @@ def test_qasm_programs_run_on_the_hip_path():
         a, b = cir().reshape(-1), again().reshape(-1)
     assert dq.executor.LAST_RUN['passes'] > 0
     assert (a - b).abs().max().item() < 1e-5
+
+
+def test_config3_pin_n28_complex64_batch16():
+    """BASELINE config 3 -- the TIMED workload of bench.py, exactly as it runs there (batch 16 with per-sample angles,
+    one-qubit runs merged, permuted stores, next-tile prefetch) -- against what the REAL reference computed for batch
+    element 0 (tests/golden/pin28.npz <- make_golden_pin28.py, 76 minutes of the reference on 8 cores): 4096 seeded
+    amplitudes, the squared norm, <Z_q> on every wire and two 5-wire marginals, at the north star's 1e-4."""
+    import os
+    import sys
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from deepquantum_amd import backend
+
+    free, _total = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip('needs 80 GiB of free device memory')
+    pin = np.load(os.path.join(root, 'tests', 'golden', 'pin28.npz'))
+    n, depth, batch = 28, 40, 16
+    spec = bench.random_circuit_spec(n, depth, 1234)
+    cir, data = bench.build_circuit(dq, n, spec, batch, torch.complex64, dev())
+    assert np.array_equal(data[0].cpu().numpy(), pin['angles_f32'])      # sample 0 = the reference's own angles
+    with torch.no_grad():
+        cir(data)
+        ev = cir.expectation()
+    assert dq.executor.LAST_RUN['passes'] > 0 and dq.executor.LAST_RUN['gates'] < len(spec)   # merged, fused
+    state = cir.state.reshape(batch, 1 << n)[:1].contiguous()
+    idx = torch.from_numpy(pin['indices']).to(state.device)
+    assert np.abs(state[0, idx].cpu().numpy() - pin['amplitudes']).max() < 1e-4
+    assert np.abs(state[0, idx].cpu().numpy() - pin['amplitudes']).max() < 1e-2 * np.abs(pin['amplitudes']).max()
+    assert abs(float(backend.expect_pauli(state, 0, 0)[0]) - float(pin['norm2'])) < 1e-4
+    ez = np.array([float(backend.expect_pauli(state, 0, 1 << (n - 1 - q))[0]) for q in range(n)])
+    assert np.abs(ez - pin['expectation_z']).max() < 1e-4
+    assert abs(float(ev.reshape(batch, -1)[0, 0]) - float(pin['expectation_z'][0])) < 1e-4
+    p0 = backend.marginal(state, [n - 1 - w for w in range(5)]).reshape(-1).cpu().numpy()
+    p1 = backend.marginal(state, [n - 1 - w for w in range(n - 5, n)]).reshape(-1).cpu().numpy()
+    assert np.abs(p0 - pin['marginal_wires_0_4']).max() < 1e-4
+    assert np.abs(p1 - pin['marginal_wires_last5']).max() < 1e-4
+    # the other samples carry other angles: they differ from sample 0 but stay normalised the same way
+    full = cir.state.reshape(batch, 1 << n)
+    norms = backend.expect_pauli(full, 0, 0).cpu().numpy()
+    assert np.abs(norms - 1).max() < 1e-4

@@ -160,7 +160,7 @@ def _case_folded_permute(dq, rank, world):
     from deepquantum_amd import distributed as D
 
     n, B = 21 + (world.bit_length() - 1), 4
-    spec = specs.random_spec(n, 4, 99)
+    spec = specs.random_spec(n, 6, 99)
     spec = [(m_, [a[0]], {'encode': True}) if m_ == 'rx' else (m_, a, k) for m_, a, k in spec]
     dense = _build(dq, dq.QubitCircuit, n, spec)
     data = (torch.rand(B, dense.ndata, generator=torch.Generator().manual_seed(8)) * 6.28).cuda()
@@ -176,11 +176,12 @@ def _case_folded_permute(dq, rank, world):
             shard = _build(dq, dq.DistributedQubitCircuit, n, spec)
             with torch.no_grad():
                 st = shard(data)
+                stats = dict(D.LAST_RUN)
                 ev = shard.expectation()
             assert (st.amps - ref).abs().max().item() < 1e-5, (fold, groups)
             assert (ev - ref_ev).abs().max().item() < 1e-5
-            assert D.LAST_RUN['remaps'] > 0
-            assert (D.LAST_RUN['folded_permutes'] > 0) == fold, D.LAST_RUN
+            assert stats['remaps'] > 0
+            assert (stats['folded_permutes'] > 0) == fold, stats
     finally:
         D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'] = True, 4
 

@@ -19,7 +19,7 @@ plan = list(dq.executor._PLAN_CACHE.values())[-1]
 steps = [s for s in plan.steps if isinstance(s, dq.fusion.FusedStep)]
 ev = dq.executor.PROFILE['events']
 tot = 0
-for i, (s, (a, b, ng)) in enumerate(zip(steps, ev)):
+for i, (s, (a, b, ng, _nb)) in enumerate(zip(steps, ev)):
     ms = a.elapsed_time(b); tot += ms
     kinds = {}
     for oi in s.ops:
