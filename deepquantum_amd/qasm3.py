@@ -245,7 +245,12 @@ def qasm3_to_cir(qasm_string: str) -> QubitCircuit:
             prog += d.body
             prog.append('}')
         prog.append(f'{name}{"(" + params + ")" if params else ""} ' + ', '.join(f'q[{i}]' for i in range(nq)) + ';')
-        return qasm3_to_cir('\n'.join(prog)).get_unitary()
+        sub = qasm3_to_cir('\n'.join(prog))
+        # the matrix comes from the gate kernels (QubitCircuit.get_unitary): on the GPU, like everything else
+        from . import backend
+        if backend.get_test_backend() is None and torch.cuda.is_available():
+            sub = sub.to('cuda')
+        return sub.get_unitary().cpu()
 
     def builtin(name: str, values: list[float], qubits: list[int], nctrl: int, outer: list[int], inverted: bool) -> None:
         controls, rest = outer + qubits[:nctrl], qubits[nctrl:]
