@@ -93,6 +93,7 @@ _SIGNATURES = {
     'dq_device_info': (_i, [_ip, C.POINTER(_i64), C.POINTER(_i64)]),
     'dq_fused_geometry': (_i, [_i, _i, _ip, _ip, _ip]),
     'dq_fused_set_tiles_per_wg': (_i, [_i]),
+    'dq_set_dense_path': (_i, [_i]),
     'dq_reduce_ws_bytes': (_i64, [_i64]),
     'dq_apply_gate_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _ip, _i, _ip, _i, _i64, _vp]),
     'dq_apply_fused_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp]),

@@ -1,0 +1,220 @@
+// Dense 2^k x 2^k gate (5 <= k <= 10) on the matrix cores: the one place on this path that is genuinely a GEMM
+// (UAnyGate / LatentGate blocks on many wires, and through them QubitCircuit.get_unitary; reference:
+// ArbitraryGate.get_unitary gate.py:318-330 -> evolve_state qmath.py:485-506, whose matmul has M = K = 2^k).
+//
+//     Y[r, c] = sum_j U[r, j] X[j, c]          r, j = patterns of the k target bits (matrix MSB = targets[0])
+//                                              c    = every other index bit with the controls at 1 (x batch)
+//
+// 8 * 2^k flop per 16 bytes moved: HBM-bound for k = 5, 6 (16 .. 32 flop/B), MFMA-bound from k = 7 on.  The parity bar
+// (1e-4 / 1e-10 against an f32 / f64 reference) rules out reduced-precision inputs, so the instructions are
+// v_mfma_f32_16x16x4_f32 and v_mfma_f64_16x16x4_f64: exact f32 / f64 fused multiply-add chains at 64 flop/clk/SIMD
+// (MI355X_MICROARCH.md: 157 TFLOP/s, what a packed-VALU kernel reaches only on paper).  The complex product is four
+// real ones per 16x16x4 block: Yr += Ur Xr - Ui Xi, Yi += Ur Xi + Ui Xr.
+//
+// A workgroup of 4 waves owns a tile of (WM * 32) rows x (4 / WM * 32) columns; a wave owns 32 x 32 (2 x 2 MFMA
+// blocks, re and im accumulators: 32 VGPRs).  The K loop walks the 2^k columns of U in chunks of 16: U's chunk and the
+// gathered X chunk go through LDS as separate re / im planes (one ds_read per MFMA operand, padded rows: no bank
+// conflicts), the NEXT chunk is already on its way from memory into registers while the MFMAs of this one run.
+// Gather / scatter addressing (any target positions, controls as fixed ones) is done once per thread.
+#include "dq_common.hpp"
+#include <type_traits>
+
+namespace dq {
+
+struct DenseGeom {
+    int n, k;
+    int tpos[10];          // bit position of matrix index bit k-1-i  (targets[i], MSB first)
+    BitList sorted;        // targets + controls ascending (for the column deposit)
+    uint64_t cmask;        // control bits (set in every column)
+    int colbits;           // n - k - nc
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+    using acc_t = f32x4;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // C/D element `reg` of lane `l`: row, column inside the 16 x 16 block
+    static __device__ __forceinline__ int row(int l, int reg) { return (l >> 4) * 4 + reg; }
+};
+template <> struct Mfma<double> {
+    using acc_t = f64x4;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int l, int reg) { return (l >> 4) + 4 * reg; }   // (f64 has its own map)
+};
+
+// offset (in amplitudes) that row / column-of-U pattern `j` contributes: matrix index bit k-1-i -> position tpos[i]
+__device__ __forceinline__ uint64_t target_offset(int j, const DenseGeom& g) {
+    uint64_t o = 0;
+    for (int i = 0; i < g.k; ++i) o |= (uint64_t)((j >> (g.k - 1 - i)) & 1) << g.tpos[i];
+    return o;
+}
+
+template <typename T, int WM>
+__global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
+                                                               const cx<T>* __restrict__ mats, int64_t mat_bstride,
+                                                               DenseGeom g, uint64_t ncols, int col_sample_shift) {
+    constexpr int WN = 4 / WM;
+    constexpr int TM = WM * 32, TN = WN * 32;      // workgroup tile: rows of U x columns
+    constexpr int KC = 16;                          // K chunk (complex columns of U per stage)
+    constexpr int APAD = KC + 1, BPAD = TN + 1;     // padded row lengths of the LDS planes (in elements)
+    using M = Mfma<T>;
+    using acc_t = typename M::acc_t;
+    __shared__ T sAr[TM * APAD], sAi[TM * APAD], sBr[KC * BPAD], sBi[KC * BPAD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int D = 1 << g.k;
+    const int row0 = blockIdx.y * TM;
+    const uint64_t col0 = (uint64_t)blockIdx.x * TN;
+    const int64_t zb = blockIdx.z;                  // sample (when every sample has its own matrix)
+    const cx<T>* U = mats + zb * mat_bstride;
+
+    // ---- staging assignment -----------------------------------------------------------------------------------
+    // A (U chunk): TM rows x KC complex = TM * KC / 256 elements per thread, consecutive k of one row
+    constexpr int A_PER = TM * KC / 256;            // 2 (WM = 1) or 4 (WM = 2)
+    const int a_row = (tid * A_PER) / KC, a_k = (tid * A_PER) % KC;
+    // B (X chunk): KC x TN complex = KC * TN / 256 per thread: column = tid % TN, k = tid / TN + i * (256 / TN)
+    constexpr int B_PER = KC * TN / 256;            // 8 (TN = 128) or 4 (TN = 64)
+    constexpr int B_KSTEP = 256 / TN;               // 2 or 4
+    const int b_col = tid % TN, b_k0 = tid / TN;
+    // where column col0 + b_col lives: sample (shared matrix: the batch is more columns) and amplitude base
+    const uint64_t my_col = col0 + (uint64_t)b_col;
+    const bool col_ok = my_col < ncols;
+    uint64_t col_base = 0;
+    {
+        const uint64_t c = col_ok ? my_col : 0;
+        const uint64_t sample = col_sample_shift >= 0 ? (c >> col_sample_shift) : (uint64_t)zb;
+        const uint64_t within = col_sample_shift >= 0 ? (c & ((1ull << col_sample_shift) - 1ull)) : c;
+        col_base = (sample << g.n) + (insert_zeros(within, g.sorted) | g.cmask);
+    }
+
+    cx<T> pa[A_PER], pb[B_PER];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) pa[i] = U[(int64_t)(row0 + a_row) * D + k0 + a_k + i];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int kk = k0 + b_k0 + i * B_KSTEP;                       // (uniform per wave-instruction group)
+            pb[i] = col_ok ? in[col_base + target_offset(kk, g)] : mk<T>(0, 0);
+        }
+    };
+    auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            sAr[a_row * APAD + a_k + i] = pa[i].x;
+            sAi[a_row * APAD + a_k + i] = pa[i].y;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            sBr[(b_k0 + i * B_KSTEP) * BPAD + b_col] = pb[i].x;
+            sBi[(b_k0 + i * B_KSTEP) * BPAD + b_col] = pb[i].y;
+        }
+    };
+
+    acc_t cr[2][2], ci[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) cr[a][b] = ci[a][b] = acc_t{0, 0, 0, 0};
+
+    const int l15 = lane & 15, l4 = lane >> 4;
+    fetch(0);
+    for (int k0 = 0; k0 < D; k0 += KC) {
+        __syncthreads();                            // everybody is done with the previous chunk
+        stash();
+        __syncthreads();
+        if (k0 + KC < D) fetch(k0 + KC);            // in flight while the matrix cores work on this chunk
+#pragma unroll
+        for (int ks = 0; ks < KC; ks += 4) {
+            T ar[2], ai[2], nai[2], br[2], bi[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {           // A[i = l & 15][k = l >> 4]
+                const int r = wm * 32 + a * 16 + l15;
+                ar[a] = sAr[r * APAD + ks + l4];
+                ai[a] = sAi[r * APAD + ks + l4];
+                nai[a] = -ai[a];
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {           // B[k = l >> 4][j = l & 15]
+                const int c = wn * 32 + b * 16 + l15;
+                br[b] = sBr[(ks + l4) * BPAD + c];
+                bi[b] = sBi[(ks + l4) * BPAD + c];
+            }
+            // 16 MFMAs; consecutive ones never touch the same accumulator
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    cr[a][b] = M::run(ar[a], br[b], cr[a][b]);
+                    ci[a][b] = M::run(ar[a], bi[b], ci[a][b]);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    cr[a][b] = M::run(nai[a], bi[b], cr[a][b]);
+                    ci[a][b] = M::run(ai[a], br[b], ci[a][b]);
+                }
+        }
+    }
+
+    // ---- scatter: lane holds column (lane & 15) of each block, four rows per block ------------------------------
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const uint64_t c = col0 + (uint64_t)(wn * 32 + b * 16 + l15);
+        if (c >= ncols) continue;
+        const uint64_t sample = col_sample_shift >= 0 ? (c >> col_sample_shift) : (uint64_t)zb;
+        const uint64_t within = col_sample_shift >= 0 ? (c & ((1ull << col_sample_shift) - 1ull)) : c;
+        cx<T>* po = out + (sample << g.n) + (insert_zeros(within, g.sorted) | g.cmask);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = row0 + wm * 32 + a * 16 + M::row(lane, reg);
+                po[target_offset(r, g)] = mk<T>(cr[a][b][reg], ci[a][b][reg]);
+            }
+    }
+}
+
+template <typename T>
+int apply_dense_mfma(const cx<T>* in, cx<T>* out, const cx<T>* mats, int64_t mat_bstride, int n, const int* targets, int k,
+                     const int* controls, int nc, const BitList& sorted, uint64_t cmask, int64_t batch, hipStream_t s) {
+    DenseGeom g;
+    g.n = n;
+    g.k = k;
+    for (int i = 0; i < k; ++i) g.tpos[i] = targets[i];
+    g.sorted = sorted;
+    g.cmask = cmask;
+    g.colbits = n - k - nc;
+    const int D = 1 << k;
+    // one matrix for all samples: the batch is just more columns of X
+    const bool shared = mat_bstride == 0;
+    const uint64_t ncols = (shared ? (uint64_t)batch : 1ull) << g.colbits;
+    const int shift = shared ? g.colbits : -1;
+    const unsigned gz = shared ? 1u : (unsigned)batch;
+    if (D == 32) {
+        constexpr int TN = 128;
+        dim3 grid((unsigned)((ncols + TN - 1) / TN), 1, gz);
+        hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 1>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
+    } else {
+        constexpr int TN = 64;
+        dim3 grid((unsigned)((ncols + TN - 1) / TN), (unsigned)(D / 64), gz);
+        hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
+    }
+    (void)controls;
+    return DQ_OK;
+}
+
+template int apply_dense_mfma<float>(const cx<float>*, cx<float>*, const cx<float>*, int64_t, int, const int*, int, const int*,
+                                     int, const BitList&, uint64_t, int64_t, hipStream_t);
+template int apply_dense_mfma<double>(const cx<double>*, cx<double>*, const cx<double>*, int64_t, int, const int*, int,
+                                      const int*, int, const BitList&, uint64_t, int64_t, hipStream_t);
+
+}  // namespace dq

@@ -98,6 +98,13 @@ __global__ __launch_bounds__(256) void apply_big_kernel(const cx<T>* __restrict_
     }
 }
 
+// csrc/dq_dense.hip: the same product on the matrix cores (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64)
+template <typename T>
+int apply_dense_mfma(const cx<T>* in, cx<T>* out, const cx<T>* mats, int64_t mat_bstride, int n, const int* targets, int k,
+                     const int* controls, int nc, const BitList& sorted, uint64_t cmask, int64_t batch, hipStream_t s);
+
+static int g_dense_path = 1;   // 1 = MFMA (default), 0 = one thread per output amplitude on the VALU (A/B, dq_set_dense_path)
+
 template <typename T>
 static int apply_gate_impl(const void* in, void* out, const void* mats, int64_t mat_bstride, int n,
                            const int* targets, int k, const int* controls, int nc, int64_t batch,
@@ -175,15 +182,35 @@ static int apply_gate_impl(const void* in, void* out, const void* mats, int64_t 
             set_error("dq_apply_gate: k=%d > 4 requires out != in", k);
             return DQ_ERR_ARG;
         }
-        uint64_t blocks = ((1ull << n) + 255) / 256;
-        if (blocks > (1u << 20)) blocks = 1u << 20;
-        dim3 grid((unsigned)blocks, (unsigned)batch);
-        hipLaunchKernelGGL(apply_big_kernel<T>, grid, dim3(256), 0, s, pin, pout, pm, mat_bstride, g);
+        if (g_dense_path == 1) {
+            // amplitudes whose controls are not all 1 are carried over; the MFMA kernel writes the controlled columns
+            if (nc > 0) {
+                uint64_t blocks = (total + 255) / 256;
+                if (blocks > 65536) blocks = 65536;
+                hipLaunchKernelGGL(copy_uncontrolled_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, pin, pout,
+                                   g.cmask, total);
+            }
+            apply_dense_mfma<T>(pin, pout, pm, mat_bstride, n, targets, k, controls, nc, g.sorted, g.cmask, batch, s);
+        } else {
+            uint64_t blocks = ((1ull << n) + 255) / 256;
+            if (blocks > (1u << 20)) blocks = 1u << 20;
+            dim3 grid((unsigned)blocks, (unsigned)batch);
+            hipLaunchKernelGGL(apply_big_kernel<T>, grid, dim3(256), 0, s, pin, pout, pm, mat_bstride, g);
+        }
     }
     return check_launch("dq_apply_gate");
 }
 
 }  // namespace dq
+
+extern "C" int dq_set_dense_path(int mfma) {
+    if (mfma != 0 && mfma != 1) {
+        dq::set_error("dq_set_dense_path: 0 (VALU) or 1 (MFMA)");
+        return DQ_ERR_ARG;
+    }
+    dq::g_dense_path = mfma;
+    return DQ_OK;
+}
 
 extern "C" int dq_apply_gate_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
                                  const int* targets, int k, const int* controls, int nc, int64_t batch,

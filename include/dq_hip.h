@@ -64,6 +64,10 @@ int dq_apply_gate_c128(const void* in, void* out, const void* mats, int64_t mat_
                        const int* targets, int k, const int* controls, int nc, int64_t batch,
                        dq_stream_t stream);
 
+/* Dense gates on 5..10 targets run as a GEMM on the matrix cores (csrc/dq_dense.hip; exact f32 / f64 MFMA).  A/B knob:
+ * 0 = the round-1 kernel (one thread per output amplitude, VALU), 1 = MFMA (default). */
+int dq_set_dense_path(int mfma);
+
 /* ------------------------------------------------------------------------------------------
  * 2. Fused pass.  Replaces a run of consecutive Gate.forward calls inside
  *    nn.Sequential(self.operators) (circuit.py:261, operation.py:274-289): one HBM read + one HBM

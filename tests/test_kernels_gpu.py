@@ -53,6 +53,35 @@ def test_apply_gate_all_positions(dtype, k, nc):
 
 
 @pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+@pytest.mark.parametrize('k,nc,n', [(5, 0, 7), (5, 2, 11), (6, 0, 9), (6, 1, 12), (7, 0, 12), (8, 1, 12), (9, 0, 11), (10, 0, 12),
+                                    (10, 2, 13), (7, 0, 7)])
+def test_dense_gates_on_the_matrix_cores(dtype, k, nc, n):
+    """Dense 2^k x 2^k blocks, k = 5..10 (csrc/dq_dense.hip: v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64): random
+    target / control positions (low bits and the top bit included, targets in any order), one matrix for the batch and
+    one per sample, fewer columns than a workgroup tile, against the oracle's permute / reshape / matmul -- and the
+    VALU kernel it replaces gives the same answer."""
+    b = 3
+    rng = random.Random(77 * k + nc + n)
+    x = rand_state(b, n, dtype, 11)
+    for trial in range(4):
+        bits = rng.sample(range(n), k + nc)
+        if trial == 0:
+            bits = list(range(k)) + bits[k:] if nc == 0 else bits          # the k lowest bits as targets
+        if trial == 1 and nc == 0:
+            bits = list(range(n - 1, n - 1 - k, -1))                       # the k highest, descending
+        m = rand_unitary(k, dtype, 100 + trial, batch=b if trial % 2 else None)
+        ref = oracle.apply_gate_bits(x, m, bits[:k], bits[k:])
+        got = backend.apply_gate(x.to(dev()), m.to(dev()), bits[:k], bits[k:]).cpu()
+        assert (got - ref).abs().max().item() < TOL[dtype], (k, nc, n, trial)
+    try:
+        _lib.check(_lib.load().dq_set_dense_path(0), 'dq_set_dense_path')
+        old = backend.apply_gate(x.to(dev()), m.to(dev()), bits[:k], bits[k:]).cpu()
+    finally:
+        _lib.check(_lib.load().dq_set_dense_path(1), 'dq_set_dense_path')
+    assert (old - ref).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
 def test_apply_gate_in_place_and_edges(dtype):
     n = 6
     x = rand_state(2, n, dtype, 3)
