@@ -79,6 +79,10 @@ def parse_args():
                     help='A/B: in-place passes (every pass gathers its qubits where they canonically live)')
     ap.add_argument('--no-merge', action='store_true',
                     help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
+    ap.add_argument('--no-lane-swaps', action='store_true',
+                    help='A/B: every layout change of a pass goes through LDS (no in-wave permlane / DPP exchanges)')
+    ap.add_argument('--swap-lanes', default=None, help='A/B: lane bits usable for in-wave exchanges, e.g. 4,5')
+    ap.add_argument('--swap-policy', default=None, choices=['plan', 'chance'])
     ap.add_argument('--tiles-per-wg', type=int, default=None,
                     help='A/B: tiles a complex64 workgroup walks with next-tile prefetch (1 = off; default: library)')
     ap.add_argument('--overlap-groups', type=int, default=None, help='N > 1: sample groups of the overlapped remap')
@@ -333,6 +337,12 @@ def main():
         dq.executor.CONFIG['merge_min_amps'] = None
     if args.no_permute_store:
         dq.executor.CONFIG['permute_store'] = False
+    if args.no_lane_swaps:
+        dq.executor.CONFIG['lane_swaps'] = False
+    if args.swap_policy is not None:
+        dq.executor.CONFIG['swap_policy'] = args.swap_policy
+    if args.swap_lanes is not None:
+        dq.executor.CONFIG['swap_lanes'] = tuple(int(x) for x in args.swap_lanes.split(',') if x != '')
     if args.overlap_groups is not None:
         dq.distributed.CONFIG['overlap_groups'] = args.overlap_groups
     if args.no_fold_permute:
@@ -502,6 +512,7 @@ def main():
                                 else 'single GPU'),
                 'fused_passes_per_step': stats.get('passes') if not distributed else launches / args.steps,
                 'lds_round_trips_per_step': stats.get('transposes') if not distributed else None,
+                'in_wave_exchange_rounds_per_step': stats.get('swaps') if not distributed else None,
                 # 2x2 matrices the kernel applies per sample after runs of one-qubit gates on the same qubit were
                 # multiplied together (executor.merge_one_qubit_runs; `--no-merge` applies all `ngates` one by one);
                 # `value` counts the circuit's gates, `unmerged_ms_per_step` times them one by one

@@ -16,10 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DQHIP_LIBRARY') or os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
-FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2 = range(5)
+FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_SWAP = range(6)
 LOC_REG, LOC_THR, LOC_OUT = range(3)
 
 FUSED_MAX_HIGH = 12
@@ -31,6 +31,7 @@ FUSED_MAX_BLK = 24
 ROUND_ALL_FAST = 0x80
 ROUND_TRANSPOSE = 0x01
 ROUND_TRANSPOSE_AFTER = 0x02
+ROUND_SWAP = 0x04
 FAST_NONE = 0xFFFFFFFF
 MAT_PAD = 16
 

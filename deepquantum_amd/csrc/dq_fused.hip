@@ -612,14 +612,19 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         const uint32_t rw1 = pw[ROUND_W0 + 4 * r + 1], rw2 = pw[ROUND_W0 + 4 * r + 2],
                        rw3 = pw[ROUND_W0 + 4 * r + 3];
         last_flags = (rw3 >> 8) & 0xffu;
-        if (last_flags & DQ_ROUND_TRANSPOSE) {
+        if (last_flags & (DQ_ROUND_TRANSPOSE | DQ_ROUND_SWAP)) {
             unsigned ntbase = 0;
 #pragma unroll
             for (int i = 0; i < LOGT; ++i) {
                 const uint32_t w = i < 4 ? rw1 : (i < 8 ? rw2 : rw3);
                 ntbase |= ((tid >> i) & 1u) << ((w >> (8 * (i & 3))) & 0xffu);
             }
-            transpose_to(ntbase, 1 + r);
+            if (last_flags & DQ_ROUND_TRANSPOSE) {
+                transpose_to(ntbase, 1 + r);
+            } else {        // the round's leading DQ_FG_SWAP records move the amplitudes inside the wavefronts
+                tbase = ntbase;
+                cur_tab = 1 + r;
+            }
         }
         const int gbeg = (int)((rw3 >> 16) & 0x7fu), gend = (int)(rw3 >> 24);
         if constexpr (FAST) {
@@ -862,7 +867,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
         const DqFusedRound& rd = p->rounds[r];
         unsigned used = 0;
         for (int s = 0; s < slots; ++s) {
-            if (rd.rb[s] >= m || (s > 0 && rd.rb[s] <= rd.rb[s - 1])) {
+            if (rd.rb[s] >= m || ((used >> rd.rb[s]) & 1u)) {
                 set_error("dq_apply_fused: round %d slot list invalid", r);
                 return DQ_ERR_ARG;
             }
@@ -900,10 +905,44 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
                     after = after || rd.tb[i] != stb[i];
                 }
             }
-            const unsigned want = (differs ? DQ_ROUND_TRANSPOSE : 0u) | (after ? DQ_ROUND_TRANSPOSE_AFTER : 0u);
+            // a layout change is an LDS trip or -- the host's choice, where it is possible -- in-wave exchanges
+            const bool swaps = differs && (rd.flags & DQ_ROUND_SWAP) != 0;
+            const unsigned want = (differs ? (swaps ? DQ_ROUND_SWAP : DQ_ROUND_TRANSPOSE) : 0u) |
+                                  (after ? DQ_ROUND_TRANSPOSE_AFTER : 0u);
             if (rd.flags != want) {
                 set_error("dq_apply_fused: round %d has layout flags %u, expected %u", r, rd.flags, want);
                 return DQ_ERR_ARG;
+            }
+            // the leading DQ_FG_SWAP records of the round, applied to the previous layout, must give this one
+            uint8_t erb[DQ_FUSED_MAX_SLOTS], etb[DQ_FUSED_MAX_TBITS];
+            for (int s = 0; s < slots; ++s) erb[s] = prb[s];
+            for (int i = 0; i < logt; ++i) etb[i] = ptb[i];
+            int nswap = 0;
+            for (int gi = rd.gate_begin & 0x7f; gi < rd.gate_end && p->gates[gi].kind == DQ_FG_SWAP; ++gi, ++nswap) {
+                const DqFusedGate& g = p->gates[gi];
+                if (!swaps || g.q >= slots || g.q2 >= 6 || g.q2 >= logt) {
+                    set_error("dq_apply_fused: round %d: exchange record %d is out of place or malformed", r, gi);
+                    return DQ_ERR_ARG;
+                }
+                const uint8_t t8 = erb[g.q];
+                erb[g.q] = etb[g.q2];
+                etb[g.q2] = t8;
+            }
+            if (swaps) {
+                bool same = nswap > 0 && sizeof(T) == 4 && slots == 4 && (rd.gate_begin & DQ_ROUND_ALL_FAST);
+                for (int s = 0; s < slots; ++s) same = same && erb[s] == rd.rb[s];
+                for (int i = 0; i < logt; ++i) same = same && etb[i] == rd.tb[i];
+                if (!same) {
+                    set_error("dq_apply_fused: round %d: the exchange records do not produce the round's layout "
+                              "(or the round is not an all-fast complex64 one)", r);
+                    return DQ_ERR_ARG;
+                }
+            }
+            for (int gi = (rd.gate_begin & 0x7f) + nswap; gi < rd.gate_end; ++gi) {
+                if (p->gates[gi].kind == DQ_FG_SWAP) {
+                    set_error("dq_apply_fused: round %d: exchange record %d does not lead the round", r, gi);
+                    return DQ_ERR_ARG;
+                }
             }
         }
         const int gate_begin = rd.gate_begin & 0x7f;
@@ -924,6 +963,14 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
                 return DQ_ERR_ARG;
             }
             const bool slot_kind = g.kind == DQ_FG_GEN1 || g.kind == DQ_FG_X1 || g.kind == DQ_FG_GEN2;
+            if (g.kind == DQ_FG_SWAP) {     // (position and layout were checked with the round)
+                if (g.mat != next_mat || g.mat_advance != 0 || g.reg_cmask || g.thr_cmask || g.out_cmask ||
+                    g.fast != 52u + 6u * g.q + g.q2) {
+                    set_error("dq_apply_fused: exchange record %d malformed", gi);
+                    return DQ_ERR_ARG;
+                }
+                continue;
+            }
             if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 3) || (g.kind == DQ_FG_GEN2 && g.loc > 1)) ||
                 (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
                 set_error("dq_apply_fused: gate %d malformed", gi);

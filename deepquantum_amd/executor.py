@@ -52,7 +52,7 @@ _PLAN_CACHE_SIZE = 64
 CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
           'max_gates': None, 'max_far': None, 'far_bit': None,
           # pass planner (fusion._plan_tiles): beam width / tiles tried per state; 0 = first-come tiles, 1 = greedy
-          'plan_width': None, 'plan_branch': None, 'asm_loop': None,
+          'plan_width': None, 'plan_branch': None, 'asm_loop': None, 'lane_swaps': None, 'swap_lanes': None, 'swap_policy': None,
           # out-of-place passes that write the next pass's qubits to cheap index bits (fusion._place_writes): needs a
           # second state buffer; used when both fit in `permute_mem_frac` of the device memory
           'permute_store': True, 'permute_mem_frac': 0.45, 'permute_min_bits': 20,
@@ -70,7 +70,7 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
 PROFILE = {'enabled': False, 'events': []}
 
 # Statistics of the most recent fused run (for bench.py and tests).
-LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'permute_folded': False}
+LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'swaps': 0, 'permute_folded': False}
 
 
 def _geometry(is128: bool) -> fusion.Geometry:
@@ -89,6 +89,18 @@ def _geometry(is128: bool) -> fusion.Geometry:
         g.plan_width = CONFIG['plan_width']
     if CONFIG['plan_branch'] is not None:
         g.plan_branch = CONFIG['plan_branch']
+    if CONFIG['lane_swaps'] is not None:
+        g.lane_swaps = bool(CONFIG['lane_swaps']) and not is128
+        if g.fallback is not None:
+            g.fallback.lane_swaps = g.lane_swaps
+    if CONFIG['swap_policy'] is not None:
+        g.swap_policy = CONFIG['swap_policy']
+        if g.fallback is not None:
+            g.fallback.swap_policy = g.swap_policy
+    if CONFIG['swap_lanes'] is not None:
+        g.swap_lanes = tuple(CONFIG['swap_lanes'])
+        if g.fallback is not None:
+            g.fallback.swap_lanes = g.swap_lanes
     if CONFIG['asm_loop'] is not None:
         g.asm_loop = CONFIG['asm_loop']
         if g.fallback is not None:
@@ -103,7 +115,7 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     if geom.fallback is not None:
         geom.fallback.permute_store = permute
     key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
-           geom.plan_branch, geom.asm_loop, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
+           geom.plan_branch, geom.asm_loop, geom.lane_swaps, geom.swap_lanes, geom.swap_policy, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
            tuple((p.kind, p.targets, p.controls, p.mode) for p in prims))
     plan = _PLAN_CACHE.get(key)
     if plan is not None:
@@ -337,7 +349,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         else:
             x = state.detach().clone(memory_format=torch.contiguous_format)
         flat, stride = _flat_mats(prims, plan.mat_order, x.shape[0], x.dtype, x.device)
-        stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0}
+        stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0, 'swaps': 0}
         spare = scratch                      # the caller's second buffer (if any)
         other = spare if permute else None
         scratch = None
@@ -362,6 +374,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 stats['passes'] += 1
                 stats['rounds'] += st.nrounds
                 stats['transposes'] += st.ntranspose
+                stats['swaps'] = stats.get('swaps', 0) + st.nswaps
             else:
                 op = plan.prim_ops[st.op]
                 d = 1 << op.k

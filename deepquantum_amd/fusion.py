@@ -48,6 +48,8 @@ class FusedStep:
     nrounds: int
     ntranspose: int           # LDS round trips the kernel will do (incl. back to canonical)
     permutes: bool = False    # writes to other index bits than it reads (needs in != out)
+    nswaps: int = 0           # layout changes done by in-wave exchanges instead (DQ_ROUND_SWAP)
+    records: list | None = None   # gate record -> index into the PrimOp list, None for an exchange record
 
 
 @dataclass
@@ -66,6 +68,9 @@ class Geometry:
     fallback: 'Geometry | None' = None   # smaller (faster per byte) tile for passes that do not need all gathered bits
     plan_width: int = 4       # gathered bits of every pass from dry runs of the pass (_plan_tiles): beam width
     plan_branch: int = 3      # ... and tiles tried per beam state; plan_width = 0: first-come tiles (no dry runs)
+    lane_swaps: bool = False  # layout changes by in-wave exchanges where possible (DQ_ROUND_SWAP; complex64 kernels)
+    swap_lanes: tuple = (0, 1, 2, 3, 4, 5)    # ... with these lane bits
+    swap_policy: str = 'chance'  # 'plan': LDS trips park the coming rounds' bits on lane bits; 'chance': trip-only layouts
     permute_store: bool = False   # passes may write to other index bits than they read (out-of-place; _place_writes)
     asm_loop: bool = True     # mark rounds whose gates all have handler ids (DQ_ROUND_ALL_FAST); off: A/B measurements
     plan_restarts: int = 3    # beam searches with different random branches (states of >= 2^plan_restart_bits amplitudes)
@@ -99,11 +104,11 @@ def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = No
     explicit = m is not None
     m = 13 if m is None else m
     slots = 4 if slots is None else slots
-    geom = Geometry(m=m, slots=slots, vb=1, min_low=max(4, m - _lib.FUSED_MAX_HIGH))
+    geom = Geometry(m=m, slots=slots, vb=1, min_low=max(4, m - _lib.FUSED_MAX_HIGH), lane_swaps=True)
     if not explicit:
         # a pass that needs no more than 8 gathered bits runs on the 12-bit tile: 5.4 instead of 5.0 TB/s for a
         # single gate application
-        geom.fallback = Geometry(m=12, slots=slots, vb=1, min_low=4)
+        geom.fallback = Geometry(m=12, slots=slots, vb=1, min_low=4, lane_swaps=True)
     return geom
 
 
@@ -547,14 +552,36 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         desc.high_pos[i] = b
         desc.high_sorted[i] = b
 
+    needs = [sorted(local[b] for b in rd.slots) for rd in rounds]
+    INF = 1 << 30
+
+    def next_use(bit: int, r0: int) -> int:
+        for r_ in range(r0, len(needs)):
+            if bit in needs[r_]:
+                return r_
+        return INF
+
+    # In-wave exchanges (DQ_ROUND_SWAP; complex64 gate loop): a round whose new register-slot bits all sit on LANE bits
+    # of the thread id gets them by v_permlane*_swap / DPP inside the wavefronts -- no LDS, no workgroup barrier --
+    # and every LDS trip therefore parks the bits the coming rounds need on the lane bits (soonest on bit 5, the
+    # cheapest exchange).  Only rounds of plain one-qubit gates and (C)NOTs qualify: their handlers exist whatever
+    # the layout, and the exchange lives in the assembly gate loop.
+    def simple(rd: _Round) -> bool:
+        return all(ops[oi].k == 1 and ((ops[oi].kind == 'x' and len(ops[oi].controls) <= 1) or
+                                       (ops[oi].kind == 'gen' and not ops[oi].controls)) for oi in rd.ops)
+
+    nreal = sum(len(rd.ops) for rd in rounds)
+    swap_budget = (_lib.FUSED_MAX_GATES - nreal) if geom.lane_swaps else 0     # exchange records share the gate array
+    nlanes = 6
     layouts: list[tuple[tuple[int, ...], tuple[int, ...]]] = []
+    swaps_of: list[list[tuple[int, int]]] = []
     prev: tuple[tuple[int, ...], tuple[int, ...]] | None = None
-    for rd in rounds:
-        need = sorted(local[b] for b in rd.slots)
+    for ri, (rd, need) in enumerate(zip(rounds, needs)):
         assert len(need) <= R
+        swaps: list[tuple[int, int]] = []
         if prev is not None and set(need) <= set(prev[0]):
             lay = prev
-        else:
+        elif not geom.lane_swaps:
             io = io_layout(need)
             if io is not None:
                 lay = (tuple(io), tuple(ascending_tb(io)))
@@ -568,7 +595,54 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
                         slots_l.append(c)
                 slots_l.sort()
                 lay = (tuple(slots_l), tuple(_thread_bit_order(m, slots_l, geom)))
+        else:
+            io = io_layout(need) if prev is None else None
+            cur = prev
+            if cur is None and io is None:
+                dio = io_layout([])
+                cur = (tuple(dio), tuple(ascending_tb(dio)))      # round 0 starts from the default load layout
+            if io is not None:
+                lay = (tuple(io), tuple(ascending_tb(io)))          # loaded straight from memory
+            else:
+                entering = [b for b in need if b not in cur[0]]
+                lane_of = {b: i for i, b in enumerate(cur[1][:nlanes]) if i in geom.swap_lanes}
+                victims = sorted((s_ for s_, b in enumerate(cur[0]) if b not in need),
+                                 key=lambda s_: (-next_use(cur[0][s_], ri + 1), s_))
+                if (simple(rd) and all(b in lane_of for b in entering) and len(entering) <= len(victims)
+                        and len(entering) <= swap_budget):
+                    new_slots, new_tb = list(cur[0]), list(cur[1])
+                    for b in sorted(entering, key=lambda b: -lane_of[b]):
+                        s_ = victims.pop(0)
+                        swaps.append((s_, lane_of[b]))
+                        new_tb[lane_of[b]], new_slots[s_] = new_slots[s_], b
+                    swap_budget -= len(swaps)
+                    lay = (tuple(new_slots), tuple(new_tb))
+                else:
+                    if geom.swap_policy == 'plan':
+                        # LDS trip: the free slots and the lane bits go to what the coming rounds need soonest: the very
+                        # next one on lane bit 5 (one v_permlane32_swap per register), the others in the order that
+                        # keeps the LDS accesses of this layout free of bank conflicts; the rest on the wave bits
+                        pool = sorted((b for b in range(m) if b not in need),
+                                      key=lambda b: (next_use(b, ri + 1), 0 if b in cur[0] else 1, -b))
+                        slots_l = sorted(list(need) + pool[: R - len(need)])
+                        free = sorted((b for b in range(m) if b not in slots_l), key=lambda b: (next_use(b, ri + 1), b))
+                        lane_set = free[:nlanes]
+                        others = _thread_bit_order(m, sorted(set(range(m)) - set(lane_set[1:])), geom)
+                        lay = (tuple(slots_l), tuple(others + lane_set[:1] + sorted(free[nlanes:])))
+                    else:
+                        # LDS trip with the layout the trip-only scheduler would take (slots: keep what is there, then
+                        # the top bits; thread bits in the bank-conflict-free order): exchanges happen where the next
+                        # round's bits happen to sit on usable lane bits
+                        slots_l = list(need)
+                        for c in list(cur[0])[::-1] + list(range(m - 1, -1, -1)):
+                            if len(slots_l) >= R:
+                                break
+                            if c not in slots_l:
+                                slots_l.append(c)
+                        slots_l.sort()
+                        lay = (tuple(slots_l), tuple(_thread_bit_order(m, slots_l, geom)))
         layouts.append(lay)
+        swaps_of.append(swaps)
         prev = lay
 
     def is_io(lay) -> bool:
@@ -576,7 +650,7 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         return io_layout(sl) == sl and list(lay[1]) == ascending_tb(sl)
 
     default_io = io_layout([])
-    load_rb = list(layouts[0][0]) if is_io(layouts[0]) else default_io
+    load_rb = list(layouts[0][0]) if is_io(layouts[0]) and not swaps_of[0] else default_io
     store_rb = list(layouts[-1][0]) if is_io(layouts[-1]) else default_io
     def goff(tl: int) -> int:                      # tile-local bit -> offset inside the state
         return 1 << (tl if tl < L else order[tl - L])
@@ -602,32 +676,48 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
     gi = 0
     ntrans = 0
     cur = (tuple(load_rb), tuple(ascending_tb(load_rb)))
+    records: list[int | None] = []        # gate record -> op index (None: an exchange record)
+    nswaps = 0
     for ri, (rd, lay) in enumerate(zip(rounds, layouts)):
         r = desc.rounds[ri]
         r.flags = 0
+        first = gi
         if lay != cur:
-            ntrans += 1
+            if swaps_of[ri]:
+                r.flags |= _lib.ROUND_SWAP
+                for s_, lane in swaps_of[ri]:
+                    g = desc.gates[gi]
+                    g.kind, g.q, g.q2, g.loc, g.loc2 = _lib.FG_SWAP, s_, lane, 0, 0
+                    g.reg_cmask = g.thr_cmask = g.out_cmask = 0
+                    g.mat = g.mat_advance = 0
+                    g.fast = 52 + 6 * s_ + lane
+                    records.append(None)
+                    gi += 1
+                nswaps += 1
+            else:
+                ntrans += 1
+                r.flags |= _lib.ROUND_TRANSPOSE
             cur = lay
-            r.flags |= _lib.ROUND_TRANSPOSE
         slot_of = {tl: s for s, tl in enumerate(lay[0])}
         for s in range(R):
             r.rb[s] = lay[0][s]
         for i, t in enumerate(lay[1]):
             r.tb[i] = t
         fill_table(1 + ri, lay[0])
-        first = gi
         for oi in rd.ops:
             _encode_gate(desc.gates[gi], ops[oi], local, slot_of, tile)
             exec_order.append(oi)
+            records.append(oi)
             gi += 1
         all_fast = all(desc.gates[k].fast != _lib.FAST_NONE for k in range(first, gi))
-        r.gate_begin = first | (_lib.ROUND_ALL_FAST if all_fast and geom.asm_loop else 0)
+        assert all_fast or not swaps_of[ri], 'an exchange round must consist of straight-line handlers'
+        r.gate_begin = first | (_lib.ROUND_ALL_FAST if all_fast and (geom.asm_loop or swaps_of[ri]) else 0)
         r.gate_end = gi
     if cur != (tuple(store_rb), tuple(ascending_tb(store_rb))):
         ntrans += 1
         desc.rounds[len(rounds) - 1].flags |= _lib.ROUND_TRANSPOSE_AFTER
     desc.nrounds = len(rounds)
-    return FusedStep(desc=desc, ops=exec_order, nrounds=len(rounds), ntranspose=ntrans)
+    return FusedStep(desc=desc, ops=exec_order, nrounds=len(rounds), ntranspose=ntrans, nswaps=nswaps, records=records)
 
 
 def lds_swizzle(e: int, period: int) -> int:
@@ -751,8 +841,12 @@ def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], 
     for st in steps:
         if isinstance(st, FusedStep):
             st.desc.mat_base = off
-            for gi, oi in enumerate(st.ops):
-                op, g = ops[oi], st.desc.gates[gi]
+            for gi, oi in enumerate(st.records if st.records is not None else st.ops):
+                g = st.desc.gates[gi]
+                if oi is None:                      # an exchange record: no matrix
+                    g.mat, g.mat_advance = off, 0
+                    continue
+                op = ops[oi]
                 size = 0 if g.kind == _lib.FG_X1 else (1 << op.k) ** 2
                 g.mat, g.mat_advance, op.pos = off, size, off
                 if size:

@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 14
+#define DQ_ABI_VERSION 15
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -87,7 +87,11 @@ typedef enum {
     DQ_FG_X1 = 1,    /* Pauli-X / CNOT / Toffoli: swap the pair of slot q     */
     DQ_FG_DIAG1 = 2, /* diagonal 2x2 (Z,S,T,Rz,P,CZ...) target anywhere      */
     DQ_FG_GEN2 = 3,  /* general 4x4 on register slots q (matrix MSB) and q2   */
-    DQ_FG_DIAG2 = 4  /* diagonal 4x4 (Rzz...) both targets anywhere           */
+    DQ_FG_DIAG2 = 4, /* diagonal 4x4 (Rzz...) both targets anywhere           */
+    DQ_FG_SWAP = 5   /* not a gate: in-wave exchange of register slot q with lane bit q2 (0..5) of the thread id --
+                        v_permlane32/16_swap for lane bits 5 / 4, DPP row shifts for 3 / 2, DPP quad permutations for
+                        1 / 0 -- a change of layout without LDS and without a workgroup barrier.  Only as the leading
+                        records of a DQ_ROUND_SWAP round of complex64 kernels; fast = 52 + 6 * q + q2 */
 } DqFusedKind;
 
 typedef enum { DQ_LOC_REG = 0, DQ_LOC_THR = 1, DQ_LOC_OUT = 2 } DqBitLoc;
@@ -121,6 +125,7 @@ typedef struct {
                             32..35  X on slot id - 32, thread / outside controls only
                             36..51  X on slot q with ONE register-slot control c (plus any thread / outside
                                     controls): id = 36 + 4 * q + c, c != q  (CNOT with both bits in registers)
+                            52..75  DQ_FG_SWAP of slot q with lane bit q2: id = 52 + 6 * q + q2 (complex64, gate loop only)
                            anything else (register-controlled 2x2 gates, X with two register controls, ...): NONE */
     uint64_t out_cmask; /* controls outside the tile (global bit positions) */
     uint32_t mat_advance; /* complex numbers this gate occupies in `mats` (0 for X1): the matrices of a pass
@@ -129,19 +134,20 @@ typedef struct {
     uint32_t reserved;  /* pads the record to 32 bytes: one s_load_dwordx8 per gate */
 } DqFusedGate;          /* 32 bytes */
 #define DQ_FAST_NONE 0xFFFFFFFFu
-#define DQ_FAST_IDS 52   /* handler ids are < DQ_FAST_IDS */
+#define DQ_FAST_IDS 76   /* handler ids are < DQ_FAST_IDS */
 /* `mats` must be readable for DQ_MAT_PAD complex numbers past the last matrix of a pass (prefetch). */
 #define DQ_MAT_PAD 16
 
 #define DQ_FUSED_MAX_TBITS 9
 #define DQ_FUSED_MAX_BLK 24      /* block-index bits: n - m <= 24 */
 typedef struct {
-    uint8_t rb[DQ_FUSED_MAX_SLOTS]; /* tile-local bit positions of the register slots, ascending */
+    uint8_t rb[DQ_FUSED_MAX_SLOTS]; /* tile-local bit position of register slot s (any order; the I/O layouts of the
+                                       pass header are ascending) */
     uint8_t tb[DQ_FUSED_MAX_TBITS]; /* tile-local bit position of thread-index bit i (the other m - slots
                                        tile bits, in an order the host picks to avoid LDS bank conflicts) */
     uint8_t flags;                  /* DQ_ROUND_TRANSPOSE: the layout (rb, tb) differs from the one the registers are in
                                        when the round starts (the previous round's, or the load layout for round 0) ->
-                                       one LDS round trip first; DQ_ROUND_TRANSPOSE_AFTER (last round only): the
+                                       one LDS round trip first; DQ_ROUND_SWAP: it differs by in-wave exchanges; DQ_ROUND_TRANSPOSE_AFTER (last round only): the
                                        layout differs from the store layout -> one LDS round trip before the store.
                                        The kernel trusts these flags (it no longer compares layouts per lane);
                                        dq_apply_fused_* recomputes and checks them. */
@@ -152,6 +158,10 @@ typedef struct {
 #define DQ_ROUND_ALL_FAST 0x80u
 #define DQ_ROUND_TRANSPOSE 0x01u
 #define DQ_ROUND_TRANSPOSE_AFTER 0x02u
+/* The layout (rb, tb) is the previous one with register slots exchanged against LANE bits of the thread id (thread
+ * bits 0..5): the round's leading gate records are DQ_FG_SWAP and carry it out inside the wavefronts; no LDS trip.
+ * Excludes DQ_ROUND_TRANSPOSE; needs DQ_ROUND_ALL_FAST (the exchange lives in the assembly gate loop). */
+#define DQ_ROUND_SWAP 0x04u
 
 typedef struct {
     uint8_t m, L, h, nrounds;

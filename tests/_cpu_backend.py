@@ -112,7 +112,7 @@ class CpuTestBackend:
         for gi in range(ngates):
             g = desc.gates[gi]
             assert g.mat == run, 'matrix layout is not sequential'
-            size = {_lib.FG_GEN1: 4, _lib.FG_X1: 0, _lib.FG_DIAG1: 4, _lib.FG_GEN2: 16, _lib.FG_DIAG2: 16}[g.kind]
+            size = {_lib.FG_GEN1: 4, _lib.FG_X1: 0, _lib.FG_DIAG1: 4, _lib.FG_GEN2: 16, _lib.FG_DIAG2: 16, _lib.FG_SWAP: 0}[g.kind]
             assert g.mat_advance == size
             run += size
         per_sample = mats.shape[-1] if mats.ndim == 2 else mats.numel()
@@ -130,8 +130,25 @@ class CpuTestBackend:
                 rd = desc.rounds[r]
                 rb = [rd.rb[s] for s in range(R)]
                 tb = [rd.tb[i] for i in range(logt)]
-                assert rb == sorted(set(rb)) and all(q < m for q in rb)
-                assert bool(rd.flags & _lib.ROUND_TRANSPOSE) == ((rb, tb) != lay), 'transposition flag wrong'
+                assert len(set(rb)) == R and all(q < m for q in rb)
+                first = rd.gate_begin & 0x7F
+                # a layout change is an LDS trip or (include/dq_hip.h, DQ_ROUND_SWAP) the in-wave exchanges that the
+                # round's leading DQ_FG_SWAP records spell out: slot q <-> lane bit q2 of the thread id
+                nswap = 0
+                exp_rb, exp_tb = list(lay[0]), list(lay[1])
+                while first + nswap < rd.gate_end and desc.gates[first + nswap].kind == _lib.FG_SWAP:
+                    g = desc.gates[first + nswap]
+                    assert rd.flags & _lib.ROUND_SWAP and g.q < R and g.q2 < 6, 'exchange record out of place'
+                    assert g.fast == 52 + 6 * g.q + g.q2 and g.mat_advance == 0
+                    assert g.reg_cmask == 0 and g.thr_cmask == 0 and g.out_cmask == 0
+                    exp_rb[g.q], exp_tb[g.q2] = exp_tb[g.q2], exp_rb[g.q]
+                    nswap += 1
+                assert all(desc.gates[k].kind != _lib.FG_SWAP for k in range(first + nswap, rd.gate_end))
+                if rd.flags & _lib.ROUND_SWAP:
+                    assert not is128 and nswap > 0 and (rb, tb) == (exp_rb, exp_tb) != lay, 'exchanges do not give the layout'
+                    assert rd.gate_begin & _lib.ROUND_ALL_FAST and not rd.flags & _lib.ROUND_TRANSPOSE
+                else:
+                    assert bool(rd.flags & _lib.ROUND_TRANSPOSE) == ((rb, tb) != lay), 'transposition flag wrong'
                 lay = (rb, tb)
                 store = [desc.store_rb[s] for s in range(R)]
                 store_tb = [q for q in range(m) if q not in store]
@@ -139,11 +156,10 @@ class CpuTestBackend:
                 assert bool(rd.flags & _lib.ROUND_TRANSPOSE_AFTER) == after, 'final transposition flag wrong'
                 assert sorted(rb + tb) == list(range(m)), 'slots + thread bits must cover the tile exactly'
                 slotmask = sum(1 << q for q in rb)
-                first = rd.gate_begin & 0x7F
                 if rd.gate_begin & _lib.ROUND_ALL_FAST:
                     assert all(desc.gates[k].fast != _lib.FAST_NONE for k in range(first, rd.gate_end)), \
                         'round promises handler ids for all gates'
-                for gi in range(first, rd.gate_end):
+                for gi in range(first + nswap, rd.gate_end):
                     g = desc.gates[gi]
                     assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
                     assert (g.reg_cmask >> R) == 0

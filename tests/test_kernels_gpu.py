@@ -126,6 +126,35 @@ def test_fused_passes_match_oracle(is128, m, n, seed):
     assert err < TOL[dtype], err
 
 
+@pytest.mark.parametrize('m,n,seeds', [(13, 15, [0, 2, 4, 5, 6, 7, 8, 9, 14, 16, 19, 21, 28, 33, 50, 58, 79, 103]),
+                                       (12, 14, [0, 2, 3, 4, 5, 6, 7, 8, 15, 18, 24, 27, 28, 29, 31, 33, 34, 65, 96])])
+def test_in_wave_exchanges_of_slots_and_lane_bits(m, n, seeds):
+    """DQ_ROUND_SWAP: layout changes carried out inside the wavefronts (v_permlane32/16_swap, DPP row shifts, DPP quad
+    permutations + v_cndmask) instead of through LDS.  The seeds are chosen so that every (register slot, lane bit)
+    pair -- 24 handlers -- occurs in some pass of the 13-bit tile; every run is compared with the oracle."""
+    dtype = torch.complex64
+    seen = set()
+    for seed in seeds:
+        ops, mats = random_ops(n, 80, seed, kinds=('gen', 'x'))
+        mats = mats.to(dtype)
+        steps = fusion.schedule(ops, n, fusion.default_geometry(False, m))
+        for st in steps:
+            if isinstance(st, fusion.FusedStep):
+                d = st.desc
+                for gi in range(d.rounds[d.nrounds - 1].gate_end):
+                    if d.gates[gi].kind == _lib.FG_SWAP:
+                        seen.add((d.gates[gi].q, d.gates[gi].q2))
+        x = rand_state(2, n, dtype, 300 + seed)
+        ref = run_reference(x, ops, mats)
+        assert all(isinstance(st, fusion.FusedStep) for st in steps)
+        xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
+        for st in steps:
+            backend.apply_fused(xd, md, 0, st.desc, out=xd)
+        err = (xd.cpu() - ref).abs().max().item()
+        assert err < TOL[dtype], (seed, err)
+    assert len(seen) >= (24 if m == 13 else 20), sorted(seen)
+
+
 @pytest.mark.parametrize('is128', [False, True])
 def test_fused_batched_matrices_and_out_of_place(is128):
     dtype = torch.complex128 if is128 else torch.complex64

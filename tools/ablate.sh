@@ -13,11 +13,12 @@ DQ_ABLATE_GATES=1 DQ_ASM_OUT=$PWD/$csrc/build/ablate/nogates_asm.inc python tool
 build() {   # tag, extra flags
   local tag=$1; shift
   $HIPCC $FLAGS "$@" -c $csrc/dq_fused.hip -o $csrc/build/ablate/dq_fused_$tag.o
-  $HIPCC --offload-arch=gfx950 -shared -fPIC $csrc/build/dq_capi.o $csrc/build/dq_gate.o $csrc/build/ablate/dq_fused_$tag.o \
+  $HIPCC --offload-arch=gfx950 -shared -fPIC $csrc/build/dq_capi.o $csrc/build/dq_gate.o $csrc/build/dq_dense.o $csrc/build/ablate/dq_fused_$tag.o \
      $csrc/build/dq_reduce.o $csrc/build/dq_dist.o -o deepquantum_amd/libdqhip_$tag.so
   echo "built deepquantum_amd/libdqhip_$tag.so"
 }
 build nogates "-DDQ_ASM_INC=\"$PWD/$csrc/build/ablate/nogates_asm.inc\"" &
 build nolds -DDQ_ABLATE_LDS &
 build nogates_nolds "-DDQ_ASM_INC=\"$PWD/$csrc/build/ablate/nogates_asm.inc\"" -DDQ_ABLATE_LDS &
+build nobar -DDQ_ABLATE_BARRIER &
 wait

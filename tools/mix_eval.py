@@ -23,5 +23,5 @@ for i, s in enumerate(steps):
     c = collections.Counter(name(merged[oi]) for oi in s.ops)
     v = sum(cost[k] * m for k, m in c.items())
     tot += v
-    print(f'pass {i:2d} m={s.desc.m} gates {len(s.ops):3d} rounds {s.nrounds} trips {s.ntranspose} valu~{v} {dict(c)}')
-print('trips', sum(s.ntranspose for s in steps)); print('passes', len(steps), 'gate VALU per pass', tot / len(steps))
+    print(f'pass {i:2d} m={s.desc.m} gates {len(s.ops):3d} rounds {s.nrounds} trips {s.ntranspose} swaps {s.nswaps} valu~{v} {dict(c)}')
+print('trips', sum(s.ntranspose for s in steps)); print('LDS trips', sum(s.ntranspose for s in steps), 'in-wave exchange rounds', sum(s.nswaps for s in steps)); print('passes', len(steps), 'gate VALU per pass', tot / len(steps))

@@ -1,14 +1,15 @@
 #!/bin/bash
-# Everything profiles/<tag>/ holds, in one go on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r01'
+# Everything profiles/<tag>/ holds, in one go on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
 # then copy gpurun_out/prof/<tag>/{summary.txt,kernel_stats.csv,traffic_*.json,bench_*.json,*.txt} to profiles/<tag>/.
 cd "$(dirname "$0")/.."
-tag=${1:-r01}
+tag=${1:-r02}
 root=$PWD/gpurun_out/prof/$tag
 bash tools/profile.sh "$tag" > /dev/null 2>&1
 cp "$root/traffic.json" "$root/traffic_n28_b16_c64.json" 2>/dev/null
 cp "$root"/trace/*kernel_stats.csv "$root/kernel_stats.csv" 2>/dev/null || find "$root/trace" -name '*kernel_stats.csv' -exec cp {} "$root/kernel_stats.csv" \;
 cp "$root/bench_trace.json" "$root/bench_under_rocprof.json"
 python bench.py --traffic-json "$root/traffic_n28_b16_c64.json" > "$root/bench_default.json" 2> "$root/bench_default.err"
+bash tools/ablation_table.sh > "$root/ablation.txt" 2>&1
 bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
 bash tools/mb_counters.sh --dtype c128 > "$root/microbench_c128.txt" 2>&1
 {
@@ -18,6 +19,7 @@ bash tools/mb_counters.sh --dtype c128 > "$root/microbench_c128.txt" 2>&1
   python tools/bench_density.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_expect.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_config2.py 2>&1 | grep -v amdgpu.ids
+  python tools/bench_dense.py 2>&1 | grep -v amdgpu.ids
   python bench.py --dtype c128 --batch 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null
 } > "$root/secondary_benchmarks.txt" 2>&1
 ls -la "$root"
