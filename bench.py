@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument('--plan-width', type=int, default=None,
                     help='pass planner beam width (0 = first-come tiles, 1 = greedy; default: library)')
     ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
+    ap.add_argument('--plan-restarts', type=int, default=None, help='pass planner: beam searches with different seeds')
     ap.add_argument('--no-asm-loop', action='store_true', help='A/B: gate loop in C++ around the jump table')
     ap.add_argument('--no-compare', action='store_true',
                     help='skip the extra runs (merging off, single-gate sweep): tools/profile.sh uses it so that the '
@@ -331,6 +332,7 @@ def main():
     dq.executor.CONFIG['far_bit'] = args.far_bit
     dq.executor.CONFIG['plan_width'] = args.plan_width
     dq.executor.CONFIG['plan_branch'] = args.plan_branch
+    dq.executor.CONFIG['plan_restarts'] = args.plan_restarts
     if args.no_asm_loop:
         dq.executor.CONFIG['asm_loop'] = False
     if args.no_merge:

@@ -52,7 +52,7 @@ _PLAN_CACHE_SIZE = 64
 CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
           'max_gates': None, 'max_far': None, 'far_bit': None,
           # pass planner (fusion._plan_tiles): beam width / tiles tried per state; 0 = first-come tiles, 1 = greedy
-          'plan_width': None, 'plan_branch': None, 'asm_loop': None, 'lane_swaps': None, 'swap_lanes': None, 'swap_policy': None,
+          'plan_width': None, 'plan_branch': None, 'plan_restarts': None, 'asm_loop': None, 'lane_swaps': None, 'swap_lanes': None, 'swap_policy': None,
           # out-of-place passes that write the next pass's qubits to cheap index bits (fusion._place_writes): needs a
           # second state buffer; used when both fit in `permute_mem_frac` of the device memory
           'permute_store': True, 'permute_mem_frac': 0.45, 'permute_min_bits': 20,
@@ -63,7 +63,9 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
           'small_fuse_min_gates': 6,
           # no-grad runs on states of at least this many amplitudes (batch included) multiply runs of one-qubit gates
           # on the same qubit into one matrix before planning (merge_one_qubit_runs); None = never
-          'merge_min_amps': 1 << 27}
+          'merge_min_amps': 1 << 27,
+          # from this many amplitudes (batch included) on, the pass planner searches wider (make_plan)
+          'plan_big_amps': 1 << 31}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates, bytes read + written) to report the kernel's average duration next to its algorithmic bytes.
@@ -89,6 +91,8 @@ def _geometry(is128: bool) -> fusion.Geometry:
         g.plan_width = CONFIG['plan_width']
     if CONFIG['plan_branch'] is not None:
         g.plan_branch = CONFIG['plan_branch']
+    if CONFIG['plan_restarts'] is not None:
+        g.plan_restarts = CONFIG['plan_restarts']
     if CONFIG['lane_swaps'] is not None:
         g.lane_swaps = bool(CONFIG['lane_swaps']) and not is128
         if g.fallback is not None:
@@ -109,13 +113,25 @@ def _geometry(is128: bool) -> fusion.Geometry:
 
 
 def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
-              out_perm: Sequence[int] | None = None) -> Plan:
+              out_perm: Sequence[int] | None = None, amps: int = 0) -> Plan:
+    """``amps`` = amplitudes the plan will be run on (batch included): from ``CONFIG['plan_big_amps']`` on a step
+    takes long enough (>= 0.1 s) for a wider search of the pass planner to pay for itself within a few steps
+    (measured on the headline: 21 -> 20 passes, -2.7 %, 4.6 s of planning once per circuit structure)."""
     geom = _geometry(is128)
+    if amps >= CONFIG['plan_big_amps']:
+        for g_ in (geom, geom.fallback):
+            if g_ is not None:
+                if CONFIG['plan_width'] is None:
+                    g_.plan_width = 8
+                if CONFIG['plan_branch'] is None:
+                    g_.plan_branch = 4
+                if CONFIG['plan_restarts'] is None:
+                    g_.plan_restarts = 6
     geom.permute_store = permute
     if geom.fallback is not None:
         geom.fallback.permute_store = permute
     key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
-           geom.plan_branch, geom.asm_loop, geom.lane_swaps, geom.swap_lanes, geom.swap_policy, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
+           geom.plan_branch, geom.plan_restarts, geom.asm_loop, geom.lane_swaps, geom.swap_lanes, geom.swap_policy, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
            tuple((p.kind, p.targets, p.controls, p.mode) for p in prims))
     plan = _PLAN_CACHE.get(key)
     if plan is not None:
@@ -336,7 +352,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 # what still has to be allocated: the second buffer, and the private working copy unless the caller's
                 # state is updated in place (never here: `inplace` runs do not permute)
                 permute = 2 * nbytes <= CONFIG['permute_mem_frac'] * total and 2.05 * nbytes <= free
-        plan = make_plan(prims, n, is128, permute, out_perm if permute else None)
+        plan = make_plan(prims, n, is128, permute, out_perm if permute else None, amps=state.numel())
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies
         shared_in = None

@@ -268,3 +268,28 @@ def test_permuted_stores_make_every_later_tile_contiguous(cpu_backend):
             cur = backend.apply_gate(cur, mats[op.mat : op.mat + d2 * d2].reshape(d2, d2), op.targets, op.controls)
     ref = run_reference(x, ops, mats)
     assert (cur - ref).abs().max().item() < 2e-5
+
+
+def test_exchange_seeds_of_the_gpu_test_cover_all_handlers():
+    """tests/test_kernels_gpu.py::test_in_wave_exchanges_of_slots_and_lane_bits relies on seeds whose schedules contain
+    every (register slot, lane bit) exchange: checked here, on the CPU, so that a scheduler change shows up before the
+    GPU run does."""
+    import ast
+    import os
+
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'test_kernels_gpu.py')).read()
+    marker = "@pytest.mark.parametrize('m,n,seeds', "
+    cases = ast.literal_eval(src[src.index(marker) + len(marker):src.index(')\ndef test_in_wave_exchanges')])
+    for m, n, seeds in cases:
+        seen = set()
+        for seed in seeds:
+            ops, _mats = random_ops(n, 80, seed, kinds=('gen', 'x'))
+            geom = fusion.default_geometry(False, m)
+            geom.swap_policy = 'plan'
+            for st in fusion.schedule(ops, n, geom):
+                assert isinstance(st, fusion.FusedStep)
+                d = st.desc
+                for gi in range(d.rounds[d.nrounds - 1].gate_end):
+                    if d.gates[gi].kind == _lib.FG_SWAP:
+                        seen.add((d.gates[gi].q, d.gates[gi].q2))
+        assert len(seen) == 24, (m, n, sorted(seen))

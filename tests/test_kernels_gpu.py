@@ -126,8 +126,8 @@ def test_fused_passes_match_oracle(is128, m, n, seed):
     assert err < TOL[dtype], err
 
 
-@pytest.mark.parametrize('m,n,seeds', [(13, 15, [0, 2, 4, 5, 6, 7, 8, 9, 14, 16, 19, 21, 28, 33, 50, 58, 79, 103]),
-                                       (12, 14, [0, 2, 3, 4, 5, 6, 7, 8, 15, 18, 24, 27, 28, 29, 31, 33, 34, 65, 96])])
+@pytest.mark.parametrize('m,n,seeds', [(13, 15, [0, 2, 4, 5, 6, 7, 8, 9, 11, 14, 16, 17, 19, 20, 28, 41, 79, 117]),
+                                       (12, 14, [0, 2, 3, 4, 5, 6, 7, 8, 15, 18, 21, 24, 27, 28, 29, 33, 34, 50, 101, 209])])
 def test_in_wave_exchanges_of_slots_and_lane_bits(m, n, seeds):
     """DQ_ROUND_SWAP: layout changes carried out inside the wavefronts (v_permlane32/16_swap, DPP row shifts, DPP quad
     permutations + v_cndmask) instead of through LDS.  The seeds are chosen so that every (register slot, lane bit)
@@ -137,7 +137,9 @@ def test_in_wave_exchanges_of_slots_and_lane_bits(m, n, seeds):
     for seed in seeds:
         ops, mats = random_ops(n, 80, seed, kinds=('gen', 'x'))
         mats = mats.to(dtype)
-        steps = fusion.schedule(ops, n, fusion.default_geometry(False, m))
+        geom = fusion.default_geometry(False, m)
+        geom.swap_policy = 'plan'          # LDS trips park the coming rounds' bits on lane bits: many exchanges
+        steps = fusion.schedule(ops, n, geom)
         for st in steps:
             if isinstance(st, fusion.FusedStep):
                 d = st.desc
@@ -152,7 +154,7 @@ def test_in_wave_exchanges_of_slots_and_lane_bits(m, n, seeds):
             backend.apply_fused(xd, md, 0, st.desc, out=xd)
         err = (xd.cpu() - ref).abs().max().item()
         assert err < TOL[dtype], (seed, err)
-    assert len(seen) >= (24 if m == 13 else 20), sorted(seen)
+    assert len(seen) == 24, sorted(seen)        # (the seeds come from a dry run of the scheduler; re-derive them if it changes)
 
 
 @pytest.mark.parametrize('is128', [False, True])
