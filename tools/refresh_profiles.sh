@@ -20,6 +20,7 @@ bash tools/mb_counters.sh --dtype c128 > "$root/microbench_c128.txt" 2>&1
   python tools/bench_expect.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_config2.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_dense.py 2>&1 | grep -v amdgpu.ids
+  python tools/bench_single_gate_kernel.py 2>&1 | grep -v amdgpu.ids
   python bench.py --dtype c128 --batch 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null
 } > "$root/secondary_benchmarks.txt" 2>&1
 ls -la "$root"
