@@ -696,7 +696,7 @@ class DistributedQubitCircuit(QubitCircuit):
         if state is None:
             if self.init_state.batch != batch:
                 old = self.init_state.amps
-                self.init_state = DistributedQubitState(self.nqubit, batch).to(old.device, old.real.dtype)
+                self.init_state = DistributedQubitState(self.nqubit, batch, device=old.device, dtype=old.dtype)
             self.init_state.reset()
         else:
             self.init_state = state

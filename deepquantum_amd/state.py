@@ -75,7 +75,12 @@ class DistributedQubitState(_ComplexBuffers):
 
     _complex_names = ('amps', 'buffer')
 
-    def __init__(self, nqubit: int, batch: int | None = None) -> None:
+    #: shards of more amplitudes than this are not built until ``reset()`` (the first forward), on the device the
+    #: state has been moved to by then: a 2^31-amplitude shard (16 GiB + 16 GiB receive buffer) must not be
+    #: allocated in host memory by every rank first and copied over PCIe
+    LAZY_AMPS = 1 << 24
+
+    def __init__(self, nqubit: int, batch: int | None = None, device: Any = None, dtype: torch.dtype = torch.cfloat) -> None:
         super().__init__()
         self.world_size = comm_get_world_size()
         self.rank = comm_get_rank()
@@ -87,15 +92,20 @@ class DistributedQubitState(_ComplexBuffers):
         self.log_num_nodes = log_base2(self.world_size)
         self.log_num_amps_per_node = nqubit - self.log_num_nodes
         self.num_amps_per_node = power_of_2(self.log_num_amps_per_node)
-        shape = (self.num_amps_per_node,) if batch is None else (batch, self.num_amps_per_node)
-        amps = torch.zeros(shape) + 0j
-        self.register_buffer('amps', amps)
-        self.register_buffer('buffer', torch.zeros_like(amps))
-        self.reset()
+        self._shape = (self.num_amps_per_node,) if batch is None else (batch, self.num_amps_per_node)
+        empty = torch.zeros(0, dtype=dtype, device=device)
+        self.register_buffer('amps', empty)
+        self.register_buffer('buffer', empty.clone())
+        if (batch or 1) * self.num_amps_per_node <= self.LAZY_AMPS or device is not None:
+            self.reset()
 
     def reset(self) -> None:
-        self.amps.zero_()
-        self.buffer.zero_()
+        if tuple(self.amps.shape) != tuple(self._shape):
+            self.amps = torch.zeros(self._shape, dtype=self.amps.dtype, device=self.amps.device)
+            self.buffer = torch.zeros_like(self.amps)
+        else:
+            self.amps.zero_()
+            self.buffer.zero_()
         self.__dict__.pop('_phys', None)   # canonical qubit order
         if self.rank == 0:
             self.amps[..., 0] = 1.0
