@@ -1,8 +1,8 @@
 #!/bin/bash
 # Timing experiments on the fused pass: builds variants of libdqhip.so with parts of the kernel removed (results are
-# WRONG, only the time is of interest) next to the real library, as deepquantum_amd/libdqhip_<tag>.so.
+# WRONG, only the time is of interest) as deepquantum_amd/csrc/build/ablate/libdqhip_<tag>.so.
 # usage: tools/ablate.sh            (here, no GPU needed)
-#        DQHIP_LIBRARY=$PWD/deepquantum_amd/libdqhip_nogates.so python bench.py ...      (on the GPU box)
+#        DQHIP_LIBRARY=$PWD/deepquantum_amd/csrc/build/ablate/libdqhip_nogates.so python bench.py ...      (on the GPU box)
 set -euo pipefail
 cd "$(dirname "$0")/.."
 csrc=deepquantum_amd/csrc
@@ -14,8 +14,8 @@ build() {   # tag, extra flags
   local tag=$1; shift
   $HIPCC $FLAGS "$@" -c $csrc/dq_fused.hip -o $csrc/build/ablate/dq_fused_$tag.o
   $HIPCC --offload-arch=gfx950 -shared -fPIC $csrc/build/dq_capi.o $csrc/build/dq_gate.o $csrc/build/dq_dense.o $csrc/build/ablate/dq_fused_$tag.o \
-     $csrc/build/dq_reduce.o $csrc/build/dq_dist.o -o deepquantum_amd/libdqhip_$tag.so
-  echo "built deepquantum_amd/libdqhip_$tag.so"
+     $csrc/build/dq_reduce.o $csrc/build/dq_dist.o -o $csrc/build/ablate/libdqhip_$tag.so
+  echo "built $csrc/build/ablate/libdqhip_$tag.so"
 }
 build nogates "-DDQ_ASM_INC=\"$PWD/$csrc/build/ablate/nogates_asm.inc\"" &
 build nolds -DDQ_ABLATE_LDS &

@@ -9,7 +9,7 @@ echo "# headline workload (n=28, depth 40, c64, batch 16), 3 steps each, same bo
 run full_kernel
 run no_prefetch_one_tile_per_wg --tiles-per-wg 1
 for v in nogates nolds nobar nogates_nolds; do
-  [ -f deepquantum_amd/libdqhip_$v.so ] && DQHIP_LIBRARY=$PWD/deepquantum_amd/libdqhip_$v.so run ablated_$v
+  [ -f deepquantum_amd/csrc/build/ablate/libdqhip_$v.so ] && DQHIP_LIBRARY=$PWD/deepquantum_amd/csrc/build/ablate/libdqhip_$v.so run ablated_$v
 done
 DQ_LDS_PAD_KB=24 run one_workgroup_per_cu
 run tile12_four_workgroups_per_cu --tile-bits 12
