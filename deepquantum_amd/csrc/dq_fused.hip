@@ -606,6 +606,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     // running byte offset of the current gate's matrix from `mbase` (32 bits: SMEM takes base pair + SGPR offset)
     uint32_t moff = pw[offsetof(DqFusedPass, mat_base) / 4] * (uint32_t)sizeof(V);
     T hscale = T(1);   // product of the deferred Hadamard factors of this pass (uniform)
+    float hsr = 1.0f, hsi = 0.0f;   // complex64: the deferred factor is complex (Hadamards and Rx-like gates, dq_hip.h)
     bool had = false;
     unsigned last_flags = 0;
     for (int r = 0; r < nrounds; ++r) {
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
             if (rw3 & (DQ_ROUND_ALL_FAST << 16)) {   // the whole gate loop of the round in assembly (dq_fused_asm.inc)
                 uint32_t goff = 32u * (unsigned)gbeg;
                 if constexpr (FAST32)
-                    fast_gate_loop_f32(a, kgates, goff, 32u * (unsigned)gend, mbase_u, moff, tile_global, tbase, hscale);
+                    fast_gate_loop_f32(a, kgates, goff, 32u * (unsigned)gend, mbase_u, moff, tile_global, tbase, hsr, hsi);
                 else
                     fast_gate_loop_f64(a, kgates, goff, 32u * (unsigned)gend, mbase_u, moff, tile_global, tbase, hscale);
                 continue;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
                         // the cost of reaching it does not depend on which one it is; handlers of controlled gates test
                         // the outside and thread controls themselves.
                         const uint64_t mq[4] = {DQ_PAIR(0), DQ_PAIR(1), DQ_PAIR(2), DQ_PAIR(3)};
-                        fast_dispatch_f32(a, mq, mqv[0], fast, g1, out_cmask, tile_global, tbase, hscale);
+                        fast_dispatch_f32(a, mq, mqv[0], mqv[1], mqv[6], fast, g1, out_cmask, tile_global, tbase, hsr, hsi);
                     } else {
                         const double md[8] = {__longlong_as_double((long long)DQ_PAIR(0)), __longlong_as_double((long long)DQ_PAIR(1)),
                                               __longlong_as_double((long long)DQ_PAIR(2)), __longlong_as_double((long long)DQ_PAIR(3)),
@@ -733,7 +734,14 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
     }
 
-    if (had || FAST) {
+    if constexpr (FAST32) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {      // a[j] *= hsr + i hsi
+            const float x = a[j].x, y = a[j].y;
+            a[j].x = fmaf(x, hsr, -y * hsi);
+            a[j].y = fmaf(x, hsi, y * hsr);
+        }
+    } else if (had || FAST) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             a[j].x *= hscale;

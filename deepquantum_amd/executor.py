@@ -43,6 +43,8 @@ class Plan:
     mat_total: int                 # complex numbers per batch sample in the flat matrix buffer (incl. tail pad)
     n_fused: int
     n_single: int
+    rx_defer: list[int] | None = None      # matrix-buffer offsets of the gates on the deferred Rx handlers
+    _rx_index: dict | None = None          # ... as a LongTensor per device
 
 
 _PLAN_CACHE: OrderedDict = OrderedDict()
@@ -145,7 +147,8 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     order, total = fusion.layout_matrices(steps, prim_ops)
     plan = Plan(steps, prim_ops, order, total,
                 sum(isinstance(s, fusion.FusedStep) for s in steps),
-                sum(isinstance(s, fusion.SingleStep) for s in steps))
+                sum(isinstance(s, fusion.SingleStep) for s in steps),
+                rx_defer=fusion.rx_defer_positions(steps, prim_ops), _rx_index={})
     _PLAN_CACHE[key] = plan
     if len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
         _PLAN_CACHE.popitem(last=False)
@@ -217,7 +220,7 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
     return _run_nograd(state, prims, inplace, scratch, out_perm)
 
 
-_MERGE_COST = {3: 30, 2: 45, 1: 45, 0: 79}    # issue slots of a wave per one-qubit gate, by matrix structure
+_MERGE_COST = {3: 30, 2: 37, 1: 45, 0: 79}    # issue slots of a wave per one-qubit gate, by matrix structure
 
 
 def merge_one_qubit_runs(prims: Sequence[Prim]) -> list[Prim]:
@@ -365,6 +368,11 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         else:
             x = state.detach().clone(memory_format=torch.contiguous_format)
         flat, stride = _flat_mats(prims, plan.mat_order, x.shape[0], x.dtype, x.device)
+        if plan.rx_defer:       # uncontrolled Rx-like gates of complex64 passes: the deferred form (fusion.defer_rx)
+            idx = plan._rx_index.get(x.device)
+            if idx is None:
+                idx = plan._rx_index[x.device] = torch.tensor(plan.rx_defer, dtype=torch.long, device=x.device)
+            fusion.defer_rx(flat, idx)
         stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0, 'swaps': 0}
         spare = scratch                      # the caller's second buffer (if any)
         other = spare if permute else None

@@ -49,6 +49,7 @@ class FusedStep:
     ntranspose: int           # LDS round trips the kernel will do (incl. back to canonical)
     permutes: bool = False    # writes to other index bits than it reads (needs in != out)
     nswaps: int = 0           # layout changes done by in-wave exchanges instead (DQ_ROUND_SWAP)
+    c64: bool = False         # a complex64 pass: uncontrolled Rx-like gates take the deferred form (defer_rx)
     records: list | None = None   # gate record -> index into the PrimOp list, None for an exchange record
 
 
@@ -717,7 +718,8 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         ntrans += 1
         desc.rounds[len(rounds) - 1].flags |= _lib.ROUND_TRANSPOSE_AFTER
     desc.nrounds = len(rounds)
-    return FusedStep(desc=desc, ops=exec_order, nrounds=len(rounds), ntranspose=ntrans, nswaps=nswaps, records=records)
+    return FusedStep(desc=desc, ops=exec_order, nrounds=len(rounds), ntranspose=ntrans, nswaps=nswaps, records=records,
+                     c64=vb == 1)
 
 
 def lds_swizzle(e: int, period: int) -> int:
@@ -860,6 +862,38 @@ def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], 
     return order, off + _lib.MAT_PAD
 
 
+def rx_defer_positions(steps: Sequence, ops: Sequence[PrimOp]) -> list[int]:
+    """Offsets (kernel matrix buffer, after ``layout_matrices``) of the gates that run on the deferred Rx handlers:
+    uncontrolled Rx-like gates (straight-line handler ids 8..11) of complex64 passes."""
+    pos = []
+    for st in steps:
+        if isinstance(st, FusedStep) and st.c64:
+            for gi, oi in enumerate(st.records if st.records is not None else st.ops):
+                if oi is not None and 8 <= st.desc.gates[gi].fast <= 11:
+                    pos.append(ops[oi].pos)
+    return pos
+
+
+def defer_rx(flat, index):
+    """Rewrite, in the kernel matrix buffer ``flat`` (Bm, total), the blocks of the gates at ``index`` (a LongTensor of
+    ``rx_defer_positions``) from the matrix  a I + i b X  to what the deferred handlers read (include/dq_hip.h,
+    DQ_MODE_RX):  f = a, t = b / a  where |a| >= |b|,  f = i b, t = -a / b  elsewhere; per sample.  The scalar f
+    leaves the gate and is applied once per pass: three packed operations per amplitude pair instead of four."""
+    import torch
+
+    if index is None or index.numel() == 0:
+        return flat
+    a = flat[:, index].real
+    b = flat[:, index + 1].imag
+    form1 = a.abs() < b.abs()
+    one, zero = torch.ones_like(a), torch.zeros_like(a)
+    t = torch.where(form1, -a / torch.where(form1, b, one), b / torch.where(form1, one, a))
+    flat[:, index] = torch.complex(torch.where(form1, zero, a), torch.where(form1, b, zero))
+    flat[:, index + 1] = torch.complex(zero, t)
+    flat[:, index + 3] = torch.complex(form1.to(a.dtype), zero)
+    return flat
+
+
 def gather_matrices(src, ops: Sequence[PrimOp], order: Sequence[int]):
     """Kernel-side matrix buffer (Bm, total) from a caller buffer ``src`` (Bm, *) indexed by ``op.mat``."""
     import torch
@@ -872,8 +906,12 @@ def gather_matrices(src, ops: Sequence[PrimOp], order: Sequence[int]):
 def kernel_matrices(steps: Sequence, ops: Sequence[PrimOp], src):
     """layout_matrices + gather_matrices for callers that drive ``apply_fused`` themselves (tests, tools):
     ``src`` is (Bm, *) or 1-D, indexed by ``op.mat``; returns the (Bm, total) buffer the descriptors expect."""
+    import torch
+
     order, _total = layout_matrices(steps, ops)
-    return gather_matrices(src if src.ndim == 2 else src.reshape(1, -1), ops, order)
+    km = gather_matrices(src if src.ndim == 2 else src.reshape(1, -1), ops, order)
+    pos = rx_defer_positions(steps, ops)
+    return defer_rx(km, torch.tensor(pos, dtype=torch.long, device=km.device)) if pos else km
 
 
 def algorithmic_bytes(ops: Sequence[PrimOp], n: int, amp_bytes: int, batch: int) -> int:

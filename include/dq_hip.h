@@ -101,7 +101,12 @@ typedef enum { DQ_LOC_REG = 0, DQ_LOC_THR = 1, DQ_LOC_OUT = 2 } DqBitLoc;
 typedef enum {
     DQ_MODE_GENERAL = 0,
     DQ_MODE_REAL = 1, /* all four entries real: H, Ry, X, Z ... */
-    DQ_MODE_RX = 2,   /* real diagonal, purely imaginary off-diagonal: Rx */
+    DQ_MODE_RX = 2,   /* a I + i b X (a, b real): Rx and products of such.  For an UNCONTROLLED gate of this mode in a
+                         complex64 pass (fast id 8..11) the caller hands over, in place of the matrix, the block
+                         { (f_re, f_im), (0, t), (-, -), (flag, -) }:  f = a and t = b / a, flag = 0  if |a| >= |b|,
+                         f = i b and t = -a / b, flag = 1  otherwise -- the kernel applies [[1, it], [it, 1]]
+                         resp. [[it, 1], [1, it]] (three packed operations per amplitude pair instead of four) and
+                         multiplies the pass's deferred scalar by f (fusion.defer_rx builds the block) */
     DQ_MODE_HAD = 3   /* s * [[1, 1], [1, -1]], s real: Hadamard.  The kernel takes sums and differences and
                          applies the product of the factors s of a pass once, at its end */
 } DqFusedMode;

@@ -188,6 +188,15 @@ class CpuTestBackend:
                             want = 4 * g.loc + g.q if free else 20 + 4 * (1 if g.loc == 3 else g.loc) + g.q
                         assert g.fast == want, 'fast-handler id wrong'
                         mat = mb[g.mat : g.mat + 4].reshape(2, 2)
+                        if g.kind == _lib.FG_GEN1 and g.loc == 2 and not is128 and 8 <= g.fast <= 11:
+                            # uncontrolled Rx-like gate of a complex64 pass: the deferred form (include/dq_hip.h,
+                            # DQ_MODE_RX): { f, i t, -, flag } stands for f [[1, it], [it, 1]] (flag 0, f real) or
+                            # f [[it, 1], [1, it]] (flag 1, f imaginary), |t| <= 1
+                            f, it, flag = mat[0, 0], mat[0, 1], mat[1, 1].real
+                            assert it.real == 0 and abs(it.imag) <= 1 and flag in (0.0, 1.0), 'deferred Rx block malformed'
+                            assert (f.imag == 0) if flag == 0 else (f.real == 0)
+                            mat = f * (np.array([[1, it], [it, 1]]) if flag == 0 else np.array([[it, 1], [1, it]]))
+                            mat = mat.astype(mb.dtype)
                         if g.kind == _lib.FG_GEN1 and g.loc == 1:
                             assert np.all(mat.imag == 0), 'gate promised a real matrix'
                         if g.kind == _lib.FG_GEN1 and g.loc == 3:

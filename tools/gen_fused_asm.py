@@ -62,6 +62,31 @@ def body(mode, q):
     return lines
 
 
+# Uncontrolled Rx-like gate  a I + i b X  with its scalar factor deferred like the Hadamards' (ids 8..11): the host
+# hands over  f = the larger of a and i b,  t = the ratio of the other to it (|t| <= 1)  instead of the matrix
+# (fusion.defer_rx):
+#   form 0, f = a:    A' = A + (i t) B,  B' = B + (i t) A      t =  b / a
+#   form 1, f = i b:  A' = B + (i t) A,  B' = A + (i t) B      t = -a / b
+# one register copy + two packed FMAs per amplitude pair instead of two multiplications + two FMAs; the deferred factor
+# (hr + i hi) is multiplied by f.  `fr`, `fi`, `flag` name 32-bit scalar sources, `it` the SGPR pair whose HIGH half is t.
+def body_rx_deferred(q, it, fr, fi, flag):
+    I3 = 'op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]'                 # (x, y) * (i t) + acc
+    f0, f1 = [], []
+    for k, (lo, hi) in enumerate(pairs(q)):
+        t = f'%{T0 if k % 2 == 0 else T1}'
+        A, B = f'%{lo}', f'%{hi}'
+        f0 += [f'v_mov_b64 {t}, {A}', f'v_pk_fma_f32 {A}, {B}, {it}, {A} {I3}', f'v_pk_fma_f32 {B}, {t}, {it}, {B} {I3}']
+        f1 += [f'v_mov_b64 {t}, {A}', f'v_pk_fma_f32 {A}, {A}, {it}, {B} {I3}', f'v_pk_fma_f32 {B}, {B}, {it}, {t} {I3}']
+    # interleave the two dependency chains a little: copies of pair k + 1 before the FMAs of pair k are not needed --
+    # the three instructions of a pair touch other registers than the next pair's
+    return ([f's_cmp_eq_u32 {flag}, 0', 's_cbranch_scc0 .Ldqrx1_%=_Q'.replace('_Q', f'_{q}_@'),
+             f'v_mul_f32 %[hr], %[hr], {fr}', f'v_mul_f32 %[hi], %[hi], {fr}'] + f0 +
+            ['s_branch .Ldqrx2_%=_Q'.replace('_Q', f'_{q}_@'), '.Ldqrx1_%=_Q:'.replace('_Q', f'_{q}_@'),
+             # (hr + i hi) * (i b) = -hi b + i hr b
+             f'v_mul_f32 %[tt], %[hr], {fi}', f'v_mul_f32 %[hr], %[hi], {fi}', 'v_xor_b32 %[hr], 0x80000000, %[hr]',
+             'v_mov_b32 %[hi], %[tt]'] + f1 + ['.Ldqrx2_%=_Q:'.replace('_Q', f'_{q}_@')])
+
+
 out = ['// GENERATED by tools/gen_fused_asm.py -- do not edit by hand.',
        '// clang-format off',
        'using V2F = vec2<float>;', '']
@@ -103,7 +128,7 @@ for q in range(R):
 # ones of include/dq_hip.h (DqFusedGate::fast) plus SKIP_ID for "an outside control is 0".  Handlers of
 # controlled gates start with the thread-control test (exec mask; skipped entirely when no lane is selected).
 NIDS = 76              # 0..51: gates (include/dq_hip.h); 52 + 6 * slot + lane: in-wave swap of a register slot with a lane bit
-DS0 = NA + 8           # operand numbers: a[0..15], t0 u0 t1 u1, tt, save, st, hs, then m00 m01 m10 m11 (SGPR pairs)
+DS0 = NA + 9           # operand numbers: a[0..15], t0 u0 t1 u1, tt, save, st, hr, hi, then m00 m01 m10 m11 (SGPR pairs)
 
 
 def dispatcher():
@@ -113,10 +138,12 @@ def dispatcher():
     for mode in (0, 1, 2, 3):
         for q in range(R):
             lines = body(mode, q)
-            if mode == 3:   # Hadamard: the pair (-2, -2) lives in vcc, the deferred factor goes into hs
+            if mode == 3:   # Hadamard: the pair (-2, -2) lives in vcc, the deferred factor goes into hr + i hi
                 lines = [ln.replace(f'%{DS0}', 'vcc') for ln in lines]
                 lines = ['s_mov_b32 vcc_lo, 0xc0000000', 's_mov_b32 vcc_hi, 0xc0000000',
-                         'v_mul_f32 %[hs], %[hs], %[m00]'] + lines
+                         'v_mul_f32 %[hr], %[hr], %[m00]', 'v_mul_f32 %[hi], %[hi], %[m00]'] + lines
+            if mode == 2:   # uncontrolled Rx-like: deferred form (the host rewrote the matrix block)
+                lines = [ln.replace('@', 'd') for ln in body_rx_deferred(q, f'%{DS0 + 1}', '%[m00]', '%[m00i]', '%[m11]')]
             handlers[4 * mode + q] = (False, lines)
             if mode < 3:
                 handlers[20 + 4 * mode + q] = (True, body(mode, q))
@@ -159,12 +186,13 @@ amps = ', '.join(f'"+v"(a[{j}])' for j in range(NA))
 out += ['// id = DqFusedGate::fast (< DQ_FAST32_IDS); g1 = word 1 of the gate record; oc = its outside-control mask;',
         '// tg = the global index bits of this workgroup; tb = the tile-local base of the thread',
         f'#define DQ_FAST32_IDS {NIDS}',
-        '__device__ __forceinline__ void fast_dispatch_f32(V2F (&a)[16], const uint64_t (&mq)[4], uint32_t m00, uint32_t id,',
-        '                                                  uint32_t g1, uint64_t oc, uint64_t tg, uint32_t tb, float& hs) {',
+        '__device__ __forceinline__ void fast_dispatch_f32(V2F (&a)[16], const uint64_t (&mq)[4], uint32_t m00, uint32_t m00i,',
+        '                                                  uint32_t m11, uint32_t id, uint32_t g1, uint64_t oc, uint64_t tg,',
+        '                                                  uint32_t tb, float& hr, float& hi) {',
         '    V2F t0, u0, t1, u1;', '    uint32_t tt, st;', '    uint64_t save;',
         f'    asm volatile(\n        "{text}"',
-        f'        : {amps}, "=&v"(t0), "=&v"(u0), "=&v"(t1), "=&v"(u1), [tt] "=&v"(tt), [save] "=&s"(save), [st] "=&s"(st), [hs] "+v"(hs)',
-        '        : "s"(mq[0]), "s"(mq[1]), "s"(mq[2]), "s"(mq[3]), [m00] "s"(m00), [id] "s"(id), [g1] "s"(g1), [oc] "s"(oc), [tg] "s"(tg), [tb] "v"(tb)',
+        f'        : {amps}, "=&v"(t0), "=&v"(u0), "=&v"(t1), "=&v"(u1), [tt] "=&v"(tt), [save] "=&s"(save), [st] "=&s"(st), [hr] "+v"(hr), [hi] "+v"(hi)',
+        '        : "s"(mq[0]), "s"(mq[1]), "s"(mq[2]), "s"(mq[3]), [m00] "s"(m00), [m00i] "s"(m00i), [m11] "s"(m11), [id] "s"(id), [g1] "s"(g1), [oc] "s"(oc), [tg] "s"(tg), [tb] "v"(tb)',
         '        : "vcc", "scc");',
         '}', '']
 # In the gate loop the amplitudes are pinned to v[40:71] (physical-register constraints): their 32-bit halves can
@@ -234,7 +262,9 @@ def gate_loop():
             lines = body(mode, q)
             if mode == 3:   # the pair (-2, -2) sits in s[80:81] for the whole loop
                 lines = [ln.replace(MATREGS[0], 's[80:81]') for ln in lines]
-                lines = [f'v_mul_f32 %[hs], %[hs], s{MAT}'] + lines
+                lines = [f'v_mul_f32 %[hr], %[hr], s{MAT}', f'v_mul_f32 %[hi], %[hi], s{MAT}'] + lines
+            if mode == 2:
+                lines = [ln.replace('@', 'l') for ln in body_rx_deferred(q, f's[{MAT + 2}:{MAT + 3}]', f's{MAT}', f's{MAT + 1}', f's{MAT + 6}')]
             handlers[4 * mode + q] = (False, lines)
             if mode < 3:
                 handlers[20 + 4 * mode + q] = (True, body(mode, q))
@@ -298,10 +328,10 @@ clob = ', '.join([f'"s{i}"' for i in range(80, MAT + 8)] + [f'"v{SWAP_TMP + i}"'
 out += ['// kg + goff = address of the first gate record of the round, gend = offset behind its last one; mb + moff = address',
         '// of the first matrix; both offsets are advanced.  Every gate of the round must have a handler id < DQ_FAST32_IDS.',
         '__device__ __forceinline__ void fast_gate_loop_f32(V2F (&a)[16], uint64_t kg, uint32_t& goff, uint32_t gend, uint64_t mb,',
-        '                                                   uint32_t& moff, uint64_t tg, uint32_t tb, float& hs) {',
+        '                                                   uint32_t& moff, uint64_t tg, uint32_t tb, float& hr, float& hi) {',
         '    V2F t0, u0, t1, u1;', '    uint32_t tt;', '    uint64_t save;',
         f'    asm volatile(\n        "{text}"',
-        f'        : {pinned}, "=&v"(t0), "=&v"(u0), "=&v"(t1), "=&v"(u1), [tt] "=&v"(tt), [save] "=&s"(save), [hs] "+v"(hs), [goff] "+s"(goff), [moff] "+s"(moff)',
+        f'        : {pinned}, "=&v"(t0), "=&v"(u0), "=&v"(t1), "=&v"(u1), [tt] "=&v"(tt), [save] "=&s"(save), [hr] "+v"(hr), [hi] "+v"(hi), [goff] "+s"(goff), [moff] "+s"(moff)',
         '        : [kg] "s"(kg), [gend] "s"(gend), [mb] "s"(mb), [tg] "s"(tg), [tb] "v"(tb)',
         f'        : "vcc", "scc", {clob});',
         '}', '']
@@ -524,7 +554,7 @@ out += ['__device__ __forceinline__ void fast_gate_loop_f64(V2D (&a)[8], uint64_
 out += ['// clang-format on', '']
 import os as _os
 if _os.environ.get('DQ_ABLATE_GATES'):   # timing experiments only (tools/ablate.sh): gate bodies without their VALU work
-    drop = ('"v_pk_', '"v_swap_b32', '"v_mov_b64', '"v_mul_f32 %[hs]', '"v_mul_f64', '"v_fma_f64', '"v_add_f64')
+    drop = ('"v_pk_', '"v_swap_b32', '"v_mov_b64', '"v_mul_f32 %[hr]', '"v_mul_f32 %[hi]', '"v_mul_f64', '"v_fma_f64', '"v_add_f64')
     out = '\n'.join(out).split('\n')
     out = [(ln[:len(ln) - len(ln.lstrip())] + '""') if ln.strip().startswith(drop) else ln for ln in out]
 open(_os.environ.get('DQ_ASM_OUT') or _os.path.join(_os.path.dirname(__file__), '..', 'deepquantum_amd', 'csrc', 'dq_fused_asm.inc'), 'w').write('\n'.join(out))
