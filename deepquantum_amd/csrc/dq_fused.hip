@@ -735,11 +735,22 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     }
 
     if constexpr (FAST32) {
+        // a[j] *= hsr + i hsi (uniform per workgroup: the deferred factors of the Hadamards and Rx-like gates)
+        const float ur = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hsr)));
+        const float ui = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hsi)));
+        if (ui == 0.0f) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {      // a[j] *= hsr + i hsi
-            const float x = a[j].x, y = a[j].y;
-            a[j].x = fmaf(x, hsr, -y * hsi);
-            a[j].y = fmaf(x, hsi, y * hsr);
+            for (int j = 0; j < NA; ++j) {
+                a[j].x *= ur;
+                a[j].y *= ur;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const float x = a[j].x, y = a[j].y;
+                a[j].x = fmaf(x, ur, -y * ui);
+                a[j].y = fmaf(x, ui, y * ur);
+            }
         }
     } else if (had || FAST) {
 #pragma unroll

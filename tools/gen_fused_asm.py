@@ -271,9 +271,14 @@ def gate_loop():
     MATREGS = None
 
     def xlines(q, cmask):
+        # three 64-bit moves per amplitude pair through a scratch pair.  (Two v_swap_b32 per pair look cheaper and are
+        # not: measured on the headline, 16.87 -> 16.62 ms per pass; with the swaps dropped altogether a pass takes
+        # 15.9 ms -- the (C)NOTs of a pass are 1.3 ms of register traffic.)
         out_ = []
-        for lo, hi in pairs(q, cmask):
-            out_ += [f'v_swap_b32 v{AMP0 + 2 * lo}, v{AMP0 + 2 * hi}', f'v_swap_b32 v{AMP0 + 2 * lo + 1}, v{AMP0 + 2 * hi + 1}']
+        for k, (lo, hi) in enumerate(pairs(q, cmask)):
+            t = f'%{T0 if k % 2 == 0 else T1}'
+            a_, b_ = f'v[{AMP0 + 2 * lo}:{AMP0 + 2 * lo + 1}]', f'v[{AMP0 + 2 * hi}:{AMP0 + 2 * hi + 1}]'
+            out_ += [f'v_mov_b64 {t}, {a_}', f'v_mov_b64 {a_}, {b_}', f'v_mov_b64 {b_}, {t}']
         return out_
 
     for q in range(R):
