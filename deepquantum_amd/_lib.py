@@ -16,10 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DQHIP_LIBRARY') or os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
-FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_SWAP = range(6)
+FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_SWAP, FG_GRAD = range(7)
 LOC_REG, LOC_THR, LOC_OUT = range(3)
 
 FUSED_MAX_HIGH = 12
@@ -99,6 +99,7 @@ _SIGNATURES = {
     'dq_apply_gate_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _ip, _i, _ip, _i, _i64, _vp]),
     'dq_apply_fused_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp]),
     'dq_apply_fused_bcast_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp]),
+    'dq_apply_fused_grad_c64': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp, _i64, _vp]),
     'dq_expect_pauli_{s}': (_i, [_vp, _u64, _u64, _i, _i64, _vp, _vp, _vp]),
     'dq_inner_{s}': (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'dq_probs_{s}': (_i, [_vp, _vp, _i64, _vp]),

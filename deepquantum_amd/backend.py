@@ -127,18 +127,34 @@ def apply_fused(
     mat_batch_stride: int,
     desc: _lib.DqFusedPass,
     out: torch.Tensor | None = None,
+    grads: torch.Tensor | None = None,
 ) -> torch.Tensor:
     """Run one fused pass (see fusion.py).  ``mats``: flat complex buffer (Bm * stride or stride).
-    ``state`` with ONE row and ``out`` with B rows: the single input state is shared by all outputs."""
+    ``state`` with ONE row and ``out`` with B rows: the single input state is shared by all outputs.
+    ``grads`` (float64, (B, rows, 8), added to): a pass of the adjoint method's reverse sweep -- its DQ_FG_GRAD
+    records reduce into it (include/dq_hip.h, dq_apply_fused_grad_c64)."""
     n = _nqubit(state)
     if out is None:
         out = state
     broadcast = state.shape[0] == 1 and out.shape[0] > 1
     if mats.dtype != state.dtype or mats.device != state.device or not mats.is_contiguous():
         raise ValueError('mats must be a contiguous buffer in the dtype/device of the state')
+    if grads is not None:
+        if (grads.dtype != torch.float64 or grads.ndim != 3 or grads.shape[0] != out.shape[0] or grads.shape[2] != 8
+                or not grads.is_contiguous() or grads.device != state.device or broadcast or state.dtype != torch.complex64):
+            raise ValueError('grads must be a contiguous float64 (batch, rows, 8) accumulator next to a complex64 state')
     if not _use_hip(state):
         src = state.expand(out.shape[0], -1) if broadcast else state
+        if grads is not None:
+            return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out, grads=grads)
         return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out)
+    if grads is not None:
+        if out.shape[0] > MAX_BATCH:
+            raise ValueError(f'reverse-sweep passes take at most {MAX_BATCH} samples')
+        rc = _lib.load().dq_apply_fused_grad_c64(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0],
+                                                 C.byref(desc), _ptr(grads), grads.shape[1], _stream(state))
+        _lib.check(rc, 'dq_apply_fused_grad')
+        return out
     if out.shape[0] > MAX_BATCH:
         rows = mats.reshape(-1, mat_batch_stride) if mat_batch_stride else None
         for lo in range(0, out.shape[0], MAX_BATCH):

@@ -342,6 +342,107 @@ __device__ __forceinline__ void dispatch_gen2(amp<T> (&a)[1 << R], int q, int q2
     }
 }
 
+// ---- DQ_FG_GRAD: sum lambda (x) conj(psi) over a thread's registers, the wavefront, into LDS -----------------
+// Eight per-lane sums g0..g7 -> for every row of 16 lanes, eight lanes that each hold ONE of the sums added up over the
+// row: a reduce-scatter over lane bits 2, 3 and 0 (every step halves the values a lane is responsible for) and a plain
+// add over lane bit 1 -- 16 DPP adds instead of the 32 a reduction of all eight values over a row takes, none of the
+// hazard no-ops and register copies hipcc puts around __builtin_amdgcn_update_dpp.  The lane with bits (b0, b3, b2)
+// ends up with sum number 4 b0 + 2 b3 + b2; lanes that differ in bit 1 hold the same value.
+__device__ __forceinline__ float row_reduce_scatter8(float g0, float g1, float g2, float g3, float g4, float g5, float g6,
+                                                     float g7) {
+    float t0, t1;
+    asm volatile(
+        // lane bit 2: lanes with the bit clear take over the even-numbered sum of each pair, the others the odd one
+        "v_add_f32_dpp %[g0], %[g0], %[g0] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[g2], %[g2], %[g2] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[g4], %[g4], %[g4] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[g6], %[g6], %[g6] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[g0], %[g1], %[g1] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[g2], %[g3], %[g3] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[g4], %[g5], %[g5] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[g6], %[g7], %[g7] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        // lane bit 3: (g0, g2) -> g0, (g4, g6) -> g4
+        "v_add_f32_dpp %[g0], %[g0], %[g0] row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[g4], %[g4], %[g4] row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[g0], %[g2], %[g2] row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[g4], %[g6], %[g6] row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        // lane bit 0: (g0, g4) -> even lanes keep g0, odd lanes g4
+        "s_mov_b32 vcc_lo, 0xaaaaaaaa\n\t"
+        "s_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[t0], %[g0], %[g0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[t1], %[g4], %[g4] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32 %[g0], %[t0], %[t1], vcc\n\t"
+        // lane bit 1: plain add
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[g0], %[g0], %[g0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : [g0] "+v"(g0), [g1] "+v"(g1), [g2] "+v"(g2), [g3] "+v"(g3), [g4] "+v"(g4), [g5] "+v"(g5), [g6] "+v"(g6),
+          [g7] "+v"(g7), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        :
+        : "vcc");
+    return g0;
+}
+
+template <int R, int Q, int QS>
+__device__ __forceinline__ void grad_body(const vec2<float> (&a)[1 << R], const unsigned reg_cmask, const bool lane_pred,
+                                          const bool thr_ok, const float scale, const unsigned acc_byte) {
+    using V2 = vec2<float>;
+    V2 g[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};      // G[0][0], G[0][1], G[1][0], G[1][1] as (re, im)
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+        if (((j >> Q) & 1) || ((j >> QS) & 1)) continue;
+        if ((j & reg_cmask) != reg_cmask) continue;      // (uniform)
+        const V2 p0 = a[j], p1 = a[j | (1 << Q)], l0 = a[j | (1 << QS)], l1 = a[j | (1 << Q) | (1 << QS)];
+        const V2 l0s = {l0.y, -l0.x}, l1s = {l1.y, -l1.x};
+        // l * conj(p) = l * p.x + (l.y, -l.x) * p.y : two packed FMAs
+        g[0] = __builtin_elementwise_fma(l0, (V2)(p0.x), g[0]);
+        g[0] = __builtin_elementwise_fma(l0s, (V2)(p0.y), g[0]);
+        g[1] = __builtin_elementwise_fma(l0, (V2)(p1.x), g[1]);
+        g[1] = __builtin_elementwise_fma(l0s, (V2)(p1.y), g[1]);
+        g[2] = __builtin_elementwise_fma(l1, (V2)(p0.x), g[2]);
+        g[2] = __builtin_elementwise_fma(l1s, (V2)(p0.y), g[2]);
+        g[3] = __builtin_elementwise_fma(l1, (V2)(p1.x), g[3]);
+        g[3] = __builtin_elementwise_fma(l1s, (V2)(p1.y), g[3]);
+    }
+    if (lane_pred) {                                     // a control on a thread bit: such lanes contribute nothing
+        const float w = thr_ok ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] *= w;
+    }
+    const float tot = row_reduce_scatter8(g[0].x, g[0].y, g[1].x, g[1].y, g[2].x, g[2].y, g[3].x, g[3].y) * scale;
+    const unsigned lane = threadIdx.x;
+    if ((lane & 2u) == 0u) {       // one lane of each pair; the four rows of the wavefront add on their own
+        const unsigned idx = ((lane & 1u) << 2) | ((lane >> 2) & 2u) | ((lane >> 2) & 1u);
+        __hip_atomic_fetch_add((__attribute__((address_space(3))) float*)(uintptr_t)(acc_byte + 4u * idx), tot,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+template <int R, int Q>
+__device__ __forceinline__ void dispatch_grad_qs(const vec2<float> (&a)[1 << R], int qs, unsigned reg_cmask, bool lane_pred,
+                                                 bool thr_ok, float scale, unsigned acc_byte) {
+    switch (qs) {
+        case 0: if constexpr (Q != 0) grad_body<R, Q, 0>(a, reg_cmask, lane_pred, thr_ok, scale, acc_byte); break;
+        case 1: if constexpr (Q != 1) grad_body<R, Q, 1>(a, reg_cmask, lane_pred, thr_ok, scale, acc_byte); break;
+        case 2: if constexpr (Q != 2) grad_body<R, Q, 2>(a, reg_cmask, lane_pred, thr_ok, scale, acc_byte); break;
+        default: if constexpr (R > 3 && Q != 3) grad_body<R, Q, 3>(a, reg_cmask, lane_pred, thr_ok, scale, acc_byte); break;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void dispatch_grad(const vec2<float> (&a)[1 << R], int q, int qs, unsigned reg_cmask, bool lane_pred,
+                                              bool thr_ok, float scale, unsigned acc_byte) {
+    switch (q) {
+        case 0: dispatch_grad_qs<R, 0>(a, qs, reg_cmask, lane_pred, thr_ok, scale, acc_byte); break;
+        case 1: dispatch_grad_qs<R, 1>(a, qs, reg_cmask, lane_pred, thr_ok, scale, acc_byte); break;
+        case 2: dispatch_grad_qs<R, 2>(a, qs, reg_cmask, lane_pred, thr_ok, scale, acc_byte); break;
+        default: if constexpr (R > 3) dispatch_grad_qs<R, 3>(a, qs, reg_cmask, lane_pred, thr_ok, scale, acc_byte); break;
+    }
+}
+template <int R>
+__device__ __forceinline__ void dispatch_grad(const vec2<double> (&)[1 << R], int, int, unsigned, bool, bool, float, unsigned) {}
+
 // XOR swizzle of the LDS element index (fusion.lds_swizzle is the same function; tools/lds_conflicts.py counts the
 // bank conflicts of a schedule under it): every higher group of 5 (8-byte elements: 32 slots per LDS row) / 4 index
 // bits is folded onto the low group, so every tile bit moves the bank; for 8-byte elements bit 4 also toggles bit 0,
@@ -366,16 +467,24 @@ struct FusedKernArgs {
     int n;
     int tpw;
     DqFusedPass p;
+    double* grads;          // GRAD kernels only: [batch, ngrads, 8], added to
+    int64_t grad_bstride;   // = ngrads * 8
 };
 
 // PF: a workgroup walks `tpw` consecutive tiles and requests tile t + 1 from HBM (into spare VGPRs) before it starts
 // the rounds of tile t, so the load latency of every tile but the first hides under the gates of its predecessor and
 // the stores of tile t drain under the gates of tile t + 1.  Two 64-KiB workgroups per CU (what the tile buffer allows)
 // cannot keep enough bytes in flight on their own: load -> gates -> store is strictly serial inside one workgroup.
-template <typename T, int R, int LOGT, bool PF>
+//
+// GRAD: the reverse sweep of the adjoint method (dq_apply_fused_grad_c64).  The pass's DQ_FG_GRAD records reduce
+// sum lambda (x) conj(psi) over the thread's registers, then over the wavefront (DPP), and add the eight real sums to
+// a per-record accumulator in LDS right behind the tile; after its last tile the workgroup adds the accumulators to
+// `grads` (double, one atomic per record and component).  A separate instantiation: the forward kernels do not change.
+template <typename T, int R, int LOGT, bool PF, bool GRAD = false>
 __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in, amp<T>* out,
                                                                const amp<T>* __restrict__ mats, int64_t mat_bstride,
-                                                               int64_t in_bstride, int n, int tpw, const DqFusedPass p) {
+                                                               int64_t in_bstride, int n, int tpw, const DqFusedPass p,
+                                                               double* grads, int64_t grad_bstride) {
     constexpr int M = R + LOGT;
     constexpr int NA = 1 << R;
     constexpr int VB = (sizeof(T) == 4) ? 1 : 0;  // low slots of the canonical layout (16 B per lane)
@@ -407,6 +516,12 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     using Piece = typename std::conditional<VB == 1, float4, V>::type;
     constexpr int NP = VB == 1 ? NA / 2 : NA;
     V a[NA];
+    constexpr unsigned ACC_BYTES0 = (unsigned)sizeof(V) << M;      // the accumulators of the DQ_FG_GRAD records
+    if constexpr (GRAD) {
+        for (unsigned i = threadIdx.x; i < DQ_FUSED_MAX_GATES * 8u; i += 1u << LOGT)
+            *(__attribute__((address_space(3))) float*)(uintptr_t)(ACC_BYTES0 + 4u * i) = 0.0f;
+        __syncthreads();
+    }
   for (int tile_no = 0; tile_no < tpw; ++tile_no, ++tile_id) {
     // Everything a tile needs is derived INSIDE the loop from two laundered values (the kernel-argument pointer and the
     // thread id): hoisted out as loop invariants, the decoded header and the per-thread offsets would stay live across
@@ -698,6 +813,13 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
                     break;
                 case DQ_FG_X1: dispatch_x1<T, R>(a, q, reg_cmask, thr_cmask != 0, thr_ok); break;
                 case DQ_FG_GEN2: dispatch_gen2<T, R>(a, q, q2, mp, loc, reg_cmask, thr_ok); break;
+                case DQ_FG_GRAD:
+                    if constexpr (GRAD && sizeof(T) == 4) {
+                        // the registers lack the pass's deferred factor f (both states alike): G_true = |f|^2 G
+                        const float f2 = hsr * hsr + hsi * hsi;
+                        dispatch_grad<R>(a, q, q2, reg_cmask, thr_cmask != 0, thr_ok, f2, ACC_BYTES0 + goff);   // 32 B per record, too
+                    }
+                    break;
                 case DQ_FG_DIAG1: {
                     const V d0 = mp[0], d1 = mp[3];
                     int fixed = -1;  // target bit value when it is not a register slot
@@ -809,6 +931,23 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         }
     }
   }
+    if constexpr (GRAD) {
+        // one atomic per (record, component) and workgroup: the records' rows come from the descriptor, read from the
+        // kernel-argument segment (constant address space; indexing `p` itself per lane would copy it to scratch)
+        __syncthreads();
+        typedef const __attribute__((address_space(4))) uint32_t* KWords;
+        const KWords kw = (KWords)((uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FusedKernArgs, p));
+        const int nr = (int)(kw[0] >> 24);
+        const unsigned ngates = kw[offsetof(DqFusedPass, rounds) / 4 + 4 * (nr - 1) + 3] >> 24;
+        double* const grow = grads + (uint64_t)sample * (uint64_t)grad_bstride;
+        for (unsigned i = threadIdx.x; i < ngates * 8u; i += 1u << LOGT) {
+            const KWords gw = kw + offsetof(DqFusedPass, gates) / 4 + 8u * (i >> 3);
+            if ((gw[0] & 0xffu) == (unsigned)DQ_FG_GRAD) {
+                const float v = *(__attribute__((address_space(3))) float*)(uintptr_t)(ACC_BYTES0 + 4u * i);
+                atomicAdd(grow + (uint64_t)gw[7] * 8u + (i & 7u), (double)v);
+            }
+        }
+    }
 }
 
 struct FusedVariant {
@@ -819,8 +958,9 @@ static const FusedVariant kVariantsC64[] = {{12, 4, 8}, {13, 4, 9}};
 static const FusedVariant kVariantsC128[] = {{11, 3, 8}, {12, 3, 9}};
 static const int kNumVariants = 2;
 
+// ngrads: rows of the caller's accumulator (dq_apply_fused_grad_*), -1 = a plain pass (DQ_FG_GRAD records refused)
 template <typename T>
-static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
+static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64_t ngrads = -1) {
     const int m = slots + logt;
     if (p->m != m || p->L + p->h != m || p->h > DQ_FUSED_MAX_HIGH || p->L < 1) {
         set_error("dq_apply_fused: inconsistent geometry (m=%d L=%d h=%d)", p->m, p->L, p->h);
@@ -990,6 +1130,15 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
                 }
                 continue;
             }
+            if (g.kind == DQ_FG_GRAD) {
+                if (ngrads < 0 || sizeof(T) != 4 || g.q >= slots || g.q2 >= slots || g.q == g.q2 || (g.reg_cmask >> slots) ||
+                    ((g.reg_cmask >> g.q) & 1u) || ((g.reg_cmask >> g.q2) & 1u) || g.mat != next_mat || g.mat_advance != 0 ||
+                    g.fast != DQ_FAST_NONE || (int64_t)g.reserved >= ngrads) {
+                    set_error("dq_apply_fused: reduction record %d malformed, or not a dq_apply_fused_grad_c64 call", gi);
+                    return DQ_ERR_ARG;
+                }
+                continue;
+            }
             if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 3) || (g.kind == DQ_FG_GEN2 && g.loc > 1)) ||
                 (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
                 set_error("dq_apply_fused: gate %d malformed", gi);
@@ -1026,33 +1175,36 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt) {
 // tuning / A-B knob, not part of the data path's contract.
 static int g_tiles_per_wg = 0;
 
-template <typename T, int R, int LOGT, bool PF>
+template <typename T, int R, int LOGT, bool PF, bool GRAD = false>
 static void launch_variant(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n,
-                           int64_t batch, const DqFusedPass* pass, hipStream_t s) {
+                           int64_t batch, const DqFusedPass* pass, hipStream_t s, double* grads = nullptr,
+                           int64_t ngrads = 0) {
     constexpr int M = R + LOGT;
     size_t lds_bytes = sizeof(amp<T>) << M;
+    if (GRAD) lds_bytes += DQ_FUSED_MAX_GATES * 8 * sizeof(float);      // the reduction records' accumulators
     if (const char* pad = getenv("DQ_LDS_PAD_KB")) lds_bytes += (size_t)atoi(pad) << 10;   // occupancy experiments
     // (cheap; not cached: a process may drive several devices, and the attribute is per device)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_pass_kernel<T, R, LOGT, PF>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_pass_kernel<T, R, LOGT, PF, GRAD>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     // tiles per workgroup: enough workgroups must remain to fill the chip several times over (256 CUs x 2..5
     // resident workgroups), and the pass that reads one shared input state keeps its XCD-aware order (one tile each)
     int tpw_log = 0;
-    if (PF && in_bstride != 0) {
+    if ((PF || GRAD) && in_bstride != 0) {
         const int want = g_tiles_per_wg > 0 ? g_tiles_per_wg : 4;
         while ((2 << tpw_log) <= want && n - M - (tpw_log + 1) >= 0 &&
                ((int64_t)batch << (n - M - (tpw_log + 1))) >= 8192)
             ++tpw_log;
     }
     dim3 grid((unsigned)(1ull << (n - M - tpw_log)), (unsigned)batch);
-    hipLaunchKernelGGL((fused_pass_kernel<T, R, LOGT, PF>), grid, dim3(1u << LOGT), lds_bytes, s,
+    hipLaunchKernelGGL((fused_pass_kernel<T, R, LOGT, PF, GRAD>), grid, dim3(1u << LOGT), lds_bytes, s,
                        static_cast<const amp<T>*>(in), static_cast<amp<T>*>(out), static_cast<const amp<T>*>(mats),
-                       mat_bstride, in_bstride, n, 1 << tpw_log, *pass);
+                       mat_bstride, in_bstride, n, 1 << tpw_log, *pass, grads, ngrads * 8);
 }
 
 template <typename T>
 static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
-                      const DqFusedPass* pass, dq_stream_t stream, bool broadcast_in = false) {
+                      const DqFusedPass* pass, dq_stream_t stream, bool broadcast_in = false, double* grads = nullptr,
+                      int64_t ngrads = -1) {
     const int64_t in_bstride = broadcast_in ? 0 : (int64_t)1 << n;
     if (broadcast_in && in == out) {
         set_error("dq_apply_fused_bcast: the shared input state cannot be the output buffer");
@@ -1076,7 +1228,7 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
         return DQ_ERR_UNSUPPORTED;
     }
     const FusedVariant v = vars[vi];
-    int rc = validate_pass<T>(pass, n, v.slots, v.logt);
+    int rc = validate_pass<T>(pass, n, v.slots, v.logt, ngrads);
     if (rc) return rc;
     if (in == out) {   // in place: every amplitude must be written where it was read
         bool same = true;
@@ -1098,6 +1250,11 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     }
     hipStream_t s = as_stream(stream);
     if constexpr (!is128) {
+        if (ngrads >= 0) {      // the reverse sweep: no next-tile prefetch (its registers go to the reductions)
+            if (v.m == 12) launch_variant<float, 4, 8, false, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+            else launch_variant<float, 4, 9, false, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+            return check_launch("dq_apply_fused_grad");
+        }
         if (v.m == 12) launch_variant<float, 4, 8, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
         else launch_variant<float, 4, 9, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
     } else {
@@ -1137,6 +1294,16 @@ extern "C" int dq_apply_fused_c64(const void* in, void* out, const void* mats, i
 extern "C" int dq_apply_fused_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
                                    int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
     return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream);
+}
+
+extern "C" int dq_apply_fused_grad_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                       int64_t batch, const DqFusedPass* pass, double* grads, int64_t ngrads,
+                                       dq_stream_t stream) {
+    if (!grads || ngrads < 1) {
+        dq::set_error("dq_apply_fused_grad_c64: no accumulator (grads = %p, ngrads = %lld)", (void*)grads, (long long)ngrads);
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream, false, grads, ngrads);
 }
 
 // Same pass, but `in` is ONE state (2^n amplitudes) shared by all `batch` outputs: the first pass of a batched

@@ -61,6 +61,10 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
           # 'adjoint': fused forward + reverse sweep with recomputation (O(1) states of memory);
           # 'per_gate': one autograd node per gate (saves every intermediate state; supports double backward)
           'grad_mode': 'adjoint',
+          # complex64 reverse sweeps run as fused passes over psi and the cotangent interleaved along one extra index
+          # bit, the reductions for the trainable gates folded into the passes (_AdjointCircuit._sweep_fused); False:
+          # the undo-then-reduce sweep (always used for complex128 and for trainable gates on two or more targets)
+          'fused_sweep': True,
           # states smaller than a tile: fuse (batch folded into the index, or zero-padded) from this many gates on
           'small_fuse_min_gates': 6,
           # no-grad runs on states of at least this many amplitudes (batch included) multiply runs of one-qubit gates
@@ -72,6 +76,9 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates, bytes read + written) to report the kernel's average duration next to its algorithmic bytes.
 PROFILE = {'enabled': False, 'events': []}
+
+# The most recent reverse sweep of _AdjointCircuit: which kind, how many fused passes / reduction records.
+LAST_SWEEP = {'fused': False, 'passes': 0, 'reductions': 0}
 
 # Statistics of the most recent fused run (for bench.py and tests).
 LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'swaps': 0, 'permute_folded': False}
@@ -142,7 +149,8 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     prim_ops, off = [], 0
     for p in prims:
         prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off, p.mode))
-        off += (1 << len(p.targets)) ** 2
+        if p.kind != 'grad':            # (a reduction of the reverse sweep has no matrix)
+            off += (1 << len(p.targets)) ** 2
     steps = fusion.schedule(prim_ops, n, geom, fuse=CONFIG['fuse'], final_perm=out_perm)
     order, total = fusion.layout_matrices(steps, prim_ops)
     plan = Plan(steps, prim_ops, order, total,
@@ -159,7 +167,7 @@ def _flat_mats(prims: Sequence[Prim], order: Sequence[int], batch: int, dtype: t
                device: torch.device) -> tuple[torch.Tensor, int]:
     """Concatenate the gate matrices in the plan's buffer order (fusion.layout_matrices) into one
     (Bm, total) buffer with the kernel's tail pad; Bm = batch if any matrix is batched."""
-    batched = any(p.matrix.ndim == 3 and p.matrix.shape[0] > 1 for p in prims)
+    batched = any(p.matrix is not None and p.matrix.ndim == 3 and p.matrix.shape[0] > 1 for p in prims)
     bm = batch if batched else 1
     rows = []
     for i in order:
@@ -329,7 +337,8 @@ def _permute_after(x: torch.Tensor, out_perm: Sequence[int], scratch: torch.Tens
 
 
 def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
-                out_perm: Sequence[int] | None = None) -> torch.Tensor:
+                out_perm: Sequence[int] | None = None, grads: torch.Tensor | None = None) -> torch.Tensor:
+    """``grads``: the accumulator of the 'grad' prims (the reverse sweep of ``_AdjointCircuit``; complex64, n >= a tile)."""
     n = state.shape[-1].bit_length() - 1
     with torch.no_grad():
         is128 = state.dtype == torch.complex128
@@ -338,6 +347,8 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         if len(prims) == 0:
             LAST_RUN['permute_folded'] = False
             return _permute_after(state, out_perm, scratch)
+        if grads is not None:
+            assert n >= m and CONFIG['fuse'] and not is128, 'the fused reverse sweep needs a state of at least one tile'
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):
             out = _run_small(state, prims, n, m)
@@ -385,14 +396,15 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                     if other is None:
                         other = torch.empty_like(x)
                     dst = other
+                gr = grads if grads is not None and any(plan.prim_ops[oi].kind == 'grad' for oi in st.ops) else None
                 if PROFILE['enabled'] and x.is_cuda:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    backend.apply_fused(src, flat, stride, st.desc, out=dst)
+                    backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr)
                     e1.record()
                     PROFILE['events'].append((e0, e1, len(st.ops), (src.numel() + dst.numel()) * x.element_size()))
                 else:
-                    backend.apply_fused(src, flat, stride, st.desc, out=dst)
+                    backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr)
                 if dst is not x:
                     x, other = dst, x
                 stats['passes'] += 1
@@ -401,6 +413,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 stats['swaps'] = stats.get('swaps', 0) + st.nswaps
             else:
                 op = plan.prim_ops[st.op]
+                assert op.kind != 'grad', 'a reduction of the reverse sweep can only run inside a fused pass'
                 d = 1 << op.k
                 mat = flat[:, op.pos : op.pos + d * d].reshape(-1, d, d)
                 if op.k <= 4:
@@ -471,7 +484,40 @@ class _AdjointCircuit(torch.autograd.Function):
             if any(need[j] for j, _ in members):
                 inv_h[key] = ({j: k for k, (j, _u) in enumerate(members)}, inv.mH.to(torch.complex128))
 
+        n = out.shape[-1].bit_length() - 1
+        g_ = _geometry(False)
+        fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and out.dtype == torch.complex64 and b <= backend.MAX_BATCH
+                 and n + 1 >= (g_.fallback.m if g_.fallback is not None else g_.m)
+                 and all(len(meta[j][1]) == 1 for j in range(len(mats)) if need[j]))
+        if fused:
+            raw, lam = _AdjointCircuit._sweep_fused(out, gy, meta, undo, need, b,
+                                                    [m.ndim == 2 or m.shape[0] == 1 for m in mats])
+        else:
+            raw, lam = _AdjointCircuit._sweep_undo_reduce(out, gy, meta, undo, need, b)
+
+        grads: list = [None] * len(mats)
+        for key, (pos, ih) in inv_h.items():
+            kind, d, nb = key
+            js = [j for j in pos if need[j]]
+            ks = [pos[j] for j in js]
+            ihs = ih if ks == list(range(ih.shape[0])) else torch.stack([ih[k] for k in ks])   # no host index tensors
+            g = torch.stack([raw[j] for j in js]) @ ihs                              # (K', b, D, D)
+            if kind == 'diag':
+                g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))      # the kernels ignore off-diagonal entries
+            if nb == 1 and b > 1:
+                g = g.sum(dim=1, keepdim=True)
+            for k, j in enumerate(js):
+                grads[j] = g[k].to(mats[j].dtype).reshape(mats[j].shape)
+        gstate = lam() if ctx.needs_input_grad[0] else None
+        return (gstate, None, *grads)
+
+    @staticmethod
+    def _sweep_undo_reduce(out, gy, meta, undo, need, b):
+        """Reverse sweep over psi and lambda stacked as one batch: gates are undone lazily (fused passes) and a
+        trainable gate's sum lambda (x) conj(psi) is reduced from a snapshot in which no pending gate touches its
+        qubits (gate-gradient kernels).  Returns ({gate: (b, D, D) sums}, thunk for lambda_0)."""
         work = torch.cat([out, gy.to(out.dtype)]).contiguous()        # rows [0, b): psi, rows [b, 2b): lambda
+        LAST_SWEEP.update(fused=False, passes=0, reductions=sum(need))
         raw: dict = {}                                                  # j -> sum lambda_j (x) conj(psi_j)
         pending: list[Prim] = []
         touched: set[int] = set()             # qubits the not-yet-undone gates act on
@@ -493,7 +539,7 @@ class _AdjointCircuit(torch.autograd.Function):
                     raw[j] = g[:, k]
                 waiting.clear()
 
-        for j in range(len(mats) - 1, -1, -1):
+        for j in range(len(meta) - 1, -1, -1):
             kind, targets, controls, mode = meta[j]
             mine = set(targets) | set(controls)
             if need[j]:
@@ -512,19 +558,29 @@ class _AdjointCircuit(torch.autograd.Function):
             touched |= mine
         reduce_waiting()
         flush()
+        return raw, lambda: work[b:].clone()
 
-        grads: list = [None] * len(mats)
-        for key, (pos, ih) in inv_h.items():
-            kind, d, nb = key
-            js = [j for j in pos if need[j]]
-            ks = [pos[j] for j in js]
-            ihs = ih if ks == list(range(ih.shape[0])) else torch.stack([ih[k] for k in ks])   # no host index tensors
-            g = torch.stack([raw[j] for j in js]) @ ihs                              # (K', b, D, D)
-            if kind == 'diag':
-                g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))      # the kernels ignore off-diagonal entries
-            if nb == 1 and b > 1:
-                g = g.sum(dim=1, keepdim=True)
-            for k, j in enumerate(js):
-                grads[j] = g[k].to(mats[j].dtype).reshape(mats[j].shape)
-        gstate = work[b:].clone() if ctx.needs_input_grad[0] else None
-        return (gstate, None, *grads)
+    @staticmethod
+    def _sweep_fused(out, gy, meta, undo, need, b, shared):
+        """The same sweep as ONE gate list run in fused passes (complex64): psi and lambda are interleaved along an
+        extra index bit 0 -- every thread of a pass then holds both halves of an amplitude pair of both states -- every
+        gate's adjoint acts on both at once (adjoint = inverse to float32 rounding, the precision psi is recomputed in
+        anyway), and in front of the adjoint of every trainable gate a 'grad' prim reduces sum lambda (x) conj(psi) on the
+        gate's target inside the pass that holds the qubit (DQ_FG_GRAD, include/dq_hip.h): no snapshots, no separate
+        reduction kernels, a pass per ~80 records instead of two per circuit layer."""
+        work = torch.stack([out, gy.to(out.dtype)], dim=-1).reshape(b, -1)        # bit 0: psi | lambda
+        rows: dict[int, int] = {}
+        prims: list[Prim] = []
+        for j in range(len(meta) - 1, -1, -1):
+            kind, targets, controls, mode = meta[j]
+            t1, c1 = tuple(t + 1 for t in targets), tuple(c + 1 for c in controls)
+            if need[j]:
+                rows[j] = len(rows)
+                prims.append(Prim('grad', None, (t1[0], 0), c1, rows[j]))
+            prims.append(Prim(kind, undo[j][b : b + 1] if shared[j] else undo[j][b:], t1, c1, mode))
+        acc = torch.zeros(b, max(len(rows), 1), 8, dtype=torch.float64, device=out.device)
+        work = _run_nograd(work, prims, inplace=True, scratch=torch.empty_like(work), grads=acc)
+        LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=len(rows))
+        g = torch.view_as_complex(acc.reshape(b, -1, 4, 2)).reshape(b, -1, 2, 2)
+        raw = {j: g[:, r] for j, r in rows.items()}
+        return raw, lambda: work.reshape(b, -1, 2)[:, :, 1].contiguous()

@@ -27,7 +27,11 @@ from . import _lib
 @dataclass
 class PrimOp:
     """One kernel-level gate: ``kind`` in {'gen', 'x', 'diag'}; ``targets`` in matrix order (MSB
-    first); ``mat`` = offset (in complex numbers) of its 2^k x 2^k matrix in the flat matrix buffer."""
+    first); ``mat`` = offset (in complex numbers) of its 2^k x 2^k matrix in the flat matrix buffer.
+
+    ``kind == 'grad'`` is not a gate but a reduction of the adjoint method's reverse sweep (DQ_FG_GRAD,
+    include/dq_hip.h): ``targets = (q, s)`` -- q the trainable gate's target, s the index bit that tells psi from the
+    cotangent -- ``controls`` the gate's controls, ``mode`` the row of the accumulator; no matrix."""
 
     kind: str
     targets: tuple[int, ...]
@@ -119,6 +123,12 @@ def _action(op: PrimOp) -> dict[int, str]:
     'X' = as a function of X (target of an X or of an Rx-like matrix a*I + i*b*X, controlled or not),
     'N' = anything else."""
     act = {q: 'D' for q in op.controls}
+    if op.kind == 'grad':
+        # a snapshot on its target (ordered against everything there); on the psi / lambda bit nothing ever acts, and
+        # reductions do not disturb each other: no dependency through it
+        act[op.targets[0]] = 'N'
+        act[op.targets[1]] = 'D'
+        return act
     if op.kind == 'diag':
         t_act = 'D'
     elif op.k == 1 and (op.kind == 'x' or (op.kind == 'gen' and op.mode == 2)):
@@ -374,57 +384,65 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
                     return False
             return True
 
-        progressed = True
-        while progressed and count < geom.max_gates:
-            progressed = False
-            cur = rounds[-1]
-            pick = None
-            pick_rank = 99
-            for i in dag.ready:
-                op = ops[i]
-                if not _fusable(op):
-                    continue
-                if op.kind == 'diag':
-                    rank = 0
-                else:
-                    tset = set(op.targets)
-                    in_tile = all(t in low or t in high for t in tset)
-                    room = round_accepts(cur, tset, first=len(rounds) == 1)
-                    more_rounds = len(rounds) < geom.max_rounds and len(tset) <= geom.slots
-                    if tset <= set(cur.slots):
-                        rank = 0
-                    elif in_tile and room:
-                        rank = 1
-                    elif fits_tile(op) and room:
-                        rank = 2
-                    elif in_tile and more_rounds:
-                        rank = 3
-                    elif fits_tile(op) and more_rounds:
-                        rank = 4
-                    else:
-                        continue
-                if rank < pick_rank:
-                    pick, pick_rank = i, rank
-                    if rank == 0:
-                        break
-            if pick is None:
-                break
-            op = ops[pick]
-            if op.kind != 'diag':
-                tset = set(op.targets)
-                for t in tset:
-                    if t not in low:
-                        high.add(t)
-                if pick_rank in (3, 4):
-                    rounds.append(_Round())
-                    cur = rounds[-1]
-                for t in op.targets:
-                    if t not in cur.slots:
-                        cur.slots.append(t)
-            cur.ops.append(pick)
-            dag.retire(pick)
-            count += 1
+        for _attempt in (0, 1):
+            high.clear()
+            rounds[:] = [_Round()]
+            count = 0
             progressed = True
+            while progressed and count < geom.max_gates:
+                progressed = False
+                cur = rounds[-1]
+                pick = None
+                pick_rank = 99
+                for i in dag.ready:
+                    op = ops[i]
+                    if not _fusable(op):
+                        continue
+                    if op.kind == 'diag':
+                        rank = 0
+                    else:
+                        tset = set(op.targets)
+                        in_tile = all(t in low or t in high for t in tset)
+                        room = round_accepts(cur, tset, first=len(rounds) == 1)
+                        more_rounds = len(rounds) < geom.max_rounds and len(tset) <= geom.slots
+                        if tset <= set(cur.slots):
+                            rank = 0
+                        elif in_tile and room:
+                            rank = 1
+                        elif fits_tile(op) and room:
+                            rank = 2
+                        elif in_tile and more_rounds:
+                            rank = 3
+                        elif fits_tile(op) and more_rounds:
+                            rank = 4
+                        else:
+                            continue
+                    if rank < pick_rank:
+                        pick, pick_rank = i, rank
+                        if rank == 0:
+                            break
+                if pick is None:
+                    break
+                op = ops[pick]
+                if op.kind != 'diag':
+                    tset = set(op.targets)
+                    for t in tset:
+                        if t not in low:
+                            high.add(t)
+                    if pick_rank in (3, 4):
+                        rounds.append(_Round())
+                        cur = rounds[-1]
+                    for t in op.targets:
+                        if t not in cur.slots:
+                            cur.slots.append(t)
+                cur.ops.append(pick)
+                dag.retire(pick)
+                count += 1
+                progressed = True
+
+            if count or allowed is None:
+                break
+            allowed = None       # the planned bits left no room for the front gate: first come, first served
 
         if count == 0:
             # nothing fusable is ready: run the lowest-index ready gate on its own
@@ -790,6 +808,7 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
     g.q = g.q2 = g.loc = g.loc2 = 0
     g.fast = _lib.FAST_NONE
     g.mat_advance = 0
+    g.reserved = 0
 
     def locate(b: int) -> tuple[int, int]:
         if b in tile:
@@ -806,6 +825,11 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
             g.loc2, g.q2 = locate(op.targets[1])
         return
     slots = [slot_of[local[t]] for t in op.targets]
+    if op.kind == 'grad':
+        g.kind = _lib.FG_GRAD
+        g.q, g.q2 = slots
+        g.reserved = op.mode
+        return
     if op.k == 1:
         g.kind = _lib.FG_X1 if op.kind == 'x' else _lib.FG_GEN1
         g.q = slots[0]
@@ -849,7 +873,7 @@ def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], 
                     g.mat, g.mat_advance = off, 0
                     continue
                 op = ops[oi]
-                size = 0 if g.kind == _lib.FG_X1 else (1 << op.k) ** 2
+                size = 0 if g.kind in (_lib.FG_X1, _lib.FG_GRAD) else (1 << op.k) ** 2
                 g.mat, g.mat_advance, op.pos = off, size, off
                 if size:
                     order.append(oi)

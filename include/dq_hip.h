@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 15
+#define DQ_ABI_VERSION 16
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -88,10 +88,15 @@ typedef enum {
     DQ_FG_DIAG1 = 2, /* diagonal 2x2 (Z,S,T,Rz,P,CZ...) target anywhere      */
     DQ_FG_GEN2 = 3,  /* general 4x4 on register slots q (matrix MSB) and q2   */
     DQ_FG_DIAG2 = 4, /* diagonal 4x4 (Rzz...) both targets anywhere           */
-    DQ_FG_SWAP = 5   /* not a gate: in-wave exchange of register slot q with lane bit q2 (0..5) of the thread id --
+    DQ_FG_SWAP = 5,  /* not a gate: in-wave exchange of register slot q with lane bit q2 (0..5) of the thread id --
                         v_permlane32/16_swap for lane bits 5 / 4, DPP row shifts for 3 / 2, DPP quad permutations for
                         1 / 0 -- a change of layout without LDS and without a workgroup barrier.  Only as the leading
                         records of a DQ_ROUND_SWAP round of complex64 kernels; fast = 52 + 6 * q + q2 */
+    DQ_FG_GRAD = 6   /* not a gate: a reduction for the reverse sweep of the adjoint method (dq_apply_fused_grad_c64).
+                        The state is psi and the cotangent lambda side by side along ONE extra index bit (register slot
+                        q2: 0 = psi, 1 = lambda); the record adds  G[a][b] = sum lambda[target = a] conj(psi[target = b])
+                        (target = register slot q; the sum runs over everything else, restricted to the controls being
+                        1) to row `reserved` of the caller's accumulator.  No matrix, no handler id */
 } DqFusedKind;
 
 typedef enum { DQ_LOC_REG = 0, DQ_LOC_THR = 1, DQ_LOC_OUT = 2 } DqBitLoc;
@@ -136,7 +141,8 @@ typedef struct {
     uint32_t mat_advance; /* complex numbers this gate occupies in `mats` (0 for X1): the matrices of a pass
                              lie back to back in gate order, mat(i+1) = mat(i) + mat_advance(i), so the kernel
                              fetches gate i's matrix together with its record instead of after decoding it */
-    uint32_t reserved;  /* pads the record to 32 bytes: one s_load_dwordx8 per gate */
+    uint32_t reserved;  /* DQ_FG_GRAD: row of the accumulator; otherwise 0 (pads the record to 32 bytes: one
+                           s_load_dwordx8 per gate) */
 } DqFusedGate;          /* 32 bytes */
 #define DQ_FAST_NONE 0xFFFFFFFFu
 #define DQ_FAST_IDS 76   /* handler ids are < DQ_FAST_IDS */
@@ -225,6 +231,16 @@ int dq_apply_fused_bcast_c64(const void* in, void* out, const void* mats, int64_
                              int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
 int dq_apply_fused_bcast_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
                               int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
+
+/* Reverse sweep of the adjoint method in fused passes (replaces the backward of autograd through circuit.py:261, one
+ * matmul backward per gate -- qmath.py:504 -- with one saved state per gate).  `in` / `out` hold, per sample, psi and
+ * the cotangent lambda as ONE state of n index bits in which one bit tells them apart; the pass un-applies gates from
+ * both at once (the caller supplies the adjoint matrices) and its DQ_FG_GRAD records reduce, at the right moments of
+ * the sweep, sum lambda (x) conj(psi) onto a trainable gate's target.  `grads` = DEVICE double [batch, ngrads, 8],
+ * ADDED to (the caller zeroes it once per sweep): row r = Re, Im of G[0][0], G[0][1], G[1][0], G[1][1] of the record
+ * with reserved = r.  Workgroups accumulate in LDS over their tiles and add to `grads` once.  complex64 only. */
+int dq_apply_fused_grad_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                            int64_t batch, const DqFusedPass* pass, double* grads, int64_t ngrads, dq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Reductions.  Results are written to DEVICE memory in double precision.

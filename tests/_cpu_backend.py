@@ -40,7 +40,7 @@ class CpuTestBackend:
         return table[(bool(is_c128), variant)]
 
     # ---- fused pass interpreter --------------------------------------------------------------------
-    def apply_fused(self, state, mats, mat_batch_stride, desc, out):
+    def apply_fused(self, state, mats, mat_batch_stride, desc, out, grads=None):
         self.fused_calls += 1
         n = state.shape[-1].bit_length() - 1
         bsz = state.shape[0]
@@ -112,7 +112,7 @@ class CpuTestBackend:
         for gi in range(ngates):
             g = desc.gates[gi]
             assert g.mat == run, 'matrix layout is not sequential'
-            size = {_lib.FG_GEN1: 4, _lib.FG_X1: 0, _lib.FG_DIAG1: 4, _lib.FG_GEN2: 16, _lib.FG_DIAG2: 16, _lib.FG_SWAP: 0}[g.kind]
+            size = {_lib.FG_GEN1: 4, _lib.FG_X1: 0, _lib.FG_DIAG1: 4, _lib.FG_GEN2: 16, _lib.FG_DIAG2: 16, _lib.FG_SWAP: 0, _lib.FG_GRAD: 0}[g.kind]
             assert g.mat_advance == size
             run += size
         per_sample = mats.shape[-1] if mats.ndim == 2 else mats.numel()
@@ -173,6 +173,23 @@ class CpuTestBackend:
                         ((outside >> p) & 1) == 0 for p in high_pos
                     ), 'outside-control on a tile bit'
                     el_ok = (e & cm) == cm
+                    if g.kind == _lib.FG_GRAD:
+                        # include/dq_hip.h, DQ_FG_GRAD: G[a][b] = sum lambda[target = a] conj(psi[target = b]) over the
+                        # controls' 1-subspace; register slot q2 tells psi (0) from lambda (1); row `reserved`
+                        assert grads is not None and not is128, 'reduction record outside a reverse-sweep pass'
+                        assert g.fast == _lib.FAST_NONE and g.q != g.q2 and g.q < R and g.q2 < R and g.reserved < grads.shape[1]
+                        tbit, sbit = rb[g.q], rb[g.q2]
+                        assert not (cm >> tbit) & 1 and not (cm >> sbit) & 1
+                        e00 = e[el_ok & (((e >> tbit) & 1) == 0) & (((e >> sbit) & 1) == 0)]
+                        psi = [t[tile_ok][:, e00].astype(np.complex128), t[tile_ok][:, e00 | (1 << tbit)].astype(np.complex128)]
+                        lam = [t[tile_ok][:, e00 | (1 << sbit)].astype(np.complex128),
+                               t[tile_ok][:, e00 | (1 << sbit) | (1 << tbit)].astype(np.complex128)]
+                        for a_ in range(2):
+                            for b_ in range(2):
+                                v = np.sum(lam[a_] * np.conj(psi[b_]))
+                                grads[b, g.reserved, 2 * (2 * a_ + b_)] += float(v.real)
+                                grads[b, g.reserved, 2 * (2 * a_ + b_) + 1] += float(v.imag)
+                        continue
                     if g.kind in (_lib.FG_GEN1, _lib.FG_X1):
                         tbit = rb[g.q]
                         assert not (cm >> tbit) & 1

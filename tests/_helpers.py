@@ -251,6 +251,76 @@ def check_adjoint_grad_mode(dq, device=None, dtype=torch.float64, n=6, tol=1e-10
         assert (x - y).abs().max().item() < tol, (x - y).abs().max()
 
 
+def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5):
+    """complex64 circuits whose trainable gates all have one target run their reverse sweep as fused passes over psi
+    and the cotangent interleaved along an extra index bit, the reductions folded into the passes (DQ_FG_GRAD):
+    against per-gate autograd and against the undo-then-reduce sweep, with controlled / diagonal / general trainable
+    gates, fixed gates of every kind, batched encoded data and an initial state that requires grad."""
+    def build():
+        torch.manual_seed(5)
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        cir.rxlayer(encode=True)
+        cir.cnot_ring()
+        cir.rylayer()                         # trainable, real
+        cir.rzlayer()                         # trainable, diagonal
+        cir.cnot_ring(reverse=True)
+        cir.u3layer()                         # trainable, general
+        cir.rz(0, encode=True)
+        cir.p(1)
+        cir.crx(0, 2, encode=True)            # trainable with a control
+        cir.u3(3, controls=[0, n - 1])        # two controls
+        cir.toffoli(0, 1, n - 2)
+        cir.rxlayer()
+        cir.s(2)
+        cir.t(4)
+        cir.swap([1, n - 1])
+        cir.cry(n - 1, 0)
+        cir.hlayer()
+        cir.rylayer(encode=True)
+        cir.observable(0)
+        cir.observable([1, 2], 'xy')
+        cir.observable([3, n - 1], 'zz')
+        if device is not None:
+            cir.to(device)
+        return cir
+
+    results = {}
+    for mode, fused in (('per_gate', False), ('adjoint', False), ('adjoint', True)):
+        dq.executor.CONFIG['grad_mode'] = mode
+        dq.executor.CONFIG['fused_sweep'] = fused
+        try:
+            cir = build()
+            g = torch.Generator().manual_seed(8)
+            data = torch.rand(batch, cir.ndata, generator=g)
+            psi0 = torch.randn(batch, 2**n, 1, generator=g) + 1j * torch.randn(batch, 2**n, 1, generator=g)
+            psi0 = psi0 / psi0.norm(dim=1, keepdim=True)
+            if device is not None:
+                data, psi0 = data.to(device), psi0.to(device)
+            data.requires_grad_(True)
+            psi0.requires_grad_(True)
+            cir(data=data, state=psi0)
+            loss = (cir.expectation() * torch.tensor([1.0, -0.5, 0.25], device=data.device)).sum()
+            loss.backward()
+            if mode == 'adjoint':
+                assert dq.executor.LAST_SWEEP['fused'] == fused
+                assert not fused or (dq.executor.LAST_SWEEP['reductions'] > 5 * n and dq.executor.LAST_SWEEP['passes'] >= 1)
+            results[mode, fused] = (loss.detach().cpu(), data.grad.cpu(), psi0.grad.cpu(),
+                                    [p.grad.cpu() for p in cir.parameters()])
+        finally:
+            dq.executor.CONFIG['grad_mode'] = 'adjoint'
+            dq.executor.CONFIG['fused_sweep'] = True
+    a = results['per_gate', False]
+    for key in (('adjoint', False), ('adjoint', True)):
+        b = results[key]
+        assert abs(a[0] - b[0]).item() < tol
+        assert (a[1] - b[1]).abs().max().item() < tol, (key, (a[1] - b[1]).abs().max())
+        assert (a[2] - b[2]).abs().max().item() < tol, (key, (a[2] - b[2]).abs().max())
+        assert len(a[3]) == len(b[3]) and len(a[3]) > 0
+        for x, y in zip(a[3], b[3], strict=True):
+            assert (x - y).abs().max().item() < tol, (key, (x - y).abs().max())
+
+
 def check_edge_cases(dq, device=None):
     """Degenerate and extreme inputs of the circuit driver: no gates, one qubit, a batch of one, only diagonal
     gates, many controls, gates on the first and last wire, repeated forward calls on the same object."""

@@ -334,3 +334,9 @@ def test_uany_kernel_kind_follows_the_matrix():
     assert u._kernel_kind == 'gen' and u.prims()[0].kind == 'gen'
     u.matrix = torch.diag(torch.tensor([1, -1], dtype=torch.cfloat))
     assert u._kernel_kind == 'diag'
+
+
+def test_fused_reverse_sweep_matches_per_gate_autograd(cpu_backend):
+    from _helpers import check_fused_sweep
+
+    check_fused_sweep(dq, n=11, batch=2)

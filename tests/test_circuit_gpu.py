@@ -239,6 +239,17 @@ def test_adjoint_grad_mode_on_gpu():
     check_adjoint_grad_mode(dq, device=dev(), dtype=torch.float64, n=13, tol=1e-10)
 
 
+def test_fused_reverse_sweep_on_gpu():
+    """complex64: the reverse sweep as fused passes with the reductions inside (dq_apply_fused_grad_c64) against
+    per-gate autograd and the undo-then-reduce sweep: 12-bit and 13-bit tiles, one sample and a batch."""
+    from _helpers import check_fused_sweep
+
+    check_fused_sweep(dq, device=dev(), n=11, batch=2)
+    check_fused_sweep(dq, device=dev(), n=12, batch=1)
+    check_fused_sweep(dq, device=dev(), n=16, batch=3)
+    check_fused_sweep(dq, device=dev(), n=20, batch=2, tol=6e-5)
+
+
 def test_adjoint_backward_memory_is_independent_of_depth():
     """Training step at n = 24 (128 MiB per state), 480 gates: stock per-gate autograd would hold one state per
     gate (~60 GiB); the adjoint node peaks at a handful of states."""

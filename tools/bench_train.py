@@ -17,8 +17,10 @@ ap.add_argument('--depth', type=int, default=20)
 ap.add_argument('--modes', default='adjoint,per_gate')
 ap.add_argument('--dtype', default='c64')
 ap.add_argument('--reps', type=int, default=2)
+ap.add_argument('--no-fused-sweep', action='store_true', help='A/B: the undo-then-reduce reverse sweep')
 args = ap.parse_args()
 
+dq.executor.CONFIG['fused_sweep'] = not args.no_fused_sweep
 for mode in args.modes.split(','):
     dq.executor.CONFIG['grad_mode'] = mode
     cir = dq.QubitCircuit(args.n)
@@ -58,7 +60,8 @@ for mode in args.modes.split(','):
         torch.cuda.synchronize()
         fwd = time.perf_counter() - t0
     sb = (8 if args.dtype == 'c64' else 16) * 2**args.n
-    print(f'{mode:9s} n={args.n} depth={args.depth} ({args.n * args.depth} gates, {nrx} trainable) {args.dtype}: '
+    sweep = dict(dq.executor.LAST_SWEEP) if mode == 'adjoint' else {}
+    print(f'{mode:9s} {sweep} n={args.n} depth={args.depth} ({args.n * args.depth} gates, {nrx} trainable) {args.dtype}: '
           f'step {dt * 1e3:8.1f} ms (no-grad forward {fwd * 1e3:6.1f} ms), peak {torch.cuda.max_memory_allocated() / sb:6.1f} states '
           f'= {torch.cuda.max_memory_allocated() / 2**30:6.1f} GiB')
     del cir
