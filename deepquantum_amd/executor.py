@@ -454,6 +454,10 @@ class _AdjointCircuit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, state, meta, *mats):
         prims = [Prim(k, m, t, c, mode) for (k, t, c, mode), m in zip(meta, mats, strict=True)]
+        # the sweep recomputes from `out` gate by gate, so the forward itself may run the merged gate list
+        if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']):
+            with torch.no_grad():
+                prims = merge_one_qubit_runs(prims)
         out = _run_nograd(state, prims)
         ctx.meta = meta
         ctx.save_for_backward(out, *mats)
