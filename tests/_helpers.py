@@ -321,6 +321,70 @@ def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5):
             assert (x - y).abs().max().item() < tol, (key, (x - y).abs().max())
 
 
+def check_grad_records(n, m, device):
+    """DQ_FG_GRAD records (dq_apply_fused_grad_c64) against numpy: psi and lambda interleaved along index bit 0, a
+    reduction sum lambda (x) conj(psi) for every target bit, with controls that land on register slots, on thread
+    bits and outside the tile, in between gates that leave deferred factors in the registers (Hadamards, Rx); the
+    accumulator is added to, rows not named stay untouched, a plain pass refuses the records."""
+    import random
+
+    import numpy as np
+    import pytest
+    from test_fusion_cpu import run_reference
+
+    from deepquantum_amd import backend, fusion
+
+    rng = random.Random(100 + n)
+    b = 2
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(b, 2**n, generator=gen, dtype=torch.float64) + 1j * torch.randn(b, 2**n, generator=gen, dtype=torch.float64)
+    x = (x / x.norm(dim=1, keepdim=True)).to(torch.complex64)
+    ops, mats_l, want = [], [], []
+    cur = x.clone()
+    off = 0
+    h = torch.tensor([[1, 1], [1, -1]], dtype=torch.complex64) / 2 ** 0.5
+    for step in range(3 * (n - 1)):
+        t = 1 + step % (n - 1)
+        th = rng.uniform(0.3, 2.8)
+        mat = h if step % 3 == 0 else torch.tensor([[np.cos(th / 2), -1j * np.sin(th / 2)], [-1j * np.sin(th / 2), np.cos(th / 2)]],
+                                                  dtype=torch.complex64)
+        ops.append(fusion.PrimOp('gen', (t,), (), off, 3 if step % 3 == 0 else 2))
+        mats_l.append(mat.reshape(-1))
+        off += 4
+        cur = run_reference(cur, [fusion.PrimOp('gen', (t,), (), 0, 0)], mat.reshape(-1))
+        q = 1 + rng.randrange(n - 1)
+        ctrl = tuple(rng.sample([c for c in range(1, n) if c != q], rng.choice([0, 0, 1, 2])))
+        row = len(want) + 1                      # row 0 stays untouched
+        ops.append(fusion.PrimOp('grad', (q, 0), ctrl, 0, row))
+        v = cur.numpy().astype(np.complex128).reshape(b, -1)
+        idx = np.arange(1 << n)
+        ok = np.ones(1 << n, dtype=bool)
+        for c in ctrl:
+            ok &= ((idx >> c) & 1) == 1
+        g = np.zeros((b, 2, 2), dtype=np.complex128)
+        for a_ in range(2):
+            for b_ in range(2):
+                la = v[:, ok & ((idx & 1) == 1) & (((idx >> q) & 1) == a_)]
+                ps = v[:, ok & ((idx & 1) == 0) & (((idx >> q) & 1) == b_)]
+                g[:, a_, b_] = (la * ps.conj()).sum(-1)
+        want.append(g)
+    mats = torch.cat(mats_l)
+    geom = fusion.default_geometry(False, m)
+    steps = fusion.schedule(ops, n, geom)
+    assert all(isinstance(s, fusion.FusedStep) for s in steps)
+    xd, md = x.to(device), fusion.kernel_matrices(steps, ops, mats).to(device)
+    acc = torch.full((b, len(want) + 1, 8), 0.5, dtype=torch.float64, device=device)
+    with pytest.raises((RuntimeError, AssertionError)):
+        backend.apply_fused(xd.clone(), md, 0, steps[0].desc)          # reduction records outside a reverse-sweep pass
+    for st in steps:
+        backend.apply_fused(xd, md, 0, st.desc, out=xd, grads=acc)
+    assert (xd.cpu() - cur).abs().max().item() < 1e-4
+    got = torch.view_as_complex((acc - 0.5).reshape(b, -1, 4, 2)).reshape(b, -1, 2, 2).cpu().numpy()
+    assert np.abs(got[:, 0]).max() == 0.0
+    for r_, g in enumerate(want):
+        assert np.abs(got[:, r_ + 1] - g).max() < 2e-5 * max(1.0, np.abs(g).max()), (r_, ops[2 * r_ + 1])
+
+
 def check_edge_cases(dq, device=None):
     """Degenerate and extreme inputs of the circuit driver: no gates, one qubit, a batch of one, only diagonal
     gates, many controls, gates on the first and last wire, repeated forward calls on the same object."""

@@ -216,6 +216,13 @@ def test_fused_pass_with_one_shared_input_state(is128, n, b):
     assert torch.equal(xd.cpu(), x)
 
 
+@pytest.mark.parametrize('n,m', [(15, 13), (14, 12), (12, 12)])
+def test_reductions_inside_fused_passes_match_numpy(n, m):
+    from _helpers import check_grad_records
+
+    check_grad_records(n, m, dev())
+
+
 @pytest.mark.parametrize('dtype,n', [(torch.complex64, 15), (torch.complex64, 11), (torch.complex128, 13),
                                      (torch.complex128, 10), (torch.complex64, 9)])
 def test_gate_grad_multi_equals_gate_by_gate(dtype, n):
