@@ -173,9 +173,10 @@ class QubitCircuit(Operation):
             thetas = torch.stack([(-g.theta if g.inv_mode else g.theta).reshape(-1) for g in gates])  # (G, B)
             mats = gates[0].get_matrix(thetas.reshape(-1))
             d = mats.shape[-1]
-            mats = mats.reshape(len(gates), numel, d, d)
-            for i, g in enumerate(gates):
-                m = mats[i] if numel > 1 else mats[i, 0]
+            # one unbind instead of a select per gate: autograd then stacks the gates' matrix gradients in ONE kernel
+            # (a select's backward is a zero-fill plus a copy per gate, and an add per gate to sum them up)
+            parts = (mats.reshape(len(gates), numel, d, d) if numel > 1 else mats.reshape(len(gates), d, d)).unbind(0)
+            for g, m in zip(gates, parts, strict=True):
                 g.__dict__['_precomputed'] = m
                 g.__dict__['_matrix_cache'] = m.detach()
                 g._stamp()

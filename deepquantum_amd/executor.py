@@ -510,6 +510,8 @@ class _AdjointCircuit(torch.autograd.Function):
                 g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))      # the kernels ignore off-diagonal entries
             if nb == 1 and b > 1:
                 g = g.sum(dim=1, keepdim=True)
+            if all(mats[j].dtype == mats[js[0]].dtype for j in js):
+                g = g.to(mats[js[0]].dtype)         # one conversion for the group, not one per gate
             for k, j in enumerate(js):
                 grads[j] = g[k].to(mats[j].dtype).reshape(mats[j].shape)
         gstate = lam() if ctx.needs_input_grad[0] else None
@@ -583,7 +585,13 @@ class _AdjointCircuit(torch.autograd.Function):
                 prims.append(Prim('grad', None, (t1[0], 0), c1, rows[j]))
             prims.append(Prim(kind, undo[j][b : b + 1] if shared[j] else undo[j][b:], t1, c1, mode))
         acc = torch.zeros(b, max(len(rows), 1), 8, dtype=torch.float64, device=out.device)
-        work = _run_nograd(work, prims, inplace=True, scratch=torch.empty_like(work), grads=acc)
+        scratch = None                    # the partner buffer of the permuted stores, when it fits what is free now
+        if work.is_cuda:
+            free, _total = torch.cuda.mem_get_info(work.device)
+            free += torch.cuda.memory_reserved(work.device) - torch.cuda.memory_allocated(work.device)
+            if 1.05 * work.numel() * work.element_size() <= free:
+                scratch = torch.empty_like(work)
+        work = _run_nograd(work, prims, inplace=True, scratch=scratch, grads=acc)
         LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=len(rows))
         g = torch.view_as_complex(acc.reshape(b, -1, 4, 2)).reshape(b, -1, 2, 2)
         raw = {j: g[:, r] for j, r in rows.items()}

@@ -299,9 +299,10 @@ def _qml_circuit(n, trainable, seed=1234):
     return cir.to(dev())
 
 
-def test_hip_graph_capture_of_forward_and_training_step():
-    """Launch-bound sizes: the whole evaluation (and the whole forward + backward) replays as one HIP graph."""
-    n = 7
+@pytest.mark.parametrize('n', [7, 12])
+def test_hip_graph_capture_of_forward_and_training_step(n):
+    """Launch-bound sizes: the whole evaluation (and the whole forward + backward) replays as one HIP graph; n = 12:
+    the backward is the fused reverse sweep (dq_apply_fused_grad_c64) inside the captured graph."""
     cir = _qml_circuit(n, trainable=False)
     data = torch.zeros(16, cir.ndata, device=dev())
     with torch.no_grad():
@@ -332,6 +333,7 @@ def test_hip_graph_capture_of_forward_and_training_step():
 
             train.zero_grad(set_to_none=True)
             graph = dq.CapturedGraph(step)
+            assert mode != 'adjoint' or dq.executor.LAST_SWEEP['fused'] == (n >= 11)
             for it in range(2):
                 for p in train.parameters():
                     p.grad.zero_()

@@ -13,8 +13,13 @@ bash tools/ablation_table.sh > "$root/ablation.txt" 2>&1
 bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
 bash tools/mb_counters.sh --dtype c128 > "$root/microbench_c128.txt" 2>&1
 {
+  python tools/bench_train.py --n 20 --depth 20 2>&1 | grep -v amdgpu.ids
+  python tools/bench_train.py --n 20 --depth 20 --modes adjoint --no-fused-sweep 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 24 --depth 20 2>&1 | grep -v amdgpu.ids
+  python tools/bench_train.py --n 24 --depth 20 --modes adjoint --no-fused-sweep 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 28 --depth 40 --modes adjoint 2>&1 | grep -v amdgpu.ids
+  python tools/bench_train.py --n 28 --depth 40 --modes adjoint --no-fused-sweep 2>&1 | grep -v amdgpu.ids
+  python tools/dump_sweep_passes.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_small.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_density.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_expect.py 2>&1 | grep -v amdgpu.ids
@@ -22,5 +27,8 @@ bash tools/mb_counters.sh --dtype c128 > "$root/microbench_c128.txt" 2>&1
   python tools/bench_dense.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_single_gate_kernel.py 2>&1 | grep -v amdgpu.ids
   python bench.py --dtype c128 --batch 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null
+  echo "# the one-GPU anchor of the strong-scaling pair (SURVEY 8d): n = 31, batch 1"
+  python bench.py --strong --steps 3 --warmup 1 --no-cpu-baseline --no-sweep 2>/dev/null
 } > "$root/secondary_benchmarks.txt" 2>&1
+python tools/crosscheck_large.py 2>&1 | grep -v amdgpu.ids > "$root/crosscheck_large.txt"
 ls -la "$root"
