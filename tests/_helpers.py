@@ -385,6 +385,77 @@ def check_grad_records(n, m, device):
         assert np.abs(got[:, r_ + 1] - g).max() < 2e-5 * max(1.0, np.abs(g).max()), (r_, ops[2 * r_ + 1])
 
 
+def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, tol=5e-5):
+    """Fuzz of the fused reverse sweep: a random sequence from the whole gate menu -- fixed, trainable and encoded
+    (batched) gates, controls of every arity, diagonal and two-qubit gates in between -- differentiated by the fused
+    sweep and by per-gate autograd."""
+    import random
+
+    def build():
+        rng = random.Random(seed)
+        torch.manual_seed(seed)
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        for _ in range(ngates):
+            kind = rng.choice(['h', 'x', 'y', 'z', 's', 't', 'rx', 'ry', 'rz', 'p', 'u3', 'cnot', 'cz', 'crx', 'cry', 'crz',
+                               'toffoli', 'swap', 'rxx_enc', 'rzz_enc', 'rx_enc', 'ry_ctrl', 'u3_ctrl2', 'fredkin', 'cp'])
+            w = rng.sample(range(n), 3)
+            if kind in ('h', 'x', 'y', 'z', 's', 't'):
+                getattr(cir, kind)(w[0], controls=[w[1]] if rng.random() < 0.2 else None)
+            elif kind in ('rx', 'ry', 'rz', 'p', 'u3'):
+                getattr(cir, kind)(w[0])
+            elif kind in ('cnot', 'cz', 'crx', 'cry', 'crz', 'cp'):
+                getattr(cir, kind)(w[0], w[1])
+            elif kind == 'toffoli':
+                cir.toffoli(w[0], w[1], w[2])
+            elif kind == 'fredkin':
+                cir.fredkin(w[0], w[1], w[2])
+            elif kind == 'swap':
+                cir.swap([w[0], w[1]])
+            elif kind == 'rxx_enc':
+                cir.rxx([w[0], w[1]], inputs=rng.uniform(0.0, 6.0))       # fixed angle: two-target gates stay untrainable
+            elif kind == 'rzz_enc':
+                cir.rzz([w[0], w[1]], inputs=rng.uniform(0.0, 6.0))
+            elif kind == 'rx_enc':
+                cir.rx(w[0], encode=True)
+            elif kind == 'ry_ctrl':
+                cir.ry(w[0], controls=[w[1]])
+            else:
+                cir.u3(w[0], controls=[w[1], w[2]])
+        cir.observable(0)
+        cir.observable([1, n - 1], 'xz')
+        if device is not None:
+            cir.to(device)
+        return cir
+
+    results = {}
+    for mode in ('per_gate', 'adjoint'):
+        dq.executor.CONFIG['grad_mode'] = mode
+        try:
+            cir = build()
+            g = torch.Generator().manual_seed(100 + seed)
+            data = torch.rand(batch, max(cir.ndata, 1), generator=g) * 6.0
+            if device is not None:
+                data = data.to(device)
+            data.requires_grad_(True)
+            cir(data=data if cir.ndata else None)
+            loss = (cir.expectation() * torch.tensor([1.0, -0.7], device=data.device)).sum()
+            loss.backward()
+            if mode == 'adjoint':
+                assert dq.executor.LAST_SWEEP['fused'] and dq.executor.LAST_SWEEP['reductions'] > 0
+            results[mode] = (loss.detach().cpu(), data.grad.cpu() if cir.ndata else None,
+                             [p.grad.cpu() for p in cir.parameters()])
+        finally:
+            dq.executor.CONFIG['grad_mode'] = 'adjoint'
+    a, b = results['per_gate'], results['adjoint']
+    assert abs(a[0] - b[0]).item() < tol
+    if a[1] is not None:
+        assert (a[1] - b[1]).abs().max().item() < tol, (a[1] - b[1]).abs().max()
+    assert len(a[2]) == len(b[2]) and len(a[2]) > 0
+    for x, y in zip(a[2], b[2], strict=True):
+        assert (x - y).abs().max().item() < tol, (x - y).abs().max()
+
+
 def check_edge_cases(dq, device=None):
     """Degenerate and extreme inputs of the circuit driver: no gates, one qubit, a batch of one, only diagonal
     gates, many controls, gates on the first and last wire, repeated forward calls on the same object."""

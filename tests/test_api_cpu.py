@@ -340,3 +340,10 @@ def test_fused_reverse_sweep_matches_per_gate_autograd(cpu_backend):
     from _helpers import check_fused_sweep
 
     check_fused_sweep(dq, n=11, batch=2)
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_fused_reverse_sweep_on_random_circuits(cpu_backend, seed):
+    from _helpers import check_fused_sweep_random
+
+    check_fused_sweep_random(dq, n=11, batch=2, seed=seed, ngates=60)

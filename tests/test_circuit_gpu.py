@@ -250,6 +250,13 @@ def test_fused_reverse_sweep_on_gpu():
     check_fused_sweep(dq, device=dev(), n=20, batch=2, tol=6e-5)
 
 
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_fused_reverse_sweep_on_random_circuits_on_gpu(seed):
+    from _helpers import check_fused_sweep_random
+
+    check_fused_sweep_random(dq, device=dev(), n=13 + seed % 3, batch=1 + seed % 2, seed=seed)
+
+
 def test_adjoint_backward_memory_is_independent_of_depth():
     """Training step at n = 24 (128 MiB per state), 480 gates: stock per-gate autograd would hold one state per
     gate (~60 GiB); the adjoint node peaks at a handful of states."""
