@@ -82,6 +82,7 @@ def parse_args():
                     help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
     ap.add_argument('--no-lane-swaps', action='store_true',
                     help='A/B: every layout change of a pass goes through LDS (no in-wave permlane / DPP exchanges)')
+    ap.add_argument('--no-free-low', action='store_true', help='A/B: the contiguous low bits keep the same qubits in every pass')
     ap.add_argument('--swap-lanes', default=None, help='A/B: lane bits usable for in-wave exchanges, e.g. 4,5')
     ap.add_argument('--swap-policy', default=None, choices=['plan', 'chance'])
     ap.add_argument('--tiles-per-wg', type=int, default=None,
@@ -341,6 +342,8 @@ def main():
         dq.executor.CONFIG['permute_store'] = False
     if args.no_lane_swaps:
         dq.executor.CONFIG['lane_swaps'] = False
+    if args.no_free_low:
+        dq.executor.CONFIG['free_low'] = False
     if args.swap_policy is not None:
         dq.executor.CONFIG['swap_policy'] = args.swap_policy
     if args.swap_lanes is not None:

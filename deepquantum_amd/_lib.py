@@ -16,13 +16,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DQHIP_LIBRARY') or os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_SWAP, FG_GRAD = range(7)
 LOC_REG, LOC_THR, LOC_OUT = range(3)
 
 FUSED_MAX_HIGH = 12
+FUSED_MAX_LOW = 8
 FUSED_MAX_ROUNDS = 24
 FUSED_MAX_GATES = 80
 FUSED_MAX_SLOTS = 4
@@ -81,6 +82,8 @@ class DqFusedPass(C.Structure):
         ('lds_tab', (C.c_uint16 * 16) * (FUSED_MAX_ROUNDS + 2)),
         ('store_high_pos', C.c_uint8 * FUSED_MAX_HIGH),
         ('store_blk_pos', C.c_uint8 * FUSED_MAX_BLK),
+        ('store_low_pos', C.c_uint8 * FUSED_MAX_LOW),
+        ('store_tb', C.c_uint8 * FUSED_MAX_TBITS),
     ]
 
 

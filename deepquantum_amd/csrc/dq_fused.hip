@@ -540,6 +540,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
                   "header word layout");
     const uint32_t hw0 = hw[0], hp0 = hw[1], hp1 = hw[2], hp2 = hw[3], hs0 = hw[4], hs1 = hw[5], hs2 = hw[6], lrb = hw[7],
                    srbw = hw[8];
+    (void)srbw;
     const int L = (int)((hw0 >> 8) & 0xffu), h = (int)((hw0 >> 16) & 0xffu);
     auto byte_of = [](uint32_t w0, uint32_t w1, uint32_t w2, int i) __attribute__((always_inline)) -> unsigned {
         return ((i < 4 ? w0 : (i < 8 ? w1 : w2)) >> (8 * (i & 3))) & 0xffu;
@@ -590,8 +591,16 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         return tw;
     };
     V* const pout0 = out + ((uint64_t)sample << n);
+    constexpr int SLP_W0 = offsetof(DqFusedPass, store_low_pos) / 4, STB_W0 = offsetof(DqFusedPass, store_tb) / 4;
+    static_assert(offsetof(DqFusedPass, store_low_pos) % 4 == 0 && offsetof(DqFusedPass, store_tb) % 4 == 0 &&
+                      DQ_FUSED_MAX_LOW == 8, "");
     auto glob_w = [&](unsigned e) __attribute__((always_inline)) -> uint64_t {
-        uint64_t g = e & ((1u << L) - 1u);
+        // tile bit i < L -> store_low_pos[i] (the low bits move like the others: include/dq_hip.h)
+        const uint32_t lp0 = hw[SLP_W0], lp1 = hw[SLP_W0 + 1];
+        uint64_t g = 0;
+#pragma unroll
+        for (int i = 0; i < DQ_FUSED_MAX_LOW; ++i)
+            if (i < L) g |= (uint64_t)((e >> i) & 1u) << (((i < 4 ? lp0 : lp1) >> (8 * (i & 3))) & 0x3fu);
         for (int i = 0; i < h; ++i)
             g |= (uint64_t)((e >> (L + i)) & 1u) << ((hw[SHP_W0 + (i >> 2)] >> (8 * (i & 3))) & 0xffu);
         return g;
@@ -883,9 +892,13 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     }
 
     if (last_flags & DQ_ROUND_TRANSPOSE_AFTER) {  // ---- into the store layout ----
-        unsigned stbase = tid;
+        unsigned stbase = 0;       // thread-index bit i sits on tile bit store_tb[i]
+        const uint32_t sw0 = hw[STB_W0], sw1 = hw[STB_W0 + 1], sw2 = hw[STB_W0 + 2];
 #pragma unroll
-        for (int s = 0; s < R; ++s) stbase = (unsigned)insert_zero(stbase, (int)((srbw >> (8 * s)) & 0xffu));
+        for (int i = 0; i < LOGT; ++i) {
+            const uint32_t w = i < 4 ? sw0 : (i < 8 ? sw1 : sw2);
+            stbase |= ((tid >> i) & 1u) << ((w >> (8 * (i & 3))) & 0xffu);
+        }
         transpose_to(stbase, DQ_FUSED_MAX_ROUNDS + 1);
     }
 
@@ -993,31 +1006,61 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
         set_error("dq_apply_fused: high_sorted is not a permutation of high_pos");
         return DQ_ERR_ARG;
     }
-    for (int io = 0; io < 2; ++io) {
-        const uint8_t* iorb = io ? p->store_rb : p->load_rb;
+    {   // load layout: tile bit 0 on slot 0 for complex64 (16 bytes per lane), otherwise gathered bits, ascending
         constexpr int vb = sizeof(T) == 4 ? 1 : 0;
         for (int s = 0; s < slots; ++s) {
-            const bool ok = (s < vb) ? (iorb[s] == s) : (iorb[s] >= p->L && iorb[s] < m);
-            if (!ok || (s > 0 && iorb[s] <= iorb[s - 1])) {
-                set_error("dq_apply_fused: %s layout invalid at slot %d", io ? "store" : "load", s);
+            const bool ok = (s < vb) ? (p->load_rb[s] == s) : (p->load_rb[s] >= p->L && p->load_rb[s] < m);
+            if (!ok || (s > 0 && p->load_rb[s] <= p->load_rb[s - 1])) {
+                set_error("dq_apply_fused: load layout invalid at slot %d", s);
                 return DQ_ERR_ARG;
             }
         }
     }
-    {   // write positions: a permutation of [L, n)
+    if (p->L > DQ_FUSED_MAX_LOW) {
+        set_error("dq_apply_fused: L = %d contiguous low bits, at most %d", p->L, DQ_FUSED_MAX_LOW);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    {   // write positions: a permutation of [0, n)
         const int nblk = n - m;
         if (nblk > DQ_FUSED_MAX_BLK) {
             set_error("dq_apply_fused: n - m = %d block bits, at most %d", nblk, DQ_FUSED_MAX_BLK);
             return DQ_ERR_UNSUPPORTED;
         }
         uint64_t wseen = 0;
-        for (int i = 0; i < p->h + nblk; ++i) {
-            const int pos = i < p->h ? p->store_high_pos[i] : p->store_blk_pos[i - p->h];
-            if (pos < p->L || pos >= n || ((wseen >> pos) & 1ull)) {
-                set_error("dq_apply_fused: write positions are not a permutation of [L, n) (entry %d = %d)", i, pos);
+        for (int i = 0; i < m + nblk; ++i) {
+            const int pos = i < p->L ? p->store_low_pos[i]
+                                     : (i < m ? p->store_high_pos[i - p->L] : p->store_blk_pos[i - m]);
+            if (pos >= n || ((wseen >> pos) & 1ull)) {
+                set_error("dq_apply_fused: write positions are not a permutation of [0, n) (entry %d = %d)", i, pos);
                 return DQ_ERR_ARG;
             }
             wseen |= 1ull << pos;
+        }
+    }
+    {   // store layout: explicit slots and thread bits covering the tile; complex64 stores two adjacent amplitudes per
+        // lane, so the tile bit of slot 0 must be written to global bit 0
+        unsigned used = 0;
+        for (int s = 0; s < slots; ++s) {
+            if (p->store_rb[s] >= m || ((used >> p->store_rb[s]) & 1u)) {
+                set_error("dq_apply_fused: store layout invalid at slot %d", s);
+                return DQ_ERR_ARG;
+            }
+            used |= 1u << p->store_rb[s];
+        }
+        for (int i = 0; i < logt; ++i) {
+            if (p->store_tb[i] >= m || ((used >> p->store_tb[i]) & 1u)) {
+                set_error("dq_apply_fused: store layout invalid at thread bit %d", i);
+                return DQ_ERR_ARG;
+            }
+            used |= 1u << p->store_tb[i];
+        }
+        if (sizeof(T) == 4) {
+            const int tb0 = p->store_rb[0];
+            const int pos = tb0 < p->L ? p->store_low_pos[tb0] : p->store_high_pos[tb0 - p->L];
+            if (pos != 0) {
+                set_error("dq_apply_fused: the tile bit of store slot 0 (%d) is written to bit %d, not bit 0", tb0, pos);
+                return DQ_ERR_ARG;
+            }
         }
     }
     int next_gate = 0;
@@ -1058,7 +1101,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
             for (int i = 0; i < logt; ++i) differs = differs || ptb[i] != rd.tb[i];
             bool after = false;
             if (r == p->nrounds - 1) {
-                io_tb(p->store_rb, stb);
+                for (int i = 0; i < logt; ++i) stb[i] = p->store_tb[i];
                 for (int s = 0; s < slots; ++s) after = after || p->store_rb[s] != rd.rb[s];
                 for (int i = 0; i < logt; ++i) {
                     after = after || rd.tb[i] != stb[i];
@@ -1232,6 +1275,7 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     if (rc) return rc;
     if (in == out) {   // in place: every amplitude must be written where it was read
         bool same = true;
+        for (int i = 0; i < pass->L; ++i) same = same && pass->store_low_pos[i] == i;
         for (int i = 0; i < pass->h; ++i) same = same && pass->store_high_pos[i] == pass->high_pos[i];
         uint64_t tilemask = 0;
         for (int i = 0; i < pass->h; ++i) tilemask |= 1ull << pass->high_pos[i];

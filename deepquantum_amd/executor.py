@@ -55,6 +55,8 @@ CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min
           'max_gates': None, 'max_far': None, 'far_bit': None,
           # pass planner (fusion._plan_tiles): beam width / tiles tried per state; 0 = first-come tiles, 1 = greedy
           'plan_width': None, 'plan_branch': None, 'plan_restarts': None, 'asm_loop': None, 'lane_swaps': None, 'swap_lanes': None, 'swap_policy': None,
+          # permuted stores also re-label the contiguous low bits, so every pass picks all its tile qubits (None = on)
+          'free_low': None,
           # out-of-place passes that write the next pass's qubits to cheap index bits (fusion._place_writes): needs a
           # second state buffer; used when both fit in `permute_mem_frac` of the device memory
           'permute_store': True, 'permute_mem_frac': 0.45, 'permute_min_bits': 20,
@@ -114,6 +116,10 @@ def _geometry(is128: bool) -> fusion.Geometry:
         g.swap_lanes = tuple(CONFIG['swap_lanes'])
         if g.fallback is not None:
             g.fallback.swap_lanes = g.swap_lanes
+    if CONFIG['free_low'] is not None:
+        g.free_low = bool(CONFIG['free_low'])
+        if g.fallback is not None:
+            g.fallback.free_low = g.free_low
     if CONFIG['asm_loop'] is not None:
         g.asm_loop = CONFIG['asm_loop']
         if g.fallback is not None:
@@ -140,7 +146,7 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     if geom.fallback is not None:
         geom.fallback.permute_store = permute
     key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
-           geom.plan_branch, geom.plan_restarts, geom.asm_loop, geom.lane_swaps, geom.swap_lanes, geom.swap_policy, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
+           geom.plan_branch, geom.plan_restarts, geom.asm_loop, geom.free_low, geom.lane_swaps, geom.swap_lanes, geom.swap_policy, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
            tuple((p.kind, p.targets, p.controls, p.mode) for p in prims))
     plan = _PLAN_CACHE.get(key)
     if plan is not None:

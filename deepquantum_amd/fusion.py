@@ -77,6 +77,7 @@ class Geometry:
     swap_lanes: tuple = (0, 1, 2, 3, 4, 5)    # ... with these lane bits
     swap_policy: str = 'chance'  # 'plan': LDS trips park the coming rounds' bits on lane bits; 'chance': trip-only layouts
     permute_store: bool = False   # passes may write to other index bits than they read (out-of-place; _place_writes)
+    free_low: bool = True         # ... including the contiguous low bits: every pass picks ALL its tile qubits (_schedule)
     asm_loop: bool = True     # mark rounds whose gates all have handler ids (DQ_ROUND_ALL_FAST); off: A/B measurements
     plan_restarts: int = 3    # beam searches with different random branches (states of >= 2^plan_restart_bits amplitudes)
     plan_restart_bits: int = 26
@@ -214,11 +215,17 @@ def _closure(dag: '_Dag', tile: set[int], cap: int, indeg: list[int] | None = No
 
 
 def _grow_tile(dag: '_Dag', low: set[int], hcap: int, cap: int, indeg: list[int] | None = None,
-               ready: list[int] | None = None, pick=None, far: tuple[int, int] | None = None) -> set[int]:
+               ready: list[int] | None = None, pick=None, far: tuple[int, int] | None = None,
+               prev: set[int] | None = None, need: int = 0) -> set[int]:
     """Gathered bits of one pass, grown one bit at a time: dry-run the pass with the bits chosen so far, look at
     the gates it leaves stuck at the front, and add the missing target bit that lets the pass retire the most
     gates (ties: the bit most stuck gates wait for, then the lowest).  ``pick(ranked)`` may choose another of the
-    ranked candidates (the beam search's branching)."""
+    ranked candidates (the beam search's branching).
+
+    ``prev`` / ``need`` (free low bits, ``low`` empty): the tile must share at least ``need`` qubits with the tile
+    ``prev`` of the pass before -- they become its contiguous low bits, which that pass must be able to write as whole
+    runs -- so once the room left equals what is still missing, only qubits of ``prev`` are candidates, and a tile
+    that ends short is padded with qubits of ``prev`` that no gate asked for."""
     chosen: set[int] = set()
     while len(chosen) < hcap:
         tile = low | chosen
@@ -235,21 +242,33 @@ def _grow_tile(dag: '_Dag', low: set[int], hcap: int, cap: int, indeg: list[int]
                     cands[t] = cands.get(t, 0) + 1
         if far is not None and sum(1 for b_ in chosen if b_ >= far[0]) >= far[1]:
             cands = {q: w for q, w in cands.items() if q < far[0]}     # the budget of far-apart bits is spent
+        if prev is not None and hcap - len(chosen) <= need - len(chosen & prev):
+            cands = {q: w for q, w in cands.items() if q in prev}
         if not cands:
             break
         ranked = sorted(((_closure(dag, tile | {q}, cap, indeg, ready)[0], w, -q) for q, w in cands.items()),
                         reverse=True)
         best = ranked[0] if pick is None else pick(ranked)
         chosen.add(-best[2])
+    if prev is not None:
+        for q in sorted(prev - chosen):
+            if len(chosen & prev) >= need:
+                break
+            if len(chosen) >= hcap:     # (cannot happen: the candidates were restricted in time)
+                break
+            chosen.add(q)
     return chosen
 
 
 def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, branch: int,
-                seed: int = 20250929, far: tuple[int, int] | None = None) -> list[set[int] | None]:
+                seed: int = 20250929, far: tuple[int, int] | None = None, free_low: int = 0) -> list[set[int] | None]:
     """Gathered-bit sets for ALL passes of a circuit by beam search over dry runs (`_closure`): every beam state
     (a front of the DAG) is extended by the greedy tile and by ``branch - 1`` randomised ones (one of the three best
     candidates at each growth step, fixed seed), the ``width`` states that have retired the most gates survive.
-    ``None`` entries stand for a gate that cannot be fused and runs on its own.  width = 1: plain greedy."""
+    ``None`` entries stand for a gate that cannot be fused and runs on its own.  width = 1: plain greedy.
+
+    ``free_low`` = L > 0: the entries are WHOLE tiles (up to hcap + L qubits, none of them fixed), each sharing at
+    least L qubits with the one before (the first with ``low``): see `_grow_tile`."""
     import random
 
     rng = random.Random(seed)
@@ -257,20 +276,26 @@ def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, bra
     def jitter(ranked):
         return ranked[rng.randrange(min(3, len(ranked)))]
 
-    beam = [(0, list(dag.indeg), list(dag.ready), [])]
+    beam = [(0, list(dag.indeg), list(dag.ready), [], set(low))]
     while True:
         nxt = []
-        for done, indeg, ready, hist in beam:
+        for done, indeg, ready, hist, prev in beam:
             if done >= dag.n_ops:
                 return hist
             seen = set()
             for b_ in range(branch if width > 1 else 1):
-                tile_bits = _grow_tile(dag, low, hcap, cap, indeg, ready, jitter if b_ else None, far)
+                if free_low:
+                    tile_bits = _grow_tile(dag, set(), hcap + free_low, cap, indeg, ready, jitter if b_ else None, far,
+                                           prev=prev, need=free_low)
+                    whole = tile_bits
+                else:
+                    tile_bits = _grow_tile(dag, low, hcap, cap, indeg, ready, jitter if b_ else None, far)
+                    whole = low | tile_bits
                 key = frozenset(tile_bits)
                 if key in seen:
                     continue
                 seen.add(key)
-                count, stuck, changed = _closure(dag, low | tile_bits, cap, indeg, ready)
+                count, stuck, changed = _closure(dag, whole, cap, indeg, ready)
                 nindeg = list(indeg)
                 for k_, v in changed.items():
                     nindeg[k_] = v
@@ -281,9 +306,9 @@ def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, bra
                         nindeg[s_] -= 1
                         if nindeg[s_] == 0:
                             stuck.append(s_)
-                    nxt.append((done + 1, nindeg, stuck, hist + [None]))
+                    nxt.append((done + 1, nindeg, stuck, hist + [None], prev))
                     break
-                nxt.append((done + count, nindeg, stuck, hist + [tile_bits]))
+                nxt.append((done + count, nindeg, stuck, hist + [tile_bits], whole))
         nxt.sort(key=lambda t: -t[0])
         beam = nxt[:width]
 
@@ -324,6 +349,13 @@ def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True,
         cand = _schedule(ops, n, geom, width, final_perm)
         if cost(cand) < cost(best):
             best = cand
+        if geom.free_low and geom.permute_store and final_perm is None and width > 1:
+            # every pass picks ALL its tile qubits (the stores also re-label the contiguous low bits): fewer passes
+            # when the circuit does not keep coming back to the same low qubits; None: it could not restore the
+            # canonical order with its last pass, or a gate had to run on its own
+            cand = _schedule(ops, n, geom, width, None, free_low=True)
+            if cand is not None and cost(cand) < cost(best):
+                best = cand
     return best
 
 
@@ -334,19 +366,28 @@ class Steps(list):
 
 
 def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
-              final_perm: Sequence[int] | None = None) -> 'Steps':
+              final_perm: Sequence[int] | None = None, free_low: bool = False) -> 'Steps | None':
+    """``free_low`` (with permuted stores and a planner): the L contiguous low bits of a pass hold whichever qubits the
+    pass before wrote there -- ``low_list``, position by position, chosen from the qubits that pass had in its tile and
+    this one wants -- so all m tile qubits are picked per pass.  Returns None when that does not work out (a gate that
+    runs on its own needs the canonical order, and so does the end of the circuit: qubits 0 .. L-1 must then be in
+    the last tile)."""
     dag = _Dag(ops, n)
-    steps: list = []                    # SingleStep | (geometry, gathered bits, rounds) of a fused pass, finalised below
-    low = set(range(geom.min_low))
-    hcap = geom.m - geom.min_low
+    steps: list = []                    # SingleStep | (geometry, low bits, gathered bits, rounds) of a fused pass, finalised below
+    L = geom.min_low
+    low_list = list(range(L))           # the qubits on index bits 0 .. L-1 when the pass starts
+    low = set(low_list)
+    hcap = geom.m - L
     # the randomised branches make the pass count vary by one or two: on big states a few restarts are worth it
     restarts = geom.plan_restarts if width > 1 and n >= geom.plan_restart_bits else 1
     far = (geom.far_bit, geom.max_far) if geom.max_far is not None else None
-    planned = min((_plan_tiles(dag, low, hcap, geom.max_gates, width, geom.plan_branch, 20250929 + r, far)
+    planned = min((_plan_tiles(dag, low, hcap, geom.max_gates, width, geom.plan_branch, 20250929 + r, far,
+                               free_low=L if free_low else 0)
                    for r in range(restarts)), key=len) if width else []
     planned.reverse()                   # consumed from the end
+    prev_tile: set[int] | None = None
     while dag.done < dag.n_ops:
-        high: set[int] = set()          # tile bits beyond the guaranteed low ones
+        high: set[int] = set()          # tile bits beyond the low ones
         rounds: list[_Round] = [_Round()]
         count = 0
         if width == 0:
@@ -356,10 +397,25 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
             if allowed is None:         # a gate the fused kernel does not take
                 i = dag.ready[0]
                 if not _fusable(ops[i]):
+                    if free_low:
+                        return None
                     steps.append(SingleStep(i))
                     dag.retire(i)
                     continue
                 allowed = _grow_tile(dag, low, hcap, geom.max_gates, far=far)
+            elif free_low and prev_tile is not None:
+                # this pass's low qubits: L of those the planned tile shares with the previous pass's (busiest first:
+                # position 0 is a register slot of the load layout), topped up with the old low qubits
+                busy = {}
+                for i in dag.ready:
+                    for t in ops[i].targets:
+                        busy[t] = busy.get(t, 0) + 1
+                cand = sorted((b for b in allowed if b in prev_tile), key=lambda b: (-busy.get(b, 0), b))
+                fill = [b for b in low_list if b not in cand] + sorted(b for b in prev_tile if b not in cand and b not in low)
+                low_list = (cand + fill)[:L]
+                low = set(low_list)
+            if free_low:
+                allowed = set(allowed) - low
         else:                           # the passes ran out of step with the dry runs (round / gate caps)
             allowed = _grow_tile(dag, low, hcap, geom.max_gates, far=far)
 
@@ -369,18 +425,18 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
                 return False    # room is kept for the planned bits; spare room goes first come, first served
             if geom.max_far is not None and sum(1 for b in high | need if b >= geom.far_bit) > geom.max_far:
                 return False    # too many far-apart address streams per tile (DRAM row conflicts)
-            return len(high) + len(need) <= hcap and len(high | need) <= min(hcap, n - geom.min_low)
+            return len(high) + len(need) <= hcap and len(high | need) <= min(hcap, n - L)
 
         def round_accepts(cur: _Round, tset: set[int], first: bool) -> bool:
             new = set(cur.slots) | tset
             if len(new) > geom.slots:
                 return False
             if first and cur.ops:
-                # keep the first round loadable straight from HBM: only bit 0 (c64) and gathered bits
+                # keep the first round loadable straight from HBM: only index bit 0 (c64) and gathered bits
                 # may be slots, and at most R - vb gathered ones
-                if any(geom.vb <= b < geom.min_low for b in new):
+                if any(b in low_list[geom.vb:] for b in new):
                     return False
-                if sum(1 for b in new if b >= geom.min_low) > geom.slots - geom.vb:
+                if sum(1 for b in new if b not in low) > geom.slots - geom.vb:
                     return False
             return True
 
@@ -446,26 +502,40 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
 
         if count == 0:
             # nothing fusable is ready: run the lowest-index ready gate on its own
+            if free_low:
+                return None
             i = dag.ready[0]
             steps.append(SingleStep(i))
             dag.retire(i)
             continue
+        if free_low and dag.done >= dag.n_ops:
+            # the last pass restores the canonical order: the qubits that belong on index bits 0 .. L-1 must be in its tile
+            missing = set(range(L)) - low - high
+            if len(high) + len(missing) > hcap:
+                return None
+            high |= missing
         small = geom.fallback
         if small is not None and n >= small.m and len(high) <= small.m - small.min_low and small.min_low == geom.min_low:
-            steps.append((small, high, rounds))
+            steps.append((small, list(low_list), high, rounds))
         else:
-            steps.append((geom, high, rounds))
+            steps.append((geom, list(low_list), high, rounds))
+        prev_tile = low | high
     return _place_writes(ops, n, steps, geom.permute_store, final_perm)
 
 
+class _Infeasible(Exception):
+    """A schedule with free low bits asks a pass to write qubits to the contiguous low bits that are not in its tile."""
+
+
 def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
-                  final_perm: Sequence[int] | None = None) -> 'Steps':
+                  final_perm: Sequence[int] | None = None) -> 'Steps | None':
     """Finalise the passes.  With ``permute`` a pass writes the qubits the NEXT pass gathers to the cheapest index
     bits (right above the contiguous run) and everybody else above them, in their current order -- gathered reads
     from far-apart addresses are what a pass pays for, scattered writes are nearly free (mb_scatter) --
-    so from the second pass on every tile is read as one contiguous block.  ``phys`` maps a qubit's index bit
-    (logical) to where it currently lives; the last pass, and any pass followed by a gate that runs on its own,
-    writes the canonical order back."""
+    so from the second pass on every tile is read as one contiguous block; and it writes the qubits the next pass
+    wants on its contiguous LOW bits there (``low_list`` of the next pass: they must be in this pass's tile).  ``phys``
+    maps a qubit's index bit (logical) to where it currently lives; the last pass, and any pass followed by a gate
+    that runs on its own, writes the canonical order back."""
     phys = list(range(n))
     out = Steps()
     final = list(range(n))
@@ -478,7 +548,9 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
             assert phys == list(range(n))
             out.append(item)
             continue
-        geom, high, rounds = item
+        geom, low_list, high, rounds = item
+        L = geom.min_low
+        assert all(phys[b] == i for i, b in enumerate(low_list)), 'the low qubits of a pass are not where it expects them'
         if phys == list(range(n)):
             tops, thigh, trounds = ops, high, rounds
         else:                               # the pass sees physical bits
@@ -492,17 +564,15 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
                                       ops[oi].pos)
                 trounds.append(_Round(slots=[phys[b] for b in rd.slots], ops=list(rd.ops)))
             thigh = {phys[b] for b in high}
-        step = _finalize(tops, n, geom, thigh, trounds)
-        desc, L, h = step.desc, geom.min_low, geom.m - geom.min_low
         nxt = pending[k + 1] if permute and k + 1 < len(pending) and not isinstance(pending[k + 1], SingleStep) else None
         if nxt is None:
             wphys = final if k == len(pending) - 1 else list(range(n))
         else:
-            ngeom, nhigh, _ = nxt
+            ngeom, nlow, nhigh, _ = nxt
             near = list(range(ngeom.min_low, ngeom.min_low + len(nhigh)))
             wphys = [None] * n
-            for b in range(L):
-                wphys[b] = b
+            for i, b in enumerate(nlow):
+                wphys[b] = i
             keep = [b for b in nhigh if phys[b] in near]             # already cheap: stay
             for b in keep:
                 wphys[b] = phys[b]
@@ -510,21 +580,14 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
             for b in sorted(nhigh - set(keep), key=lambda b: phys[b]):
                 wphys[b] = free.pop(0)
             taken = {w for w in wphys if w is not None}
-            rest = [p_ for p_ in range(L, n) if p_ not in taken]
-            for b in sorted((b for b in range(L, n) if wphys[b] is None), key=lambda b: phys[b]):
+            rest = [p_ for p_ in range(n) if p_ not in taken]
+            for b in sorted((b for b in range(n) if wphys[b] is None), key=lambda b: phys[b]):
                 wphys[b] = rest.pop(0)
         inv = {phys[b]: b for b in range(n)}                          # physical (read side) -> logical
-        tile_pos = [desc.high_sorted[i] for i in range(h)]            # read position of tile bit L + i
-        for i, pos in enumerate(tile_pos):
-            desc.store_high_pos[i] = wphys[inv[pos]]
-        tileset = set(tile_pos)
-        blk = [p_ for p_ in range(L, n) if p_ not in tileset]         # read position of block-index bit j
-        assert len(blk) <= _lib.FUSED_MAX_BLK
-        for j, pos in enumerate(blk):
-            desc.store_blk_pos[j] = wphys[inv[pos]]
-        for s_ in range(geom.slots):
-            tl = desc.store_rb[s_]
-            desc.store_slot_off[s_] = 1 << (tl if tl < L else desc.store_high_pos[tl - L])
+        try:
+            step = _finalize(tops, n, geom, thigh, trounds, [wphys[inv[p_]] for p_ in range(n)])
+        except _Infeasible:
+            return None
         step.permutes = wphys != phys
         phys = wphys
         out.append(step)
@@ -532,7 +595,9 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
     return out
 
 
-def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rounds: list[_Round]) -> FusedStep:
+def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rounds: list[_Round],
+              wpos: Sequence[int] | None = None) -> FusedStep:
+    """``wpos[p]`` = index bit the pass WRITES what it reads at index bit p to (None: where it was)."""
     m, R, vb = geom.m, geom.slots, geom.vb
     rounds = [r for r in rounds if r.ops]
     L = geom.min_low
@@ -670,15 +735,49 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
 
     default_io = io_layout([])
     load_rb = list(layouts[0][0]) if is_io(layouts[0]) and not swaps_of[0] else default_io
-    store_rb = list(layouts[-1][0]) if is_io(layouts[-1]) else default_io
-    def goff(tl: int) -> int:                      # tile-local bit -> offset inside the state
-        return 1 << (tl if tl < L else order[tl - L])
 
+    def read_pos(tl: int) -> int:                  # tile-local bit -> index bit on the read side
+        return tl if tl < L else order[tl - L]
+
+    if wpos is None:
+        wpos = list(range(n))
+    wtile = [wpos[read_pos(tl)] for tl in range(m)]            # tile-local bit -> index bit on the write side
+    to_low = sorted((tl for tl in range(m) if wtile[tl] < L), key=lambda tl: wtile[tl])
+    if len(to_low) != L:
+        raise _Infeasible           # a qubit wanted on the contiguous low bits is not in this tile
+    if to_low == list(range(L)):
+        # the low bits stay: the store layout is an I/O layout like the load's (the last round's if it is one)
+        store_rb = list(layouts[-1][0]) if is_io(layouts[-1]) else default_io
+        store_tb = ascending_tb(store_rb)
+    else:
+        # the low bits are re-labelled on the way out: slot 0 = the tile bit written to index bit 0 (complex64: a lane
+        # stores two adjacent amplitudes), the tile bits written to index bits vb .. L-1 on the lowest lane bits (128
+        # contiguous bytes per 8 lanes), the other thread bits in the order of their write positions
+        store_rb = to_low[:vb]
+        for c in list(layouts[-1][0]) + list(range(m - 1, -1, -1)):
+            if len(store_rb) >= R:
+                break
+            if c not in store_rb and c not in to_low:
+                store_rb.append(c)
+        store_rb = store_rb[:vb] + sorted(store_rb[vb:])
+        store_tb = to_low[vb:] + sorted((tl for tl in range(m) if tl not in store_rb and tl not in to_low),
+                                        key=lambda tl: wtile[tl])
     for s in range(R):
         desc.load_rb[s] = load_rb[s]
         desc.store_rb[s] = store_rb[s]
-        desc.load_slot_off[s] = goff(load_rb[s])
-        desc.store_slot_off[s] = goff(store_rb[s])
+        desc.load_slot_off[s] = 1 << read_pos(load_rb[s])
+        desc.store_slot_off[s] = 1 << wtile[store_rb[s]]
+    for i, t in enumerate(store_tb):
+        desc.store_tb[i] = t
+    for i in range(L):
+        desc.store_low_pos[i] = wtile[i]
+    for i in range(h):
+        desc.store_high_pos[i] = wtile[L + i]
+    tileset = set(order)
+    blk = [p_ for p_ in range(L, n) if p_ not in tileset]         # read position of block-index bit j
+    assert len(blk) <= _lib.FUSED_MAX_BLK
+    for j, pos in enumerate(blk):
+        desc.store_blk_pos[j] = wpos[pos]
 
     esz_log = 3 if vb == 1 else 4           # complex64: 8-byte amplitudes; complex128: 16
 
@@ -732,7 +831,7 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         assert all_fast or not swaps_of[ri], 'an exchange round must consist of straight-line handlers'
         r.gate_begin = first | (_lib.ROUND_ALL_FAST if all_fast and (geom.asm_loop or swaps_of[ri]) else 0)
         r.gate_end = gi
-    if cur != (tuple(store_rb), tuple(ascending_tb(store_rb))):
+    if cur != (tuple(store_rb), tuple(store_tb)):
         ntrans += 1
         desc.rounds[len(rounds) - 1].flags |= _lib.ROUND_TRANSPOSE_AFTER
     desc.nrounds = len(rounds)

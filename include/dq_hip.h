@@ -43,7 +43,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 16
+#define DQ_ABI_VERSION 17
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -78,6 +78,7 @@ int dq_set_dense_path(int mfma);
  *    The host scheduler (deepquantum_amd/fusion.py) builds these descriptors.
  * ------------------------------------------------------------------------------------------ */
 #define DQ_FUSED_MAX_HIGH 12
+#define DQ_FUSED_MAX_LOW 8      /* contiguous low tile bits: L <= 8 */
 #define DQ_FUSED_MAX_ROUNDS 24
 #define DQ_FUSED_MAX_GATES 80
 #define DQ_FUSED_MAX_SLOTS 4
@@ -209,6 +210,16 @@ typedef struct {
      * store_slot_off is in write positions. */
     uint8_t store_high_pos[DQ_FUSED_MAX_HIGH];
     uint8_t store_blk_pos[DQ_FUSED_MAX_BLK];
+    /* The low tile bits move too: tile bit i < L is written to global bit store_low_pos[i] (identity for an in-place
+     * pass), so that the NEXT pass may find other qubits on its contiguous low bits -- every pass then chooses all m
+     * tile qubits freely instead of sharing L fixed ones with every other pass, provided the qubits it wants on its low
+     * bits were in the tile of the pass before (which must write them as contiguous runs).  store_low_pos,
+     * store_high_pos and store_blk_pos together are a permutation of [0, n).  The store layout is explicit for the
+     * same reason: register slots store_rb (any tile bits; complex64: the tile bit of slot 0 must be written to
+     * global bit 0, a lane stores two adjacent amplitudes) and thread bits store_tb (the other tile bits; the host
+     * puts the tile bits written to global bits 1 .. L-1 on the lowest lane bits: 128 contiguous bytes per 8 lanes). */
+    uint8_t store_low_pos[DQ_FUSED_MAX_LOW];
+    uint8_t store_tb[DQ_FUSED_MAX_TBITS];
 } DqFusedPass;
 
 /* Tile geometries this build was compiled with (m = slots + log2(threads)); variant 0 is the

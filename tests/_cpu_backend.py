@@ -55,18 +55,25 @@ class CpuTestBackend:
         high_sorted = [desc.high_sorted[i] for i in range(h)]
         assert sorted(high_pos) == high_sorted and all(L <= p < n for p in high_pos)
         assert len(set(high_pos)) == h
-        for rbio in (desc.load_rb, desc.store_rb):
-            sl = [rbio[s] for s in range(R)]
-            assert sl == sorted(set(sl)), 'I/O slots must be ascending and distinct'
-            assert all((q == s) if s < vb else (L <= q < m) for s, q in enumerate(sl)), 'I/O layout not coalesced'
+        sl = [desc.load_rb[s] for s in range(R)]
+        assert sl == sorted(set(sl)), 'load slots must be ascending and distinct'
+        assert all((q == s) if s < vb else (L <= q < m) for s, q in enumerate(sl)), 'load layout not coalesced'
+        # the store layout is explicit (include/dq_hip.h): any slots, the other tile bits as thread bits
+        store_sl = [desc.store_rb[s] for s in range(R)]
+        store_tb = [desc.store_tb[i] for i in range(logt)]
+        assert sorted(store_sl + store_tb) == list(range(m)), 'store layout does not cover the tile'
 
+        store_low = [desc.store_low_pos[i] for i in range(L)]
         store_high = [desc.store_high_pos[i] for i in range(h)]
         store_blk = [desc.store_blk_pos[j] for j in range(n - m)]
-        assert sorted(store_high + store_blk) == list(range(L, n)), 'write positions are not a permutation of [L, n)'
-        for rbio, offs, pos in ((desc.load_rb, desc.load_slot_off, high_pos), (desc.store_rb, desc.store_slot_off, store_high)):
-            for sl in range(R):
-                tl = rbio[sl]
-                assert offs[sl] == 1 << (tl if tl < L else pos[tl - L]), 'slot offset table wrong'
+        assert sorted(store_low + store_high + store_blk) == list(range(n)), 'write positions are not a permutation of [0, n)'
+        wpos = store_low + store_high                     # tile bit -> global bit on the write side
+        if vb:
+            assert wpos[store_sl[0]] == 0, 'complex64: store slot 0 must be written to bit 0 (two adjacent amplitudes per lane)'
+        for sl_ in range(R):
+            tl = desc.load_rb[sl_]
+            assert desc.load_slot_off[sl_] == 1 << (tl if tl < L else high_pos[tl - L]), 'slot offset table wrong'
+            assert desc.store_slot_off[sl_] == 1 << wpos[store_sl[sl_]], 'slot offset table wrong'
         def want_table(slots_l):
             out = []       # the kernel's lds_swz (csrc/dq_fused.hip), restated
             for j in range(1 << R):
@@ -94,9 +101,9 @@ class CpuTestBackend:
         idx = tiles[:, None] | glob[None, :]            # (ntiles, 2^m) global amplitude indices
         assert np.array_equal(np.sort(idx.reshape(-1)), np.arange(1 << n)), 'tiles do not partition the state'
         # write side: tile bit L + i -> store_high_pos[i], block-index bit j -> store_blk_pos[j]
-        globw = e & ((1 << L) - 1)
-        for i in range(h):
-            globw |= ((e >> (L + i)) & 1) << store_high[i]
+        globw = np.zeros_like(e)
+        for i in range(m):
+            globw |= ((e >> i) & 1) << wpos[i]
         blk = np.arange(1 << (n - m), dtype=np.int64)
         tilesw = np.zeros_like(blk)
         for j in range(n - m):
@@ -150,9 +157,7 @@ class CpuTestBackend:
                 else:
                     assert bool(rd.flags & _lib.ROUND_TRANSPOSE) == ((rb, tb) != lay), 'transposition flag wrong'
                 lay = (rb, tb)
-                store = [desc.store_rb[s] for s in range(R)]
-                store_tb = [q for q in range(m) if q not in store]
-                after = r == desc.nrounds - 1 and lay != (store, store_tb)
+                after = r == desc.nrounds - 1 and lay != (store_sl, store_tb)
                 assert bool(rd.flags & _lib.ROUND_TRANSPOSE_AFTER) == after, 'final transposition flag wrong'
                 assert sorted(rb + tb) == list(range(m)), 'slots + thread bits must cover the tile exactly'
                 slotmask = sum(1 << q for q in rb)

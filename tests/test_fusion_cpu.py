@@ -105,8 +105,8 @@ def test_descriptor_struct_sizes_match_header():
 
     assert ctypes.sizeof(_lib.DqFusedGate) == 32
     assert ctypes.sizeof(_lib.DqFusedRound) == 16
-    assert ctypes.sizeof(_lib.DqFusedPass) == 36 + 24 * 16 + 4 + 80 * 32 + 64 + 26 * 32 + 12 + 24 + 4   # (+ 4 pad to 8)
-    assert ctypes.sizeof(_lib.DqFusedPass) + 48 <= 4096      # the descriptor travels in the kernel-argument segment
+    assert ctypes.sizeof(_lib.DqFusedPass) == 36 + 24 * 16 + 4 + 80 * 32 + 64 + 26 * 32 + 12 + 24 + 8 + 9 + 3   # (+ 3 pad to 8)
+    assert ctypes.sizeof(_lib.DqFusedPass) + 48 + 16 <= 4096      # the descriptor travels in the kernel-argument segment
 
 
 def test_x_type_gates_commute_in_the_dag():
@@ -235,6 +235,7 @@ def test_permuted_stores_make_every_later_tile_contiguous(cpu_backend):
     geom = fusion.default_geometry(False)
     geom.permute_store = True
     geom.fallback.permute_store = True
+    geom.free_low = geom.fallback.free_low = False      # (the low bits stay put here; the test below moves them too)
     steps = fusion.schedule(ops, n, geom)
     fused = [s for s in steps if isinstance(s, fusion.FusedStep)]
     assert len(fused) >= 3 and any(s.permutes for s in fused)
@@ -301,3 +302,90 @@ def test_reduction_records_of_the_reverse_sweep(cpu_backend, n, m):
     from _helpers import check_grad_records
 
     check_grad_records(n, m, torch.device('cpu'))
+
+
+def free_low_schedule(ops, n, is128, m, width=4):
+    geom = fusion.default_geometry(is128, m)
+    geom.permute_store = geom.free_low = True
+    if geom.fallback is not None:
+        geom.fallback.permute_store = geom.fallback.free_low = True
+    return fusion._schedule(ops, n, geom, width, None, free_low=True)
+
+
+@pytest.mark.parametrize('n,seed,m,is128', [(18, 5, None, False), (17, 1, None, False), (16, 2, 12, False),
+                                            (15, 3, None, True), (16, 4, 11, True)])
+def test_stores_that_relabel_the_low_bits(cpu_backend, n, seed, m, is128):
+    """Schedules in which every pass picks ALL its tile qubits (fusion._schedule(free_low=True)): a pass writes the
+    qubits its successor wants on the contiguous low bits there (store_low_pos), which needs them in its own tile;
+    the write positions of a pass are a permutation of [0, n), complex64 passes write the tile bit of store slot 0 to
+    index bit 0, the passes compose to the canonical order, and the state equals the reference's."""
+    dtype = torch.complex128 if is128 else torch.complex64
+    ops, mats = random_ops(n, 300, seed, kinds=('gen', 'x', 'diag'))
+    mats = mats.to(dtype)
+    steps = free_low_schedule(ops, n, is128, m)
+    assert steps is not None and all(isinstance(s, fusion.FusedStep) for s in steps)
+    moved = 0
+    where = list(range(n))                      # where[p] = which canonical bit currently lives at physical bit p
+    for k, st in enumerate(steps):
+        d, L, h = st.desc, st.desc.L, st.desc.h
+        read = list(range(L)) + [d.high_sorted[i] for i in range(h)]
+        if k > 0:
+            assert read == list(range(L + h)), 'tile not contiguous after a permuting pass'
+        blk = [p for p in range(L, n) if p not in read]
+        wr = {p: d.store_low_pos[p] for p in range(L)}
+        wr.update({read[L + i]: d.store_high_pos[i] for i in range(h)})
+        wr.update({p: d.store_blk_pos[j] for j, p in enumerate(blk)})
+        assert sorted(wr.values()) == list(range(n))
+        low_src = sorted(p for p, w in wr.items() if w < L)
+        assert all(p in read for p in low_src), 'a low write position is fed from outside the tile'
+        moved += [wr[p] for p in range(L)] != list(range(L))
+        if not is128:
+            tl = d.store_rb[0]
+            assert wr[read[tl]] == 0
+        new = list(where)
+        for src, dst in wr.items():
+            new[dst] = where[src]
+        where = new
+    assert where == list(range(n)), 'the passes do not compose to the canonical order'
+    assert moved >= 2
+    x = torch.randn(2, 1 << n, dtype=dtype)
+    km = fusion.kernel_matrices(steps, ops, mats)
+    cur = x.clone()
+    for st in steps:
+        nxt = torch.empty_like(cur)
+        backend.apply_fused(cur, km, 0, st.desc, out=nxt)
+        cur = nxt
+    ref = run_reference(x, ops, mats)
+    assert (cur - ref).abs().max().item() < (1e-10 if is128 else 2e-5)
+
+
+def test_free_low_schedules_win_on_deep_layered_circuits():
+    """The benchmark generator at n = 26: picking all tile qubits per pass needs fewer passes than sharing four fixed low
+    qubits, and fusion.schedule takes the better of the two; circuits with a gate that must run on its own, or whose
+    last tile has no room for qubits 0 .. L-1, keep the fixed low bits (None from _schedule)."""
+    import bench
+
+    n = 26
+    ops, off = [], 0
+    for op in bench.random_circuit_spec(n, 40, 1234):
+        if op[0] == 'cnot':
+            ops.append(fusion.PrimOp('x', (n - 1 - op[2],), (n - 1 - op[1],), off, 0))
+        else:
+            ops.append(fusion.PrimOp('gen', (n - 1 - op[1],), (), off, 3 if op[0] == 'h' else 2))
+        off += 4
+    counts = {}
+    for fl in (False, True):
+        geom = fusion.default_geometry(False)
+        geom.permute_store = geom.fallback.permute_store = True
+        geom.free_low = geom.fallback.free_low = fl
+        geom.plan_width, geom.plan_branch, geom.plan_restarts = 4, 3, 1
+        steps = fusion.schedule(ops, n, geom)
+        counts[fl] = len(steps)
+        relabelled = any([s.desc.store_low_pos[i] for i in range(s.desc.L)] != list(range(s.desc.L)) for s in steps)
+        assert relabelled == fl
+    assert counts[True] < counts[False], counts
+    big = ops + [fusion.PrimOp('gen', (5, 9, 13), (), off, 0)]          # a three-qubit gate runs on its own
+    geom = fusion.default_geometry(False)
+    geom.permute_store = geom.fallback.permute_store = True
+    assert fusion._schedule(big, n, geom, 4, None, free_low=True) is None
+    assert any(isinstance(s, fusion.SingleStep) for s in fusion.schedule(big, n, geom))

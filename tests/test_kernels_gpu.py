@@ -216,6 +216,32 @@ def test_fused_pass_with_one_shared_input_state(is128, n, b):
     assert torch.equal(xd.cpu(), x)
 
 
+@pytest.mark.parametrize('n,seed,m,is128', [(18, 5, None, False), (17, 1, None, False), (16, 2, 12, False), (20, 7, None, False),
+                                            (15, 3, None, True), (16, 4, 11, True)])
+def test_stores_that_relabel_the_low_bits_on_gpu(n, seed, m, is128):
+    """Passes that write other qubits to the contiguous low bits than they read there (store_low_pos, the explicit store
+    layout store_rb / store_tb): schedules in which every pass picks all its tile qubits, against the oracle."""
+    from test_fusion_cpu import free_low_schedule
+
+    dtype = torch.complex128 if is128 else torch.complex64
+    ops, mats = random_ops(n, 300, seed, kinds=('gen', 'x', 'diag'))
+    mats = mats.to(dtype)
+    steps = free_low_schedule(ops, n, is128, m)
+    assert steps is not None
+    assert sum([s.desc.store_low_pos[i] for i in range(s.desc.L)] != list(range(s.desc.L)) for s in steps) >= 2
+    x = rand_state(2, n, dtype, 60 + seed)
+    ref = run_reference(x, ops, mats)
+    cur, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
+    with pytest.raises(RuntimeError):
+        backend.apply_fused(cur, md, 0, steps[0].desc, out=cur)        # a re-labelling pass cannot run in place
+    for st in steps:
+        nxt = torch.empty_like(cur)
+        backend.apply_fused(cur, md, 0, st.desc, out=nxt)
+        cur = nxt
+    err = (cur.cpu() - ref).abs().max().item()
+    assert err < TOL[dtype], err
+
+
 @pytest.mark.parametrize('n,m', [(15, 13), (14, 12), (12, 12)])
 def test_reductions_inside_fused_passes_match_numpy(n, m):
     from _helpers import check_grad_records

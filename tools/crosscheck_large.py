@@ -1,7 +1,7 @@
 """Large-size cross-check of every scheduler / kernel optimisation against the plain path: the benchmark generator at
-n = 26..28, several seeds, run (a) with the defaults -- merged one-qubit runs, wide planner, permuted stores, next-tile
+n = 26..28, several seeds, run (a) with the defaults -- merged one-qubit runs, wide planner, permuted stores that also re-label the low bits, next-tile
 prefetch, in-wave exchanges, deferred Hadamard / Rx factors -- and (b) with all of that off (one gate per record,
-first-come tiles, in-place passes, one tile per workgroup, LDS trips only); the two states must agree to complex64
+first-come tiles, in-place passes with fixed low bits, one tile per workgroup, LDS trips only); the two states must agree to complex64
 round-off, and <Z0>, the norm and a checksum of checksums are printed.  usage (GPU box): python tools/crosscheck_large.py"""
 import os
 import sys
@@ -14,7 +14,7 @@ import deepquantum_amd as dq  # noqa: E402
 from deepquantum_amd import _lib  # noqa: E402
 
 dev = torch.device('cuda', 0)
-PLAIN = {'merge_min_amps': None, 'permute_store': False, 'lane_swaps': False, 'plan_width': 0}
+PLAIN = {'merge_min_amps': None, 'permute_store': False, 'lane_swaps': False, 'plan_width': 0, 'free_low': False}
 
 
 def run(n, depth, seed, batch, dtype, plain):

@@ -73,7 +73,7 @@ def main():
                 a, b = layout_cost(nt, ntab, nthreads, False); RW += a; RI += b
                 cur_t, cur_tab = nt, ntab
             if rd.flags & _lib.ROUND_TRANSPOSE_AFTER:
-                nt, ntab = io_tbits(d.store_rb), list(d.lds_tab[_lib.FUSED_MAX_ROUNDS + 1])
+                nt, ntab = [d.store_tb[i] for i in range(m - R)], list(d.lds_tab[_lib.FUSED_MAX_ROUNDS + 1])
                 a, b = layout_cost(cur_t, cur_tab, nthreads, True); W += a; I += b
                 a, b = layout_cost(nt, ntab, nthreads, False); RW += a; RI += b
     print(f'writes: {W} cycles, ideal {I} (x{W / I:.2f}); reads: {RW}, ideal {RI} (x{RW / RI:.2f}); '
