@@ -16,4 +16,5 @@ run tile12_four_workgroups_per_cu --tile-bits 12
 DQ_LDS_PAD_KB=20 run tile12_three_workgroups_per_cu --tile-bits 12
 DQ_LDS_PAD_KB=40 run tile12_two_workgroups_per_cu --tile-bits 12
 run unmerged_gates --no-merge
+run fixed_low_bits --no-free-low
 run in_place_no_permuted_stores --no-permute-store
