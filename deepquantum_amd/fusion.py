@@ -349,11 +349,11 @@ def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True,
         cand = _schedule(ops, n, geom, width, final_perm)
         if cost(cand) < cost(best):
             best = cand
-        if geom.free_low and geom.permute_store and final_perm is None and width > 1:
+        if geom.free_low and geom.permute_store and width > 1:
             # every pass picks ALL its tile qubits (the stores also re-label the contiguous low bits): fewer passes
             # when the circuit does not keep coming back to the same low qubits; None: it could not restore the
             # canonical order with its last pass, or a gate had to run on its own
-            cand = _schedule(ops, n, geom, width, None, free_low=True)
+            cand = _schedule(ops, n, geom, width, final_perm, free_low=True)
             if cand is not None and cost(cand) < cost(best):
                 best = cand
     return best
