@@ -381,6 +381,7 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize(device)
 
+    step()          # setup, not warm-up: pass plans (seconds of host work per circuit structure), second state buffer
     for _ in range(args.warmup):
         step()
     sync()
