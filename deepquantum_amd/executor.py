@@ -117,7 +117,7 @@ def _geometry(is128: bool) -> fusion.Geometry:
         if g.fallback is not None:
             g.fallback.swap_lanes = g.swap_lanes
     if CONFIG['free_low'] is not None:
-        g.free_low = bool(CONFIG['free_low'])
+        g.free_low = CONFIG['free_low'] if CONFIG['free_low'] == 'force' else bool(CONFIG['free_low'])
         if g.fallback is not None:
             g.fallback.free_low = g.free_low
     if CONFIG['asm_loop'] is not None:

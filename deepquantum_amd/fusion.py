@@ -77,7 +77,7 @@ class Geometry:
     swap_lanes: tuple = (0, 1, 2, 3, 4, 5)    # ... with these lane bits
     swap_policy: str = 'chance'  # 'plan': LDS trips park the coming rounds' bits on lane bits; 'chance': trip-only layouts
     permute_store: bool = False   # passes may write to other index bits than they read (out-of-place; _place_writes)
-    free_low: bool = True         # ... including the contiguous low bits: every pass picks ALL its tile qubits (_schedule)
+    free_low: bool | str = True   # ... including the contiguous low bits: every pass picks ALL its tile qubits (_schedule)
     asm_loop: bool = True     # mark rounds whose gates all have handler ids (DQ_ROUND_ALL_FAST); off: A/B measurements
     plan_restarts: int = 3    # beam searches with different random branches (states of >= 2^plan_restart_bits amplitudes)
     plan_restart_bits: int = 26
@@ -343,19 +343,23 @@ def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True,
         return Steps(SingleStep(i) for i in range(len(ops)))
     width = geom.plan_width if n >= geom.plan_min_bits else min(geom.plan_width, 1)
     best = _schedule(ops, n, geom, 0, final_perm)
-    if width and sum(isinstance(s_, FusedStep) for s_ in best) > 1:
-        def cost(steps):
-            return (not steps.applied_final_perm, len(steps), sum(s_.ntranspose for s_ in steps if isinstance(s_, FusedStep)))
+
+    def cost(steps):
+        return (not steps.applied_final_perm, len(steps), sum(s_.ntranspose for s_ in steps if isinstance(s_, FusedStep)))
+
+    several = sum(isinstance(s_, FusedStep) for s_ in best) > 1
+    if width and several:
         cand = _schedule(ops, n, geom, width, final_perm)
         if cost(cand) < cost(best):
             best = cand
-        if geom.free_low and geom.permute_store and width > 1:
-            # every pass picks ALL its tile qubits (the stores also re-label the contiguous low bits): fewer passes
-            # when the circuit does not keep coming back to the same low qubits; None: it could not restore the
-            # canonical order with its last pass, or a gate had to run on its own
-            cand = _schedule(ops, n, geom, width, final_perm, free_low=True)
-            if cand is not None and cost(cand) < cost(best):
-                best = cand
+    force = geom.free_low == 'force'          # (a testing aid: take the candidate below whenever it exists)
+    if geom.free_low and geom.permute_store and several and (width > 1 or force):
+        # every pass picks ALL its tile qubits (the stores also re-label the contiguous low bits): fewer passes
+        # when the circuit does not keep coming back to the same low qubits; None: it could not restore the
+        # canonical order with its last pass, or a gate had to run on its own
+        cand = _schedule(ops, n, geom, max(width, 2), final_perm, free_low=True)
+        if cand is not None and (cost(cand) < cost(best) or force):
+            best = cand
     return best
 
 

@@ -675,7 +675,12 @@ def check_fuzz_against_oracle(dq, device=None, n=13, seeds=(0, 1, 2), depth=6, b
             for cfg in ({'merge_min_amps': None, 'plan_width': 0}, {'merge_min_amps': 0, 'plan_width': 1},
                         {'merge_min_amps': 0, 'plan_width': 4}, {'merge_min_amps': 0, 'asm_loop': False},
                         {'merge_min_amps': 0, 'permute_store': True, 'permute_min_bits': 0},
-                        {'merge_min_amps': None, 'plan_width': 0, 'permute_store': True, 'permute_min_bits': 0}):
+                        {'merge_min_amps': None, 'plan_width': 0, 'permute_store': True, 'permute_min_bits': 0},
+                        {'merge_min_amps': 0, 'permute_store': True, 'permute_min_bits': 0, 'free_low': False},
+                        {'merge_min_amps': 0, 'permute_store': True, 'permute_min_bits': 0, 'free_low': 'force',
+                         'plan_width': 4},
+                        {'merge_min_amps': None, 'permute_store': True, 'permute_min_bits': 0, 'free_low': 'force',
+                         'plan_width': 2, 'lane_swaps': False}):
                 dq.executor.CONFIG.update(keep)
                 dq.executor.CONFIG.update(cfg)
                 dq.executor._PLAN_CACHE.clear()
