@@ -191,7 +191,7 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
     total = a.shape[0]
     x, y = a[rows], b[rows]
     if CONFIG['fold_permute'] or out_perm is None:
-        out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm)
+        out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel())
     else:                                         # A/B: the re-labelling as a pass of its own
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y)
         if out.data_ptr() not in (x.data_ptr(), y.data_ptr()):

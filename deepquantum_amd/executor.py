@@ -207,13 +207,15 @@ def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
 
 
 def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
-        out_perm: Sequence[int] | None = None) -> torch.Tensor:
+        out_perm: Sequence[int] | None = None, amps: int | None = None) -> torch.Tensor:
     """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state.
 
     ``scratch`` (no-grad runs): a second buffer like ``state`` that the passes may ping-pong with (permuted stores
     without an allocation; the sharded state passes its receive buffer) -- the result then lives in ``state`` OR in
     ``scratch``, whichever the last pass wrote.  ``out_perm``: afterwards index bit b sits at position out_perm[b]
-    (the re-labelling a shard exchange needs); the last pass writes it if it can, else one extra permute pass."""
+    (the re-labelling a shard exchange needs); the last pass writes it if it can, else one extra permute pass.
+    ``amps``: amplitudes the plan will be run on in total when ``state`` is only a slice of them (the sample groups of
+    the sharded state): the planner's effort goes by the whole."""
     if len(prims) == 0 and out_perm is None:
         return state
     if state.ndim != 2:
@@ -231,7 +233,7 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
     if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']
             and not ops._is_batched(state)):
         prims = merge_one_qubit_runs(prims)
-    return _run_nograd(state, prims, inplace, scratch, out_perm)
+    return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps)
 
 
 _MERGE_COST = {3: 30, 2: 37, 1: 45, 0: 79}    # issue slots of a wave per one-qubit gate, by matrix structure
@@ -343,7 +345,8 @@ def _permute_after(x: torch.Tensor, out_perm: Sequence[int], scratch: torch.Tens
 
 
 def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
-                out_perm: Sequence[int] | None = None, grads: torch.Tensor | None = None) -> torch.Tensor:
+                out_perm: Sequence[int] | None = None, grads: torch.Tensor | None = None,
+                amps: int | None = None) -> torch.Tensor:
     """``grads``: the accumulator of the 'grad' prims (the reverse sweep of ``_AdjointCircuit``; complex64, n >= a tile)."""
     n = state.shape[-1].bit_length() - 1
     with torch.no_grad():
@@ -372,7 +375,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 # what still has to be allocated: the second buffer, and the private working copy unless the caller's
                 # state is updated in place (never here: `inplace` runs do not permute)
                 permute = 2 * nbytes <= CONFIG['permute_mem_frac'] * total and 2.05 * nbytes <= free
-        plan = make_plan(prims, n, is128, permute, out_perm if permute else None, amps=state.numel())
+        plan = make_plan(prims, n, is128, permute, out_perm if permute else None, amps=max(state.numel(), amps or 0))
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies
         shared_in = None
