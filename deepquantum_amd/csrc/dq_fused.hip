@@ -516,6 +516,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     using Piece = typename std::conditional<VB == 1, float4, V>::type;
     constexpr int NP = VB == 1 ? NA / 2 : NA;
     V a[NA];
+    uint64_t gt_store = 0;
     constexpr unsigned ACC_BYTES0 = (unsigned)sizeof(V) << M;      // the accumulators of the DQ_FG_GRAD records
     if constexpr (GRAD) {
         for (unsigned i = threadIdx.x; i < DQ_FUSED_MAX_GATES * 8u; i += 1u << LOGT)
@@ -904,7 +905,11 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
 
     {
         V* const pout = pout0 + tile_w_of(tile_id);
-        const uint64_t gt = glob_w(tbase);
+        // a thread's offset inside the written tile is the same for every tile of the pass: computed for the first tile
+        // of a workgroup and carried in two VGPRs -- the deposit of m tile bits costs ~50 VALU issue slots per tile,
+        // 0.5 ms of an 18.9-ms pass (A/B).  (Only the prefetching kernels walk several tiles.)
+        if (!PF || tile_no == 0) gt_store = glob_w(tbase);
+        const uint64_t gt = gt_store;
         const __attribute__((address_space(4))) uint64_t* so = (const __attribute__((address_space(4))) uint64_t*)(hw + offsetof(DqFusedPass, store_slot_off) / 4);
         uint64_t gs[R];
 #pragma unroll
