@@ -517,6 +517,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     constexpr int NP = VB == 1 ? NA / 2 : NA;
     V a[NA];
     uint64_t gt_store = 0;
+    unsigned tbase0_keep = 0;
     constexpr unsigned ACC_BYTES0 = (unsigned)sizeof(V) << M;      // the accumulators of the DQ_FG_GRAD records
     if constexpr (GRAD) {
         for (unsigned i = threadIdx.x; i < DQ_FUSED_MAX_GATES * 8u; i += 1u << LOGT)
@@ -617,9 +618,13 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     };
 
     // ---- load layout: slots from the descriptor, thread bits = remaining tile bits ascending ----
-    unsigned tbase0 = tid;  // thread base (tile-local) in the load layout
+    if (!PF || tile_no == 0) {     // (the same for every tile of the workgroup: carried, like the write offset below)
+        unsigned b0 = tid;  // thread base (tile-local) in the load layout
 #pragma unroll
-    for (int s = 0; s < R; ++s) tbase0 = (unsigned)insert_zero(tbase0, (int)((lrb >> (8 * s)) & 0xffu));
+        for (int s = 0; s < R; ++s) b0 = (unsigned)insert_zero(b0, (int)((lrb >> (8 * s)) & 0xffu));
+        tbase0_keep = b0;
+    }
+    const unsigned tbase0 = tbase0_keep;
     unsigned tbase = tbase0;  // current thread base
 
     // per-thread offset of the load layout inside a tile, and what each register slot adds to it
