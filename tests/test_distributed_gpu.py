@@ -171,19 +171,25 @@ def _case_folded_permute(dq, rank, world):
     del dense
     torch.cuda.empty_cache()
     try:
-        for fold, groups in ((True, 4), (False, 2), (True, 1)):
-            D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'] = fold, groups
+        remaps = {}
+        for fold, groups, reorder in ((True, 4, False), (False, 2, False), (True, 1, False), (True, 4, True), (False, 2, True)):
+            D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'], D.CONFIG['reorder'] = fold, groups, reorder
             shard = _build(dq, dq.DistributedQubitCircuit, n, spec)
             with torch.no_grad():
                 st = shard(data)
                 stats = dict(D.LAST_RUN)
                 ev = shard.expectation()
-            assert (st.amps - ref).abs().max().item() < 1e-5, (fold, groups)
+            assert (st.amps - ref).abs().max().item() < 1e-5, (fold, groups, reorder)
             assert (ev - ref_ev).abs().max().item() < 1e-5
             assert stats['remaps'] > 0
-            assert (stats['folded_permutes'] > 0) == fold, stats
+            remaps[reorder] = stats['remaps']
+            if not reorder:         # (in program order this circuit's remaps re-label local qubits)
+                assert (stats['folded_permutes'] > 0) == fold, stats
+            else:
+                assert stats['folded_permutes'] == 0 or fold, stats
+        assert remaps[True] <= remaps[False], remaps     # gates re-ordered along the commutation DAG: no more exchanges
     finally:
-        D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'] = True, 4
+        D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'], D.CONFIG['reorder'] = True, 4, True
 
 
 def _case_measure(dq, rank, world):
