@@ -1,0 +1,27 @@
+"""Randomised soak of the product path on the GPU, beyond what the test-suite runs every time: circuits over the whole
+gate vocabulary under every scheduler configuration against the oracle (tests/_helpers.check_fuzz_against_oracle) and
+fused reverse sweeps against per-gate autograd (check_fused_sweep_random), many seeds.
+usage (GPU box): python tools/soak.py [first_seed] [count]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import deepquantum_amd as dq  # noqa: E402
+from _helpers import check_fused_sweep_random, check_fuzz_against_oracle  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+dev = torch.device('cuda', 0)
+t0 = time.time()
+for k in range(count):
+    seed = first + k
+    n = 13 + seed % 5
+    check_fuzz_against_oracle(dq, device=dev, n=n, seeds=(seed,), depth=5 + seed % 4, batch=1 + seed % 3, double=(seed % 4 == 3))
+    check_fused_sweep_random(dq, device=dev, n=12 + seed % 6, batch=1 + seed % 2, seed=seed, ngates=70 + 10 * (seed % 5))
+    print(f'seed {seed}: n = {n} ok ({time.time() - t0:.0f} s)', flush=True)
+print(f'{count} seeds from {first}: all agree')
