@@ -696,7 +696,7 @@ class DistributedQubitCircuit(QubitCircuit):
         batch = data.shape[0] if (data is not None and data.ndim == 2) else None
         if state is None:
             if self.init_state.batch != batch:
-                old = self.init_state.amps
+                old = self.init_state._buffers['amps']
                 self.init_state = DistributedQubitState(self.nqubit, batch, device=old.device, dtype=old.dtype)
             self.init_state.reset()
         else:
@@ -705,7 +705,7 @@ class DistributedQubitCircuit(QubitCircuit):
             self.encode(data)
         touched = self._precompute_matrices()
         try:
-            self.state = dist_run(self.init_state, self.operators)
+            self.state = dist_run(self.init_state, self.operators, keep_layout=True)   # (``state.amps`` restores the order)
         finally:
             for g in touched:
                 g.__dict__['_precomputed'] = None

@@ -64,6 +64,23 @@ LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_pe
 
 # ---------------------------------------------------------------------------------------------------
 # helpers on one shard
+class _raw:
+    """While one of these is open on a state its ``amps`` is the raw shard in whatever qubit order the last remap left
+    (DistributedQubitState.__getattr__ restores the canonical order for everybody else).  Re-entrant."""
+
+    def __init__(self, *states: DistributedQubitState):
+        self.states = states
+
+    def __enter__(self):
+        for st in self.states:
+            st.__dict__['_raw'] = st.__dict__.get('_raw', 0) + 1
+
+    def __exit__(self, *exc):
+        for st in self.states:
+            st.__dict__['_raw'] -= 1
+        return False
+
+
 def _view(state: DistributedQubitState) -> torch.Tensor:
     """(batch, 2^L) view of the shard(s)."""
     return state.amps.view(-1, state.num_amps_per_node)
@@ -591,6 +608,11 @@ def canonicalize(state: DistributedQubitState) -> DistributedQubitState:
     """Restore phys[q] == q: at most two all-to-all steps for the rank bits, then one local re-labelling."""
     if _is_canonical(state):
         return state
+    with _raw(state):
+        return _canonicalize(state)
+
+
+def _canonicalize(state: DistributedQubitState) -> DistributedQubitState:
     n, L = state.nqubit, state.log_num_amps_per_node
     ph = _phys(state)
     for _ in range(4):
@@ -623,6 +645,11 @@ def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: 
                      keep_layout: bool = False) -> DistributedQubitState:
     """Apply kernel primitives (logical bit positions) to the sharded state, fusing local stretches.
     Unless ``keep_layout`` is set the canonical qubit order is restored before returning."""
+    with _raw(state):
+        return _dist_apply_prims(state, prims, mode, keep_layout)
+
+
+def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None, keep_layout: bool) -> DistributedQubitState:
     for k in LAST_RUN:
         LAST_RUN[k] = 0
     mode = mode or CONFIG['mode']
@@ -664,13 +691,14 @@ def dist_gate(state: DistributedQubitState, gate) -> DistributedQubitState:
         return dist_apply_prims(state, gate.prims(decompose=True))
 
 
-def dist_run(state: DistributedQubitState, operators) -> DistributedQubitState:
-    """Whole circuit on the sharded state (reference: circuit.py:1655-1675)."""
+def dist_run(state: DistributedQubitState, operators, keep_layout: bool = False) -> DistributedQubitState:
+    """Whole circuit on the sharded state (reference: circuit.py:1655-1675).  ``keep_layout``: the qubits stay where
+    the last remap put them; ``state.amps`` restores the reference's order when somebody reads it."""
     prims: list[Prim] = []
     for op in operators:
         prims.extend(op.prims(decompose=True))
     with torch.no_grad():
-        return dist_apply_prims(state, prims)
+        return dist_apply_prims(state, prims, keep_layout=keep_layout)
 
 
 def dist_swap_gate(state: DistributedQubitState, qb1: int, qb2: int) -> DistributedQubitState:
@@ -695,14 +723,23 @@ def expect_pauli_dist(state: DistributedQubitState, observable) -> torch.Tensor:
     Works on batched shards; returns a 0-dim tensor (or (B,) for batched shards)."""
     L = state.log_num_amps_per_node
     xmask, zmask = observable.pauli_masks()
-    if xmask >> L == 0:
-        sign = -1.0 if bin((zmask >> L) & state.rank).count('1') & 1 else 1.0
-        val = backend.expect_pauli(_view(state), xmask, zmask & ((1 << L) - 1)) * sign     # (B,) float64
-        if state.world_size > 1:
-            dist.all_reduce(val, dist.ReduceOp.SUM)
-        val = val.to(state.amps.real.dtype)
+    ph = _phys(state)            # the masks are in logical qubits; the shard may be in another order (keep_layout)
+
+    def placed(mask: int) -> int:
+        return sum(1 << ph[q] for q in range(state.nqubit) if (mask >> q) & 1)
+
+    px, pz = placed(xmask), placed(zmask)
+    if px >> L == 0:
+        with _raw(state):
+            sign = -1.0 if bin((pz >> L) & state.rank).count('1') & 1 else 1.0
+            val = backend.expect_pauli(_view(state), px, pz & ((1 << L) - 1)) * sign     # (B,) float64
+            if state.world_size > 1:
+                dist.all_reduce(val, dist.ReduceOp.SUM)
+            val = val.to(state.amps.real.dtype)
         return val[0] if state.batch is None else val
     from copy import deepcopy
+
+    canonicalize(state)
 
     lam = deepcopy(state)
     dist_apply_prims(lam, observable.prims())

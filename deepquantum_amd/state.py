@@ -99,13 +99,27 @@ class DistributedQubitState(_ComplexBuffers):
         if (batch or 1) * self.num_amps_per_node <= self.LAZY_AMPS or device is not None:
             self.reset()
 
+    def __getattr__(self, name: str):
+        # ``amps`` read from outside the sharded kernels is always in the reference's layout: a circuit leaves the
+        # qubits wherever its last remap put them (distributed.dist_run(keep_layout=True): the exchange back is only
+        # paid by who looks at the amplitudes -- expectation values of Pauli strings do not), and the canonical order
+        # is restored here, on first access.  The routines of distributed.py work on the raw shard (`_raw`).
+        if name == 'amps':
+            d = self.__dict__
+            ph = d.get('_phys')
+            if ph is not None and not d.get('_raw', 0) and any(p != q for q, p in enumerate(ph)):
+                from .distributed import canonicalize
+
+                canonicalize(self)
+        return super().__getattr__(name)
+
     def reset(self) -> None:
+        self.__dict__.pop('_phys', None)   # canonical qubit order (first: ``amps`` below must not trigger an exchange)
         if tuple(self.amps.shape) != tuple(self._shape):
             self.amps = torch.zeros(self._shape, dtype=self.amps.dtype, device=self.amps.device)
             self.buffer = torch.zeros_like(self.amps)
         else:
             self.amps.zero_()
             self.buffer.zero_()
-        self.__dict__.pop('_phys', None)   # canonical qubit order
         if self.rank == 0:
             self.amps[..., 0] = 1.0

@@ -272,10 +272,15 @@ def _case_folded_permute_w2(dq, rank, world):
     spec = specs.random_spec(n, 6, 321)
     spec = [(m_, [a[0]], {'encode': True}) if m_ == 'rx' else (m_, a, k) for m_, a, k in spec]
     dense = specs.build(dq, n, spec)
+    obs = [(0, 'z'), ([1, n - 1], 'zz'), ([2, 5, n - 2], 'zzz'), ([n - 1, 3], 'xz')]
+    for w, basis in obs:
+        dense.observable(w, basis)
     data = torch.rand(B, dense.ndata, generator=torch.Generator().manual_seed(8)) * 6.28
     with torch.no_grad():
         ref = dense(data).reshape(B, -1)
+        ref_ev = dense.expectation()
     per = 2**n // world
+    lazy = 0
     keep = dq.executor.CONFIG['permute_min_bits']
     dq.executor.CONFIG['permute_min_bits'] = 12
     try:
@@ -285,9 +290,26 @@ def _case_folded_permute_w2(dq, rank, world):
             D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'], D.CONFIG['reorder'] = fold, groups, reorder
             shard = dq.DistributedQubitCircuit(n)
             _apply_spec(shard, spec)
+            for w, basis in obs:
+                shard.observable(w, basis)
             st = shard(data)
+            stats = dict(D.LAST_RUN)
+            # the circuit leaves the qubits where its last remap put them; Z-type expectation values are taken from
+            # the shard as it lies (no exchange), an X factor on a rank bit or a look at the amplitudes restores the
+            # reference's order first
+            moved = not D._is_canonical(st)
+            lazy += moved
+            with torch.no_grad():
+                ev3 = torch.stack([D.expect_pauli_dist(st, ob) for ob in list(shard.observables)[:3]], dim=-1)
+            assert D._is_canonical(st) == (not moved)
+            assert (ev3 - ref_ev[:, :3]).abs().max().item() < 1e-5
+            with torch.no_grad():
+                ev = shard.expectation()
+            assert (ev - ref_ev).abs().max().item() < 1e-5
             err = (st.amps - ref[:, rank * per : (rank + 1) * per]).abs().max().item()
+            assert D._is_canonical(st)
             assert err < 1e-5, f'rank {rank} fold={fold} groups={groups} reorder={reorder}: {err}'
+            D.LAST_RUN.update(stats)
             assert D.LAST_RUN['remaps'] > 0 and D.LAST_RUN['groups'] in (groups, 1)
             remaps[reorder] = D.LAST_RUN['remaps']
             if not reorder:         # (in program order this circuit's remaps need a re-labelling of local qubits)
@@ -297,6 +319,7 @@ def _case_folded_permute_w2(dq, rank, world):
                     assert D.LAST_RUN['folded_permutes'] == 0 and D.LAST_RUN['permute_passes'] > 0, D.LAST_RUN
             assert D.LAST_RUN['wire_bytes'] > 0
         assert remaps[True] < remaps[False], remaps      # gates re-ordered along the commutation DAG: fewer exchanges
+        assert lazy > 0, 'no run ended in a non-canonical qubit order: the lazy restore was not exercised'
     finally:
         dq.executor.CONFIG['permute_min_bits'] = keep
         D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'], D.CONFIG['reorder'] = True, 4, True
