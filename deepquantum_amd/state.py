@@ -119,7 +119,6 @@ class DistributedQubitState(_ComplexBuffers):
             self.amps = torch.zeros(self._shape, dtype=self.amps.dtype, device=self.amps.device)
             self.buffer = torch.zeros_like(self.amps)
         else:
-            self.amps.zero_()
-            self.buffer.zero_()
+            self.amps.zero_()       # (the receive buffer is scratch: every use writes all of what it then reads)
         if self.rank == 0:
             self.amps[..., 0] = 1.0
