@@ -113,6 +113,10 @@ class DistributedQubitState(_ComplexBuffers):
                 canonicalize(self)
         return super().__getattr__(name)
 
+    def state_dict(self, *args, **kwargs):
+        _ = self.amps          # (a saved shard is in the reference's qubit order)
+        return super().state_dict(*args, **kwargs)
+
     def reset(self) -> None:
         self.__dict__.pop('_phys', None)   # canonical qubit order (first: ``amps`` below must not trigger an exchange)
         if tuple(self.amps.shape) != tuple(self._shape):
