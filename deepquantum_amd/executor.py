@@ -239,14 +239,17 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
 _MERGE_COST = {3: 30, 2: 37, 1: 45, 0: 79}    # issue slots of a wave per one-qubit gate, by matrix structure
 
 
-def merge_one_qubit_runs(prims: Sequence[Prim]) -> list[Prim]:
-    """Multiply runs of uncontrolled one-qubit gates on the same qubit into one 2x2 matrix (what qsim / Aer call
-    gate fusion, at its smallest): gates with nothing else on the qubit in between, and -- because functions of X
-    commute -- all Rx-like gates of a stretch in which the qubit only sees X-type actions (CNOT targets, X).  A
-    merge happens only when the product is cheaper for the kernel than its factors (two Hadamards -> one real
-    matrix, two Rx -> one Rx-like matrix, anything into a general matrix; NOT Hadamard + Rx -> general).  The
-    product matrix is always applied, also when it is (numerically almost) the identity.  The matrices of all
-    groups are multiplied level by level in stacked matmuls: a handful of launches whatever the circuit."""
+_MERGE_CACHE: OrderedDict = OrderedDict()
+
+
+def _merge_structure(prims: Sequence[Prim]):
+    """Which gates of ``prims`` multiply into which product (a function of the circuit structure only; cached):
+    (groups [members in order of application, mode of the product], order of the output list)."""
+    key = tuple((p.kind, p.targets, p.controls, p.mode, p.unitary) for p in prims)
+    hit = _MERGE_CACHE.get(key)
+    if hit is not None:
+        _MERGE_CACHE.move_to_end(key)
+        return hit
     groups: list[list] = []            # [members (prim indices, in order of application), mode]
     order: list[tuple[str, int]] = []  # ('g', group) | ('p', prim)
     last: dict[int, int] = {}          # qubit -> open group
@@ -277,33 +280,50 @@ def merge_one_qubit_runs(prims: Sequence[Prim]) -> list[Prim]:
                 nothing[q] = False
             else:
                 last.pop(q, None)
-    if all(len(g[0]) == 1 for g in groups):
+    # the products with most factors first: at every level of the stacked multiplication the groups still growing are
+    # then a PREFIX of the stack (a slice: no index tensor, which would be a host-to-device copy and a stream sync)
+    multi = sorted((gi for gi, g in enumerate(groups) if len(g[0]) > 1), key=lambda gi: -len(groups[gi][0]))
+    levels: list[list[int]] = []       # levels[l] = the l-th factor of every product that has one, in stack order
+    for lv in range(max((len(groups[gi][0]) for gi in multi), default=0)):
+        levels.append([groups[gi][0][lv] for gi in multi if len(groups[gi][0]) > lv])
+    hit = (groups, order, multi, levels)
+    _MERGE_CACHE[key] = hit
+    if len(_MERGE_CACHE) > _PLAN_CACHE_SIZE:
+        _MERGE_CACHE.popitem(last=False)
+    return hit
+
+
+def merge_one_qubit_runs(prims: Sequence[Prim]) -> list[Prim]:
+    """Multiply runs of uncontrolled one-qubit gates on the same qubit into one 2x2 matrix (what qsim / Aer call
+    gate fusion, at its smallest): gates with nothing else on the qubit in between, and -- because functions of X
+    commute -- all Rx-like gates of a stretch in which the qubit only sees X-type actions (CNOT targets, X).  A
+    merge happens only when the product is cheaper for the kernel than its factors (two Hadamards -> one real
+    matrix, two Rx -> one Rx-like matrix, anything into a general matrix; NOT Hadamard + Rx -> general).  The
+    product matrix is always applied, also when it is (numerically almost) the identity.  The matrices of all
+    groups are multiplied level by level in stacked matmuls: ONE stack of all factors, then a matmul and a copy per
+    level -- a handful of launches whatever the circuit, no host-device synchronisation."""
+    groups, order, multi, levels = _merge_structure(prims)
+    if not multi:
         return list(prims)
-    multi = [g for g in groups if len(g[0]) > 1]
-    bm = max(prims[i].matrix.shape[0] if prims[i].matrix.ndim == 3 else 1 for g in multi for i in g[0])
+    members = [i for lv in levels for i in lv]
+    bm = max(prims[i].matrix.shape[0] if prims[i].matrix.ndim == 3 else 1 for i in members)
 
     def mat(i: int) -> torch.Tensor:
         m = prims[i].matrix
         return (m if m.ndim == 3 else m.unsqueeze(0)).expand(bm, 2, 2)
 
-    acc = torch.stack([mat(g[0][0]) for g in multi])                    # (G, bm, 2, 2)
-    live = list(range(len(multi)))
-    level = 1
-    while live:
-        live = [k for k in live if len(multi[k][0]) > level]
-        if not live:
-            break
-        nxt = torch.stack([mat(multi[k][0][level]) for k in live])
-        prod = torch.matmul(nxt, acc[live] if len(live) < len(multi) else acc)   # the later gate multiplies from the left
-        if len(live) < len(multi):
-            acc = acc.index_copy(0, torch.tensor(live, device=acc.device), prod)
-        else:
-            acc = prod
-        level += 1
+    stack = torch.stack([mat(i) for i in members])                      # (all factors, bm, 2, 2), level by level
+    acc = stack[: len(multi)].clone()                                   # (G, bm, 2, 2): the first factors
+    off = len(multi)
+    for lv in levels[1:]:
+        k = len(lv)
+        acc[:k] = torch.matmul(stack[off : off + k], acc[:k])           # the later gate multiplies from the left
+        off += k
+
     def batched(g) -> bool:
         return any(prims[i].matrix.ndim == 3 and prims[i].matrix.shape[0] > 1 for i in g[0])
 
-    merged = {id(g): acc[k] if batched(g) else acc[k, 0] for k, g in enumerate(multi)}
+    merged = {gi: acc[k] if batched(groups[gi]) else acc[k, 0] for k, gi in enumerate(multi)}
     out: list[Prim] = []
     for kind, idx in order:
         if kind == 'p':
@@ -313,7 +333,7 @@ def merge_one_qubit_runs(prims: Sequence[Prim]) -> list[Prim]:
             if len(g[0]) == 1:
                 out.append(prims[g[0][0]])
             else:
-                out.append(Prim('gen', merged[id(g)], prims[g[0][0]].targets, (), g[1]))
+                out.append(Prim('gen', merged[idx], prims[g[0][0]].targets, (), g[1]))
     return out
 
 
