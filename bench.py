@@ -121,6 +121,8 @@ def build_circuit(dq, n, spec, batch, dtype, device, distributed=False, shard=0)
     slice of a batch sharded over ranks this is (its samples get their own angles).  ``batch`` None: 1-D data (the
     reference's un-batched call)."""
     cir = dq.DistributedQubitCircuit(n) if distributed else dq.QubitCircuit(n)
+    if distributed:
+        cir.lazy_layout = True      # the step takes <Z0> from the shards as they lie; nobody looks at amps on one rank only
     angles = []
     for op in spec:
         if op[0] == 'h':

@@ -677,6 +677,12 @@ class DistributedQubitCircuit(QubitCircuit):
 
     def __init__(self, nqubit: int, name: str | None = None, reupload: bool = False, shots: int = 1024) -> None:
         super().__init__(nqubit=nqubit, init_state='zeros', name=name, reupload=reupload, shots=shots)
+        #: extension (off = the reference's behaviour: ``forward`` returns the shards in canonical qubit order).  On: the
+        #: qubits stay where the circuit's last remap put them; expectation values of Pauli strings are taken from the
+        #: shards as they lie, and the canonical order is restored -- one or two collective exchanges -- the first time
+        #: ``state.amps`` is read.  That read must then happen on EVERY rank (a collective hides behind it); code that
+        #: looks at the amplitudes on one rank only must leave this off.
+        self.lazy_layout = False
 
     def set_init_state(self, init_state: Any = 'zeros') -> None:
         if isinstance(init_state, DistributedQubitState):
@@ -705,7 +711,7 @@ class DistributedQubitCircuit(QubitCircuit):
             self.encode(data)
         touched = self._precompute_matrices()
         try:
-            self.state = dist_run(self.init_state, self.operators, keep_layout=True)   # (``state.amps`` restores the order)
+            self.state = dist_run(self.init_state, self.operators, keep_layout=self.lazy_layout)
         finally:
             for g in touched:
                 g.__dict__['_precomputed'] = None

@@ -289,11 +289,13 @@ def _case_folded_permute_w2(dq, rank, world):
                                       (True, 4, True), (False, 2, True)):
             D.CONFIG['fold_permute'], D.CONFIG['overlap_groups'], D.CONFIG['reorder'] = fold, groups, reorder
             shard = dq.DistributedQubitCircuit(n)
+            shard.lazy_layout = reorder          # (off: the reference's behaviour, canonical shards out of forward)
             _apply_spec(shard, spec)
             for w, basis in obs:
                 shard.observable(w, basis)
             st = shard(data)
             stats = dict(D.LAST_RUN)
+            assert shard.lazy_layout or D._is_canonical(st)
             # the circuit leaves the qubits where its last remap put them; Z-type expectation values are taken from
             # the shard as it lies (no exchange), an X factor on a rank bit or a look at the amplitudes restores the
             # reference's order first
