@@ -553,7 +553,6 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
             out.append(item)
             continue
         geom, low_list, high, rounds = item
-        L = geom.min_low
         assert all(phys[b] == i for i, b in enumerate(low_list)), 'the low qubits of a pass are not where it expects them'
         if phys == list(range(n)):
             tops, thigh, trounds = ops, high, rounds
@@ -938,7 +937,6 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         g.q = slots[0]
         g.loc = op.mode if op.kind == 'gen' else 0
         # straight-line handler id (index of the kernel's jump table): see include/dq_hip.h
-        free = reg_c == 0 and thr_c == 0 and out_c == 0
         g.fast = fast_id(g.kind, g.loc, slots[0], reg_c, thr_c, out_c)
     else:
         g.kind = _lib.FG_GEN2
