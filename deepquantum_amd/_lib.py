@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DQHIP_LIBRARY') or os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_SWAP, FG_GRAD = range(7)
@@ -26,7 +26,7 @@ FUSED_MAX_HIGH = 12
 FUSED_MAX_LOW = 8
 FUSED_MAX_ROUNDS = 24
 FUSED_MAX_GATES = 80
-FUSED_MAX_SLOTS = 4
+FUSED_MAX_SLOTS = 6
 FUSED_MAX_TBITS = 9
 FUSED_MAX_BLK = 24
 ROUND_ALL_FAST = 0x80
@@ -84,6 +84,7 @@ class DqFusedPass(C.Structure):
         ('store_blk_pos', C.c_uint8 * FUSED_MAX_BLK),
         ('store_low_pos', C.c_uint8 * FUSED_MAX_LOW),
         ('store_tb', C.c_uint8 * FUSED_MAX_TBITS),
+        ('slots', C.c_uint8),
     ]
 
 
@@ -94,9 +95,11 @@ _ip = C.POINTER(C.c_int)
 _SIGNATURES = {
     'dq_abi_version': (_i, []),
     'dq_last_error': (C.c_char_p, []),
+    'dq_struct_layout': (_i, [_ip, _i]),
     'dq_device_info': (_i, [_ip, C.POINTER(_i64), C.POINTER(_i64)]),
     'dq_fused_geometry': (_i, [_i, _i, _ip, _ip, _ip]),
     'dq_fused_set_tiles_per_wg': (_i, [_i]),
+    'dq_wave_descriptor': (_i, [C.POINTER(DqFusedPass), _i, _vp, _i]),
     'dq_set_dense_path': (_i, [_i]),
     'dq_reduce_ws_bytes': (_i64, [_i64]),
     'dq_apply_gate_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _ip, _i, _ip, _i, _i64, _vp]),

@@ -1,6 +1,7 @@
 // Error plumbing, version and device queries of the C ABI.
 #include "dq_common.hpp"
 #include <string.h>
+#include <stddef.h>
 
 namespace dq {
 
@@ -54,6 +55,16 @@ int validate_bits(int n, const int* targets, int k, const int* controls, int nc)
 }  // namespace dq
 
 extern "C" int dq_abi_version(void) { return DQ_ABI_VERSION; }
+
+extern "C" int dq_struct_layout(int* out, int max) {
+    const int v[] = {(int)sizeof(DqFusedGate), (int)sizeof(DqFusedRound), (int)sizeof(DqFusedPass),
+                     (int)offsetof(DqFusedPass, rounds), (int)offsetof(DqFusedPass, gates), (int)offsetof(DqFusedPass, load_slot_off),
+                     (int)offsetof(DqFusedPass, lds_tab), (int)offsetof(DqFusedPass, store_high_pos), (int)offsetof(DqFusedPass, store_tb),
+                     (int)offsetof(DqFusedPass, slots)};
+    const int n = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; i < n && i < max && out; ++i) out[i] = v[i];
+    return n;
+}
 
 extern "C" const char* dq_last_error(void) { return dq::g_err; }
 

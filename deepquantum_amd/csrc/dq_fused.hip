@@ -23,6 +23,7 @@
 #include <type_traits>
 #include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 
 #ifndef DQ_USE_ASM_BLOCKS
 #define DQ_USE_ASM_BLOCKS 1
@@ -457,6 +458,53 @@ template <int ESZ> __device__ __forceinline__ unsigned lds_swz(unsigned e) {
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
+// Kernel-side copy of a workgroup-tile pass: the layout these kernels decode word by word from the kernel-argument
+// segment.  (The public DqFusedPass has room for the six slots of the wave-tile geometry; these kernels use four.)
+struct KFusedRound {
+    uint8_t rb[4];
+    uint8_t tb[DQ_FUSED_MAX_TBITS];
+    uint8_t flags, gate_begin, gate_end;
+};
+struct KFusedPass {
+    uint8_t m, L, h, nrounds;
+    uint8_t high_pos[DQ_FUSED_MAX_HIGH];
+    uint8_t high_sorted[DQ_FUSED_MAX_HIGH];
+    uint8_t load_rb[4];
+    uint8_t store_rb[4];
+    KFusedRound rounds[DQ_FUSED_MAX_ROUNDS];
+    uint32_t mat_base;
+    DqFusedGate gates[DQ_FUSED_MAX_GATES];
+    uint64_t load_slot_off[4];
+    uint64_t store_slot_off[4];
+    uint16_t lds_tab[DQ_FUSED_MAX_ROUNDS + 2][16];
+    uint8_t store_high_pos[DQ_FUSED_MAX_HIGH];
+    uint8_t store_blk_pos[DQ_FUSED_MAX_BLK];
+    uint8_t store_low_pos[DQ_FUSED_MAX_LOW];
+    uint8_t store_tb[DQ_FUSED_MAX_TBITS];
+};
+static void repack(const DqFusedPass& s, KFusedPass& d) {
+    memset(&d, 0, sizeof(d));
+    d.m = s.m, d.L = s.L, d.h = s.h, d.nrounds = s.nrounds;
+    memcpy(d.high_pos, s.high_pos, sizeof(d.high_pos));
+    memcpy(d.high_sorted, s.high_sorted, sizeof(d.high_sorted));
+    for (int i = 0; i < 4; ++i) {
+        d.load_rb[i] = s.load_rb[i], d.store_rb[i] = s.store_rb[i];
+        d.load_slot_off[i] = s.load_slot_off[i], d.store_slot_off[i] = s.store_slot_off[i];
+    }
+    for (int r = 0; r < DQ_FUSED_MAX_ROUNDS; ++r) {
+        for (int i = 0; i < 4; ++i) d.rounds[r].rb[i] = s.rounds[r].rb[i];
+        memcpy(d.rounds[r].tb, s.rounds[r].tb, sizeof(d.rounds[r].tb));
+        d.rounds[r].flags = s.rounds[r].flags, d.rounds[r].gate_begin = s.rounds[r].gate_begin, d.rounds[r].gate_end = s.rounds[r].gate_end;
+    }
+    d.mat_base = s.mat_base;
+    memcpy(d.gates, s.gates, sizeof(d.gates));
+    memcpy(d.lds_tab, s.lds_tab, sizeof(d.lds_tab));
+    memcpy(d.store_high_pos, s.store_high_pos, sizeof(d.store_high_pos));
+    memcpy(d.store_blk_pos, s.store_blk_pos, sizeof(d.store_blk_pos));
+    memcpy(d.store_low_pos, s.store_low_pos, sizeof(d.store_low_pos));
+    memcpy(d.store_tb, s.store_tb, sizeof(d.store_tb));
+}
+
 // Mirror of the kernel's argument list: where the by-value descriptor sits in the kernarg segment.
 struct FusedKernArgs {
     const void* in;
@@ -466,7 +514,7 @@ struct FusedKernArgs {
     int64_t in_bstride;
     int n;
     int tpw;
-    DqFusedPass p;
+    KFusedPass p;
     double* grads;          // GRAD kernels only: [batch, ngrads, 8], added to
     int64_t grad_bstride;   // = ngrads * 8
 };
@@ -483,7 +531,7 @@ struct FusedKernArgs {
 template <typename T, int R, int LOGT, bool PF, bool GRAD = false>
 __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in, amp<T>* out,
                                                                const amp<T>* __restrict__ mats, int64_t mat_bstride,
-                                                               int64_t in_bstride, int n, int tpw, const DqFusedPass p,
+                                                               int64_t in_bstride, int n, int tpw, const KFusedPass p,
                                                                double* grads, int64_t grad_bstride) {
     constexpr int M = R + LOGT;
     constexpr int NA = 1 << R;
@@ -537,8 +585,8 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     typedef const __attribute__((address_space(4))) uint32_t* KArgWords;
     const KArgWords hw = (KArgWords)(karg + offsetof(FusedKernArgs, p));
     static_assert(DQ_FAST32_IDS == DQ_FAST_IDS, "tools/gen_fused_asm.py and include/dq_hip.h disagree on the handler ids");
-    static_assert(DQ_FUSED_MAX_HIGH == 12 && offsetof(DqFusedPass, high_pos) == 4 && offsetof(DqFusedPass, high_sorted) == 16 &&
-                      offsetof(DqFusedPass, load_rb) == 28 && offsetof(DqFusedPass, store_rb) == 32,
+    static_assert(DQ_FUSED_MAX_HIGH == 12 && offsetof(KFusedPass, high_pos) == 4 && offsetof(KFusedPass, high_sorted) == 16 &&
+                      offsetof(KFusedPass, load_rb) == 28 && offsetof(KFusedPass, store_rb) == 32,
                   "header word layout");
     const uint32_t hw0 = hw[0], hp0 = hw[1], hp1 = hw[2], hp2 = hw[3], hs0 = hw[4], hs1 = hw[5], hs2 = hw[6], lrb = hw[7],
                    srbw = hw[8];
@@ -572,8 +620,8 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     const V* const pin0 = in + (uint64_t)sample * (uint64_t)in_bstride;
     // write side: block-index bit j goes to global bit store_blk_pos[j], tile bit L + i to store_high_pos[i]
     // (both equal to the read positions for an in-place pass; include/dq_hip.h)
-    constexpr int SHP_W0 = offsetof(DqFusedPass, store_high_pos) / 4, SBP_W0 = offsetof(DqFusedPass, store_blk_pos) / 4;
-    static_assert(offsetof(DqFusedPass, store_high_pos) % 4 == 0 && offsetof(DqFusedPass, store_blk_pos) % 4 == 0, "");
+    constexpr int SHP_W0 = offsetof(KFusedPass, store_high_pos) / 4, SBP_W0 = offsetof(KFusedPass, store_blk_pos) / 4;
+    static_assert(offsetof(KFusedPass, store_high_pos) % 4 == 0 && offsetof(KFusedPass, store_blk_pos) % 4 == 0, "");
     auto tile_w_of = [&](unsigned id) __attribute__((always_inline)) -> uint64_t {
         // position bytes fetched once (six words), the loop unrolled with constant byte positions: no scalar load per
         // bit.  Block-index bits above n - m are zero, so whatever their position bytes hold contributes nothing.
@@ -593,8 +641,8 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         return tw;
     };
     V* const pout0 = out + ((uint64_t)sample << n);
-    constexpr int SLP_W0 = offsetof(DqFusedPass, store_low_pos) / 4, STB_W0 = offsetof(DqFusedPass, store_tb) / 4;
-    static_assert(offsetof(DqFusedPass, store_low_pos) % 4 == 0 && offsetof(DqFusedPass, store_tb) % 4 == 0 &&
+    constexpr int SLP_W0 = offsetof(KFusedPass, store_low_pos) / 4, STB_W0 = offsetof(KFusedPass, store_tb) / 4;
+    static_assert(offsetof(KFusedPass, store_low_pos) % 4 == 0 && offsetof(KFusedPass, store_tb) % 4 == 0 &&
                       DQ_FUSED_MAX_LOW == 8, "");
     auto glob_w = [&](unsigned e) __attribute__((always_inline)) -> uint64_t {
         // tile bit i < L -> store_low_pos[i] (the low bits move like the others: include/dq_hip.h)
@@ -631,7 +679,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     const uint64_t gt_load = glob(tbase0);
     uint64_t gs_load[R];
     {
-        const __attribute__((address_space(4))) uint64_t* so = (const __attribute__((address_space(4))) uint64_t*)(hw + offsetof(DqFusedPass, load_slot_off) / 4);
+        const __attribute__((address_space(4))) uint64_t* so = (const __attribute__((address_space(4))) uint64_t*)(hw + offsetof(KFusedPass, load_slot_off) / 4);
 #pragma unroll
         for (int s = 0; s < R; ++s) gs_load[s] = so[s];
     }
@@ -673,7 +721,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     // LDS staging: a thread's byte address = swizzle(its base) * sizeof(V)  XOR  the host-made table entry of the
     // register-slot pattern (the swizzle is XOR-linear; include/dq_hip.h, lds_tab).  `ctab` = table of the layout
     // the registers are in right now.
-    constexpr int TAB_W0 = offsetof(DqFusedPass, lds_tab) / 4;   // 8 words = 16 entries per table
+    constexpr int TAB_W0 = offsetof(KFusedPass, lds_tab) / 4;   // 8 words = 16 entries per table
     constexpr int TAB_WORDS = (NA + 1) / 2;
     int cur_tab = 0;   // table of the layout the registers are in right now (0 = load layout, 1 + r = round r)
     auto tab_entry = [](const uint32_t (&tab)[TAB_WORDS], int j) __attribute__((always_inline)) -> unsigned {
@@ -715,13 +763,13 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     constexpr bool FAST = FAST32 || FAST64;
     // Gate records are fetched with explicit scalar loads from the kernel-argument segment (the descriptor
     // is passed by value; its address must not be taken through `&p`, that would force a private copy).
-    const uint64_t kgates = karg + offsetof(FusedKernArgs, p) + offsetof(DqFusedPass, gates);
+    const uint64_t kgates = karg + offsetof(FusedKernArgs, p) + offsetof(KFusedPass, gates);
 
     // The descriptor is read as 32-bit words (scalar loads; gfx950 has no sub-dword s_load) and decoded
     // with SALU bit ops, so no vector memory instruction is spent on it.
     const KArgWords pw = hw;
-    constexpr int ROUND_W0 = offsetof(DqFusedPass, rounds) / 4;
-    constexpr int GATE_W0 = offsetof(DqFusedPass, gates) / 4;
+    constexpr int ROUND_W0 = offsetof(KFusedPass, rounds) / 4;
+    constexpr int GATE_W0 = offsetof(KFusedPass, gates) / 4;
     const int nrounds = (int)(pw[0] >> 24);
     const uint64_t mbase_u = (uint64_t)mbase;
     const uint64_t tile_global = tile_of(tile_id);  // global index bits fixed for this tile (outside the tile)
@@ -734,7 +782,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
     tbase = tbase0;
     cur_tab = 0;
     // running byte offset of the current gate's matrix from `mbase` (32 bits: SMEM takes base pair + SGPR offset)
-    uint32_t moff = pw[offsetof(DqFusedPass, mat_base) / 4] * (uint32_t)sizeof(V);
+    uint32_t moff = pw[offsetof(KFusedPass, mat_base) / 4] * (uint32_t)sizeof(V);
     T hscale = T(1);   // product of the deferred Hadamard factors of this pass (uniform)
     float hsr = 1.0f, hsi = 0.0f;   // complex64: the deferred factor is complex (Hadamards and Rx-like gates, dq_hip.h)
     bool had = false;
@@ -915,7 +963,7 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         // 0.5 ms of an 18.9-ms pass (A/B).  (Only the prefetching kernels walk several tiles.)
         if (!PF || tile_no == 0) gt_store = glob_w(tbase);
         const uint64_t gt = gt_store;
-        const __attribute__((address_space(4))) uint64_t* so = (const __attribute__((address_space(4))) uint64_t*)(hw + offsetof(DqFusedPass, store_slot_off) / 4);
+        const __attribute__((address_space(4))) uint64_t* so = (const __attribute__((address_space(4))) uint64_t*)(hw + offsetof(KFusedPass, store_slot_off) / 4);
         uint64_t gs[R];
 #pragma unroll
         for (int s = 0; s < R; ++s) gs[s] = so[s];
@@ -961,10 +1009,10 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
         typedef const __attribute__((address_space(4))) uint32_t* KWords;
         const KWords kw = (KWords)((uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FusedKernArgs, p));
         const int nr = (int)(kw[0] >> 24);
-        const unsigned ngates = kw[offsetof(DqFusedPass, rounds) / 4 + 4 * (nr - 1) + 3] >> 24;
+        const unsigned ngates = kw[offsetof(KFusedPass, rounds) / 4 + 4 * (nr - 1) + 3] >> 24;
         double* const grow = grads + (uint64_t)sample * (uint64_t)grad_bstride;
         for (unsigned i = threadIdx.x; i < ngates * 8u; i += 1u << LOGT) {
-            const KWords gw = kw + offsetof(DqFusedPass, gates) / 4 + 8u * (i >> 3);
+            const KWords gw = kw + offsetof(KFusedPass, gates) / 4 + 8u * (i >> 3);
             if ((gw[0] & 0xffu) == (unsigned)DQ_FG_GRAD) {
                 const float v = *(__attribute__((address_space(3))) float*)(uintptr_t)(ACC_BYTES0 + 4u * i);
                 atomicAdd(grow + (uint64_t)gw[7] * 8u + (i & 7u), (double)v);
@@ -976,10 +1024,11 @@ __global__ __launch_bounds__(1 << LOGT) void fused_pass_kernel(const amp<T>* in,
 struct FusedVariant {
     int m, slots, logt;
 };
-// variant 0 is the default geometry of each precision
-static const FusedVariant kVariantsC64[] = {{12, 4, 8}, {13, 4, 9}};
+// variant 0 is the default geometry of each precision; complex64: the wave tile (csrc/dq_wave.hip), then the two
+// workgroup tiles
+static const FusedVariant kVariantsC64[] = {{12, 6, 6}, {13, 4, 9}, {12, 4, 8}};
 static const FusedVariant kVariantsC128[] = {{11, 3, 8}, {12, 3, 9}};
-static const int kNumVariants = 2;
+static const int kNumVariantsC64 = 3, kNumVariantsC128 = 2;
 
 // ngrads: rows of the caller's accumulator (dq_apply_fused_grad_*), -1 = a plain pass (DQ_FG_GRAD records refused)
 template <typename T>
@@ -1249,9 +1298,11 @@ static void launch_variant(const void* in, void* out, const void* mats, int64_t 
             ++tpw_log;
     }
     dim3 grid((unsigned)(1ull << (n - M - tpw_log)), (unsigned)batch);
+    KFusedPass kp;
+    repack(*pass, kp);
     hipLaunchKernelGGL((fused_pass_kernel<T, R, LOGT, PF, GRAD>), grid, dim3(1u << LOGT), lds_bytes, s,
                        static_cast<const amp<T>*>(in), static_cast<amp<T>*>(out), static_cast<const amp<T>*>(mats),
-                       mat_bstride, in_bstride, n, 1 << tpw_log, *pass, grads, ngrads * 8);
+                       mat_bstride, in_bstride, n, 1 << tpw_log, kp, grads, ngrads * 8);
 }
 
 template <typename T>
@@ -1273,11 +1324,12 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     }
     constexpr bool is128 = sizeof(T) == 8;
     const FusedVariant* vars = is128 ? kVariantsC128 : kVariantsC64;
+    const int want_slots = pass->slots ? pass->slots : (is128 ? 3 : 4);
     int vi = -1;
-    for (int i = 0; i < kNumVariants; ++i)
-        if (vars[i].m == pass->m) vi = i;
+    for (int i = 0; i < (is128 ? kNumVariantsC128 : kNumVariantsC64); ++i)
+        if (vars[i].m == pass->m && vars[i].slots == want_slots) vi = i;
     if (vi < 0) {
-        set_error("dq_apply_fused: no kernel variant with m=%d", pass->m);
+        set_error("dq_apply_fused: no kernel variant with m=%d and %d register slots", pass->m, want_slots);
         return DQ_ERR_UNSUPPORTED;
     }
     const FusedVariant v = vars[vi];
@@ -1304,6 +1356,13 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     }
     hipStream_t s = as_stream(stream);
     if constexpr (!is128) {
+        if (v.slots == 6) {     // one wavefront per tile: csrc/dq_wave.hip
+            if (ngrads >= 0) {
+                set_error("dq_apply_fused_grad_c64: reverse-sweep passes run on the workgroup-tile geometries");
+                return DQ_ERR_UNSUPPORTED;
+            }
+            return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+        }
         if (ngrads >= 0) {      // the reverse sweep: no next-tile prefetch (its registers go to the reductions)
             if (v.m == 12) launch_variant<float, 4, 8, false, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
             else launch_variant<float, 4, 9, false, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
@@ -1330,7 +1389,7 @@ extern "C" int dq_fused_set_tiles_per_wg(int tiles) {
 }
 
 extern "C" int dq_fused_geometry(int is_c128, int variant, int* m, int* slots, int* threads) {
-    if (variant < 0 || variant >= dq::kNumVariants) {
+    if (variant < 0 || variant >= (is_c128 ? dq::kNumVariantsC128 : dq::kNumVariantsC64)) {
         dq::set_error("dq_fused_geometry: variant %d out of range", variant);
         return DQ_ERR_ARG;
     }

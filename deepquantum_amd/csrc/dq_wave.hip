@@ -1,0 +1,363 @@
+// Wave-tile fused pass for gfx950 (complex64): ONE wavefront owns a tile of 2^12 amplitudes -- 64 lanes x 64
+// amplitudes in 128 VGPRs -- so a pass has no workgroup barrier at all: every wave loads its tile (32 x 16 bytes per
+// lane), walks the pass's records (gates on the six register-slot bits, layout changes through a small wave-private LDS
+// buffer), and stores.  Replaces the same run of Gate.forward calls as csrc/dq_fused.hip (circuit.py:261 ->
+// operation.py:274-289 -> qmath.py:485-506 / operation.py:203-219).
+//
+// Why: the workgroup-tile kernel (dq_fused.hip; 512 threads, 64 KiB of LDS, two workgroups per CU) spends a third of a
+// pass waiting -- its eight waves meet at two barriers per layout change and only two such workgroups fit a CU, so VALU
+// (65 % busy) and HBM (78 %) never overlap fully.  With wave-private tiles there is nothing to wait for: measured on
+// the headline state, 96 Hadamard-sized gates + 4 layout changes per tile run at the speed of the bare load / store
+// skeleton (tools/experiments/mb_wavetile.hip: 13.3 vs 13.2 ms per pass; the workgroup-tile kernel: 18.7 ms).
+//
+// Layout changes ("trips").  Registers hold the slot bits, lanes the other six tile bits.  When k slot bits trade
+// places with k lane bits, the tile falls apart into 2^(6-k) sub-tiles (one per value of the slots that stay), each
+// 2^k registers x 64 lanes, which are transposed one after the other through the same 2^k x (64 + pad) x 8-byte buffer:
+// DS operations of one wave execute in order, so neither a barrier nor a wait separates the groups.  All addresses are
+// a per-lane base (a few VALU operations per trip) plus an immediate.  k <= 4 (8.4 KiB per wave, twelve waves per CU);
+// bigger changes take two trips.
+//
+// The host describes a pass by rounds (which tile bits are register slots when); translate() below turns that into the
+// flat record list the kernel walks: it tracks which PHYSICAL slot (register-index bit) holds which tile bit, so the
+// host's slot order never costs a register move, picks the lane order of every layout (bank-conflict-free where it
+// can), and computes the per-trip address contributions.
+#include "dq_common.hpp"
+#include <stddef.h>
+#include <string.h>
+
+namespace dq {
+
+#include "dq_wave_asm.inc"
+
+constexpr int WAVE_M = 12, WAVE_R = 6, WAVE_LANES = 6;
+constexpr int WAVE_MAX_REC = 112;
+constexpr unsigned WAVE_LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
+
+struct WaveRec {
+    uint32_t w[8];
+};
+
+// Kernel-side descriptor (by value in the kernel-argument segment).
+struct WaveKernPass {
+    uint64_t load_off[5];           // bytes that physical slots 1..5 add on the read side
+    uint64_t store_off[5];          // ... on the write side
+    uint32_t load_lane_shift[6];    // lane bit b adds 1 << load_lane_shift[b] bytes to the load address
+    uint32_t store_lane_shift[6];   // ... to the store address
+    uint32_t tb_contrib[6];         // ... and this to the thread's tile-local base in the load layout
+    uint32_t nrec_bytes, mat_base_bytes;
+    uint8_t read_blk_pos[DQ_FUSED_MAX_BLK];    // index bit (read side) of bit j of the tile number; unused entries: any
+    uint8_t store_blk_pos[DQ_FUSED_MAX_BLK];   // ... on the write side
+    WaveRec rec[WAVE_MAX_REC];
+};
+static_assert(offsetof(WaveKernPass, store_off) == 40 && offsetof(WaveKernPass, load_lane_shift) == 80 &&
+                  offsetof(WaveKernPass, tb_contrib) == 128 && offsetof(WaveKernPass, rec) == 208, "descriptor layout");
+
+struct WaveKernArgs {
+    const void* in;
+    void* out;
+    const void* mats;
+    int64_t mat_bstride;
+    int64_t in_bstride;
+    int n;
+    int pad_;
+    WaveKernPass p;
+};
+static_assert(sizeof(WaveKernArgs) <= 4096 && (offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec)) % 32 == 0, "kernel-argument segment");
+
+__global__ __launch_bounds__(256) void wave_pass_kernel(const float2* in, float2* out, const float2* mats, int64_t mat_bstride,
+                                                        int64_t in_bstride, int n, int pad_, const WaveKernPass p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dq_wave_smem[];
+    (void)dq_wave_smem;
+    (void)pad_;
+    const unsigned tid = threadIdx.x;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    unsigned grp = blockIdx.x, sample = blockIdx.y;
+    // all samples read ONE input state (the first pass of a batched circuit): the B workgroups of a tile group become
+    // neighbours in dispatch order on the same XCD, so the tiles come from HBM once and from that XCD's L2 otherwise
+    if (in_bstride == 0 && (gridDim.x & 7u) == 0) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.y;
+        const unsigned group = lin / (8u * nb), r = lin % (8u * nb);
+        sample = r >> 3;
+        grp = group * 8u + (r & 7u);
+    }
+    const uint64_t tile_id = (uint64_t)grp * 4u + wave;
+    if (tile_id >= (1ull << (n - WAVE_M))) return;
+    // where the tile lies: bit j of the tile number goes to index bit read_blk_pos[j] / store_blk_pos[j] (the descriptor
+    // is read as words through the constant address space: scalar loads, constant byte positions)
+    typedef const __attribute__((address_space(4))) uint32_t* KWords;
+    const uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const KWords hw = (KWords)(karg + offsetof(WaveKernArgs, p));
+    uint64_t tg = 0, tw = 0;
+#pragma unroll
+    for (int w = 0; w < DQ_FUSED_MAX_BLK / 4; ++w) {
+        const uint32_t rw = hw[offsetof(WaveKernPass, read_blk_pos) / 4 + w], sw = hw[offsetof(WaveKernPass, store_blk_pos) / 4 + w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t bit = (tile_id >> (4 * w + k)) & 1ull;
+            tg |= bit << ((rw >> (8 * k)) & 0x3fu);
+            tw |= bit << ((sw >> (8 * k)) & 0x3fu);
+        }
+    }
+    const uint64_t inb = (uint64_t)(in + (uint64_t)sample * (uint64_t)in_bstride + tg);
+    const uint64_t outb = (uint64_t)(out + ((uint64_t)sample << n) + tw);
+    const uint64_t mb = (uint64_t)(mats + (int64_t)sample * mat_bstride);
+    wave_tile_body_f32(karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec), p.nrec_bytes, mb, p.mat_base_bytes, tg,
+                       karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, load_off), inb, outb, wave * WAVE_LDS_PER_WAVE, tid);
+}
+
+// ---- host: DqFusedPass (rounds) -> records ------------------------------------------------------------------------
+namespace {
+
+struct Xlate {
+    const DqFusedPass* p;
+    WaveKernPass* k;
+    int phys[WAVE_R];        // tile-local bit held by physical slot s (register-index bit s)
+    int lanes[WAVE_LANES];   // tile-local bit on lane bit b
+    int nrec = 0;
+
+    bool push(const WaveRec& r) {
+        if (nrec >= WAVE_MAX_REC) return false;
+        k->rec[nrec++] = r;
+        return true;
+    }
+    int slot_of(int tile_bit) const {
+        for (int s = 0; s < WAVE_R; ++s)
+            if (phys[s] == tile_bit) return s;
+        return -1;
+    }
+
+    // k slots (mask) <-> the lane bits inc_lanes[0..k) (ascending); `want` = the lane order afterwards (tile bits per
+    // lane bit) or nullptr: chosen here
+    bool trip(unsigned mask, const int* inc_lanes, int kk, const int* want) {
+        const int a = 5 - kk, S = 64 + (1 << a);
+        int moving[WAVE_R], out_bits[WAVE_R], inc_bits[WAVE_R], stay_lanes[WAVE_LANES], stay_bits[WAVE_LANES], fpos[WAVE_LANES];
+        int nm = 0, ns = 0;
+        for (int s = 0; s < WAVE_R; ++s)
+            if ((mask >> s) & 1u) {
+                moving[nm] = s;
+                out_bits[nm] = phys[s];
+                ++nm;
+            }
+        for (int i = 0; i < kk; ++i) inc_bits[i] = lanes[inc_lanes[i]];
+        for (int b = 0; b < WAVE_LANES; ++b) {
+            bool inc = false;
+            for (int i = 0; i < kk; ++i) inc = inc || inc_lanes[i] == b;
+            if (!inc) {
+                stay_lanes[ns] = b;
+                stay_bits[ns] = lanes[b];
+                ++ns;
+            }
+        }
+        // slot (8-byte units) of element (x, y, z) = x * S + (y << a) + F(z): the lane bits that stay fill the positions
+        // below the field [a, a + k) in their old order, the highest of them position 5 (so the 32 lanes of a read
+        // group and the 16 of a write group differ in the low positions only: no bank conflicts where that is possible)
+        if (kk == 0) {
+            for (int t = 0; t < ns; ++t) fpos[t] = t;
+        } else {
+            for (int t = 0; t < ns; ++t) fpos[t] = t < a ? t : 5;
+        }
+        uint32_t cw[WAVE_LANES] = {0}, cr[WAVE_LANES] = {0}, tbc[WAVE_LANES] = {0};
+        for (int i = 0; i < kk; ++i) cw[inc_lanes[i]] = 8u << (a + i);
+        for (int t = 0; t < ns; ++t) cw[stay_lanes[t]] = 8u << fpos[t];
+        int nl[WAVE_LANES];
+        if (want) {
+            for (int b = 0; b < WAVE_LANES; ++b) nl[b] = want[b];
+        } else if (kk == 0) {
+            for (int b = 0; b < WAVE_LANES; ++b) nl[b] = lanes[b];
+        } else {
+            for (int b = 0; b < WAVE_LANES; ++b) nl[b] = b < a ? stay_bits[b] : (b < 5 ? out_bits[b - a] : stay_bits[a]);
+        }
+        for (int b = 0; b < WAVE_LANES; ++b) {
+            bool found = false;
+            for (int i = 0; i < kk && !found; ++i)
+                if (nl[b] == out_bits[i]) {
+                    cr[b] = (8u * (unsigned)S) << i;
+                    found = true;
+                }
+            for (int t = 0; t < ns && !found; ++t)
+                if (nl[b] == stay_bits[t]) {
+                    cr[b] = 8u << fpos[t];
+                    found = true;
+                }
+            if (!found) return false;      // `want` is not made of the bits that are on the lanes afterwards
+            tbc[b] = 1u << nl[b];
+        }
+        WaveRec ra{}, rb{};
+        ra.w[0] = kk == 0 ? (uint32_t)DQ_WID_TRIP0 : (uint32_t)kWaveTripId[mask];
+        ra.w[1] = tbc[0], ra.w[2] = tbc[1], ra.w[3] = tbc[2], ra.w[5] = tbc[3], ra.w[6] = tbc[4], ra.w[7] = tbc[5];
+        for (int b = 0; b < WAVE_LANES; ++b) rb.w[b] = cw[b] | (cr[b] << 16);
+        for (int i = 0; i < kk; ++i) phys[moving[i]] = inc_bits[i];
+        for (int b = 0; b < WAVE_LANES; ++b) lanes[b] = nl[b];
+        return push(ra) && push(rb);
+    }
+
+    // make `slotset` (bit mask over tile-local bits) the register slots; `want` as above (for the last trip)
+    bool go(unsigned slotset, const int* want) {
+        for (;;) {
+            unsigned mask = 0;
+            int inc[WAVE_LANES], ninc = 0, nout = 0;
+            for (int s = 0; s < WAVE_R; ++s)
+                if (!((slotset >> phys[s]) & 1u)) {
+                    mask |= 1u << s;
+                    ++nout;
+                }
+            for (int b = 0; b < WAVE_LANES; ++b)
+                if ((slotset >> lanes[b]) & 1u) inc[ninc++] = b;
+            if (nout != ninc) return false;
+            if (nout == 0) return true;
+            int kk = nout;
+            if (kk > DQ_WAVE_MAXK) kk = (nout + 1) / 2;      // 5 -> 3 + 2, 6 -> 3 + 3
+            if (kk < nout) {                                  // keep the first kk outgoing slots / incoming lanes
+                unsigned m2 = 0;
+                int c = 0;
+                for (int s = 0; s < WAVE_R && c < kk; ++s)
+                    if ((mask >> s) & 1u) {
+                        m2 |= 1u << s;
+                        ++c;
+                    }
+                mask = m2;
+            }
+            if (!trip(mask, inc, kk, kk == nout ? want : nullptr)) return false;
+        }
+    }
+};
+
+}  // namespace
+
+static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
+    memset(k, 0, sizeof(*k));
+    const int L = p->L, h = p->h;
+    auto rpos = [&](int tl) { return tl < L ? tl : (int)p->high_pos[tl - L]; };
+    auto wpos = [&](int tl) { return tl < L ? (int)p->store_low_pos[tl] : (int)p->store_high_pos[tl - L]; };
+    Xlate x;
+    x.p = p;
+    x.k = k;
+    unsigned slotmask = 0;
+    for (int s = 0; s < WAVE_R; ++s) {
+        x.phys[s] = p->load_rb[s];
+        slotmask |= 1u << p->load_rb[s];
+    }
+    for (int b = 0, q = 0; b < WAVE_LANES; ++b, ++q) {
+        while ((slotmask >> q) & 1u) ++q;
+        x.lanes[b] = q;
+    }
+    {   // read side: the tile number's bits fill the index bits outside the tile, in ascending order
+        uint64_t tilemask = (1ull << L) - 1ull;
+        for (int i = 0; i < h; ++i) tilemask |= 1ull << p->high_pos[i];
+        for (int j = 0, q = 0; j < DQ_FUSED_MAX_BLK; ++j, ++q) {
+            while (q < 64 && ((tilemask >> q) & 1ull)) ++q;
+            k->read_blk_pos[j] = (uint8_t)(q < 63 ? q : 63);
+            k->store_blk_pos[j] = j < n - WAVE_M ? p->store_blk_pos[j] : (uint8_t)63;
+        }
+    }
+    for (int s = 1; s < WAVE_R; ++s) k->load_off[s - 1] = 8ull << rpos(x.phys[s]);
+    for (int b = 0; b < WAVE_LANES; ++b) {
+        k->load_lane_shift[b] = 3u + (uint32_t)rpos(x.lanes[b]);
+        k->tb_contrib[b] = 1u << x.lanes[b];
+    }
+    k->mat_base_bytes = p->mat_base * 8u;
+
+    const char* why = "too many records for one pass (gates + layout changes)";
+    for (int r = 0; r < p->nrounds; ++r) {
+        const DqFusedRound& rd = p->rounds[r];
+        unsigned want = 0;
+        for (int s = 0; s < WAVE_R; ++s) want |= 1u << rd.rb[s];
+        if (!x.go(want, nullptr)) goto fail;
+        for (int gi = rd.gate_begin & 0x7f; gi < rd.gate_end; ++gi) {
+            const DqFusedGate& g = p->gates[gi];
+            if (g.kind != DQ_FG_GEN1 && g.kind != DQ_FG_X1) {
+                set_error("dq_apply_fused: the wave-tile kernel takes one-target gates (record %d has kind %d); plan this "
+                          "circuit for a workgroup-tile geometry", gi, (int)g.kind);
+                return DQ_ERR_UNSUPPORTED;
+            }
+            const int q = x.slot_of(rd.rb[g.q]);
+            unsigned pc = 0;
+            int nc = 0, onec = 0;
+            for (int s = 0; s < WAVE_R; ++s)
+                if ((g.reg_cmask >> s) & 1u) {
+                    onec = x.slot_of(rd.rb[s]);
+                    pc |= 1u << onec;
+                    ++nc;
+                }
+            const bool ctl = g.thr_cmask != 0 || g.out_cmask != 0;
+            WaveRec rec{};
+            rec.w[1] = g.thr_cmask;
+            rec.w[2] = (uint32_t)g.out_cmask, rec.w[3] = (uint32_t)(g.out_cmask >> 32);
+            rec.w[4] = g.mat_advance;
+            if (nc > 0) {       // pair i of slot q = the i-th register pattern with bit q clear
+                uint32_t pm = 0;
+                for (int j = 0, i = 0; j < 64; ++j) {
+                    if ((j >> q) & 1) continue;
+                    if (((unsigned)j & pc) == pc) pm |= 1u << i;
+                    ++i;
+                }
+                rec.w[5] = pm;
+            }
+            if (g.kind == DQ_FG_X1) {
+                if (nc == 0) rec.w[0] = (ctl ? DQ_WID_X_C : DQ_WID_X_U) + q;
+                else if (nc == 1) rec.w[0] = DQ_WID_X_R1 + 5 * q + (onec < q ? onec : onec - 1);
+                else rec.w[0] = DQ_WID_X_R + q;
+            } else {
+                if (nc > 0) rec.w[0] = DQ_WID_GEN_R + q;
+                else if (ctl) rec.w[0] = DQ_WID_GEN_C + q;
+                else rec.w[0] = DQ_WID_GEN_U + 6 * g.loc + q;
+            }
+            if (!x.push(rec)) goto fail;
+        }
+    }
+    {   // into the store layout: slot 0 = the tile bit written to index bit 0, lanes exactly as the host ordered them
+        unsigned want = 0;
+        int want_lanes[WAVE_LANES];
+        for (int s = 0; s < WAVE_R; ++s) want |= 1u << p->store_rb[s];
+        for (int b = 0; b < WAVE_LANES; ++b) want_lanes[b] = p->store_tb[b];
+        if (!x.go(want, want_lanes)) goto fail;
+        bool same = true;
+        for (int b = 0; b < WAVE_LANES; ++b) same = same && x.lanes[b] == want_lanes[b];
+        if (!same && !x.trip(0, nullptr, 0, want_lanes)) goto fail;
+        const int s0 = x.slot_of(p->store_rb[0]);
+        if (s0 != 0) {
+            WaveRec rec{};
+            rec.w[0] = (uint32_t)kWaveSwapId[0][s0];
+            if (!x.push(rec)) goto fail;
+            const int t = x.phys[0];
+            x.phys[0] = x.phys[s0];
+            x.phys[s0] = t;
+        }
+    }
+    for (int s = 1; s < WAVE_R; ++s) k->store_off[s - 1] = 8ull << wpos(x.phys[s]);
+    for (int b = 0; b < WAVE_LANES; ++b) k->store_lane_shift[b] = 3u + (uint32_t)wpos(x.lanes[b]);
+    k->nrec_bytes = 32u * (unsigned)x.nrec;
+    return DQ_OK;
+fail:
+    set_error("dq_apply_fused (wave tile): %s", why);
+    return DQ_ERR_UNSUPPORTED;
+}
+
+int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
+                    const DqFusedPass* pass, hipStream_t s) {
+    WaveKernPass kp;
+    const int rc = wave_translate(pass, n, &kp);
+    if (rc) return rc;
+    const uint64_t tiles = 1ull << (n - WAVE_M);
+    dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)batch);
+    hipLaunchKernelGGL(wave_pass_kernel, grid, dim3(256), 4 * WAVE_LDS_PER_WAVE, s, static_cast<const float2*>(in),
+                       static_cast<float2*>(out), static_cast<const float2*>(mats), mat_bstride, in_bstride, n, 0, kp);
+    return check_launch("dq_apply_fused (wave tile)");
+}
+
+}  // namespace dq
+
+// Test hook (no GPU needed): the kernel-side descriptor the library would hand to the wave-tile kernel for `pass` --
+// slot offsets, lane shifts, tile-number positions, records (struct WaveKernPass above) -- as raw bytes.
+extern "C" int dq_wave_descriptor(const DqFusedPass* pass, int n, void* out, int max_bytes) {
+    if (!pass) {
+        dq::set_error("dq_wave_descriptor: null pointer");
+        return DQ_ERR_ARG;
+    }
+    dq::WaveKernPass kp;
+    const int rc = dq::wave_translate(pass, n, &kp);
+    if (rc) return rc;
+    const int bytes = (int)(offsetof(dq::WaveKernPass, rec) + kp.nrec_bytes);
+    if (out) memcpy(out, &kp, bytes < max_bytes ? bytes : max_bytes);
+    return bytes;
+}

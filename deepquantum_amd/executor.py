@@ -51,7 +51,8 @@ _PLAN_CACHE: OrderedDict = OrderedDict()
 _PLAN_CACHE_SIZE = 64
 
 # Tunables (debug / benchmarking): tile bits per precision; None = library default.
-CONFIG = {'fuse': True, 'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
+CONFIG = {'fuse': True, 'wave': None,     # complex64: None = wave-tile kernel where it takes the circuit, False = workgroup tiles
+          'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
           'max_gates': None, 'max_far': None, 'far_bit': None,
           # pass planner (fusion._plan_tiles): beam width / tiles tried per state; 0 = first-come tiles, 1 = greedy
           'plan_width': None, 'plan_branch': None, 'plan_restarts': None, 'asm_loop': None, 'lane_swaps': None, 'swap_lanes': None, 'swap_policy': None,
@@ -86,8 +87,13 @@ LAST_SWEEP = {'fused': False, 'passes': 0, 'reductions': 0}
 LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'swaps': 0, 'permute_folded': False}
 
 
-def _geometry(is128: bool) -> fusion.Geometry:
-    g = fusion.default_geometry(is128, CONFIG['m_c128'] if is128 else CONFIG['m_c64'])
+def _geometry(is128: bool, wave: bool = True) -> fusion.Geometry:
+    """``wave`` = False: a workgroup-tile geometry (what circuits with gates the wave-tile kernel does not take run on)."""
+    m = CONFIG['m_c128'] if is128 else CONFIG['m_c64']
+    if is128 or m is not None or not wave or CONFIG['wave'] is False:
+        g = fusion.workgroup_geometry(is128, m)
+    else:
+        g = fusion.default_geometry(is128)
     ml = CONFIG['min_low_c128'] if is128 else CONFIG['min_low_c64']
     if ml is not None:
         g.min_low = ml
@@ -133,6 +139,8 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     takes long enough (>= 0.1 s) for a wider search of the pass planner to pay for itself within a few steps
     (measured on the headline: 21 -> 20 passes, -2.7 %, 4.6 s of planning once per circuit structure)."""
     geom = _geometry(is128)
+    if geom.wave and not fusion.wave_supports(prims):
+        geom = _geometry(is128, wave=False)
     if amps >= CONFIG['plan_big_amps']:
         for g_ in (geom, geom.fallback):
             if g_ is not None:

@@ -84,6 +84,8 @@ class Geometry:
     plan_min_bits: int = 20   # states below 2^plan_min_bits amplitudes: greedy (width 1) -- planning time matters there
     far_bit: int = 19         # index bits >= far_bit are "far": every one gathered doubles the number of
     max_far: int | None = None  # distant address streams of a tile; None = no limit (tools/sweep_tile_bits*.py)
+    wave: bool = False        # the wave-tile kernel (csrc/dq_wave.hip): one wavefront per tile, the library derives slot
+    #                           order, lane order and handlers itself; one-target 'gen' / 'x' gates only
 
     @property
     def logt(self) -> int:
@@ -91,9 +93,24 @@ class Geometry:
 
 
 def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = None) -> Geometry:
-    """Tile geometry per precision.  ``min_low`` = contiguous low bits every tile keeps: fewer of them leave more
-    tile bits for the qubits the gates need (fewer passes) at the price of shorter contiguous runs (slower
-    passes).  Measured on the headline sizes (ms per step, passes): c64, n = 28, batch 16: min_low 6 / 5 / 4 ->
+    """Tile geometry per precision.  complex64 without arguments: the WAVE TILE (m = 12, six register slots, one
+    wavefront per tile; csrc/dq_wave.hip).  With ``m`` / ``slots`` given, and for complex128: a workgroup tile
+    (`workgroup_geometry`)."""
+    if not is_c128 and m is None and slots is None:
+        # records of a pass: gates + 2 per layout change (twice that when it exchanges more than four bits) <= 112
+        return Geometry(m=12, slots=6, vb=1, min_low=4, wave=True, max_gates=72, max_rounds=8)
+    return workgroup_geometry(is_c128, m, slots)
+
+
+def wave_supports(ops: Sequence['PrimOp']) -> bool:
+    """Can the wave-tile kernel run all of ``ops``?  (One-target dense gates and X with any controls.)"""
+    return all(op.kind in ("gen", "x") and len(op.targets) == 1 for op in ops)
+
+
+def workgroup_geometry(is_c128: bool, m: int | None = None, slots: int | None = None) -> Geometry:
+    """The workgroup-tile kernels (csrc/dq_fused.hip).  ``min_low`` = contiguous low bits every tile keeps: fewer of
+    them leave more tile bits for the qubits the gates need (fewer passes) at the price of shorter contiguous runs
+    (slower passes).  Measured on the headline sizes (ms per step, passes): c64, n = 28, batch 16: min_low 6 / 5 / 4 ->
     643 (40) / 614 (35) / 596 (32); c128, n = 28, batch 8: min_low 4 / 3 -> 703 (38) / 671 (33).  The optimum is
     128-byte runs (one cache line per lane group) in both precisions."""
     if is_c128:
@@ -634,7 +651,7 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         return [b for b in range(m) if b not in slots_l]
 
     desc = _lib.DqFusedPass()
-    desc.m, desc.L, desc.h = m, L, h
+    desc.m, desc.L, desc.h, desc.slots = m, L, h, R
     for i, b in enumerate(order):
         desc.high_pos[i] = b
         desc.high_sorted[i] = b
@@ -785,6 +802,8 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
     esz_log = 3 if vb == 1 else 4           # complex64: 8-byte amplitudes; complex128: 16
 
     def fill_table(index: int, slots_l) -> None:
+        if geom.wave:                       # (the wave-tile kernel addresses its staging buffer on its own)
+            return
         period = 5 if vb == 1 else 4
         for j in range(1 << R):
             e = sum(1 << slots_l[s_] for s_ in range(R) if (j >> s_) & 1)
@@ -826,13 +845,13 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
             r.tb[i] = t
         fill_table(1 + ri, lay[0])
         for oi in rd.ops:
-            _encode_gate(desc.gates[gi], ops[oi], local, slot_of, tile)
+            _encode_gate(desc.gates[gi], ops[oi], local, slot_of, tile, handlers=not geom.wave)
             exec_order.append(oi)
             records.append(oi)
             gi += 1
         all_fast = all(desc.gates[k].fast != _lib.FAST_NONE for k in range(first, gi))
         assert all_fast or not swaps_of[ri], 'an exchange round must consist of straight-line handlers'
-        r.gate_begin = first | (_lib.ROUND_ALL_FAST if all_fast and (geom.asm_loop or swaps_of[ri]) else 0)
+        r.gate_begin = first | (_lib.ROUND_ALL_FAST if all_fast and not geom.wave and (geom.asm_loop or swaps_of[ri]) else 0)
         r.gate_end = gi
     if cur != (tuple(store_rb), tuple(store_tb)):
         ntrans += 1
@@ -894,7 +913,8 @@ def _thread_bit_order(m: int, slots_l: list[int], geom: Geometry) -> list[int]:
     return chosen + restb
 
 
-def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of: dict[int, int], tile: set[int]) -> None:
+def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of: dict[int, int], tile: set[int],
+                 handlers: bool = True) -> None:
     reg_c, thr_c, out_c = 0, 0, 0
     for c in op.controls:
         if c in tile:
@@ -937,7 +957,8 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         g.q = slots[0]
         g.loc = op.mode if op.kind == 'gen' else 0
         # straight-line handler id (index of the kernel's jump table): see include/dq_hip.h
-        g.fast = fast_id(g.kind, g.loc, slots[0], reg_c, thr_c, out_c)
+        if handlers:
+            g.fast = fast_id(g.kind, g.loc, slots[0], reg_c, thr_c, out_c)
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots
@@ -994,9 +1015,16 @@ def rx_defer_positions(steps: Sequence, ops: Sequence[PrimOp]) -> list[int]:
     for st in steps:
         if isinstance(st, FusedStep) and st.c64:
             for gi, oi in enumerate(st.records if st.records is not None else st.ops):
-                if oi is not None and 8 <= st.desc.gates[gi].fast <= 11:
+                if oi is not None and deferred_rx(st.desc.gates[gi]):
                     pos.append(ops[oi].pos)
     return pos
+
+
+def deferred_rx(g) -> bool:
+    """Does this record of a complex64 pass read the deferred Rx block (include/dq_hip.h, DQ_MODE_RX)?  An Rx-like 2x2
+    gate without a control of any kind -- handler ids 8..11 of the workgroup-tile kernels, the same rule in the wave-tile
+    kernel."""
+    return (g.kind == _lib.FG_GEN1 and g.loc == 2 and g.reg_cmask == 0 and g.thr_cmask == 0 and g.out_cmask == 0)
 
 
 def defer_rx(flat, index):

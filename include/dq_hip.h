@@ -43,11 +43,16 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 17
+#define DQ_ABI_VERSION 18
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
 const char* dq_last_error(void);
+/* What the compiled library believes the descriptor structs below look like: sizeof(DqFusedGate), sizeof(DqFusedRound),
+ * sizeof(DqFusedPass), then the offsets of DqFusedPass::rounds, gates, load_slot_off, lds_tab, store_high_pos, store_tb,
+ * slots -- at most `max` values written to `out`; returns how many there are.  Lets a binding check its own struct
+ * definitions against the library instead of against numbers typed in by hand. */
+int dq_struct_layout(int* out, int max);
 /* Fills CU count, LDS bytes per workgroup, total global memory of the current device. */
 int dq_device_info(int* cu_count, int64_t* lds_per_block, int64_t* global_mem);
 
@@ -76,12 +81,23 @@ int dq_set_dense_path(int mfma);
  *    workgroup stages one 2^m tile (registers + LDS) and walks the pass's rounds.  A round names
  *    R register-slot bits (tile-local positions); gates of the round act on register slots.
  *    The host scheduler (deepquantum_amd/fusion.py) builds these descriptors.
+ *
+ *    Geometries (dq_fused_geometry).  complex64, variant 0 -- the default -- is the WAVE TILE: m = 12, 6 register
+ *    slots, 64 threads: ONE wavefront owns a tile (64 lanes x 64 amplitudes in registers), a workgroup is four
+ *    independent waves, and a pass has no workgroup barrier at all; a layout change between rounds goes through a small
+ *    wave-private LDS buffer.  For such a pass the library derives everything below the level of "which tile bits are
+ *    register slots in which round" itself (csrc/dq_wave.hip translates the descriptor into the kernel's records):
+ *    the order of a round's slots and of its thread bits, `fast`, DQ_ROUND_ALL_FAST, DQ_ROUND_SWAP and lds_tab are
+ *    not used (fast must be DQ_FAST_NONE), and this build takes DQ_FG_GEN1 and DQ_FG_X1 records there (anything
+ *    else: DQ_ERR_UNSUPPORTED -- plan such circuits for a workgroup-tile geometry).  The workgroup-tile geometries
+ *    (complex64 variants 1, 2: m = 13 / 12, 4 slots, 512 / 256 threads; complex128: m = 12 / 11, 3 slots) stage the
+ *    tile in LDS between rounds, two barriers per change.
  * ------------------------------------------------------------------------------------------ */
 #define DQ_FUSED_MAX_HIGH 12
 #define DQ_FUSED_MAX_LOW 8      /* contiguous low tile bits: L <= 8 */
 #define DQ_FUSED_MAX_ROUNDS 24
 #define DQ_FUSED_MAX_GATES 80
-#define DQ_FUSED_MAX_SLOTS 4
+#define DQ_FUSED_MAX_SLOTS 6
 
 typedef enum {
     DQ_FG_GEN1 = 0,  /* general 2x2 on register slot q                       */
@@ -166,7 +182,7 @@ typedef struct {
     uint8_t gate_begin, gate_end;   /* [begin & 0x7f, end) into gates[]; DQ_ROUND_ALL_FAST in gate_begin promises
                                        that every gate of the round has a handler id (fast != DQ_FAST_NONE): the
                                        kernel then runs the round's gate loop without leaving its assembly block */
-} DqFusedRound;                     /* 16 bytes */
+} DqFusedRound;                     /* 18 bytes */
 #define DQ_ROUND_ALL_FAST 0x80u
 #define DQ_ROUND_TRANSPOSE 0x01u
 #define DQ_ROUND_TRANSPOSE_AFTER 0x02u
@@ -220,6 +236,8 @@ typedef struct {
      * puts the tile bits written to global bits 1 .. L-1 on the lowest lane bits: 128 contiguous bytes per 8 lanes). */
     uint8_t store_low_pos[DQ_FUSED_MAX_LOW];
     uint8_t store_tb[DQ_FUSED_MAX_TBITS];
+    uint8_t slots;                              /* register slots per thread of the geometry the pass was planned for
+                                                   (dq_fused_geometry); with m it selects the kernel */
 } DqFusedPass;
 
 /* Tile geometries this build was compiled with (m = slots + log2(threads)); variant 0 is the
@@ -229,6 +247,13 @@ int dq_fused_geometry(int is_c128, int variant, int* m, int* slots, int* threads
  * consecutive tiles of a pass and requests tile t + 1 from HBM while the gates of tile t run.  0 = automatic (4 where
  * the grid stays large enough), 1 = one tile per workgroup (no prefetch), otherwise a power of two <= 64. */
 int dq_fused_set_tiles_per_wg(int tiles);
+/* Test hook, no device needed: the kernel-side descriptor the library derives for a wave-tile pass (`pass`: HOST
+ * pointer, complex64, m = 12, 6 slots) as raw bytes -- 80 bytes of slot offsets (load, store: 5 x 8 each), 6 + 6 + 6
+ * words (byte shift of every lane bit on the load side / the store side, what it adds to the thread's tile-local base),
+ * record bytes, matrix base, 24 + 24 index positions of the tile number's bits (read, write), then the 32-byte records
+ * (word 0 = handler id, csrc/dq_wave_asm.inc).  At most `max_bytes` are copied to `out` (may be NULL); returns the size,
+ * or a negative DqStatus.  tests/_wave_emulator.py executes such a descriptor on the CPU. */
+int dq_wave_descriptor(const DqFusedPass* pass, int n, void* out, int max_bytes);
 /* `pass` is a HOST pointer; it is copied into the kernel argument segment.  in == out allowed.
  * Requires n >= pass->m. */
 int dq_apply_fused_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,

@@ -36,7 +36,8 @@ class CpuTestBackend:
         return out
 
     def fused_geometry(self, is_c128, variant):
-        table = {(False, 0): (12, 4, 256), (False, 1): (13, 4, 512), (True, 0): (11, 3, 256), (True, 1): (12, 3, 512)}
+        table = {(False, 0): (12, 6, 64), (False, 1): (13, 4, 512), (False, 2): (12, 4, 256),
+                 (True, 0): (11, 3, 256), (True, 1): (12, 3, 512)}
         return table[(bool(is_c128), variant)]
 
     # ---- fused pass interpreter --------------------------------------------------------------------
@@ -46,8 +47,11 @@ class CpuTestBackend:
         bsz = state.shape[0]
         is128 = state.dtype == torch.complex128
         m, L, h = desc.m, desc.L, desc.h
-        geoms = {(False, 12): 4, (False, 13): 4, (True, 11): 3, (True, 12): 3}
-        R = geoms[(is128, m)]
+        R = desc.slots
+        assert (is128, m, R) in ((False, 12, 6), (False, 12, 4), (False, 13, 4), (True, 11, 3), (True, 12, 3)), 'no such kernel'
+        wave = R == 6           # the wave-tile kernel (include/dq_hip.h): no offset tables, no handler ids, no exchanges
+        if wave:
+            assert grads is None, 'reverse-sweep passes run on the workgroup-tile geometries'
         vb = 0 if is128 else 1
         logt = m - R
         assert L + h == m and n >= m
@@ -84,12 +88,13 @@ class CpuTestBackend:
                     out.append((e_ ^ ((e_ >> 5) & 31) ^ ((e_ >> 10) & 31) ^ ((e_ >> 4) & 1)) * 8)
             return out
 
-        assert [desc.lds_tab[0][j] for j in range(1 << R)] == want_table([desc.load_rb[s] for s in range(R)])
-        assert [desc.lds_tab[_lib.FUSED_MAX_ROUNDS + 1][j] for j in range(1 << R)] == \
-            want_table([desc.store_rb[s] for s in range(R)])
-        for r_ in range(desc.nrounds):
-            assert [desc.lds_tab[1 + r_][j] for j in range(1 << R)] == \
-                want_table([desc.rounds[r_].rb[s] for s in range(R)]), 'LDS offset table wrong'
+        if not wave:
+            assert [desc.lds_tab[0][j] for j in range(1 << R)] == want_table([desc.load_rb[s] for s in range(R)])
+            assert [desc.lds_tab[_lib.FUSED_MAX_ROUNDS + 1][j] for j in range(1 << R)] == \
+                want_table([desc.store_rb[s] for s in range(R)])
+            for r_ in range(desc.nrounds):
+                assert [desc.lds_tab[1 + r_][j] for j in range(1 << R)] == \
+                    want_table([desc.rounds[r_].rb[s] for s in range(R)]), 'LDS offset table wrong'
         # tile-local index -> global offset, tile index -> base
         e = np.arange(1 << m, dtype=np.int64)
         glob = e & ((1 << L) - 1)
@@ -151,6 +156,8 @@ class CpuTestBackend:
                     exp_rb[g.q], exp_tb[g.q2] = exp_tb[g.q2], exp_rb[g.q]
                     nswap += 1
                 assert all(desc.gates[k].kind != _lib.FG_SWAP for k in range(first + nswap, rd.gate_end))
+                if wave:
+                    assert nswap == 0 and not rd.flags & _lib.ROUND_SWAP and not rd.gate_begin & _lib.ROUND_ALL_FAST
                 if rd.flags & _lib.ROUND_SWAP:
                     assert not is128 and nswap > 0 and (rb, tb) == (exp_rb, exp_tb) != lay, 'exchanges do not give the layout'
                     assert rd.gate_begin & _lib.ROUND_ALL_FAST and not rd.flags & _lib.ROUND_TRANSPOSE
@@ -167,6 +174,7 @@ class CpuTestBackend:
                 for gi in range(first + nswap, rd.gate_end):
                     g = desc.gates[gi]
                     assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
+                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1), 'the wave-tile kernel takes one-target gates only'
                     assert (g.reg_cmask >> R) == 0
                     cm = g.thr_cmask
                     for s in range(R):
@@ -201,7 +209,9 @@ class CpuTestBackend:
                         # restated from include/dq_hip.h (DqFusedGate::fast), independently of fusion.fast_id
                         free = g.reg_cmask == 0 and g.thr_cmask == 0 and g.out_cmask == 0
                         want = _lib.FAST_NONE
-                        if g.kind == _lib.FG_X1:
+                        if wave:
+                            pass
+                        elif g.kind == _lib.FG_X1:
                             if g.reg_cmask == 0:
                                 want = (16 if free else 32) + g.q
                             elif bin(g.reg_cmask).count('1') == 1:
@@ -210,7 +220,7 @@ class CpuTestBackend:
                             want = 4 * g.loc + g.q if free else 20 + 4 * (1 if g.loc == 3 else g.loc) + g.q
                         assert g.fast == want, 'fast-handler id wrong'
                         mat = mb[g.mat : g.mat + 4].reshape(2, 2)
-                        if g.kind == _lib.FG_GEN1 and g.loc == 2 and not is128 and 8 <= g.fast <= 11:
+                        if g.kind == _lib.FG_GEN1 and g.loc == 2 and not is128 and free:
                             # uncontrolled Rx-like gate of a complex64 pass: the deferred form (include/dq_hip.h,
                             # DQ_MODE_RX): { f, i t, -, flag } stands for f [[1, it], [it, 1]] (flag 0, f real) or
                             # f [[it, 1], [1, it]] (flag 1, f imaginary), |t| <= 1

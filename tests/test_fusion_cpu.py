@@ -101,12 +101,12 @@ def test_small_state_is_not_fused():
 
 
 def test_descriptor_struct_sizes_match_header():
+    """(The full comparison with the compiled library is tests/test_abi_cpu.py::test_struct_layout_matches_header.)"""
     import ctypes
 
     assert ctypes.sizeof(_lib.DqFusedGate) == 32
-    assert ctypes.sizeof(_lib.DqFusedRound) == 16
-    assert ctypes.sizeof(_lib.DqFusedPass) == 36 + 24 * 16 + 4 + 80 * 32 + 64 + 26 * 32 + 12 + 24 + 8 + 9 + 3   # (+ 3 pad to 8)
-    assert ctypes.sizeof(_lib.DqFusedPass) + 48 + 16 <= 4096      # the descriptor travels in the kernel-argument segment
+    assert ctypes.sizeof(_lib.DqFusedRound) == _lib.FUSED_MAX_SLOTS + _lib.FUSED_MAX_TBITS + 3
+    assert ctypes.sizeof(_lib.DqFusedPass) <= 4096
 
 
 def test_x_type_gates_commute_in_the_dag():
@@ -146,7 +146,9 @@ def test_planned_tiles_need_fewer_passes_and_keep_the_result(cpu_backend):
                 spec.append(('cnot', q, t + (t >= q)))
 
     def run(width):
-        dq.executor.CONFIG['plan_width'] = width
+        # (workgroup tiles: with the wave tile's cap of 72 gates per pass this small circuit is bounded by the cap,
+        # not by the tiles, and every rule needs the same five passes)
+        dq.executor.CONFIG['plan_width'], dq.executor.CONFIG['wave'] = width, False
         dq.executor._PLAN_CACHE.clear()
         try:
             cir = dq.QubitCircuit(n)
@@ -156,7 +158,7 @@ def test_planned_tiles_need_fewer_passes_and_keep_the_result(cpu_backend):
                 out = cir().clone()
             return out, dq.executor.LAST_RUN['passes']
         finally:
-            dq.executor.CONFIG['plan_width'] = None
+            dq.executor.CONFIG['plan_width'], dq.executor.CONFIG['wave'] = None, None
             dq.executor._PLAN_CACHE.clear()
 
     s0, p0 = run(0)
@@ -232,7 +234,7 @@ def test_permuted_stores_make_every_later_tile_contiguous(cpu_backend):
     n = 18
     ops, mats = random_ops(n, 200, 5, kinds=('gen', 'x', 'diag', 'gen2'))
     mats = mats.to(torch.complex64)
-    geom = fusion.default_geometry(False)
+    geom = fusion.workgroup_geometry(False)
     geom.permute_store = True
     geom.fallback.permute_store = True
     geom.free_low = geom.fallback.free_low = False      # (the low bits stay put here; the test below moves them too)
@@ -305,7 +307,7 @@ def test_reduction_records_of_the_reverse_sweep(cpu_backend, n, m):
 
 
 def free_low_schedule(ops, n, is128, m, width=4):
-    geom = fusion.default_geometry(is128, m)
+    geom = fusion.default_geometry(False) if m == 'wave' else fusion.workgroup_geometry(is128, m)
     geom.permute_store = geom.free_low = True
     if geom.fallback is not None:
         geom.fallback.permute_store = geom.fallback.free_low = True
@@ -313,14 +315,15 @@ def free_low_schedule(ops, n, is128, m, width=4):
 
 
 @pytest.mark.parametrize('n,seed,m,is128', [(18, 5, None, False), (17, 1, None, False), (16, 2, 12, False),
-                                            (15, 3, None, True), (16, 4, 11, True)])
+                                            (15, 3, None, True), (16, 4, 11, True), (18, 5, 'wave', False),
+                                            (17, 1, 'wave', False)])
 def test_stores_that_relabel_the_low_bits(cpu_backend, n, seed, m, is128):
     """Schedules in which every pass picks ALL its tile qubits (fusion._schedule(free_low=True)): a pass writes the
     qubits its successor wants on the contiguous low bits there (store_low_pos), which needs them in its own tile;
     the write positions of a pass are a permutation of [0, n), complex64 passes write the tile bit of store slot 0 to
     index bit 0, the passes compose to the canonical order, and the state equals the reference's."""
     dtype = torch.complex128 if is128 else torch.complex64
-    ops, mats = random_ops(n, 300, seed, kinds=('gen', 'x', 'diag'))
+    ops, mats = random_ops(n, 300, seed, kinds=('gen', 'x') if m == 'wave' else ('gen', 'x', 'diag'))
     mats = mats.to(dtype)
     steps = free_low_schedule(ops, n, is128, m)
     assert steps is not None and all(isinstance(s, fusion.FusedStep) for s in steps)
@@ -375,7 +378,7 @@ def test_free_low_schedules_win_on_deep_layered_circuits():
         off += 4
     counts = {}
     for fl in (False, True):
-        geom = fusion.default_geometry(False)
+        geom = fusion.workgroup_geometry(False)
         geom.permute_store = geom.fallback.permute_store = True
         geom.free_low = geom.fallback.free_low = fl
         geom.plan_width, geom.plan_branch, geom.plan_restarts = 4, 3, 1
@@ -385,7 +388,7 @@ def test_free_low_schedules_win_on_deep_layered_circuits():
         assert relabelled == fl
     assert counts[True] < counts[False], counts
     big = ops + [fusion.PrimOp('gen', (5, 9, 13), (), off, 0)]          # a three-qubit gate runs on its own
-    geom = fusion.default_geometry(False)
+    geom = fusion.workgroup_geometry(False)
     geom.permute_store = geom.fallback.permute_store = True
     assert fusion._schedule(big, n, geom, 4, None, free_low=True) is None
     assert any(isinstance(s, fusion.SingleStep) for s in fusion.schedule(big, n, geom))

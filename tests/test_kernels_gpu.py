@@ -173,7 +173,7 @@ def test_fused_batched_matrices_and_out_of_place(is128):
                 mi[op.mat : op.mat + d2] *= torch.exp(1j * torch.rand(1, generator=g, dtype=torch.float64) * 3)
         per_sample.append(mi)
     mats = torch.stack(per_sample).to(dtype)
-    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+    steps = fusion.schedule(ops, n, fusion.workgroup_geometry(is128))
     x = rand_state(b, n, dtype, 5)
     ref = torch.cat([run_reference(x[i : i + 1], ops, mats[i]) for i in range(b)])
     xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev()).contiguous()
@@ -202,7 +202,7 @@ def test_fused_pass_with_one_shared_input_state(is128, n, b):
                 mi[op.mat : op.mat + d2] *= torch.exp(1j * torch.rand(1, generator=g, dtype=torch.float64) * 3)
         per_sample.append(mi)
     mats = torch.stack(per_sample).to(dtype)
-    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+    steps = fusion.schedule(ops, n, fusion.workgroup_geometry(is128))
     assert all(isinstance(s_, fusion.FusedStep) for s_ in steps)
     x = rand_state(1, n, dtype, 77)
     ref = torch.cat([run_reference(x, ops, mats[i]) for i in range(b)])
@@ -281,7 +281,7 @@ def test_batches_wider_than_a_grid_dimension_go_in_slices(monkeypatch):
     for op in ops:      # X-type matrices are not read by the kernels: keep the per-sample phase off them
         if op.kind == 'x':
             mats[:, op.mat:op.mat + 4] = mats0[op.mat:op.mat + 4].to(dtype)
-    steps = fusion.schedule(ops, n, fusion.default_geometry(False))
+    steps = fusion.schedule(ops, n, fusion.workgroup_geometry(False))
     x = rand_state(b, n, dtype, 3)
     ref = torch.cat([run_reference(x[i:i + 1], ops, mats[i]) for i in range(b)])
     xd = x.to(dev())
@@ -403,7 +403,7 @@ def test_all_handler_round_flag(is128):
     victim = None
     for kinds in (('gen', 'x'), ('gen', 'x', 'diag', 'gen2')):
         ops, mats = random_ops(n, 80, 3, kinds=kinds)
-        steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+        steps = fusion.schedule(ops, n, fusion.workgroup_geometry(is128))
         for st in steps:
             for r in range(st.desc.nrounds):
                 rd = st.desc.rounds[r]
@@ -460,7 +460,7 @@ def test_assembly_gate_loop_matches_oracle(is128, n, seed):
     dtype = torch.complex128 if is128 else torch.complex64
     ops, mats = handler_ops(n, 150, seed)
     mats = mats.to(dtype)
-    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
+    steps = fusion.schedule(ops, n, fusion.workgroup_geometry(is128))
     rounds = [st.desc.rounds[r] for st in steps for r in range(st.desc.nrounds)]
     flagged = sum(bool(rd.gate_begin & _lib.ROUND_ALL_FAST) for rd in rounds)
     assert flagged >= 0.5 * len(rounds), (flagged, len(rounds))

@@ -1,0 +1,111 @@
+"""The wave-tile kernel without a GPU: the library's translation of a pass (rounds -> records: physical slots, trips,
+pair masks, byte offsets; csrc/dq_wave.hip) executed by the emulator of tests/_wave_emulator.py -- which moves data with
+the very instruction lists of the generator that writes the kernel -- against the descriptor interpreter of
+tests/_cpu_backend.py and against the oracle applying the gates one by one."""
+
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from deepquantum_amd import _lib, backend, fusion
+from oracle import statevec_oracle as oracle
+
+import _wave_emulator as emu
+
+
+def random_ops(n, ngates, seed, modes=True):
+    """One-target gates with 0..3 controls anywhere; 'gen' matrices general / real / Rx-like / Hadamard-like."""
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(seed)
+    ops, mats, off = [], [], 0
+    for _ in range(ngates):
+        kind = rng.choice(['gen', 'gen', 'x'])
+        nc = rng.choice([0, 0, 0, 1, 1, 2, 3])
+        bits = rng.sample(range(n), 1 + nc)
+        mode = 0
+        if kind == 'x':
+            m = torch.tensor([[0, 1], [1, 0]], dtype=torch.complex128)
+        else:
+            mode = rng.choice([0, 1, 2, 3]) if modes else 0
+            th = float(torch.rand(1, generator=g, dtype=torch.float64)) * 6.28
+            c, s_ = np.cos(th / 2), np.sin(th / 2)
+            if mode == 1:
+                m = torch.tensor([[c, -s_], [s_, c]], dtype=torch.complex128)
+            elif mode == 2:
+                m = torch.tensor([[c, -1j * s_], [-1j * s_, c]], dtype=torch.complex128)
+            elif mode == 3:
+                m = torch.tensor([[1, 1], [1, -1]], dtype=torch.complex128) * (2 ** -0.5)
+            else:
+                a = torch.randn(2, 2, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 2, generator=g, dtype=torch.float64)
+                m, _ = torch.linalg.qr(a)
+        ops.append(fusion.PrimOp(kind, (bits[0],), tuple(bits[1:]), off, mode))
+        mats.append(m.reshape(-1))
+        off += 4
+    return ops, torch.cat(mats).to(torch.complex64)
+
+
+def reference(state, ops, mats):
+    x = state
+    for op in ops:
+        x = oracle.apply_gate_bits(x, mats[op.mat:op.mat + 4].reshape(2, 2), list(op.targets), list(op.controls))
+    return x
+
+
+@pytest.mark.parametrize('n,ngates,seed,permute', [(12, 40, 0, False), (13, 120, 1, False), (14, 200, 2, False),
+                                                   (15, 300, 3, True), (16, 260, 4, True), (14, 150, 5, True)])
+def test_translated_passes_match_the_descriptor_semantics(cpu_backend, n, ngates, seed, permute):
+    ops, mats = random_ops(n, ngates, seed)
+    geom = fusion.default_geometry(False)
+    assert geom.wave
+    geom.permute_store = permute
+    geom.plan_min_bits = 12          # (plan the tiles as for big states, so that free low bits are exercised)
+    steps = fusion.schedule(ops, n, geom)
+    assert all(isinstance(s, fusion.FusedStep) for s in steps)
+    km = fusion.kernel_matrices(steps, ops, mats)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 1 << n, generator=g, dtype=torch.float64)
+    x = (x / x.norm(dim=-1, keepdim=True)).to(torch.complex64)
+    ref = reference(x, ops, mats)
+    cur_d, cur_e = x.clone(), x.numpy().copy()
+    trips = 0
+    for st in steps:
+        nxt = torch.empty_like(cur_d)
+        backend.apply_fused(cur_d, km, 0, st.desc, out=nxt)           # the descriptor interpreter
+        cur_d = nxt
+        cur_e = emu.run_pass(st.desc, n, cur_e, km.numpy(), 0)        # the library's records, emulated
+        kp = emu.descriptor(st.desc, n)
+        ids = [kp.rec[i][0] for i in range(kp.nrec_bytes // 32)]
+        trips += sum(emu.gen().ID_TRIP0 <= i < emu.gen().ID_SWAP for i in ids)
+        assert np.abs(cur_e - cur_d.numpy()).max() < 2e-6
+    assert (cur_d - ref).abs().max().item() < 2e-5
+    assert np.abs(cur_e - ref.numpy()).max() < 2e-5
+    assert trips > 0 or n == 12
+
+
+def test_trips_cover_every_slot_mask_and_stay_inside_the_buffer():
+    """Every generated trip variant (k <= 4 outgoing slots, any mask) transposes a sub-tile correctly when driven the way
+    the translator drives it: checked on the identity pass 'load layout -> a layout with other slots -> store layout'."""
+    g = emu.gen()
+    assert len(g.TRIP_MASKS) == 56 and g.MAXK == 4
+    for mask in g.TRIP_MASKS:
+        k = bin(mask).count('1')
+        lines = [ln for ln in g.trip(k, mask) if ln.startswith('ds_')]
+        assert len(lines) == 128
+        a, S = 5 - k, 64 + (1 << (5 - k))
+        imm_w = sorted({int(ln.split('offset:')[1]) for ln in lines if ln.startswith('ds_write')})
+        imm_r = sorted({int(ln.split('offset:')[1]) for ln in lines if ln.startswith('ds_read')})
+        assert imm_w == [8 * S * x for x in range(1 << k)] and imm_r == [8 * (y << a) for y in range(1 << k)]
+        assert 8 * (S * ((1 << k) - 1) + 63) + 8 <= 8448
+
+
+def test_unsupported_records_are_refused(cpu_backend):
+    ops = [fusion.PrimOp('gen', (3,), (), 0, 0), fusion.PrimOp('diag', (5,), (), 4, 0)]
+    geom = fusion.default_geometry(False)
+    steps = fusion.schedule(ops, 13, geom)
+    lib = _lib.load()
+    import ctypes as C
+    rc = lib.dq_wave_descriptor(C.byref(steps[0].desc), 13, None, 0)
+    assert rc == -3 and b'one-target' in lib.dq_last_error()
+    assert not fusion.wave_supports(ops) and fusion.wave_supports(ops[:1])

@@ -1,0 +1,125 @@
+"""The wave-tile kernel (csrc/dq_wave.hip, complex64 default geometry) on the GPU, through the C ABI, against the oracle
+applying the same gates one by one (1e-4 on amplitudes, the north star's complex64 bar; measured ~1e-6)."""
+
+import pytest
+import torch
+
+from deepquantum_amd import backend, fusion
+
+from test_wave_cpu import random_ops, reference
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def rand_state(b, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(b, 1 << n, generator=g, dtype=torch.float64)
+    return (x / x.norm(dim=-1, keepdim=True)).to(torch.complex64)
+
+
+def wave_steps(ops, n, permute=False):
+    geom = fusion.default_geometry(False)
+    assert geom.wave
+    geom.permute_store = permute
+    geom.plan_min_bits = 12
+    steps = fusion.schedule(ops, n, geom)
+    assert all(isinstance(s, fusion.FusedStep) and s.desc.slots == 6 and s.desc.m == 12 for s in steps)
+    return steps
+
+
+@pytest.mark.parametrize('n,ngates,seed', [(12, 60, 0), (13, 120, 1), (14, 200, 2), (15, 300, 3), (17, 300, 4), (20, 400, 5)])
+def test_wave_passes_match_oracle_in_place(n, ngates, seed):
+    ops, mats = random_ops(n, ngates, seed)
+    steps = wave_steps(ops, n)
+    x = rand_state(2, n, 10 + seed)
+    ref = reference(x, ops, mats)
+    xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
+    for st in steps:
+        backend.apply_fused(xd, md, 0, st.desc, out=xd)
+    err = (xd.cpu() - ref).abs().max().item()
+    assert err < TOL, err
+
+
+@pytest.mark.parametrize('n,ngates,seed', [(14, 150, 5), (16, 260, 4), (18, 300, 6), (21, 500, 7)])
+def test_wave_passes_with_permuted_stores(n, ngates, seed):
+    """Out-of-place passes that re-label index bits on the way out (every tile after the first is contiguous on the
+    read side, the low bits move too): the store layout is reached by a trip, a lane permutation or a slot swap."""
+    ops, mats = random_ops(n, ngates, seed)
+    steps = wave_steps(ops, n, permute=True)
+    assert any(s.permutes for s in steps)
+    x = rand_state(2, n, 20 + seed)
+    ref = reference(x, ops, mats)
+    cur, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
+    for st in steps:
+        nxt = torch.empty_like(cur)
+        backend.apply_fused(cur, md, 0, st.desc, out=nxt)
+        cur = nxt
+    err = (cur.cpu() - ref).abs().max().item()
+    assert err < TOL, err
+
+
+def test_wave_kernel_equals_its_cpu_emulation():
+    """Pass by pass against tests/_wave_emulator.py (the library's own records executed on the CPU)."""
+    import _wave_emulator as emu
+
+    n = 14
+    ops, mats = random_ops(n, 200, 8)
+    steps = wave_steps(ops, n, permute=True)
+    x = rand_state(2, n, 3)
+    km = fusion.kernel_matrices(steps, ops, mats)
+    cur, md = x.to(dev()), km.to(dev())
+    cur_e = x.numpy().copy()
+    for st in steps:
+        nxt = torch.empty_like(cur)
+        backend.apply_fused(cur, md, 0, st.desc, out=nxt)
+        cur = nxt
+        cur_e = emu.run_pass(st.desc, n, cur_e, km.numpy(), 0)
+        assert (cur.cpu() - torch.from_numpy(cur_e)).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize('n,b', [(15, 3), (16, 16), (13, 4), (12, 5)])
+def test_wave_batched_matrices_and_one_shared_input_state(n, b):
+    """Per-sample matrices (the vmap case of circuit.py:232-240) and the first pass of a batched circuit reading ONE
+    input state (dq_apply_fused_bcast_c64)."""
+    ops, mats0 = random_ops(n, 60, 21)
+    g = torch.Generator().manual_seed(5)
+    mats = mats0.unsqueeze(0).repeat(b, 1)
+    for i, op in enumerate(ops):                 # per-sample Rx-like angles on the mode-2 gates, shared elsewhere
+        if op.kind == 'gen' and op.mode == 2:
+            th = torch.rand(b, generator=g, dtype=torch.float64) * 6.28
+            c, s_ = torch.cos(th / 2), torch.sin(th / 2)
+            m = torch.stack([c + 0j, -1j * s_, -1j * s_, c + 0j], dim=1).to(torch.complex64)
+            mats[:, op.mat:op.mat + 4] = m
+    steps = wave_steps(ops, n)
+    x1 = rand_state(1, n, 31)
+    ref = torch.cat([reference(x1, ops, mats[i]) for i in range(b)])
+    km = fusion.kernel_matrices(steps, ops, mats).to(dev())
+    out = torch.empty(b, 1 << n, dtype=torch.complex64, device=dev())
+    src = x1.to(dev())
+    for k, st in enumerate(steps):
+        if k == 0:
+            backend.apply_fused(src, km.reshape(-1), km.shape[1], st.desc, out=out)     # one state in, b states out
+        else:
+            backend.apply_fused(out, km.reshape(-1), km.shape[1], st.desc, out=out)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < TOL, err
+    assert torch.equal(src.cpu(), x1)
+
+
+def test_wave_pass_refuses_what_it_cannot_run():
+    from test_fusion_cpu import random_ops as mixed_ops
+
+    n = 13
+    ops, mats = mixed_ops(n, 30, 2, kinds=('gen', 'diag', 'gen2'))
+    geom = fusion.default_geometry(False)
+    steps = fusion.schedule(ops, n, geom)
+    x = rand_state(1, n, 1).to(dev())
+    md = fusion.kernel_matrices(steps, ops, mats.to(torch.complex64)).to(dev())
+    with pytest.raises(RuntimeError, match='one-target'):
+        for st in steps:
+            backend.apply_fused(x, md, 0, st.desc, out=x)

@@ -1,0 +1,309 @@
+"""Generate csrc/dq_wave_asm.inc: the body of the wave-tile pass kernel (complex64).
+
+One wavefront owns a 12-bit tile: 64 lanes x 64 amplitudes in v[40:167] (amplitude j = register-slot pattern j at
+v[40 + 2j : 41 + 2j]).  The whole life of a tile -- 32 x 16-byte loads, the record loop (gates, layout changes), the
+deferred scale, 32 stores -- is ONE asm statement with fixed registers; C++ only computes the addresses it starts from
+(csrc/dq_wave.hip).  No workgroup barrier anywhere: a layout change ("trip") goes through a small wave-private LDS
+buffer, sub-tile by sub-tile (2^k registers x 64 lanes), addressed with immediates.
+
+Records (32 bytes, made by the translator in csrc/dq_wave.hip from the host's DqFusedPass):
+  w0 handler id   w1 thread-control mask (tile-local bits)   w2:w3 outside-control mask   w4 matrix advance (complex
+  numbers)   w5 pair mask (register-controlled gates)   w6, w7 unused
+  trip: two records -- A: w0 id, w4 0, (w1 w2 w3 w5 w6 w7) = what lane bits 0..5 add to the thread's tile-local base in
+  the new layout;  B: w0..w5 = what lane bit b adds to the LDS write address (low half) and read address (high half).
+"""
+import os
+
+R = 6
+NA = 1 << R
+AMP0 = 40
+T0, U0, T1, U1 = 'v[10:11]', 'v[12:13]', 'v[14:15]', 'v[16:17]'
+TT, HR, HI, TB, LANE, WB, RB = 'v18', 'v19', 'v20', 'v21', 'v22', 'v23', 'v24'
+LB = [f'v{25 + b}' for b in range(6)]            # the lane's bits as masks: 0 / 0xffffffff
+ADDR = ['v[32:33]', 'v[34:35]', 'v[36:37]', 'v[38:39]']
+LLD, LST = 'v[2:3]', 'v[4:5]'                    # the lane's byte offset in the load / store layout
+SLOTOFF = [f's[{40 + 2 * i}:{41 + 2 * i}]' for i in range(5)]     # what slots 1..5 add (bytes)
+RUN, SAVE, TABLE, HADC = 's[50:51]', 's[52:53]', 's[54:55]', 's[56:57]'
+GOFF, GEND, MOFF, STMP = 's58', 's59', 's60', 's61'
+MB, KG, TG, LDSB = 's[62:63]', 's[64:65]', 's[66:67]', 's68'
+REC, REC2, MAT = 72, 80, 88
+M = [f's[{MAT + 2 * i}:{MAT + 2 * i + 1}]' for i in range(4)]     # m00 m01 m10 m11
+
+
+def A(j):
+    return f'v[{AMP0 + 2 * j}:{AMP0 + 2 * j + 1}]'
+
+
+def pairs(q, cmask=0):
+    return [(j, j | (1 << q)) for j in range(NA) if not (j >> q) & 1 and (j & cmask) == cmask]
+
+
+RE2, RE3 = 'op_sel_hi:[1,0]', 'op_sel_hi:[1,0,1]'
+I2 = 'op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]'
+I3 = 'op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]'
+
+
+def pair_general(lo, hi, t, u):
+    a_, b_ = A(lo), A(hi)
+    return [f'v_pk_mul_f32 {t}, {b_}, {M[1]} {RE2}', f'v_pk_mul_f32 {u}, {a_}, {M[2]} {RE2}',
+            f'v_pk_fma_f32 {t}, {b_}, {M[1]}, {t} {I3}', f'v_pk_fma_f32 {u}, {a_}, {M[2]}, {u} {I3}',
+            f'v_pk_fma_f32 {t}, {a_}, {M[0]}, {t} {I3}', f'v_pk_fma_f32 {u}, {b_}, {M[3]}, {u} {I3}',
+            f'v_pk_fma_f32 {a_}, {a_}, {M[0]}, {t} {RE3}', f'v_pk_fma_f32 {b_}, {b_}, {M[3]}, {u} {RE3}']
+
+
+def body(mode, q):
+    lines = []
+    for k, (lo, hi) in enumerate(pairs(q)):
+        t, u = (T0, U0) if k % 2 == 0 else (T1, U1)
+        a_, b_ = A(lo), A(hi)
+        if mode == 3:      # s [[1, 1], [1, -1]], s deferred: all sums first, then all differences B' = A' - 2 B
+            lines.insert(k, f'v_pk_add_f32 {a_}, {a_}, {b_}')
+            lines.append(f'v_pk_fma_f32 {b_}, {b_}, {HADC}, {a_}')
+        elif mode == 1:    # all entries real
+            lines += [f'v_pk_mul_f32 {t}, {b_}, {M[1]} {RE2}', f'v_pk_mul_f32 {u}, {a_}, {M[2]} {RE2}',
+                      f'v_pk_fma_f32 {a_}, {a_}, {M[0]}, {t} {RE3}', f'v_pk_fma_f32 {b_}, {b_}, {M[3]}, {u} {RE3}']
+        else:
+            lines += pair_general(lo, hi, t, u)
+    return lines
+
+
+def body_rx_deferred(q, tag):
+    """f [[1, it], [it, 1]] (flag 0) or f [[it, 1], [1, it]] (flag 1): the host's deferred block (include/dq_hip.h,
+    DQ_MODE_RX); f multiplies the pass's deferred factor hr + i hi."""
+    it, fr, fi, flag = M[1], f's{MAT}', f's{MAT + 1}', f's{MAT + 6}'
+    f0, f1 = [], []
+    for k, (lo, hi) in enumerate(pairs(q)):
+        t = T0 if k % 2 == 0 else T1
+        a_, b_ = A(lo), A(hi)
+        f0 += [f'v_mov_b64 {t}, {a_}', f'v_pk_fma_f32 {a_}, {b_}, {it}, {a_} {I3}', f'v_pk_fma_f32 {b_}, {t}, {it}, {b_} {I3}']
+        f1 += [f'v_mov_b64 {t}, {a_}', f'v_pk_fma_f32 {a_}, {a_}, {it}, {b_} {I3}', f'v_pk_fma_f32 {b_}, {b_}, {it}, {t} {I3}']
+    l1, l2 = f'.Lrx1_{tag}_%=', f'.Lrx2_{tag}_%='
+    return ([f's_cmp_eq_u32 {flag}, 0', f's_cbranch_scc0 {l1}', f'v_mul_f32 {HR}, {HR}, {fr}', f'v_mul_f32 {HI}, {HI}, {fr}'] + f0 +
+            [f's_branch {l2}', f'{l1}:',
+             f'v_mul_f32 {TT}, {HR}, {fi}', f'v_mul_f32 {HR}, {HI}, {fi}', f'v_xor_b32 {HR}, 0x80000000, {HR}',
+             f'v_mov_b32 {HI}, {TT}'] + f1 + [f'{l2}:'])
+
+
+def xlines(q, cmask=0):
+    out_ = []
+    for k, (lo, hi) in enumerate(pairs(q, cmask)):
+        t = T0 if k % 2 == 0 else T1
+        out_ += [f'v_mov_b64 {t}, {A(lo)}', f'v_mov_b64 {A(lo)}, {A(hi)}', f'v_mov_b64 {A(hi)}, {t}']
+    return out_
+
+
+def masked(q, tag, per_pair):
+    """Pair i of slot q (in the order of pairs(q)) acts only if bit i of the record's pair mask (w5) is set."""
+    out_ = []
+    for i, (lo, hi) in enumerate(pairs(q)):
+        t, u = (T0, U0) if i % 2 == 0 else (T1, U1)
+        out_ += [f's_bitcmp1_b32 s{REC + 5}, {i}', f's_cbranch_scc0 .Lm{tag}_{i}_%='] + per_pair(lo, hi, t, u) + [f'.Lm{tag}_{i}_%=:']
+    return out_
+
+
+def slotswap(i, j):
+    out_ = []
+    k = 0
+    for r in range(NA):
+        if (r >> i) & 1 and not (r >> j) & 1:
+            o = r ^ (1 << i) ^ (1 << j)
+            t = T0 if k % 2 == 0 else T1
+            out_ += [f'v_mov_b64 {t}, {A(r)}', f'v_mov_b64 {A(r)}, {A(o)}', f'v_mov_b64 {A(o)}, {t}']
+            k += 1
+    return out_
+
+
+def deposit(val, positions):
+    return sum(((val >> i) & 1) << p for i, p in enumerate(positions))
+
+
+def trip(k, mask):
+    """The slots of `mask` (k of them) trade places with k lane bits; all lanes may be re-ordered.  Sub-tile element
+    (x = pattern of the outgoing slot bits, y = of the incoming bits, z = of the lane bits that stay) lives at slot
+    x * S + (y << a) + F(z), S = 64 + 2^a, a = 5 - k: written with immediate x * S, read with immediate y << a."""
+    pre = [f's_load_dwordx8 s[{REC2}:{REC2 + 7}], {KG}, {GOFF}', f's_add_u32 {GOFF}, {GOFF}, 32']
+    tbw = [REC + 1, REC + 2, REC + 3, REC + 5, REC + 6, REC + 7]
+    pre += [f'v_and_b32 {TB}, s{tbw[0]}, {LB[0]}'] + [f'v_and_or_b32 {TB}, {LB[b]}, s{tbw[b]}, {TB}' for b in range(1, 6)]
+    pre += ['s_waitcnt lgkmcnt(0)']
+    pre += [f'v_and_b32 {WB}, s{REC2}, {LB[0]}'] + [f'v_and_or_b32 {WB}, {LB[b]}, s{REC2 + b}, {WB}' for b in range(1, 6)]
+    pre += [f'v_lshrrev_b32 {RB}, 16, {WB}', f'v_and_b32 {WB}, 0xffff, {WB}', f'v_add_u32 {WB}, {LDSB}, {WB}', f'v_add_u32 {RB}, {LDSB}, {RB}']
+    if k == 0:
+        body_ = []
+        for j in range(NA):
+            body_ += [f'ds_write_b64 {WB}, {A(j)}', f'ds_read_b64 {A(j)}, {RB}']
+        return pre + body_
+    a = 5 - k
+    S = 64 + (1 << a)
+    moving = [s for s in range(R) if (mask >> s) & 1]
+    staying = [s for s in range(R) if not (mask >> s) & 1]
+    body_ = []
+    for g in range(1 << (R - k)):
+        base = deposit(g, staying)
+        for x in range(1 << k):
+            body_.append(f'ds_write_b64 {WB}, {A(base | deposit(x, moving))} offset:{8 * S * x}')
+        for y in range(1 << k):
+            body_.append(f'ds_read_b64 {A(base | deposit(y, moving))}, {RB} offset:{8 * (y << a)}')
+    return pre + body_
+
+
+MAXK = 4
+TRIP_MASKS = [m for m in range(1, 64) if bin(m).count('1') <= MAXK]
+SWAP_PAIRS = [(i, j) for i in range(R) for j in range(i + 1, R)]
+
+# handler ids
+ID_GEN_U = 0        # + 6 * mode + q          mode: 0 general, 1 real, 2 Rx-like (deferred block), 3 Hadamard-like
+ID_GEN_C = 24       # + q   any 2x2 with thread / outside controls
+ID_GEN_R = 30       # + q   ... with a register-pair mask as well
+ID_X_U = 36         # + q
+ID_X_C = 42         # + q
+ID_X_R = 48         # + q   pair mask
+ID_X_R1 = 54        # + 5 * q + c'   one register control c (c' = c, or c - 1 above q), thread / outside controls too
+ID_TRIP0 = 84
+ID_TRIP = 85        # + index in TRIP_MASKS
+ID_SWAP = ID_TRIP + len(TRIP_MASKS)       # + index in SWAP_PAIRS
+NIDS = ID_SWAP + len(SWAP_PAIRS)
+
+
+def handlers():
+    h = {}
+    for q in range(R):
+        h[ID_GEN_U + 0 * 6 + q] = (False, body(0, q))
+        h[ID_GEN_U + 1 * 6 + q] = (False, body(1, q))
+        h[ID_GEN_U + 2 * 6 + q] = (False, body_rx_deferred(q, f'u{q}'))
+        h[ID_GEN_U + 3 * 6 + q] = (False, [f'v_mul_f32 {HR}, {HR}, s{MAT}', f'v_mul_f32 {HI}, {HI}, s{MAT}'] + body(3, q))
+        h[ID_GEN_C + q] = (True, body(0, q))
+        h[ID_GEN_R + q] = (True, masked(q, f'g{q}', pair_general))
+        h[ID_X_U + q] = (False, xlines(q))
+        h[ID_X_C + q] = (True, xlines(q))
+        h[ID_X_R + q] = (True, masked(q, f'x{q}', lambda lo, hi, t, u: [f'v_mov_b64 {t}, {A(lo)}', f'v_mov_b64 {A(lo)}, {A(hi)}', f'v_mov_b64 {A(hi)}, {t}']))
+        for c in range(R):
+            if c != q:
+                h[ID_X_R1 + 5 * q + (c if c < q else c - 1)] = (True, xlines(q, 1 << c))
+    h[ID_TRIP0] = (False, trip(0, 0))
+    for i, m in enumerate(TRIP_MASKS):
+        h[ID_TRIP + i] = (False, trip(bin(m).count('1'), m))
+    for i, (a_, b_) in enumerate(SWAP_PAIRS):
+        h[ID_SWAP + i] = (False, slotswap(a_, b_))
+    return h
+
+
+def gray_walk(op, base_operand, lane_operand):
+    """32 x (address = base + running slot offset + lane offset; op).  The running offset follows a Gray code over the
+    slot bits 1..5, so each step is one 64-bit scalar add or subtract."""
+    out_ = [f's_mov_b64 {RUN}, {base_operand}']
+    for i in range(32):
+        g = i ^ (i >> 1)
+        if i:
+            b = (i & -i).bit_length() - 1
+            lo, hi = f's{40 + 2 * b}', f's{41 + 2 * b}'
+            if (g >> b) & 1:
+                out_ += [f's_add_u32 s50, s50, {lo}', f's_addc_u32 s51, s51, {hi}']
+            else:
+                out_ += [f's_sub_u32 s50, s50, {lo}', f's_subb_u32 s51, s51, {hi}']
+        ad = ADDR[i % 4]
+        out_.append(f'v_lshl_add_u64 {ad}, {RUN}, 0, {lane_operand}')
+        regs = f'v[{AMP0 + 4 * g}:{AMP0 + 4 * g + 3}]'
+        out_.append(f'global_load_dwordx4 {regs}, {ad}, off' if op == 'load' else f'global_store_dwordx4 {ad}, {regs}, off')
+    return out_
+
+
+def kernel_body():
+    h = handlers()
+    ids = sorted(h)
+    half = len(ids) // 2
+    # split the handlers around the loop head so that every s_branch stays within its 16-bit reach: the trips (the
+    # bulk of the code) go behind the table, the gates in front of it
+    front = [i for i in ids if i < ID_TRIP0]
+    back = [i for i in ids if i >= ID_TRIP0]
+    nxt = [f's_cmp_lt_u32 {GOFF}, {GEND}', 's_cbranch_scc1 .Lloop_%=', 's_branch .Lexit_%=']
+
+    def emit(i):
+        ctl, lines = h[i]
+        out_ = [f'.Lh{i}_%=:']
+        if ctl:
+            out_ += [f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]',
+                     's_cbranch_scc0 .Lnext_%=',
+                     f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}',
+                     f's_and_saveexec_b64 {SAVE}, vcc', 's_cbranch_execz .Lrestore_%=']
+        out_ += lines
+        if ctl:
+            out_.append(f's_mov_b64 exec, {SAVE}')
+        return out_ + nxt
+
+    text = [f's_mov_b64 {KG}, %[kg]', f's_mov_b32 {GOFF}, 0', f's_mov_b32 {GEND}, %[gend]', f's_mov_b64 {MB}, %[mb]',
+            f's_mov_b32 {MOFF}, %[moff]', f's_mov_b64 {TG}, %[tg]', f's_mov_b32 {LDSB}, %[ldsb]',
+            # slot offsets of the load layout; byte shifts of the lane bits (load, store) and what they add to the
+            # thread's tile-local base (WaveKernPass::load_off .. tb_contrib)
+            f's_load_dwordx8 s[40:47], %[ks], 0', f's_load_dwordx2 s[48:49], %[ks], 32',
+            f's_load_dwordx8 s[{REC}:{REC + 7}], %[ks], 80', f's_load_dwordx8 s[{REC2}:{REC2 + 7}], %[ks], 112',
+            f's_load_dwordx2 s[{MAT}:{MAT + 1}], %[ks], 144',
+            f'v_and_b32 {LANE}, 63, %[tid]', f'v_mov_b32 {HR}, 1.0', f'v_mov_b32 {HI}, 0',
+            's_mov_b32 s56, 0xc0000000', 's_mov_b32 s57, 0xc0000000']
+    text += [f'v_bfe_i32 {LB[b]}, {LANE}, {b}, 1' for b in range(6)]          # (sign-extended: 0 or all ones)
+    text += ['v_mov_b32 v2, 0', 'v_mov_b32 v3, 0', 'v_mov_b32 v4, 0', 'v_mov_b32 v5, 0', 's_waitcnt lgkmcnt(0)']
+    text += [f'v_and_b32 {TB}, s{REC + 12}, {LB[0]}'] + [f'v_and_or_b32 {TB}, {LB[b]}, s{REC + 12 + b}, {TB}' for b in range(1, 6)]
+    for b in range(6):
+        for lo, hi, sh in (('v2', 'v3', REC + b), ('v4', 'v5', REC + 6 + b)):
+            text += [f'v_and_b32 v32, 1, {LB[b]}', 'v_mov_b32 v33, 0', f'v_lshlrev_b64 v[32:33], s{sh}, v[32:33]',
+                     f'v_or_b32 {lo}, {lo}, v32', f'v_or_b32 {hi}, {hi}, v33']
+    text += gray_walk('load', '%[inb]', LLD)
+    text += [f's_getpc_b64 {TABLE}', '.Lanchor_%=:', 's_add_u32 s54, s54, .Ltable_%=-.Lanchor_%=', 's_addc_u32 s55, s55, 0',
+             's_waitcnt vmcnt(0)', 's_branch .Lloop_%=']
+    for i in front:
+        text += emit(i)
+    text += ['.Lrestore_%=:', f's_mov_b64 exec, {SAVE}', '.Lnext_%=:'] + nxt
+    text += ['.Lloop_%=:',
+             f's_load_dwordx8 s[{REC}:{REC + 7}], {KG}, {GOFF}',
+             f's_load_dwordx8 s[{MAT}:{MAT + 7}], {MB}, {MOFF}',
+             's_waitcnt lgkmcnt(0)',
+             f's_add_u32 {GOFF}, {GOFF}, 32',
+             f's_lshl3_add_u32 {MOFF}, s{REC + 4}, {MOFF}',
+             f's_lshl2_add_u32 vcc_lo, s{REC}, s54', 's_addc_u32 vcc_hi, s55, 0', 's_setpc_b64 vcc',
+             '.Ltable_%=:']
+    for i in range(NIDS):
+        text.append(f's_branch .Lh{i}_%=' if i in h else 's_branch .Lnext_%=')
+    # ---- epilogue: the pass's deferred factor, then the stores ----
+    text += ['.Lexit_%=:', 's_load_dwordx8 s[40:47], %[ks], 40', 's_load_dwordx2 s[48:49], %[ks], 72',
+             's_waitcnt lgkmcnt(0)',          # (the slot offsets -- and the LDS reads of a trip that ended the pass)
+             f'v_readfirstlane_b32 {STMP}, {HI}', f'v_mov_b32 v10, {HR}', f'v_mov_b32 v11, {HR}',
+             f's_cmp_eq_u32 {STMP}, 0', 's_cbranch_scc0 .Lcplx_%=']
+    text += [f'v_pk_mul_f32 {A(j)}, {A(j)}, v[10:11]' for j in range(NA)]
+    text += ['s_branch .Lstore_%=', '.Lcplx_%=:', f'v_mov_b32 v12, {HI}', f'v_mov_b32 v13, {HI}']
+    for j in range(NA):
+        t = 'v[14:15]' if j % 2 == 0 else 'v[16:17]'
+        text += [f'v_pk_mul_f32 {t}, {A(j)}, v[12:13] op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]',
+                 f'v_pk_fma_f32 {A(j)}, {A(j)}, v[10:11], {t}']
+    text += ['.Lstore_%=:']
+    text += gray_walk('store', '%[outb]', LST)
+    text += ['s_branch .Ldone_%=']
+    for i in back:
+        text += emit(i)
+    text += ['.Ldone_%=:']
+    return text
+
+
+out = ['// GENERATED by tools/gen_wave_asm.py -- do not edit by hand.', '// clang-format off',
+       f'#define DQ_WAVE_NIDS {NIDS}', f'#define DQ_WAVE_MAXK {MAXK}',
+       f'#define DQ_WID_GEN_U {ID_GEN_U}', f'#define DQ_WID_GEN_C {ID_GEN_C}', f'#define DQ_WID_GEN_R {ID_GEN_R}',
+       f'#define DQ_WID_X_U {ID_X_U}', f'#define DQ_WID_X_C {ID_X_C}', f'#define DQ_WID_X_R {ID_X_R}', f'#define DQ_WID_X_R1 {ID_X_R1}',
+       f'#define DQ_WID_TRIP0 {ID_TRIP0}', f'#define DQ_WID_TRIP {ID_TRIP}', f'#define DQ_WID_SWAP {ID_SWAP}',
+       '// trip handler id by slot mask (popcount 1..DQ_WAVE_MAXK), -1 otherwise; slot-swap handler id by (i < j)',
+       'static const short kWaveTripId[64] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(64)) + '};',
+       'static const short kWaveSwapId[6][6] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
+       '']
+text = '\\n\\t"\n        "'.join(kernel_body())
+clob = ', '.join([f'"s{i}"' for i in range(40, 96)] + [f'"v{i}"' for i in range(1, AMP0 + 2 * NA)])
+out += ['// kg = address of the records, gend = their size in bytes; mb + moff = address of the first matrix; tg = the index',
+        '// bits this tile fixes; ks = address of WaveKernPass::load_off (slot offsets, lane shifts); inb / outb = tile bases;',
+        '// ldsb = the wave\'s LDS region; tid = threadIdx.x',
+        '__device__ __forceinline__ void wave_tile_body_f32(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg,',
+        '                                                   uint64_t ks, uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid) {',
+        f'    asm volatile(\n        "{text}"',
+        '        :',
+        '        : [kg] "s"(kg), [gend] "s"(gend), [mb] "s"(mb), [moff] "s"(moff), [tg] "s"(tg), [ks] "s"(ks), [inb] "s"(inb),',
+        '          [outb] "s"(outb), [ldsb] "s"(ldsb), [tid] "v"(tid)',
+        f'        : "vcc", "scc", "memory", {clob});',
+        '}', '// clang-format on', '']
+path = os.environ.get('DQ_ASM_OUT') or os.path.join(os.path.dirname(__file__), '..', 'deepquantum_amd', 'csrc', 'dq_wave_asm.inc')
+open(path, 'w').write('\n'.join(out))
+print('generated', len(out), 'lines;', NIDS, 'handler ids;', sum(len(v[1]) for v in handlers().values()), 'handler instructions')
