@@ -73,6 +73,8 @@ def parse_args():
     ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
     ap.add_argument('--plan-restarts', type=int, default=None, help='pass planner: beam searches with different seeds')
     ap.add_argument('--no-asm-loop', action='store_true', help='A/B: gate loop in C++ around the jump table')
+    ap.add_argument('--no-wave', action='store_true',
+                    help='A/B: complex64 on the workgroup-tile kernels (13-bit tiles, barriers) instead of the wave-tile kernel')
     ap.add_argument('--no-compare', action='store_true',
                     help='skip the extra runs (merging off, single-gate sweep): tools/profile.sh uses it so that the '
                          'profiled launches are the timed ones only')
@@ -338,6 +340,8 @@ def main():
     dq.executor.CONFIG['plan_restarts'] = args.plan_restarts
     if args.no_asm_loop:
         dq.executor.CONFIG['asm_loop'] = False
+    if args.no_wave:
+        dq.executor.CONFIG['wave'] = False
     if args.no_merge:
         dq.executor.CONFIG['merge_min_amps'] = None
     if args.no_permute_store:
