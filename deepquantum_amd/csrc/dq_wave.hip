@@ -24,6 +24,7 @@
 #include "dq_common.hpp"
 #include <stddef.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace dq {
 
@@ -340,7 +341,12 @@ int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bst
     if (rc) return rc;
     const uint64_t tiles = 1ull << (n - WAVE_M);
     dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)batch);
-    hipLaunchKernelGGL(wave_pass_kernel, grid, dim3(256), 4 * WAVE_LDS_PER_WAVE, s, static_cast<const float2*>(in),
+    size_t lds = 4 * WAVE_LDS_PER_WAVE;
+    if (const char* kb = getenv("DQ_WAVE_LDS_KB")) {      // occupancy experiments: workgroups per CU = 160 KiB / this
+        lds = (size_t)atoi(kb) << 10;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(wave_pass_kernel, grid, dim3(256), lds, s, static_cast<const float2*>(in),
                        static_cast<float2*>(out), static_cast<const float2*>(mats), mat_bstride, in_bstride, n, 0, kp);
     return check_launch("dq_apply_fused (wave tile)");
 }

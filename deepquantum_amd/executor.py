@@ -244,7 +244,11 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
     return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps)
 
 
-_MERGE_COST = {3: 30, 2: 37, 1: 45, 0: 79}    # issue slots of a wave per one-qubit gate, by matrix structure
+# Issue slots of a wave per one-qubit gate, by matrix structure, on the workgroup-tile kernels.  They also decide
+# for the wave-tile kernel: with ITS costs (64 / 192 / 128 / 256 packed operations + ~12 slots of dispatch) Hadamard x Rx
+# would merge into a general matrix -- 20 % fewer gates, the same arithmetic -- and the step gets 5 % SLOWER (measured,
+# one box: 282 vs 268 ms): a general matrix commutes with nothing, so the scheduler loses the freedom the Rx-like factor had.
+_MERGE_COST = {3: 30, 2: 37, 1: 45, 0: 79}
 
 
 _MERGE_CACHE: OrderedDict = OrderedDict()
@@ -253,6 +257,7 @@ _MERGE_CACHE: OrderedDict = OrderedDict()
 def _merge_structure(prims: Sequence[Prim]):
     """Which gates of ``prims`` multiply into which product (a function of the circuit structure only; cached):
     (groups [members in order of application, mode of the product], order of the output list)."""
+    cost = _MERGE_COST
     key = tuple((p.kind, p.targets, p.controls, p.mode, p.unitary) for p in prims)
     hit = _MERGE_CACHE.get(key)
     if hit is not None:
@@ -271,7 +276,7 @@ def _merge_structure(prims: Sequence[Prim]):
                 mode = groups[g][1]
                 if nothing[q] or (only_x[q] and mode == 2 and p.mode == 2):
                     new = 2 if (mode == 2 and p.mode == 2) else 1 if (mode in (1, 3) and p.mode in (1, 3)) else 0
-                    if _MERGE_COST[new] <= _MERGE_COST[mode] + _MERGE_COST[p.mode] - 5:
+                    if cost[new] <= cost[mode] + cost[p.mode] - 5:
                         groups[g][0].append(i)
                         groups[g][1] = new
                         continue

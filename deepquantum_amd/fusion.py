@@ -593,12 +593,20 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
             wphys = [None] * n
             for i, b in enumerate(nlow):
                 wphys[b] = i
-            keep = [b for b in nhigh if phys[b] in near]             # already cheap: stay
-            for b in keep:
-                wphys[b] = phys[b]
-            free = [p_ for p_ in near if p_ not in {phys[b] for b in keep}]
-            for b in sorted(nhigh - set(keep), key=lambda b: phys[b]):
-                wphys[b] = free.pop(0)
+            if geom.wave:
+                # the qubits this pass has in its own tile first: index bits L, L + 1, .. then extend the contiguous
+                # runs it writes (a tile bit written to bit L doubles them to 256 bytes: +5 % on the wave-tile kernel,
+                # tools/experiments/mb_wavetile.hip); which of its bits a tile reads where does not matter to the reader
+                mine = set(low_list) | set(high)
+                for b, pos in zip(sorted(nhigh, key=lambda b: (b not in mine, phys[b])), near):
+                    wphys[b] = pos
+            else:
+                keep = [b for b in nhigh if phys[b] in near]             # already cheap: stay
+                for b in keep:
+                    wphys[b] = phys[b]
+                free = [p_ for p_ in near if p_ not in {phys[b] for b in keep}]
+                for b in sorted(nhigh - set(keep), key=lambda b: phys[b]):
+                    wphys[b] = free.pop(0)
             taken = {w for w in wphys if w is not None}
             rest = [p_ for p_ in range(n) if p_ not in taken]
             for b in sorted((b for b in range(n) if wphys[b] is None), key=lambda b: phys[b]):
@@ -774,7 +782,10 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         # stores two adjacent amplitudes), the tile bits written to index bits vb .. L-1 on the lowest lane bits (128
         # contiguous bytes per 8 lanes), the other thread bits in the order of their write positions
         store_rb = to_low[:vb]
-        for c in list(layouts[-1][0]) + list(range(m - 1, -1, -1)):
+        # (wave tile: a layout change costs next to nothing, so the slots are simply the tile bits written FARTHEST away
+        # and the lanes of a store instruction cover the longest contiguous runs the write positions allow)
+        prefer = sorted(range(m), key=lambda tl: -wtile[tl]) if geom.wave else list(layouts[-1][0]) + list(range(m - 1, -1, -1))
+        for c in prefer:
             if len(store_rb) >= R:
                 break
             if c not in store_rb and c not in to_low:

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deepquantum_amd as dq
 import bench
 from bench import random_circuit_spec
-n, depth, batch = 28, 40, int(os.environ.get('B', 4))
+n, depth, batch = 28, 40, int(os.environ.get('B', 16))
 dev = torch.device('cuda', 0)
 spec = random_circuit_spec(n, depth, 1234)
 cir, data = bench.build_circuit(dq, n, spec, batch, torch.complex64, dev)
@@ -26,5 +26,16 @@ for i, (s, (a, b, ng, _nb)) in enumerate(zip(steps, ev)):
         op = plan.prim_ops[oi]
         k = 'x' if op.kind == 'x' else ('h' if op.mode == 1 else 'rx' if op.mode == 2 else 'g')
         kinds[k] = kinds.get(k, 0) + 1
-    print(f'pass {i:2d}: gates {len(s.ops):3d} {kinds} rounds {s.nrounds} trips {s.ntranspose}  {ms:6.2f} ms')
+    extra = ''
+    if s.desc.slots == 6:        # wave tile: what the library made of the rounds (csrc/dq_wave.hip)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+        import _wave_emulator as emu
+        g = emu.gen()
+        kp = emu.descriptor(s.desc, n)
+        ids = [kp.rec[j][0] for j in range(kp.nrec_bytes // 32)]
+        trips = [g.TRIP_MASKS[j - g.ID_TRIP] for j in ids if g.ID_TRIP <= j < g.ID_SWAP]
+        extra = (f' records {len(ids)} trips k={[bin(t).count("1") for t in trips]} lane-perm {ids.count(g.ID_TRIP0)} '
+                 f'swaps {sum(j >= g.ID_SWAP for j in ids)} read {sorted(s.desc.high_sorted[j] for j in range(s.desc.h))} '
+                 f'write-lanes {sorted(kp.store_lane_shift[j] - 3 for j in range(6))} write-slots {sorted(int(kp.store_off[j]).bit_length() - 4 for j in range(5))}')
+    print(f'pass {i:2d}: gates {len(s.ops):3d} {kinds} rounds {s.nrounds} trips {s.ntranspose}  {ms:6.2f} ms{extra}')
 print('total', tot)

@@ -51,19 +51,40 @@ def pair_general(lo, hi, t, u):
             f'v_pk_fma_f32 {a_}, {a_}, {M[0]}, {t} {RE3}', f'v_pk_fma_f32 {b_}, {b_}, {M[3]}, {u} {RE3}']
 
 
+def interleave(seqs):
+    """Instruction lists of independent computations merged round-robin: no instruction reads what the one right before
+    it wrote (a dependent packed operation waits ~2 issue slots of its wave; the H and Rx bodies have no such pairs)."""
+    out_, i = [], 0
+    while any(i < len(s_) for s_ in seqs):
+        out_ += [s_[i] for s_ in seqs if i < len(s_)]
+        i += 1
+    return out_
+
+
 def body(mode, q):
     lines = []
-    for k, (lo, hi) in enumerate(pairs(q)):
-        t, u = (T0, U0) if k % 2 == 0 else (T1, U1)
-        a_, b_ = A(lo), A(hi)
-        if mode == 3:      # s [[1, 1], [1, -1]], s deferred: all sums first, then all differences B' = A' - 2 B
-            lines.insert(k, f'v_pk_add_f32 {a_}, {a_}, {b_}')
-            lines.append(f'v_pk_fma_f32 {b_}, {b_}, {HADC}, {a_}')
-        elif mode == 1:    # all entries real
-            lines += [f'v_pk_mul_f32 {t}, {b_}, {M[1]} {RE2}', f'v_pk_mul_f32 {u}, {a_}, {M[2]} {RE2}',
-                      f'v_pk_fma_f32 {a_}, {a_}, {M[0]}, {t} {RE3}', f'v_pk_fma_f32 {b_}, {b_}, {M[3]}, {u} {RE3}']
+    ps = pairs(q)
+    if mode == 3:      # s [[1, 1], [1, -1]], s deferred: all sums first, then all differences B' = A' - 2 B
+        for lo, hi in ps:
+            lines.append(f'v_pk_add_f32 {A(lo)}, {A(lo)}, {A(hi)}')
+        for lo, hi in ps:
+            lines.append(f'v_pk_fma_f32 {A(hi)}, {A(hi)}, {HADC}, {A(lo)}')
+        return lines
+    for k in range(0, len(ps), 2):      # two pairs at a time: four independent chains
+        seqs = []
+        for (lo, hi), (t, u) in zip(ps[k:k + 2], ((T0, U0), (T1, U1))):
+            a_, b_ = A(lo), A(hi)
+            if mode == 1:    # all entries real
+                seqs += [[f'v_pk_mul_f32 {t}, {b_}, {M[1]} {RE2}', f'v_pk_fma_f32 {a_}, {a_}, {M[0]}, {t} {RE3}'],
+                         [f'v_pk_mul_f32 {u}, {a_}, {M[2]} {RE2}', f'v_pk_fma_f32 {b_}, {b_}, {M[3]}, {u} {RE3}']]
+            else:
+                g_ = pair_general(lo, hi, t, u)
+                seqs += [g_[0::2], g_[1::2]]
+        if mode == 1:
+            # (the real body overwrites A before the second chain has read it: keep the reads first)
+            lines += [s_[0] for s_ in seqs] + [s_[1] for s_ in seqs]
         else:
-            lines += pair_general(lo, hi, t, u)
+            lines += interleave(seqs)
     return lines
 
 
