@@ -180,6 +180,7 @@ class _on:
 def _settle(state: DistributedQubitState) -> None:
     """Join the group streams: everything in flight for this state (exchanges included) is ordered before whatever the
     current stream does next."""
+    keep = state.__dict__.pop('_inflight_keep', None)
     for stream, works in state.__dict__.pop('_inflight', []):
         if stream is not None:
             with torch.cuda.stream(stream):
@@ -189,6 +190,7 @@ def _settle(state: DistributedQubitState) -> None:
         else:
             for w in works:
                 w.wait()
+    del keep        # (the matrices the group streams were reading: only now may their memory be reused)
 
 
 def _rows_of(pending: Sequence[Prim], rows: slice, total: int) -> list[Prim]:
@@ -434,6 +436,12 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     for st, works in inflight_prev.values():                          # (streams of another grouping: join them)
         inflight.append((st, works))
     state.__dict__['_inflight'] = inflight
+    # The passes queued on the group streams read the matrices of `pending` -- some of them temporaries that
+    # `_localize` made on the main stream (rank-selected phases of diagonal gates on global qubits).  Dropping the last
+    # reference here would hand their memory back to the caching allocator while that work is still queued, and the
+    # next main-stream allocation could overwrite it: they stay referenced until `_settle` has joined the streams.
+    if any(st is not None for st, _ in inflight):
+        state.__dict__.setdefault('_inflight_keep', []).append(list(pending))
     if not all(landed_in_a):
         if any(landed_in_a):         # groups disagree on the buffer they ended in (never with equal group sizes)
             _settle(state)

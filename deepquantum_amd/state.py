@@ -104,6 +104,17 @@ class DistributedQubitState(_ComplexBuffers):
         # qubits wherever its last remap put them (distributed.dist_run(keep_layout=True): the exchange back is only
         # paid by who looks at the amplitudes -- expectation values of Pauli strings do not), and the canonical order
         # is restored here, on first access.  The routines of distributed.py work on the raw shard (`_raw`).
+        if name in ('amps', 'buffer'):
+            # a big shard is not built by the constructor (LAZY_AMPS): whoever touches it first builds |0...0> on the
+            # device the state lives on by then -- gate routines, `cir(state=s)`, load_state_dict all see a usable shard
+            d = self.__dict__
+            t = super().__getattr__(name)
+            if tuple(t.shape) != tuple(d.get('_shape', t.shape)) and not d.get('_building'):
+                d['_building'] = True
+                try:
+                    self.reset()
+                finally:
+                    d['_building'] = False
         if name == 'amps':
             d = self.__dict__
             ph = d.get('_phys')

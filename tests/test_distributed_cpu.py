@@ -378,6 +378,32 @@ def test_single_process_world_of_one(cpu_backend):
     assert (shard().amps - dense().reshape(-1)).abs().max().item() < 1e-6
 
 
+def test_lazily_built_shard_is_usable_by_everyone(cpu_backend, monkeypatch):
+    """A shard bigger than LAZY_AMPS is not allocated by the constructor (2^31 amplitudes must not pass through host
+    memory); whoever touches it first -- a gate routine, ``cir(state=s)``, ``state_dict`` -- finds |0...0> (the
+    reference always constructs a usable shard, state.py:342-383)."""
+    import deepquantum_amd as dq
+    from deepquantum_amd.state import DistributedQubitState
+
+    monkeypatch.setattr(DistributedQubitState, 'LAZY_AMPS', 4)
+    s = DistributedQubitState(5)
+    assert tuple(s._buffers['amps'].shape) == (0,)                 # not built yet
+    assert tuple(s.amps.shape) == (32,) and s.amps[0] == 1 and s.amps.abs().sum() == 1
+    assert tuple(s.buffer.shape) == (32,)
+    s2 = DistributedQubitState(5)
+    assert tuple(s2.state_dict()['amps'].shape) == (32,)
+    cir = dq.DistributedQubitCircuit(5)
+    cir.h(0)
+    cir.cnot(0, 4)
+    out = cir(state=DistributedQubitState(5))
+    dense = dq.QubitCircuit(5)
+    dense.h(0)
+    dense.cnot(0, 4)
+    assert (out.amps - dense().reshape(-1)).abs().max().item() < 1e-6
+    s3 = DistributedQubitState(5, batch=3)
+    assert tuple(s3.amps.shape) == (3, 32) and torch.all(s3.amps[:, 0] == 1)
+
+
 def test_gates_reordered_along_the_commutation_dag_need_fewer_exchanges():
     """distributed._order_for_remaps: a permutation of the gate list that keeps every pair of non-commuting gates in
     order (so the circuit is the same operator: checked on a random state with the oracle), and that cuts the

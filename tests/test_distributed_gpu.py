@@ -1,7 +1,8 @@
 """The sharded path with the REAL kernels: two (and four) ranks share the one GPU of the test box and
 exchange through gloo (host staged), so the pack / unpack / permute-bits kernels, the per-rank predicates
-and the remap planner run end to end on HIP.  RCCL itself needs one GPU per rank and is exercised by
-``bench.py --gpus N`` only."""
+and the remap planner run end to end on HIP.  RCCL needs one GPU per rank: here it runs at world size 1
+(``test_rccl_process_group_of_one_on_the_gpu``: every call, dtype view and stream hand-off of the N > 1 path), between
+ranks by ``bench.py --gpus N`` only."""
 
 import os
 import socket
@@ -24,7 +25,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, case, ret):
+def _worker(rank, world, port, case, ret, backend='gloo'):
     try:
         sys.path.insert(0, os.path.dirname(HERE))
         sys.path.insert(0, HERE)
@@ -34,7 +35,7 @@ def _worker(rank, world, port, case, ret):
         import deepquantum_amd as dq
 
         torch.cuda.set_device(0)
-        dq.setup_distributed('gloo')
+        dq.setup_distributed(backend)
         globals()['_case_' + case](dq, rank, world)
         dq.cleanup_distributed()
         ret[rank] = 'ok'
@@ -42,11 +43,11 @@ def _worker(rank, world, port, case, ret):
         ret[rank] = traceback.format_exc()
 
 
-def _run(case, world):
+def _run(case, world, backend='gloo'):
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, case, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, case, ret, backend), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == 'ok', f'rank {r}: {ret.get(r)}'
 
@@ -226,6 +227,91 @@ def _case_measure(dq, rank, world):
     # the circuit-level entry point (DistributedQubitCircuit.measure) takes the same path
     res = shard.measure(shots=64, wires=[0, n - 1])
     assert (rank == 0) == bool(res)
+
+
+def _case_rccl(dq, rank, world):
+    """Every RCCL call, dtype view and stream hand-off that ``bench.py --gpus N`` hits first, on the one GPU of the test
+    box (process group 'nccl' = RCCL, world size 1; reference: communication.py:9-35, 58-91): asynchronous
+    all_to_all_single on a side stream with complex shards viewed as reals, work.wait(), joining the streams, the
+    pairwise exchange helper, all_reduce of the small results, and a sharded circuit -- forward, expectation, adjoint
+    backward -- in both exchange modes.  It cannot test a remap between ranks; it does test that nothing on that path
+    raises, hangs or mis-orders streams."""
+    import torch.distributed as dist
+
+    import specs
+    from deepquantum_amd import communication as C
+    from deepquantum_amd import distributed as D
+
+    assert dist.get_backend() == 'nccl' and world == 1
+    dev = torch.device('cuda', 0)
+    for dtype in (torch.complex64, torch.complex128):
+        g = torch.Generator().manual_seed(3)
+        send = torch.randn(1 << 16, generator=g, dtype=torch.float64).to(dtype).to(dev) * (1 + 2j)
+        recv = torch.zeros_like(send)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            sr, rr = torch.view_as_real(send).reshape(-1), torch.view_as_real(recv).reshape(-1)
+            w = C.all_to_all_flat(rr, sr, [sr.numel()], async_op=True)
+            assert w is not None
+            w.wait()                                    # orders the collective before the side stream's next kernel
+            doubled = recv * 2
+        torch.cuda.current_stream(dev).wait_stream(side)
+        assert torch.equal(recv, send) and torch.equal(doubled, send * 2)
+        recv.zero_()
+        C.comm_exchange_arrays(send, recv, None)        # the pairwise helper: nobody to talk to at world size 1
+        torch.cuda.synchronize()
+        assert not recv.any()
+        # the small collectives of the reductions (inner products, marginals): complex scalars travel as reals
+        z = torch.tensor([1.5 - 2j], dtype=dtype, device=dev)
+        zr = torch.view_as_real(z)
+        dist.all_reduce(zr)
+        assert torch.equal(z.cpu(), torch.tensor([1.5 - 2j], dtype=dtype))
+    n = 12
+    spec = specs.random_spec(n, 5, 31)
+    dense = _build(dq, dq.QubitCircuit, n, spec)
+    for mode in ('remap', 'pairwise'):
+        D.CONFIG['mode'] = mode
+        try:
+            shard = _build(dq, dq.DistributedQubitCircuit, n, spec)
+            with torch.no_grad():
+                ref = dense().reshape(-1)
+                ref_ev = dense.expectation()
+                st = shard()
+                ev = shard.expectation()
+            assert (st.amps - ref).abs().max().item() < 1e-5, mode
+            assert (ev.reshape(-1) - ref_ev.reshape(-1)).abs().max().item() < 1e-5, mode
+            # batched shards: sample groups on their own streams, each with its own (self) exchange in flight
+            data = torch.rand(4, max(1, shard.ndata), device=dev) if shard.ndata else None
+            if data is not None:
+                with torch.no_grad():
+                    sb = shard(data)
+                    rb = dense(data)
+                assert (sb.amps - rb.reshape(4, -1)).abs().max().item() < 1e-5
+        finally:
+            D.CONFIG['mode'] = 'remap'
+    # adjoint-mode gradient through the sharded state (reference: adjoint.py:19-83, circuit.py:1706-1738)
+    qa = dq.DistributedQubitCircuit(8)
+    qd = dq.QubitCircuit(8)
+    th_a = torch.tensor([0.3, 1.1, -0.4], device=dev, requires_grad=True)
+    th_d = th_a.detach().clone().requires_grad_(True)
+    for cir, th in ((qa, th_a), (qd, th_d)):
+        cir.hlayer()
+        cir.rx(0, encode=True)
+        cir.cnot(0, 7)
+        cir.ry(7, encode=True)
+        cir.cnot(7, 3)
+        cir.rz(3, encode=True)
+        cir.observable([0, 7])
+        cir.observable(3, 'x')
+        cir.to(dev)
+        cir(th)
+        cir.expectation().sum().backward()
+    assert (th_a.grad - th_d.grad).abs().max().item() < 1e-5
+
+
+def test_rccl_process_group_of_one_on_the_gpu():
+    _run('rccl', 1, backend='nccl')
 
 
 def test_reference_dist_tests_on_gpu_world_of_one():

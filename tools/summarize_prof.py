@@ -25,14 +25,14 @@ for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq1', 'pmc_sq2'):
     acc = counters(sub)
     print('# counters:', sub)
     for k, d in acc.items():
-        if 'fused' not in k:
+        if 'fused' not in k and 'wave_pass' not in k:
             continue
         for c, v in d.items():
             print('  %-55s %-22s launches %5d  mean/launch %.4g' % (k, c, len(v), sum(v) / len(v)))
 
 f = counters('pmc_fetch'); w = counters('pmc_write')
 for k in f:
-    if 'fused' in k and k in w:
+    if ('fused' in k or 'wave_pass' in k) and k in w:
         fs = f[k]['FETCH_SIZE']; ws = w[k]['WRITE_SIZE']
         fb = sum(fs) / len(fs) * 1024 * 2   # KiB -> bytes, x2 gfx950 correction for 16 B/lane streams
         wb = sum(ws) / len(ws) * 1024
@@ -41,7 +41,7 @@ for k in f:
 # machine-readable traffic record for bench.py (--traffic-json / profiles/traffic_*.json)
 import json
 for k in f:
-    if 'fused' in k and k in w:
+    if ('fused' in k or 'wave_pass' in k) and k in w:
         fs = f[k]['FETCH_SIZE']; ws = w[k]['WRITE_SIZE']
         rec = {'kernel': k, 'launches': len(fs), 'hbm_bytes_per_launch': sum(fs) / len(fs) * 2048 + sum(ws) / len(ws) * 1024,
                'fetch_size_kib_mean': sum(fs) / len(fs), 'write_size_kib_mean': sum(ws) / len(ws),
