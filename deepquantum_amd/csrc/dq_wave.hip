@@ -266,12 +266,11 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
         if (!x.go(want, nullptr)) goto fail;
         for (int gi = rd.gate_begin & 0x7f; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
-            if (g.kind != DQ_FG_GEN1 && g.kind != DQ_FG_X1) {
-                set_error("dq_apply_fused: the wave-tile kernel takes one-target gates (record %d has kind %d); plan this "
-                          "circuit for a workgroup-tile geometry", gi, (int)g.kind);
+            if (g.kind != DQ_FG_GEN1 && g.kind != DQ_FG_X1 && g.kind != DQ_FG_DIAG1 && g.kind != DQ_FG_DIAG2) {
+                set_error("dq_apply_fused: the wave-tile kernel takes one-target and diagonal gates (record %d has kind %d); "
+                          "plan this circuit for a workgroup-tile geometry", gi, (int)g.kind);
                 return DQ_ERR_UNSUPPORTED;
             }
-            const int q = x.slot_of(rd.rb[g.q]);
             unsigned pc = 0;
             int nc = 0, onec = 0;
             for (int s = 0; s < WAVE_R; ++s)
@@ -285,6 +284,52 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
             rec.w[1] = g.thr_cmask;
             rec.w[2] = (uint32_t)g.out_cmask, rec.w[3] = (uint32_t)(g.out_cmask >> 32);
             rec.w[4] = g.mat_advance;
+            if (g.kind == DQ_FG_DIAG1 || g.kind == DQ_FG_DIAG2) {
+                // a phase per amplitude: PH0 / PH1 by the bit of one register slot (or PH0 for all), each picked per lane
+                // from the gate's diagonal by up to two selectors (targets on thread bits / outside the tile) --
+                // csrc/dq_wave_asm.inc, diag_code; controls on register slots become a mask over the 64 registers
+                auto regmask = [&](unsigned must_set, unsigned must_clear) {
+                    uint64_t mk = 0;
+                    for (unsigned j = 0; j < 64; ++j)
+                        if ((j & must_set) == must_set && (j & must_clear) == 0) mk |= 1ull << j;
+                    return mk;
+                };
+                auto selector = [&](int loc, int q_) -> uint32_t {
+                    return loc == DQ_LOC_THR ? ((1u << 6) | (uint32_t)q_) : loc == DQ_LOC_OUT ? ((2u << 6) | (uint32_t)q_) : 0u;
+                };
+                auto put = [&](int base, int variant, bool masked, uint32_t selA, uint32_t selB, uint32_t idx0, uint32_t idx1,
+                               uint64_t mk, uint32_t advance) {
+                    WaveRec r2 = rec;
+                    r2.w[0] = (uint32_t)(base + variant + (masked ? 7 : 0));
+                    r2.w[4] = advance;
+                    r2.w[5] = selA | (selB << 8) | (idx0 << 16) | (idx1 << 24);
+                    r2.w[6] = (uint32_t)mk, r2.w[7] = (uint32_t)(mk >> 32);
+                    return x.push(r2);
+                };
+                const bool masked = nc > 0;
+                const uint64_t ctlmask = regmask(pc, 0);
+                bool ok;
+                if (g.kind == DQ_FG_DIAG1) {
+                    if (g.loc == DQ_LOC_REG) ok = put(DQ_WID_DIAG1, 1 + x.slot_of(rd.rb[g.q]), masked, 0, 0, 0x00, 0x55, ctlmask, 4);
+                    else ok = put(DQ_WID_DIAG1, 0, masked, 0, selector(g.loc, g.q), 0x44, 0, ctlmask, 4);
+                } else {
+                    const bool r1 = g.loc == DQ_LOC_REG, r2_ = g.loc2 == DQ_LOC_REG;
+                    const int p1 = r1 ? x.slot_of(rd.rb[g.q]) : -1, p2 = r2_ ? x.slot_of(rd.rb[g.q2]) : -1;
+                    if (r1 && r2_) {    // both targets on register slots: the halves of slot p1, by the bit of slot p2
+                        ok = put(DQ_WID_DIAG2, 1 + p2, true, 0, 0, 0x00, 0x55, regmask(pc, 1u << p1), 16) &&
+                             put(DQ_WID_DIAG2, 1 + p2, true, 0, 0, 0xAA, 0xFF, regmask(pc | (1u << p1), 0), 0);
+                    } else if (r1) {
+                        ok = put(DQ_WID_DIAG2, 1 + p1, masked, selector(g.loc2, g.q2), 0, 0x10, 0x32, ctlmask, 16);
+                    } else if (r2_) {
+                        ok = put(DQ_WID_DIAG2, 1 + p2, masked, selector(g.loc, g.q), 0, 0x20, 0x31, ctlmask, 16);
+                    } else {
+                        ok = put(DQ_WID_DIAG2, 0, masked, selector(g.loc, g.q), selector(g.loc2, g.q2), 0xE4, 0, ctlmask, 16);
+                    }
+                }
+                if (!ok) goto fail;
+                continue;
+            }
+            const int q = x.slot_of(rd.rb[g.q]);
             if (nc > 0) {       // pair i of slot q = the i-th register pattern with bit q clear
                 uint32_t pm = 0;
                 for (int j = 0, i = 0; j < 64; ++j) {

@@ -88,7 +88,7 @@ int dq_set_dense_path(int mfma);
  *    wave-private LDS buffer.  For such a pass the library derives everything below the level of "which tile bits are
  *    register slots in which round" itself (csrc/dq_wave.hip translates the descriptor into the kernel's records):
  *    the order of a round's slots and of its thread bits, `fast`, DQ_ROUND_ALL_FAST, DQ_ROUND_SWAP and lds_tab are
- *    not used (fast must be DQ_FAST_NONE), and this build takes DQ_FG_GEN1 and DQ_FG_X1 records there (anything
+ *    not used (fast must be DQ_FAST_NONE), and this build takes DQ_FG_GEN1, DQ_FG_X1, DQ_FG_DIAG1 and DQ_FG_DIAG2 records there (anything
  *    else: DQ_ERR_UNSUPPORTED -- plan such circuits for a workgroup-tile geometry).  The workgroup-tile geometries
  *    (complex64 variants 1, 2: m = 13 / 12, 4 slots, 512 / 256 threads; complex128: m = 12 / 11, 3 slots) stage the
  *    tile in LDS between rounds, two barriers per change.

@@ -174,7 +174,7 @@ class CpuTestBackend:
                 for gi in range(first + nswap, rd.gate_end):
                     g = desc.gates[gi]
                     assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
-                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1), 'the wave-tile kernel takes one-target gates only'
+                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1, _lib.FG_DIAG1, _lib.FG_DIAG2), 'the wave-tile kernel takes one-target and diagonal gates only'
                     assert (g.reg_cmask >> R) == 0
                     cm = g.thr_cmask
                     for s in range(R):

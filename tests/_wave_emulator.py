@@ -161,6 +161,39 @@ def run_pass(desc, n, state, mats, mat_batch_stride):
                     continue
                 if not tile_ok:
                     continue
+                if hid >= g.ID_DIAG1:
+                    # diagonal gate (tools/gen_wave_asm.py, diag_code): four phases, candidates by the indices in w5,
+                    # two per-lane selectors, PH0 / PH1 by the bit of one register slot, an optional register mask
+                    four = hid >= g.ID_DIAG2
+                    variant = (hid - g.ID_DIAG1) % 14
+                    if four:
+                        blk = mb[moff - 16:moff]
+                        d = [blk[0], blk[5], blk[10], blk[15]]
+                    else:
+                        d = [m[0], m[3], m[0], m[3]]
+                    w5 = w[5]
+
+                    def sel(byte):
+                        kind, pos = (byte >> 6) & 3, byte & 63
+                        if kind == 1:
+                            return ((tb >> pos) & 1).astype(bool)
+                        if kind == 2:
+                            return np.full(64, bool((tg >> pos) & 1))
+                        return np.zeros(64, bool)
+
+                    sa, sb = sel(w5 & 0xFF), sel((w5 >> 8) & 0xFF)
+                    c0 = [d[(w5 >> (16 + 2 * k)) & 3] for k in range(4)]
+                    c1 = {k: d[(w5 >> (24 + 2 * k)) & 3] for k in (0, 2)}
+                    ph0 = np.where(sa, np.where(sb, c0[3], c0[2]), np.where(sb, c0[1], c0[0]))
+                    ph1 = np.where(sa, c1[2], c1[0])
+                    masked, v = variant >= 7, variant % 7
+                    rmask = w[6] | (w[7] << 32)
+                    for j in range(64):
+                        if masked and not (rmask >> j) & 1:
+                            continue
+                        ph = ph0 if v == 0 or not (j >> (v - 1)) & 1 else ph1
+                        a[active, j] = (a[:, j] * ph.astype(a.dtype))[active]
+                    continue
                 if g.ID_GEN_U <= hid < g.ID_GEN_C:
                     mode, q = divmod(hid - g.ID_GEN_U, 6)
                     everyone = np.ones(64, bool)

@@ -21,10 +21,18 @@ def random_ops(n, ngates, seed, modes=True):
     g = torch.Generator().manual_seed(seed)
     ops, mats, off = [], [], 0
     for _ in range(ngates):
-        kind = rng.choice(['gen', 'gen', 'x'])
+        kind = rng.choice(['gen', 'gen', 'x', 'diag', 'diag2'])
         nc = rng.choice([0, 0, 0, 1, 1, 2, 3])
-        bits = rng.sample(range(n), 1 + nc)
+        k = 2 if kind == 'diag2' else 1
+        bits = rng.sample(range(n), k + nc)
         mode = 0
+        if kind in ('diag', 'diag2'):
+            d = 1 << k
+            m = torch.diag(torch.exp(1j * torch.rand(d, generator=g, dtype=torch.float64) * 6.28))
+            ops.append(fusion.PrimOp('diag', tuple(bits[:k]), tuple(bits[k:]), off, 0))
+            mats.append(m.reshape(-1))
+            off += d * d
+            continue
         if kind == 'x':
             m = torch.tensor([[0, 1], [1, 0]], dtype=torch.complex128)
         else:
@@ -49,7 +57,8 @@ def random_ops(n, ngates, seed, modes=True):
 def reference(state, ops, mats):
     x = state
     for op in ops:
-        x = oracle.apply_gate_bits(x, mats[op.mat:op.mat + 4].reshape(2, 2), list(op.targets), list(op.controls))
+        d = 1 << op.k
+        x = oracle.apply_gate_bits(x, mats[op.mat:op.mat + d * d].reshape(d, d), list(op.targets), list(op.controls))
     return x
 
 
@@ -101,11 +110,12 @@ def test_trips_cover_every_slot_mask_and_stay_inside_the_buffer():
 
 
 def test_unsupported_records_are_refused(cpu_backend):
-    ops = [fusion.PrimOp('gen', (3,), (), 0, 0), fusion.PrimOp('diag', (5,), (), 4, 0)]
+    ops = [fusion.PrimOp('gen', (3,), (), 0, 0), fusion.PrimOp('gen', (5, 7), (), 4, 0)]
     geom = fusion.default_geometry(False)
     steps = fusion.schedule(ops, 13, geom)
     lib = _lib.load()
     import ctypes as C
     rc = lib.dq_wave_descriptor(C.byref(steps[0].desc), 13, None, 0)
-    assert rc == -3 and b'one-target' in lib.dq_last_error()
+    assert rc == -3 and b'one-target and diagonal' in lib.dq_last_error()
     assert not fusion.wave_supports(ops) and fusion.wave_supports(ops[:1])
+    assert fusion.wave_supports([fusion.PrimOp('diag', (5, 2), (1,), 0, 0)])

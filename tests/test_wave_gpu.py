@@ -120,6 +120,6 @@ def test_wave_pass_refuses_what_it_cannot_run():
     steps = fusion.schedule(ops, n, geom)
     x = rand_state(1, n, 1).to(dev())
     md = fusion.kernel_matrices(steps, ops, mats.to(torch.complex64)).to(dev())
-    with pytest.raises(RuntimeError, match='one-target'):
+    with pytest.raises(RuntimeError, match='one-target and diagonal'):
         for st in steps:
             backend.apply_fused(x, md, 0, st.desc, out=x)

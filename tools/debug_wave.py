@@ -27,15 +27,17 @@ X = torch.tensor([[0, 1], [1, 0]], dtype=torch.complex128)
 def run(name, gates):
     ops, mats, off = [], [], 0
     for kind, t, c, m, mode in gates:
-        ops.append(fusion.PrimOp(kind, (t,), tuple(c), off, mode))
+        t = (t,) if isinstance(t, int) else tuple(t)
+        ops.append(fusion.PrimOp(kind, t, tuple(c), off, mode))
         mats.append(m.reshape(-1))
-        off += 4
+        off += m.numel()
     mats = torch.cat(mats).to(torch.complex64)
     geom = fusion.default_geometry(False)
     steps = fusion.schedule(ops, n, geom)
     ref = x
     for op in ops:
-        ref = oracle.apply_gate_bits(ref, mats[op.mat:op.mat + 4].reshape(2, 2), list(op.targets), list(op.controls))
+        d_ = 1 << op.k
+        ref = oracle.apply_gate_bits(ref, mats[op.mat:op.mat + d_ * d_].reshape(d_, d_), list(op.targets), list(op.controls))
     km = fusion.kernel_matrices(steps, ops, mats)
     xd = x.to(dev)
     xe = x.numpy().copy()
@@ -51,6 +53,20 @@ def run(name, gates):
     print(f'{name:40s} gpu err {err:9.2e}  emu err {erre:9.2e}  ids {ids}  {"OK" if err < 1e-5 else "FAIL"}', flush=True)
 
 
+D1 = torch.diag(torch.exp(1j * torch.tensor([0.3, 1.1], dtype=torch.float64)))
+D2 = torch.diag(torch.exp(1j * torch.tensor([0.3, 1.1, -0.7, 2.0], dtype=torch.float64)))
+if len(sys.argv) > 2 and sys.argv[2] == 'diag':
+    for q in (0, 2, 5, 9, n - 1):
+        run(f'DIAG1 q{q}', [('diag', q, (), D1, 0)])
+        run(f'H q4; DIAG1 q{q}', [('gen', 4, (), H, 3), ('diag', q, (), D1, 0)])
+    for c, q in ((1, 0), (0, 1), (n - 1, 5), (5, n - 1), (9, 10), (2, 3)):
+        run(f'C-DIAG1 c{c} q{q}', [('diag', q, (c,), D1, 0)])
+        run(f'H q4; C-DIAG1 c{c} q{q}', [('gen', 4, (), H, 3), ('diag', q, (c,), D1, 0)])
+    for a_, b_ in ((0, 1), (1, 0), (5, 9), (9, 5), (0, n - 1), (n - 1, 0), (2, 3), (3, n - 1), (9, 10)):
+        run(f'DIAG2 {a_},{b_}', [('diag', (a_, b_), (), D2, 0)])
+        run(f'H q4; DIAG2 {a_},{b_}', [('gen', 4, (), H, 3), ('diag', (a_, b_), (), D2, 0)])
+        run(f'H q4; C7-DIAG2 {a_},{b_}', [('gen', 4, (), H, 3), ('diag', (a_, b_), (7,), D2, 0)])
+    sys.exit(0)
 for q in range(n):
     run(f'H q{q}', [('gen', q, (), H, 3)])
 for q in (0, 5, 11):

@@ -182,7 +182,11 @@ ID_X_R1 = 54        # + 5 * q + c'   one register control c (c' = c, or c - 1 ab
 ID_TRIP0 = 84
 ID_TRIP = 85        # + index in TRIP_MASKS
 ID_SWAP = ID_TRIP + len(TRIP_MASKS)       # + index in SWAP_PAIRS
-NIDS = ID_SWAP + len(SWAP_PAIRS)
+# diagonal gates: + variant (0: one phase for every register, 1 + q: by the bit of slot q, 7 / 8 + q: the same with a
+# register mask); ID_DIAG2: the four phases are the diagonal of a 4x4 block that ends at the current matrix offset
+ID_DIAG1 = ID_SWAP + len(SWAP_PAIRS)
+ID_DIAG2 = ID_DIAG1 + 14
+NIDS = ID_DIAG2 + 14
 
 
 def handlers():
@@ -206,6 +210,74 @@ def handlers():
     for i, (a_, b_) in enumerate(SWAP_PAIRS):
         h[ID_SWAP + i] = (False, slotswap(a_, b_))
     return h
+
+
+PH0, PH1 = 'v[10:11]', 'v[12:13]'
+
+
+def cmul_inplace(j, ph, t):
+    return [f'v_pk_mul_f32 {t}, {A(j)}, {ph} op_sel_hi:[1,0]', f'v_pk_fma_f32 {A(j)}, {A(j)}, {ph}, {t} {I3}']
+
+
+def diag_body(variant):
+    """variant 0: PH0 for every register; 1 + q: PH0 / PH1 by bit q of the register index; + 7: only the registers whose
+    bit is set in the record's 64-bit mask (w6:w7)."""
+    masked, v = variant >= 7, variant % 7
+    out_ = []
+    for j in range(NA):
+        ph = PH0 if v == 0 or not (j >> (v - 1)) & 1 else PH1
+        t = 'v[14:15]' if j % 2 == 0 else 'v[16:17]'
+        if masked:
+            out_ += [f's_bitcmp1_b64 s[{REC + 6}:{REC + 7}], {j}', f's_cbranch_scc0 .Ldg{variant}_{j}_%=']
+        out_ += cmul_inplace(j, ph, t)
+        if masked:
+            out_.append(f'.Ldg{variant}_{j}_%=:')
+    return out_
+
+
+def diag_code():
+    """Entry of every diagonal record: controls, the four phases d0..d3 -> s[40:47], the candidates of PH0 / PH1 (indices
+    in w5 bits 16..31) -> s[80:87] / s[96:99], the two per-lane selectors (w5 bytes 0, 1: kind << 6 | position;
+    kind 1 = a tile-local bit of the thread, 2 = an index bit outside the tile) -> s[50:51], s[70:71], then
+    PH = selA ? (selB ? c3 : c2) : (selB ? c1 : c0) per lane, and on to the body of the variant."""
+    W5 = f's{REC + 5}'
+    t = ['.Ldiag_%=:',
+         f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc0 .Lnext_%=',
+         f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
+         's_cbranch_execz .Lrestore_%=',
+         f's_cmp_ge_u32 s{REC}, {ID_DIAG2}', 's_cbranch_scc1 .Ldiag4_%=',
+         f's_mov_b64 s[40:41], {M[0]}', f's_mov_b64 s[42:43], {M[3]}', f's_mov_b64 s[44:45], {M[0]}', f's_mov_b64 s[46:47], {M[3]}',
+         's_branch .Ldiagsel_%=', '.Ldiag4_%=:', f's_sub_u32 s69, {MOFF}, 128']
+    for k in range(4):
+        t += [f's_load_dwordx2 s[{40 + 2 * k}:{41 + 2 * k}], {MB}, s69'] + (['s_add_u32 s69, s69, 40'] if k < 3 else [])
+    t += ['s_waitcnt lgkmcnt(0)', '.Ldiagsel_%=:']
+    cand0 = ['s[80:81]', 's[82:83]', 's[84:85]', 's[86:87]']
+    cand1 = {0: 's[96:97]', 2: 's[98:99]'}      # (PH1 exists where a slot bit is one of the targets: one selector at most)
+    for k in range(4):
+        t += [f's_bfe_u32 s69, {W5}, {(16 + 2 * k) | (2 << 16)}', 's_lshl_b32 m0, s69, 1', 's_nop 0', f's_movrels_b64 {cand0[k]}, s[40:41]']      # (one wait state between a write of M0 and s_movrel)
+    for k in (0, 2):
+        t += [f's_bfe_u32 s69, {W5}, {(24 + 2 * k) | (2 << 16)}', 's_lshl_b32 m0, s69, 1', 's_nop 0', f's_movrels_b64 {cand1[k]}, s[40:41]']
+    for name, byte, dst in (('a', 0, 's[50:51]'), ('b', 8, 's[70:71]')):
+        t += [f's_bfe_u32 s69, {W5}, {byte | (6 << 16)}', f's_bfe_u32 vcc_lo, {W5}, {(byte + 6) | (2 << 16)}', f's_mov_b64 {dst}, 0',
+              's_cmp_eq_u32 vcc_lo, 1', f's_cbranch_scc0 .Lsel{name}o_%=',
+              f'v_lshrrev_b32 {TT}, s69, {TB}', f'v_and_b32 {TT}, 1, {TT}', f'v_cmp_ne_u32 {dst}, 0, {TT}', f's_branch .Lsel{name}d_%=',
+              f'.Lsel{name}o_%=:', 's_cmp_eq_u32 vcc_lo, 2', f's_cbranch_scc0 .Lsel{name}d_%=',
+              f's_lshr_b64 vcc, {TG}, s69', 's_bitcmp1_b32 vcc_lo, 0', f's_cselect_b64 {dst}, -1, 0', f'.Lsel{name}d_%=:']
+    for half in (0, 1):
+        regs = [f's{int(c[2:c.index(":")]) + half}' for c in cand0]
+        t += [f'v_mov_b32 v14, {regs[0]}', f'v_mov_b32 v15, {regs[1]}', f'v_mov_b32 v16, {regs[2]}', f'v_mov_b32 v17, {regs[3]}',
+              'v_cndmask_b32 v14, v14, v15, s[70:71]', 'v_cndmask_b32 v16, v16, v17, s[70:71]',
+              f'v_cndmask_b32 v{10 + half}, v14, v16, s[50:51]']
+        r0, r2 = (f's{int(cand1[k][2:cand1[k].index(":")]) + half}' for k in (0, 2))
+        t += [f'v_mov_b32 v14, {r0}', f'v_mov_b32 v16, {r2}', f'v_cndmask_b32 v{12 + half}, v14, v16, s[50:51]']
+    # second-level table: the body of the variant
+    t += [f's_sub_u32 s69, s{REC}, {ID_DIAG1}', 's_cmp_ge_u32 s69, 14', 's_cbranch_scc0 .Ldiagv_%=', 's_sub_u32 s69, s69, 14', '.Ldiagv_%=:',
+          's_getpc_b64 vcc', '.Ldiaganchor_%=:', 's_lshl2_add_u32 vcc_lo, s69, vcc_lo', 's_addc_u32 vcc_hi, vcc_hi, 0',
+          's_add_u32 vcc_lo, vcc_lo, .Ldiagtable_%=-.Ldiaganchor_%=', 's_addc_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc', '.Ldiagtable_%=:']
+    t += [f's_branch .Ldiagb{v}_%=' for v in range(14)]
+    for v in range(14):
+        t += [f'.Ldiagb{v}_%=:'] + diag_body(v) + [f's_mov_b64 exec, {SAVE}', f's_cmp_lt_u32 {GOFF}, {GEND}', 's_cbranch_scc1 .Lloop_%=', 's_branch .Lexit_%=']
+    return t
 
 
 def gray_walk(op, base_operand, lane_operand):
@@ -282,7 +354,7 @@ def kernel_body():
              f's_lshl2_add_u32 vcc_lo, s{REC}, s54', 's_addc_u32 vcc_hi, s55, 0', 's_setpc_b64 vcc',
              '.Ltable_%=:']
     for i in range(NIDS):
-        text.append(f's_branch .Lh{i}_%=' if i in h else 's_branch .Lnext_%=')
+        text.append(f's_branch .Lh{i}_%=' if i in h else ('s_branch .Ldiag_%=' if i >= ID_DIAG1 else 's_branch .Lnext_%='))
     # ---- epilogue: the pass's deferred factor, then the stores ----
     text += ['.Lexit_%=:', 's_load_dwordx8 s[40:47], %[ks], 40', 's_load_dwordx2 s[48:49], %[ks], 72',
              's_waitcnt lgkmcnt(0)',          # (the slot offsets -- and the LDS reads of a trip that ended the pass)
@@ -297,6 +369,7 @@ def kernel_body():
     text += ['.Lstore_%=:']
     text += gray_walk('store', '%[outb]', LST)
     text += ['s_branch .Ldone_%=']
+    text += diag_code()
     for i in back:
         text += emit(i)
     text += ['.Ldone_%=:']
@@ -308,12 +381,13 @@ out = ['// GENERATED by tools/gen_wave_asm.py -- do not edit by hand.', '// clan
        f'#define DQ_WID_GEN_U {ID_GEN_U}', f'#define DQ_WID_GEN_C {ID_GEN_C}', f'#define DQ_WID_GEN_R {ID_GEN_R}',
        f'#define DQ_WID_X_U {ID_X_U}', f'#define DQ_WID_X_C {ID_X_C}', f'#define DQ_WID_X_R {ID_X_R}', f'#define DQ_WID_X_R1 {ID_X_R1}',
        f'#define DQ_WID_TRIP0 {ID_TRIP0}', f'#define DQ_WID_TRIP {ID_TRIP}', f'#define DQ_WID_SWAP {ID_SWAP}',
+       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}',
        '// trip handler id by slot mask (popcount 1..DQ_WAVE_MAXK), -1 otherwise; slot-swap handler id by (i < j)',
        'static const short kWaveTripId[64] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(64)) + '};',
        'static const short kWaveSwapId[6][6] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
        '']
 text = '\\n\\t"\n        "'.join(kernel_body())
-clob = ', '.join([f'"s{i}"' for i in range(40, 96)] + [f'"v{i}"' for i in range(1, AMP0 + 2 * NA)])
+clob = ', '.join(['"m0"'] + [f'"s{i}"' for i in range(40, 100)] + [f'"v{i}"' for i in range(1, AMP0 + 2 * NA)])
 out += ['// kg = address of the records, gend = their size in bytes; mb + moff = address of the first matrix; tg = the index',
         '// bits this tile fixes; ks = address of WaveKernPass::load_off (slot offsets, lane shifts); inb / outb = tile bases;',
         '// ldsb = the wave\'s LDS region; tid = threadIdx.x',
