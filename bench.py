@@ -387,7 +387,11 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize(device)
 
-    step()          # setup, not warm-up: pass plans (seconds of host work per circuit structure), second state buffer
+    t_setup = time.perf_counter()
+    step()          # setup, not warm-up: pass plans (host work once per circuit structure), second state buffer
+    sync()
+    setup_s = time.perf_counter() - t_setup
+    plan_s = dq.executor.PLAN_STATS['seconds']
     for _ in range(args.warmup):
         step()
     sync()
@@ -530,6 +534,10 @@ def main():
                 # `value` counts the circuit's gates, `unmerged_ms_per_step` times them one by one
                 'kernel_gates_per_step': stats.get('gates') if not distributed else None,
                 'unmerged_ms_per_step': unmerged_ms,
+                # what a ONE-SHOT run pays on top of a steady-state step: the pass planner (host, once per circuit
+                # structure, cached afterwards) and the whole first step including it and the allocations
+                'plan_seconds': plan_s,
+                'first_step_seconds': setup_s,
                 'ms_per_step_hip_events_median': statistics.median(step_ms) if step_ms else None,
                 'ms_per_step_hip_events_min': min(step_ms) if step_ms else None,
             },

@@ -100,6 +100,11 @@ _SIGNATURES = {
     'dq_fused_geometry': (_i, [_i, _i, _ip, _ip, _ip]),
     'dq_fused_set_tiles_per_wg': (_i, [_i]),
     'dq_wave_descriptor': (_i, [C.POINTER(DqFusedPass), _i, _vp, _i]),
+    'dq_dag_create': (_vp, [_i, _vp, _vp, _vp, _vp]),
+    'dq_dag_destroy': (None, [_vp]),
+    'dq_dag_closure': (_i, [_vp, _u64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    'dq_dag_rank': (_i, [_vp, _u64, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    'dq_dag_grow_step': (_i, [_vp, _u64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'dq_set_dense_path': (_i, [_i]),
     'dq_reduce_ws_bytes': (_i64, [_i64]),
     'dq_apply_gate_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _ip, _i, _ip, _i, _i64, _vp]),

@@ -5,7 +5,7 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${here}/../libdqhip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-srcs=(dq_capi.hip dq_gate.hip dq_dense.hip dq_fused.hip dq_wave.hip dq_reduce.hip dq_dist.hip)
+srcs=(dq_capi.hip dq_gate.hip dq_dense.hip dq_fused.hip dq_wave.hip dq_reduce.hip dq_dist.hip dq_plan.hip)
 objs=()
 mkdir -p "${here}/build"
 pids=()

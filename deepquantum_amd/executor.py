@@ -83,6 +83,9 @@ PROFILE = {'enabled': False, 'events': []}
 # The most recent reverse sweep of _AdjointCircuit: which kind, how many fused passes / reduction records.
 LAST_SWEEP = {'fused': False, 'passes': 0, 'reductions': 0}
 
+# Host time spent in the pass planner (fusion.schedule; once per circuit structure, plans are cached) since import.
+PLAN_STATS = {'seconds': 0.0, 'plans': 0}
+
 # Statistics of the most recent fused run (for bench.py and tests).
 LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'swaps': 0, 'permute_folded': False}
 
@@ -165,7 +168,12 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
         prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off, p.mode))
         if p.kind != 'grad':            # (a reduction of the reverse sweep has no matrix)
             off += (1 << len(p.targets)) ** 2
+    import time
+
+    t0 = time.perf_counter()
     steps = fusion.schedule(prim_ops, n, geom, fuse=CONFIG['fuse'], final_perm=out_perm)
+    PLAN_STATS['seconds'] += time.perf_counter() - t0
+    PLAN_STATS['plans'] += 1
     order, total = fusion.layout_matrices(steps, prim_ops)
     plan = Plan(steps, prim_ops, order, total,
                 sum(isinstance(s, fusion.FusedStep) for s in steps),

@@ -192,6 +192,37 @@ class _Dag:
             self.indeg[i] = len(deps)
         self.ready = sorted(i for i in range(self.n_ops) if self.indeg[i] == 0)
         self.done = 0
+        self._native = None
+
+    def native(self):
+        """The DAG inside libdqhip (csrc/dq_plan.hip: the planner's dry runs as a loop over flat arrays), made on first
+        use: (handle, scratch arrays)."""
+        if self._native is None:
+            import numpy as np
+
+            lib = _lib.load()
+            off = np.zeros(self.n_ops + 1, dtype=np.int32)
+            for i, s_ in enumerate(self.succ):
+                off[i + 1] = off[i] + len(s_)
+            succ = np.array([x for s_ in self.succ for x in s_] or [0], dtype=np.int32)
+            tmask = np.array([0 if op.kind == 'diag' else sum(1 << t for t in op.targets) for op in self.ops] or [0],
+                             dtype=np.uint64)
+            fus = np.array([1 if _fusable(op) else 0 for op in self.ops] or [0], dtype=np.uint8)
+            h = lib.dq_dag_create(self.n_ops, off.ctypes.data, succ.ctypes.data, tmask.ctypes.data, fus.ctypes.data)
+            if not h:
+                raise RuntimeError('dq_dag_create failed: ' + lib.dq_last_error().decode())
+            n1 = max(self.n_ops, 1)
+            self._native = (lib, h, np.empty(n1, np.int32), np.empty(n1, np.int32), np.empty(n1, np.int32),
+                            np.empty(64, np.int32))
+        return self._native
+
+    def __del__(self):
+        nat = getattr(self, '_native', None)
+        if nat is not None:
+            try:
+                nat[0].dq_dag_destroy(nat[1])
+            except Exception:      # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def retire(self, i: int) -> None:
         self.ready.remove(i)
@@ -211,25 +242,40 @@ def _closure(dag: '_Dag', tile: set[int], cap: int, indeg: list[int] | None = No
     ignoring the round / slot limits: retires every fusable diagonal gate and every other fusable gate whose
     targets lie in the tile, up to ``cap`` gates.  Returns (gates retired, the gates left ready but stuck,
     the in-degrees it changed)."""
-    ops = dag.ops
-    base = dag.indeg if indeg is None else indeg
-    changed: dict[int, int] = {}
-    stack = list(dag.ready if ready is None else ready)
-    stuck: list[int] = []
-    count = 0
-    while stack:
-        i = stack.pop()
-        op = ops[i]
-        if count >= cap or not _fusable(op) or (op.kind != 'diag' and not all(t in tile for t in op.targets)):
-            stuck.append(i)
-            continue
-        count += 1
-        for s_ in dag.succ[i]:
-            left = changed.get(s_, base[s_]) - 1
-            changed[s_] = left
-            if left == 0:
-                stack.append(s_)
-    return count, stuck, changed
+    import ctypes as C
+
+    import numpy as np
+
+    lib, h, stuck, cidx, cval, _ = dag.native()
+    base = np.ascontiguousarray(dag.indeg if indeg is None else indeg, dtype=np.int32)
+    rd = np.array(dag.ready if ready is None else ready, dtype=np.int32)
+    ns, nc = C.c_int(0), C.c_int(0)
+    count = lib.dq_dag_closure(h, _mask(tile), cap, base.ctypes.data, rd.ctypes.data, len(rd), stuck.ctypes.data, C.byref(ns),
+                               cidx.ctypes.data, cval.ctypes.data, C.byref(nc))
+    if count < 0:
+        raise RuntimeError('dq_dag_closure failed: ' + lib.dq_last_error().decode())
+    return count, stuck[:ns.value].tolist(), dict(zip(cidx[:nc.value].tolist(), cval[:nc.value].tolist()))
+
+
+def _mask(bits) -> int:
+    m = 0
+    for b in bits:
+        m |= 1 << b
+    return m
+
+
+def _rank_candidates(dag: '_Dag', tile: set[int], cands: Sequence[int], cap: int, indeg, ready) -> list[int]:
+    """Gates a pass would retire with ``tile`` + each of ``cands`` (one native call for all of them)."""
+    import numpy as np
+
+    lib, h, _s, _i, _v, counts = dag.native()
+    base = np.ascontiguousarray(dag.indeg if indeg is None else indeg, dtype=np.int32)
+    rd = np.array(dag.ready if ready is None else ready, dtype=np.int32)
+    cd = np.array(list(cands), dtype=np.int32)
+    rc = lib.dq_dag_rank(h, _mask(tile), cap, base.ctypes.data, rd.ctypes.data, len(rd), cd.ctypes.data, len(cd), counts.ctypes.data)
+    if rc < 0:
+        raise RuntimeError('dq_dag_rank failed: ' + lib.dq_last_error().decode())
+    return counts[:len(cd)].tolist()
 
 
 def _grow_tile(dag: '_Dag', low: set[int], hcap: int, cap: int, indeg: list[int] | None = None,
@@ -244,28 +290,33 @@ def _grow_tile(dag: '_Dag', low: set[int], hcap: int, cap: int, indeg: list[int]
     ``prev`` of the pass before -- they become its contiguous low bits, which that pass must be able to write as whole
     runs -- so once the room left equals what is still missing, only qubits of ``prev`` are candidates, and a tile
     that ends short is padded with qubits of ``prev`` that no gate asked for."""
+    import ctypes as C
+
+    import numpy as np
+
+    lib, h = dag.native()[:2]
+    base_arr = np.ascontiguousarray(dag.indeg if indeg is None else indeg, dtype=np.int32)
+    rd = np.array(dag.ready if ready is None else ready, dtype=np.int32)
+    cq, cw, cc = (C.c_int * 64)(), (C.c_int * 64)(), (C.c_int * 64)()
+    nbase = C.c_int(0)
     chosen: set[int] = set()
     while len(chosen) < hcap:
         tile = low | chosen
-        base, stuck, _ = _closure(dag, tile, cap, indeg, ready)
-        if base >= cap:
+        # one native call per step (csrc/dq_plan.hip): the dry run with the tile, the qubits the stuck gates wait for,
+        # and the dry run with each of them added
+        nq = lib.dq_dag_grow_step(h, _mask(tile), cap, base_arr.ctypes.data, rd.ctypes.data, len(rd), C.byref(nbase), cq, cw, cc)
+        if nq < 0:
+            raise RuntimeError('dq_dag_grow_step failed: ' + lib.dq_last_error().decode())
+        if nbase.value >= cap:
             break
-        cands: dict[int, int] = {}
-        for i in stuck:
-            op = dag.ops[i]
-            if not _fusable(op):
-                continue
-            for t in op.targets:
-                if t not in tile:
-                    cands[t] = cands.get(t, 0) + 1
+        cands = {cq[k]: (cw[k], cc[k]) for k in range(nq)}
         if far is not None and sum(1 for b_ in chosen if b_ >= far[0]) >= far[1]:
             cands = {q: w for q, w in cands.items() if q < far[0]}     # the budget of far-apart bits is spent
         if prev is not None and hcap - len(chosen) <= need - len(chosen & prev):
             cands = {q: w for q, w in cands.items() if q in prev}
         if not cands:
             break
-        ranked = sorted(((_closure(dag, tile | {q}, cap, indeg, ready)[0], w, -q) for q, w in cands.items()),
-                        reverse=True)
+        ranked = sorted(((c_, w_, -q) for q, (w_, c_) in cands.items()), reverse=True)
         best = ranked[0] if pick is None else pick(ranked)
         chosen.add(-best[2])
     if prev is not None:
@@ -294,7 +345,9 @@ def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, bra
     def jitter(ranked):
         return ranked[rng.randrange(min(3, len(ranked)))]
 
-    beam = [(0, list(dag.indeg), list(dag.ready), [], set(low))]
+    import numpy as np
+
+    beam = [(0, np.array(dag.indeg, dtype=np.int32), list(dag.ready), [], set(low))]
     while True:
         nxt = []
         for done, indeg, ready, hist, prev in beam:
@@ -314,7 +367,7 @@ def _plan_tiles(dag: '_Dag', low: set[int], hcap: int, cap: int, width: int, bra
                     continue
                 seen.add(key)
                 count, stuck, changed = _closure(dag, whole, cap, indeg, ready)
-                nindeg = list(indeg)
+                nindeg = indeg.copy()
                 for k_, v in changed.items():
                     nindeg[k_] = v
                 if count == 0:       # nothing fusable at the front: the lowest ready gate runs on its own
@@ -389,6 +442,31 @@ class Steps(list):
 
 def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
               final_perm: Sequence[int] | None = None, free_low: bool = False) -> 'Steps | None':
+    """The planner's restarts give several tile sequences: tried shortest first, the first that can be carried out wins
+    (with free low bits a sequence may turn out infeasible -- `_schedule_planned` -- and the next one often is not)."""
+    if not width:
+        return _schedule_planned(ops, n, geom, width, final_perm, free_low, None)
+    dag = _Dag(ops, n)
+    L = geom.min_low
+    restarts = geom.plan_restarts if width > 1 and n >= geom.plan_restart_bits else 1
+    far = (geom.far_bit, geom.max_far) if geom.max_far is not None else None
+    plans = [_plan_tiles(dag, set(range(L)), geom.m - L, geom.max_gates, width, geom.plan_branch, 20250929 + r, far,
+                         free_low=L if free_low else 0) for r in range(restarts)]
+    seen = []
+    for plan in sorted(plans, key=len):
+        if plan in seen:
+            continue
+        seen.append(plan)
+        out = _schedule_planned(ops, n, geom, width, final_perm, free_low, list(plan))
+        if out is not None:
+            return out
+        if len(seen) >= 4:
+            break
+    return None
+
+
+def _schedule_planned(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int, final_perm: Sequence[int] | None,
+                      free_low: bool, planned: list | None) -> 'Steps | None':
     """``free_low`` (with permuted stores and a planner): the L contiguous low bits of a pass hold whichever qubits the
     pass before wrote there -- ``low_list``, position by position, chosen from the qubits that pass had in its tile and
     this one wants -- so all m tile qubits are picked per pass.  Returns None when that does not work out (a gate that
@@ -400,12 +478,8 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
     low_list = list(range(L))           # the qubits on index bits 0 .. L-1 when the pass starts
     low = set(low_list)
     hcap = geom.m - L
-    # the randomised branches make the pass count vary by one or two: on big states a few restarts are worth it
-    restarts = geom.plan_restarts if width > 1 and n >= geom.plan_restart_bits else 1
     far = (geom.far_bit, geom.max_far) if geom.max_far is not None else None
-    planned = min((_plan_tiles(dag, low, hcap, geom.max_gates, width, geom.plan_branch, 20250929 + r, far,
-                               free_low=L if free_low else 0)
-                   for r in range(restarts)), key=len) if width else []
+    planned = planned if planned is not None else []
     planned.reverse()                   # consumed from the end
     prev_tile: set[int] | None = None
     while dag.done < dag.n_ops:

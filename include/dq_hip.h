@@ -247,6 +247,25 @@ int dq_fused_geometry(int is_c128, int variant, int* m, int* slots, int* threads
  * consecutive tiles of a pass and requests tile t + 1 from HBM while the gates of tile t run.  0 = automatic (4 where
  * the grid stays large enough), 1 = one tile per workgroup (no prefetch), otherwise a power of two <= 64. */
 int dq_fused_set_tiles_per_wg(int tiles);
+/* Host-side core of the pass planner (no device code; deepquantum_amd/fusion.py drives it): dry runs of a pass over the
+ * commutation DAG of a gate list.  dq_dag_create copies the DAG: successors of gate i = succ[succ_off[i] .. succ_off[i+1]),
+ * target_mask[i] = the qubits gate i needs inside the tile (0: it runs anywhere, e.g. a diagonal gate), fusable[i] = may it
+ * enter a fused pass at all.  dq_dag_closure retires, depth-first from the `ready` gates, every fusable gate whose
+ * targets lie in `tile` (bit mask over qubits) while fewer than `cap` have retired; returns how many did, and optionally
+ * the gates left stuck at the front and the in-degrees it changed (index / value pairs; `indeg` itself is not written).
+ * dq_dag_rank does the count for tile | (1 << cand[c]), every c.  A handle is not thread-safe (it carries scratch). */
+void* dq_dag_create(int n_ops, const int* succ_off, const int* succ, const uint64_t* target_mask, const uint8_t* fusable);
+void dq_dag_destroy(void* dag);
+int dq_dag_closure(void* dag, uint64_t tile, int cap, const int* indeg, const int* ready, int nready, int* stuck, int* nstuck,
+                   int* changed_idx, int* changed_val, int* nchanged);
+int dq_dag_rank(void* dag, uint64_t tile, int cap, const int* indeg, const int* ready, int nready, const int* cand, int ncand,
+                int* counts);
+/* One growth step of a tile: *base = dq_dag_closure(tile); the qubits outside the tile that the stuck gates wait for
+ * (cand_q, cand_w = how many gates wait for each; arrays of 64), and cand_count = dq_dag_closure(tile | qubit) for each.
+ * Returns the number of candidates (0 when the pass is full: *base >= cap). */
+int dq_dag_grow_step(void* dag, uint64_t tile, int cap, const int* indeg, const int* ready, int nready, int* base, int* cand_q,
+                     int* cand_w, int* cand_count);
+
 /* Test hook, no device needed: the kernel-side descriptor the library derives for a wave-tile pass (`pass`: HOST
  * pointer, complex64, m = 12, 6 slots) as raw bytes -- 80 bytes of slot offsets (load, store: 5 x 8 each), 6 + 6 + 6
  * words (byte shift of every lane bit on the load side / the store side, what it adds to the thread's tile-local base),
