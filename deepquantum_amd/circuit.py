@@ -740,7 +740,37 @@ class DistributedQubitCircuit(QubitCircuit):
         assert len(self.observables) > 0, 'There is no observable'
         assert isinstance(self.state, DistributedQubitState), 'There is no final state'
         if shots is not None:
-            raise NotImplementedError('sampled expectation on the sharded state is not implemented yet')
+            # sampled estimate (reference circuit.py:1739-1758): rotate every observable into the Z basis on a copy of
+            # the shards, sample its wires with measure_dist, average the parities; the value lives on rank 0 (the other
+            # ranks return an empty tensor per observable, as in the reference)
+            from copy import deepcopy
+
+            from .distributed import measure_dist
+
+            if self.state.batch is not None:
+                raise NotImplementedError('sampled expectation values of a batched sharded state')
+            self.shots = shots
+            dtype, device = self.state.amps.real.dtype, self.state.amps.device
+            out = []
+            for ob in self.observables:
+                cir_basis = DistributedQubitCircuit(self.nqubit)
+                for wire, basis in zip(ob.wires, ob.basis, strict=True):
+                    if basis == 'x':
+                        cir_basis.h(wire)
+                    elif basis == 'y':
+                        cir_basis.sdg(wire)
+                        cir_basis.h(wire)
+                cir_basis.to(device)
+                if dtype == torch.float64:
+                    cir_basis.to(torch.double)
+                with torch.no_grad():
+                    state = cir_basis(state=deepcopy(self.state)) if cir_basis.operators else self.state
+                    samples = measure_dist(state, shots=shots, wires=sum(ob.wires, []))
+                if self.state.rank == 0:
+                    out.append(sample2expval(samples).to(device, dtype).squeeze(0))
+                else:
+                    out.append(torch.tensor([], dtype=dtype, device=device))
+            return torch.stack(out, dim=-1)
         if self.state.batch is not None or not torch.is_grad_enabled():
             # forward-only evaluation (also the only one defined for batched shards)
             from .distributed import expect_pauli_dist

@@ -21,6 +21,7 @@
 // pass of 2 * 2^(n - nc) * sizeof(amp) * batch; actual traffic = 2 * 2^n * sizeof(amp) * batch.
 #include "dq_common.hpp"
 #include <type_traits>
+#include <atomic>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1275,7 +1276,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
 
 // Tiles per workgroup of the prefetching variants (complex64): 0 = pick by size.  dq_fused_set_tiles_per_wg() is a
 // tuning / A-B knob, not part of the data path's contract.
-static int g_tiles_per_wg = 0;
+static std::atomic<int> g_tiles_per_wg{0};       // (relaxed atomic: a measurement knob, read once per launch)
 
 template <typename T, int R, int LOGT, bool PF, bool GRAD = false>
 static void launch_variant(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n,
@@ -1292,7 +1293,8 @@ static void launch_variant(const void* in, void* out, const void* mats, int64_t 
     // resident workgroups), and the pass that reads one shared input state keeps its XCD-aware order (one tile each)
     int tpw_log = 0;
     if ((PF || GRAD) && in_bstride != 0) {
-        const int want = g_tiles_per_wg > 0 ? g_tiles_per_wg : 4;
+        const int knob = g_tiles_per_wg.load(std::memory_order_relaxed);
+        const int want = knob > 0 ? knob : 4;
         while ((2 << tpw_log) <= want && n - M - (tpw_log + 1) >= 0 &&
                ((int64_t)batch << (n - M - (tpw_log + 1))) >= 8192)
             ++tpw_log;
@@ -1384,7 +1386,7 @@ extern "C" int dq_fused_set_tiles_per_wg(int tiles) {
         dq::set_error("dq_fused_set_tiles_per_wg: %d is not 0 (automatic) or a power of two <= 64", tiles);
         return DQ_ERR_ARG;
     }
-    dq::g_tiles_per_wg = tiles;
+    dq::g_tiles_per_wg.store(tiles, std::memory_order_relaxed);
     return DQ_OK;
 }
 

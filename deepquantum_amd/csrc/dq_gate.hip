@@ -6,6 +6,7 @@
 // HBM traffic per launch: 2 * 2^(n-nc) * sizeof(amp) * batch (each touched amplitude read once and
 // written once); nothing is staged or copied around the controlled slice.
 #include "dq_common.hpp"
+#include <atomic>
 
 namespace dq {
 
@@ -126,7 +127,7 @@ template <typename T>
 int apply_dense_mfma(const cx<T>* in, cx<T>* out, const cx<T>* mats, int64_t mat_bstride, int n, const int* targets, int k,
                      const int* controls, int nc, const BitList& sorted, uint64_t cmask, int64_t batch, hipStream_t s);
 
-static int g_dense_path = 1;   // 1 = MFMA (default), 0 = one thread per output amplitude on the VALU (A/B, dq_set_dense_path)
+static std::atomic<int> g_dense_path{1};   // 1 = MFMA (default), 0 = one thread per output amplitude on the VALU (A/B, dq_set_dense_path)
 
 template <typename T>
 static int apply_gate_impl(const void* in, void* out, const void* mats, int64_t mat_bstride, int n,
@@ -229,7 +230,7 @@ static int apply_gate_impl(const void* in, void* out, const void* mats, int64_t 
             set_error("dq_apply_gate: k=%d > 4 requires out != in", k);
             return DQ_ERR_ARG;
         }
-        if (g_dense_path == 1) {
+        if (g_dense_path.load(std::memory_order_relaxed) == 1) {
             // amplitudes whose controls are not all 1 are carried over; the MFMA kernel writes the controlled columns
             if (nc > 0) {
                 uint64_t blocks = (total + 255) / 256;
@@ -255,7 +256,7 @@ extern "C" int dq_set_dense_path(int mfma) {
         dq::set_error("dq_set_dense_path: 0 (VALU) or 1 (MFMA)");
         return DQ_ERR_ARG;
     }
-    dq::g_dense_path = mfma;
+    dq::g_dense_path.store(mfma, std::memory_order_relaxed);
     return DQ_OK;
 }
 

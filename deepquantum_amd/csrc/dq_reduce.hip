@@ -166,6 +166,42 @@ __global__ __launch_bounds__(RED_THREADS) void marginal_kernel(const cx<T>* __re
     if (threadIdx.x == 0) unsafeAtomicAdd(out + ((size_t)b << nw) + o, acc);
 }
 
+// More than 12 measured bits (up to all n): a block owns 2^c contiguous amplitudes (c = min(12, n)), adds |psi|^2 into an
+// LDS histogram over the measured bits BELOW c -- reads stay coalesced whatever is measured -- and then adds the
+// histogram to the rows of `out` that the measured bits at or above c select (one atomic per local outcome and block:
+// 2^(n - c + measured bits below c) in all, instead of one per amplitude).
+struct WideGeom {
+    int nlo, nhi;
+    uint8_t lo_pos[12], lo_out[12];     // measured index bit < c -> bit of the outcome index
+    uint8_t hi_pos[40], hi_out[40];     // measured index bit >= c
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void marginal_wide_kernel(const cx<T>* __restrict__ psi, int n, int c, int nw, WideGeom g,
+                                                            double* __restrict__ out) {
+    extern __shared__ double hist[];
+    const unsigned nloc = 1u << g.nlo;
+    for (unsigned j = threadIdx.x; j < nloc; j += 256) hist[j] = 0.0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x << c;
+    const cx<T>* p = psi + ((uint64_t)blockIdx.y << n) + base;
+    for (unsigned i = threadIdx.x; i < (1u << c); i += 256) {
+        const cx<T> a = p[i];
+        unsigned j = 0;
+        for (int t = 0; t < g.nlo; ++t) j |= ((i >> g.lo_pos[t]) & 1u) << t;
+        unsafeAtomicAdd(&hist[j], (double)a.x * a.x + (double)a.y * a.y);
+    }
+    __syncthreads();
+    uint64_t hi = 0;
+    for (int t = 0; t < g.nhi; ++t) hi |= ((base >> g.hi_pos[t]) & 1ull) << g.hi_out[t];
+    double* row = out + ((size_t)blockIdx.y << nw);
+    for (unsigned j = threadIdx.x; j < nloc; j += 256) {
+        uint64_t o = hi;
+        for (int t = 0; t < g.nlo; ++t) o |= (uint64_t)((j >> t) & 1u) << g.lo_out[t];
+        unsafeAtomicAdd(row + o, hist[j]);
+    }
+}
+
 struct GradGeom {
     BitList sorted;
     int tpos[2];
@@ -409,12 +445,32 @@ static int marginal_impl(const void* psi, int n, const int* bits, int nw, int64_
         set_error("dq_marginal: bad argument");
         return DQ_ERR_ARG;
     }
-    if (nw < 1 || nw > 12) {
-        set_error("dq_marginal: nw=%d unsupported (1..12)", nw);
+    if (nw < 1 || nw > n || n > 40) {
+        set_error("dq_marginal: nw=%d unsupported (1..n)", nw);
         return DQ_ERR_UNSUPPORTED;
     }
     int rc = validate_bits(n, bits, nw, nullptr, 0);
     if (rc) return rc;
+    if (nw > 12) {
+        if (batch > 65535) {
+            set_error("dq_marginal: batch %lld exceeds 65535", (long long)batch);
+            return DQ_ERR_UNSUPPORTED;
+        }
+        const int c = n < 12 ? n : 12;
+        WideGeom g{};
+        for (int i = 0; i < nw; ++i) {          // bits[i] <-> outcome bit nw - 1 - i
+            if (bits[i] < c) {
+                g.lo_pos[g.nlo] = (uint8_t)bits[i];
+                g.lo_out[g.nlo++] = (uint8_t)(nw - 1 - i);
+            } else {
+                g.hi_pos[g.nhi] = (uint8_t)(bits[i]);
+                g.hi_out[g.nhi++] = (uint8_t)(nw - 1 - i);
+            }
+        }
+        hipLaunchKernelGGL(marginal_wide_kernel<T>, dim3((unsigned)(1ull << (n - c)), (unsigned)batch), dim3(256),
+                           sizeof(double) << g.nlo, as_stream(stream), static_cast<const cx<T>*>(psi), n, c, nw, g, out);
+        return check_launch("dq_marginal");
+    }
     if (((uint64_t)batch << nw) > 65535) {
         set_error("dq_marginal: batch * 2^nw = %llu exceeds 65535", (unsigned long long)((uint64_t)batch << nw));
         return DQ_ERR_UNSUPPORTED;

@@ -205,13 +205,8 @@ def measure(
                 all_probs = all_probs.reshape([batch] + [2] * n).permute(pm).reshape(batch, 2 ** len(wires), -1).sum(-1)
         elif wires is None or len(wires) == n:
             all_probs = backend.probs(flat)
-        elif len(wires) <= 12:
+        else:           # one read of the state whatever the number of wires (dq_marginal_*: LDS histograms above 12)
             all_probs = backend.marginal(flat, [n - 1 - w for w in wires]).to(flat.real.dtype)
-        else:
-            p = backend.probs(flat).reshape([batch] + [2] * n)
-            axes = [w + 1 for w in wires]
-            pm = [0] + axes + [i for i in range(1, n + 1) if i not in axes]
-            all_probs = p.permute(pm).reshape(batch, 2 ** len(wires), -1).sum(-1)
     results = []
     for i in range(batch):
         probs = all_probs[i]

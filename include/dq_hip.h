@@ -21,7 +21,9 @@
  *     circuit.py:232-240).
  *   - Every call enqueues on `stream` (a hipStream_t passed as void*; NULL = default stream) and
  *     returns without synchronising.  The library keeps no device memory and no global mutable
- *     state besides a thread-local error string; it is re-entrant.
+ *     state besides a thread-local error string; it is re-entrant.  The two exceptions are A/B MEASUREMENT
+ *     knobs, not part of the data path's contract: dq_set_dense_path and dq_fused_set_tiles_per_wg set a
+ *     process-wide (atomic) integer that later launches of every thread read; results never depend on them.
  *   - Return value: DQ_OK (0) or a negative DqStatus; dq_last_error() describes the failure.
  *     No exception crosses the ABI.
  */
@@ -339,7 +341,8 @@ int dq_probs_c128(const void* psi, void* probs, int64_t count, dq_stream_t strea
 
 /* Marginal distribution over `nw` bit positions (host array, bits[0] = MSB of the outcome index):
  * out[b, o] = sum over the other bits of |psi|^2, double precision, out must be zeroed by the
- * caller.  nw <= 12.  Replaces the permute/reshape/sum of qmath.py:626. */
+ * caller.  1 <= nw <= n (up to 12 bits: one block per outcome and chunk, batch * 2^nw <= 65535; more: a block per 2^12
+ * amplitudes with a histogram in LDS over the measured low bits).  Replaces the permute/reshape/sum of qmath.py:626. */
 int dq_marginal_c64(const void* psi, int n, const int* bits, int nw, int64_t batch, double* out,
                     dq_stream_t stream);
 int dq_marginal_c128(const void* psi, int n, const int* bits, int nw, int64_t batch, double* out,

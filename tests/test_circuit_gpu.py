@@ -129,6 +129,54 @@ def test_measure_marginals_and_sampling(prec):
     assert all(abs(float(v[1]) - 0.5) < 1e-5 for v in res.values())
 
 
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+def test_marginals_over_more_than_twelve_wires(prec):
+    """dq_marginal_* with 13 .. n measured bits (LDS histograms; reference qmath.py:624-626) against permute / reshape / sum of
+    |psi|^2 in float64, for wire sets that do and do not contain the low index bits, batched."""
+    from deepquantum_amd import backend
+
+    n, b = 18, 3
+    dtype = torch.complex64 if prec == 'c64' else torch.complex128
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(b, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(b, 1 << n, generator=g, dtype=torch.float64)
+    x = (x / x.norm(dim=-1, keepdim=True)).to(dtype)
+    p = (x.to(torch.complex128).abs() ** 2).reshape([b] + [2] * n)
+    for bits in ([17, 3, 5, 0, 1, 2, 9, 16, 4, 12, 13, 7, 8], list(range(17, 3, -1)), list(range(13)),
+                 [2 * i % n if i < 9 else 2 * (i - 9) + 1 for i in range(16)], list(range(n))[::-1]):
+        assert len(set(bits)) == len(bits) > 12
+        got = backend.marginal(x.to(dev()), bits).cpu()
+        axes = [1 + (n - 1 - q) for q in bits]                 # index bit q = tensor axis n - q (axis 0 = batch)
+        ref = p.permute([0] + axes + [a for a in range(1, n + 1) if a not in axes]).reshape(b, 1 << len(bits), -1).sum(-1)
+        assert (got - ref).abs().max().item() < (1e-9 if prec == 'c64' else 1e-13), bits
+    # and through the circuit-level entry point
+    cir = dq.QubitCircuit(16)
+    cir.hlayer(list(range(0, 16, 2)))
+    cir.to(dev())
+    with torch.no_grad():
+        cir()
+    res = cir.measure(shots=64, wires=list(range(14)), with_prob=True)
+    assert all(len(k) == 14 and k[1::2] == '0' * 7 and abs(float(v[1]) - 2.0 ** -7) < 1e-6 for k, v in res.items())
+
+
+def test_sampling_a_state_of_more_than_one_block():
+    """measure() on 2^26 outcomes: block_sample's multi-block branch (reference qmath.py:543-565: blocks of 2^24
+    probabilities, a block first, then an outcome inside it)."""
+    n = 26
+    cir = dq.QubitCircuit(n)
+    cir.h(0)                       # wire 0 = index bit 25: the two halves of the outcome range live in different blocks
+    cir.h(n - 1)
+    cir.x(3)
+    cir.to(dev())
+    with torch.no_grad():
+        cir()
+    res = cir.measure(shots=400)
+    want = {a + '00' + '1' + '0' * (n - 5) + c for a in '01' for c in '01'}
+    assert set(res) <= want and sum(res.values()) == 400
+    assert all(40 < res.get(k, 0) < 170 for k in want), res
+    res = cir.measure(shots=200, wires=list(range(13)), with_prob=True)          # 13 wires: the wide marginal kernel
+    assert set(res) <= {'0001' + '0' * 9, '1001' + '0' * 9} and all(abs(float(v[1]) - 0.5) < 1e-6 for v in res.values())
+
+
 # ---- properties at the benchmark's full size (BASELINE config 3: n=28, complex64) -------------------------
 def test_full_size_ghz_and_norm_n28():
     n = 28

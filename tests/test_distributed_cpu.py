@@ -344,7 +344,36 @@ def _case_measure_w2(dq, rank, world):
         assert set(res) <= {'00', '11'}
 
 
-@pytest.mark.parametrize('case,world', [('gates_w2', 2), ('gates_w4', 4), ('fused_local_w2', 2),
+def _case_sampled_expectation_w4(dq, rank, world):
+    """expectation(shots=...) on the sharded state (reference circuit.py:1739-1758): basis change on a copy of the shards,
+    measure_dist on the observable's wires, parity average on rank 0 (empty tensors elsewhere) -- against the exact
+    values, for Z, X, Y and a mixed two-wire string, on global and local wires."""
+    torch.manual_seed(7 + rank * 0)
+    n = 6
+    cir = dq.DistributedQubitCircuit(n)
+    cir.hlayer()
+    cir.rx(0, 0.7)
+    cir.ry(1, -0.4)
+    cir.cnot(0, 5)
+    cir.rz(5, 1.3)
+    cir.cnot(5, 2)
+    cir.observable(0)
+    cir.observable(5, 'x')
+    cir.observable(1, 'y')
+    cir.observable([0, 4], 'zx')
+    with torch.no_grad():
+        cir()
+        exact = cir.expectation()
+        est = cir.expectation(shots=20000)
+    if rank == 0:
+        assert est.shape == exact.shape
+        assert (est - exact).abs().max().item() < 0.03, (est, exact)
+    else:
+        assert est.numel() == 0
+    assert cir.shots == 20000
+
+
+@pytest.mark.parametrize('case,world', [('gates_w2', 2), ('gates_w4', 4), ('fused_local_w2', 2), ('sampled_expectation_w4', 4),
                                         ('random_remap_w4', 4), ('remap_w8', 8),
                                         ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4), ('folded_permute_w2', 2),
                                         ('golden_w2', 2), ('golden_w4', 4), ('golden_w8', 8)])
