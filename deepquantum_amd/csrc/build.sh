@@ -12,7 +12,7 @@ pids=()
 for s in "${srcs[@]}"; do
   o="${here}/build/${s%.hip}.o"
   objs+=("$o")
-  if [[ ! -f "$o" || "${here}/$s" -nt "$o" || "${here}/dq_common.hpp" -nt "$o" || "${here}/../../include/dq_hip.h" -nt "$o" || ( "$s" == dq_fused.hip && "${here}/dq_fused_asm.inc" -nt "$o" ) || ( "$s" == dq_wave.hip && "${here}/dq_wave_asm.inc" -nt "$o" ) ]]; then
+  if [[ ! -f "$o" || "${here}/$s" -nt "$o" || "${here}/dq_common.hpp" -nt "$o" || "${here}/../../include/dq_hip.h" -nt "$o" || ( "$s" == dq_fused.hip && "${here}/dq_fused_asm.inc" -nt "$o" ) || ( "$s" == dq_wave.hip && ( "${here}/dq_wave_asm.inc" -nt "$o" || "${here}/dq_wave_asm64.inc" -nt "$o" ) ) ]]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value -mllvm -simplifycfg-sink-common=false -mllvm -structurizecfg-skip-uniform-regions ${DQ_HIPCC_EXTRA:-} -c "${here}/$s" -o "$o" &
     pids+=($!)
   fi

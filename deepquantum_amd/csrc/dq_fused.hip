@@ -1028,8 +1028,8 @@ struct FusedVariant {
 // variant 0 is the default geometry of each precision; complex64: the wave tile (csrc/dq_wave.hip), then the two
 // workgroup tiles
 static const FusedVariant kVariantsC64[] = {{12, 6, 6}, {13, 4, 9}, {12, 4, 8}};
-static const FusedVariant kVariantsC128[] = {{11, 3, 8}, {12, 3, 9}};
-static const int kNumVariantsC64 = 3, kNumVariantsC128 = 2;
+static const FusedVariant kVariantsC128[] = {{11, 5, 6}, {12, 3, 9}, {11, 3, 8}};
+static const int kNumVariantsC64 = 3, kNumVariantsC128 = 3;
 
 // ngrads: rows of the caller's accumulator (dq_apply_fused_grad_*), -1 = a plain pass (DQ_FG_GRAD records refused)
 template <typename T>
@@ -1357,14 +1357,15 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
         return DQ_ERR_UNSUPPORTED;
     }
     hipStream_t s = as_stream(stream);
-    if constexpr (!is128) {
-        if (v.slots == 6) {     // one wavefront per tile: csrc/dq_wave.hip
-            if (ngrads >= 0) {
-                set_error("dq_apply_fused_grad_c64: reverse-sweep passes run on the workgroup-tile geometries");
-                return DQ_ERR_UNSUPPORTED;
-            }
-            return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+    if (v.logt == 6) {     // one wavefront per tile: csrc/dq_wave.hip
+        if (ngrads >= 0) {
+            set_error("dq_apply_fused_grad_c64: reverse-sweep passes run on the workgroup-tile geometries");
+            return DQ_ERR_UNSUPPORTED;
         }
+        if constexpr (is128) return wave_launch_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+        else return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+    }
+    if constexpr (!is128) {
         if (ngrads >= 0) {      // the reverse sweep: no next-tile prefetch (its registers go to the reductions)
             if (v.m == 12) launch_variant<float, 4, 8, false, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
             else launch_variant<float, 4, 9, false, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);

@@ -29,10 +29,44 @@
 namespace dq {
 
 #include "dq_wave_asm.inc"
+#include "dq_wave_asm64.inc"
 
-constexpr int WAVE_M = 12, WAVE_R = 6, WAVE_LANES = 6;
+constexpr int WAVE_LANES = 6;
 constexpr int WAVE_MAX_REC = 112;
-constexpr unsigned WAVE_LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
+
+// The two precisions: complex64 -- 64 amplitudes per lane, six slots, a 12-bit tile, slot 0 = index bit 0 inside the
+// 16-byte piece a lane loads -- and complex128 -- 32 amplitudes per lane, five slots, an 11-bit tile, every slot a
+// gathered bit.  Handler ids and the trip / swap tables come from the generated files.
+struct WaveC64 {
+    using real = float;
+    static constexpr int M = 12, R = 6, NA = 64, VB = 1, MAXK = DQ_WAVE_MAXK, ELEM = 8;
+    static constexpr unsigned LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
+    static constexpr int ID_GEN_U = DQ_WID_GEN_U, ID_GEN_C = DQ_WID_GEN_C, ID_GEN_R = DQ_WID_GEN_R, ID_X_U = DQ_WID_X_U,
+                         ID_X_C = DQ_WID_X_C, ID_X_R = DQ_WID_X_R, ID_X_R1 = DQ_WID_X_R1, ID_TRIP0 = DQ_WID_TRIP0,
+                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2;
+    static int trip_id(unsigned mask) { return kWaveTripId[mask]; }
+    static int swap_id(int i, int j) { return kWaveSwapId[i][j]; }
+    __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
+                                                uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid) {
+        wave_tile_body_f32(kg, gend, mb, moff, tg, ks, inb, outb, ldsb, tid);
+    }
+};
+struct WaveC128 {
+    using real = double;
+    static constexpr int M = 11, R = 5, NA = 32, VB = 0, MAXK = DQ_WAVE64_MAXK, ELEM = 16;
+    static constexpr unsigned LDS_PER_WAVE = 8704;      // (7 * 68 + 64) * 16 bytes: the k = 3 sub-tile buffer
+    static constexpr int ID_GEN_U = DQ_WID64_GEN_U, ID_GEN_C = DQ_WID64_GEN_C, ID_GEN_R = DQ_WID64_GEN_R, ID_X_U = DQ_WID64_X_U,
+                         ID_X_C = DQ_WID64_X_C, ID_X_R = DQ_WID64_X_R, ID_X_R1 = DQ_WID64_X_R1, ID_TRIP0 = DQ_WID64_TRIP0,
+                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2;
+    static int trip_id(unsigned mask) { return kWave64TripId[mask]; }
+    static int swap_id(int i, int j) { return kWave64SwapId[i][j]; }
+    __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
+                                                uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid) {
+        wave_tile_body_f64(kg, gend, mb, moff, tg, ks, inb, outb, ldsb, tid);
+    }
+};
+
+template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
 
 struct WaveRec {
     uint32_t w[8];
@@ -65,7 +99,9 @@ struct WaveKernArgs {
 };
 static_assert(sizeof(WaveKernArgs) <= 4096 && (offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec)) % 32 == 0, "kernel-argument segment");
 
-__global__ __launch_bounds__(256) void wave_pass_kernel(const float2* in, float2* out, const float2* mats, int64_t mat_bstride,
+template <class W>
+__global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::real>* in, vec2<typename W::real>* out,
+                                                        const vec2<typename W::real>* mats, int64_t mat_bstride,
                                                         int64_t in_bstride, int n, int pad_, const WaveKernPass p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dq_wave_smem[];
     (void)dq_wave_smem;
@@ -82,7 +118,7 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const float2* in, float2
         grp = group * 8u + (r & 7u);
     }
     const uint64_t tile_id = (uint64_t)grp * 4u + wave;
-    if (tile_id >= (1ull << (n - WAVE_M))) return;
+    if (tile_id >= (1ull << (n - W::M))) return;
     // where the tile lies: bit j of the tile number goes to index bit read_blk_pos[j] / store_blk_pos[j] (the descriptor
     // is read as words through the constant address space: scalar loads, constant byte positions)
     typedef const __attribute__((address_space(4))) uint32_t* KWords;
@@ -102,17 +138,18 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const float2* in, float2
     const uint64_t inb = (uint64_t)(in + (uint64_t)sample * (uint64_t)in_bstride + tg);
     const uint64_t outb = (uint64_t)(out + ((uint64_t)sample << n) + tw);
     const uint64_t mb = (uint64_t)(mats + (int64_t)sample * mat_bstride);
-    wave_tile_body_f32(karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec), p.nrec_bytes, mb, p.mat_base_bytes, tg,
-                       karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, load_off), inb, outb, wave * WAVE_LDS_PER_WAVE, tid);
+    W::body(karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec), p.nrec_bytes, mb, p.mat_base_bytes, tg,
+            karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, load_off), inb, outb, wave * W::LDS_PER_WAVE, tid);
 }
 
 // ---- host: DqFusedPass (rounds) -> records ------------------------------------------------------------------------
 namespace {
 
+template <class W>
 struct Xlate {
     const DqFusedPass* p;
     WaveKernPass* k;
-    int phys[WAVE_R];        // tile-local bit held by physical slot s (register-index bit s)
+    int phys[W::R];        // tile-local bit held by physical slot s (register-index bit s)
     int lanes[WAVE_LANES];   // tile-local bit on lane bit b
     int nrec = 0;
 
@@ -122,7 +159,7 @@ struct Xlate {
         return true;
     }
     int slot_of(int tile_bit) const {
-        for (int s = 0; s < WAVE_R; ++s)
+        for (int s = 0; s < W::R; ++s)
             if (phys[s] == tile_bit) return s;
         return -1;
     }
@@ -131,9 +168,9 @@ struct Xlate {
     // lane bit) or nullptr: chosen here
     bool trip(unsigned mask, const int* inc_lanes, int kk, const int* want) {
         const int a = 5 - kk, S = 64 + (1 << a);
-        int moving[WAVE_R], out_bits[WAVE_R], inc_bits[WAVE_R], stay_lanes[WAVE_LANES], stay_bits[WAVE_LANES], fpos[WAVE_LANES];
+        int moving[W::R], out_bits[W::R], inc_bits[W::R], stay_lanes[WAVE_LANES], stay_bits[WAVE_LANES], fpos[WAVE_LANES];
         int nm = 0, ns = 0;
-        for (int s = 0; s < WAVE_R; ++s)
+        for (int s = 0; s < W::R; ++s)
             if ((mask >> s) & 1u) {
                 moving[nm] = s;
                 out_bits[nm] = phys[s];
@@ -158,8 +195,8 @@ struct Xlate {
             for (int t = 0; t < ns; ++t) fpos[t] = t < a ? t : 5;
         }
         uint32_t cw[WAVE_LANES] = {0}, cr[WAVE_LANES] = {0}, tbc[WAVE_LANES] = {0};
-        for (int i = 0; i < kk; ++i) cw[inc_lanes[i]] = 8u << (a + i);
-        for (int t = 0; t < ns; ++t) cw[stay_lanes[t]] = 8u << fpos[t];
+        for (int i = 0; i < kk; ++i) cw[inc_lanes[i]] = (unsigned)W::ELEM << (a + i);
+        for (int t = 0; t < ns; ++t) cw[stay_lanes[t]] = (unsigned)W::ELEM << fpos[t];
         int nl[WAVE_LANES];
         if (want) {
             for (int b = 0; b < WAVE_LANES; ++b) nl[b] = want[b];
@@ -172,19 +209,19 @@ struct Xlate {
             bool found = false;
             for (int i = 0; i < kk && !found; ++i)
                 if (nl[b] == out_bits[i]) {
-                    cr[b] = (8u * (unsigned)S) << i;
+                    cr[b] = ((unsigned)W::ELEM * (unsigned)S) << i;
                     found = true;
                 }
             for (int t = 0; t < ns && !found; ++t)
                 if (nl[b] == stay_bits[t]) {
-                    cr[b] = 8u << fpos[t];
+                    cr[b] = (unsigned)W::ELEM << fpos[t];
                     found = true;
                 }
             if (!found) return false;      // `want` is not made of the bits that are on the lanes afterwards
             tbc[b] = 1u << nl[b];
         }
         WaveRec ra{}, rb{};
-        ra.w[0] = kk == 0 ? (uint32_t)DQ_WID_TRIP0 : (uint32_t)kWaveTripId[mask];
+        ra.w[0] = kk == 0 ? (uint32_t)W::ID_TRIP0 : (uint32_t)W::trip_id(mask);
         ra.w[1] = tbc[0], ra.w[2] = tbc[1], ra.w[3] = tbc[2], ra.w[5] = tbc[3], ra.w[6] = tbc[4], ra.w[7] = tbc[5];
         for (int b = 0; b < WAVE_LANES; ++b) rb.w[b] = cw[b] | (cr[b] << 16);
         for (int i = 0; i < kk; ++i) phys[moving[i]] = inc_bits[i];
@@ -197,7 +234,7 @@ struct Xlate {
         for (;;) {
             unsigned mask = 0;
             int inc[WAVE_LANES], ninc = 0, nout = 0;
-            for (int s = 0; s < WAVE_R; ++s)
+            for (int s = 0; s < W::R; ++s)
                 if (!((slotset >> phys[s]) & 1u)) {
                     mask |= 1u << s;
                     ++nout;
@@ -207,11 +244,11 @@ struct Xlate {
             if (nout != ninc) return false;
             if (nout == 0) return true;
             int kk = nout;
-            if (kk > DQ_WAVE_MAXK) kk = (nout + 1) / 2;      // 5 -> 3 + 2, 6 -> 3 + 3
+            if (kk > W::MAXK) kk = nout > 2 * W::MAXK ? W::MAXK : (nout + 1) / 2;      // e.g. 5 -> 3 + 2, 6 -> 3 + 3
             if (kk < nout) {                                  // keep the first kk outgoing slots / incoming lanes
                 unsigned m2 = 0;
                 int c = 0;
-                for (int s = 0; s < WAVE_R && c < kk; ++s)
+                for (int s = 0; s < W::R && c < kk; ++s)
                     if ((mask >> s) & 1u) {
                         m2 |= 1u << s;
                         ++c;
@@ -225,16 +262,17 @@ struct Xlate {
 
 }  // namespace
 
+template <class W>
 static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
     memset(k, 0, sizeof(*k));
     const int L = p->L, h = p->h;
     auto rpos = [&](int tl) { return tl < L ? tl : (int)p->high_pos[tl - L]; };
     auto wpos = [&](int tl) { return tl < L ? (int)p->store_low_pos[tl] : (int)p->store_high_pos[tl - L]; };
-    Xlate x;
+    Xlate<W> x;
     x.p = p;
     x.k = k;
     unsigned slotmask = 0;
-    for (int s = 0; s < WAVE_R; ++s) {
+    for (int s = 0; s < W::R; ++s) {
         x.phys[s] = p->load_rb[s];
         slotmask |= 1u << p->load_rb[s];
     }
@@ -248,21 +286,21 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
         for (int j = 0, q = 0; j < DQ_FUSED_MAX_BLK; ++j, ++q) {
             while (q < 64 && ((tilemask >> q) & 1ull)) ++q;
             k->read_blk_pos[j] = (uint8_t)(q < 63 ? q : 63);
-            k->store_blk_pos[j] = j < n - WAVE_M ? p->store_blk_pos[j] : (uint8_t)63;
+            k->store_blk_pos[j] = j < n - W::M ? p->store_blk_pos[j] : (uint8_t)63;
         }
     }
-    for (int s = 1; s < WAVE_R; ++s) k->load_off[s - 1] = 8ull << rpos(x.phys[s]);
+    for (int s = W::VB; s < W::R; ++s) k->load_off[s - W::VB] = (uint64_t)W::ELEM << rpos(x.phys[s]);
     for (int b = 0; b < WAVE_LANES; ++b) {
-        k->load_lane_shift[b] = 3u + (uint32_t)rpos(x.lanes[b]);
+        k->load_lane_shift[b] = (W::ELEM == 8 ? 3u : 4u) + (uint32_t)rpos(x.lanes[b]);
         k->tb_contrib[b] = 1u << x.lanes[b];
     }
-    k->mat_base_bytes = p->mat_base * 8u;
+    k->mat_base_bytes = p->mat_base * (uint32_t)W::ELEM;
 
     const char* why = "too many records for one pass (gates + layout changes)";
     for (int r = 0; r < p->nrounds; ++r) {
         const DqFusedRound& rd = p->rounds[r];
         unsigned want = 0;
-        for (int s = 0; s < WAVE_R; ++s) want |= 1u << rd.rb[s];
+        for (int s = 0; s < W::R; ++s) want |= 1u << rd.rb[s];
         if (!x.go(want, nullptr)) goto fail;
         for (int gi = rd.gate_begin & 0x7f; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
@@ -273,7 +311,7 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
             }
             unsigned pc = 0;
             int nc = 0, onec = 0;
-            for (int s = 0; s < WAVE_R; ++s)
+            for (int s = 0; s < W::R; ++s)
                 if ((g.reg_cmask >> s) & 1u) {
                     onec = x.slot_of(rd.rb[s]);
                     pc |= 1u << onec;
@@ -290,7 +328,7 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
                 // csrc/dq_wave_asm.inc, diag_code; controls on register slots become a mask over the 64 registers
                 auto regmask = [&](unsigned must_set, unsigned must_clear) {
                     uint64_t mk = 0;
-                    for (unsigned j = 0; j < 64; ++j)
+                    for (unsigned j = 0; j < (unsigned)W::NA; ++j)
                         if ((j & must_set) == must_set && (j & must_clear) == 0) mk |= 1ull << j;
                     return mk;
                 };
@@ -300,7 +338,7 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
                 auto put = [&](int base, int variant, bool masked, uint32_t selA, uint32_t selB, uint32_t idx0, uint32_t idx1,
                                uint64_t mk, uint32_t advance) {
                     WaveRec r2 = rec;
-                    r2.w[0] = (uint32_t)(base + variant + (masked ? 7 : 0));
+                    r2.w[0] = (uint32_t)(base + variant + (masked ? W::R + 1 : 0));
                     r2.w[4] = advance;
                     r2.w[5] = selA | (selB << 8) | (idx0 << 16) | (idx1 << 24);
                     r2.w[6] = (uint32_t)mk, r2.w[7] = (uint32_t)(mk >> 32);
@@ -310,20 +348,20 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
                 const uint64_t ctlmask = regmask(pc, 0);
                 bool ok;
                 if (g.kind == DQ_FG_DIAG1) {
-                    if (g.loc == DQ_LOC_REG) ok = put(DQ_WID_DIAG1, 1 + x.slot_of(rd.rb[g.q]), masked, 0, 0, 0x00, 0x55, ctlmask, 4);
-                    else ok = put(DQ_WID_DIAG1, 0, masked, 0, selector(g.loc, g.q), 0x44, 0, ctlmask, 4);
+                    if (g.loc == DQ_LOC_REG) ok = put(W::ID_DIAG1, 1 + x.slot_of(rd.rb[g.q]), masked, 0, 0, 0x00, 0x55, ctlmask, 4);
+                    else ok = put(W::ID_DIAG1, 0, masked, 0, selector(g.loc, g.q), 0x44, 0, ctlmask, 4);
                 } else {
                     const bool r1 = g.loc == DQ_LOC_REG, r2_ = g.loc2 == DQ_LOC_REG;
                     const int p1 = r1 ? x.slot_of(rd.rb[g.q]) : -1, p2 = r2_ ? x.slot_of(rd.rb[g.q2]) : -1;
                     if (r1 && r2_) {    // both targets on register slots: the halves of slot p1, by the bit of slot p2
-                        ok = put(DQ_WID_DIAG2, 1 + p2, true, 0, 0, 0x00, 0x55, regmask(pc, 1u << p1), 16) &&
-                             put(DQ_WID_DIAG2, 1 + p2, true, 0, 0, 0xAA, 0xFF, regmask(pc | (1u << p1), 0), 0);
+                        ok = put(W::ID_DIAG2, 1 + p2, true, 0, 0, 0x00, 0x55, regmask(pc, 1u << p1), 16) &&
+                             put(W::ID_DIAG2, 1 + p2, true, 0, 0, 0xAA, 0xFF, regmask(pc | (1u << p1), 0), 0);
                     } else if (r1) {
-                        ok = put(DQ_WID_DIAG2, 1 + p1, masked, selector(g.loc2, g.q2), 0, 0x10, 0x32, ctlmask, 16);
+                        ok = put(W::ID_DIAG2, 1 + p1, masked, selector(g.loc2, g.q2), 0, 0x10, 0x32, ctlmask, 16);
                     } else if (r2_) {
-                        ok = put(DQ_WID_DIAG2, 1 + p2, masked, selector(g.loc, g.q), 0, 0x20, 0x31, ctlmask, 16);
+                        ok = put(W::ID_DIAG2, 1 + p2, masked, selector(g.loc, g.q), 0, 0x20, 0x31, ctlmask, 16);
                     } else {
-                        ok = put(DQ_WID_DIAG2, 0, masked, selector(g.loc, g.q), selector(g.loc2, g.q2), 0xE4, 0, ctlmask, 16);
+                        ok = put(W::ID_DIAG2, 0, masked, selector(g.loc, g.q), selector(g.loc2, g.q2), 0xE4, 0, ctlmask, 16);
                     }
                 }
                 if (!ok) goto fail;
@@ -332,7 +370,7 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
             const int q = x.slot_of(rd.rb[g.q]);
             if (nc > 0) {       // pair i of slot q = the i-th register pattern with bit q clear
                 uint32_t pm = 0;
-                for (int j = 0, i = 0; j < 64; ++j) {
+                for (int j = 0, i = 0; j < W::NA; ++j) {
                     if ((j >> q) & 1) continue;
                     if (((unsigned)j & pc) == pc) pm |= 1u << i;
                     ++i;
@@ -340,13 +378,13 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
                 rec.w[5] = pm;
             }
             if (g.kind == DQ_FG_X1) {
-                if (nc == 0) rec.w[0] = (ctl ? DQ_WID_X_C : DQ_WID_X_U) + q;
-                else if (nc == 1) rec.w[0] = DQ_WID_X_R1 + 5 * q + (onec < q ? onec : onec - 1);
-                else rec.w[0] = DQ_WID_X_R + q;
+                if (nc == 0) rec.w[0] = (ctl ? W::ID_X_C : W::ID_X_U) + q;
+                else if (nc == 1) rec.w[0] = W::ID_X_R1 + (W::R - 1) * q + (onec < q ? onec : onec - 1);
+                else rec.w[0] = W::ID_X_R + q;
             } else {
-                if (nc > 0) rec.w[0] = DQ_WID_GEN_R + q;
-                else if (ctl) rec.w[0] = DQ_WID_GEN_C + q;
-                else rec.w[0] = DQ_WID_GEN_U + 6 * g.loc + q;
+                if (nc > 0) rec.w[0] = W::ID_GEN_R + q;
+                else if (ctl) rec.w[0] = W::ID_GEN_C + q;
+                else rec.w[0] = W::ID_GEN_U + W::R * g.loc + q;
             }
             if (!x.push(rec)) goto fail;
         }
@@ -354,24 +392,24 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
     {   // into the store layout: slot 0 = the tile bit written to index bit 0, lanes exactly as the host ordered them
         unsigned want = 0;
         int want_lanes[WAVE_LANES];
-        for (int s = 0; s < WAVE_R; ++s) want |= 1u << p->store_rb[s];
+        for (int s = 0; s < W::R; ++s) want |= 1u << p->store_rb[s];
         for (int b = 0; b < WAVE_LANES; ++b) want_lanes[b] = p->store_tb[b];
         if (!x.go(want, want_lanes)) goto fail;
         bool same = true;
         for (int b = 0; b < WAVE_LANES; ++b) same = same && x.lanes[b] == want_lanes[b];
         if (!same && !x.trip(0, nullptr, 0, want_lanes)) goto fail;
-        const int s0 = x.slot_of(p->store_rb[0]);
+        const int s0 = W::VB ? x.slot_of(p->store_rb[0]) : 0;       // (complex64: slot 0 = the tile bit written to index bit 0)
         if (s0 != 0) {
             WaveRec rec{};
-            rec.w[0] = (uint32_t)kWaveSwapId[0][s0];
+            rec.w[0] = (uint32_t)W::swap_id(0, s0);
             if (!x.push(rec)) goto fail;
             const int t = x.phys[0];
             x.phys[0] = x.phys[s0];
             x.phys[s0] = t;
         }
     }
-    for (int s = 1; s < WAVE_R; ++s) k->store_off[s - 1] = 8ull << wpos(x.phys[s]);
-    for (int b = 0; b < WAVE_LANES; ++b) k->store_lane_shift[b] = 3u + (uint32_t)wpos(x.lanes[b]);
+    for (int s = W::VB; s < W::R; ++s) k->store_off[s - W::VB] = (uint64_t)W::ELEM << wpos(x.phys[s]);
+    for (int b = 0; b < WAVE_LANES; ++b) k->store_lane_shift[b] = (W::ELEM == 8 ? 3u : 4u) + (uint32_t)wpos(x.lanes[b]);
     k->nrec_bytes = 32u * (unsigned)x.nrec;
     return DQ_OK;
 fail:
@@ -379,34 +417,52 @@ fail:
     return DQ_ERR_UNSUPPORTED;
 }
 
-int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                    const DqFusedPass* pass, hipStream_t s) {
+template <class W>
+static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
+                       const DqFusedPass* pass, hipStream_t s) {
     WaveKernPass kp;
-    const int rc = wave_translate(pass, n, &kp);
+    const int rc = wave_translate<W>(pass, n, &kp);
     if (rc) return rc;
-    const uint64_t tiles = 1ull << (n - WAVE_M);
+    const uint64_t tiles = 1ull << (n - W::M);
     dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)batch);
-    size_t lds = 4 * WAVE_LDS_PER_WAVE;
+    size_t lds = 4 * W::LDS_PER_WAVE;
     if (const char* kb = getenv("DQ_WAVE_LDS_KB")) {      // occupancy experiments: workgroups per CU = 160 KiB / this
         lds = (size_t)atoi(kb) << 10;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_pass_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL(wave_pass_kernel, grid, dim3(256), lds, s, static_cast<const float2*>(in),
-                       static_cast<float2*>(out), static_cast<const float2*>(mats), mat_bstride, in_bstride, n, 0, kp);
+    using V = vec2<typename W::real>;
+    hipLaunchKernelGGL(wave_pass_kernel<W>, grid, dim3(256), lds, s, static_cast<const V*>(in), static_cast<V*>(out),
+                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, 0, kp);
     return check_launch("dq_apply_fused (wave tile)");
+}
+
+int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
+                    const DqFusedPass* pass, hipStream_t s) {
+    return wave_launch<WaveC64>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+}
+int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
+                     const DqFusedPass* pass, hipStream_t s) {
+    return wave_launch<WaveC128>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
 }
 
 }  // namespace dq
 
 // Test hook (no GPU needed): the kernel-side descriptor the library would hand to the wave-tile kernel for `pass` --
-// slot offsets, lane shifts, tile-number positions, records (struct WaveKernPass above) -- as raw bytes.
+// slot offsets, lane shifts, tile-number positions, records (struct WaveKernPass above) -- as raw bytes.  The precision
+// follows the geometry: m = 12 / 6 slots = complex64, m = 11 / 5 slots = complex128.
 extern "C" int dq_wave_descriptor(const DqFusedPass* pass, int n, void* out, int max_bytes) {
     if (!pass) {
         dq::set_error("dq_wave_descriptor: null pointer");
         return DQ_ERR_ARG;
     }
     dq::WaveKernPass kp;
-    const int rc = dq::wave_translate(pass, n, &kp);
+    int rc;
+    if (pass->m == 12 && pass->slots == 6) rc = dq::wave_translate<dq::WaveC64>(pass, n, &kp);
+    else if (pass->m == 11 && pass->slots == 5) rc = dq::wave_translate<dq::WaveC128>(pass, n, &kp);
+    else {
+        dq::set_error("dq_wave_descriptor: not a wave-tile pass (m = %d, %d slots)", pass->m, pass->slots);
+        return DQ_ERR_ARG;
+    }
     if (rc) return rc;
     const int bytes = (int)(offsetof(dq::WaveKernPass, rec) + kp.nrec_bytes);
     if (out) memcpy(out, &kp, bytes < max_bytes ? bytes : max_bytes);

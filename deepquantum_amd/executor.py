@@ -51,7 +51,7 @@ _PLAN_CACHE: OrderedDict = OrderedDict()
 _PLAN_CACHE_SIZE = 64
 
 # Tunables (debug / benchmarking): tile bits per precision; None = library default.
-CONFIG = {'fuse': True, 'wave': None,     # complex64: None = wave-tile kernel where it takes the circuit, False = workgroup tiles
+CONFIG = {'fuse': True, 'wave': None,     # None = wave-tile kernel where it takes the circuit, False = workgroup tiles
           'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
           'max_gates': None, 'max_far': None, 'far_bit': None,
           # pass planner (fusion._plan_tiles): beam width / tiles tried per state; 0 = first-come tiles, 1 = greedy
@@ -93,7 +93,7 @@ LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0,
 def _geometry(is128: bool, wave: bool = True) -> fusion.Geometry:
     """``wave`` = False: a workgroup-tile geometry (what circuits with gates the wave-tile kernel does not take run on)."""
     m = CONFIG['m_c128'] if is128 else CONFIG['m_c64']
-    if is128 or m is not None or not wave or CONFIG['wave'] is False:
+    if m is not None or not wave or CONFIG['wave'] is False:
         g = fusion.workgroup_geometry(is128, m)
     else:
         g = fusion.default_geometry(is128)

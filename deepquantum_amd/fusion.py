@@ -93,11 +93,13 @@ class Geometry:
 
 
 def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = None) -> Geometry:
-    """Tile geometry per precision.  complex64 without arguments: the WAVE TILE (m = 12, six register slots, one
-    wavefront per tile; csrc/dq_wave.hip).  With ``m`` / ``slots`` given, and for complex128: a workgroup tile
+    """Tile geometry per precision.  Without arguments: the WAVE TILE (one wavefront per tile, csrc/dq_wave.hip: m = 12 and
+    six register slots for complex64, m = 11 and five for complex128).  With ``m`` / ``slots`` given: a workgroup tile
     (`workgroup_geometry`)."""
-    if not is_c128 and m is None and slots is None:
-        # records of a pass: gates + 2 per layout change (twice that when it exchanges more than four bits) <= 112
+    if m is None and slots is None:
+        # records of a pass: gates + 2 per layout change (twice that when it exchanges more bits than one trip moves) <= 112
+        if is_c128:     # 32 amplitudes of 16 bytes per lane: five slots, an 11-bit tile, 128-byte runs = 3 low bits
+            return Geometry(m=11, slots=5, vb=0, min_low=3, wave=True, max_gates=72, max_rounds=8)
         return Geometry(m=12, slots=6, vb=1, min_low=4, wave=True, max_gates=72, max_rounds=8)
     return workgroup_geometry(is_c128, m, slots)
 

@@ -37,7 +37,7 @@ class CpuTestBackend:
 
     def fused_geometry(self, is_c128, variant):
         table = {(False, 0): (12, 6, 64), (False, 1): (13, 4, 512), (False, 2): (12, 4, 256),
-                 (True, 0): (11, 3, 256), (True, 1): (12, 3, 512)}
+                 (True, 0): (11, 5, 64), (True, 1): (12, 3, 512), (True, 2): (11, 3, 256)}
         return table[(bool(is_c128), variant)]
 
     # ---- fused pass interpreter --------------------------------------------------------------------
@@ -48,8 +48,8 @@ class CpuTestBackend:
         is128 = state.dtype == torch.complex128
         m, L, h = desc.m, desc.L, desc.h
         R = desc.slots
-        assert (is128, m, R) in ((False, 12, 6), (False, 12, 4), (False, 13, 4), (True, 11, 3), (True, 12, 3)), 'no such kernel'
-        wave = R == 6           # the wave-tile kernel (include/dq_hip.h): no offset tables, no handler ids, no exchanges
+        assert (is128, m, R) in ((False, 12, 6), (False, 12, 4), (False, 13, 4), (True, 11, 5), (True, 11, 3), (True, 12, 3)), 'no such kernel'
+        wave = m - R == 6       # the wave-tile kernels (include/dq_hip.h): no offset tables, no handler ids, no exchanges
         if wave:
             assert grads is None, 'reverse-sweep passes run on the workgroup-tile geometries'
         vb = 0 if is128 else 1

@@ -24,24 +24,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from deepquantum_amd import _lib  # noqa: E402
 
-_gen = None
+_gens = {}
 
 
-def gen():
-    """tools/gen_wave_asm.py as a module (its output goes to a scratch file)."""
-    global _gen
-    if _gen is None:
-        os.environ['DQ_ASM_OUT'] = os.path.join('/tmp', f'dq_wave_asm_{os.getpid()}.inc')
-        spec = importlib.util.spec_from_file_location('gen_wave_asm', os.path.join(ROOT, 'tools', 'gen_wave_asm.py'))
-        _gen = importlib.util.module_from_spec(spec)
+def gen(c128: bool = False):
+    """tools/gen_wave_asm.py (complex64) / gen_wave_asm64.py (complex128) as a module (output to a scratch file)."""
+    if c128 not in _gens:
+        name = 'gen_wave_asm64' if c128 else 'gen_wave_asm'
+        os.environ['DQ_ASM_OUT'] = os.path.join('/tmp', f'dq_{name}_{os.getpid()}.inc')
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, 'tools', name + '.py'))
+        mod = importlib.util.module_from_spec(spec)
         stdout = sys.stdout
         sys.stdout = open(os.devnull, 'w')
         try:
-            spec.loader.exec_module(_gen)
+            spec.loader.exec_module(mod)
         finally:
             sys.stdout = stdout
             os.environ.pop('DQ_ASM_OUT', None)
-    return _gen
+        _gens[c128] = mod
+    return _gens[c128]
 
 
 class WaveKernPass(C.Structure):
@@ -64,24 +65,58 @@ def descriptor(desc, n) -> WaveKernPass:
 _AMP = re.compile(r'v\[(\d+):(\d+)\]')
 
 
-def _amp_index(tok: str) -> int:
-    lo = int(_AMP.fullmatch(tok).group(1))
-    g = gen()
-    assert lo >= g.AMP0 and (lo - g.AMP0) % 2 == 0
-    return (lo - g.AMP0) // 2
+class _Regs:
+    """The amplitude registers of a wave as the generated code names them: complex64 -- amplitude j = the 64-bit pair
+    v[40 + 2j : 41 + 2j]; complex128 -- re = v[40 + 4j : 41 + 4j], im = v[42 + 4j : 43 + 4j], the whole amplitude the
+    quad.  `a` is the (64 lanes, NA) complex array; temporaries of v_mov_b64 sequences live in `tmp`."""
+
+    def __init__(self, g, a):
+        self.g, self.a, self.c128 = g, a, getattr(g, 'ELEM', 8) == 16
+
+    def amp(self, tok):
+        lo, hi = (int(x) for x in _AMP.fullmatch(tok).groups())
+        assert lo >= self.g.AMP0
+        if self.c128:
+            assert hi - lo == 3 and (lo - self.g.AMP0) % 4 == 0
+            return (lo - self.g.AMP0) // 4
+        assert hi - lo == 1 and (lo - self.g.AMP0) % 2 == 0
+        return (lo - self.g.AMP0) // 2
+
+    def is_amp_reg(self, tok):
+        m = _AMP.fullmatch(tok)
+        return bool(m) and int(m.group(1)) >= self.g.AMP0
+
+    def get64(self, tok):
+        lo = int(_AMP.fullmatch(tok).group(1))
+        if not self.c128:
+            return self.a[:, (lo - self.g.AMP0) // 2].copy()
+        j, comp = divmod((lo - self.g.AMP0) // 2, 2)
+        return (self.a[:, j].imag if comp else self.a[:, j].real).copy()
+
+    def set64(self, tok, val, active):
+        lo = int(_AMP.fullmatch(tok).group(1))
+        if not self.c128:
+            self.a[active, (lo - self.g.AMP0) // 2] = val[active]
+            return
+        j, comp = divmod((lo - self.g.AMP0) // 2, 2)
+        col = self.a[:, j].copy()
+        if comp:
+            col.imag[active] = val[active]
+        else:
+            col.real[active] = val[active]
+        self.a[:, j] = col
 
 
-def _run_moves(lines, a, active):
-    """Interpret v_mov_b64 lines (X gates, slot swaps) on the register file a[lane, reg]; `active` = exec mask."""
-    tmp = {}
+def _run_moves(g, lines, a, active):
+    """Interpret v_mov_b64 lines (X gates, slot swaps) on the register file; `active` = exec mask."""
+    regs, tmp = _Regs(g, a), {}
     for ln in lines:
         op, rest = ln.split(' ', 1)
         assert op == 'v_mov_b64', ln
         dst, src = [t.strip() for t in rest.split(',')]
-        val = tmp[src] if src in tmp else a[:, _amp_index(src)].copy()
-        if _AMP.fullmatch(dst) and int(_AMP.fullmatch(dst).group(1)) >= gen().AMP0:
-            j = _amp_index(dst)
-            a[active, j] = val[active]
+        val = tmp[src] if src in tmp else regs.get64(src)
+        if regs.is_amp_reg(dst):
+            regs.set64(dst, val, active)
         else:
             tmp[dst] = val
 
@@ -93,8 +128,12 @@ def _apply2(a, lo, hi, m, active):
 
 
 def run_pass(desc, n, state, mats, mat_batch_stride):
-    """state (B, 2^n) complex64 numpy -> the state after the pass, as the wave-tile kernel computes it."""
-    g = gen()
+    """state (B, 2^n) complex numpy -> the state after the pass, as the wave-tile kernel of its precision computes it."""
+    c128 = state.dtype == np.complex128
+    g = gen(c128)
+    NA, R, EL, M_ = g.NA, g.R, (16 if c128 else 8), (11 if c128 else 12)
+    NV = 2 * (R + 1)
+    regs_of = lambda arr: _Regs(g, arr)      # noqa: E731
     kp = descriptor(desc, n)
     nrec = kp.nrec_bytes // 32
     rec = [list(kp.rec[i]) for i in range(nrec)]
@@ -103,7 +142,7 @@ def run_pass(desc, n, state, mats, mat_batch_stride):
     lb = [(lanes >> b) & 1 for b in range(6)]
     lld = sum(lb[b].astype(np.int64) << kp.load_lane_shift[b] for b in range(6))
     lst = sum(lb[b].astype(np.int64) << kp.store_lane_shift[b] for b in range(6))
-    ntiles = 1 << (n - 12)
+    ntiles = 1 << (n - M_)
     flat_m = np.asarray(mats).reshape(-1)
     trip_of = {g.ID_TRIP + i: (bin(mk).count('1'), mk) for i, mk in enumerate(g.TRIP_MASKS)}
     trip_of[g.ID_TRIP0] = (0, 0)
@@ -114,15 +153,18 @@ def run_pass(desc, n, state, mats, mat_batch_stride):
         for tile in range(ntiles):
             tg = sum(((tile >> j) & 1) << kp.read_blk_pos[j] for j in range(24))
             tw = sum(((tile >> j) & 1) << kp.store_blk_pos[j] for j in range(24))
-            a = np.zeros((64, 64), dtype=state.dtype)
+            a = np.zeros((64, NA), dtype=state.dtype)
             for piece in range(32):
                 off = sum(kp.load_off[s] for s in range(5) if (piece >> s) & 1)
-                addr = (tg * 8 + off + lld) // 8
-                a[:, 2 * piece] = flat_in[addr]
-                a[:, 2 * piece + 1] = flat_in[addr + 1]
+                addr = (tg * EL + off + lld) // EL
+                if c128:
+                    a[:, piece] = flat_in[addr]
+                else:
+                    a[:, 2 * piece] = flat_in[addr]
+                    a[:, 2 * piece + 1] = flat_in[addr + 1]
             tb = sum(lb[b_] * kp.tb_contrib[b_] for b_ in range(6))
             scale = np.complex128(1.0)
-            moff = kp.mat_base_bytes // 8
+            moff = kp.mat_base_bytes // EL
             i = 0
             while i < nrec:
                 w = rec[i]
@@ -142,22 +184,23 @@ def run_pass(desc, n, state, mats, mat_batch_stride):
                     packed = sum(lb[b_].astype(np.int64) * wb2[b_] for b_ in range(6))
                     wbase, rbase = packed & 0xFFFF, packed >> 16
                     lds = {}
+                    rg = regs_of(a)
                     for ln in g.trip(k, mask):
-                        if ln.startswith('ds_write_b64'):
-                            mm = re.fullmatch(r'ds_write_b64 v\d+, (v\[\d+:\d+\])(?: offset:(\d+))?', ln)
-                            j, imm = _amp_index(mm.group(1)), int(mm.group(2) or 0)
+                        if ln.startswith('ds_write_b'):
+                            mm = re.fullmatch(r'ds_write_b(?:64|128) v\d+, (v\[\d+:\d+\])(?: offset:(\d+))?', ln)
+                            j, imm = rg.amp(mm.group(1)), int(mm.group(2) or 0)
                             for lane in range(64):
                                 ad = int(wbase[lane]) + imm
-                                assert ad % 8 == 0 and ad < 8448, 'LDS write outside the wave\'s region'
+                                assert ad % EL == 0 and ad + EL <= (8704 if c128 else 8448), 'LDS write outside the wave\'s region'
                                 lds[ad] = a[lane, j]
-                        elif ln.startswith('ds_read_b64'):
-                            mm = re.fullmatch(r'ds_read_b64 (v\[\d+:\d+\]), v\d+(?: offset:(\d+))?', ln)
-                            j, imm = _amp_index(mm.group(1)), int(mm.group(2) or 0)
+                        elif ln.startswith('ds_read_b'):
+                            mm = re.fullmatch(r'ds_read_b(?:64|128) (v\[\d+:\d+\]), v\d+(?: offset:(\d+))?', ln)
+                            j, imm = rg.amp(mm.group(1)), int(mm.group(2) or 0)
                             for lane in range(64):
                                 a[lane, j] = lds[int(rbase[lane]) + imm]      # KeyError: reads what nobody wrote
                     continue
                 if hid in swap_of:
-                    _run_moves(g.slotswap(*swap_of[hid]), a, np.ones(64, bool))
+                    _run_moves(g, g.slotswap(*swap_of[hid]), a, np.ones(64, bool))
                     continue
                 if not tile_ok:
                     continue
@@ -165,7 +208,7 @@ def run_pass(desc, n, state, mats, mat_batch_stride):
                     # diagonal gate (tools/gen_wave_asm.py, diag_code): four phases, candidates by the indices in w5,
                     # two per-lane selectors, PH0 / PH1 by the bit of one register slot, an optional register mask
                     four = hid >= g.ID_DIAG2
-                    variant = (hid - g.ID_DIAG1) % 14
+                    variant = (hid - g.ID_DIAG1) % NV
                     if four:
                         blk = mb[moff - 16:moff]
                         d = [blk[0], blk[5], blk[10], blk[15]]
@@ -186,18 +229,18 @@ def run_pass(desc, n, state, mats, mat_batch_stride):
                     c1 = {k: d[(w5 >> (24 + 2 * k)) & 3] for k in (0, 2)}
                     ph0 = np.where(sa, np.where(sb, c0[3], c0[2]), np.where(sb, c0[1], c0[0]))
                     ph1 = np.where(sa, c1[2], c1[0])
-                    masked, v = variant >= 7, variant % 7
+                    masked, v = variant >= R + 1, variant % (R + 1)
                     rmask = w[6] | (w[7] << 32)
-                    for j in range(64):
+                    for j in range(NA):
                         if masked and not (rmask >> j) & 1:
                             continue
                         ph = ph0 if v == 0 or not (j >> (v - 1)) & 1 else ph1
                         a[active, j] = (a[:, j] * ph.astype(a.dtype))[active]
                     continue
                 if g.ID_GEN_U <= hid < g.ID_GEN_C:
-                    mode, q = divmod(hid - g.ID_GEN_U, 6)
+                    mode, q = divmod(hid - g.ID_GEN_U, R)
                     everyone = np.ones(64, bool)
-                    if mode == 2:       # the deferred Rx block { f, (0, t), -, (flag, -) }
+                    if mode == 2 and not c128:       # the deferred Rx block { f, (0, t), -, (flag, -) }
                         f, it, flag = m[0], m[1], m[3].real
                         assert it.real == 0 and flag in (0.0, 1.0)
                         mat = np.array([1, it, it, 1]) if flag == 0 else np.array([it, 1, 1, it])
@@ -217,9 +260,9 @@ def run_pass(desc, n, state, mats, mat_batch_stride):
                         if (w[5] >> pi) & 1:
                             _apply2(a, lo, hi, m, active)
                 elif g.ID_X_U <= hid < g.ID_X_C:
-                    _run_moves(g.xlines(hid - g.ID_X_U), a, np.ones(64, bool))
+                    _run_moves(g, g.xlines(hid - g.ID_X_U), a, np.ones(64, bool))
                 elif g.ID_X_C <= hid < g.ID_X_R:
-                    _run_moves(g.xlines(hid - g.ID_X_C), a, active)
+                    _run_moves(g, g.xlines(hid - g.ID_X_C), a, active)
                 elif g.ID_X_R <= hid < g.ID_X_R1:
                     q = hid - g.ID_X_R
                     for pi, (lo, hi) in enumerate(g.pairs(q)):
@@ -228,16 +271,19 @@ def run_pass(desc, n, state, mats, mat_batch_stride):
                             a[active, lo] = a[active, hi]
                             a[active, hi] = x0[active]
                 elif g.ID_X_R1 <= hid < g.ID_TRIP0:
-                    q, cc = divmod(hid - g.ID_X_R1, 5)
+                    q, cc = divmod(hid - g.ID_X_R1, R - 1)
                     c = cc if cc < q else cc + 1
-                    _run_moves(g.xlines(q, 1 << c), a, active)
+                    _run_moves(g, g.xlines(q, 1 << c), a, active)
                 else:
                     raise AssertionError(f'unknown handler id {hid}')
             a = (a * scale).astype(state.dtype)
             base = b
             for piece in range(32):
                 off = sum(kp.store_off[s] for s in range(5) if (piece >> s) & 1)
-                addr = (tw * 8 + off + lst) // 8
-                out[base][addr] = a[:, 2 * piece]
-                out[base][addr + 1] = a[:, 2 * piece + 1]
+                addr = (tw * EL + off + lst) // EL
+                if c128:
+                    out[base][addr] = a[:, piece]
+                else:
+                    out[base][addr] = a[:, 2 * piece]
+                    out[base][addr + 1] = a[:, 2 * piece + 1]
     return out

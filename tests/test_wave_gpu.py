@@ -1,5 +1,6 @@
-"""The wave-tile kernel (csrc/dq_wave.hip, complex64 default geometry) on the GPU, through the C ABI, against the oracle
-applying the same gates one by one (1e-4 on amplitudes, the north star's complex64 bar; measured ~1e-6)."""
+"""The wave-tile kernels (csrc/dq_wave.hip, the default geometry of both precisions) on the GPU, through the C ABI, against
+the oracle applying the same gates one by one: 1e-4 (complex64) / 1e-10 (complex128) on amplitudes, the north star's bars
+(measured ~1e-6 / ~1e-15)."""
 
 import pytest
 import torch
@@ -9,50 +10,60 @@ from deepquantum_amd import backend, fusion
 from test_wave_cpu import random_ops, reference
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+TOL = {False: 1e-4, True: 1e-10}
+PREC = pytest.mark.parametrize('is128', [False, True], ids=['c64', 'c128'])
 
 
 def dev():
     return torch.device('cuda', 0)
 
 
-def rand_state(b, n, seed):
+def cdtype(is128):
+    return torch.complex128 if is128 else torch.complex64
+
+
+def rand_state(b, n, seed, is128=False):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(b, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(b, 1 << n, generator=g, dtype=torch.float64)
-    return (x / x.norm(dim=-1, keepdim=True)).to(torch.complex64)
+    return (x / x.norm(dim=-1, keepdim=True)).to(cdtype(is128))
 
 
-def wave_steps(ops, n, permute=False):
-    geom = fusion.default_geometry(False)
+def wave_steps(ops, n, permute=False, is128=False):
+    geom = fusion.default_geometry(is128)
     assert geom.wave
     geom.permute_store = permute
-    geom.plan_min_bits = 12
+    geom.plan_min_bits = 11
     steps = fusion.schedule(ops, n, geom)
-    assert all(isinstance(s, fusion.FusedStep) and s.desc.slots == 6 and s.desc.m == 12 for s in steps)
+    want = (5, 11) if is128 else (6, 12)
+    assert all(isinstance(s, fusion.FusedStep) and (s.desc.slots, s.desc.m) == want for s in steps)
     return steps
 
 
+@PREC
 @pytest.mark.parametrize('n,ngates,seed', [(12, 60, 0), (13, 120, 1), (14, 200, 2), (15, 300, 3), (17, 300, 4), (20, 400, 5)])
-def test_wave_passes_match_oracle_in_place(n, ngates, seed):
+def test_wave_passes_match_oracle_in_place(n, ngates, seed, is128):
     ops, mats = random_ops(n, ngates, seed)
-    steps = wave_steps(ops, n)
-    x = rand_state(2, n, 10 + seed)
+    mats = mats.to(cdtype(is128))
+    steps = wave_steps(ops, n, is128=is128)
+    x = rand_state(2, n, 10 + seed, is128)
     ref = reference(x, ops, mats)
     xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
     for st in steps:
         backend.apply_fused(xd, md, 0, st.desc, out=xd)
     err = (xd.cpu() - ref).abs().max().item()
-    assert err < TOL, err
+    assert err < TOL[is128], err
 
 
+@PREC
 @pytest.mark.parametrize('n,ngates,seed', [(14, 150, 5), (16, 260, 4), (18, 300, 6), (21, 500, 7)])
-def test_wave_passes_with_permuted_stores(n, ngates, seed):
+def test_wave_passes_with_permuted_stores(n, ngates, seed, is128):
     """Out-of-place passes that re-label index bits on the way out (every tile after the first is contiguous on the
     read side, the low bits move too): the store layout is reached by a trip, a lane permutation or a slot swap."""
     ops, mats = random_ops(n, ngates, seed)
-    steps = wave_steps(ops, n, permute=True)
+    mats = mats.to(cdtype(is128))
+    steps = wave_steps(ops, n, permute=True, is128=is128)
     assert any(s.permutes for s in steps)
-    x = rand_state(2, n, 20 + seed)
+    x = rand_state(2, n, 20 + seed, is128)
     ref = reference(x, ops, mats)
     cur, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
     for st in steps:
@@ -60,17 +71,19 @@ def test_wave_passes_with_permuted_stores(n, ngates, seed):
         backend.apply_fused(cur, md, 0, st.desc, out=nxt)
         cur = nxt
     err = (cur.cpu() - ref).abs().max().item()
-    assert err < TOL, err
+    assert err < TOL[is128], err
 
 
-def test_wave_kernel_equals_its_cpu_emulation():
+@PREC
+def test_wave_kernel_equals_its_cpu_emulation(is128):
     """Pass by pass against tests/_wave_emulator.py (the library's own records executed on the CPU)."""
     import _wave_emulator as emu
 
     n = 14
     ops, mats = random_ops(n, 200, 8)
-    steps = wave_steps(ops, n, permute=True)
-    x = rand_state(2, n, 3)
+    mats = mats.to(cdtype(is128))
+    steps = wave_steps(ops, n, permute=True, is128=is128)
+    x = rand_state(2, n, 3, is128)
     km = fusion.kernel_matrices(steps, ops, mats)
     cur, md = x.to(dev()), km.to(dev())
     cur_e = x.numpy().copy()
@@ -79,11 +92,12 @@ def test_wave_kernel_equals_its_cpu_emulation():
         backend.apply_fused(cur, md, 0, st.desc, out=nxt)
         cur = nxt
         cur_e = emu.run_pass(st.desc, n, cur_e, km.numpy(), 0)
-        assert (cur.cpu() - torch.from_numpy(cur_e)).abs().max().item() < 2e-6
+        assert (cur.cpu() - torch.from_numpy(cur_e)).abs().max().item() < (1e-13 if is128 else 2e-6)
 
 
+@PREC
 @pytest.mark.parametrize('n,b', [(15, 3), (16, 16), (13, 4), (12, 5)])
-def test_wave_batched_matrices_and_one_shared_input_state(n, b):
+def test_wave_batched_matrices_and_one_shared_input_state(n, b, is128):
     """Per-sample matrices (the vmap case of circuit.py:232-240) and the first pass of a batched circuit reading ONE
     input state (dq_apply_fused_bcast_c64)."""
     ops, mats0 = random_ops(n, 60, 21)
@@ -95,11 +109,12 @@ def test_wave_batched_matrices_and_one_shared_input_state(n, b):
             c, s_ = torch.cos(th / 2), torch.sin(th / 2)
             m = torch.stack([c + 0j, -1j * s_, -1j * s_, c + 0j], dim=1).to(torch.complex64)
             mats[:, op.mat:op.mat + 4] = m
-    steps = wave_steps(ops, n)
-    x1 = rand_state(1, n, 31)
+    mats = mats.to(cdtype(is128))
+    steps = wave_steps(ops, n, is128=is128)
+    x1 = rand_state(1, n, 31, is128)
     ref = torch.cat([reference(x1, ops, mats[i]) for i in range(b)])
     km = fusion.kernel_matrices(steps, ops, mats).to(dev())
-    out = torch.empty(b, 1 << n, dtype=torch.complex64, device=dev())
+    out = torch.empty(b, 1 << n, dtype=cdtype(is128), device=dev())
     src = x1.to(dev())
     for k, st in enumerate(steps):
         if k == 0:
@@ -107,7 +122,7 @@ def test_wave_batched_matrices_and_one_shared_input_state(n, b):
         else:
             backend.apply_fused(out, km.reshape(-1), km.shape[1], st.desc, out=out)
     err = (out.cpu() - ref).abs().max().item()
-    assert err < TOL, err
+    assert err < TOL[is128], err
     assert torch.equal(src.cpu(), x1)
 
 

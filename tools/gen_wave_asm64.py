@@ -1,0 +1,346 @@
+"""Generate csrc/dq_wave_asm64.inc: the body of the wave-tile pass kernel for complex128.
+
+Same design as tools/gen_wave_asm.py (one wavefront per tile, no workgroup barrier, layout changes through a small
+wave-private LDS buffer), with 16-byte amplitudes: 64 lanes x 32 amplitudes = an 11-bit tile in v[40:167] (amplitude j:
+re = v[40 + 4j : 41 + 4j], im = v[42 + 4j : 43 + 4j]), five register-slot bits, v_fma_f64 bodies, ds_*_b128 trips of up
+to three slots (8.6 KiB per wave).  Record format and handler families as in the complex64 generator; the matrix of a
+gate is 16 dwords (s[80:95]), the Hadamard factor is deferred (a real f64), Rx-like gates keep their plain matrix.
+"""
+import os
+
+R = 5
+NA = 1 << R
+AMP0 = 40
+TMP = ['v[10:11]', 'v[12:13]', 'v[14:15]', 'v[16:17]']
+TT, HS, TB, LANE, WB, RB = 'v18', 'v[20:21]', 'v22', 'v23', 'v24', 'v25'
+LB = [f'v{26 + b}' for b in range(6)]            # the lane's bits as masks: 0 / 0xffffffff
+ADDR = ['v[32:33]', 'v[34:35]', 'v[36:37]', 'v[38:39]']
+LLD, LST = 'v[2:3]', 'v[4:5]'
+RUN, SAVE, TABLE = 's[50:51]', 's[52:53]', 's[54:55]'
+GOFF, GEND, MOFF, STMP = 's58', 's59', 's60', 's61'
+MB, KG, TG, LDSB = 's[62:63]', 's[64:65]', 's[66:67]', 's68'
+REC, REC2, MAT = 72, 80, 80
+MNAMES = ['00r', '00i', '01r', '01i', '10r', '10i', '11r', '11i']
+M = {nm: f's[{MAT + 2 * i}:{MAT + 2 * i + 1}]' for i, nm in enumerate(MNAMES)}
+ELEM = 16
+
+
+def RE(j):
+    return f'v[{AMP0 + 4 * j}:{AMP0 + 4 * j + 1}]'
+
+
+def IM(j):
+    return f'v[{AMP0 + 4 * j + 2}:{AMP0 + 4 * j + 3}]'
+
+
+def A(j):
+    return f'v[{AMP0 + 4 * j}:{AMP0 + 4 * j + 3}]'
+
+
+def pairs(q, cmask=0):
+    return [(j, j | (1 << q)) for j in range(NA) if not (j >> q) & 1 and (j & cmask) == cmask]
+
+
+def pair_body(mode, lo, hi):
+    ar, ai, br, bi = RE(lo), IM(lo), RE(hi), IM(hi)
+    t = TMP
+    if mode == 3:      # s [[1, 1], [1, -1]], s deferred
+        return [f'v_add_f64 {ar}, {ar}, {br}', f'v_add_f64 {ai}, {ai}, {bi}',
+                f'v_fma_f64 {br}, -2.0, {br}, {ar}', f'v_fma_f64 {bi}, -2.0, {bi}, {ai}']
+    last = [f'v_fma_f64 {ar}, {M["00r"]}, {ar}, {t[0]}', f'v_fma_f64 {ai}, {M["00r"]}, {ai}, {t[1]}',
+            f'v_fma_f64 {br}, {M["11r"]}, {br}, {t[2]}', f'v_fma_f64 {bi}, {M["11r"]}, {bi}, {t[3]}']
+    if mode == 1:      # real matrix
+        return [f'v_mul_f64 {t[0]}, {M["01r"]}, {br}', f'v_mul_f64 {t[1]}, {M["01r"]}, {bi}',
+                f'v_mul_f64 {t[2]}, {M["10r"]}, {ar}', f'v_mul_f64 {t[3]}, {M["10r"]}, {ai}'] + last
+    if mode == 2:      # real diagonal, imaginary off-diagonal: (i s)(x + i y) = -s y + i s x
+        return [f'v_mul_f64 {t[0]}, -{M["01i"]}, {bi}', f'v_mul_f64 {t[1]}, {M["01i"]}, {br}',
+                f'v_mul_f64 {t[2]}, -{M["10i"]}, {ai}', f'v_mul_f64 {t[3]}, {M["10i"]}, {ar}'] + last
+    return [f'v_mul_f64 {t[0]}, -{M["00i"]}, {ai}', f'v_mul_f64 {t[1]}, {M["00i"]}, {ar}',
+            f'v_mul_f64 {t[2]}, {M["10r"]}, {ar}', f'v_mul_f64 {t[3]}, {M["10r"]}, {ai}',
+            f'v_fma_f64 {t[0]}, {M["01r"]}, {br}, {t[0]}', f'v_fma_f64 {t[1]}, {M["01r"]}, {bi}, {t[1]}',
+            f'v_fma_f64 {t[2]}, -{M["10i"]}, {ai}, {t[2]}', f'v_fma_f64 {t[3]}, {M["10i"]}, {ar}, {t[3]}',
+            f'v_fma_f64 {t[0]}, -{M["01i"]}, {bi}, {t[0]}', f'v_fma_f64 {t[1]}, {M["01i"]}, {br}, {t[1]}',
+            f'v_fma_f64 {t[2]}, -{M["11i"]}, {bi}, {t[2]}', f'v_fma_f64 {t[3]}, {M["11i"]}, {br}, {t[3]}'] + last
+
+
+def body(mode, q):
+    out_ = []
+    for lo, hi in pairs(q):
+        out_ += pair_body(mode, lo, hi)
+    return out_
+
+
+def swap_pair(lo, hi):
+    t = TMP
+    return [f'v_mov_b64 {t[0]}, {RE(lo)}', f'v_mov_b64 {t[1]}, {IM(lo)}', f'v_mov_b64 {RE(lo)}, {RE(hi)}', f'v_mov_b64 {IM(lo)}, {IM(hi)}',
+            f'v_mov_b64 {RE(hi)}, {t[0]}', f'v_mov_b64 {IM(hi)}, {t[1]}']
+
+
+def xlines(q, cmask=0):
+    out_ = []
+    for lo, hi in pairs(q, cmask):
+        out_ += swap_pair(lo, hi)
+    return out_
+
+
+def masked(q, tag, per_pair):
+    out_ = []
+    for i, (lo, hi) in enumerate(pairs(q)):
+        out_ += [f's_bitcmp1_b32 s{REC + 5}, {i}', f's_cbranch_scc0 .Lm{tag}_{i}_%='] + per_pair(lo, hi) + [f'.Lm{tag}_{i}_%=:']
+    return out_
+
+
+def slotswap(i, j):
+    out_ = []
+    for r in range(NA):
+        if (r >> i) & 1 and not (r >> j) & 1:
+            out_ += swap_pair(r, r ^ (1 << i) ^ (1 << j))
+    return out_
+
+
+def deposit(val, positions):
+    return sum(((val >> i) & 1) << p for i, p in enumerate(positions))
+
+
+def trip(k, mask):
+    """As in the complex64 generator, 16-byte elements: slot (16-byte units) of element (x, y, z) = x * S + (y << a) + F(z),
+    S = 64 + 2^a, a = 5 - k."""
+    pre = [f's_load_dwordx8 s[{REC2}:{REC2 + 7}], {KG}, {GOFF}', f's_add_u32 {GOFF}, {GOFF}, 32']
+    tbw = [REC + 1, REC + 2, REC + 3, REC + 5, REC + 6, REC + 7]
+    pre += [f'v_and_b32 {TB}, s{tbw[0]}, {LB[0]}'] + [f'v_and_or_b32 {TB}, {LB[b]}, s{tbw[b]}, {TB}' for b in range(1, 6)]
+    pre += ['s_waitcnt lgkmcnt(0)']
+    pre += [f'v_and_b32 {WB}, s{REC2}, {LB[0]}'] + [f'v_and_or_b32 {WB}, {LB[b]}, s{REC2 + b}, {WB}' for b in range(1, 6)]
+    pre += [f'v_lshrrev_b32 {RB}, 16, {WB}', f'v_and_b32 {WB}, 0xffff, {WB}', f'v_add_u32 {WB}, {LDSB}, {WB}', f'v_add_u32 {RB}, {LDSB}, {RB}']
+    if k == 0:
+        body_ = []
+        for j in range(NA):
+            body_ += [f'ds_write_b128 {WB}, {A(j)}', f'ds_read_b128 {A(j)}, {RB}']
+        return pre + body_
+    a = 5 - k
+    S = 64 + (1 << a)
+    moving = [s for s in range(R) if (mask >> s) & 1]
+    staying = [s for s in range(R) if not (mask >> s) & 1]
+    body_ = []
+    for g in range(1 << (R - k)):
+        base = deposit(g, staying)
+        for x in range(1 << k):
+            body_.append(f'ds_write_b128 {WB}, {A(base | deposit(x, moving))} offset:{ELEM * S * x}')
+        for y in range(1 << k):
+            body_.append(f'ds_read_b128 {A(base | deposit(y, moving))}, {RB} offset:{ELEM * (y << a)}')
+    return pre + body_
+
+
+MAXK = 3
+TRIP_MASKS = [m for m in range(1, NA) if bin(m).count('1') <= MAXK]
+SWAP_PAIRS = [(i, j) for i in range(R) for j in range(i + 1, R)]
+NV = 2 * (R + 1)      # diag variants: 0 all, 1 + q by slot q, then the same with a register mask
+
+ID_GEN_U = 0          # + 5 * mode + q
+ID_GEN_C = 4 * R      # + q
+ID_GEN_R = ID_GEN_C + R
+ID_X_U = ID_GEN_R + R
+ID_X_C = ID_X_U + R
+ID_X_R = ID_X_C + R
+ID_X_R1 = ID_X_R + R  # + 4 * q + c'
+ID_TRIP0 = ID_X_R1 + R * (R - 1)
+ID_TRIP = ID_TRIP0 + 1
+ID_SWAP = ID_TRIP + len(TRIP_MASKS)
+ID_DIAG1 = ID_SWAP + len(SWAP_PAIRS)
+ID_DIAG2 = ID_DIAG1 + NV
+NIDS = ID_DIAG2 + NV
+
+
+def handlers():
+    h = {}
+    for q in range(R):
+        for mode in (0, 1, 2):
+            h[ID_GEN_U + R * mode + q] = (False, body(mode, q))
+        h[ID_GEN_U + R * 3 + q] = (False, [f'v_mul_f64 {HS}, {HS}, {M["00r"]}'] + body(3, q))
+        h[ID_GEN_C + q] = (True, body(0, q))
+        h[ID_GEN_R + q] = (True, masked(q, f'g{q}', lambda lo, hi: pair_body(0, lo, hi)))
+        h[ID_X_U + q] = (False, xlines(q))
+        h[ID_X_C + q] = (True, xlines(q))
+        h[ID_X_R + q] = (True, masked(q, f'x{q}', swap_pair))
+        for c in range(R):
+            if c != q:
+                h[ID_X_R1 + (R - 1) * q + (c if c < q else c - 1)] = (True, xlines(q, 1 << c))
+    h[ID_TRIP0] = (False, trip(0, 0))
+    for i, m in enumerate(TRIP_MASKS):
+        h[ID_TRIP + i] = (False, trip(bin(m).count('1'), m))
+    for i, (a_, b_) in enumerate(SWAP_PAIRS):
+        h[ID_SWAP + i] = (False, slotswap(a_, b_))
+    return h
+
+
+PH0, PH1 = ('v[6:7]', 'v[8:9]'), ('v[32:33]', 'v[34:35]')        # (re, im) as f64 pairs
+
+
+def cmul_inplace(j, ph):
+    t = TMP[0] if j % 2 == 0 else TMP[1]
+    return [f'v_mul_f64 {t}, {RE(j)}, {ph[1]}', f'v_mul_f64 {RE(j)}, {RE(j)}, {ph[0]}',
+            f'v_fma_f64 {RE(j)}, -{IM(j)}, {ph[1]}, {RE(j)}', f'v_fma_f64 {IM(j)}, {IM(j)}, {ph[0]}, {t}']
+
+
+def diag_body(variant):
+    masked_, v = variant >= R + 1, variant % (R + 1)
+    out_ = []
+    for j in range(NA):
+        ph = PH0 if v == 0 or not (j >> (v - 1)) & 1 else PH1
+        if masked_:
+            out_ += [f's_bitcmp1_b32 s{REC + 6}, {j}', f's_cbranch_scc0 .Ldg{variant}_{j}_%=']
+        out_ += cmul_inplace(j, ph)
+        if masked_:
+            out_.append(f'.Ldg{variant}_{j}_%=:')
+    return out_
+
+
+def diag_code():
+    """As in the complex64 generator.  The four phases (16 bytes each) sit in s[80:95] -- the diagonal of the 2x2 block the
+    loop head loaded (entries 0, 3, twice), or of the 4x4 block that ends at the current matrix offset (entries 0, 5, 10,
+    15) -- and the candidates of PH0 / PH1 go through s[40:43] into VGPRs."""
+    W5 = f's{REC + 5}'
+    t = ['.Ldiag_%=:',
+         f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc0 .Lnext_%=',
+         f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
+         's_cbranch_execz .Lrestore_%=',
+         f's_cmp_ge_u32 s{REC}, {ID_DIAG2}', 's_cbranch_scc1 .Ldiag4_%=',
+         # 2x2 block: entry 0 = s[80:83] stays, entry 3 = s[92:95] -> phase 1 (s[84:87]); phases 2, 3 = copies
+         's_mov_b64 s[84:85], s[92:93]', 's_mov_b64 s[86:87], s[94:95]', 's_mov_b64 s[88:89], s[80:81]', 's_mov_b64 s[90:91], s[82:83]',
+         's_mov_b64 s[92:93], s[84:85]', 's_mov_b64 s[94:95], s[86:87]',
+         's_branch .Ldiagsel_%=', '.Ldiag4_%=:', f's_sub_u32 s69, {MOFF}, 256']
+    for k in range(4):
+        t += [f's_load_dwordx4 s[{80 + 4 * k}:{83 + 4 * k}], {MB}, s69'] + (['s_add_u32 s69, s69, 80'] if k < 3 else [])
+    t += ['s_waitcnt lgkmcnt(0)', '.Ldiagsel_%=:']
+    for name, byte, dst in (('a', 0, 's[50:51]'), ('b', 8, 's[70:71]')):
+        t += [f's_bfe_u32 s69, {W5}, {byte | (6 << 16)}', f's_bfe_u32 vcc_lo, {W5}, {(byte + 6) | (2 << 16)}', f's_mov_b64 {dst}, 0',
+              's_cmp_eq_u32 vcc_lo, 1', f's_cbranch_scc0 .Lsel{name}o_%=',
+              f'v_lshrrev_b32 {TT}, s69, {TB}', f'v_and_b32 {TT}, 1, {TT}', f'v_cmp_ne_u32 {dst}, 0, {TT}', f's_branch .Lsel{name}d_%=',
+              f'.Lsel{name}o_%=:', 's_cmp_eq_u32 vcc_lo, 2', f's_cbranch_scc0 .Lsel{name}d_%=',
+              f's_lshr_b64 vcc, {TG}, s69', 's_bitcmp1_b32 vcc_lo, 0', f's_cselect_b64 {dst}, -1, 0', f'.Lsel{name}d_%=:']
+
+    def fetch(bitpos, vbase):      # candidate = phase number (2 bits of w5 at bitpos) -> 4 dwords in v[vbase : vbase + 3]
+        return [f's_bfe_u32 s69, {W5}, {bitpos | (2 << 16)}', 's_lshl_b32 m0, s69, 2', 's_nop 0',
+                's_movrels_b64 s[40:41], s[80:81]', 's_movrels_b64 s[42:43], s[82:83]'] + \
+               [f'v_mov_b32 v{vbase + d}, s{40 + d}' for d in range(4)]
+
+    # PH0 = selA ? (selB ? c3 : c2) : (selB ? c1 : c0): candidates in v[10:13], v[14:17], v[36:39], v[32:35]
+    cv = [10, 14, 36, 32]
+    for k in range(4):
+        t += fetch(16 + 2 * k, cv[k])
+    for d in range(4):
+        t += [f'v_cndmask_b32 v{cv[0] + d}, v{cv[0] + d}, v{cv[1] + d}, s[70:71]', f'v_cndmask_b32 v{cv[2] + d}, v{cv[2] + d}, v{cv[3] + d}, s[70:71]',
+              f'v_cndmask_b32 v{6 + d}, v{cv[0] + d}, v{cv[2] + d}, s[50:51]']
+    # PH1 = selA ? c2 : c0 -> v[32:35]
+    t += fetch(24, 10) + fetch(28, 14)
+    t += [f'v_cndmask_b32 v{32 + d}, v{10 + d}, v{14 + d}, s[50:51]' for d in range(4)]
+    t += [f's_sub_u32 s69, s{REC}, {ID_DIAG1}', f's_cmp_ge_u32 s69, {NV}', 's_cbranch_scc0 .Ldiagv_%=', f's_sub_u32 s69, s69, {NV}', '.Ldiagv_%=:',
+          's_getpc_b64 vcc', '.Ldiaganchor_%=:', 's_lshl2_add_u32 vcc_lo, s69, vcc_lo', 's_addc_u32 vcc_hi, vcc_hi, 0',
+          's_add_u32 vcc_lo, vcc_lo, .Ldiagtable_%=-.Ldiaganchor_%=', 's_addc_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc', '.Ldiagtable_%=:']
+    t += [f's_branch .Ldiagb{v}_%=' for v in range(NV)]
+    for v in range(NV):
+        t += [f'.Ldiagb{v}_%=:'] + diag_body(v) + [f's_mov_b64 exec, {SAVE}', f's_cmp_lt_u32 {GOFF}, {GEND}', 's_cbranch_scc1 .Lloop_%=', 's_branch .Lexit_%=']
+    return t
+
+
+def gray_walk(op, base_operand, lane_operand):
+    """32 x (address = base + running slot offset + lane offset; op): a Gray code over the five slot bits."""
+    out_ = [f's_mov_b64 {RUN}, {base_operand}']
+    for i in range(NA):
+        g = i ^ (i >> 1)
+        if i:
+            b = (i & -i).bit_length() - 1
+            lo, hi = f's{40 + 2 * b}', f's{41 + 2 * b}'
+            if (g >> b) & 1:
+                out_ += [f's_add_u32 s50, s50, {lo}', f's_addc_u32 s51, s51, {hi}']
+            else:
+                out_ += [f's_sub_u32 s50, s50, {lo}', f's_subb_u32 s51, s51, {hi}']
+        ad = ADDR[i % 4]
+        out_.append(f'v_lshl_add_u64 {ad}, {RUN}, 0, {lane_operand}')
+        out_.append(f'global_load_dwordx4 {A(g)}, {ad}, off' if op == 'load' else f'global_store_dwordx4 {ad}, {A(g)}, off')
+    return out_
+
+
+def kernel_body():
+    h = handlers()
+    ids = sorted(h)
+    front = [i for i in ids if i < ID_TRIP0]
+    back = [i for i in ids if i >= ID_TRIP0]
+    nxt = [f's_cmp_lt_u32 {GOFF}, {GEND}', 's_cbranch_scc1 .Lloop_%=', 's_branch .Lexit_%=']
+
+    def emit(i):
+        ctl, lines = h[i]
+        out_ = [f'.Lh{i}_%=:']
+        if ctl:
+            out_ += [f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]',
+                     's_cbranch_scc0 .Lnext_%=',
+                     f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}',
+                     f's_and_saveexec_b64 {SAVE}, vcc', 's_cbranch_execz .Lrestore_%=']
+        out_ += lines
+        if ctl:
+            out_.append(f's_mov_b64 exec, {SAVE}')
+        return out_ + nxt
+
+    text = [f's_mov_b64 {KG}, %[kg]', f's_mov_b32 {GOFF}, 0', f's_mov_b32 {GEND}, %[gend]', f's_mov_b64 {MB}, %[mb]',
+            f's_mov_b32 {MOFF}, %[moff]', f's_mov_b64 {TG}, %[tg]', f's_mov_b32 {LDSB}, %[ldsb]',
+            's_load_dwordx8 s[40:47], %[ks], 0', 's_load_dwordx2 s[48:49], %[ks], 32',
+            f's_load_dwordx8 s[{REC}:{REC + 7}], %[ks], 80', 's_load_dwordx8 s[80:87], %[ks], 112',
+            's_load_dwordx2 s[88:89], %[ks], 144',
+            f'v_and_b32 {LANE}, 63, %[tid]', 'v_mov_b32 v20, 0', 'v_mov_b32 v21, 0x3ff00000']        # HS = 1.0
+    text += [f'v_bfe_i32 {LB[b]}, {LANE}, {b}, 1' for b in range(6)]
+    text += ['v_mov_b32 v2, 0', 'v_mov_b32 v3, 0', 'v_mov_b32 v4, 0', 'v_mov_b32 v5, 0', 's_waitcnt lgkmcnt(0)']
+    text += [f'v_and_b32 {TB}, s{REC + 12}, {LB[0]}'] + [f'v_and_or_b32 {TB}, {LB[b]}, s{REC + 12 + b}, {TB}' for b in range(1, 6)]
+    for b in range(6):
+        for lo, hi, sh in (('v2', 'v3', REC + b), ('v4', 'v5', REC + 6 + b)):
+            text += [f'v_and_b32 v32, 1, {LB[b]}', 'v_mov_b32 v33, 0', f'v_lshlrev_b64 v[32:33], s{sh}, v[32:33]',
+                     f'v_or_b32 {lo}, {lo}, v32', f'v_or_b32 {hi}, {hi}, v33']
+    text += gray_walk('load', '%[inb]', LLD)
+    text += [f's_getpc_b64 {TABLE}', '.Lanchor_%=:', 's_add_u32 s54, s54, .Ltable_%=-.Lanchor_%=', 's_addc_u32 s55, s55, 0',
+             's_waitcnt vmcnt(0)', 's_branch .Lloop_%=']
+    for i in front:
+        text += emit(i)
+    text += ['.Lrestore_%=:', f's_mov_b64 exec, {SAVE}', '.Lnext_%=:'] + nxt
+    text += ['.Lloop_%=:',
+             f's_load_dwordx8 s[{REC}:{REC + 7}], {KG}, {GOFF}',
+             f's_load_dwordx16 s[{MAT}:{MAT + 15}], {MB}, {MOFF}',
+             's_waitcnt lgkmcnt(0)',
+             f's_add_u32 {GOFF}, {GOFF}, 32',
+             f's_lshl4_add_u32 {MOFF}, s{REC + 4}, {MOFF}',
+             f's_lshl2_add_u32 vcc_lo, s{REC}, s54', 's_addc_u32 vcc_hi, s55, 0', 's_setpc_b64 vcc',
+             '.Ltable_%=:']
+    for i in range(NIDS):
+        text.append(f's_branch .Lh{i}_%=' if i in h else ('s_branch .Ldiag_%=' if i >= ID_DIAG1 else 's_branch .Lnext_%='))
+    text += ['.Lexit_%=:', 's_load_dwordx8 s[40:47], %[ks], 40', 's_load_dwordx2 s[48:49], %[ks], 72', 's_waitcnt lgkmcnt(0)']
+    for j in range(NA):
+        text += [f'v_mul_f64 {RE(j)}, {RE(j)}, {HS}', f'v_mul_f64 {IM(j)}, {IM(j)}, {HS}']
+    text += gray_walk('store', '%[outb]', LST)
+    text += ['s_branch .Ldone_%=']
+    text += diag_code()
+    for i in back:
+        text += emit(i)
+    text += ['.Ldone_%=:']
+    return text
+
+
+if __name__ == '__main__' or os.environ.get('DQ_ASM_OUT'):
+    out = ['// GENERATED by tools/gen_wave_asm64.py -- do not edit by hand.', '// clang-format off',
+           f'#define DQ_WAVE64_NIDS {NIDS}', f'#define DQ_WAVE64_MAXK {MAXK}',
+           f'#define DQ_WID64_GEN_U {ID_GEN_U}', f'#define DQ_WID64_GEN_C {ID_GEN_C}', f'#define DQ_WID64_GEN_R {ID_GEN_R}',
+           f'#define DQ_WID64_X_U {ID_X_U}', f'#define DQ_WID64_X_C {ID_X_C}', f'#define DQ_WID64_X_R {ID_X_R}', f'#define DQ_WID64_X_R1 {ID_X_R1}',
+           f'#define DQ_WID64_TRIP0 {ID_TRIP0}', f'#define DQ_WID64_TRIP {ID_TRIP}', f'#define DQ_WID64_SWAP {ID_SWAP}',
+           f'#define DQ_WID64_DIAG1 {ID_DIAG1}', f'#define DQ_WID64_DIAG2 {ID_DIAG2}',
+           'static const short kWave64TripId[32] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(NA)) + '};',
+           'static const short kWave64SwapId[5][5] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
+           '']
+    text = '\\n\\t"\n        "'.join(kernel_body())
+    clob = ', '.join(['"m0"'] + [f'"s{i}"' for i in range(40, 96)] + [f'"v{i}"' for i in range(1, AMP0 + 4 * NA)])
+    out += ['__device__ __forceinline__ void wave_tile_body_f64(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg,',
+            '                                                   uint64_t ks, uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid) {',
+            f'    asm volatile(\n        "{text}"',
+            '        :',
+            '        : [kg] "s"(kg), [gend] "s"(gend), [mb] "s"(mb), [moff] "s"(moff), [tg] "s"(tg), [ks] "s"(ks), [inb] "s"(inb),',
+            '          [outb] "s"(outb), [ldsb] "s"(ldsb), [tid] "v"(tid)',
+            f'        : "vcc", "scc", "memory", {clob});',
+            '}', '// clang-format on', '']
+    path = os.environ.get('DQ_ASM_OUT') or os.path.join(os.path.dirname(__file__), '..', 'deepquantum_amd', 'csrc', 'dq_wave_asm64.inc')
+    open(path, 'w').write('\n'.join(out))
+    print('generated', NIDS, 'handler ids;', sum(len(v[1]) for v in handlers().values()), 'handler instructions')
