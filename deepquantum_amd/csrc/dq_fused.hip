@@ -1359,8 +1359,12 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     hipStream_t s = as_stream(stream);
     if (v.logt == 6) {     // one wavefront per tile: csrc/dq_wave.hip
         if (ngrads >= 0) {
-            set_error("dq_apply_fused_grad_c64: reverse-sweep passes run on the workgroup-tile geometries");
-            return DQ_ERR_UNSUPPORTED;
+            if constexpr (is128) {
+                set_error("dq_apply_fused_grad: complex64 only");
+                return DQ_ERR_UNSUPPORTED;
+            } else {
+                return wave_launch_grad_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+            }
         }
         if constexpr (is128) return wave_launch_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
         else return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);

@@ -43,7 +43,7 @@ struct WaveC64 {
     static constexpr unsigned LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID_GEN_U, ID_GEN_C = DQ_WID_GEN_C, ID_GEN_R = DQ_WID_GEN_R, ID_X_U = DQ_WID_X_U,
                          ID_X_C = DQ_WID_X_C, ID_X_R = DQ_WID_X_R, ID_X_R1 = DQ_WID_X_R1, ID_TRIP0 = DQ_WID_TRIP0,
-                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2;
+                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2, ID_GRAD = DQ_WID_GRAD;
     static int trip_id(unsigned mask) { return kWaveTripId[mask]; }
     static int swap_id(int i, int j) { return kWaveSwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -57,7 +57,7 @@ struct WaveC128 {
     static constexpr unsigned LDS_PER_WAVE = 8704;      // (7 * 68 + 64) * 16 bytes: the k = 3 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID64_GEN_U, ID_GEN_C = DQ_WID64_GEN_C, ID_GEN_R = DQ_WID64_GEN_R, ID_X_U = DQ_WID64_X_U,
                          ID_X_C = DQ_WID64_X_C, ID_X_R = DQ_WID64_X_R, ID_X_R1 = DQ_WID64_X_R1, ID_TRIP0 = DQ_WID64_TRIP0,
-                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2;
+                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = -1;      // (no reverse-sweep records yet)
     static int trip_id(unsigned mask) { return kWave64TripId[mask]; }
     static int swap_id(int i, int j) { return kWave64SwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -94,19 +94,29 @@ struct WaveKernArgs {
     int64_t mat_bstride;
     int64_t in_bstride;
     int n;
-    int pad_;
+    int tpw;
     WaveKernPass p;
+    double* grads;
+    int64_t grad_bstride;
 };
 static_assert(sizeof(WaveKernArgs) <= 4096 && (offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec)) % 32 == 0, "kernel-argument segment");
 
-template <class W>
+// GRAD: a pass of the adjoint method's reverse sweep (dq_apply_fused_grad_c64).  Its DQ_FG_GRAD records add their sums to
+// accumulators in LDS (32 bytes per record, behind the staging buffers); a wave walks `tpw` tiles so that a workgroup
+// adds to the caller's float64 `grads` only once: one atomic per record and component and 4 * tpw tiles.
+template <class W, bool GRAD>
 __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::real>* in, vec2<typename W::real>* out,
                                                         const vec2<typename W::real>* mats, int64_t mat_bstride,
-                                                        int64_t in_bstride, int n, int pad_, const WaveKernPass p) {
+                                                        int64_t in_bstride, int n, int tpw, const WaveKernPass p, double* grads,
+                                                        int64_t grad_bstride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dq_wave_smem[];
     (void)dq_wave_smem;
-    (void)pad_;
     const unsigned tid = threadIdx.x;
+    if constexpr (GRAD) {
+        for (unsigned i = tid; i < WAVE_MAX_REC * 8u; i += 256u)
+            *(__attribute__((address_space(3))) float*)(uintptr_t)(4u * W::LDS_PER_WAVE + 4u * i) = 0.0f;
+        __syncthreads();
+    }
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     unsigned grp = blockIdx.x, sample = blockIdx.y;
     // all samples read ONE input state (the first pass of a batched circuit): the B workgroups of a tile group become
@@ -117,8 +127,12 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
         sample = r >> 3;
         grp = group * 8u + (r & 7u);
     }
-    const uint64_t tile_id = (uint64_t)grp * 4u + wave;
-    if (tile_id >= (1ull << (n - W::M))) return;
+  for (int t = 0; t < (GRAD ? tpw : 1); ++t) {
+    const uint64_t tile_id = GRAD ? ((uint64_t)grp * 4u + wave) * (uint64_t)tpw + (uint64_t)t : (uint64_t)grp * 4u + wave;
+    if (tile_id >= (1ull << (n - W::M))) {
+        if constexpr (GRAD) break;
+        else return;
+    }
     // where the tile lies: bit j of the tile number goes to index bit read_blk_pos[j] / store_blk_pos[j] (the descriptor
     // is read as words through the constant address space: scalar loads, constant byte positions)
     typedef const __attribute__((address_space(4))) uint32_t* KWords;
@@ -140,6 +154,21 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
     const uint64_t mb = (uint64_t)(mats + (int64_t)sample * mat_bstride);
     W::body(karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec), p.nrec_bytes, mb, p.mat_base_bytes, tg,
             karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, load_off), inb, outb, wave * W::LDS_PER_WAVE, tid);
+  }
+    if constexpr (GRAD) {
+        __syncthreads();
+        typedef const __attribute__((address_space(4))) uint32_t* KW;
+        const KW rw = (KW)((uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec));
+        const unsigned nrec = p.nrec_bytes / 32u;
+        double* const grow = grads + (uint64_t)sample * (uint64_t)grad_bstride;
+        for (unsigned i = tid; i < nrec * 8u; i += 256u) {
+            const unsigned id = rw[8u * (i >> 3)];
+            if (id >= (unsigned)W::ID_GRAD && id < (unsigned)W::ID_GRAD + 5u) {
+                const float v = *(__attribute__((address_space(3))) float*)(uintptr_t)(4u * W::LDS_PER_WAVE + 4u * i);
+                atomicAdd(grow + (uint64_t)rw[8u * (i >> 3) + 6] * 8u + (i & 7u), (double)v);
+            }
+        }
+    }
 }
 
 // ---- host: DqFusedPass (rounds) -> records ------------------------------------------------------------------------
@@ -304,6 +333,35 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
         if (!x.go(want, nullptr)) goto fail;
         for (int gi = rd.gate_begin & 0x7f; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
+            if (g.kind == DQ_FG_GRAD && W::ID_GRAD >= 0) {
+                // reduction of the reverse sweep: the handlers want psi / lambda on physical slot 0 (where the load layout
+                // puts index bit 0 anyway); a register swap brings it back there if a trip moved it
+                int ps = x.slot_of(rd.rb[g.q2]);
+                if (ps != 0) {
+                    WaveRec sw{};
+                    sw.w[0] = (uint32_t)W::swap_id(0, ps);
+                    if (!x.push(sw)) goto fail;
+                    const int t_ = x.phys[0];
+                    x.phys[0] = x.phys[ps];
+                    x.phys[ps] = t_;
+                }
+                const int q = x.slot_of(rd.rb[g.q]);
+                unsigned pc = 0;
+                for (int s = 0; s < W::R; ++s)
+                    if ((g.reg_cmask >> s) & 1u) pc |= 1u << x.slot_of(rd.rb[s]);
+                WaveRec rec{};
+                rec.w[0] = (uint32_t)(W::ID_GRAD + q - 1);
+                rec.w[1] = g.thr_cmask;
+                rec.w[2] = (uint32_t)g.out_cmask, rec.w[3] = (uint32_t)(g.out_cmask >> 32);
+                for (int j = 0, i = 0; j < W::NA; ++j) {         // group i = the i-th pattern with bits q and 0 clear
+                    if (((j >> q) & 1) || (j & 1)) continue;
+                    if (((unsigned)j & pc) == pc) rec.w[5] |= 1u << i;
+                    ++i;
+                }
+                rec.w[6] = g.reserved;
+                if (!x.push(rec)) goto fail;
+                continue;
+            }
             if (g.kind != DQ_FG_GEN1 && g.kind != DQ_FG_X1 && g.kind != DQ_FG_DIAG1 && g.kind != DQ_FG_DIAG2) {
                 set_error("dq_apply_fused: the wave-tile kernel takes one-target and diagonal gates (record %d has kind %d); "
                           "plan this circuit for a workgroup-tile geometry", gi, (int)g.kind);
@@ -417,28 +475,35 @@ fail:
     return DQ_ERR_UNSUPPORTED;
 }
 
-template <class W>
+template <class W, bool GRAD = false>
 static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                       const DqFusedPass* pass, hipStream_t s) {
+                       const DqFusedPass* pass, hipStream_t s, double* grads = nullptr, int64_t ngrads = 0) {
     WaveKernPass kp;
     const int rc = wave_translate<W>(pass, n, &kp);
     if (rc) return rc;
     const uint64_t tiles = 1ull << (n - W::M);
-    dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)batch);
-    size_t lds = 4 * W::LDS_PER_WAVE;
+    int tpw = 1;
+    if (GRAD)       // tiles per wave: as many as leave >= 2048 workgroups per sample batch
+        while (tpw < 64 && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
+    dim3 grid((unsigned)((tiles + 4ull * tpw - 1) / (4ull * tpw)), (unsigned)batch);
+    size_t lds = 4 * W::LDS_PER_WAVE + (GRAD ? WAVE_MAX_REC * 32 : 0);
     if (const char* kb = getenv("DQ_WAVE_LDS_KB")) {      // occupancy experiments: workgroups per CU = 160 KiB / this
         lds = (size_t)atoi(kb) << 10;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_pass_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_pass_kernel<W, GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     using V = vec2<typename W::real>;
-    hipLaunchKernelGGL(wave_pass_kernel<W>, grid, dim3(256), lds, s, static_cast<const V*>(in), static_cast<V*>(out),
-                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, 0, kp);
+    hipLaunchKernelGGL((wave_pass_kernel<W, GRAD>), grid, dim3(256), lds, s, static_cast<const V*>(in), static_cast<V*>(out),
+                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, tpw, kp, grads, ngrads * 8);
     return check_launch("dq_apply_fused (wave tile)");
 }
 
 int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                     const DqFusedPass* pass, hipStream_t s) {
     return wave_launch<WaveC64>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+}
+int wave_launch_grad_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
+                         const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads) {
+    return wave_launch<WaveC64, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
 }
 int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                      const DqFusedPass* pass, hipStream_t s) {

@@ -106,8 +106,9 @@ def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = No
 
 def wave_supports(ops: Sequence['PrimOp']) -> bool:
     """Can the wave-tile kernel run all of ``ops``?  (One-target dense gates and X, diagonal gates on one or two
-    targets, any controls.)"""
-    return all((op.kind in ('gen', 'x') and len(op.targets) == 1) or (op.kind == 'diag' and len(op.targets) <= 2) for op in ops)
+    targets, any controls, the reductions of the reverse sweep.)"""
+    return all((op.kind in ('gen', 'x') and len(op.targets) == 1) or (op.kind == 'diag' and len(op.targets) <= 2)
+               or op.kind == 'grad' for op in ops)
 
 
 def workgroup_geometry(is_c128: bool, m: int | None = None, slots: int | None = None) -> Geometry:

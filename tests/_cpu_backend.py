@@ -51,7 +51,7 @@ class CpuTestBackend:
         assert (is128, m, R) in ((False, 12, 6), (False, 12, 4), (False, 13, 4), (True, 11, 5), (True, 11, 3), (True, 12, 3)), 'no such kernel'
         wave = m - R == 6       # the wave-tile kernels (include/dq_hip.h): no offset tables, no handler ids, no exchanges
         if wave:
-            assert grads is None, 'reverse-sweep passes run on the workgroup-tile geometries'
+            assert grads is None or not is128, 'reverse-sweep passes are complex64'
         vb = 0 if is128 else 1
         logt = m - R
         assert L + h == m and n >= m
@@ -174,7 +174,7 @@ class CpuTestBackend:
                 for gi in range(first + nswap, rd.gate_end):
                     g = desc.gates[gi]
                     assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
-                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1, _lib.FG_DIAG1, _lib.FG_DIAG2), 'the wave-tile kernel takes one-target and diagonal gates only'
+                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1, _lib.FG_DIAG1, _lib.FG_DIAG2, _lib.FG_GRAD), 'the wave-tile kernel takes one-target and diagonal gates only'
                     assert (g.reg_cmask >> R) == 0
                     cm = g.thr_cmask
                     for s in range(R):

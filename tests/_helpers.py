@@ -369,7 +369,7 @@ def check_grad_records(n, m, device):
                 g[:, a_, b_] = (la * ps.conj()).sum(-1)
         want.append(g)
     mats = torch.cat(mats_l)
-    geom = fusion.default_geometry(False, m)
+    geom = fusion.default_geometry(False) if m == 'wave' else fusion.default_geometry(False, m)
     steps = fusion.schedule(ops, n, geom)
     assert all(isinstance(s, fusion.FusedStep) for s in steps)
     xd, md = x.to(device), fusion.kernel_matrices(steps, ops, mats).to(device)

@@ -127,7 +127,7 @@ def _apply2(a, lo, hi, m, active):
     a[active, hi] = (m[2] * x0 + m[3] * x1)[active]
 
 
-def run_pass(desc, n, state, mats, mat_batch_stride):
+def run_pass(desc, n, state, mats, mat_batch_stride, grads=None):
     """state (B, 2^n) complex numpy -> the state after the pass, as the wave-tile kernel of its precision computes it."""
     c128 = state.dtype == np.complex128
     g = gen(c128)
@@ -203,6 +203,25 @@ def run_pass(desc, n, state, mats, mat_batch_stride):
                     _run_moves(g, g.slotswap(*swap_of[hid]), a, np.ones(64, bool))
                     continue
                 if not tile_ok:
+                    continue
+                if getattr(g, 'ID_GRAD', 1 << 30) <= hid < getattr(g, 'ID_GRAD', 1 << 30) + 5:
+                    # reduction of the reverse sweep (gen_wave_asm.py, grad_code): target slot q, psi / lambda on slot 0
+                    q = 1 + hid - g.ID_GRAD
+                    acc = np.zeros((2, 2), dtype=np.complex128)
+                    for gi, j in enumerate(g.grad_groups(q)):
+                        if not (w[5] >> gi) & 1:
+                            continue
+                        p_ = [a[active, j], a[active, j | (1 << q)]]
+                        l_ = [a[active, j | 1], a[active, j | (1 << q) | 1]]
+                        for a_ in range(2):
+                            for b_ in range(2):
+                                acc[a_, b_] += np.sum(l_[a_].astype(np.complex128) * np.conj(p_[b_].astype(np.complex128)))
+                    acc *= abs(scale) ** 2
+                    assert grads is not None, 'a reduction record outside a reverse-sweep pass'
+                    for a_ in range(2):
+                        for b_ in range(2):
+                            grads[b, w[6], 2 * (2 * a_ + b_)] += acc[a_, b_].real
+                            grads[b, w[6], 2 * (2 * a_ + b_) + 1] += acc[a_, b_].imag
                     continue
                 if hid >= g.ID_DIAG1:
                     # diagonal gate (tools/gen_wave_asm.py, diag_code): four phases, candidates by the indices in w5,

@@ -298,7 +298,7 @@ def test_exchange_seeds_of_the_gpu_test_cover_all_handlers():
         assert len(seen) == 24, (m, n, sorted(seen))
 
 
-@pytest.mark.parametrize('n,m', [(13, 13), (12, 12)])
+@pytest.mark.parametrize('n,m', [(13, 13), (12, 12), (13, 'wave'), (12, 'wave')])
 def test_reduction_records_of_the_reverse_sweep(cpu_backend, n, m):
     """DQ_FG_GRAD records through the descriptor interpreter (the GPU suite runs the same check on the kernel)."""
     from _helpers import check_grad_records

@@ -242,7 +242,7 @@ def test_stores_that_relabel_the_low_bits_on_gpu(n, seed, m, is128):
     assert err < TOL[dtype], err
 
 
-@pytest.mark.parametrize('n,m', [(15, 13), (14, 12), (12, 12)])
+@pytest.mark.parametrize('n,m', [(15, 13), (14, 12), (12, 12), (15, 'wave'), (13, 'wave'), (12, 'wave')])
 def test_reductions_inside_fused_passes_match_numpy(n, m):
     from _helpers import check_grad_records
 

@@ -186,7 +186,10 @@ ID_SWAP = ID_TRIP + len(TRIP_MASKS)       # + index in SWAP_PAIRS
 # register mask); ID_DIAG2: the four phases are the diagonal of a 4x4 block that ends at the current matrix offset
 ID_DIAG1 = ID_SWAP + len(SWAP_PAIRS)
 ID_DIAG2 = ID_DIAG1 + 14
-NIDS = ID_DIAG2 + 14
+# reduction of the adjoint method's reverse sweep: target on slot 1 + (id - ID_GRAD), psi / lambda told apart by slot 0
+ID_GRAD = ID_DIAG2 + 14
+NIDS = ID_GRAD + 5
+ACC_BASE = 4 * 8448       # LDS offset of the reduction accumulators: behind the four waves' staging buffers
 
 
 def handlers():
@@ -204,6 +207,8 @@ def handlers():
         for c in range(R):
             if c != q:
                 h[ID_X_R1 + 5 * q + (c if c < q else c - 1)] = (True, xlines(q, 1 << c))
+    for q in range(1, R):
+        h[ID_GRAD + q - 1] = (False, grad_code(q))
     h[ID_TRIP0] = (False, trip(0, 0))
     for i, m in enumerate(TRIP_MASKS):
         h[ID_TRIP + i] = (False, trip(bin(m).count('1'), m))
@@ -277,6 +282,58 @@ def diag_code():
     t += [f's_branch .Ldiagb{v}_%=' for v in range(14)]
     for v in range(14):
         t += [f'.Ldiagb{v}_%=:'] + diag_body(v) + [f's_mov_b64 exec, {SAVE}', f's_cmp_lt_u32 {GOFF}, {GEND}', 's_cbranch_scc1 .Lloop_%=', 's_branch .Lexit_%=']
+    return t
+
+
+def grad_groups(q):
+    return [j for j in range(NA) if not (j >> q) & 1 and not j & 1]
+
+
+def grad_code(q):
+    """DQ_FG_GRAD with the target on slot q, psi (0) / lambda (1) on slot 0: G[a][b] = sum lambda[target = a] conj(psi[target
+    = b]) over the thread's register groups (w5 = mask of the groups whose register controls are set), lanes that fail the
+    thread controls contribute nothing; |f|^2 of the pass's deferred factor; reduce-scatter over each row of 16 lanes (16
+    DPP adds), then 32 lanes add to the record's eight accumulators in LDS (ACC_BASE + 32 * record number)."""
+    G = ['v[10:11]', 'v[12:13]', 'v[14:15]', 'v[16:17]']
+    C2 = 'op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]'
+    t = [f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc0 .Lnext_%=']
+    t += [f'v_mov_b32 v{r}, 0' for r in range(10, 18)]
+    t += [f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
+          f's_cbranch_execz .Lgz{q}_%=']
+    for i, j in enumerate(grad_groups(q)):
+        p0, l0, p1, l1 = A(j), A(j | 1), A(j | (1 << q)), A(j | (1 << q) | 1)
+        t += [f's_bitcmp1_b32 s{REC + 5}, {i}', f's_cbranch_scc0 .Lgg{q}_{i}_%=']
+        for g_, l_, p_ in ((G[0], l0, p0), (G[1], l0, p1), (G[2], l1, p0), (G[3], l1, p1)):
+            t.append(f'v_pk_fma_f32 {g_}, {l_}, {p_}, {g_} {RE3}')
+        for g_, l_, p_ in ((G[0], l0, p0), (G[1], l0, p1), (G[2], l1, p0), (G[3], l1, p1)):
+            t.append(f'v_pk_fma_f32 {g_}, {l_}, {p_}, {g_} {C2}')
+        t.append(f'.Lgg{q}_{i}_%=:')
+    g = [f'v{r}' for r in range(10, 18)]
+    t += [f'.Lgz{q}_%=:', f's_mov_b64 exec, {SAVE}',
+          f'v_mul_f32 {TT}, {HR}, {HR}', f'v_fma_f32 {TT}, {HI}, {HI}, {TT}', 's_nop 1',
+          # lane bit 2: lanes with the bit clear take over the even-numbered sum of each pair, the others the odd one
+          f'v_add_f32_dpp {g[0]}, {g[0]}, {g[0]} row_shl:4 row_mask:0xf bank_mask:0x5', f'v_add_f32_dpp {g[2]}, {g[2]}, {g[2]} row_shl:4 row_mask:0xf bank_mask:0x5',
+          f'v_add_f32_dpp {g[4]}, {g[4]}, {g[4]} row_shl:4 row_mask:0xf bank_mask:0x5', f'v_add_f32_dpp {g[6]}, {g[6]}, {g[6]} row_shl:4 row_mask:0xf bank_mask:0x5',
+          f'v_add_f32_dpp {g[0]}, {g[1]}, {g[1]} row_shr:4 row_mask:0xf bank_mask:0xa', f'v_add_f32_dpp {g[2]}, {g[3]}, {g[3]} row_shr:4 row_mask:0xf bank_mask:0xa',
+          f'v_add_f32_dpp {g[4]}, {g[5]}, {g[5]} row_shr:4 row_mask:0xf bank_mask:0xa', f'v_add_f32_dpp {g[6]}, {g[7]}, {g[7]} row_shr:4 row_mask:0xf bank_mask:0xa',
+          # lane bit 3
+          f'v_add_f32_dpp {g[0]}, {g[0]}, {g[0]} row_shl:8 row_mask:0xf bank_mask:0x3', f'v_add_f32_dpp {g[4]}, {g[4]}, {g[4]} row_shl:8 row_mask:0xf bank_mask:0x3',
+          's_nop 1',
+          f'v_add_f32_dpp {g[0]}, {g[2]}, {g[2]} row_shr:8 row_mask:0xf bank_mask:0xc', f'v_add_f32_dpp {g[4]}, {g[6]}, {g[6]} row_shr:8 row_mask:0xf bank_mask:0xc',
+          # lane bit 0: even lanes keep g0, odd lanes g4
+          's_mov_b32 vcc_lo, 0xaaaaaaaa', 's_mov_b32 vcc_hi, 0xaaaaaaaa', 's_nop 1',
+          f'v_add_f32_dpp v32, {g[0]}, {g[0]} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf',
+          f'v_add_f32_dpp v33, {g[4]}, {g[4]} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf',
+          f'v_cndmask_b32 {g[0]}, v32, v33, vcc',
+          # lane bit 1: plain add
+          's_nop 1', f'v_add_f32_dpp {g[0]}, {g[0]}, {g[0]} quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf',
+          f'v_mul_f32 {g[0]}, {g[0]}, {TT}',
+          # the lane with bits (b0, b3, b2) holds sum number 4 b0 + 2 b3 + b2; lanes that differ in bit 1 hold the same
+          f'v_and_b32 v32, 1, {LANE}', 'v_lshlrev_b32 v32, 2, v32', f'v_lshrrev_b32 v33, 2, {LANE}', 'v_and_b32 v34, 2, v33', 'v_and_b32 v33, 1, v33',
+          'v_or3_b32 v32, v32, v34, v33', 'v_lshlrev_b32 v32, 2, v32', f'v_add_u32 v32, {GOFF}, v32', f'v_add_u32 v32, {ACC_BASE - 32}, v32',
+          's_mov_b32 exec_lo, 0x33333333', 's_mov_b32 exec_hi, 0x33333333',
+          f'ds_add_f32 v32, {g[0]}',
+          's_mov_b64 exec, -1']
     return t
 
 
@@ -381,7 +438,7 @@ out = ['// GENERATED by tools/gen_wave_asm.py -- do not edit by hand.', '// clan
        f'#define DQ_WID_GEN_U {ID_GEN_U}', f'#define DQ_WID_GEN_C {ID_GEN_C}', f'#define DQ_WID_GEN_R {ID_GEN_R}',
        f'#define DQ_WID_X_U {ID_X_U}', f'#define DQ_WID_X_C {ID_X_C}', f'#define DQ_WID_X_R {ID_X_R}', f'#define DQ_WID_X_R1 {ID_X_R1}',
        f'#define DQ_WID_TRIP0 {ID_TRIP0}', f'#define DQ_WID_TRIP {ID_TRIP}', f'#define DQ_WID_SWAP {ID_SWAP}',
-       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}',
+       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
        '// trip handler id by slot mask (popcount 1..DQ_WAVE_MAXK), -1 otherwise; slot-swap handler id by (i < j)',
        'static const short kWaveTripId[64] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(64)) + '};',
        'static const short kWaveSwapId[6][6] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
