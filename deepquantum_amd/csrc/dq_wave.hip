@@ -21,6 +21,8 @@
 // flat record list the kernel walks: it tracks which PHYSICAL slot (register-index bit) holds which tile bit, so the
 // host's slot order never costs a register move, picks the lane order of every layout (bank-conflict-free where it
 // can), and computes the per-trip address contributions.
+#include <utility>
+
 #include "dq_common.hpp"
 #include <stddef.h>
 #include <string.h>
@@ -47,8 +49,8 @@ struct WaveC64 {
     static int trip_id(unsigned mask) { return kWaveTripId[mask]; }
     static int swap_id(int i, int j) { return kWaveSwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
-                                                uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid) {
-        wave_tile_body_f32(kg, gend, mb, moff, tg, ks, inb, outb, ldsb, tid);
+                                                uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid, uint32_t flags) {
+        wave_tile_body_f32(kg, gend, mb, moff, tg, ks, inb, outb, ldsb, tid, flags);
     }
 };
 struct WaveC128 {
@@ -61,8 +63,8 @@ struct WaveC128 {
     static int trip_id(unsigned mask) { return kWave64TripId[mask]; }
     static int swap_id(int i, int j) { return kWave64SwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
-                                                uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid) {
-        wave_tile_body_f64(kg, gend, mb, moff, tg, ks, inb, outb, ldsb, tid);
+                                                uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid, uint32_t flags) {
+        wave_tile_body_f64(kg, gend, mb, moff, tg, ks, inb, outb, ldsb, tid, flags);
     }
 };
 
@@ -107,8 +109,11 @@ static_assert(sizeof(WaveKernArgs) <= 4096 && (offsetof(WaveKernArgs, p) + offse
 template <class W, bool GRAD>
 __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::real>* in, vec2<typename W::real>* out,
                                                         const vec2<typename W::real>* mats, int64_t mat_bstride,
-                                                        int64_t in_bstride, int n, int tpw, const WaveKernPass p, double* grads,
-                                                        int64_t grad_bstride) {
+                                                        int64_t in_bstride, int n, int tpw_flags, const WaveKernPass p,
+                                                        double* grads, int64_t grad_bstride) {
+    const int tpw = tpw_flags & 0xffff;
+    // bit 0 / 1: streaming loads / stores (see wave_launch); a pass whose samples share ONE input keeps it in the L2
+    const unsigned flags = in_bstride == 0 ? ((unsigned)tpw_flags >> 16) & ~1u : (unsigned)tpw_flags >> 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char dq_wave_smem[];
     (void)dq_wave_smem;
     const unsigned tid = threadIdx.x;
@@ -153,7 +158,8 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
     const uint64_t outb = (uint64_t)(out + ((uint64_t)sample << n) + tw);
     const uint64_t mb = (uint64_t)(mats + (int64_t)sample * mat_bstride);
     W::body(karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec), p.nrec_bytes, mb, p.mat_base_bytes, tg,
-            karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, load_off), inb, outb, wave * W::LDS_PER_WAVE, tid);
+            karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, load_off), inb, outb, wave * W::LDS_PER_WAVE, tid,
+            flags);
   }
     if constexpr (GRAD) {
         __syncthreads();
@@ -317,6 +323,17 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
             k->read_blk_pos[j] = (uint8_t)(q < 63 ? q : 63);
             k->store_blk_pos[j] = j < n - W::M ? p->store_blk_pos[j] : (uint8_t)63;
         }
+        // ... re-ordered by where they land on the WRITE side: tiles that run at the same time (neighbours in the tile
+        // number) then write neighbouring runs, i.e. whole DRAM pages between them, while the read side does not care
+        // (a tile reads one contiguous 32 KiB block wherever it lies).  DQ_WAVE_TILE_ORDER=read keeps the read order.
+        static const bool by_store = [] { const char* e = getenv("DQ_WAVE_TILE_ORDER"); return !(e && e[0] == 'r'); }();
+        const int nb = n - W::M;
+        if (by_store)
+            for (int i = 1; i < nb; ++i)        // insertion sort of (read, store) pairs by store position
+                for (int j = i; j > 0 && k->store_blk_pos[j] < k->store_blk_pos[j - 1]; --j) {
+                    std::swap(k->store_blk_pos[j], k->store_blk_pos[j - 1]);
+                    std::swap(k->read_blk_pos[j], k->read_blk_pos[j - 1]);
+                }
     }
     for (int s = W::VB; s < W::R; ++s) k->load_off[s - W::VB] = (uint64_t)W::ELEM << rpos(x.phys[s]);
     for (int b = 0; b < WAVE_LANES; ++b) {
@@ -491,9 +508,15 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
         lds = (size_t)atoi(kb) << 10;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_pass_kernel<W, GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
+    // Streaming (non-temporal) loads and stores for states far beyond the 256 MiB Infinity Cache: nothing a pass writes
+    // survives until the next pass reads it, and not allocating the lines is worth 10-15 % of the memory side
+    // (profiles/r03/mb_wavetile_nt.txt).  Smaller states stay cacheable.  DQ_WAVE_NT=0..3 overrides (experiments).
+    static const int nt_env = [] { const char* e = getenv("DQ_WAVE_NT"); return e ? atoi(e) & 3 : -1; }();
+    const uint64_t state_bytes = ((uint64_t)batch << n) * (uint64_t)W::ELEM;
+    const int nt = nt_env >= 0 ? nt_env : (state_bytes >= (1ull << 30) ? 3 : 0);
     using V = vec2<typename W::real>;
     hipLaunchKernelGGL((wave_pass_kernel<W, GRAD>), grid, dim3(256), lds, s, static_cast<const V*>(in), static_cast<V*>(out),
-                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, tpw, kp, grads, ngrads * 8);
+                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, tpw | (nt << 16), kp, grads, ngrads * 8);
     return check_launch("dq_apply_fused (wave tile)");
 }
 

@@ -10,6 +10,7 @@
 #include <vector>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct Args {
     const float4* in;
@@ -55,7 +56,7 @@ template <int K> __device__ __forceinline__ void trip(v2f (&a)[64], unsigned lds
 
 __host__ __device__ constexpr unsigned wave_lds_bytes(int k) { return (k <= 3 ? 2u : 1u) * 8u * (1u << k) * (64u + (1u << (6 - k))); }
 
-template <int WPS, int GATES, int TRIPS, int K>
+template <int WPS, int GATES, int TRIPS, int K, int NT = 0>
 __global__ __launch_bounds__(256, WPS) void pass_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -73,7 +74,9 @@ __global__ __launch_bounds__(256, WPS) void pass_kernel(const Args p) {
         const float4* src = p.in + tile * 2048u + lane;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            const float4 v = src[64 * j];
+            float4 v;
+            if (NT & 1) { const v4f t_ = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + 64 * j)); v = float4{t_.x, t_.y, t_.z, t_.w}; }
+            else v = src[64 * j];
             a[2 * j] = v2f{v.x, v.y};
             a[2 * j + 1] = v2f{v.z, v.w};
         }
@@ -95,13 +98,14 @@ __global__ __launch_bounds__(256, WPS) void pass_kernel(const Args p) {
 #pragma unroll
             for (int s = 1; s < 6; ++s)
                 if ((j >> (s - 1)) & 1) o += p.wr_slot_off[s];
-            dst[o] = float4{a[2 * j].x * p.c1, a[2 * j].y * p.c1, a[2 * j + 1].x * p.c1, a[2 * j + 1].y * p.c1};
+            const float4 w_ = float4{a[2 * j].x * p.c1, a[2 * j].y * p.c1, a[2 * j + 1].x * p.c1, a[2 * j + 1].y * p.c1};
+            if (NT & 2) __builtin_nontemporal_store(v4f{w_.x, w_.y, w_.z, w_.w}, reinterpret_cast<v4f*>(dst + o)); else dst[o] = w_;
         }
     }
     (void)smem;
 }
 
-template <int WPS, int GATES, int TRIPS, int K>
+template <int WPS, int GATES, int TRIPS, int K, int NT = 0>
 static void run(const char* name, Args a, int nbits, int tiles_per_wave) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -110,11 +114,11 @@ static void run(const char* name, Args a, int nbits, int tiles_per_wave) {
     const uint64_t tiles = 1ull << (nbits - 12);
     const unsigned grid = (unsigned)(tiles / tiles_per_wave / 4);
     const size_t lds = WPS == 2 ? 60u * 1024u : 4u * wave_lds_bytes(K);   // 2 waves per SIMD: LDS padded so that two workgroups fit a CU
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<WPS, GATES, TRIPS, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<WPS, GATES, TRIPS, K, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     float best = 1e9;
     for (int it = 0; it < 4; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((pass_kernel<WPS, GATES, TRIPS, K>), dim3(grid), dim3(256), lds, 0, a);
+        hipLaunchKernelGGL((pass_kernel<WPS, GATES, TRIPS, K, NT>), dim3(grid), dim3(256), lds, 0, a);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -173,6 +177,10 @@ int main(int argc, char** argv) {
         run<3, 72, 4, 3>("skeleton + 72 gates + 4 staged trips", a, nbits, 1);
         run<3, 96, 4, 3>("skeleton + 96 gates + 4 staged trips", a, nbits, 1);
         run<2, 72, 4, 3>("skeleton + 72 gates + 4 staged trips", a, nbits, 1);
+        run<3, 0, 0, 3, 1>("skeleton, nt loads", a, nbits, 1);
+        run<3, 0, 0, 3, 2>("skeleton, nt stores", a, nbits, 1);
+        run<3, 0, 0, 3, 3>("skeleton, nt loads + stores", a, nbits, 1);
+        run<3, 72, 4, 3, 3>("72 gates + 4 trips, nt loads + stores", a, nbits, 1);
     }
     return 0;
 }

@@ -27,6 +27,8 @@ RUN, SAVE, TABLE, HADC = 's[50:51]', 's[52:53]', 's[54:55]', 's[56:57]'
 GOFF, GEND, MOFF, STMP = 's58', 's59', 's60', 's61'
 MB, KG, TG, LDSB = 's[62:63]', 's[64:65]', 's[66:67]', 's68'
 REC, REC2, MAT = 72, 80, 88
+NMAT = 40            # the next record's matrix, fetched one record ahead like the next record itself (REC2); the slot
+                     # offsets that live in s[40:49] are only needed by the loads and the stores, outside the record loop
 M = [f's[{MAT + 2 * i}:{MAT + 2 * i + 1}]' for i in range(4)]     # m00 m01 m10 m11
 
 
@@ -134,6 +136,14 @@ def slotswap(i, j):
     return out_
 
 
+def prefetch(tag, mat=True):
+    """Fetch the record at GOFF (and its matrix at MOFF) into the look-ahead registers, if there is one: the scalar
+    loads' latency (~300 cycles each record otherwise) hides behind the current record's work."""
+    return [f's_cmp_lt_u32 {GOFF}, {GEND}', f's_cbranch_scc0 .Lnp{tag}_%=',
+            f's_load_dwordx8 s[{REC2}:{REC2 + 7}], {KG}, {GOFF}'] + \
+        ([f's_load_dwordx8 s[{NMAT}:{NMAT + 7}], {MB}, {MOFF}'] if mat else []) + [f'.Lnp{tag}_%=:']
+
+
 def deposit(val, positions):
     return sum(((val >> i) & 1) << p for i, p in enumerate(positions))
 
@@ -142,11 +152,11 @@ def trip(k, mask):
     """The slots of `mask` (k of them) trade places with k lane bits; all lanes may be re-ordered.  Sub-tile element
     (x = pattern of the outgoing slot bits, y = of the incoming bits, z = of the lane bits that stay) lives at slot
     x * S + (y << a) + F(z), S = 64 + 2^a, a = 5 - k: written with immediate x * S, read with immediate y << a."""
-    pre = [f's_load_dwordx8 s[{REC2}:{REC2 + 7}], {KG}, {GOFF}', f's_add_u32 {GOFF}, {GOFF}, 32']
     tbw = [REC + 1, REC + 2, REC + 3, REC + 5, REC + 6, REC + 7]
-    pre += [f'v_and_b32 {TB}, s{tbw[0]}, {LB[0]}'] + [f'v_and_or_b32 {TB}, {LB[b]}, s{tbw[b]}, {TB}' for b in range(1, 6)]
-    pre += ['s_waitcnt lgkmcnt(0)']
+    pre = [f'v_and_b32 {TB}, s{tbw[0]}, {LB[0]}'] + [f'v_and_or_b32 {TB}, {LB[b]}, s{tbw[b]}, {TB}' for b in range(1, 6)]
+    pre += ['s_waitcnt lgkmcnt(0)']           # record B = the look-ahead record
     pre += [f'v_and_b32 {WB}, s{REC2}, {LB[0]}'] + [f'v_and_or_b32 {WB}, {LB[b]}, s{REC2 + b}, {WB}' for b in range(1, 6)]
+    pre += [f's_add_u32 {GOFF}, {GOFF}, 32'] + prefetch(f't{mask}', mat=False)      # (trips advance no matrix: NMAT stays)
     pre += [f'v_lshrrev_b32 {RB}, 16, {WB}', f'v_and_b32 {WB}, 0xffff, {WB}', f'v_add_u32 {WB}, {LDSB}, {WB}', f'v_add_u32 {RB}, {LDSB}, {RB}']
     if k == 0:
         body_ = []
@@ -246,7 +256,7 @@ def diag_code():
     kind 1 = a tile-local bit of the thread, 2 = an index bit outside the tile) -> s[50:51], s[70:71], then
     PH = selA ? (selB ? c3 : c2) : (selB ? c1 : c0) per lane, and on to the body of the variant."""
     W5 = f's{REC + 5}'
-    t = ['.Ldiag_%=:',
+    t = ['.Ldiag_%=:', 's_waitcnt lgkmcnt(0)',        # (the look-ahead matrix is on its way into s[40:47])
          f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc0 .Lnext_%=',
          f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
          's_cbranch_execz .Lrestore_%=',
@@ -275,13 +285,14 @@ def diag_code():
               f'v_cndmask_b32 v{10 + half}, v14, v16, s[50:51]']
         r0, r2 = (f's{int(cand1[k][2:cand1[k].index(":")]) + half}' for k in (0, 2))
         t += [f'v_mov_b32 v14, {r0}', f'v_mov_b32 v16, {r2}', f'v_cndmask_b32 v{12 + half}, v14, v16, s[50:51]']
+    t += prefetch('dg')      # (s[80:87] held the candidates, s[40:47] the phases: fetch the look-ahead record and matrix again)
     # second-level table: the body of the variant
     t += [f's_sub_u32 s69, s{REC}, {ID_DIAG1}', 's_cmp_ge_u32 s69, 14', 's_cbranch_scc0 .Ldiagv_%=', 's_sub_u32 s69, s69, 14', '.Ldiagv_%=:',
           's_getpc_b64 vcc', '.Ldiaganchor_%=:', 's_lshl2_add_u32 vcc_lo, s69, vcc_lo', 's_addc_u32 vcc_hi, vcc_hi, 0',
           's_add_u32 vcc_lo, vcc_lo, .Ldiagtable_%=-.Ldiaganchor_%=', 's_addc_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc', '.Ldiagtable_%=:']
     t += [f's_branch .Ldiagb{v}_%=' for v in range(14)]
     for v in range(14):
-        t += [f'.Ldiagb{v}_%=:'] + diag_body(v) + [f's_mov_b64 exec, {SAVE}', f's_cmp_lt_u32 {GOFF}, {GEND}', 's_cbranch_scc1 .Lloop_%=', 's_branch .Lexit_%=']
+        t += [f'.Ldiagb{v}_%=:'] + diag_body(v) + [f's_mov_b64 exec, {SAVE}', 's_branch .Lnext_%=']
     return t
 
 
@@ -337,7 +348,7 @@ def grad_code(q):
     return t
 
 
-def gray_walk(op, base_operand, lane_operand):
+def gray_walk(op, base_operand, lane_operand, nt=False):
     """32 x (address = base + running slot offset + lane offset; op).  The running offset follows a Gray code over the
     slot bits 1..5, so each step is one 64-bit scalar add or subtract."""
     out_ = [f's_mov_b64 {RUN}, {base_operand}']
@@ -353,7 +364,7 @@ def gray_walk(op, base_operand, lane_operand):
         ad = ADDR[i % 4]
         out_.append(f'v_lshl_add_u64 {ad}, {RUN}, 0, {lane_operand}')
         regs = f'v[{AMP0 + 4 * g}:{AMP0 + 4 * g + 3}]'
-        out_.append(f'global_load_dwordx4 {regs}, {ad}, off' if op == 'load' else f'global_store_dwordx4 {ad}, {regs}, off')
+        out_.append((f'global_load_dwordx4 {regs}, {ad}, off' if op == 'load' else f'global_store_dwordx4 {ad}, {regs}, off') + (' nt' if nt else ''))
     return out_
 
 
@@ -365,7 +376,7 @@ def kernel_body():
     # bulk of the code) go behind the table, the gates in front of it
     front = [i for i in ids if i < ID_TRIP0]
     back = [i for i in ids if i >= ID_TRIP0]
-    nxt = [f's_cmp_lt_u32 {GOFF}, {GEND}', 's_cbranch_scc1 .Lloop_%=', 's_branch .Lexit_%=']
+    nxt = ['s_branch .Lnext_%=']
 
     def emit(i):
         ctl, lines = h[i]
@@ -396,19 +407,26 @@ def kernel_body():
         for lo, hi, sh in (('v2', 'v3', REC + b), ('v4', 'v5', REC + 6 + b)):
             text += [f'v_and_b32 v32, 1, {LB[b]}', 'v_mov_b32 v33, 0', f'v_lshlrev_b64 v[32:33], s{sh}, v[32:33]',
                      f'v_or_b32 {lo}, {lo}, v32', f'v_or_b32 {hi}, {hi}, v33']
-    text += gray_walk('load', '%[inb]', LLD)
+    # streaming (non-temporal) loads and stores when the host says so (flags bit 0 / 1: states far bigger than the
+    # caches; +10-15 % on the memory side, tools/experiments/mb_wavetile.hip), plain ones otherwise (small states live in
+    # the Infinity Cache between passes; the pass that reads ONE shared input state relies on the L2)
+    text += ['s_bitcmp1_b32 %[flags], 0', 's_cbranch_scc0 .Lldp_%='] + gray_walk('load', '%[inb]', LLD, nt=True) + ['s_branch .Lldd_%=', '.Lldp_%=:']
+    text += gray_walk('load', '%[inb]', LLD) + ['.Lldd_%=:']
+    # the first record and its matrix arrive with the tile
+    text += prefetch('first')
     text += [f's_getpc_b64 {TABLE}', '.Lanchor_%=:', 's_add_u32 s54, s54, .Ltable_%=-.Lanchor_%=', 's_addc_u32 s55, s55, 0',
-             's_waitcnt vmcnt(0)', 's_branch .Lloop_%=']
+             's_waitcnt vmcnt(0)', 's_branch .Lnext_%=']
     for i in front:
         text += emit(i)
-    text += ['.Lrestore_%=:', f's_mov_b64 exec, {SAVE}', '.Lnext_%=:'] + nxt
-    text += ['.Lloop_%=:',
-             f's_load_dwordx8 s[{REC}:{REC + 7}], {KG}, {GOFF}',
-             f's_load_dwordx8 s[{MAT}:{MAT + 7}], {MB}, {MOFF}',
-             's_waitcnt lgkmcnt(0)',
-             f's_add_u32 {GOFF}, {GOFF}, 32',
-             f's_lshl3_add_u32 {MOFF}, s{REC + 4}, {MOFF}',
-             f's_lshl2_add_u32 vcc_lo, s{REC}, s54', 's_addc_u32 vcc_hi, s55, 0', 's_setpc_b64 vcc',
+    # loop head: the look-ahead record becomes the current one, the one behind it is requested, then the handler
+    text += ['.Lrestore_%=:', f's_mov_b64 exec, {SAVE}', '.Lnext_%=:',
+             f's_cmp_lt_u32 {GOFF}, {GEND}', 's_cbranch_scc0 .Lexit_%=', 's_waitcnt lgkmcnt(0)']
+    text += [f's_mov_b64 s[{REC + 2 * i}:{REC + 2 * i + 1}], s[{REC2 + 2 * i}:{REC2 + 2 * i + 1}]' for i in range(4)]
+    text += [f's_mov_b64 s[{MAT + 2 * i}:{MAT + 2 * i + 1}], s[{NMAT + 2 * i}:{NMAT + 2 * i + 1}]' for i in range(4)]
+    text += [f's_add_u32 {GOFF}, {GOFF}, 32',
+             f's_lshl3_add_u32 {MOFF}, s{REC + 4}, {MOFF}']
+    text += prefetch('loop')
+    text += [f's_lshl2_add_u32 vcc_lo, s{REC}, s54', 's_addc_u32 vcc_hi, s55, 0', 's_setpc_b64 vcc',
              '.Ltable_%=:']
     for i in range(NIDS):
         text.append(f's_branch .Lh{i}_%=' if i in h else ('s_branch .Ldiag_%=' if i >= ID_DIAG1 else 's_branch .Lnext_%='))
@@ -424,6 +442,7 @@ def kernel_body():
         text += [f'v_pk_mul_f32 {t}, {A(j)}, v[12:13] op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]',
                  f'v_pk_fma_f32 {A(j)}, {A(j)}, v[10:11], {t}']
     text += ['.Lstore_%=:']
+    text += ['s_bitcmp1_b32 %[flags], 1', 's_cbranch_scc0 .Lstp_%='] + gray_walk('store', '%[outb]', LST, nt=True) + ['s_branch .Ldone_%=', '.Lstp_%=:']
     text += gray_walk('store', '%[outb]', LST)
     text += ['s_branch .Ldone_%=']
     text += diag_code()
@@ -449,11 +468,11 @@ out += ['// kg = address of the records, gend = their size in bytes; mb + moff =
         '// bits this tile fixes; ks = address of WaveKernPass::load_off (slot offsets, lane shifts); inb / outb = tile bases;',
         '// ldsb = the wave\'s LDS region; tid = threadIdx.x',
         '__device__ __forceinline__ void wave_tile_body_f32(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg,',
-        '                                                   uint64_t ks, uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid) {',
+        '                                                   uint64_t ks, uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid, uint32_t flags) {',
         f'    asm volatile(\n        "{text}"',
         '        :',
         '        : [kg] "s"(kg), [gend] "s"(gend), [mb] "s"(mb), [moff] "s"(moff), [tg] "s"(tg), [ks] "s"(ks), [inb] "s"(inb),',
-        '          [outb] "s"(outb), [ldsb] "s"(ldsb), [tid] "v"(tid)',
+        '          [outb] "s"(outb), [ldsb] "s"(ldsb), [tid] "v"(tid), [flags] "s"(flags)',
         f'        : "vcc", "scc", "memory", {clob});',
         '}', '// clang-format on', '']
 path = os.environ.get('DQ_ASM_OUT') or os.path.join(os.path.dirname(__file__), '..', 'deepquantum_amd', 'csrc', 'dq_wave_asm.inc')

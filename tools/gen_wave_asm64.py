@@ -242,7 +242,7 @@ def diag_code():
     return t
 
 
-def gray_walk(op, base_operand, lane_operand):
+def gray_walk(op, base_operand, lane_operand, nt=False):
     """32 x (address = base + running slot offset + lane offset; op): a Gray code over the five slot bits."""
     out_ = [f's_mov_b64 {RUN}, {base_operand}']
     for i in range(NA):
@@ -256,7 +256,7 @@ def gray_walk(op, base_operand, lane_operand):
                 out_ += [f's_sub_u32 s50, s50, {lo}', f's_subb_u32 s51, s51, {hi}']
         ad = ADDR[i % 4]
         out_.append(f'v_lshl_add_u64 {ad}, {RUN}, 0, {lane_operand}')
-        out_.append(f'global_load_dwordx4 {A(g)}, {ad}, off' if op == 'load' else f'global_store_dwordx4 {ad}, {A(g)}, off')
+        out_.append((f'global_load_dwordx4 {A(g)}, {ad}, off' if op == 'load' else f'global_store_dwordx4 {ad}, {A(g)}, off') + (' nt' if nt else ''))
     return out_
 
 
@@ -293,7 +293,11 @@ def kernel_body():
         for lo, hi, sh in (('v2', 'v3', REC + b), ('v4', 'v5', REC + 6 + b)):
             text += [f'v_and_b32 v32, 1, {LB[b]}', 'v_mov_b32 v33, 0', f'v_lshlrev_b64 v[32:33], s{sh}, v[32:33]',
                      f'v_or_b32 {lo}, {lo}, v32', f'v_or_b32 {hi}, {hi}, v33']
-    text += gray_walk('load', '%[inb]', LLD)
+    # streaming (non-temporal) loads and stores when the host says so (flags bit 0 / 1: states far bigger than the
+    # caches; +10-15 % on the memory side, tools/experiments/mb_wavetile.hip), plain ones otherwise (small states live in
+    # the Infinity Cache between passes; the pass that reads ONE shared input state relies on the L2)
+    text += ['s_bitcmp1_b32 %[flags], 0', 's_cbranch_scc0 .Lldp_%='] + gray_walk('load', '%[inb]', LLD, nt=True) + ['s_branch .Lldd_%=', '.Lldp_%=:']
+    text += gray_walk('load', '%[inb]', LLD) + ['.Lldd_%=:']
     text += [f's_getpc_b64 {TABLE}', '.Lanchor_%=:', 's_add_u32 s54, s54, .Ltable_%=-.Lanchor_%=', 's_addc_u32 s55, s55, 0',
              's_waitcnt vmcnt(0)', 's_branch .Lloop_%=']
     for i in front:
@@ -312,6 +316,7 @@ def kernel_body():
     text += ['.Lexit_%=:', 's_load_dwordx8 s[40:47], %[ks], 40', 's_load_dwordx2 s[48:49], %[ks], 72', 's_waitcnt lgkmcnt(0)']
     for j in range(NA):
         text += [f'v_mul_f64 {RE(j)}, {RE(j)}, {HS}', f'v_mul_f64 {IM(j)}, {IM(j)}, {HS}']
+    text += ['s_bitcmp1_b32 %[flags], 1', 's_cbranch_scc0 .Lstp_%='] + gray_walk('store', '%[outb]', LST, nt=True) + ['s_branch .Ldone_%=', '.Lstp_%=:']
     text += gray_walk('store', '%[outb]', LST)
     text += ['s_branch .Ldone_%=']
     text += diag_code()
@@ -334,11 +339,11 @@ if __name__ == '__main__' or os.environ.get('DQ_ASM_OUT'):
     text = '\\n\\t"\n        "'.join(kernel_body())
     clob = ', '.join(['"m0"'] + [f'"s{i}"' for i in range(40, 96)] + [f'"v{i}"' for i in range(1, AMP0 + 4 * NA)])
     out += ['__device__ __forceinline__ void wave_tile_body_f64(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg,',
-            '                                                   uint64_t ks, uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid) {',
+            '                                                   uint64_t ks, uint64_t inb, uint64_t outb, uint32_t ldsb, uint32_t tid, uint32_t flags) {',
             f'    asm volatile(\n        "{text}"',
             '        :',
             '        : [kg] "s"(kg), [gend] "s"(gend), [mb] "s"(mb), [moff] "s"(moff), [tg] "s"(tg), [ks] "s"(ks), [inb] "s"(inb),',
-            '          [outb] "s"(outb), [ldsb] "s"(ldsb), [tid] "v"(tid)',
+            '          [outb] "s"(outb), [ldsb] "s"(ldsb), [tid] "v"(tid), [flags] "s"(flags)',
             f'        : "vcc", "scc", "memory", {clob});',
             '}', '// clang-format on', '']
     path = os.environ.get('DQ_ASM_OUT') or os.path.join(os.path.dirname(__file__), '..', 'deepquantum_amd', 'csrc', 'dq_wave_asm64.inc')
