@@ -543,7 +543,8 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm',
-                'kernel': 'dq::fused_pass_kernel',
+                'kernel': ('dq::wave_pass_kernel' if dq.executor.CONFIG.get('wave', True) and not args.tile_bits
+                           else 'dq::fused_pass_kernel'),
                 # PHYSICAL rate of the dominant kernel: bytes its launches read + wrote / their summed duration
                 'achieved': physical,
                 'peak': HBM_PEAK_GBS,

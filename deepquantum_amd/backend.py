@@ -132,7 +132,7 @@ def apply_fused(
     """Run one fused pass (see fusion.py).  ``mats``: flat complex buffer (Bm * stride or stride).
     ``state`` with ONE row and ``out`` with B rows: the single input state is shared by all outputs.
     ``grads`` (float64, (B, rows, 8), added to): a pass of the adjoint method's reverse sweep -- its DQ_FG_GRAD
-    records reduce into it (include/dq_hip.h, dq_apply_fused_grad_c64)."""
+    records reduce into it (include/dq_hip.h, dq_apply_fused_grad_c64 / _c128)."""
     n = _nqubit(state)
     if out is None:
         out = state
@@ -141,8 +141,8 @@ def apply_fused(
         raise ValueError('mats must be a contiguous buffer in the dtype/device of the state')
     if grads is not None:
         if (grads.dtype != torch.float64 or grads.ndim != 3 or grads.shape[0] != out.shape[0] or grads.shape[2] != 8
-                or not grads.is_contiguous() or grads.device != state.device or broadcast or state.dtype != torch.complex64):
-            raise ValueError('grads must be a contiguous float64 (batch, rows, 8) accumulator next to a complex64 state')
+                or not grads.is_contiguous() or grads.device != state.device or broadcast):
+            raise ValueError('grads must be a contiguous float64 (batch, rows, 8) accumulator on the device of the state')
     if not _use_hip(state):
         src = state.expand(out.shape[0], -1) if broadcast else state
         if grads is not None:
@@ -151,8 +151,10 @@ def apply_fused(
     if grads is not None:
         if out.shape[0] > MAX_BATCH:
             raise ValueError(f'reverse-sweep passes take at most {MAX_BATCH} samples')
-        rc = _lib.load().dq_apply_fused_grad_c64(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0],
-                                                 C.byref(desc), _ptr(grads), grads.shape[1], _stream(state))
+        lib = _lib.load()
+        fn = lib.dq_apply_fused_grad_c128 if state.dtype == torch.complex128 else lib.dq_apply_fused_grad_c64
+        rc = fn(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0], C.byref(desc), _ptr(grads),
+                grads.shape[1], _stream(state))
         _lib.check(rc, 'dq_apply_fused_grad')
         return out
     if out.shape[0] > MAX_BATCH:

@@ -84,6 +84,8 @@ int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bst
                     const DqFusedPass* pass, hipStream_t s);
 int wave_launch_grad_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads);
+int wave_launch_grad_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
+                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads);
 int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                      const DqFusedPass* pass, hipStream_t s);
 

@@ -1234,10 +1234,10 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
                 continue;
             }
             if (g.kind == DQ_FG_GRAD) {
-                if (ngrads < 0 || sizeof(T) != 4 || g.q >= slots || g.q2 >= slots || g.q == g.q2 || (g.reg_cmask >> slots) ||
+                if (ngrads < 0 || (sizeof(T) != 4 && logt != 6) || g.q >= slots || g.q2 >= slots || g.q == g.q2 || (g.reg_cmask >> slots) ||
                     ((g.reg_cmask >> g.q) & 1u) || ((g.reg_cmask >> g.q2) & 1u) || g.mat != next_mat || g.mat_advance != 0 ||
                     g.fast != DQ_FAST_NONE || (int64_t)g.reserved >= ngrads) {
-                    set_error("dq_apply_fused: reduction record %d malformed, or not a dq_apply_fused_grad_c64 call", gi);
+                    set_error("dq_apply_fused: reduction record %d malformed, or not a dq_apply_fused_grad_* call (complex128: wave-tile geometry only)", gi);
                     return DQ_ERR_ARG;
                 }
                 continue;
@@ -1359,12 +1359,8 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     hipStream_t s = as_stream(stream);
     if (v.logt == 6) {     // one wavefront per tile: csrc/dq_wave.hip
         if (ngrads >= 0) {
-            if constexpr (is128) {
-                set_error("dq_apply_fused_grad: complex64 only");
-                return DQ_ERR_UNSUPPORTED;
-            } else {
-                return wave_launch_grad_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
-            }
+            if constexpr (is128) return wave_launch_grad_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+            else return wave_launch_grad_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
         }
         if constexpr (is128) return wave_launch_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
         else return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
@@ -1424,6 +1420,16 @@ extern "C" int dq_apply_fused_grad_c64(const void* in, void* out, const void* ma
         return DQ_ERR_ARG;
     }
     return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream, false, grads, ngrads);
+}
+
+extern "C" int dq_apply_fused_grad_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                        int64_t batch, const DqFusedPass* pass, double* grads, int64_t ngrads,
+                                        dq_stream_t stream) {
+    if (!grads || ngrads < 1) {
+        dq::set_error("dq_apply_fused_grad_c128: no accumulator (grads = %p, ngrads = %lld)", (void*)grads, (long long)ngrads);
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, false, grads, ngrads);
 }
 
 // Same pass, but `in` is ONE state (2^n amplitudes) shared by all `batch` outputs: the first pass of a batched

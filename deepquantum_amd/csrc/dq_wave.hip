@@ -41,6 +41,7 @@ constexpr int WAVE_MAX_REC = 112;
 // gathered bit.  Handler ids and the trip / swap tables come from the generated files.
 struct WaveC64 {
     using real = float;
+    using acc_t = float;        // the reverse sweep's accumulators in LDS
     static constexpr int M = 12, R = 6, NA = 64, VB = 1, MAXK = DQ_WAVE_MAXK, ELEM = 8;
     static constexpr unsigned LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID_GEN_U, ID_GEN_C = DQ_WID_GEN_C, ID_GEN_R = DQ_WID_GEN_R, ID_X_U = DQ_WID_X_U,
@@ -55,11 +56,12 @@ struct WaveC64 {
 };
 struct WaveC128 {
     using real = double;
+    using acc_t = double;
     static constexpr int M = 11, R = 5, NA = 32, VB = 0, MAXK = DQ_WAVE64_MAXK, ELEM = 16;
     static constexpr unsigned LDS_PER_WAVE = 8704;      // (7 * 68 + 64) * 16 bytes: the k = 3 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID64_GEN_U, ID_GEN_C = DQ_WID64_GEN_C, ID_GEN_R = DQ_WID64_GEN_R, ID_X_U = DQ_WID64_X_U,
                          ID_X_C = DQ_WID64_X_C, ID_X_R = DQ_WID64_X_R, ID_X_R1 = DQ_WID64_X_R1, ID_TRIP0 = DQ_WID64_TRIP0,
-                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = -1;      // (no reverse-sweep records yet)
+                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD;
     static int trip_id(unsigned mask) { return kWave64TripId[mask]; }
     static int swap_id(int i, int j) { return kWave64SwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
     const unsigned tid = threadIdx.x;
     if constexpr (GRAD) {
         for (unsigned i = tid; i < WAVE_MAX_REC * 8u; i += 256u)
-            *(__attribute__((address_space(3))) float*)(uintptr_t)(4u * W::LDS_PER_WAVE + 4u * i) = 0.0f;
+            *(__attribute__((address_space(3))) typename W::acc_t*)(uintptr_t)(4u * W::LDS_PER_WAVE + (unsigned)sizeof(typename W::acc_t) * i) = 0;
         __syncthreads();
     }
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
         double* const grow = grads + (uint64_t)sample * (uint64_t)grad_bstride;
         for (unsigned i = tid; i < nrec * 8u; i += 256u) {
             const unsigned id = rw[8u * (i >> 3)];
-            if (id >= (unsigned)W::ID_GRAD && id < (unsigned)W::ID_GRAD + 5u) {
-                const float v = *(__attribute__((address_space(3))) float*)(uintptr_t)(4u * W::LDS_PER_WAVE + 4u * i);
+            if (id >= (unsigned)W::ID_GRAD && id < (unsigned)W::ID_GRAD + (unsigned)W::R - 1u) {
+                const typename W::acc_t v = *(__attribute__((address_space(3))) typename W::acc_t*)(uintptr_t)(4u * W::LDS_PER_WAVE + (unsigned)sizeof(typename W::acc_t) * i);
                 atomicAdd(grow + (uint64_t)rw[8u * (i >> 3) + 6] * 8u + (i & 7u), (double)v);
             }
         }
@@ -503,7 +505,7 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
     if (GRAD)       // tiles per wave: as many as leave >= 2048 workgroups per sample batch
         while (tpw < 64 && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
     dim3 grid((unsigned)((tiles + 4ull * tpw - 1) / (4ull * tpw)), (unsigned)batch);
-    size_t lds = 4 * W::LDS_PER_WAVE + (GRAD ? WAVE_MAX_REC * 32 : 0);
+    size_t lds = 4 * W::LDS_PER_WAVE + (GRAD ? WAVE_MAX_REC * 8 * sizeof(typename W::acc_t) : 0);
     if (const char* kb = getenv("DQ_WAVE_LDS_KB")) {      // occupancy experiments: workgroups per CU = 160 KiB / this
         lds = (size_t)atoi(kb) << 10;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_pass_kernel<W, GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -527,6 +529,10 @@ int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bst
 int wave_launch_grad_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads) {
     return wave_launch<WaveC64, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+}
+int wave_launch_grad_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
+                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads) {
+    return wave_launch<WaveC128, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
 }
 int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                      const DqFusedPass* pass, hipStream_t s) {

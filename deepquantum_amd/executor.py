@@ -33,6 +33,7 @@ class Prim:
     controls: tuple[int, ...] = ()
     mode: int = 0                  # 2x2 matrix structure known from the gate class: 0 general, 1 real, 2 Rx-like
     unitary: bool = True           # False for channel superoperators: not reversible, per-gate autograd only
+    order: tuple[int, ...] = ()    # bits the gate is ordered on without touching them (fusion.PrimOp.order)
 
 
 @dataclass
@@ -45,6 +46,7 @@ class Plan:
     n_single: int
     rx_defer: list[int] | None = None      # matrix-buffer offsets of the gates on the deferred Rx handlers
     _rx_index: dict | None = None          # ... as a LongTensor per device
+    _scale_cache: dict | None = None       # complex128 reverse sweeps: which scalar gates run before which reduction
 
 
 _PLAN_CACHE: OrderedDict = OrderedDict()
@@ -64,9 +66,10 @@ CONFIG = {'fuse': True, 'wave': None,     # None = wave-tile kernel where it tak
           # 'adjoint': fused forward + reverse sweep with recomputation (O(1) states of memory);
           # 'per_gate': one autograd node per gate (saves every intermediate state; supports double backward)
           'grad_mode': 'adjoint',
-          # complex64 reverse sweeps run as fused passes over psi and the cotangent interleaved along one extra index
-          # bit, the reductions for the trainable gates folded into the passes (_AdjointCircuit._sweep_fused); False:
-          # the undo-then-reduce sweep (always used for complex128 and for trainable gates on two or more targets)
+          # reverse sweeps run as fused passes over psi and the cotangent interleaved along one extra index bit, the
+          # reductions for the trainable gates folded into the passes (_AdjointCircuit._sweep_fused); False: the
+          # undo-then-reduce sweep (always used for trainable gates on two or more targets, and for complex128
+          # circuits the wave-tile kernel cannot run)
           'fused_sweep': True,
           # states smaller than a tile: fuse (batch folded into the index, or zero-padded) from this many gates on
           'small_fuse_min_gates': 6,
@@ -158,14 +161,14 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
         geom.fallback.permute_store = permute
     key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
            geom.plan_branch, geom.plan_restarts, geom.asm_loop, geom.free_low, geom.lane_swaps, geom.swap_lanes, geom.swap_policy, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
-           tuple((p.kind, p.targets, p.controls, p.mode) for p in prims))
+           tuple((p.kind, p.targets, p.controls, p.mode, p.order) for p in prims))
     plan = _PLAN_CACHE.get(key)
     if plan is not None:
         _PLAN_CACHE.move_to_end(key)
         return plan
     prim_ops, off = [], 0
     for p in prims:
-        prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off, p.mode))
+        prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off, p.mode, 0, tuple(p.order)))
         if p.kind != 'grad':            # (a reduction of the reverse sweep has no matrix)
             off += (1 << len(p.targets)) ** 2
     import time
@@ -398,7 +401,9 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
             LAST_RUN['permute_folded'] = False
             return _permute_after(state, out_perm, scratch)
         if grads is not None:
-            assert n >= m and CONFIG['fuse'] and not is128, 'the fused reverse sweep needs a state of at least one tile'
+            assert n >= m and CONFIG['fuse'], 'the fused reverse sweep needs a state of at least one tile'
+            assert not is128 or (g_.wave and fusion.wave_supports(prims)), \
+                'complex128 reverse sweeps run on the wave-tile kernel only (one-target and diagonal gates)'
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):
             out = _run_small(state, prims, n, m)
@@ -475,6 +480,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                     x, scratch = scratch, x
                 stats['singles'] += 1
         stats['permute_folded'] = out_perm is not None and permute and plan.steps.applied_final_perm
+        stats['plan'] = plan
         LAST_RUN.update(stats)
         if out_perm is not None and not (permute and plan.steps.applied_final_perm):
             x = _permute_after(x, out_perm, other if other is not None else spare)
@@ -528,6 +534,8 @@ class _AdjointCircuit(torch.autograd.Function):
             groups.setdefault((kind, u.shape[-1], u.shape[0]), []).append((j, u))
         undo: list = [None] * len(mats)       # (2b, D, D): rows [0, b) the inverse, rows [b, 2b) the adjoint
         inv_h: dict = {}                      # group key -> (positions, inverse^dagger stack) for the gradients
+        is128 = out.dtype == torch.complex128
+        corr: dict = {}
         for key, members in groups.items():
             kind, d, nb = key
             us = torch.stack([u for _, u in members]).to(out.dtype)           # (K, nb, D, D)
@@ -535,17 +543,28 @@ class _AdjointCircuit(torch.autograd.Function):
             both = torch.cat([inv.expand(-1, b, d, d), us.mH.expand(-1, b, d, d)], dim=1).contiguous()
             for k, (j, _u) in enumerate(members):
                 undo[j] = both[k]
+            if is128 and kind != 'x':     # U^dagger U: what the fused complex128 sweep multiplies lambda by after U^-1
+                cs = us.mH @ us
+                for k, (j, _u) in enumerate(members):
+                    corr[j] = cs[k]
             if any(need[j] for j, _ in members):
                 inv_h[key] = ({j: k for k, (j, _u) in enumerate(members)}, inv.mH.to(torch.complex128))
 
         n = out.shape[-1].bit_length() - 1
-        g_ = _geometry(False)
-        fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and out.dtype == torch.complex64 and b <= backend.MAX_BATCH
+        g_ = _geometry(is128)
+        # complex128: the wave-tile kernel only (one-target dense / X gates, diagonal gates on one or two targets)
+        wave_ok = g_.wave and all((kind in ('gen', 'x') and len(targets) == 1) or (kind == 'diag' and len(targets) <= 2)
+                                  for kind, targets, _c, _m in meta)
+        fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and (not is128 or wave_ok) and b <= backend.MAX_BATCH
                  and n + 1 >= (g_.fallback.m if g_.fallback is not None else g_.m)
                  and all(len(meta[j][1]) == 1 for j in range(len(mats)) if need[j]))
         if fused:
+            # complex128: a matrix that is not computed from parameters or data may be unitary only to float32 rounding
+            # (the reference's fixed matrices are, after .to(torch.double)): the sweep then tells U^-1 from U^dagger
+            inexact = [is128 and j in corr and not need[j] and m.grad_fn is None and not m.requires_grad
+                       for j, m in enumerate(mats)]
             raw, lam = _AdjointCircuit._sweep_fused(out, gy, meta, undo, need, b,
-                                                    [m.ndim == 2 or m.shape[0] == 1 for m in mats])
+                                                    [m.ndim == 2 or m.shape[0] == 1 for m in mats], corr, inexact)
         else:
             raw, lam = _AdjointCircuit._sweep_undo_reduce(out, gy, meta, undo, need, b)
 
@@ -617,22 +636,43 @@ class _AdjointCircuit(torch.autograd.Function):
         return raw, lambda: work[b:].clone()
 
     @staticmethod
-    def _sweep_fused(out, gy, meta, undo, need, b, shared):
-        """The same sweep as ONE gate list run in fused passes (complex64): psi and lambda are interleaved along an
+    def _sweep_fused(out, gy, meta, undo, need, b, shared, corr=None, inexact=None):
+        """The same sweep as ONE gate list run in fused passes: psi and lambda are interleaved along an
         extra index bit 0 -- every thread of a pass then holds both halves of an amplitude pair of both states -- every
-        gate's adjoint acts on both at once (adjoint = inverse to float32 rounding, the precision psi is recomputed in
-        anyway), and in front of the adjoint of every trainable gate a 'grad' prim reduces sum lambda (x) conj(psi) on the
+        gate's adjoint acts on both at once (adjoint = inverse to the rounding of the state's precision, the precision psi
+        is recomputed in anyway), and in front of the adjoint of every trainable gate a 'grad' prim reduces sum lambda (x) conj(psi) on the
         gate's target inside the pass that holds the qubit (DQ_FG_GRAD, include/dq_hip.h): no snapshots, no separate
-        reduction kernels, a pass per ~80 records instead of two per circuit layer."""
+        reduction kernels, a pass per ~80 records instead of two per circuit layer.  complex128 holds the 1e-10 bar
+        against gates that are unitary only to float32 rounding (``inexact``): those are undone with the exact inverse
+        on both halves, and lambda -- the half with bit 0 set -- is multiplied by U^dagger U afterwards (``corr``, a
+        gate controlled by bit 0): U^dagger lambda exactly, psi never drifts."""
         work = torch.stack([out, gy.to(out.dtype)], dim=-1).reshape(b, -1)        # bit 0: psi | lambda
         rows: dict[int, int] = {}
         prims: list[Prim] = []
+        scalars: dict[int, int] = {}      # prim index -> gate, for the gates whose U^dagger U is a scalar != 1
+        grad_at: dict[int, int] = {}      # prim index of a reduction -> its row
         for j in range(len(meta) - 1, -1, -1):
             kind, targets, controls, mode = meta[j]
             t1, c1 = tuple(t + 1 for t in targets), tuple(c + 1 for c in controls)
             if need[j]:
                 rows[j] = len(rows)
+                grad_at[len(prims)] = rows[j]
                 prims.append(Prim('grad', None, (t1[0], 0), c1, rows[j]))
+            if (inexact is not None and inexact[j] and kind == 'gen' and mode == 3 and not controls and shared[j]
+                    and len(targets) == 1):
+                # Hadamard-like, s [[1, 1], [1, -1]] with 2 s^2 = 1 only to float32 rounding: U^dagger U = 2 s^2 exactly,
+                # a SCALAR.  The adjoint goes over both halves as in complex64; psi is then 2 s^2 times what it should
+                # be from here on, and so is every sum reduced later in the sweep: divided out below, by the order the
+                # plan executes things in.  No correction gate, no ordering constraint.
+                scalars[len(prims)] = j
+                prims.append(Prim(kind, undo[j][b : b + 1], t1, c1, mode))
+                continue
+            if inexact is not None and inexact[j]:
+                # (ordered on the psi / lambda bit like its correction: no reduction may come between the two)
+                prims.append(Prim(kind, undo[j][0:1] if shared[j] else undo[j][:b], t1, c1, 0 if kind == 'gen' else mode,
+                                  order=(0,)))
+                prims.append(Prim(kind, corr[j][0:1] if shared[j] else corr[j].expand(b, -1, -1), t1, c1 + (0,), 0))
+                continue
             prims.append(Prim(kind, undo[j][b : b + 1] if shared[j] else undo[j][b:], t1, c1, mode))
         acc = torch.zeros(b, max(len(rows), 1), 8, dtype=torch.float64, device=out.device)
         scratch = None                    # the partner buffer of the permuted stores, when it fits what is free now
@@ -644,5 +684,28 @@ class _AdjointCircuit(torch.autograd.Function):
         work = _run_nograd(work, prims, inplace=True, scratch=scratch, grads=acc)
         LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=len(rows))
         g = torch.view_as_complex(acc.reshape(b, -1, 4, 2)).reshape(b, -1, 2, 2)
+        if scalars and rows:
+            # row r was reduced from a psi that is  prod 2 s_k^2  (over the scalar gates executed before it) too large
+            plan = LAST_RUN['plan']
+            key = tuple(scalars)
+            before = plan._scale_cache.get((key, work.device)) if plan._scale_cache is not None else None
+            if before is None:
+                rank = {}
+                for st in plan.steps:
+                    for oi in (st.ops if isinstance(st, fusion.FusedStep) else [st.op]):
+                        rank[oi] = len(rank)
+                sc = sorted(scalars)
+                bmat = torch.zeros(max(len(rows), 1), len(sc), dtype=torch.float64)
+                for pi, r in grad_at.items():
+                    for k, si in enumerate(sc):
+                        if rank[si] < rank[pi]:
+                            bmat[r, k] = 1.0
+                before = bmat.to(work.device)
+                if plan._scale_cache is None:
+                    plan._scale_cache = {}
+                plan._scale_cache[(key, work.device)] = before
+            s00 = torch.stack([undo[scalars[si]][b, 0, 0] for si in sorted(scalars)])      # s of every scalar gate
+            logc = torch.log(2.0 * (s00.real * s00.real + s00.imag * s00.imag))
+            g = g / torch.exp(before @ logc)[None, :, None, None]
         raw = {j: g[:, r] for j, r in rows.items()}
         return raw, lambda: work.reshape(b, -1, 2)[:, :, 1].contiguous()

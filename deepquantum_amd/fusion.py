@@ -39,6 +39,7 @@ class PrimOp:
     mat: int = 0              # offset in the CALLER's matrix buffer (source of gather_matrices)
     mode: int = 0             # matrix structure promised by the gate class: 0 general, 1 real, 2 Rx-like
     pos: int = 0              # offset in the kernel's matrix buffer, assigned by layout_matrices
+    order: tuple[int, ...] = ()   # bits the gate does not touch but is ordered on like a control (the scheduler only)
 
     @property
     def k(self) -> int:
@@ -143,13 +144,15 @@ def workgroup_geometry(is_c128: bool, m: int | None = None, slots: int | None = 
 def _action(op: PrimOp) -> dict[int, str]:
     """How ``op`` acts on each of its qubits: 'D' = as a function of Z (controls, targets of diagonal gates),
     'X' = as a function of X (target of an X or of an Rx-like matrix a*I + i*b*X, controlled or not),
-    'N' = anything else."""
-    act = {q: 'D' for q in op.controls}
+    'G' = a reduction of the reverse sweep reading the psi / lambda bit, 'N' = anything else."""
+    act = {q: 'D' for q in op.controls + op.order}
     if op.kind == 'grad':
-        # a snapshot on its target (ordered against everything there); on the psi / lambda bit nothing ever acts, and
-        # reductions do not disturb each other: no dependency through it
+        # a snapshot on its target (ordered against everything there).  On the psi / lambda bit reductions do not
+        # disturb each other (a type of their own, 'G'), but they are ordered against every gate that tells psi from
+        # lambda -- the complex128 sweep's U^dagger U corrections, controlled by that bit: between an exact inverse and
+        # its correction the sum lambda (x) conj(psi) is not the invariant it is before and after both
         act[op.targets[0]] = 'N'
-        act[op.targets[1]] = 'D'
+        act[op.targets[1]] = 'G'
         return act
     if op.kind == 'diag':
         t_act = 'D'
@@ -164,7 +167,7 @@ def _action(op: PrimOp) -> dict[int, str]:
 
 class _Dag:
     """Dependency bookkeeping with the commutation rule: two gates commute when on every shared qubit both are
-    'D' or both are 'X' (each is then a polynomial in the same commuting Paulis on the shared qubits).  Per qubit
+    'D' or both are 'X' (each is then a polynomial in the same commuting Paulis on the shared qubits), or both 'G'.  Per qubit
     the gate list therefore splits into groups -- maximal runs of one type, every 'N' gate a group of its own --
     and a gate depends on all members of the group before its own."""
 
@@ -659,7 +662,7 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
             for rd in rounds:
                 for oi in rd.ops:
                     tops[oi] = PrimOp(ops[oi].kind, tr(ops[oi].targets), tr(ops[oi].controls), ops[oi].mat, ops[oi].mode,
-                                      ops[oi].pos)
+                                      ops[oi].pos, tr(ops[oi].order))
                 trounds.append(_Round(slots=[phys[b] for b in rd.slots], ops=list(rd.ops)))
             thigh = {phys[b] for b in high}
         nxt = pending[k + 1] if permute and k + 1 < len(pending) and not isinstance(pending[k + 1], SingleStep) else None

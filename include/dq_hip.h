@@ -45,7 +45,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 18
+#define DQ_ABI_VERSION 19
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -111,7 +111,7 @@ typedef enum {
                         v_permlane32/16_swap for lane bits 5 / 4, DPP row shifts for 3 / 2, DPP quad permutations for
                         1 / 0 -- a change of layout without LDS and without a workgroup barrier.  Only as the leading
                         records of a DQ_ROUND_SWAP round of complex64 kernels; fast = 52 + 6 * q + q2 */
-    DQ_FG_GRAD = 6   /* not a gate: a reduction for the reverse sweep of the adjoint method (dq_apply_fused_grad_c64).
+    DQ_FG_GRAD = 6   /* not a gate: a reduction for the reverse sweep of the adjoint method (dq_apply_fused_grad_c64 / _c128).
                         The state is psi and the cotangent lambda side by side along ONE extra index bit (register slot
                         q2: 0 = psi, 1 = lambda); the record adds  G[a][b] = sum lambda[target = a] conj(psi[target = b])
                         (target = register slot q; the sum runs over everything else, restricted to the controls being
@@ -295,9 +295,12 @@ int dq_apply_fused_bcast_c128(const void* in, void* out, const void* mats, int64
  * both at once (the caller supplies the adjoint matrices) and its DQ_FG_GRAD records reduce, at the right moments of
  * the sweep, sum lambda (x) conj(psi) onto a trainable gate's target.  `grads` = DEVICE double [batch, ngrads, 8],
  * ADDED to (the caller zeroes it once per sweep): row r = Re, Im of G[0][0], G[0][1], G[1][0], G[1][1] of the record
- * with reserved = r.  Workgroups accumulate in LDS over their tiles and add to `grads` once.  complex64 only. */
+ * with reserved = r.  Workgroups accumulate in LDS over their tiles (float32 sums for complex64, float64 for
+ * complex128) and add to `grads` once.  complex128: wave-tile geometry only (m = 11, 5 slots). */
 int dq_apply_fused_grad_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
                             int64_t batch, const DqFusedPass* pass, double* grads, int64_t ngrads, dq_stream_t stream);
+int dq_apply_fused_grad_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                             int64_t batch, const DqFusedPass* pass, double* grads, int64_t ngrads, dq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Reductions.  Results are written to DEVICE memory in double precision.

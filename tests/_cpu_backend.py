@@ -50,8 +50,7 @@ class CpuTestBackend:
         R = desc.slots
         assert (is128, m, R) in ((False, 12, 6), (False, 12, 4), (False, 13, 4), (True, 11, 5), (True, 11, 3), (True, 12, 3)), 'no such kernel'
         wave = m - R == 6       # the wave-tile kernels (include/dq_hip.h): no offset tables, no handler ids, no exchanges
-        if wave:
-            assert grads is None or not is128, 'reverse-sweep passes are complex64'
+        assert grads is None or wave or not is128, 'complex128 reverse-sweep passes: wave-tile geometry only'
         vb = 0 if is128 else 1
         logt = m - R
         assert L + h == m and n >= m
@@ -189,7 +188,7 @@ class CpuTestBackend:
                     if g.kind == _lib.FG_GRAD:
                         # include/dq_hip.h, DQ_FG_GRAD: G[a][b] = sum lambda[target = a] conj(psi[target = b]) over the
                         # controls' 1-subspace; register slot q2 tells psi (0) from lambda (1); row `reserved`
-                        assert grads is not None and not is128, 'reduction record outside a reverse-sweep pass'
+                        assert grads is not None, 'reduction record outside a reverse-sweep pass'
                         assert g.fast == _lib.FAST_NONE and g.q != g.q2 and g.q < R and g.q2 < R and g.reserved < grads.shape[1]
                         tbit, sbit = rb[g.q], rb[g.q2]
                         assert not (cm >> tbit) & 1 and not (cm >> sbit) & 1

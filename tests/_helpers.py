@@ -251,7 +251,7 @@ def check_adjoint_grad_mode(dq, device=None, dtype=torch.float64, n=6, tol=1e-10
         assert (x - y).abs().max().item() < tol, (x - y).abs().max()
 
 
-def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5):
+def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5, dtype=torch.float32):
     """complex64 circuits whose trainable gates all have one target run their reverse sweep as fused passes over psi
     and the cotangent interleaved along an extra index bit, the reductions folded into the passes (DQ_FG_GRAD):
     against per-gate autograd and against the undo-then-reduce sweep, with controlled / diagonal / general trainable
@@ -274,7 +274,8 @@ def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5):
         cir.rxlayer()
         cir.s(2)
         cir.t(4)
-        cir.swap([1, n - 1])
+        if dtype == torch.float32:            # (a two-target gate: complex128 sweeps are fused on the wave-tile kernel only)
+            cir.swap([1, n - 1])
         cir.cry(n - 1, 0)
         cir.hlayer()
         cir.rylayer(encode=True)
@@ -283,6 +284,8 @@ def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5):
         cir.observable([3, n - 1], 'zz')
         if device is not None:
             cir.to(device)
+        if dtype == torch.float64:
+            cir.to(torch.double)
         return cir
 
     results = {}
@@ -292,15 +295,16 @@ def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5):
         try:
             cir = build()
             g = torch.Generator().manual_seed(8)
-            data = torch.rand(batch, cir.ndata, generator=g)
-            psi0 = torch.randn(batch, 2**n, 1, generator=g) + 1j * torch.randn(batch, 2**n, 1, generator=g)
+            data = torch.rand(batch, cir.ndata, generator=g, dtype=dtype)
+            psi0 = (torch.randn(batch, 2**n, 1, generator=g, dtype=dtype)
+                    + 1j * torch.randn(batch, 2**n, 1, generator=g, dtype=dtype))
             psi0 = psi0 / psi0.norm(dim=1, keepdim=True)
             if device is not None:
                 data, psi0 = data.to(device), psi0.to(device)
             data.requires_grad_(True)
             psi0.requires_grad_(True)
             cir(data=data, state=psi0)
-            loss = (cir.expectation() * torch.tensor([1.0, -0.5, 0.25], device=data.device)).sum()
+            loss = (cir.expectation() * torch.tensor([1.0, -0.5, 0.25], device=data.device, dtype=dtype)).sum()
             loss.backward()
             if mode == 'adjoint':
                 assert dq.executor.LAST_SWEEP['fused'] == fused
@@ -321,8 +325,8 @@ def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5):
             assert (x - y).abs().max().item() < tol, (key, (x - y).abs().max())
 
 
-def check_grad_records(n, m, device):
-    """DQ_FG_GRAD records (dq_apply_fused_grad_c64) against numpy: psi and lambda interleaved along index bit 0, a
+def check_grad_records(n, m, device, is128=False):
+    """DQ_FG_GRAD records (dq_apply_fused_grad_c64 / _c128) against numpy: psi and lambda interleaved along index bit 0, a
     reduction sum lambda (x) conj(psi) for every target bit, with controls that land on register slots, on thread
     bits and outside the tile, in between gates that leave deferred factors in the registers (Hadamards, Rx); the
     accumulator is added to, rows not named stay untouched, a plain pass refuses the records."""
@@ -338,16 +342,17 @@ def check_grad_records(n, m, device):
     b = 2
     gen = torch.Generator().manual_seed(77)
     x = torch.randn(b, 2**n, generator=gen, dtype=torch.float64) + 1j * torch.randn(b, 2**n, generator=gen, dtype=torch.float64)
-    x = (x / x.norm(dim=1, keepdim=True)).to(torch.complex64)
+    cdt = torch.complex128 if is128 else torch.complex64
+    x = (x / x.norm(dim=1, keepdim=True)).to(cdt)
     ops, mats_l, want = [], [], []
     cur = x.clone()
     off = 0
-    h = torch.tensor([[1, 1], [1, -1]], dtype=torch.complex64) / 2 ** 0.5
+    h = torch.tensor([[1, 1], [1, -1]], dtype=cdt) / 2 ** 0.5
     for step in range(3 * (n - 1)):
         t = 1 + step % (n - 1)
         th = rng.uniform(0.3, 2.8)
         mat = h if step % 3 == 0 else torch.tensor([[np.cos(th / 2), -1j * np.sin(th / 2)], [-1j * np.sin(th / 2), np.cos(th / 2)]],
-                                                  dtype=torch.complex64)
+                                                  dtype=cdt)
         ops.append(fusion.PrimOp('gen', (t,), (), off, 3 if step % 3 == 0 else 2))
         mats_l.append(mat.reshape(-1))
         off += 4
@@ -369,7 +374,7 @@ def check_grad_records(n, m, device):
                 g[:, a_, b_] = (la * ps.conj()).sum(-1)
         want.append(g)
     mats = torch.cat(mats_l)
-    geom = fusion.default_geometry(False) if m == 'wave' else fusion.default_geometry(False, m)
+    geom = fusion.default_geometry(is128) if m == 'wave' else fusion.default_geometry(False, m)
     steps = fusion.schedule(ops, n, geom)
     assert all(isinstance(s, fusion.FusedStep) for s in steps)
     xd, md = x.to(device), fusion.kernel_matrices(steps, ops, mats).to(device)
@@ -378,11 +383,11 @@ def check_grad_records(n, m, device):
         backend.apply_fused(xd.clone(), md, 0, steps[0].desc)          # reduction records outside a reverse-sweep pass
     for st in steps:
         backend.apply_fused(xd, md, 0, st.desc, out=xd, grads=acc)
-    assert (xd.cpu() - cur).abs().max().item() < 1e-4
+    assert (xd.cpu() - cur).abs().max().item() < (1e-10 if is128 else 1e-4)
     got = torch.view_as_complex((acc - 0.5).reshape(b, -1, 4, 2)).reshape(b, -1, 2, 2).cpu().numpy()
     assert np.abs(got[:, 0]).max() == 0.0
     for r_, g in enumerate(want):
-        assert np.abs(got[:, r_ + 1] - g).max() < 2e-5 * max(1.0, np.abs(g).max()), (r_, ops[2 * r_ + 1])
+        assert np.abs(got[:, r_ + 1] - g).max() < (1e-12 if is128 else 2e-5) * max(1.0, np.abs(g).max()), (r_, ops[2 * r_ + 1])
 
 
 def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, tol=5e-5):

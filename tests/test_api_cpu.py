@@ -340,6 +340,7 @@ def test_fused_reverse_sweep_matches_per_gate_autograd(cpu_backend):
     from _helpers import check_fused_sweep
 
     check_fused_sweep(dq, n=11, batch=2)
+    check_fused_sweep(dq, n=10, batch=2, tol=1e-10, dtype=torch.float64)      # complex128: wave-tile geometry
 
 
 @pytest.mark.parametrize('seed', [0, 1])

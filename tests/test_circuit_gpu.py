@@ -298,6 +298,17 @@ def test_fused_reverse_sweep_on_gpu():
     check_fused_sweep(dq, device=dev(), n=20, batch=2, tol=6e-5)
 
 
+def test_fused_reverse_sweep_c128_on_gpu():
+    """complex128: the same sweep on the wave-tile kernel (dq_apply_fused_grad_c128, float64 sums) at the north star's
+    1e-10 against per-gate autograd and the undo-then-reduce sweep."""
+    from _helpers import check_fused_sweep
+
+    check_fused_sweep(dq, device=dev(), n=10, batch=2, tol=1e-10, dtype=torch.float64)
+    check_fused_sweep(dq, device=dev(), n=12, batch=1, tol=1e-10, dtype=torch.float64)
+    check_fused_sweep(dq, device=dev(), n=16, batch=3, tol=1e-10, dtype=torch.float64)
+    check_fused_sweep(dq, device=dev(), n=20, batch=2, tol=1e-10, dtype=torch.float64)
+
+
 @pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
 def test_fused_reverse_sweep_on_random_circuits_on_gpu(seed):
     from _helpers import check_fused_sweep_random

@@ -306,6 +306,13 @@ def test_reduction_records_of_the_reverse_sweep(cpu_backend, n, m):
     check_grad_records(n, m, torch.device('cpu'))
 
 
+@pytest.mark.parametrize('n', [12, 11])
+def test_reduction_records_of_the_reverse_sweep_c128(cpu_backend, n):
+    from _helpers import check_grad_records
+
+    check_grad_records(n, 'wave', torch.device('cpu'), is128=True)
+
+
 def free_low_schedule(ops, n, is128, m, width=4):
     geom = fusion.default_geometry(False) if m == 'wave' else fusion.workgroup_geometry(is128, m)
     geom.permute_store = geom.free_low = True

@@ -249,6 +249,14 @@ def test_reductions_inside_fused_passes_match_numpy(n, m):
     check_grad_records(n, m, dev())
 
 
+@pytest.mark.parametrize('n', [15, 13, 12, 11])
+def test_reductions_inside_fused_passes_match_numpy_c128(n):
+    """dq_apply_fused_grad_c128 (wave-tile kernel, float64 sums all the way): 1e-12 relative."""
+    from _helpers import check_grad_records
+
+    check_grad_records(n, 'wave', dev(), is128=True)
+
+
 @pytest.mark.parametrize('dtype,n', [(torch.complex64, 15), (torch.complex64, 11), (torch.complex128, 13),
                                      (torch.complex128, 10), (torch.complex64, 9)])
 def test_gate_grad_multi_equals_gate_by_gate(dtype, n):

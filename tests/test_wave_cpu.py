@@ -126,8 +126,8 @@ def test_unsupported_records_are_refused(cpu_backend):
     assert fusion.wave_supports([fusion.PrimOp('diag', (5, 2), (1,), 0, 0)])
 
 
-@pytest.mark.parametrize('n,seed', [(12, 0), (13, 1), (15, 2)])
-def test_reduction_records_of_the_reverse_sweep_translate(cpu_backend, n, seed):
+@pytest.mark.parametrize('n,seed,is128', [(12, 0, False), (13, 1, False), (15, 2, False), (11, 3, True), (13, 4, True)])
+def test_reduction_records_of_the_reverse_sweep_translate(cpu_backend, n, seed, is128):
     """DQ_FG_GRAD records through the library's translation (psi / lambda slot brought to physical slot 0, group masks
     of the register controls, accumulator rows): emulator against the descriptor interpreter, states and sums."""
     rng = random.Random(seed)
@@ -142,21 +142,22 @@ def test_reduction_records_of_the_reverse_sweep_translate(cpu_backend, n, seed):
         ops.append(fusion.PrimOp(op.kind, tuple(t + 1 for t in op.targets), tuple(c + 1 for c in op.controls), off, op.mode))
         mats.append(base_mats[op.mat:op.mat + d * d])
         off += d * d
-    mats = torch.cat(mats)
-    geom = fusion.default_geometry(False)
-    geom.plan_min_bits = 12
+    cdt = torch.complex128 if is128 else torch.complex64
+    mats = torch.cat(mats).to(cdt)
+    geom = fusion.default_geometry(is128)
+    geom.plan_min_bits = 11
     steps = fusion.schedule(ops, n, geom)
     assert all(isinstance(s, fusion.FusedStep) for s in steps)
     km = fusion.kernel_matrices(steps, ops, mats)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(2, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 1 << n, generator=g, dtype=torch.float64)
-    x = (x / x.norm(dim=-1, keepdim=True)).to(torch.complex64)
+    x = (x / x.norm(dim=-1, keepdim=True)).to(cdt)
     acc_d = torch.zeros(2, rows, 8, dtype=torch.float64)
     acc_e = np.zeros((2, rows, 8))
     cur_d, cur_e = x.clone(), x.numpy().copy()
     for st in steps:
         backend.apply_fused(cur_d, km, 0, st.desc, out=cur_d, grads=acc_d)
         cur_e = emu.run_pass(st.desc, n, cur_e, km.numpy(), 0, grads=acc_e)
-    assert np.abs(cur_e - cur_d.numpy()).max() < 2e-6
-    assert np.abs(acc_e - acc_d.numpy()).max() < 2e-5 * max(1.0, float(acc_d.abs().max()))
+    assert np.abs(cur_e - cur_d.numpy()).max() < (1e-13 if is128 else 2e-6)
+    assert np.abs(acc_e - acc_d.numpy()).max() < (1e-12 if is128 else 2e-5) * max(1.0, float(acc_d.abs().max()))
     assert float(acc_d.abs().max()) > 0

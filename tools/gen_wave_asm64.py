@@ -147,7 +147,10 @@ ID_TRIP = ID_TRIP0 + 1
 ID_SWAP = ID_TRIP + len(TRIP_MASKS)
 ID_DIAG1 = ID_SWAP + len(SWAP_PAIRS)
 ID_DIAG2 = ID_DIAG1 + NV
-NIDS = ID_DIAG2 + NV
+# reduction of the adjoint method's reverse sweep: target on slot 1 + (id - ID_GRAD), psi / lambda told apart by slot 0
+ID_GRAD = ID_DIAG2 + NV
+NIDS = ID_GRAD + R - 1
+ACC_BASE = 4 * 8704       # LDS offset of the reduction accumulators (8 doubles per record): behind the staging buffers
 
 
 def handlers():
@@ -169,10 +172,54 @@ def handlers():
         h[ID_TRIP + i] = (False, trip(bin(m).count('1'), m))
     for i, (a_, b_) in enumerate(SWAP_PAIRS):
         h[ID_SWAP + i] = (False, slotswap(a_, b_))
+    for q in range(1, R):
+        h[ID_GRAD + q - 1] = (False, grad_code(q))
     return h
 
 
 PH0, PH1 = ('v[6:7]', 'v[8:9]'), ('v[32:33]', 'v[34:35]')        # (re, im) as f64 pairs
+
+
+def grad_groups(q):
+    return [j for j in range(NA) if not (j >> q) & 1 and not j & 1]
+
+
+def grad_code(q):
+    """DQ_FG_GRAD with the target on slot q, psi (0) / lambda (1) on slot 0: G[a][b] = sum lambda[target = a] conj(psi[target
+    = b]) over the thread's register groups (w5 = mask of the groups whose register controls are set; lanes that fail the
+    thread controls contribute nothing), eight float64 sums per lane: (G00, G01, G10, G11) x (re, im).  Across the lanes
+    they go through the wave's staging buffer: every lane writes its eight sums (72-byte rows), lane L then adds sum
+    number L & 7 of the eight lanes 8 (L >> 3) .. + 7, scales by the square of the pass's deferred factor and adds to the
+    record's accumulator in LDS (ACC_BASE + 64 * record number + 8 * (L & 7)): eight lanes per address."""
+    G = ['v[10:11]', 'v[12:13]', 'v[14:15]', 'v[16:17]', 'v[32:33]', 'v[34:35]', 'v[36:37]', 'v[38:39]']     # re, im of G00 G01 G10 G11
+    t = [f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc0 .Lnext_%=']
+    t += [f'v_mov_b32 v{r}, 0' for r in list(range(10, 18)) + list(range(32, 40))]
+    t += [f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
+          f's_cbranch_execz .Lgz{q}_%=']
+    for i, j in enumerate(grad_groups(q)):
+        ps, ls = (j, j | (1 << q)), (j | 1, j | (1 << q) | 1)
+        t += [f's_bitcmp1_b32 s{REC + 5}, {i}', f's_cbranch_scc0 .Lgg{q}_{i}_%=']
+        ab = [(a_, b_) for a_ in range(2) for b_ in range(2)]
+        # term by term over the four entries: four independent chains per term
+        t += [f'v_fma_f64 {G[2 * (2 * a_ + b_)]}, {RE(ls[a_])}, {RE(ps[b_])}, {G[2 * (2 * a_ + b_)]}' for a_, b_ in ab]
+        t += [f'v_fma_f64 {G[2 * (2 * a_ + b_) + 1]}, {IM(ls[a_])}, {RE(ps[b_])}, {G[2 * (2 * a_ + b_) + 1]}' for a_, b_ in ab]
+        t += [f'v_fma_f64 {G[2 * (2 * a_ + b_)]}, {IM(ls[a_])}, {IM(ps[b_])}, {G[2 * (2 * a_ + b_)]}' for a_, b_ in ab]
+        t += [f'v_fma_f64 {G[2 * (2 * a_ + b_) + 1]}, -{RE(ls[a_])}, {IM(ps[b_])}, {G[2 * (2 * a_ + b_) + 1]}' for a_, b_ in ab]
+        t.append(f'.Lgg{q}_{i}_%=:')
+    t += [f'.Lgz{q}_%=:', f's_mov_b64 exec, {SAVE}',
+          f'v_mul_f64 v[6:7], {HS}, {HS}',
+          f'v_mul_u32_u24 v8, 72, {LANE}', f'v_add_u32 v8, {LDSB}, v8']
+    t += [f'ds_write_b64 v8, {G[c]} offset:{8 * c}' for c in range(8)]
+    t += [f'v_lshrrev_b32 v9, 3, {LANE}', 'v_mul_u32_u24 v9, 576, v9', f'v_and_b32 {TT}, 7, {LANE}', f'v_lshl_add_u32 v9, {TT}, 3, v9',
+          f'v_add_u32 v9, {LDSB}, v9']
+    t += [f'ds_read_b64 {G[c]}, v9 offset:{72 * c}' for c in range(8)]
+    t += ['s_waitcnt lgkmcnt(0)',
+          f'v_add_f64 {G[0]}, {G[0]}, {G[1]}', f'v_add_f64 {G[2]}, {G[2]}, {G[3]}', f'v_add_f64 {G[4]}, {G[4]}, {G[5]}', f'v_add_f64 {G[6]}, {G[6]}, {G[7]}',
+          f'v_add_f64 {G[0]}, {G[0]}, {G[2]}', f'v_add_f64 {G[4]}, {G[4]}, {G[6]}', f'v_add_f64 {G[0]}, {G[0]}, {G[4]}',
+          f'v_mul_f64 {G[0]}, {G[0]}, v[6:7]',
+          f's_lshl_b32 {STMP}, {GOFF}, 1', f'v_lshlrev_b32 {TT}, 3, {TT}', f'v_add_u32 v9, {STMP}, {TT}', f'v_add_u32 v9, {ACC_BASE - 64}, v9',
+          f'ds_add_f64 v9, {G[0]}']
+    return t
 
 
 def cmul_inplace(j, ph):
@@ -332,7 +379,7 @@ if __name__ == '__main__' or os.environ.get('DQ_ASM_OUT'):
            f'#define DQ_WID64_GEN_U {ID_GEN_U}', f'#define DQ_WID64_GEN_C {ID_GEN_C}', f'#define DQ_WID64_GEN_R {ID_GEN_R}',
            f'#define DQ_WID64_X_U {ID_X_U}', f'#define DQ_WID64_X_C {ID_X_C}', f'#define DQ_WID64_X_R {ID_X_R}', f'#define DQ_WID64_X_R1 {ID_X_R1}',
            f'#define DQ_WID64_TRIP0 {ID_TRIP0}', f'#define DQ_WID64_TRIP {ID_TRIP}', f'#define DQ_WID64_SWAP {ID_SWAP}',
-           f'#define DQ_WID64_DIAG1 {ID_DIAG1}', f'#define DQ_WID64_DIAG2 {ID_DIAG2}',
+           f'#define DQ_WID64_DIAG1 {ID_DIAG1}', f'#define DQ_WID64_DIAG2 {ID_DIAG2}', f'#define DQ_WID64_GRAD {ID_GRAD}', f'#define DQ_WAVE64_ACC_BASE {ACC_BASE}',
            'static const short kWave64TripId[32] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(NA)) + '};',
            'static const short kWave64SwapId[5][5] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
            '']

@@ -11,7 +11,6 @@ cp "$root/bench_trace.json" "$root/bench_under_rocprof.json"
 python bench.py --traffic-json "$root/traffic_n28_b16_c64.json" > "$root/bench_default.json" 2> "$root/bench_default.err"
 bash tools/ablation_table.sh > "$root/ablation.txt" 2>&1
 bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
-bash tools/mb_counters.sh --dtype c128 > "$root/microbench_c128.txt" 2>&1
 {
   python tools/bench_train.py --n 20 --depth 20 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 20 --depth 20 --modes adjoint --no-fused-sweep 2>&1 | grep -v amdgpu.ids
@@ -19,6 +18,10 @@ bash tools/mb_counters.sh --dtype c128 > "$root/microbench_c128.txt" 2>&1
   python tools/bench_train.py --n 24 --depth 20 --modes adjoint --no-fused-sweep 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 28 --depth 40 --modes adjoint 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 28 --depth 40 --modes adjoint --no-fused-sweep 2>&1 | grep -v amdgpu.ids
+  python tools/bench_train.py --n 24 --depth 20 --modes adjoint --dtype c128 2>&1 | grep -v amdgpu.ids
+  python tools/bench_train.py --n 24 --depth 20 --modes adjoint --dtype c128 --no-fused-sweep 2>&1 | grep -v amdgpu.ids
+  python tools/bench_train.py --n 27 --depth 40 --modes adjoint --dtype c128 2>&1 | grep -v amdgpu.ids
+  python tools/bench_train.py --n 27 --depth 40 --modes adjoint --dtype c128 --no-fused-sweep 2>&1 | grep -v amdgpu.ids
   python tools/dump_sweep_passes.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_small.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_density.py 2>&1 | grep -v amdgpu.ids
