@@ -73,6 +73,8 @@ def parse_args():
     ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
     ap.add_argument('--plan-restarts', type=int, default=None, help='pass planner: beam searches with different seeds')
     ap.add_argument('--no-asm-loop', action='store_true', help='A/B: gate loop in C++ around the jump table')
+    ap.add_argument('--no-fused-sweep', action='store_true',
+                    help='A/B (config 5): gate-by-gate reverse sweep of the sharded adjoint instead of fused passes')
     ap.add_argument('--no-wave', action='store_true',
                     help='A/B: complex64 on the workgroup-tile kernels (13-bit tiles, barriers) instead of the wave-tile kernel')
     ap.add_argument('--no-compare', action='store_true',
@@ -342,6 +344,8 @@ def main():
         dq.executor.CONFIG['asm_loop'] = False
     if args.no_wave:
         dq.executor.CONFIG['wave'] = False
+    if args.no_fused_sweep:
+        dq.executor.CONFIG['fused_sweep'] = False
     if args.no_merge:
         dq.executor.CONFIG['merge_min_amps'] = None
     if args.no_permute_store:
@@ -490,7 +494,8 @@ def main():
         cost.backward()
         sync()
         qaoa = {'edges': len(pairs), 'gates': len(qc.operators), 'cost': float(cost.detach()), 'dcost_dgamma': float(gamma.grad),
-                'dcost_dbeta': float(beta.grad), 'seconds_forward_backward': time.perf_counter() - t0}
+                'dcost_dbeta': float(beta.grad), 'seconds_forward_backward': time.perf_counter() - t0,
+                'fused_reverse_sweep': bool(distributed and dq.adjoint.LAST_SWEEP.get('fused'))}
 
     if rank == 0:
         total_gate_applies = ngates * nbatch * args.steps * (world if multi and not distributed else 1)

@@ -79,6 +79,97 @@ def _bracket(lam: DistributedQubitState, phi: DistributedQubitState, gate, dmat:
     return val
 
 
+def _sweep_fused_sharded(ctx, grad_out, params):
+    """The reverse sweep as ONE gate list on the (psi, lambda) pair: the two shards interleaved along an extra lowest
+    index bit form the shard of an (n + 1)-qubit sharded state, every gate's inverse acts on both halves at once, and in
+    front of every trainable gate a 'grad' primitive reduces G' = sum lambda (x) conj(psi) on the gate's target inside the
+    fused pass that holds the qubit (DQ_FG_GRAD, include/dq_hip.h; executor._AdjointCircuit._sweep_fused on one GPU).
+    The list goes through the same machinery as a forward circuit -- commutation-DAG order, remaps that bring a target
+    from the rank bits (both halves move together), local stretches as fused passes -- so the sweep costs a few passes
+    and a handful of exchanges instead of two kernel launches and up to two exchanges per gate.  The partial sums of the
+    ranks are all-reduced once at the end;  <lambda| dU |phi> = sum dU[i, j] conj(G[i, j]),  G = G' U^-dagger
+    (phi = U^-1 psi).  Returns the gradients (list, forward parameter order) or None: not applicable -- a trainable
+    gate on two or more targets, batched shards, shards smaller than a tile."""
+    from . import distributed as D
+    from . import executor, fusion
+
+    phi, lam = ctx.state_phi, ctx.state_lambda
+    if not (executor.CONFIG['fused_sweep'] and executor.CONFIG['fuse']) or phi.batch is not None:
+        return None
+    is128 = phi.amps.dtype == torch.complex128
+    geom = executor._geometry(is128)
+    if phi.log_num_amps_per_node + 1 < (geom.fallback.m if geom.fallback is not None else geom.m):
+        return None
+    gates = list(reversed(_flatten_gates(ctx.operators)))
+    prims: list[Prim] = []
+    todo = []                  # (row, gate, parameter, exact inverse matrix) per gradient that is wanted
+    idx = 1
+    slots: list = []           # per parametrised gate, in sweep order: index into `todo` or None
+    for gate in gates:
+        inv_prims = gate.inverse().prims()
+        if gate.npara > 0:
+            p = params[-idx]
+            if ctx.needs_input_grad[3 + len(params) - idx]:
+                if (len(inv_prims) != 1 or len(inv_prims[0].targets) != 1 or inv_prims[0].kind not in ('gen', 'diag')
+                        or inv_prims[0].matrix.ndim != 2):
+                    return None
+                ip = inv_prims[0]
+                slots.append(len(todo))
+                prims.append(Prim('grad', None, (ip.targets[0] + 1, 0), tuple(c + 1 for c in ip.controls), len(todo)))
+                todo.append((gate, p, ip.matrix))
+            else:
+                slots.append(None)
+            idx += 1
+        for ip in inv_prims:
+            prims.append(Prim(ip.kind, ip.matrix, tuple(t + 1 for t in ip.targets), tuple(c + 1 for c in ip.controls), ip.mode))
+    if not todo:
+        return [None] * len(slots)
+    ops = [fusion.PrimOp(q.kind, q.targets, q.controls, 0, q.mode) for q in prims]
+    if is128 and not (geom.wave and fusion.wave_supports(ops)):
+        return None
+    if any(len(q.targets) > 2 for q in prims):
+        return None
+    # the pair as a sharded state of n + 1 qubits: bit 0 tells psi from lambda, the rank bits are the same
+    from .state import DistributedQubitState
+
+    with torch.no_grad():
+        work = torch.stack([phi.amps.reshape(-1), lam.amps.reshape(-1)], dim=-1).reshape(-1)
+        empty = work.new_zeros(0)
+        phi.amps = phi.buffer = lam.amps = lam.buffer = empty        # (three states regardless of depth, not five)
+        phi._shape = lam._shape = (0,)
+        lazy = DistributedQubitState.LAZY_AMPS
+        DistributedQubitState.LAZY_AMPS = -1                         # (do not build |0..0> first)
+        try:
+            pair = DistributedQubitState(phi.nqubit + 1, dtype=work.dtype)
+        finally:
+            DistributedQubitState.LAZY_AMPS = lazy
+        pair.amps, pair.buffer = work, torch.empty_like(work)
+        acc = torch.zeros(1, len(todo), 8, dtype=torch.float64, device=work.device)
+        D._SWEEP['grads'] = acc
+        try:
+            D.dist_apply_prims(pair, prims, mode='remap', keep_layout=True, force_mode=True)
+        finally:
+            D._SWEEP['grads'] = None
+        stats = dict(D.LAST_RUN)
+        if pair.world_size > 1:
+            dist.all_reduce(acc, dist.ReduceOp.SUM)
+        gsum = torch.view_as_complex(acc.reshape(-1, 4, 2)).reshape(-1, 2, 2)       # G' per row
+    LAST_SWEEP.update(fused=True, rows=len(todo), remaps=stats.get('remaps', 0), local_flushes=stats.get('local_flushes', 0))
+    vals = []
+    for r, (gate, p, inv) in enumerate(todo):
+        with torch.enable_grad():
+            du = gate.get_derivative(p.detach())
+        du = du.unsqueeze(0).flatten(0, -3).to(torch.complex128)                     # (npara, 2, 2)
+        g = gsum[r] @ inv.to(torch.complex128).mH                                    # G = G' U^-dagger
+        brackets = (du * g.conj()).sum(dim=(-2, -1))
+        vals.append((grad_out * 2 * brackets.real.to(grad_out.dtype)).reshape(p.shape))
+    return [None if sl is None else vals[sl] for sl in slots]
+
+
+#: what the last backward of ``AdjointExpectation`` did (tests / bench)
+LAST_SWEEP: dict = {'fused': False}
+
+
 class AdjointExpectation(Function):
     @staticmethod
     def forward(ctx, state: DistributedQubitState, operators, observable, *parameters: torch.Tensor) -> torch.Tensor:
@@ -93,6 +184,11 @@ class AdjointExpectation(Function):
     def backward(ctx, grad_out: torch.Tensor):
         params = list(ctx.saved_tensors)
         phi, lam = ctx.state_phi, ctx.state_lambda
+        LAST_SWEEP.clear()
+        LAST_SWEEP['fused'] = False
+        fused = _sweep_fused_sharded(ctx, grad_out, params)
+        if fused is not None:
+            return (None, None, None, *fused[::-1])
         grads: list = []
         idx = 1
         with torch.no_grad():

@@ -57,6 +57,10 @@ CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_gr
           # current placement runs before the next exchange (_order_for_remaps)
           'reorder': True}
 
+#: the accumulator of the DQ_FG_GRAD reductions while a fused reverse sweep runs on a sharded (psi, lambda) pair
+#: (adjoint._sweep_fused_sharded): every local stretch hands its rows to the passes
+_SWEEP: dict = {'grads': None}
+
 #: statistics of the last ``dist_apply_prims`` call (bench / tests)
 LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_permutes': 0, 'permute_passes': 0,
             'wire_bytes': 0, 'groups': 1}
@@ -200,7 +204,7 @@ def _rows_of(pending: Sequence[Prim], rows: slice, total: int) -> list[Prim]:
     out = []
     for p in pending:
         m = p.matrix
-        if m.ndim == 3 and m.shape[0] == total and total > 1:
+        if m is not None and m.ndim == 3 and m.shape[0] == total and total > 1:
             m = m[rows]
         out.append(Prim(p.kind, m, p.targets, p.controls, p.mode))
     return out
@@ -212,7 +216,10 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
     permuted stores; afterwards local bit q sits at position out_perm[q].  Returns True if the result lives in ``b``."""
     total = a.shape[0]
     x, y = a[rows], b[rows]
-    if CONFIG['fold_permute'] or out_perm is None:
+    if _SWEEP['grads'] is not None:               # a stretch of a fused reverse sweep: reductions inside the passes
+        out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel(),
+                           grads=_SWEEP['grads'][rows])
+    elif CONFIG['fold_permute'] or out_perm is None:
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel())
     else:                                         # A/B: the re-labelling as a pass of its own
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y)
@@ -650,18 +657,20 @@ def _canonicalize(state: DistributedQubitState) -> DistributedQubitState:
 # ---------------------------------------------------------------------------------------------------
 # public entry points
 def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None = None,
-                     keep_layout: bool = False) -> DistributedQubitState:
+                     keep_layout: bool = False, force_mode: bool = False) -> DistributedQubitState:
     """Apply kernel primitives (logical bit positions) to the sharded state, fusing local stretches.
-    Unless ``keep_layout`` is set the canonical qubit order is restored before returning."""
+    Unless ``keep_layout`` is set the canonical qubit order is restored before returning.  ``force_mode``: ``mode`` also
+    for short gate lists (which otherwise go gate by gate, pairwise exchanges)."""
     with _raw(state):
-        return _dist_apply_prims(state, prims, mode, keep_layout)
+        return _dist_apply_prims(state, prims, mode, keep_layout, force_mode)
 
 
-def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None, keep_layout: bool) -> DistributedQubitState:
+def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None, keep_layout: bool,
+                      force_mode: bool = False) -> DistributedQubitState:
     for k in LAST_RUN:
         LAST_RUN[k] = 0
     mode = mode or CONFIG['mode']
-    if len(prims) < CONFIG['remap_min_prims'] or state.world_size == 1:
+    if (len(prims) < CONFIG['remap_min_prims'] and not force_mode) or state.world_size == 1:
         mode = 'pairwise'
     if mode == 'pairwise' and not _is_canonical(state):
         canonicalize(state)

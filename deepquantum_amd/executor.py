@@ -222,11 +222,11 @@ def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
         return True
     if not torch.is_grad_enabled():
         return False
-    return state.requires_grad or any(p.matrix.requires_grad for p in prims)
+    return state.requires_grad or any(p.matrix is not None and p.matrix.requires_grad for p in prims)
 
 
 def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
-        out_perm: Sequence[int] | None = None, amps: int | None = None) -> torch.Tensor:
+        out_perm: Sequence[int] | None = None, amps: int | None = None, grads: torch.Tensor | None = None) -> torch.Tensor:
     """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state.
 
     ``scratch`` (no-grad runs): a second buffer like ``state`` that the passes may ping-pong with (permuted stores
@@ -239,6 +239,8 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
         return state
     if state.ndim != 2:
         raise ValueError('state must be (batch, 2**n)')
+    if grads is not None:       # a stretch of a reverse sweep ('grad' prims reduce into ``grads``; the sharded state's)
+        return _run_nograd(state, prims, inplace=inplace, scratch=scratch, out_perm=out_perm, grads=grads, amps=amps)
     if needs_autograd(state, prims):
         assert scratch is None and out_perm is None, 'scratch / out_perm are for no-grad runs'
         vmapped = ops._is_batched(state) or any(ops._is_batched(p.matrix) for p in prims)

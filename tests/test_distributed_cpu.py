@@ -175,6 +175,82 @@ def _case_expectation_grad_w4(dq, rank, world):
     assert (d1.grad - d2.grad).abs().max().item() < 1e-4, (d1.grad, d2.grad)
 
 
+def _fused_sweep_case(dq, rank, world, n, double, device=None):
+    """The reverse sweep of the sharded adjoint as fused passes on the (psi, lambda) pair (adjoint._sweep_fused_sharded):
+    trainable / encoded one-target gates on local and on global qubits, with local and global controls, fixed gates of
+    every kind in between (two-target ones too in complex64); against the dense circuit's autograd and against the
+    gate-by-gate sweep of the reference (adjoint.py:42-83)."""
+    from deepquantum_amd import adjoint, executor
+
+    def make(cls):
+        torch.manual_seed(3)
+        cir = cls(n)
+        cir.hlayer()
+        cir.rxlayer(encode=True)
+        cir.cnot_ring()
+        cir.rylayer()                              # trainable
+        cir.rz(0, encode=True)                     # diagonal, global target
+        cir.crx(1, n - 1, encode=True)             # global control
+        cir.crx(n - 2, 0, encode=True)             # global target, local control
+        cir.u3(1, controls=[0, n - 1])             # trainable, general, a global and a local control
+        cir.toffoli(0, 1, n - 3)
+        if not double:
+            cir.swap([0, n - 2])                   # (fixed two-target gate: complex64 only)
+        cir.p(2)
+        cir.cnot_ring(reverse=True)
+        cir.rxlayer()
+        cir.hlayer()
+        cir.observable(0)
+        cir.observable([1, n - 1], 'xy')
+        if double:
+            cir.to(torch.double)
+        if device is not None:
+            cir.to(device)
+        return cir
+
+    dt = torch.double if double else torch.float
+    # complex128: the fixed gates are unitary to float32 rounding only (the reference's matrices after .to(double)) and
+    # the sweep undoes with gate.inverse() like the reference's (adjoint.py:56-61): every Hadamard leaves psi a factor
+    # 1 + 6e-8 off, in the reference's sweep as in this one
+    tol = 2e-6 if double else 2e-4
+    res = {}
+    for which in ('dense', 'fused', 'gate_by_gate'):
+        executor.CONFIG['fused_sweep'] = which != 'gate_by_gate'
+        try:
+            cir = make(dq.QubitCircuit if which == 'dense' else dq.DistributedQubitCircuit)
+            data = torch.rand(cir.ndata, generator=torch.Generator().manual_seed(4), dtype=dt)
+            if device is not None:
+                data = data.to(device)
+            data.requires_grad_(True)
+            cir(data)
+            ev = cir.expectation()
+            (ev * torch.tensor([1.0, -0.5], dtype=dt, device=ev.device)).sum().backward()
+            if which != 'dense':
+                assert adjoint.LAST_SWEEP['fused'] == (which == 'fused'), adjoint.LAST_SWEEP
+                if which == 'fused':
+                    assert adjoint.LAST_SWEEP['rows'] >= 2 * n and (world == 1 or adjoint.LAST_SWEEP['remaps'] >= 1)
+            res[which] = (ev.detach().cpu(), data.grad.cpu(), [p.grad.cpu() for p in cir.parameters()])
+        finally:
+            executor.CONFIG['fused_sweep'] = True
+    a = res['dense']
+    for which in ('fused', 'gate_by_gate'):
+        b = res[which]
+        assert (a[0] - b[0]).abs().max().item() < tol, (which, a[0], b[0])
+        assert (a[1] - b[1]).abs().max().item() < tol, (which, (a[1] - b[1]).abs().max())
+        assert len(a[2]) == len(b[2]) > n
+        for x, y in zip(a[2], b[2], strict=True):
+            assert (x - y).abs().max().item() < tol, (which, (x - y).abs().max())
+
+
+def _case_fused_sweep_w2(dq, rank, world):
+    _fused_sweep_case(dq, rank, world, 12, False)          # 11 local qubits: the pair is one 12-bit tile per rank
+    _fused_sweep_case(dq, rank, world, 12, True)           # complex128: two 11-bit tiles
+
+
+def _case_fused_sweep_w4(dq, rank, world):
+    _fused_sweep_case(dq, rank, world, 13, False)
+
+
 def _case_batched_w4(dq, rank, world):
     """Extension over the reference: a batch of encoded samples on the sharded state -- (B, 2^L) shards,
     per-sample matrices through global targets / controls, both exchange modes."""
@@ -376,7 +452,8 @@ def _case_sampled_expectation_w4(dq, rank, world):
 @pytest.mark.parametrize('case,world', [('gates_w2', 2), ('gates_w4', 4), ('fused_local_w2', 2), ('sampled_expectation_w4', 4),
                                         ('random_remap_w4', 4), ('remap_w8', 8),
                                         ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4), ('folded_permute_w2', 2),
-                                        ('golden_w2', 2), ('golden_w4', 4), ('golden_w8', 8)])
+                                        ('golden_w2', 2), ('golden_w4', 4), ('golden_w8', 8),
+                                        ('fused_sweep_w2', 2), ('fused_sweep_w4', 4)])
 def test_sharded_circuit(case, world):
     _run(case, world)
 

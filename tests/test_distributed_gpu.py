@@ -141,6 +141,16 @@ def _case_adjoint_grad(dq, rank, world):
     assert (d1.grad - d2.grad).abs().max().item() < 1e-4, (d1.grad, d2.grad)
 
 
+def _case_fused_sweep(dq, rank, world):
+    """The sharded adjoint's reverse sweep as fused passes on the (psi, lambda) pair with the real kernels
+    (dq_apply_fused_grad_c64 / _c128 between remaps): against the dense circuit and the gate-by-gate sweep."""
+    from test_distributed_cpu import _fused_sweep_case
+
+    _fused_sweep_case(dq, rank, world, 13 + (world > 2), False, device='cuda')
+    _fused_sweep_case(dq, rank, world, 13 + (world > 2), True, device='cuda')
+    _fused_sweep_case(dq, rank, world, 17, False, device='cuda')           # several tiles per shard, permuted stores
+
+
 def _case_golden(dq, rank, world):
     """Reference-made fixtures (real DistributedQubitCircuit under gloo) vs. the HIP kernels."""
     from deepquantum_amd import distributed as D
@@ -323,6 +333,7 @@ def test_reference_dist_tests_on_gpu_world_of_one():
 
 
 @pytest.mark.parametrize('case,world', [('golden', 2), ('golden', 4), ('golden', 8), ('random_c64', 2), ('random_c64', 4), ('batched_c128', 4), ('adjoint_grad', 2),
-                                        ('measure', 2), ('measure', 4), ('folded_permute', 2), ('folded_permute', 4)])
+                                        ('measure', 2), ('measure', 4), ('folded_permute', 2), ('folded_permute', 4),
+                                        ('fused_sweep', 2), ('fused_sweep', 4)])
 def test_sharded_on_gpu(case, world):
     _run(case, world)
