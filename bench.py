@@ -443,7 +443,7 @@ def main():
         traffic = json.load(open(tj)).get('hbm_bytes_per_launch')
         traffic_src = (os.path.relpath(tj, ROOT) + ': rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command by '
                        'the builder (tools/profile.sh), not measured during this run')
-    stats = dict(dq.executor.LAST_RUN)
+    stats = {k: v for k, v in dq.executor.LAST_RUN.items() if k != 'plan'}
     dstats = dict(dq.distributed.LAST_RUN) if distributed else None
     z0 = float(out.reshape(-1)[0]) if out is not None else None
 
@@ -548,7 +548,7 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm',
-                'kernel': ('dq::wave_pass_kernel' if dq.executor.CONFIG.get('wave', True) and not args.tile_bits
+                'kernel': ('dq::wave_pass_kernel' if dq.executor.CONFIG.get('wave') is not False and not args.tile_bits
                            else 'dq::fused_pass_kernel'),
                 # PHYSICAL rate of the dominant kernel: bytes its launches read + wrote / their summed duration
                 'achieved': physical,
