@@ -182,32 +182,82 @@ class AdjointExpectation(Function):
 
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor):
-        params = list(ctx.saved_tensors)
-        phi, lam = ctx.state_phi, ctx.state_lambda
-        LAST_SWEEP.clear()
-        LAST_SWEEP['fused'] = False
-        fused = _sweep_fused_sharded(ctx, grad_out, params)
-        if fused is not None:
-            return (None, None, None, *fused[::-1])
-        grads: list = []
-        idx = 1
+        return (None, None, None, *_reverse_sweep(ctx, grad_out, list(ctx.saved_tensors)))
+
+
+def _reverse_sweep(ctx, grad_out: torch.Tensor, params: list) -> list:
+    """Gradients w.r.t. ``params`` (forward order) from ``ctx.state_phi`` (the final state) and ``ctx.state_lambda``
+    (the observable applied to it): fused passes on the pair where that applies, the reference's gate-by-gate sweep
+    (adjoint.py:42-83) otherwise."""
+    phi, lam = ctx.state_phi, ctx.state_lambda
+    LAST_SWEEP.clear()
+    LAST_SWEEP['fused'] = False
+    fused = _sweep_fused_sharded(ctx, grad_out, params)
+    if fused is not None:
+        return fused[::-1]
+    grads: list = []
+    idx = 1
+    with torch.no_grad():
+        for gate in reversed(_flatten_gates(ctx.operators)):
+            inv_prims = gate.inverse().prims()
+            dist_apply_prims(phi, inv_prims)
+            if gate.npara > 0:
+                p = params[-idx]
+                if ctx.needs_input_grad[3 + len(params) - idx]:
+                    with torch.enable_grad():
+                        du = gate.get_derivative(p.detach())
+                    du = du.unsqueeze(0).flatten(0, -3)  # (npara, D, D)
+                    vals = [grad_out * 2 * _bracket(lam, phi, gate, d).real.to(grad_out.dtype) for d in du]
+                    grads.append(torch.stack(vals).reshape(p.shape))
+                else:
+                    grads.append(None)
+                idx += 1
+            dist_apply_prims(lam, inv_prims)
+    return grads[::-1]
+
+
+class AdjointExpectations(Function):
+    """ALL observables of a circuit as one node: the values from one read of the shards each (no copy), and in the
+    backward ONE reverse sweep with  lambda = sum_k g_k O_k psi  (the cost is linear in the observables; g = the incoming
+    gradient).  The reference -- and ``adjoint_expectation`` -- build one (psi, lambda) pair and run one sweep PER
+    observable (circuit.py:1706-1738): for the 34 ZZ terms of a QAOA ring on 34 qubits that is 34 sweeps and 68 shards
+    held between forward and backward; here it is one sweep and three shards whatever the number of observables."""
+
+    @staticmethod
+    def forward(ctx, state: DistributedQubitState, operators, observables, *parameters: torch.Tensor) -> torch.Tensor:
+        from .distributed import expect_pauli_dist
+
+        ctx.state_phi = state
+        ctx.operators = operators
+        ctx.observables = observables
+        ctx.save_for_backward(*parameters)
+        return torch.stack([expect_pauli_dist(state, ob) for ob in observables], dim=-1)
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        phi = ctx.state_phi
         with torch.no_grad():
-            for gate in reversed(_flatten_gates(ctx.operators)):
-                inv_prims = gate.inverse().prims()
-                dist_apply_prims(phi, inv_prims)
-                if gate.npara > 0:
-                    p = params[-idx]
-                    if ctx.needs_input_grad[3 + len(params) - idx]:
-                        with torch.enable_grad():
-                            du = gate.get_derivative(p.detach())
-                        du = du.unsqueeze(0).flatten(0, -3)  # (npara, D, D)
-                        vals = [grad_out * 2 * _bracket(lam, phi, gate, d).real.to(grad_out.dtype) for d in du]
-                        grads.append(torch.stack(vals).reshape(p.shape))
-                    else:
-                        grads.append(None)
-                    idx += 1
-                dist_apply_prims(lam, inv_prims)
-        return (None, None, None, *grads[::-1])
+            lam = None
+            for k, ob in enumerate(ctx.observables):
+                tmp = deepcopy(phi)
+                dist_apply_prims(tmp, ob.prims())
+                gk = grad_out[..., k].to(tmp.amps.real.dtype)
+                if lam is None:
+                    lam = tmp
+                    lam.amps.mul_(gk)
+                else:
+                    lam.amps.add_(tmp.amps * gk)
+                del tmp
+        ctx.state_lambda = lam
+        one = torch.ones((), dtype=grad_out.dtype, device=grad_out.device)
+        return (None, None, None, *_reverse_sweep(ctx, one, list(ctx.saved_tensors)))
+
+
+def adjoint_expectations(state: DistributedQubitState, operators, observables) -> torch.Tensor:
+    """Differentiable expectation values of all ``observables`` on the sharded state, shape (len(observables),)."""
+    parameters = [_gate_parameters(g) for g in _flatten_gates(operators) if g.npara > 0]
+    work = deepcopy(state)
+    return AdjointExpectations.apply(work, operators, list(observables), *parameters)
 
 
 def adjoint_expectation(state: DistributedQubitState, operators, observable) -> torch.Tensor:

@@ -735,7 +735,8 @@ class DistributedQubitCircuit(QubitCircuit):
                             block_size=block_size)
 
     def expectation(self, shots: int | None = None) -> torch.Tensor:
-        from .adjoint import adjoint_expectation
+        from . import executor
+        from .adjoint import adjoint_expectation, adjoint_expectations
 
         assert len(self.observables) > 0, 'There is no observable'
         assert isinstance(self.state, DistributedQubitState), 'There is no final state'
@@ -776,8 +777,9 @@ class DistributedQubitCircuit(QubitCircuit):
             from .distributed import expect_pauli_dist
 
             return torch.stack([expect_pauli_dist(self.state, ob) for ob in self.observables], dim=-1)
-        out = [adjoint_expectation(self.state, self.operators, ob) for ob in self.observables]
-        return torch.stack(out, dim=-1)
+        if not executor.CONFIG['joint_adjoint']:       # the reference's structure: one sweep per observable
+            return torch.stack([adjoint_expectation(self.state, self.operators, ob) for ob in self.observables], dim=-1)
+        return adjoint_expectations(self.state, self.operators, self.observables)
 
     def cnot(self, control: int, target: int) -> None:
         super().cx(control, target)

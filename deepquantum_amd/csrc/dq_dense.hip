@@ -17,6 +17,7 @@
 // conflicts), the NEXT chunk is already on its way from memory into registers while the MFMAs of this one run.
 // Gather / scatter addressing (any target positions, controls as fixed ones) is done once per thread.
 #include "dq_common.hpp"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace dq {
@@ -56,7 +57,29 @@ __device__ __forceinline__ uint64_t target_offset(int j, const DenseGeom& g) {
     return o;
 }
 
-template <typename T, int WM>
+// streaming (non-temporal) 8- / 16-byte accesses: a dense gate reads and writes the state once (DQ_DENSE_NT=0: plain)
+template <typename T> struct NtVec;
+template <> struct NtVec<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct NtVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <typename T, bool NT> __device__ __forceinline__ cx<T> ld_amp(const cx<T>* p) {
+    if constexpr (NT) {
+        const typename NtVec<T>::type v = __builtin_nontemporal_load(reinterpret_cast<const typename NtVec<T>::type*>(p));
+        return mk<T>(v.x, v.y);
+    } else {
+        return *p;
+    }
+}
+template <typename T, bool NT> __device__ __forceinline__ void st_amp(cx<T>* p, T re, T im) {
+    if constexpr (NT) {
+        typename NtVec<T>::type v;
+        v.x = re, v.y = im;
+        __builtin_nontemporal_store(v, reinterpret_cast<typename NtVec<T>::type*>(p));
+    } else {
+        *p = mk<T>(re, im);
+    }
+}
+
+template <typename T, int WM, bool NT>
 __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
                                                                const cx<T>* __restrict__ mats, int64_t mat_bstride,
                                                                DenseGeom g, uint64_t ncols, int col_sample_shift) {
@@ -102,7 +125,7 @@ __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __re
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int kk = k0 + b_k0 + i * B_KSTEP;                       // (uniform per wave-instruction group)
-            pb[i] = col_ok ? in[col_base + target_offset(kk, g)] : mk<T>(0, 0);
+            pb[i] = col_ok ? ld_amp<T, NT>(in + col_base + target_offset(kk, g)) : mk<T>(0, 0);
         }
     };
     auto stash = [&]() __attribute__((always_inline)) {
@@ -178,7 +201,7 @@ __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __re
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = row0 + wm * 32 + a * 16 + M::row(lane, reg);
-                po[target_offset(r, g)] = mk<T>(cr[a][b][reg], ci[a][b][reg]);
+                st_amp<T, NT>(po + target_offset(r, g), cr[a][b][reg], ci[a][b][reg]);
             }
     }
 }
@@ -199,14 +222,19 @@ int apply_dense_mfma(const cx<T>* in, cx<T>* out, const cx<T>* mats, int64_t mat
     const uint64_t ncols = (shared ? (uint64_t)batch : 1ull) << g.colbits;
     const int shift = shared ? g.colbits : -1;
     const unsigned gz = shared ? 1u : (unsigned)batch;
+    // states far beyond the Infinity Cache stream through (nothing is reused after the pass): non-temporal accesses
+    static const int nt_env = [] { const char* e = getenv("DQ_DENSE_NT"); return e ? atoi(e) : -1; }();
+    const bool nt = nt_env >= 0 ? nt_env != 0 : ((uint64_t)batch << n) * sizeof(cx<T>) >= (1ull << 30);
     if (D == 32) {
         constexpr int TN = 128;
         dim3 grid((unsigned)((ncols + TN - 1) / TN), 1, gz);
-        hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 1>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
+        if (nt) hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 1, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
+        else hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 1, false>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
     } else {
         constexpr int TN = 64;
         dim3 grid((unsigned)((ncols + TN - 1) / TN), (unsigned)(D / 64), gz);
-        hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
+        if (nt) hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
+        else hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2, false>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
     }
     (void)controls;
     return DQ_OK;

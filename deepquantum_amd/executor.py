@@ -71,6 +71,9 @@ CONFIG = {'fuse': True, 'wave': None,     # None = wave-tile kernel where it tak
           # undo-then-reduce sweep (always used for trainable gates on two or more targets, and for complex128
           # circuits the wave-tile kernel cannot run)
           'fused_sweep': True,
+          # sharded adjoint: all observables of a circuit share ONE reverse sweep (lambda = sum_k g_k O_k psi); False: one
+          # sweep and one (psi, lambda) pair per observable, the reference's structure (circuit.py:1706-1738)
+          'joint_adjoint': True,
           # states smaller than a tile: fuse (batch folded into the index, or zero-padded) from this many gates on
           'small_fuse_min_gates': 6,
           # no-grad runs on states of at least this many amplitudes (batch included) multiply runs of one-qubit gates

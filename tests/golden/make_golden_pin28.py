@@ -26,7 +26,7 @@ def main():
     n = int(os.environ.get('PIN_N', 28))
     depth = int(os.environ.get('PIN_DEPTH', 40))
     dq = import_reference()
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(int(os.environ.get('PIN_THREADS', os.cpu_count() or 1)))
     spec = random_spec(n, depth, 1234)
     cir = dq.QubitCircuit(n)
     angles = []
@@ -38,7 +38,10 @@ def main():
             getattr(cir, method)(*args)
     for q in range(n):
         cir.observable(q)
-    data = torch.tensor(angles, dtype=torch.float32)
+    c128 = os.environ.get('PIN_DTYPE', 'c64') == 'c128'      # the complex128 pin: PIN_N=26 PIN_DTYPE=c128
+    if c128:
+        cir.to(torch.double)
+    data = torch.tensor(angles, dtype=torch.float64 if c128 else torch.float32)
     t0 = time.perf_counter()
     with torch.no_grad():
         state = cir(data)          # QubitCircuit.forward, circuit.py:180-263
@@ -47,7 +50,7 @@ def main():
         ev = cir.expectation()
         print(f'expectation {time.perf_counter() - t1:.1f} s', flush=True)
         flat = state.reshape(-1)
-        assert flat.dtype == torch.complex64 and flat.numel() == 2**n
+        assert flat.dtype == (torch.complex128 if c128 else torch.complex64) and flat.numel() == 2**n
         idx = torch.randint(0, 2**n, (4096,), generator=torch.Generator().manual_seed(28))
         p = (flat.real.double() ** 2 + flat.imag.double() ** 2)
         out = {
@@ -62,7 +65,7 @@ def main():
         pt = p.reshape([2] * n)
         out['marginal_wires_0_4'] = pt.reshape(32, -1).sum(-1).numpy()
         out['marginal_wires_last5'] = pt.reshape(-1, 32).sum(0).numpy()
-    name = 'pin28.npz' if (n, depth) == (28, 40) else f'pin{n}_d{depth}.npz'
+    name = 'pin28.npz' if (n, depth, c128) == (28, 40, False) else f'pin{n}_d{depth}{"_c128" if c128 else ""}.npz'
     np.savez_compressed(os.path.join(HERE, name), **out)
     print('norm2', out['norm2'], 'Z0', out['expectation_z'][0], 'wrote', name, flush=True)
 

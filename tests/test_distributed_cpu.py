@@ -214,8 +214,9 @@ def _fused_sweep_case(dq, rank, world, n, double, device=None):
     # 1 + 6e-8 off, in the reference's sweep as in this one
     tol = 2e-6 if double else 2e-4
     res = {}
-    for which in ('dense', 'fused', 'gate_by_gate'):
+    for which in ('dense', 'fused', 'gate_by_gate', 'per_observable'):
         executor.CONFIG['fused_sweep'] = which != 'gate_by_gate'
+        executor.CONFIG['joint_adjoint'] = which != 'per_observable'     # (one sweep per observable: the reference's way)
         try:
             cir = make(dq.QubitCircuit if which == 'dense' else dq.DistributedQubitCircuit)
             data = torch.rand(cir.ndata, generator=torch.Generator().manual_seed(4), dtype=dt)
@@ -226,14 +227,15 @@ def _fused_sweep_case(dq, rank, world, n, double, device=None):
             ev = cir.expectation()
             (ev * torch.tensor([1.0, -0.5], dtype=dt, device=ev.device)).sum().backward()
             if which != 'dense':
-                assert adjoint.LAST_SWEEP['fused'] == (which == 'fused'), adjoint.LAST_SWEEP
+                assert adjoint.LAST_SWEEP['fused'] == (which != 'gate_by_gate'), adjoint.LAST_SWEEP
                 if which == 'fused':
                     assert adjoint.LAST_SWEEP['rows'] >= 2 * n and (world == 1 or adjoint.LAST_SWEEP['remaps'] >= 1)
             res[which] = (ev.detach().cpu(), data.grad.cpu(), [p.grad.cpu() for p in cir.parameters()])
         finally:
             executor.CONFIG['fused_sweep'] = True
+            executor.CONFIG['joint_adjoint'] = True
     a = res['dense']
-    for which in ('fused', 'gate_by_gate'):
+    for which in ('fused', 'gate_by_gate', 'per_observable'):
         b = res[which]
         assert (a[0] - b[0]).abs().max().item() < tol, (which, a[0], b[0])
         assert (a[1] - b[1]).abs().max().item() < tol, (which, (a[1] - b[1]).abs().max())
