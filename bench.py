@@ -73,6 +73,8 @@ def parse_args():
     ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
     ap.add_argument('--plan-restarts', type=int, default=None, help='pass planner: beam searches with different seeds')
     ap.add_argument('--no-asm-loop', action='store_true', help='A/B: gate loop in C++ around the jump table')
+    ap.add_argument('--no-fused-expectation', action='store_true',
+                    help='A/B: <Z0> from a separate read of the final state instead of the registers of the last pass')
     ap.add_argument('--no-fused-sweep', action='store_true',
                     help='A/B (config 5): gate-by-gate reverse sweep of the sharded adjoint instead of fused passes')
     ap.add_argument('--no-wave', action='store_true',
@@ -344,6 +346,8 @@ def main():
         dq.executor.CONFIG['asm_loop'] = False
     if args.no_wave:
         dq.executor.CONFIG['wave'] = False
+    if args.no_fused_expectation:
+        dq.executor.CONFIG['fused_expectation'] = False
     if args.no_fused_sweep:
         dq.executor.CONFIG['fused_sweep'] = False
     if args.no_merge:
@@ -418,6 +422,21 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
     step_ms = [a.elapsed_time(b) for a, b in step_events]      # HIP events around every step (this rank)
+    # The sharded circuit runs with lazy_layout = True: the qubits stay where the last remap put them, <Z0> is taken
+    # from the shards as they lie, and the exchange(s) that restore the reference's shard order are paid by whoever
+    # reads state.amps.  The reference's forward always pays them: timed here once, outside the step, so that the
+    # drop-in cost (step + restore) is visible in the line (collective: every rank reads).
+    restore_ms = None
+    if distributed:
+        sync()
+        t_r = time.perf_counter()
+        _ = cir.state.amps
+        sync()
+        restore_ms = (time.perf_counter() - t_r) * 1e3
+        if multi:
+            t = torch.tensor([restore_ms], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            restore_ms = t.item()
 
     # dominant kernel: the fused pass -- durations from HIP events recorded on the stream it is launched on, and the
     # bytes each launch physically moves (one read + one write of the rows it works on)
@@ -531,6 +550,8 @@ def main():
                                 if distributed else
                                 f'batch-shard x{world} (independent samples, no collective in the data path)' if multi
                                 else 'single GPU'),
+                'lazy_layout': bool(distributed),
+                'ms_restore_canonical_layout': restore_ms,
                 'fused_passes_per_step': stats.get('passes') if not distributed else launches / args.steps,
                 'lds_round_trips_per_step': stats.get('transposes') if not distributed else None,
                 'in_wave_exchange_rounds_per_step': stats.get('swaps') if not distributed else None,

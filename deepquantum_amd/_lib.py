@@ -16,10 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DQHIP_LIBRARY') or os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
-FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_SWAP, FG_GRAD = range(7)
+FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_SWAP, FG_GRAD, FG_EXPZ = range(8)
 LOC_REG, LOC_THR, LOC_OUT = range(3)
 
 FUSED_MAX_HIGH = 12

@@ -1242,6 +1242,15 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
                 }
                 continue;
             }
+            if (g.kind == DQ_FG_EXPZ) {
+                if (ngrads < 0 || logt != 6 || (g.reg_cmask >> slots) || g.mat != next_mat || g.mat_advance != 0 ||
+                    g.fast != DQ_FAST_NONE || (int64_t)g.reserved >= ngrads) {
+                    set_error("dq_apply_fused: expectation record %d malformed, or not a dq_apply_fused_grad_* call on a "
+                              "wave-tile geometry", gi);
+                    return DQ_ERR_ARG;
+                }
+                continue;
+            }
             if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 3) || (g.kind == DQ_FG_GEN2 && g.loc > 1)) ||
                 (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
                 set_error("dq_apply_fused: gate %d malformed", gi);

@@ -46,7 +46,7 @@ struct WaveC64 {
     static constexpr unsigned LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID_GEN_U, ID_GEN_C = DQ_WID_GEN_C, ID_GEN_R = DQ_WID_GEN_R, ID_X_U = DQ_WID_X_U,
                          ID_X_C = DQ_WID_X_C, ID_X_R = DQ_WID_X_R, ID_X_R1 = DQ_WID_X_R1, ID_TRIP0 = DQ_WID_TRIP0,
-                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2, ID_GRAD = DQ_WID_GRAD;
+                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2, ID_GRAD = DQ_WID_GRAD, ID_EXPZ = DQ_WID_EXPZ;
     static int trip_id(unsigned mask) { return kWaveTripId[mask]; }
     static int swap_id(int i, int j) { return kWaveSwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -61,7 +61,7 @@ struct WaveC128 {
     static constexpr unsigned LDS_PER_WAVE = 8704;      // (7 * 68 + 64) * 16 bytes: the k = 3 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID64_GEN_U, ID_GEN_C = DQ_WID64_GEN_C, ID_GEN_R = DQ_WID64_GEN_R, ID_X_U = DQ_WID64_X_U,
                          ID_X_C = DQ_WID64_X_C, ID_X_R = DQ_WID64_X_R, ID_X_R1 = DQ_WID64_X_R1, ID_TRIP0 = DQ_WID64_TRIP0,
-                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD;
+                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD, ID_EXPZ = DQ_WID64_EXPZ;
     static int trip_id(unsigned mask) { return kWave64TripId[mask]; }
     static int swap_id(int i, int j) { return kWave64SwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
         double* const grow = grads + (uint64_t)sample * (uint64_t)grad_bstride;
         for (unsigned i = tid; i < nrec * 8u; i += 256u) {
             const unsigned id = rw[8u * (i >> 3)];
-            if (id >= (unsigned)W::ID_GRAD && id < (unsigned)W::ID_GRAD + (unsigned)W::R - 1u) {
+            if (id >= (unsigned)W::ID_GRAD && id <= (unsigned)W::ID_EXPZ) {      // (an expectation value fills component 0 only)
                 const typename W::acc_t v = *(__attribute__((address_space(3))) typename W::acc_t*)(uintptr_t)(4u * W::LDS_PER_WAVE + (unsigned)sizeof(typename W::acc_t) * i);
                 atomicAdd(grow + (uint64_t)rw[8u * (i >> 3) + 6] * 8u + (i & 7u), (double)v);
             }
@@ -352,6 +352,21 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
         if (!x.go(want, nullptr)) goto fail;
         for (int gi = rd.gate_begin & 0x7f; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
+            if (g.kind == DQ_FG_EXPZ) {
+                // <Z..Z> from the registers: the sign of a register from the Z bits that are register slots right now
+                unsigned pm = 0;
+                for (int s = 0; s < W::R; ++s)
+                    if ((g.reg_cmask >> s) & 1u) pm |= 1u << x.slot_of(rd.rb[s]);
+                WaveRec rec{};
+                rec.w[0] = (uint32_t)W::ID_EXPZ;
+                rec.w[1] = g.thr_cmask;
+                rec.w[2] = (uint32_t)g.out_cmask, rec.w[3] = (uint32_t)(g.out_cmask >> 32);
+                for (int j = 0; j < W::NA; ++j)
+                    if (__builtin_popcount((unsigned)j & pm) & 1) rec.w[j < 32 ? 5 : 7] |= 1u << (j & 31);
+                rec.w[6] = g.reserved;
+                if (!x.push(rec)) goto fail;
+                continue;
+            }
             if (g.kind == DQ_FG_GRAD && W::ID_GRAD >= 0) {
                 // reduction of the reverse sweep: the handlers want psi / lambda on physical slot 0 (where the load layout
                 // puts index bit 0 anyway); a register swap brings it back there if a trip moved it

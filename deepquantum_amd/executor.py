@@ -74,6 +74,9 @@ CONFIG = {'fuse': True, 'wave': None,     # None = wave-tile kernel where it tak
           # sharded adjoint: all observables of a circuit share ONE reverse sweep (lambda = sum_k g_k O_k psi); False: one
           # sweep and one (psi, lambda) pair per observable, the reference's structure (circuit.py:1706-1738)
           'joint_adjoint': True,
+          # no-grad forwards of circuits with Z-type observables take <Z..Z> from the registers of the last pass
+          # (DQ_FG_EXPZ records; wave-tile kernel): `expectation()` then costs no read of the state
+          'fused_expectation': True,
           # states smaller than a tile: fuse (batch folded into the index, or zero-padded) from this many gates on
           'small_fuse_min_gates': 6,
           # no-grad runs on states of at least this many amplitudes (batch included) multiply runs of one-qubit gates
@@ -172,7 +175,7 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     prim_ops, off = [], 0
     for p in prims:
         prim_ops.append(fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), off, p.mode, 0, tuple(p.order)))
-        if p.kind != 'grad':            # (a reduction of the reverse sweep has no matrix)
+        if p.kind not in ('grad', 'expz'):            # (reductions have no matrix)
             off += (1 << len(p.targets)) ** 2
     import time
 
@@ -229,7 +232,8 @@ def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
 
 
 def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
-        out_perm: Sequence[int] | None = None, amps: int | None = None, grads: torch.Tensor | None = None) -> torch.Tensor:
+        out_perm: Sequence[int] | None = None, amps: int | None = None, grads: torch.Tensor | None = None,
+        expect_z: dict | None = None) -> torch.Tensor:
     """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state.
 
     ``scratch`` (no-grad runs): a second buffer like ``state`` that the passes may ping-pong with (permuted stores
@@ -257,6 +261,22 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
     if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']
             and not ops._is_batched(state)):
         prims = merge_one_qubit_runs(prims)
+    if expect_z is not None and expect_z.get('masks') and CONFIG['fused_expectation'] and CONFIG['fuse'] and out_perm is None:
+        # ``expect_z = {'masks': [zmask, ..]}``: the Z strings' expectation values of the FINAL state come out of the last
+        # pass (``expect_z['values']``, float64 (B, K)) when the wave-tile kernel runs the circuit; untouched otherwise
+        n = state.shape[-1].bit_length() - 1
+        is128 = state.dtype == torch.complex128
+        g_ = _geometry(is128)
+        ops_ = [fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), 0, p.mode) for p in prims]
+        if (g_.wave and n >= g_.m and len(prims) > 0 and fusion.wave_supports(ops_) and not ops._is_batched(state)
+                and state.shape[0] <= backend.MAX_BATCH):
+            every = tuple(range(n))
+            extra = [Prim('expz', None, (), tuple(q for q in range(n) if (int(z) >> q) & 1), r, order=every)
+                     for r, z in enumerate(expect_z['masks'])]
+            acc = torch.zeros(state.shape[0], len(extra), 8, dtype=torch.float64, device=state.device)
+            out = _run_nograd(state, list(prims) + extra, inplace, scratch, out_perm, grads=acc, amps=amps)
+            expect_z['values'] = acc[:, :, 0]
+            return out
     return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps)
 
 
@@ -456,7 +476,10 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                     if other is None:
                         other = torch.empty_like(x)
                     dst = other
-                gr = grads if grads is not None and any(plan.prim_ops[oi].kind == 'grad' for oi in st.ops) else None
+                gr = grads if grads is not None and any(plan.prim_ops[oi].kind in ('grad', 'expz') for oi in st.ops) else None
+                if gr is not None and src is not x:      # (a reducing pass takes no shared input state: materialise it)
+                    x.copy_(src.expand_as(x))
+                    src = x
                 if PROFILE['enabled'] and x.is_cuda:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -473,7 +496,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 stats['swaps'] = stats.get('swaps', 0) + st.nswaps
             else:
                 op = plan.prim_ops[st.op]
-                assert op.kind != 'grad', 'a reduction of the reverse sweep can only run inside a fused pass'
+                assert op.kind not in ('grad', 'expz'), 'a reduction can only run inside a fused pass'
                 d = 1 << op.k
                 mat = flat[:, op.pos : op.pos + d * d].reshape(-1, d, d)
                 if op.k <= 4:

@@ -31,7 +31,10 @@ class PrimOp:
 
     ``kind == 'grad'`` is not a gate but a reduction of the adjoint method's reverse sweep (DQ_FG_GRAD,
     include/dq_hip.h): ``targets = (q, s)`` -- q the trainable gate's target, s the index bit that tells psi from the
-    cotangent -- ``controls`` the gate's controls, ``mode`` the row of the accumulator; no matrix."""
+    cotangent -- ``controls`` the gate's controls, ``mode`` the row of the accumulator; no matrix.
+    ``kind == 'expz'``: the expectation value of a Z string taken from the registers of whatever pass it lands in
+    (DQ_FG_EXPZ): no targets, ``controls`` = the string's qubits, ``mode`` = the row, ``order`` = the qubits whose gates
+    it waits for (all of them, for a value of the final state); no matrix."""
 
     kind: str
     targets: tuple[int, ...]
@@ -109,7 +112,7 @@ def wave_supports(ops: Sequence['PrimOp']) -> bool:
     """Can the wave-tile kernel run all of ``ops``?  (One-target dense gates and X, diagonal gates on one or two
     targets, any controls, the reductions of the reverse sweep.)"""
     return all((op.kind in ('gen', 'x') and len(op.targets) == 1) or (op.kind == 'diag' and len(op.targets) <= 2)
-               or op.kind == 'grad' for op in ops)
+               or op.kind in ('grad', 'expz') for op in ops)
 
 
 def workgroup_geometry(is_c128: bool, m: int | None = None, slots: int | None = None) -> Geometry:
@@ -146,6 +149,12 @@ def _action(op: PrimOp) -> dict[int, str]:
     'X' = as a function of X (target of an X or of an Rx-like matrix a*I + i*b*X, controlled or not),
     'G' = a reduction of the reverse sweep reading the psi / lambda bit, 'N' = anything else."""
     act = {q: 'D' for q in op.controls + op.order}
+    if op.kind == 'expz':
+        # <Z..Z> is invariant under unitaries on the other qubits and under diagonal gates on its own -- but the
+        # reference's fixed matrices are unitary to float32 rounding only (DESIGN 2), so a value taken before the last
+        # gate differs from the final state's by 1e-7: the caller lists every qubit in ``order`` and the record waits
+        # for everything
+        return {q: 'N' for q in op.controls + op.order}
     if op.kind == 'grad':
         # a snapshot on its target (ordered against everything there).  On the psi / lambda bit reductions do not
         # disturb each other (a type of their own, 'G'), but they are ordered against every gate that tells psi from
@@ -1038,6 +1047,10 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         if op.k == 2:
             g.loc2, g.q2 = locate(op.targets[1])
         return
+    if op.kind == 'expz':
+        g.kind = _lib.FG_EXPZ
+        g.reserved = op.mode
+        return
     slots = [slot_of[local[t]] for t in op.targets]
     if op.kind == 'grad':
         g.kind = _lib.FG_GRAD
@@ -1087,7 +1100,7 @@ def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], 
                     g.mat, g.mat_advance = off, 0
                     continue
                 op = ops[oi]
-                size = 0 if g.kind in (_lib.FG_X1, _lib.FG_GRAD) else (1 << op.k) ** 2
+                size = 0 if g.kind in (_lib.FG_X1, _lib.FG_GRAD, _lib.FG_EXPZ) else (1 << op.k) ** 2
                 g.mat, g.mat_advance, op.pos = off, size, off
                 if size:
                     order.append(oi)

@@ -45,7 +45,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 19
+#define DQ_ABI_VERSION 20
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -111,11 +111,17 @@ typedef enum {
                         v_permlane32/16_swap for lane bits 5 / 4, DPP row shifts for 3 / 2, DPP quad permutations for
                         1 / 0 -- a change of layout without LDS and without a workgroup barrier.  Only as the leading
                         records of a DQ_ROUND_SWAP round of complex64 kernels; fast = 52 + 6 * q + q2 */
-    DQ_FG_GRAD = 6   /* not a gate: a reduction for the reverse sweep of the adjoint method (dq_apply_fused_grad_c64 / _c128).
+    DQ_FG_GRAD = 6,  /* not a gate: a reduction for the reverse sweep of the adjoint method (dq_apply_fused_grad_c64 / _c128).
                         The state is psi and the cotangent lambda side by side along ONE extra index bit (register slot
                         q2: 0 = psi, 1 = lambda); the record adds  G[a][b] = sum lambda[target = a] conj(psi[target = b])
                         (target = register slot q; the sum runs over everything else, restricted to the controls being
                         1) to row `reserved` of the caller's accumulator.  No matrix, no handler id */
+    DQ_FG_EXPZ = 7   /* not a gate: the expectation value of a Z string taken from the registers, so that a circuit's
+                        <Z..Z> observables cost no extra read of the state (replaces qmath.expectation qmath.py:830-860
+                        for Z-type observables): adds  sum_i (-1)^popc(i & zmask) |a_i|^2  to component 0 of row
+                        `reserved` of the accumulator of a dq_apply_fused_grad_* call.  The Z bits are given like
+                        controls: reg_cmask (register slots), thr_cmask (tile-local bits on lanes), out_cmask (index
+                        bits outside the tile).  Wave-tile geometries only.  No matrix */
 } DqFusedKind;
 
 typedef enum { DQ_LOC_REG = 0, DQ_LOC_THR = 1, DQ_LOC_OUT = 2 } DqBitLoc;
@@ -160,7 +166,7 @@ typedef struct {
     uint32_t mat_advance; /* complex numbers this gate occupies in `mats` (0 for X1): the matrices of a pass
                              lie back to back in gate order, mat(i+1) = mat(i) + mat_advance(i), so the kernel
                              fetches gate i's matrix together with its record instead of after decoding it */
-    uint32_t reserved;  /* DQ_FG_GRAD: row of the accumulator; otherwise 0 (pads the record to 32 bytes: one
+    uint32_t reserved;  /* DQ_FG_GRAD, DQ_FG_EXPZ: row of the accumulator; otherwise 0 (pads the record to 32 bytes: one
                            s_load_dwordx8 per gate) */
 } DqFusedGate;          /* 32 bytes */
 #define DQ_FAST_NONE 0xFFFFFFFFu

@@ -123,7 +123,7 @@ class CpuTestBackend:
         for gi in range(ngates):
             g = desc.gates[gi]
             assert g.mat == run, 'matrix layout is not sequential'
-            size = {_lib.FG_GEN1: 4, _lib.FG_X1: 0, _lib.FG_DIAG1: 4, _lib.FG_GEN2: 16, _lib.FG_DIAG2: 16, _lib.FG_SWAP: 0, _lib.FG_GRAD: 0}[g.kind]
+            size = {_lib.FG_GEN1: 4, _lib.FG_X1: 0, _lib.FG_DIAG1: 4, _lib.FG_GEN2: 16, _lib.FG_DIAG2: 16, _lib.FG_SWAP: 0, _lib.FG_GRAD: 0, _lib.FG_EXPZ: 0}[g.kind]
             assert g.mat_advance == size
             run += size
         per_sample = mats.shape[-1] if mats.ndim == 2 else mats.numel()
@@ -173,7 +173,7 @@ class CpuTestBackend:
                 for gi in range(first + nswap, rd.gate_end):
                     g = desc.gates[gi]
                     assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
-                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1, _lib.FG_DIAG1, _lib.FG_DIAG2, _lib.FG_GRAD), 'the wave-tile kernel takes one-target and diagonal gates only'
+                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1, _lib.FG_DIAG1, _lib.FG_DIAG2, _lib.FG_GRAD, _lib.FG_EXPZ), 'the wave-tile kernel takes one-target and diagonal gates only'
                     assert (g.reg_cmask >> R) == 0
                     cm = g.thr_cmask
                     for s in range(R):
@@ -184,6 +184,22 @@ class CpuTestBackend:
                     assert all(((outside >> p) & 1) == 0 for p in range(L)) and all(
                         ((outside >> p) & 1) == 0 for p in high_pos
                     ), 'outside-control on a tile bit'
+                    if g.kind == _lib.FG_EXPZ:
+                        # include/dq_hip.h, DQ_FG_EXPZ: sum (-1)^popc(index & zmask) |a|^2 over the whole state; the Z
+                        # bits come as control masks (cm = the tile-local ones, `outside` the others); row `reserved`
+                        assert grads is not None and wave and g.reserved < grads.shape[1], 'expectation record outside a dq_apply_fused_grad call'
+                        par_e = np.zeros(e.shape, dtype=np.int64)
+                        for bit in range(m):
+                            if (cm >> bit) & 1:
+                                par_e ^= (e >> bit) & 1
+                        par_t = np.zeros(tiles.shape, dtype=np.int64)
+                        for bit in range(n):
+                            if (outside >> bit) & 1:
+                                par_t ^= (tiles >> bit) & 1
+                        sign = 1.0 - 2.0 * (par_t[:, None] ^ par_e[None, :])
+                        v = t.astype(np.complex128)
+                        grads[b, g.reserved, 0] += float((sign * (v.real ** 2 + v.imag ** 2)).sum())
+                        continue
                     el_ok = (e & cm) == cm
                     if g.kind == _lib.FG_GRAD:
                         # include/dq_hip.h, DQ_FG_GRAD: G[a][b] = sum lambda[target = a] conj(psi[target = b]) over the

@@ -202,6 +202,17 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None):
                 if hid in swap_of:
                     _run_moves(g, g.slotswap(*swap_of[hid]), a, np.ones(64, bool))
                     continue
+                if hid == getattr(g, 'ID_EXPZ', -1):
+                    # <Z..Z> from the registers (expz_code): register signs in w5 / w7, lane parity mask w1, tile parity mask
+                    # w2:w3 -- parity masks, not controls: every tile and every lane contributes
+                    rs = np.array([(w[5 if j < 32 else 7] >> (j % 32)) & 1 for j in range(NA)])
+                    lane_par = np.array([bin(int(tb[ln]) & w[1]).count('1') & 1 for ln in range(64)])
+                    tile_par = bin(tg & oc).count('1') & 1
+                    sign = 1.0 - 2.0 * ((lane_par[:, None] ^ rs[None, :]) ^ tile_par)
+                    v = a.astype(np.complex128)
+                    assert grads is not None, 'an expectation record outside a dq_apply_fused_grad call'
+                    grads[b, w[6], 0] += float((sign * (v.real ** 2 + v.imag ** 2)).sum()) * abs(scale) ** 2
+                    continue
                 if not tile_ok:
                     continue
                 if getattr(g, 'ID_GRAD', 1 << 30) <= hid < getattr(g, 'ID_GRAD', 1 << 30) + 5:

@@ -348,3 +348,40 @@ def test_fused_reverse_sweep_on_random_circuits(cpu_backend, seed):
     from _helpers import check_fused_sweep_random
 
     check_fused_sweep_random(dq, n=11, batch=2, seed=seed, ngates=60)
+
+
+def test_z_expectations_come_out_of_the_last_pass(cpu_backend):
+    """No-grad forwards take <Z..Z> of the Z-type observables from the registers of the last pass (DQ_FG_EXPZ): same values
+    as the separate reduction, for one sample and a batch, both precisions; other observables still read the state."""
+    from deepquantum_amd import executor
+
+    for n, dt, tol in ((12, torch.float32, 3e-6), (13, torch.float64, 1e-12)):
+        for batch in (None, 3):
+            def build():
+                torch.manual_seed(1)
+                c = dq.QubitCircuit(n)
+                c.hlayer(); c.rxlayer(encode=True); c.cnot_ring(); c.rylayer(); c.rz(0, encode=True); c.hlayer()
+                c.observable(0); c.observable([1, n - 1], 'zz'); c.observable([2, 3], 'xy'); c.observable(list(range(n)), 'z' * n)
+                if dt == torch.float64:
+                    c.to(torch.double)
+                return c
+            data = torch.rand((batch, n + 1) if batch else (n + 1,), dtype=dt)
+            res = {}
+            for fused in (True, False):
+                executor.CONFIG['fused_expectation'] = fused
+                try:
+                    c = build()
+                    with torch.no_grad():
+                        c(data)
+                        assert (c._expz is not None) == fused
+                        res[fused] = c.expectation()
+                        if fused:           # the values belong to the state they were taken from
+                            c.state = c.state.clone()
+                            assert (c.expectation() - res[True]).abs().max().item() < tol
+                finally:
+                    executor.CONFIG['fused_expectation'] = True
+            assert res[True].shape == res[False].shape and (res[True] - res[False]).abs().max().item() < tol
+    c = dq.QubitCircuit(12)
+    c.hlayer(); c.rxlayer(); c.observable(0)
+    c()                                     # under grad mode: the differentiable reduction
+    assert c._expz is None and c.expectation().requires_grad

@@ -587,3 +587,32 @@ def test_config3_pin_n28_complex64_batch16():
     full = cir.state.reshape(batch, 1 << n)
     norms = backend.expect_pauli(full, 0, 0).cpu().numpy()
     assert np.abs(norms - 1).max() < 1e-4
+
+
+@pytest.mark.parametrize('n,dt,batch,tol', [(14, torch.float32, 4, 3e-6), (20, torch.float32, None, 3e-6), (22, torch.float32, 3, 3e-6),
+                                            (13, torch.float64, 2, 1e-12), (21, torch.float64, None, 1e-12)])
+def test_z_expectations_come_out_of_the_last_pass_on_gpu(n, dt, batch, tol):
+    """`expectation()` after a no-grad forward: Z-type observables from the registers of the last pass (DQ_FG_EXPZ), the
+    others from the state; equal to the separate reductions."""
+    def build():
+        torch.manual_seed(1)
+        c = dq.QubitCircuit(n)
+        c.hlayer(); c.rxlayer(encode=True); c.cnot_ring(); c.rylayer(); c.rz(0, encode=True); c.cnot_ring(reverse=True); c.hlayer()
+        c.observable(0); c.observable([1, n - 1], 'zz'); c.observable([2, 3], 'xy'); c.observable(list(range(n)), 'z' * n)
+        c.to(dev())
+        if dt == torch.float64:
+            c.to(torch.double)
+        return c
+    data = torch.rand((batch, n + 1) if batch else (n + 1,), dtype=dt, device=dev())
+    res = {}
+    for fused in (True, False):
+        dq.executor.CONFIG['fused_expectation'] = fused
+        try:
+            c = build()
+            with torch.no_grad():
+                c(data)
+                assert (c._expz is not None) == fused
+                res[fused] = c.expectation()
+        finally:
+            dq.executor.CONFIG['fused_expectation'] = True
+    assert res[True].shape == res[False].shape and (res[True] - res[False]).abs().max().item() < tol, (res[True], res[False])

@@ -161,3 +161,42 @@ def test_reduction_records_of_the_reverse_sweep_translate(cpu_backend, n, seed, 
     assert np.abs(cur_e - cur_d.numpy()).max() < (1e-13 if is128 else 2e-6)
     assert np.abs(acc_e - acc_d.numpy()).max() < (1e-12 if is128 else 2e-5) * max(1.0, float(acc_d.abs().max()))
     assert float(acc_d.abs().max()) > 0
+
+
+@pytest.mark.parametrize('n,seed,is128', [(12, 0, False), (14, 1, False), (15, 2, False), (11, 3, True), (13, 4, True)])
+def test_z_string_expectations_from_the_registers(cpu_backend, n, seed, is128):
+    """DQ_FG_EXPZ records: <Z..Z> of several strings reduced inside the last pass, descriptor interpreter and emulator
+    against numpy on the final state."""
+    rng = random.Random(seed)
+    ops, mats = random_ops(n, 70, seed)
+    ops = list(ops)
+    masks = [1 << (n - 1), 1, (1 << (n - 1)) | 1, sum(1 << q for q in rng.sample(range(n), 4)), (1 << n) - 1]
+    for r, zm in enumerate(masks):
+        ops.append(fusion.PrimOp('expz', (), tuple(q for q in range(n) if (zm >> q) & 1), 0, r, 0, tuple(range(n))))
+    cdt = torch.complex128 if is128 else torch.complex64
+    mats = mats.to(cdt)
+    geom = fusion.default_geometry(is128)
+    geom.plan_min_bits = 11
+    steps = fusion.schedule(ops, n, geom)
+    assert all(isinstance(s, fusion.FusedStep) for s in steps)
+    km = fusion.kernel_matrices(steps, ops, mats)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 1 << n, generator=g, dtype=torch.float64)
+    x = (x / x.norm(dim=-1, keepdim=True)).to(cdt)
+    acc_d = torch.zeros(2, len(masks), 8, dtype=torch.float64)
+    acc_e = np.zeros((2, len(masks), 8))
+    cur_d, cur_e = x.clone(), x.numpy().copy()
+    for st in steps:
+        backend.apply_fused(cur_d, km, 0, st.desc, out=cur_d, grads=acc_d)
+        cur_e = emu.run_pass(st.desc, n, cur_e, km.numpy(), 0, grads=acc_e)
+    ref = reference(x, [op for op in ops if op.kind != 'expz'], mats)
+    assert (cur_d - ref).abs().max().item() < (1e-10 if is128 else 1e-4)
+    p = (ref.real.double() ** 2 + ref.imag.double() ** 2).numpy()
+    idx = np.arange(1 << n)
+    tol = 1e-12 if is128 else 2e-6
+    for r, zm in enumerate(masks):
+        sign = 1.0 - 2.0 * (np.array([bin(int(i) & zm).count('1') & 1 for i in idx]))
+        want = (p * sign[None, :]).sum(-1)
+        assert np.abs(acc_d[:, r, 0].numpy() - want).max() < tol, (r, acc_d[:, r, 0], want)
+        assert np.abs(acc_e[:, r, 0] - want).max() < tol, (r, acc_e[:, r, 0], want)
+    assert float(acc_d[:, :, 1:].abs().max()) == 0.0

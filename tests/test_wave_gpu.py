@@ -138,3 +138,38 @@ def test_wave_pass_refuses_what_it_cannot_run():
     with pytest.raises(RuntimeError, match='one-target and diagonal'):
         for st in steps:
             backend.apply_fused(x, md, 0, st.desc, out=x)
+
+
+@PREC
+@pytest.mark.parametrize('n,seed', [(12, 0), (14, 1), (17, 2), (21, 3)])
+def test_z_string_expectations_from_the_registers_on_gpu(n, seed, is128):
+    """DQ_FG_EXPZ records on the kernel: <Z..Z> of several strings out of the last pass against float64 sums of the oracle's
+    final state (complex64: float32 partial sums per workgroup, 1e-6)."""
+    import numpy as np
+
+    ops, mats = random_ops(n, 100, seed)
+    ops = list(ops)
+    masks = [1 << (n - 1), 1, (1 << (n - 1)) | 1, 0b1011 << (n // 2), (1 << n) - 1]
+    for r, zm in enumerate(masks):
+        ops.append(fusion.PrimOp('expz', (), tuple(q for q in range(n) if (zm >> q) & 1), 0, r, 0, tuple(range(n))))
+    mats = mats.to(cdtype(is128))
+    steps = wave_steps(ops, n, permute=True, is128=is128)
+    x = rand_state(2, n, 40 + seed, is128)
+    ref = reference(x, [op for op in ops if op.kind != 'expz'], mats)
+    cur, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
+    acc = torch.zeros(2, len(masks), 8, dtype=torch.float64, device=dev())
+    for st in steps:
+        nxt = torch.empty_like(cur)
+        backend.apply_fused(cur, md, 0, st.desc, out=nxt, grads=acc)
+        cur = nxt
+    assert (cur.cpu() - ref).abs().max().item() < TOL[is128]
+    p = (ref.real.double() ** 2 + ref.imag.double() ** 2)
+    idx = torch.arange(1 << n)
+    for r, zm in enumerate(masks):
+        par = torch.zeros(1 << n, dtype=torch.long)
+        for q in range(n):
+            if (zm >> q) & 1:
+                par ^= (idx >> q) & 1
+        want = (p * (1.0 - 2.0 * par)[None, :]).sum(-1)
+        assert (acc[:, r, 0].cpu() - want).abs().max().item() < (1e-12 if is128 else 1e-6), (r, acc[:, r, 0], want)
+    assert float(acc[:, :, 1:].abs().max()) == 0.0

@@ -198,7 +198,9 @@ ID_DIAG1 = ID_SWAP + len(SWAP_PAIRS)
 ID_DIAG2 = ID_DIAG1 + 14
 # reduction of the adjoint method's reverse sweep: target on slot 1 + (id - ID_GRAD), psi / lambda told apart by slot 0
 ID_GRAD = ID_DIAG2 + 14
-NIDS = ID_GRAD + 5
+# expectation value of a Z string, reduced from the registers (DQ_FG_EXPZ): same accumulators as the reductions above
+ID_EXPZ = ID_GRAD + 5
+NIDS = ID_EXPZ + 1
 ACC_BASE = 4 * 8448       # LDS offset of the reduction accumulators: behind the four waves' staging buffers
 
 
@@ -219,6 +221,7 @@ def handlers():
                 h[ID_X_R1 + 5 * q + (c if c < q else c - 1)] = (True, xlines(q, 1 << c))
     for q in range(1, R):
         h[ID_GRAD + q - 1] = (False, grad_code(q))
+    h[ID_EXPZ] = (False, expz_code())
     h[ID_TRIP0] = (False, trip(0, 0))
     for i, m in enumerate(TRIP_MASKS):
         h[ID_TRIP + i] = (False, trip(bin(m).count('1'), m))
@@ -348,6 +351,29 @@ def grad_code(q):
     return t
 
 
+def expz_code():
+    """DQ_FG_EXPZ: sum_i (-1)^popc(i & zmask) |a_i|^2 over the tile, added to component 0 of the record's accumulator.
+    The parity of an amplitude splits into its register's (w5 / w7: bit j = sign of register j, made by the translator
+    from the Z bits that are register slots), its lane's (w1 against the lane's tile-local index) and the tile's (w2:w3
+    against the index bits outside the tile).  The registers lack the pass's deferred factor f: times |f|^2."""
+    P, M_ = 'v[10:11]', 'v[12:13]'
+    t = [f'v_mov_b32 v{r}, 0' for r in range(10, 14)]
+    for j in range(NA):
+        word = REC + 5 if j < 32 else REC + 7
+        t += [f's_bitcmp1_b32 s{word}, {j % 32}', f's_cbranch_scc1 .Lezm{j}_%=',
+              f'v_pk_fma_f32 {P}, {A(j)}, {A(j)}, {P}', f's_branch .Lezn{j}_%=',
+              f'.Lezm{j}_%=:', f'v_pk_fma_f32 {M_}, {A(j)}, {A(j)}, {M_}', f'.Lezn{j}_%=:']
+    t += ['v_sub_f32 v10, v10, v12', 'v_sub_f32 v11, v11, v13', 'v_add_f32 v10, v10, v11',
+          # sign of the lane and of the tile
+          f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_bcnt_u32_b32 {TT}, {TT}, 0',
+          f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_bcnt1_i32_b64 {STMP}, vcc',
+          f'v_add_u32 {TT}, {STMP}, {TT}', f'v_lshlrev_b32 {TT}, 31, {TT}', f'v_xor_b32 v10, {TT}, v10',
+          f'v_mul_f32 {TT}, {HR}, {HR}', f'v_fma_f32 {TT}, {HI}, {HI}, {TT}', f'v_mul_f32 v10, v10, {TT}',
+          f's_add_u32 {STMP}, {GOFF}, {ACC_BASE - 32}', f'v_mov_b32 v32, {STMP}',
+          'ds_add_f32 v32, v10']
+    return t
+
+
 def gray_walk(op, base_operand, lane_operand, nt=False):
     """32 x (address = base + running slot offset + lane offset; op).  The running offset follows a Gray code over the
     slot bits 1..5, so each step is one 64-bit scalar add or subtract."""
@@ -457,7 +483,7 @@ out = ['// GENERATED by tools/gen_wave_asm.py -- do not edit by hand.', '// clan
        f'#define DQ_WID_GEN_U {ID_GEN_U}', f'#define DQ_WID_GEN_C {ID_GEN_C}', f'#define DQ_WID_GEN_R {ID_GEN_R}',
        f'#define DQ_WID_X_U {ID_X_U}', f'#define DQ_WID_X_C {ID_X_C}', f'#define DQ_WID_X_R {ID_X_R}', f'#define DQ_WID_X_R1 {ID_X_R1}',
        f'#define DQ_WID_TRIP0 {ID_TRIP0}', f'#define DQ_WID_TRIP {ID_TRIP}', f'#define DQ_WID_SWAP {ID_SWAP}',
-       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
+       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WID_EXPZ {ID_EXPZ}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
        '// trip handler id by slot mask (popcount 1..DQ_WAVE_MAXK), -1 otherwise; slot-swap handler id by (i < j)',
        'static const short kWaveTripId[64] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(64)) + '};',
        'static const short kWaveSwapId[6][6] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',

@@ -149,7 +149,8 @@ ID_DIAG1 = ID_SWAP + len(SWAP_PAIRS)
 ID_DIAG2 = ID_DIAG1 + NV
 # reduction of the adjoint method's reverse sweep: target on slot 1 + (id - ID_GRAD), psi / lambda told apart by slot 0
 ID_GRAD = ID_DIAG2 + NV
-NIDS = ID_GRAD + R - 1
+ID_EXPZ = ID_GRAD + R - 1      # expectation value of a Z string (DQ_FG_EXPZ)
+NIDS = ID_EXPZ + 1
 ACC_BASE = 4 * 8704       # LDS offset of the reduction accumulators (8 doubles per record): behind the staging buffers
 
 
@@ -174,6 +175,7 @@ def handlers():
         h[ID_SWAP + i] = (False, slotswap(a_, b_))
     for q in range(1, R):
         h[ID_GRAD + q - 1] = (False, grad_code(q))
+    h[ID_EXPZ] = (False, expz_code())
     return h
 
 
@@ -219,6 +221,25 @@ def grad_code(q):
           f'v_mul_f64 {G[0]}, {G[0]}, v[6:7]',
           f's_lshl_b32 {STMP}, {GOFF}, 1', f'v_lshlrev_b32 {TT}, 3, {TT}', f'v_add_u32 v9, {STMP}, {TT}', f'v_add_u32 v9, {ACC_BASE - 64}, v9',
           f'ds_add_f64 v9, {G[0]}']
+    return t
+
+
+def expz_code():
+    """As in the complex64 generator, float64 sums: w5 = sign of register j (32 registers), w1 / w2:w3 the lane's and the
+    tile's parity masks; eight-byte accumulator (component 0 of the record's row)."""
+    P, M_ = 'v[10:11]', 'v[12:13]'
+    t = [f'v_mov_b32 v{r}, 0' for r in range(10, 14)]
+    for j in range(NA):
+        t += [f's_bitcmp1_b32 s{REC + 5}, {j}', f's_cbranch_scc1 .Lezm{j}_%=',
+              f'v_fma_f64 {P}, {RE(j)}, {RE(j)}, {P}', f'v_fma_f64 {P}, {IM(j)}, {IM(j)}, {P}', f's_branch .Lezn{j}_%=',
+              f'.Lezm{j}_%=:', f'v_fma_f64 {M_}, {RE(j)}, {RE(j)}, {M_}', f'v_fma_f64 {M_}, {IM(j)}, {IM(j)}, {M_}', f'.Lezn{j}_%=:']
+    t += [f'v_add_f64 {P}, {P}, -{M_}',
+          f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_bcnt_u32_b32 {TT}, {TT}, 0',
+          f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_bcnt1_i32_b64 {STMP}, vcc',
+          f'v_add_u32 {TT}, {STMP}, {TT}', f'v_lshlrev_b32 {TT}, 31, {TT}', f'v_xor_b32 v11, {TT}, v11',
+          f'v_mul_f64 v[6:7], {HS}, {HS}', f'v_mul_f64 {P}, {P}, v[6:7]',
+          f's_lshl_b32 {STMP}, {GOFF}, 1', f's_add_u32 {STMP}, {STMP}, {ACC_BASE - 64}', f'v_mov_b32 v9, {STMP}',
+          f'ds_add_f64 v9, {P}']
     return t
 
 
@@ -379,7 +400,7 @@ if __name__ == '__main__' or os.environ.get('DQ_ASM_OUT'):
            f'#define DQ_WID64_GEN_U {ID_GEN_U}', f'#define DQ_WID64_GEN_C {ID_GEN_C}', f'#define DQ_WID64_GEN_R {ID_GEN_R}',
            f'#define DQ_WID64_X_U {ID_X_U}', f'#define DQ_WID64_X_C {ID_X_C}', f'#define DQ_WID64_X_R {ID_X_R}', f'#define DQ_WID64_X_R1 {ID_X_R1}',
            f'#define DQ_WID64_TRIP0 {ID_TRIP0}', f'#define DQ_WID64_TRIP {ID_TRIP}', f'#define DQ_WID64_SWAP {ID_SWAP}',
-           f'#define DQ_WID64_DIAG1 {ID_DIAG1}', f'#define DQ_WID64_DIAG2 {ID_DIAG2}', f'#define DQ_WID64_GRAD {ID_GRAD}', f'#define DQ_WAVE64_ACC_BASE {ACC_BASE}',
+           f'#define DQ_WID64_DIAG1 {ID_DIAG1}', f'#define DQ_WID64_DIAG2 {ID_DIAG2}', f'#define DQ_WID64_GRAD {ID_GRAD}', f'#define DQ_WID64_EXPZ {ID_EXPZ}', f'#define DQ_WAVE64_ACC_BASE {ACC_BASE}',
            'static const short kWave64TripId[32] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(NA)) + '};',
            'static const short kWave64SwapId[5][5] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
            '']
