@@ -18,6 +18,7 @@
 // Gather / scatter addressing (any target positions, controls as fixed ones) is done once per thread.
 #include "dq_common.hpp"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 namespace dq {
@@ -206,6 +207,111 @@ __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __re
     }
 }
 
+// ---- k = 5: no LDS for the state, no barrier in the loop -----------------------------------------------------------
+// 32 x 32 is small enough for the MFMA operand layout to be filled straight from memory: lane (j = l & 15, q = l >> 4)
+// of a 16x16x4 block wants B[k = 4 s + q][column j] -- for complex64 a 16-byte load brings columns 2 j and 2 j + 1 (any
+// 16 columns can form a block: the even ones are block 0, the odd ones block 1), for complex128 one column.  A wave owns
+// a group of 32 (16) columns: eight 16-byte loads per lane, 128 (64) MFMAs, eight 16-byte stores, the next group's loads
+// already in flight; U sits in LDS as re / im planes (read per k step), written once per workgroup.  8 * 32 flop per 16
+// bytes: the memory side has to stream at >= 4.4 TB/s while the matrix cores run at >= 0.45 of their f32 peak.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int CPL = 2; };
+template <> struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int CPL = 1; };
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void apply_dense5_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
+                                                           const cx<T>* __restrict__ mats, int64_t mat_bstride, DenseGeom g,
+                                                           uint64_t ngroups, int col_sample_shift) {
+    constexpr int D = 32, CPL = Vec16<T>::CPL, CG = 16 * CPL, PAD = D + 1;
+    using M = Mfma<T>;
+    using acc_t = typename M::acc_t;
+    using V = typename Vec16<T>::type;
+    __shared__ T sUr[D * PAD], sUi[D * PAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t zb = blockIdx.y;
+    const cx<T>* U = mats + zb * mat_bstride;
+    for (int i = tid; i < D * D; i += 256) {
+        const cx<T> u = U[i];
+        sUr[(i >> 5) * PAD + (i & 31)] = u.x;
+        sUi[(i >> 5) * PAD + (i & 31)] = u.y;
+    }
+    __syncthreads();
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // offsets (in amplitudes) of the matrix-index patterns this lane touches
+    const uint64_t off_l4 = target_offset(l4, g);                                  // k = 4 s + l4: the low two bits
+    uint64_t off_s[8];
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) off_s[s_] = target_offset(4 * s_, g);
+    auto col_base = [&](uint64_t grp) __attribute__((always_inline)) {
+        const uint64_t c = grp * CG + (uint64_t)l15 * CPL;
+        const uint64_t sample = col_sample_shift >= 0 ? (c >> col_sample_shift) : (uint64_t)zb;
+        const uint64_t within = col_sample_shift >= 0 ? (c & ((1ull << col_sample_shift) - 1ull)) : c;
+        return (sample << g.n) + (insert_zeros(within, g.sorted) | g.cmask);
+    };
+    auto fetch = [&](V (&b)[8], uint64_t base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const V* p = reinterpret_cast<const V*>(in + base + (off_s[s_] | off_l4));
+            if constexpr (NT) b[s_] = __builtin_nontemporal_load(p);
+            else b[s_] = *p;
+        }
+    };
+    const uint64_t stride = (uint64_t)gridDim.x * 4u;
+    uint64_t grp = (uint64_t)blockIdx.x * 4u + (uint64_t)wave;
+    V b[8], bn[8];
+    uint64_t base = 0;
+    if (grp < ngroups) {
+        base = col_base(grp);
+        fetch(b, base);
+    }
+    for (; grp < ngroups; grp += stride) {
+        const uint64_t nbase = grp + stride < ngroups ? col_base(grp + stride) : 0;
+        if (grp + stride < ngroups) fetch(bn, nbase);            // in flight while the matrix cores work on this group
+        acc_t cr[2][CPL], ci[2][CPL];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) cr[a][c] = ci[a][c] = acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            T ar[2], ai[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {           // A[i = l & 15][k = 4 s + (l >> 4)]
+                ar[a] = sUr[(a * 16 + l15) * PAD + 4 * s_ + l4];
+                ai[a] = sUi[(a * 16 + l15) * PAD + 4 * s_ + l4];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const T br = b[s_][2 * c], bi = b[s_][2 * c + 1];
+                    cr[a][c] = M::run(ar[a], br, cr[a][c]);
+                    ci[a][c] = M::run(ar[a], bi, ci[a][c]);
+                    cr[a][c] = M::run(-ai[a], bi, cr[a][c]);
+                    ci[a][c] = M::run(ai[a], br, ci[a][c]);
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = a * 16 + M::row(lane, reg);
+                V v;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    v[2 * c] = cr[a][c][reg];
+                    v[2 * c + 1] = ci[a][c][reg];
+                }
+                V* p = reinterpret_cast<V*>(out + base + target_offset(r, g));
+                if constexpr (NT) __builtin_nontemporal_store(v, p);
+                else *p = v;
+            }
+        base = nbase;
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) b[s_] = bn[s_];
+    }
+}
+
 template <typename T>
 int apply_dense_mfma(const cx<T>* in, cx<T>* out, const cx<T>* mats, int64_t mat_bstride, int n, const int* targets, int k,
                      const int* controls, int nc, const BitList& sorted, uint64_t cmask, int64_t batch, hipStream_t s) {
@@ -225,7 +331,16 @@ int apply_dense_mfma(const cx<T>* in, cx<T>* out, const cx<T>* mats, int64_t mat
     // states far beyond the Infinity Cache stream through (nothing is reused after the pass): non-temporal accesses
     static const int nt_env = [] { const char* e = getenv("DQ_DENSE_NT"); return e ? atoi(e) : -1; }();
     const bool nt = nt_env >= 0 ? nt_env != 0 : ((uint64_t)batch << n) * sizeof(cx<T>) >= (1ull << 30);
-    if (D == 32) {
+    static const int d5_env = [] { const char* e = getenv("DQ_DENSE5"); return e ? atoi(e) : 1; }();
+    constexpr int CG = 16 * Vec16<T>::CPL;
+    // (complex64: a 16-byte access is two neighbouring columns -- index bit 0 must be a column bit)
+    if (D == 32 && d5_env && ncols % CG == 0 && (sizeof(T) == 8 || sorted.n == 0 || sorted.pos[0] != 0)) {
+        const uint64_t ngroups = ncols / CG;
+        const unsigned blocks = (unsigned)std::min<uint64_t>((ngroups + 3) / 4, 256ull * 12ull);
+        dim3 grid(blocks, gz);
+        if (nt) hipLaunchKernelGGL((apply_dense5_kernel<T, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ngroups, shift);
+        else hipLaunchKernelGGL((apply_dense5_kernel<T, false>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ngroups, shift);
+    } else if (D == 32) {
         constexpr int TN = 128;
         dim3 grid((unsigned)((ncols + TN - 1) / TN), 1, gz);
         if (nt) hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 1, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);

@@ -390,7 +390,7 @@ def check_grad_records(n, m, device, is128=False):
         assert np.abs(got[:, r_ + 1] - g).max() < (1e-12 if is128 else 2e-5) * max(1.0, np.abs(g).max()), (r_, ops[2 * r_ + 1])
 
 
-def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, tol=5e-5):
+def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, tol=5e-5, dtype=torch.float32):
     """Fuzz of the fused reverse sweep: a random sequence from the whole gate menu -- fixed, trainable and encoded
     (batched) gates, controls of every arity, diagonal and two-qubit gates in between -- differentiated by the fused
     sweep and by per-gate autograd."""
@@ -402,8 +402,11 @@ def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, 
         cir = dq.QubitCircuit(n)
         cir.hlayer()
         for _ in range(ngates):
-            kind = rng.choice(['h', 'x', 'y', 'z', 's', 't', 'rx', 'ry', 'rz', 'p', 'u3', 'cnot', 'cz', 'crx', 'cry', 'crz',
-                               'toffoli', 'swap', 'rxx_enc', 'rzz_enc', 'rx_enc', 'ry_ctrl', 'u3_ctrl2', 'fredkin', 'cp'])
+            menu = ['h', 'x', 'y', 'z', 's', 't', 'rx', 'ry', 'rz', 'p', 'u3', 'cnot', 'cz', 'crx', 'cry', 'crz',
+                    'toffoli', 'rzz_enc', 'rx_enc', 'ry_ctrl', 'u3_ctrl2', 'cp']
+            if dtype == torch.float32:       # (two-target dense gates: complex128 sweeps are fused on the wave-tile kernel only)
+                menu += ['swap', 'rxx_enc', 'fredkin']
+            kind = rng.choice(menu)
             w = rng.sample(range(n), 3)
             if kind in ('h', 'x', 'y', 'z', 's', 't'):
                 getattr(cir, kind)(w[0], controls=[w[1]] if rng.random() < 0.2 else None)
@@ -431,6 +434,8 @@ def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, 
         cir.observable([1, n - 1], 'xz')
         if device is not None:
             cir.to(device)
+        if dtype == torch.float64:
+            cir.to(torch.double)
         return cir
 
     results = {}
@@ -439,12 +444,12 @@ def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, 
         try:
             cir = build()
             g = torch.Generator().manual_seed(100 + seed)
-            data = torch.rand(batch, max(cir.ndata, 1), generator=g) * 6.0
+            data = torch.rand(batch, max(cir.ndata, 1), generator=g, dtype=dtype) * 6.0
             if device is not None:
                 data = data.to(device)
             data.requires_grad_(True)
             cir(data=data if cir.ndata else None)
-            loss = (cir.expectation() * torch.tensor([1.0, -0.7], device=data.device)).sum()
+            loss = (cir.expectation() * torch.tensor([1.0, -0.7], device=data.device, dtype=dtype)).sum()
             loss.backward()
             if mode == 'adjoint':
                 assert dq.executor.LAST_SWEEP['fused'] and dq.executor.LAST_SWEEP['reductions'] > 0

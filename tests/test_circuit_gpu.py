@@ -316,6 +316,13 @@ def test_fused_reverse_sweep_on_random_circuits_on_gpu(seed):
     check_fused_sweep_random(dq, device=dev(), n=13 + seed % 3, batch=1 + seed % 2, seed=seed)
 
 
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_fused_reverse_sweep_c128_on_random_circuits_on_gpu(seed):
+    from _helpers import check_fused_sweep_random
+
+    check_fused_sweep_random(dq, device=dev(), n=11 + 2 * seed, batch=1 + seed % 2, seed=seed, tol=1e-10, dtype=torch.float64)
+
+
 def test_adjoint_backward_memory_is_independent_of_depth():
     """Training step at n = 24 (128 MiB per state), 480 gates: stock per-gate autograd would hold one state per
     gate (~60 GiB); the adjoint node peaks at a handful of states."""
@@ -587,6 +594,46 @@ def test_config3_pin_n28_complex64_batch16():
     full = cir.state.reshape(batch, 1 << n)
     norms = backend.expect_pauli(full, 0, 0).cpu().numpy()
     assert np.abs(norms - 1).max() < 1e-4
+
+
+def test_pin_n26_complex128_batch4():
+    """The benchmark circuit in complex128 at the size the wave-tile kernel's big-state paths start (n = 26, depth 40, 1040
+    gates; batch 4 = 4 GiB: merged one-qubit runs, permuted stores, streaming accesses, <Z0> out of the last pass) against
+    what the REAL reference computed in double precision for batch element 0 (tests/golden/pin26_d40_c128.npz <-
+    PIN_N=26 PIN_DTYPE=c128 make_golden_pin28.py, 17 minutes of the reference): 4096 seeded amplitudes, the squared
+    norm, <Z_q> on every wire and two 5-wire marginals, at the north star's 1e-10."""
+    import os
+    import sys
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from deepquantum_amd import backend
+
+    pin = np.load(os.path.join(root, 'tests', 'golden', 'pin26_d40_c128.npz'))
+    n, depth, batch = 26, 40, 4
+    assert int(pin['nqubit']) == n and int(pin['depth']) == depth
+    spec = bench.random_circuit_spec(n, depth, 1234)
+    cir, data = bench.build_circuit(dq, n, spec, batch, torch.complex128, dev())
+    assert data.dtype == torch.float64 and np.array_equal(data[0].cpu().numpy(), pin['angles_f32'])
+    with torch.no_grad():
+        cir(data)
+        ev = cir.expectation()
+    assert dq.executor.LAST_RUN['passes'] > 0 and dq.executor.LAST_RUN['gates'] < len(spec) + 1   # merged, fused
+    assert cir._expz is not None
+    state = cir.state.reshape(batch, 1 << n)[:1].contiguous()
+    idx = torch.from_numpy(pin['indices']).to(state.device)
+    assert np.abs(state[0, idx].cpu().numpy() - pin['amplitudes']).max() < 1e-10
+    assert abs(float(backend.expect_pauli(state, 0, 0)[0]) - float(pin['norm2'])) < 1e-10
+    ez = np.array([float(backend.expect_pauli(state, 0, 1 << (n - 1 - q))[0]) for q in range(n)])
+    assert np.abs(ez - pin['expectation_z']).max() < 1e-10
+    assert abs(float(ev.reshape(batch, -1)[0, 0]) - float(pin['expectation_z'][0])) < 1e-10        # (from the last pass)
+    p0 = backend.marginal(state, [n - 1 - w for w in range(5)]).reshape(-1).cpu().numpy()
+    p1 = backend.marginal(state, [n - 1 - w for w in range(n - 5, n)]).reshape(-1).cpu().numpy()
+    assert np.abs(p0 - pin['marginal_wires_0_4']).max() < 1e-10
+    assert np.abs(p1 - pin['marginal_wires_last5']).max() < 1e-10
 
 
 @pytest.mark.parametrize('n,dt,batch,tol', [(14, torch.float32, 4, 3e-6), (20, torch.float32, None, 3e-6), (22, torch.float32, 3, 3e-6),

@@ -23,5 +23,8 @@ for k in range(count):
     n = 13 + seed % 5
     check_fuzz_against_oracle(dq, device=dev, n=n, seeds=(seed,), depth=5 + seed % 4, batch=1 + seed % 3, double=(seed % 4 == 3))
     check_fused_sweep_random(dq, device=dev, n=12 + seed % 6, batch=1 + seed % 2, seed=seed, ngates=70 + 10 * (seed % 5))
+    if seed % 3 == 0:        # complex128: the wave-tile kernel's float64 reductions, exact inverses / corrections, 1e-10
+        check_fused_sweep_random(dq, device=dev, n=11 + seed % 7, batch=1 + seed % 2, seed=seed, ngates=60 + 10 * (seed % 5),
+                                 tol=1e-10, dtype=torch.float64)
     print(f'seed {seed}: n = {n} ok ({time.time() - t0:.0f} s)', flush=True)
 print(f'{count} seeds from {first}: all agree')
