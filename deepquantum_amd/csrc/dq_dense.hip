@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __re
     }
 }
 
-// ---- k = 5: no LDS for the state, no barrier in the loop -----------------------------------------------------------
-// 32 x 32 is small enough for the MFMA operand layout to be filled straight from memory: lane (j = l & 15, q = l >> 4)
+// ---- k = 5, 6: no LDS for the state, no barrier in the loop -----------------------------------------------------------
+// 32 x 32 (64 x 64) is small enough for the MFMA operand layout to be filled straight from memory: lane (j = l & 15, q = l >> 4)
 // of a 16x16x4 block wants B[k = 4 s + q][column j] -- for complex64 a 16-byte load brings columns 2 j and 2 j + 1 (any
 // 16 columns can form a block: the even ones are block 0, the odd ones block 1), for complex128 one column.  A wave owns
 // a group of 32 (16) columns: eight 16-byte loads per lane, 128 (64) MFMAs, eight 16-byte stores, the next group's loads
@@ -218,11 +218,14 @@ template <typename T> struct Vec16;
 template <> struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int CPL = 2; };
 template <> struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int CPL = 1; };
 
-template <typename T, bool NT>
-__global__ __launch_bounds__(256) void apply_dense5_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
-                                                           const cx<T>* __restrict__ mats, int64_t mat_bstride, DenseGeom g,
-                                                           uint64_t ngroups, int col_sample_shift) {
-    constexpr int D = 32, CPL = Vec16<T>::CPL, CG = 16 * CPL, PAD = D + 1;
+template <typename T, int KB, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 && KB == 5 ? 3 : 2, sizeof(T) == 4 && KB == 5 ? 3 : 2)))
+void apply_dense56_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, const cx<T>* __restrict__ mats,
+                          int64_t mat_bstride, DenseGeom g, uint64_t ngroups, int col_sample_shift) {
+    constexpr int D = 1 << KB, CPL = Vec16<T>::CPL, CG = 16 * CPL, PAD = D + 1;
+    constexpr int RB = 2, KS = D / 4;               // row blocks of 16 per wave, k steps of 4
+    constexpr int H = D / 32;                       // waves that share a column group (k = 6: two, 32 rows each)
+    constexpr bool PREFETCH = KB == 5;              // (k = 6: the operands of one group fill the registers)
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
     using V = typename Vec16<T>::type;
@@ -232,56 +235,63 @@ __global__ __launch_bounds__(256) void apply_dense5_kernel(const cx<T>* __restri
     const cx<T>* U = mats + zb * mat_bstride;
     for (int i = tid; i < D * D; i += 256) {
         const cx<T> u = U[i];
-        sUr[(i >> 5) * PAD + (i & 31)] = u.x;
-        sUi[(i >> 5) * PAD + (i & 31)] = u.y;
+        sUr[(i >> KB) * PAD + (i & (D - 1))] = u.x;
+        sUi[(i >> KB) * PAD + (i & (D - 1))] = u.y;
     }
     __syncthreads();
     const int l15 = lane & 15, l4 = lane >> 4;
     // offsets (in amplitudes) of the matrix-index patterns this lane touches
     const uint64_t off_l4 = target_offset(l4, g);                                  // k = 4 s + l4: the low two bits
-    uint64_t off_s[8];
+    uint64_t off_s[KS];
 #pragma unroll
-    for (int s_ = 0; s_ < 8; ++s_) off_s[s_] = target_offset(4 * s_, g);
+    for (int s_ = 0; s_ < KS; ++s_) off_s[s_] = target_offset(4 * s_, g);
     auto col_base = [&](uint64_t grp) __attribute__((always_inline)) {
         const uint64_t c = grp * CG + (uint64_t)l15 * CPL;
         const uint64_t sample = col_sample_shift >= 0 ? (c >> col_sample_shift) : (uint64_t)zb;
         const uint64_t within = col_sample_shift >= 0 ? (c & ((1ull << col_sample_shift) - 1ull)) : c;
         return (sample << g.n) + (insert_zeros(within, g.sorted) | g.cmask);
     };
-    auto fetch = [&](V (&b)[8], uint64_t base) __attribute__((always_inline)) {
+    auto fetch = [&](V (&b)[KS], uint64_t base) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s_ = 0; s_ < 8; ++s_) {
+        for (int s_ = 0; s_ < KS; ++s_) {
             const V* p = reinterpret_cast<const V*>(in + base + (off_s[s_] | off_l4));
             if constexpr (NT) b[s_] = __builtin_nontemporal_load(p);
             else b[s_] = *p;
         }
     };
-    const uint64_t stride = (uint64_t)gridDim.x * 4u;
-    uint64_t grp = (uint64_t)blockIdx.x * 4u + (uint64_t)wave;
-    V b[8], bn[8];
+    const int row0 = (wave % H) * 32;
+    const uint64_t stride = (uint64_t)gridDim.x * (4u / H);
+    uint64_t grp = (uint64_t)blockIdx.x * (4u / H) + (uint64_t)(wave / H);
+    V b[KS], bn[PREFETCH ? KS : 1];
     uint64_t base = 0;
-    if (grp < ngroups) {
+    if (PREFETCH && grp < ngroups) {
         base = col_base(grp);
         fetch(b, base);
     }
     for (; grp < ngroups; grp += stride) {
-        const uint64_t nbase = grp + stride < ngroups ? col_base(grp + stride) : 0;
-        if (grp + stride < ngroups) fetch(bn, nbase);            // in flight while the matrix cores work on this group
-        acc_t cr[2][CPL], ci[2][CPL];
+        uint64_t nbase = 0;
+        if constexpr (PREFETCH) {
+            nbase = grp + stride < ngroups ? col_base(grp + stride) : 0;
+            if (grp + stride < ngroups) fetch(bn, nbase);        // in flight while the matrix cores work on this group
+        } else {
+            base = col_base(grp);
+            fetch(b, base);
+        }
+        acc_t cr[RB][CPL], ci[RB][CPL];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < RB; ++a)
 #pragma unroll
             for (int c = 0; c < CPL; ++c) cr[a][c] = ci[a][c] = acc_t{0, 0, 0, 0};
 #pragma unroll
-        for (int s_ = 0; s_ < 8; ++s_) {
-            T ar[2], ai[2];
+        for (int s_ = 0; s_ < KS; ++s_) {
+            T ar[RB], ai[RB];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {           // A[i = l & 15][k = 4 s + (l >> 4)]
-                ar[a] = sUr[(a * 16 + l15) * PAD + 4 * s_ + l4];
-                ai[a] = sUi[(a * 16 + l15) * PAD + 4 * s_ + l4];
+            for (int a = 0; a < RB; ++a) {          // A[i = l & 15][k = 4 s + (l >> 4)]
+                ar[a] = sUr[(row0 + a * 16 + l15) * PAD + 4 * s_ + l4];
+                ai[a] = sUi[(row0 + a * 16 + l15) * PAD + 4 * s_ + l4];
             }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < RB; ++a)
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const T br = b[s_][2 * c], bi = b[s_][2 * c + 1];
@@ -292,10 +302,10 @@ __global__ __launch_bounds__(256) void apply_dense5_kernel(const cx<T>* __restri
                 }
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < RB; ++a)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int r = a * 16 + M::row(lane, reg);
+                const int r = row0 + a * 16 + M::row(lane, reg);
                 V v;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
@@ -306,9 +316,11 @@ __global__ __launch_bounds__(256) void apply_dense5_kernel(const cx<T>* __restri
                 if constexpr (NT) __builtin_nontemporal_store(v, p);
                 else *p = v;
             }
-        base = nbase;
+        if constexpr (PREFETCH) {
+            base = nbase;
 #pragma unroll
-        for (int s_ = 0; s_ < 8; ++s_) b[s_] = bn[s_];
+            for (int s_ = 0; s_ < KS; ++s_) b[s_] = bn[s_];
+        }
     }
 }
 
@@ -334,12 +346,22 @@ int apply_dense_mfma(const cx<T>* in, cx<T>* out, const cx<T>* mats, int64_t mat
     static const int d5_env = [] { const char* e = getenv("DQ_DENSE5"); return e ? atoi(e) : 1; }();
     constexpr int CG = 16 * Vec16<T>::CPL;
     // (complex64: a 16-byte access is two neighbouring columns -- index bit 0 must be a column bit)
-    if (D == 32 && d5_env && ncols % CG == 0 && (sizeof(T) == 8 || sorted.n == 0 || sorted.pos[0] != 0)) {
+    // (k = 6 in complex128: the operands of 32 rows x 16 columns do not fit the registers -- the LDS-staged kernel stays)
+    if ((D == 32 || (D == 64 && sizeof(T) == 4)) && d5_env && ncols % CG == 0 && (sizeof(T) == 8 || sorted.n == 0 || sorted.pos[0] != 0)) {
         const uint64_t ngroups = ncols / CG;
-        const unsigned blocks = (unsigned)std::min<uint64_t>((ngroups + 3) / 4, 256ull * 12ull);
+        static const int blk_env = [] { const char* e = getenv("DQ_DENSE5_BLOCKS"); return e ? atoi(e) : 0; }();
+        // = the resident workgroups: every wave loops over its share of the column groups
+        const uint64_t resident = 256ull * (sizeof(T) == 4 && D == 32 ? 3ull : 2ull);
+        const uint64_t per_wg = D == 32 ? 4 : 2;       // column groups a workgroup works on at a time
+        const unsigned blocks = (unsigned)std::min<uint64_t>((ngroups + per_wg - 1) / per_wg, blk_env > 0 ? (uint64_t)blk_env : resident);
         dim3 grid(blocks, gz);
-        if (nt) hipLaunchKernelGGL((apply_dense5_kernel<T, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ngroups, shift);
-        else hipLaunchKernelGGL((apply_dense5_kernel<T, false>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ngroups, shift);
+        if (D == 32) {
+            if (nt) hipLaunchKernelGGL((apply_dense56_kernel<T, 5, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ngroups, shift);
+            else hipLaunchKernelGGL((apply_dense56_kernel<T, 5, false>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ngroups, shift);
+        } else {
+            if (nt) hipLaunchKernelGGL((apply_dense56_kernel<T, 6, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ngroups, shift);
+            else hipLaunchKernelGGL((apply_dense56_kernel<T, 6, false>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ngroups, shift);
+        }
     } else if (D == 32) {
         constexpr int TN = 128;
         dim3 grid((unsigned)((ncols + TN - 1) / TN), 1, gz);
