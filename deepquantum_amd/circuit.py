@@ -736,7 +736,9 @@ class DistributedQubitCircuit(QubitCircuit):
             self.encode(data)
         touched = self._precompute_matrices()
         try:
-            self.state = dist_run(self.init_state, self.operators, keep_layout=self.lazy_layout)
+            masks = sorted({ob.pauli_masks()[1] for ob in self.observables if ob.pauli_masks()[0] == 0})
+            ez = masks if (masks and len(masks) <= 64 and executor.CONFIG['fused_expectation']) else None
+            self.state = dist_run(self.init_state, self.operators, keep_layout=self.lazy_layout, expect_z=ez)
         finally:
             for g in touched:
                 g.__dict__['_precomputed'] = None
@@ -799,9 +801,20 @@ class DistributedQubitCircuit(QubitCircuit):
             return torch.stack(out, dim=-1)
         if self.state.batch is not None or not torch.is_grad_enabled():
             # forward-only evaluation (also the only one defined for batched shards)
-            from .distributed import expect_pauli_dist
+            from .distributed import cached_expect_z, expect_pauli_dist
 
-            return torch.stack([expect_pauli_dist(self.state, ob) for ob in self.observables], dim=-1)
+            ez = cached_expect_z(self.state)           # Z-type strings: reduced by the forward's last pass (DQ_FG_EXPZ)
+            out = []
+            for ob in self.observables:
+                xm, zm = ob.pauli_masks()
+                if ez is not None and xm == 0 and zm in ez['masks']:
+                    # (`state.amps` would restore the canonical shard order -- an exchange -- under lazy_layout)
+                    cdt = self.state._buffers['amps'].dtype
+                    v = ez['values'][:, ez['masks'].index(zm)].to(torch.float64 if cdt == torch.complex128 else torch.float32)
+                    out.append(v[0] if self.state.batch is None else v)
+                else:
+                    out.append(expect_pauli_dist(self.state, ob))
+            return torch.stack(out, dim=-1)
         if not executor.CONFIG['joint_adjoint']:       # the reference's structure: one sweep per observable
             return torch.stack([adjoint_expectation(self.state, self.operators, ob) for ob in self.observables], dim=-1)
         return adjoint_expectations(self.state, self.operators, self.observables)

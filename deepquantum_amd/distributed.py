@@ -211,7 +211,7 @@ def _rows_of(pending: Sequence[Prim], rows: slice, total: int) -> list[Prim]:
 
 
 def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: slice,
-              out_perm: Sequence[int] | None = None) -> bool:
+              out_perm: Sequence[int] | None = None, expect_z: dict | None = None) -> bool:
     """Fused local passes on rows ``rows`` of the shard ``a`` with the receive buffer ``b`` as the second buffer of the
     permuted stores; afterwards local bit q sits at position out_perm[q].  Returns True if the result lives in ``b``."""
     total = a.shape[0]
@@ -220,7 +220,8 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel(),
                            grads=_SWEEP['grads'][rows])
     elif CONFIG['fold_permute'] or out_perm is None:
-        out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel())
+        out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel(),
+                           expect_z=expect_z)
     else:                                         # A/B: the re-labelling as a pass of its own
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y)
         if out.data_ptr() not in (x.data_ptr(), y.data_ptr()):
@@ -234,15 +235,53 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
     return False
 
 
-def _flush(state: DistributedQubitState, pending: list[Prim]) -> None:
+def _flush(state: DistributedQubitState, pending: list[Prim], expect_z: dict | None = None) -> None:
     _settle(state)
     if not pending:
         return
     LAST_RUN['local_flushes'] += 1
     a, b = _view(state), _bview(state)
-    if _run_rows(a, b, pending, slice(0, a.shape[0])):
+    if _run_rows(a, b, pending, slice(0, a.shape[0]), expect_z=expect_z):
         state.amps, state.buffer = state.buffer, state.amps
     pending.clear()
+
+
+def _expect_z_local(state: DistributedQubitState, zmasks: Sequence[int]) -> tuple[dict, list[float]]:
+    """The Z strings ``zmasks`` (logical qubits) as the last local stretch of a circuit sees them: the factors on local
+    bits (masks in physical positions, for executor.run(expect_z=...)) and this rank's sign from the factors on rank bits."""
+    L, ph = state.log_num_amps_per_node, _phys(state)
+    local, signs = [], []
+    for zm in zmasks:
+        pz = sum(1 << ph[q] for q in range(state.nqubit) if (int(zm) >> q) & 1)
+        local.append(pz & ((1 << L) - 1))
+        signs.append(-1.0 if bin((pz >> L) & state.rank).count('1') & 1 else 1.0)
+    return {'masks': local}, signs
+
+
+def _expect_z_finish(state: DistributedQubitState, zmasks: Sequence[int], holder: dict | None, signs: list[float] | None) -> None:
+    """Every rank adds what its last pass reduced (times its sign) -- or says that it reduced nothing, in which case all
+    ranks drop the values alike (a rank whose last stretch was empty, or did not run on the wave-tile kernel) -- and the
+    sums are cached on the state for ``expectation()``: <Z..Z> of a sharded circuit without another read of the shards."""
+    rows = _view(state).shape[0]
+    k = len(zmasks)
+    buf = torch.zeros(rows, k + 1, dtype=torch.float64, device=state.amps.device)
+    if holder is not None and holder.get('values') is not None:
+        buf[:, :k] = holder['values'] * torch.tensor(signs, dtype=torch.float64, device=buf.device)
+        buf[:, k] = 1.0
+    if state.world_size > 1 and dist.is_initialized():
+        dist.all_reduce(buf, dist.ReduceOp.SUM)
+    # (whether every rank contributed is a number on the device: `expectation()` looks at it -- no host sync in the forward)
+    state.__dict__['_expz'] = {'masks': [int(z) for z in zmasks], 'values': buf[:, :k], 'ranks': buf[0, k]}
+
+
+def cached_expect_z(state: DistributedQubitState) -> dict | None:
+    """The Z-string values the last circuit's final pass left on the state, if every rank took part."""
+    ez = state.__dict__.get('_expz')
+    if ez is None:
+        return None
+    if 'ok' not in ez:
+        ez['ok'] = float(ez['ranks']) == state.world_size
+    return ez if ez['ok'] else None
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -657,16 +696,18 @@ def _canonicalize(state: DistributedQubitState) -> DistributedQubitState:
 # ---------------------------------------------------------------------------------------------------
 # public entry points
 def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None = None,
-                     keep_layout: bool = False, force_mode: bool = False) -> DistributedQubitState:
+                     keep_layout: bool = False, force_mode: bool = False,
+                     expect_z: Sequence[int] | None = None) -> DistributedQubitState:
     """Apply kernel primitives (logical bit positions) to the sharded state, fusing local stretches.
     Unless ``keep_layout`` is set the canonical qubit order is restored before returning.  ``force_mode``: ``mode`` also
     for short gate lists (which otherwise go gate by gate, pairwise exchanges)."""
     with _raw(state):
-        return _dist_apply_prims(state, prims, mode, keep_layout, force_mode)
+        return _dist_apply_prims(state, prims, mode, keep_layout, force_mode, expect_z)
 
 
 def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None, keep_layout: bool,
-                      force_mode: bool = False) -> DistributedQubitState:
+                      force_mode: bool = False, expect_z: Sequence[int] | None = None) -> DistributedQubitState:
+    state.__dict__.pop('_expz', None)        # (cached expectation values belong to the state as it was)
     for k in LAST_RUN:
         LAST_RUN[k] = 0
     mode = mode or CONFIG['mode']
@@ -694,8 +735,16 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
             i += 1
         else:
             _remap_for(state, prims, i, pending)     # local gates so far + exchange; then gate i under the new layout
-    _flush(state, pending)
-    _settle(state)
+    if expect_z:
+        # the Z-type observables of the circuit: reduced from the registers of the last local pass (DQ_FG_EXPZ)
+        holder, signs = _expect_z_local(state, expect_z)
+        had = bool(pending)
+        _flush(state, pending, holder)
+        _settle(state)
+        _expect_z_finish(state, expect_z, holder if had else None, signs)
+    else:
+        _flush(state, pending)
+        _settle(state)
     if not keep_layout:
         canonicalize(state)
     return state
@@ -708,14 +757,15 @@ def dist_gate(state: DistributedQubitState, gate) -> DistributedQubitState:
         return dist_apply_prims(state, gate.prims(decompose=True))
 
 
-def dist_run(state: DistributedQubitState, operators, keep_layout: bool = False) -> DistributedQubitState:
+def dist_run(state: DistributedQubitState, operators, keep_layout: bool = False,
+             expect_z: Sequence[int] | None = None) -> DistributedQubitState:
     """Whole circuit on the sharded state (reference: circuit.py:1655-1675).  ``keep_layout``: the qubits stay where
     the last remap put them; ``state.amps`` restores the reference's order when somebody reads it."""
     prims: list[Prim] = []
     for op in operators:
         prims.extend(op.prims(decompose=True))
     with torch.no_grad():
-        return dist_apply_prims(state, prims, keep_layout=keep_layout)
+        return dist_apply_prims(state, prims, keep_layout=keep_layout, expect_z=expect_z)
 
 
 def dist_swap_gate(state: DistributedQubitState, qb1: int, qb2: int) -> DistributedQubitState:

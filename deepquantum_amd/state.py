@@ -130,6 +130,7 @@ class DistributedQubitState(_ComplexBuffers):
 
     def reset(self) -> None:
         self.__dict__.pop('_phys', None)   # canonical qubit order (first: ``amps`` below must not trigger an exchange)
+        self.__dict__.pop('_expz', None)   # (expectation values cached by a circuit's last pass)
         if tuple(self.amps.shape) != tuple(self._shape):
             self.amps = torch.zeros(self._shape, dtype=self.amps.dtype, device=self.amps.device)
             self.buffer = torch.zeros_like(self.amps)

@@ -385,9 +385,21 @@ def _case_folded_permute_w2(dq, rank, world):
             # (complex64: the dense circuit's Z values come out of its last pass in float64, the shards' from the float32
             # reductions of the test double -- up to 7e-6 apart on <Z0> = 0)
             assert (ev3 - ref_ev[:, :3]).abs().max().item() < 3e-5
+            # (the three Z strings were reduced by the forward's last local pass, DQ_FG_EXPZ, signs of the rank bits and an
+            # all-reduce included: `expectation` takes them from the cache, the 'xz' string from the shards)
+            assert D.cached_expect_z(st) is not None and len(D.cached_expect_z(st)['masks']) == 3
             with torch.no_grad():
                 ev = shard.expectation()
             assert (ev - ref_ev).abs().max().item() < 3e-5
+            dq.executor.CONFIG['fused_expectation'] = False
+            try:
+                st2 = shard(data)
+                assert D.cached_expect_z(st2) is None
+                with torch.no_grad():
+                    assert (shard.expectation() - ev).abs().max().item() < 3e-5
+            finally:
+                dq.executor.CONFIG['fused_expectation'] = True
+            st = shard(data)
             err = (st.amps - ref[:, rank * per : (rank + 1) * per]).abs().max().item()
             assert D._is_canonical(st)
             assert err < 1e-5, f'rank {rank} fold={fold} groups={groups} reorder={reorder}: {err}'
