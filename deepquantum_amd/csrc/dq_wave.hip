@@ -113,9 +113,8 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
                                                         const vec2<typename W::real>* mats, int64_t mat_bstride,
                                                         int64_t in_bstride, int n, int tpw_flags, const WaveKernPass p,
                                                         double* grads, int64_t grad_bstride) {
-    const int tpw = tpw_flags & 0xffff;
-    // bit 0 / 1: streaming loads / stores (see wave_launch); a pass whose samples share ONE input keeps it in the L2
-    const unsigned flags = in_bstride == 0 ? ((unsigned)tpw_flags >> 16) & ~1u : (unsigned)tpw_flags >> 16;
+    (void)tpw_flags;      // (low byte: log2 of the tiles a wave walks; bits 16, 17: streaming loads / stores)
+    (void)in, (void)out, (void)mats, (void)mat_bstride;
     extern __shared__ __attribute__((aligned(16))) unsigned char dq_wave_smem[];
     (void)dq_wave_smem;
     const unsigned tid = threadIdx.x;
@@ -134,17 +133,27 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
         sample = r >> 3;
         grp = group * 8u + (r & 7u);
     }
-  for (int t = 0; t < (GRAD ? tpw : 1); ++t) {
-    const uint64_t tile_id = GRAD ? ((uint64_t)grp * 4u + wave) * (uint64_t)tpw + (uint64_t)t : (uint64_t)grp * 4u + wave;
-    if (tile_id >= (1ull << (n - W::M))) {
-        if constexpr (GRAD) break;
-        else return;
-    }
+  // a wave walks `tpw` tiles: its next loads leave right behind its stores (no launch gap, no prologue in between).  The
+  // tiles of one wave lie a whole grid apart, so that the tiles in flight at any time stay neighbours (write locality)
+  // (tpw is a power of two and the grid ceil(tiles / (4 tpw)) workgroups: stride and count are re-derived per tile from the
+  // kernel arguments instead of living in SGPRs across the assembly)
+  uint32_t tile32 = grp * 4u + wave;
+  for (;;) {      // (ends by the tile count: after `tpw` strides the number is past it)
+    const uint64_t tile_id = tile32;
     // where the tile lies: bit j of the tile number goes to index bit read_blk_pos[j] / store_blk_pos[j] (the descriptor
     // is read as words through the constant address space: scalar loads, constant byte positions)
     typedef const __attribute__((address_space(4))) uint32_t* KWords;
-    const uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    // (laundered: what the tile needs from the descriptor is re-read per tile -- hoisted out of the tile loop it would stay
+    // live across the assembly, which owns s40..s99: 50 SGPR spills and a 169th VGPR, i.e. two waves per SIMD instead of three)
+    asm volatile("" : "+s"(karg));
     const KWords hw = (KWords)(karg + offsetof(WaveKernArgs, p));
+    {
+        const uint32_t a_n0 = ((KWords)karg)[offsetof(WaveKernArgs, n) / 4], a_tf0 = ((KWords)karg)[offsetof(WaveKernArgs, tpw) / 4];
+        const uint32_t ntiles = 1u << (a_n0 - (uint32_t)W::M), lper = 2u + (a_tf0 & 0xffu);     // log2(4 tpw)
+        if (tile32 >= ntiles) break;
+        tile32 += ((ntiles + (1u << lper) - 1u) >> lper) * 4u;        // (for the next round; `tile_id` holds this one's)
+    }
     uint64_t tg = 0, tw = 0;
 #pragma unroll
     for (int w = 0; w < DQ_FUSED_MAX_BLK / 4; ++w) {
@@ -156,10 +165,19 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
             tw |= bit << ((sw >> (8 * k)) & 0x3fu);
         }
     }
-    const uint64_t inb = (uint64_t)(in + (uint64_t)sample * (uint64_t)in_bstride + tg);
-    const uint64_t outb = (uint64_t)(out + ((uint64_t)sample << n) + tw);
-    const uint64_t mb = (uint64_t)(mats + (int64_t)sample * mat_bstride);
-    W::body(karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec), p.nrec_bytes, mb, p.mat_base_bytes, tg,
+    // (the kernel's own arguments too, through the laundered pointer: re-read per tile instead of held across the assembly)
+    typedef const __attribute__((address_space(4))) uint64_t* KQuads;
+    const KQuads kq = (KQuads)karg;
+    const uint64_t a_in = kq[0], a_out = kq[1], a_mats = kq[2], a_mbs = kq[3], a_ibs = kq[4];
+    const uint32_t a_n = ((KWords)karg)[offsetof(WaveKernArgs, n) / 4], a_tf = ((KWords)karg)[offsetof(WaveKernArgs, tpw) / 4];
+    constexpr uint64_t ES = W::ELEM;
+    const uint64_t inb = a_in + ((uint64_t)sample * a_ibs + tg) * ES;
+    const uint64_t outb = a_out + (((uint64_t)sample << a_n) + tw) * ES;
+    const uint64_t mb = a_mats + (uint64_t)((int64_t)sample * (int64_t)a_mbs) * ES;
+    // bit 0 / 1: streaming loads / stores (see wave_launch); a pass whose samples share ONE input keeps it in the L2
+    const unsigned flags = a_ibs == 0 ? (a_tf >> 16) & ~1u : a_tf >> 16;
+    W::body(karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec), hw[offsetof(WaveKernPass, nrec_bytes) / 4], mb,
+            hw[offsetof(WaveKernPass, mat_base_bytes) / 4], tg,
             karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, load_off), inb, outb, wave * W::LDS_PER_WAVE, tid,
             flags);
   }
@@ -517,8 +535,12 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
     if (rc) return rc;
     const uint64_t tiles = 1ull << (n - W::M);
     int tpw = 1;
-    if (GRAD)       // tiles per wave: as many as leave >= 2048 workgroups per sample batch
+    if (GRAD) {     // tiles per wave: as many as leave >= 2048 workgroups per sample batch
         while (tpw < 64 && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
+    } else {
+        static const int tpw_env = [] { const char* e = getenv("DQ_WAVE_TPW"); return e ? atoi(e) : 1; }();
+        while (tpw < tpw_env && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
+    }
     dim3 grid((unsigned)((tiles + 4ull * tpw - 1) / (4ull * tpw)), (unsigned)batch);
     size_t lds = 4 * W::LDS_PER_WAVE + (GRAD ? WAVE_MAX_REC * 8 * sizeof(typename W::acc_t) : 0);
     if (const char* kb = getenv("DQ_WAVE_LDS_KB")) {      // occupancy experiments: workgroups per CU = 160 KiB / this
@@ -533,7 +555,7 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
     const int nt = nt_env >= 0 ? nt_env : (state_bytes >= (1ull << 30) ? 3 : 0);
     using V = vec2<typename W::real>;
     hipLaunchKernelGGL((wave_pass_kernel<W, GRAD>), grid, dim3(256), lds, s, static_cast<const V*>(in), static_cast<V*>(out),
-                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, tpw | (nt << 16), kp, grads, ngrads * 8);
+                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, (31 - __builtin_clz((unsigned)tpw)) | (nt << 16), kp, grads, ngrads * 8);
     return check_launch("dq_apply_fused (wave tile)");
 }
 
