@@ -95,8 +95,14 @@ __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int D = 1 << g.k;
-    const int row0 = blockIdx.y * TM;
-    const uint64_t col0 = (uint64_t)blockIdx.x * TN;
+    // col_sample_shift bit 30 (host flag): row tiles vary fastest in dispatch order -- the workgroups that share a column
+    // tile of X run back to back (X is then read from HBM once and from the caches otherwise; U lives in the Infinity Cache)
+    const bool rows_fast = (col_sample_shift & 0x40000000) != 0 && col_sample_shift >= 0;
+    if (col_sample_shift >= 0) col_sample_shift &= 0x3fffffff;
+    const unsigned nrt = (unsigned)((1u << g.k) / TM);
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int row0 = (rows_fast ? (int)(lin % nrt) : (int)blockIdx.y) * TM;
+    const uint64_t col0 = (uint64_t)(rows_fast ? lin / nrt : blockIdx.x) * TN;
     const int64_t zb = blockIdx.z;                  // sample (when every sample has its own matrix)
     const cx<T>* U = mats + zb * mat_bstride;
 
@@ -370,8 +376,10 @@ int apply_dense_mfma(const cx<T>* in, cx<T>* out, const cx<T>* mats, int64_t mat
     } else {
         constexpr int TN = 64;
         dim3 grid((unsigned)((ncols + TN - 1) / TN), (unsigned)(D / 64), gz);
-        if (nt) hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
-        else hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2, false>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
+        static const int rf_env = [] { const char* e = getenv("DQ_DENSE_ROWS_FAST"); return e ? atoi(e) : 1; }();
+        const int shift2 = (rf_env && shift >= 0) ? (shift | 0x40000000) : shift;
+        if (nt) hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift2);
+        else hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2, false>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift2);
     }
     (void)controls;
     return DQ_OK;

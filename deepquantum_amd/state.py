@@ -124,6 +124,23 @@ class DistributedQubitState(_ComplexBuffers):
                 canonicalize(self)
         return super().__getattr__(name)
 
+    def __deepcopy__(self, memo):
+        # a copy is a state of its own: exchanges in flight on the group streams are joined first (the copy kernels run
+        # on the current stream), and the bookkeeping of whoever holds the original open (`_raw` nesting, cached
+        # expectation values, stream hand-offs) is not inherited
+        from copy import deepcopy
+
+        from .distributed import _settle
+
+        _settle(self)
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for key, value in self.__dict__.items():
+            if key in ('_raw', '_inflight', '_inflight_keep', '_expz', '_building'):
+                continue
+            new.__dict__[key] = deepcopy(value, memo)
+        return new
+
     def state_dict(self, *args, **kwargs):
         _ = self.amps          # (a saved shard is in the reference's qubit order)
         return super().state_dict(*args, **kwargs)
