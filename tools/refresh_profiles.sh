@@ -33,5 +33,12 @@ bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
   echo "# the one-GPU anchor of the strong-scaling pair (SURVEY 8d): n = 31, batch 1"
   python bench.py --strong --steps 3 --warmup 1 --no-cpu-baseline --no-sweep 2>/dev/null
 } > "$root/secondary_benchmarks.txt" 2>&1
+{
+  for a in "" "--strong" "--config 4" "--config 5" "--batch-shard"; do
+    echo "# bench_two_ranks_one_gpu.sh --nqubit 24 --depth 10 --batch 4 $a (gloo, two ranks sharing one GPU: functional check, not a performance number)"
+    bash tools/bench_two_ranks_one_gpu.sh --nqubit 24 --depth 10 --batch 4 --no-cpu-baseline --no-sweep $a 2>&1 | tail -1
+  done
+} > "$root/two_ranks_one_gpu_functional.txt" 2>&1
+python tools/bench_dense.py 2>&1 | grep -v amdgpu.ids > "$root/bench_dense.txt"
 python tools/crosscheck_large.py 2>&1 | grep -v amdgpu.ids > "$root/crosscheck_large.txt"
 ls -la "$root"
