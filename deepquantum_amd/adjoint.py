@@ -125,7 +125,7 @@ def _sweep_fused_sharded(ctx, grad_out, params):
     if not todo:
         return [None] * len(slots)
     ops = [fusion.PrimOp(q.kind, q.targets, q.controls, 0, q.mode) for q in prims]
-    if is128 and not (geom.wave and fusion.wave_supports(ops)):
+    if is128 and not (geom.wave and fusion.wave_supports(ops, is128)):
         return None
     if any(len(q.targets) > 2 for q in prims):
         return None

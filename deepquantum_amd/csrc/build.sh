@@ -21,7 +21,13 @@ for s in "${srcs[@]}"; do
     pids+=($!)
   fi
 done
-for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+for p in "${pids[@]:-}"; do
+  if [[ -n "$p" ]] && ! wait "$p"; then
+    grep -B2 -A3 "error" "${here}/build/dq_wave.usage" 2>/dev/null | head -40 >&2
+    echo "build failed" >&2
+    exit 1
+  fi
+done
 # The wave-tile kernels are built for three waves per SIMD: 168 VGPRs, nothing spilled.  One SGPR too many held across
 # the assembly spills into a 169th VGPR and silently costs a third of the occupancy (8 % of the headline, measured).
 if [[ -f "${here}/build/dq_wave.usage" ]]; then

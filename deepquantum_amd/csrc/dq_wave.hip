@@ -46,7 +46,7 @@ struct WaveC64 {
     static constexpr unsigned LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID_GEN_U, ID_GEN_C = DQ_WID_GEN_C, ID_GEN_R = DQ_WID_GEN_R, ID_X_U = DQ_WID_X_U,
                          ID_X_C = DQ_WID_X_C, ID_X_R = DQ_WID_X_R, ID_X_R1 = DQ_WID_X_R1, ID_TRIP0 = DQ_WID_TRIP0,
-                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2, ID_GRAD = DQ_WID_GRAD, ID_EXPZ = DQ_WID_EXPZ;
+                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2, ID_GRAD = DQ_WID_GRAD, ID_EXPZ = DQ_WID_EXPZ, ID_GEN2 = DQ_WID_GEN2, ID_SWAP = DQ_WID_SWAP;
     static int trip_id(unsigned mask) { return kWaveTripId[mask]; }
     static int swap_id(int i, int j) { return kWaveSwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -61,7 +61,7 @@ struct WaveC128 {
     static constexpr unsigned LDS_PER_WAVE = 8704;      // (7 * 68 + 64) * 16 bytes: the k = 3 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID64_GEN_U, ID_GEN_C = DQ_WID64_GEN_C, ID_GEN_R = DQ_WID64_GEN_R, ID_X_U = DQ_WID64_X_U,
                          ID_X_C = DQ_WID64_X_C, ID_X_R = DQ_WID64_X_R, ID_X_R1 = DQ_WID64_X_R1, ID_TRIP0 = DQ_WID64_TRIP0,
-                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD, ID_EXPZ = DQ_WID64_EXPZ;
+                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD, ID_EXPZ = DQ_WID64_EXPZ, ID_GEN2 = -1, ID_SWAP = DQ_WID64_SWAP;      // (no two-target dense gates: 64 dwords of matrix)
     static int trip_id(unsigned mask) { return kWave64TripId[mask]; }
     static int swap_id(int i, int j) { return kWave64SwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -370,6 +370,28 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
         if (!x.go(want, nullptr)) goto fail;
         for (int gi = rd.gate_begin & 0x7f; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
+            if (g.kind == DQ_FG_GEN2 && W::ID_GEN2 >= 0) {
+                // dense gate on two slots: the handler of the slot pair a < b reads the matrix index as 2 * bit(b) + bit(a);
+                // a first target on the lower slot makes the kernel swap the two index bits of the matrix (w6)
+                const int q1 = x.slot_of(rd.rb[g.q]), q2 = x.slot_of(rd.rb[g.q2]);
+                const int a = q1 < q2 ? q1 : q2, b = q1 < q2 ? q2 : q1;
+                unsigned pc = 0;
+                for (int s = 0; s < W::R; ++s)
+                    if ((g.reg_cmask >> s) & 1u) pc |= 1u << x.slot_of(rd.rb[s]);
+                WaveRec rec{};
+                rec.w[0] = (uint32_t)(W::ID_GEN2 + (W::swap_id(a, b) - W::ID_SWAP));
+                rec.w[1] = g.thr_cmask;
+                rec.w[2] = (uint32_t)g.out_cmask, rec.w[3] = (uint32_t)(g.out_cmask >> 32);
+                rec.w[4] = g.mat_advance;
+                for (int j = 0, i = 0; j < W::NA; ++j) {         // group i = the i-th pattern with bits a and b clear
+                    if (((j >> a) & 1) || ((j >> b) & 1)) continue;
+                    if (((unsigned)j & pc) == pc) rec.w[5] |= 1u << i;
+                    ++i;
+                }
+                rec.w[6] = q1 == a ? 1u : 0u;
+                if (!x.push(rec)) goto fail;
+                continue;
+            }
             if (g.kind == DQ_FG_EXPZ) {
                 // <Z..Z> from the registers: the sign of a register from the Z bits that are register slots right now
                 unsigned pm = 0;
@@ -415,7 +437,7 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
                 continue;
             }
             if (g.kind != DQ_FG_GEN1 && g.kind != DQ_FG_X1 && g.kind != DQ_FG_DIAG1 && g.kind != DQ_FG_DIAG2) {
-                set_error("dq_apply_fused: the wave-tile kernel takes one-target and diagonal gates (record %d has kind %d); "
+                set_error("dq_apply_fused: the wave-tile kernel takes one-target and diagonal gates (and, in complex64, dense gates on two targets; record %d has kind %d); "
                           "plan this circuit for a workgroup-tile geometry", gi, (int)g.kind);
                 return DQ_ERR_UNSUPPORTED;
             }

@@ -151,7 +151,7 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     takes long enough (>= 0.1 s) for a wider search of the pass planner to pay for itself within a few steps
     (measured on the headline: 21 -> 20 passes, -2.7 %, 4.6 s of planning once per circuit structure)."""
     geom = _geometry(is128)
-    if geom.wave and not fusion.wave_supports(prims):
+    if geom.wave and not fusion.wave_supports(prims, is128):
         geom = _geometry(is128, wave=False)
     if amps >= CONFIG['plan_big_amps']:
         for g_ in (geom, geom.fallback):
@@ -268,7 +268,7 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
         is128 = state.dtype == torch.complex128
         g_ = _geometry(is128)
         ops_ = [fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), 0, p.mode) for p in prims]
-        if (g_.wave and n >= g_.m and len(prims) > 0 and fusion.wave_supports(ops_) and not ops._is_batched(state)
+        if (g_.wave and n >= g_.m and len(prims) > 0 and fusion.wave_supports(ops_, is128) and not ops._is_batched(state)
                 and state.shape[0] <= backend.MAX_BATCH):
             every = tuple(range(n))
             extra = [Prim('expz', None, (), tuple(q for q in range(n) if (int(z) >> q) & 1), r, order=every)
@@ -427,7 +427,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
             return _permute_after(state, out_perm, scratch)
         if grads is not None:
             assert n >= m and CONFIG['fuse'], 'the fused reverse sweep needs a state of at least one tile'
-            assert not is128 or (g_.wave and fusion.wave_supports(prims)), \
+            assert not is128 or (g_.wave and fusion.wave_supports(prims, is128)), \
                 'complex128 reverse sweeps run on the wave-tile kernel only (one-target and diagonal gates)'
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):

@@ -108,10 +108,12 @@ def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = No
     return workgroup_geometry(is_c128, m, slots)
 
 
-def wave_supports(ops: Sequence['PrimOp']) -> bool:
+def wave_supports(ops: Sequence['PrimOp'], is128: bool = False) -> bool:
     """Can the wave-tile kernel run all of ``ops``?  (One-target dense gates and X, diagonal gates on one or two
-    targets, any controls, the reductions of the reverse sweep.)"""
+    targets, any controls, the reductions; in complex64 also dense gates on two targets -- the 4x4 matrix of a
+    complex128 one does not fit the scalar registers.)"""
     return all((op.kind in ('gen', 'x') and len(op.targets) == 1) or (op.kind == 'diag' and len(op.targets) <= 2)
+               or (op.kind == 'gen' and len(op.targets) == 2 and not is128)
                or op.kind in ('grad', 'expz') for op in ops)
 
 

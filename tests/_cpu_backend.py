@@ -173,7 +173,7 @@ class CpuTestBackend:
                 for gi in range(first + nswap, rd.gate_end):
                     g = desc.gates[gi]
                     assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
-                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1, _lib.FG_DIAG1, _lib.FG_DIAG2, _lib.FG_GRAD, _lib.FG_EXPZ), 'the wave-tile kernel takes one-target and diagonal gates only'
+                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1, _lib.FG_DIAG1, _lib.FG_DIAG2, _lib.FG_GRAD, _lib.FG_EXPZ) or (g.kind == _lib.FG_GEN2 and not is128), 'the wave-tile kernel takes one-target and diagonal gates (complex64: two-target dense ones too)'
                     assert (g.reg_cmask >> R) == 0
                     cm = g.thr_cmask
                     for s in range(R):

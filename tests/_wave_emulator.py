@@ -215,6 +215,23 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None):
                     continue
                 if not tile_ok:
                     continue
+                if getattr(g, 'ID_GEN2', 1 << 30) <= hid < getattr(g, 'ID_GEN2', 1 << 30) + 15:
+                    # dense gate on two slots a < b (gen2_code): matrix index = 2 * bit(b) + bit(a), w6 = swap the two
+                    # index bits of the matrix first, w5 = group mask
+                    a_, b_ = g.SWAP_PAIRS[hid - g.ID_GEN2]
+                    m4 = mb[moff - 16:moff].reshape(4, 4)
+                    if w[6]:
+                        perm = [0, 2, 1, 3]
+                        m4 = m4[perm][:, perm]
+                    for gi, j in enumerate(g.gen2_groups(a_, b_)):
+                        if not (w[5] >> gi) & 1:
+                            continue
+                        regs = [j | (((r >> 1) & 1) << b_) | ((r & 1) << a_) for r in range(4)]
+                        old = [a[:, r].copy() for r in regs]
+                        for r in range(4):
+                            new = sum(m4[r, c].astype(a.dtype) * old[c] for c in range(4))
+                            a[active, regs[r]] = new[active]
+                    continue
                 if getattr(g, 'ID_GRAD', 1 << 30) <= hid < getattr(g, 'ID_GRAD', 1 << 30) + 5:
                     # reduction of the reverse sweep (gen_wave_asm.py, grad_code): target slot q, psi / lambda on slot 0
                     q = 1 + hid - g.ID_GRAD

@@ -115,14 +115,15 @@ def test_trips_cover_every_slot_mask_and_stay_inside_the_buffer():
 
 
 def test_unsupported_records_are_refused(cpu_backend):
+    # (complex128: the 4x4 matrix of a two-target dense gate does not fit the scalar registers)
     ops = [fusion.PrimOp('gen', (3,), (), 0, 0), fusion.PrimOp('gen', (5, 7), (), 4, 0)]
-    geom = fusion.default_geometry(False)
+    geom = fusion.default_geometry(True)
     steps = fusion.schedule(ops, 13, geom)
     lib = _lib.load()
     import ctypes as C
     rc = lib.dq_wave_descriptor(C.byref(steps[0].desc), 13, None, 0)
     assert rc == -3 and b'one-target and diagonal' in lib.dq_last_error()
-    assert not fusion.wave_supports(ops) and fusion.wave_supports(ops[:1])
+    assert not fusion.wave_supports(ops, True) and fusion.wave_supports(ops[:1], True) and fusion.wave_supports(ops, False)
     assert fusion.wave_supports([fusion.PrimOp('diag', (5, 2), (1,), 0, 0)])
 
 
@@ -200,3 +201,33 @@ def test_z_string_expectations_from_the_registers(cpu_backend, n, seed, is128):
         assert np.abs(acc_d[:, r, 0].numpy() - want).max() < tol, (r, acc_d[:, r, 0], want)
         assert np.abs(acc_e[:, r, 0] - want).max() < tol, (r, acc_e[:, r, 0], want)
     assert float(acc_d[:, :, 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('n,seed', [(12, 0), (13, 1), (15, 2)])
+def test_two_target_dense_gates_on_the_wave_tile_kernel(cpu_backend, n, seed):
+    """complex64: dense 4x4 gates on two register slots (any target order, register / thread / outside controls) among the
+    other records -- the library's translation executed by the emulator, the descriptor interpreter and the oracle."""
+    from test_fusion_cpu import random_ops as mixed_ops, run_reference
+
+    ops, mats = mixed_ops(n, 60, seed, kinds=('gen', 'x', 'diag', 'gen2', 'gen2', 'diag2'))
+    mats = mats.to(torch.complex64)
+    assert fusion.wave_supports(ops, False) and any(op.kind == 'gen' and op.k == 2 for op in ops)
+    geom = fusion.default_geometry(False)
+    geom.plan_min_bits = 12
+    steps = fusion.schedule(ops, n, geom)
+    assert all(isinstance(s, fusion.FusedStep) and s.desc.slots == 6 for s in steps)
+    km = fusion.kernel_matrices(steps, ops, mats)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 1 << n, generator=g, dtype=torch.float64)
+    x = (x / x.norm(dim=-1, keepdim=True)).to(torch.complex64)
+    ref = run_reference(x, ops, mats)
+    cur_d, cur_e = x.clone(), x.numpy().copy()
+    ngen2 = 0
+    for st in steps:
+        backend.apply_fused(cur_d, km, 0, st.desc, out=cur_d)
+        cur_e = emu.run_pass(st.desc, n, cur_e, km.numpy(), 0)
+        kp = emu.descriptor(st.desc, n)
+        ngen2 += sum(emu.gen().ID_GEN2 <= kp.rec[i][0] < emu.gen().ID_GEN2 + 15 for i in range(kp.nrec_bytes // 32))
+    assert ngen2 == sum(op.kind == 'gen' and op.k == 2 for op in ops)
+    assert (cur_d - ref).abs().max().item() < 1e-5
+    assert np.abs(cur_e - ref.numpy()).max() < 1e-5

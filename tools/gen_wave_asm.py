@@ -200,7 +200,9 @@ ID_DIAG2 = ID_DIAG1 + 14
 ID_GRAD = ID_DIAG2 + 14
 # expectation value of a Z string, reduced from the registers (DQ_FG_EXPZ): same accumulators as the reductions above
 ID_EXPZ = ID_GRAD + 5
-NIDS = ID_EXPZ + 1
+# dense gate on two register slots a < b (index in SWAP_PAIRS): a 4x4 matrix, index = 2 * (bit of slot b) + (bit of slot a)
+ID_GEN2 = ID_EXPZ + 1
+NIDS = ID_GEN2 + 15
 ACC_BASE = 4 * 8448       # LDS offset of the reduction accumulators: behind the four waves' staging buffers
 
 
@@ -351,6 +353,76 @@ def grad_code(q):
     return t
 
 
+G2ROW = [88, 40, 80, 72]         # SGPR base of matrix row r (eight dwords: four complex entries)
+
+
+def far_next():
+    """Back to the loop head from code that lies out of the reach of s_branch."""
+    return ['s_sub_u32 vcc_lo, s54, .Ltable_%=-.Lnext_%=', 's_subb_u32 vcc_hi, s55, 0', 's_setpc_b64 vcc']
+
+
+def gen2_groups(a, b):
+    return [j for j in range(NA) if not (j >> a) & 1 and not (j >> b) & 1]
+
+
+def gen2_body(a, b):
+    """out[r] = sum_c M[r][c] in[c] on every group of four registers (r, c = 2 * bit b + bit a), groups by the mask."""
+    out_ = []
+    T = [T0, U0, T1, U1]
+    for i, j in enumerate(gen2_groups(a, b)):
+        rg = [A(j | (((r >> 1) & 1) << b) | ((r & 1) << a)) for r in range(4)]
+        m = lambda r, c: f's[{G2ROW[r] + 2 * c}:{G2ROW[r] + 2 * c + 1}]'      # noqa: E731
+        out_ += [f's_bitcmp1_b32 {STMP}, {i}', f's_cbranch_scc0 .Lg2s{a}{b}_{i}_%=']
+        out_ += [f'v_pk_mul_f32 {T[r]}, {rg[0]}, {m(r, 0)} {RE2}' for r in range(4)]
+        out_ += [f'v_pk_fma_f32 {T[r]}, {rg[0]}, {m(r, 0)}, {T[r]} {I3}' for r in range(4)]
+        for c in range(1, 4):
+            out_ += [f'v_pk_fma_f32 {T[r]}, {rg[c]}, {m(r, c)}, {T[r]} {RE3}' for r in range(4)]
+            out_ += [f'v_pk_fma_f32 {T[r]}, {rg[c]}, {m(r, c)}, {T[r]} {I3}' for r in range(4)]
+        out_ += [f'v_mov_b64 {rg[r]}, {T[r]}' for r in range(4)]
+        out_.append(f'.Lg2s{a}{b}_{i}_%=:')
+    return out_
+
+
+def gen2_code():
+    """Entry of every two-target dense record: controls; group mask -> STMP, first-target-on-the-lower-slot flag -> s70,
+    pair number -> s71; rows 1 .. 3 of the 4x4 matrix (the look-ahead fetched row 0 as "the matrix") into s[40:47],
+    s[80:87], s[72:79] -- the record itself and both look-ahead registers, fetched again afterwards; with the flag the
+    two matrix index bits trade places (rows 1 <-> 2 by loading them crosswise, columns 1 <-> 2 by twelve s_mov); then
+    the body of the slot pair through a second jump table (computed: the bodies lie out of the reach of s_branch)."""
+    t = ['.Lgen2_%=:', 's_waitcnt lgkmcnt(0)',
+         f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc1 .Lg2in_%='] + far_next()
+    t += ['.Lg2in_%=:', f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
+          's_cbranch_execnz .Lg2go_%=', f's_mov_b64 exec, {SAVE}'] + far_next()
+    t += ['.Lg2go_%=:', f's_mov_b32 {STMP}, s{REC + 5}', f's_mov_b32 s70, s{REC + 6}', f's_sub_u32 s71, s{REC}, {ID_GEN2}',
+          f's_sub_u32 s69, {MOFF}, 128', 's_cmp_eq_u32 s70, 0', 's_cbranch_scc0 .Lg2x_%=',
+          f's_add_u32 s69, s69, 32', f's_load_dwordx8 s[40:47], {MB}, s69', f's_add_u32 s69, s69, 32', f's_load_dwordx8 s[80:87], {MB}, s69',
+          's_branch .Lg2r3_%=', '.Lg2x_%=:',
+          f's_add_u32 s69, s69, 32', f's_load_dwordx8 s[80:87], {MB}, s69', f's_add_u32 s69, s69, 32', f's_load_dwordx8 s[40:47], {MB}, s69',
+          '.Lg2r3_%=:', f's_add_u32 s69, s69, 32', f's_load_dwordx8 s[72:79], {MB}, s69', 's_waitcnt lgkmcnt(0)',
+          's_cmp_eq_u32 s70, 0', 's_cbranch_scc1 .Lg2j_%=']
+    for r in range(4):
+        b0 = G2ROW[r]
+        t += [f's_mov_b64 vcc, s[{b0 + 2}:{b0 + 3}]', f's_mov_b64 s[{b0 + 2}:{b0 + 3}], s[{b0 + 4}:{b0 + 5}]', f's_mov_b64 s[{b0 + 4}:{b0 + 5}], vcc']
+    t += ['.Lg2j_%=:', 's_getpc_b64 vcc', '.Lg2anchor_%=:', 's_lshl3_add_u32 vcc_lo, s71, vcc_lo', 's_addc_u32 vcc_hi, vcc_hi, 0',
+          's_add_u32 vcc_lo, vcc_lo, .Lg2table_%=-.Lg2anchor_%=', 's_addc_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc', '.Lg2table_%=:']
+    # eight bytes per entry: s_getpc + 64-bit add + s_setpc would not fit four; a long jump is s_getpc_b64 / s_add / s_setpc:
+    # instead every entry is an s_branch to a trampoline that sits right behind the table, within reach of nothing but it
+    for v in range(15):
+        t += [f's_branch .Lg2t{v}_%=', 's_nop 0']
+    for v, (a, b) in enumerate(SWAP_PAIRS):
+        t += [f'.Lg2t{v}_%=:', 's_getpc_b64 vcc', f'.Lg2ta{v}_%=:', f's_sub_u32 vcc_lo, vcc_lo, .Lg2ta{v}_%=-.Lg2b{v}_%=',
+              's_subb_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc']          # (the bodies lie in front of everything)
+    return t
+
+
+def gen2_bodies():
+    t = []
+    for v, (a, b) in enumerate(SWAP_PAIRS):
+        t += [f'.Lg2b{v}_%=:'] + gen2_body(a, b) + [f's_mov_b64 exec, {SAVE}']
+        t += prefetch(f'g2{v}') + far_next()
+    return t
+
+
 def expz_code():
     """DQ_FG_EXPZ: sum_i (-1)^popc(i & zmask) |a_i|^2 over the tile, added to component 0 of the record's accumulator.
     The parity of an amplitude splits into its register's (w5 / w7: bit j = sign of register j, made by the translator
@@ -417,7 +489,10 @@ def kernel_body():
             out_.append(f's_mov_b64 exec, {SAVE}')
         return out_ + nxt
 
-    text = [f's_mov_b64 {KG}, %[kg]', f's_mov_b32 {GOFF}, 0', f's_mov_b32 {GEND}, %[gend]', f's_mov_b64 {MB}, %[mb]',
+    # the bodies of the two-target dense gates first (74 KB, jumped over; reached and left by computed jumps): behind
+    # everything else they would push the last labels out of the reach of the store walks' s_branch
+    text = ['s_branch .Lstart_%='] + gen2_bodies() + ['.Lstart_%=:']
+    text += [f's_mov_b64 {KG}, %[kg]', f's_mov_b32 {GOFF}, 0', f's_mov_b32 {GEND}, %[gend]', f's_mov_b64 {MB}, %[mb]',
             f's_mov_b32 {MOFF}, %[moff]', f's_mov_b64 {TG}, %[tg]', f's_mov_b32 {LDSB}, %[ldsb]',
             # slot offsets of the load layout; byte shifts of the lane bits (load, store) and what they add to the
             # thread's tile-local base (WaveKernPass::load_off .. tb_contrib)
@@ -455,7 +530,8 @@ def kernel_body():
     text += [f's_lshl2_add_u32 vcc_lo, s{REC}, s54', 's_addc_u32 vcc_hi, s55, 0', 's_setpc_b64 vcc',
              '.Ltable_%=:']
     for i in range(NIDS):
-        text.append(f's_branch .Lh{i}_%=' if i in h else ('s_branch .Ldiag_%=' if i >= ID_DIAG1 else 's_branch .Lnext_%='))
+        text.append(f's_branch .Lh{i}_%=' if i in h else ('s_branch .Lgen2_%=' if i >= ID_GEN2 else
+                                                         's_branch .Ldiag_%=' if i >= ID_DIAG1 else 's_branch .Lnext_%='))
     # ---- epilogue: the pass's deferred factor, then the stores ----
     text += ['.Lexit_%=:', 's_load_dwordx8 s[40:47], %[ks], 40', 's_load_dwordx2 s[48:49], %[ks], 72',
              's_waitcnt lgkmcnt(0)',          # (the slot offsets -- and the LDS reads of a trip that ended the pass)
@@ -471,6 +547,7 @@ def kernel_body():
     text += ['s_bitcmp1_b32 %[flags], 1', 's_cbranch_scc0 .Lstp_%='] + gray_walk('store', '%[outb]', LST, nt=True) + ['s_branch .Ldone_%=', '.Lstp_%=:']
     text += gray_walk('store', '%[outb]', LST)
     text += ['s_branch .Ldone_%=']
+    text += gen2_code()          # (the entry: within reach of the table; the bodies at the far end, reached by computed jumps)
     text += diag_code()
     for i in back:
         text += emit(i)
@@ -483,7 +560,7 @@ out = ['// GENERATED by tools/gen_wave_asm.py -- do not edit by hand.', '// clan
        f'#define DQ_WID_GEN_U {ID_GEN_U}', f'#define DQ_WID_GEN_C {ID_GEN_C}', f'#define DQ_WID_GEN_R {ID_GEN_R}',
        f'#define DQ_WID_X_U {ID_X_U}', f'#define DQ_WID_X_C {ID_X_C}', f'#define DQ_WID_X_R {ID_X_R}', f'#define DQ_WID_X_R1 {ID_X_R1}',
        f'#define DQ_WID_TRIP0 {ID_TRIP0}', f'#define DQ_WID_TRIP {ID_TRIP}', f'#define DQ_WID_SWAP {ID_SWAP}',
-       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WID_EXPZ {ID_EXPZ}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
+       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WID_EXPZ {ID_EXPZ}', f'#define DQ_WID_GEN2 {ID_GEN2}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
        '// trip handler id by slot mask (popcount 1..DQ_WAVE_MAXK), -1 otherwise; slot-swap handler id by (i < j)',
        'static const short kWaveTripId[64] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(64)) + '};',
        'static const short kWaveSwapId[6][6] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
