@@ -105,7 +105,7 @@ typedef enum {
     DQ_FG_GEN1 = 0,  /* general 2x2 on register slot q                       */
     DQ_FG_X1 = 1,    /* Pauli-X / CNOT / Toffoli: swap the pair of slot q     */
     DQ_FG_DIAG1 = 2, /* diagonal 2x2 (Z,S,T,Rz,P,CZ...) target anywhere      */
-    DQ_FG_GEN2 = 3,  /* general 4x4 on register slots q (matrix MSB) and q2   */
+    DQ_FG_GEN2 = 3,  /* general 4x4 on register slots q (matrix MSB) and q2 (wave-tile geometries: complex64 only) */
     DQ_FG_DIAG2 = 4, /* diagonal 4x4 (Rzz...) both targets anywhere           */
     DQ_FG_SWAP = 5,  /* not a gate: in-wave exchange of register slot q with lane bit q2 (0..5) of the thread id --
                         v_permlane32/16_swap for lane bits 5 / 4, DPP row shifts for 3 / 2, DPP quad permutations for
