@@ -16,7 +16,7 @@ ap.add_argument('--n', type=int, default=24)
 ap.add_argument('--depth', type=int, default=20)
 ap.add_argument('--modes', default='adjoint,per_gate')
 ap.add_argument('--dtype', default='c64')
-ap.add_argument('--reps', type=int, default=2)
+ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--no-fused-sweep', action='store_true', help='A/B: the undo-then-reduce reverse sweep')
 args = ap.parse_args()
 
@@ -43,11 +43,16 @@ for mode in args.modes.split(','):
         cir()
         cir.expectation().sum().backward()
 
-    step()
+    for _ in range(3):              # plans, second buffers, the caching allocator's blocks: steady state from here on
+        step()
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
-    for _ in range(args.reps):
+    step()
+    torch.cuda.synchronize()
+    lat = time.perf_counter() - t0      # one step with the device idle before and after: host work exposed
+    t0 = time.perf_counter()
+    for _ in range(args.reps):          # a training loop: steps back to back, the host runs ahead of the device
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.reps
@@ -62,7 +67,7 @@ for mode in args.modes.split(','):
     sb = (8 if args.dtype == 'c64' else 16) * 2**args.n
     sweep = dict(dq.executor.LAST_SWEEP) if mode == 'adjoint' else {}
     print(f'{mode:9s} {sweep} n={args.n} depth={args.depth} ({args.n * args.depth} gates, {nrx} trainable) {args.dtype}: '
-          f'step {dt * 1e3:8.1f} ms (no-grad forward {fwd * 1e3:6.1f} ms), peak {torch.cuda.max_memory_allocated() / sb:6.1f} states '
+          f'step {dt * 1e3:8.1f} ms back to back, {lat * 1e3:6.1f} ms alone (no-grad forward {fwd * 1e3:6.1f} ms), peak {torch.cuda.max_memory_allocated() / sb:6.1f} states '
           f'= {torch.cuda.max_memory_allocated() / 2**30:6.1f} GiB')
     del cir
     torch.cuda.empty_cache()
