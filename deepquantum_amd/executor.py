@@ -34,6 +34,8 @@ class Prim:
     mode: int = 0                  # 2x2 matrix structure known from the gate class: 0 general, 1 real, 2 Rx-like
     unitary: bool = True           # False for channel superoperators: not reversible, per-gate autograd only
     order: tuple[int, ...] = ()    # bits the gate is ordered on without touching them (fusion.PrimOp.order)
+    exact: bool = True             # unitary to the rounding of its precision by construction; False: a user-supplied
+    #                                matrix that passed only the reference's 1e-4 check (UAnyGate)
 
 
 @dataclass
@@ -252,7 +254,7 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
         assert scratch is None and out_perm is None, 'scratch / out_perm are for no-grad runs'
         vmapped = ops._is_batched(state) or any(ops._is_batched(p.matrix) for p in prims)
         if CONFIG['grad_mode'] == 'adjoint' and not vmapped and all(p.unitary for p in prims):
-            meta = tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode) for p in prims)
+            meta = tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode, p.exact) for p in prims)
             return _AdjointCircuit.apply(state, meta, *[p.matrix for p in prims])
         x = state
         for p in prims:
@@ -537,7 +539,7 @@ class _AdjointCircuit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, state, meta, *mats):
-        prims = [Prim(k, m, t, c, mode) for (k, t, c, mode), m in zip(meta, mats, strict=True)]
+        prims = [Prim(k, m, t, c, mode) for (k, t, c, mode, _e), m in zip(meta, mats, strict=True)]
         # the sweep recomputes from `out` gate by gate, so the forward itself may run the merged gate list
         if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']):
             with torch.no_grad():
@@ -557,7 +559,7 @@ class _AdjointCircuit(torch.autograd.Function):
         # Inverses / adjoints of ALL gates in a few vectorised calls (grouped by kind, size and batchness): at
         # launch-bound sizes a handful of tiny kernels per gate would dominate the whole sweep.
         groups: dict = {}
-        for j, ((kind, _t, _c, _mode), m) in enumerate(zip(meta, mats, strict=True)):
+        for j, ((kind, _t, _c, _mode, _e), m) in enumerate(zip(meta, mats, strict=True)):
             u = m if m.ndim == 3 else m.unsqueeze(0)
             groups.setdefault((kind, u.shape[-1], u.shape[0]), []).append((j, u))
         undo: list = [None] * len(mats)       # (2b, D, D): rows [0, b) the inverse, rows [b, 2b) the adjoint
@@ -571,7 +573,8 @@ class _AdjointCircuit(torch.autograd.Function):
             both = torch.cat([inv.expand(-1, b, d, d), us.mH.expand(-1, b, d, d)], dim=1).contiguous()
             for k, (j, _u) in enumerate(members):
                 undo[j] = both[k]
-            if is128 and kind != 'x':     # U^dagger U: what the fused complex128 sweep multiplies lambda by after U^-1
+            # U^dagger U: what the fused sweep multiplies lambda by after U^-1 (complex128; user matrices in any precision)
+            if kind != 'x' and (is128 or any(not meta[j][4] for j, _ in members)):
                 cs = us.mH @ us
                 for k, (j, _u) in enumerate(members):
                     corr[j] = cs[k]
@@ -582,14 +585,15 @@ class _AdjointCircuit(torch.autograd.Function):
         g_ = _geometry(is128)
         # complex128: the wave-tile kernel only (one-target dense / X gates, diagonal gates on one or two targets)
         wave_ok = g_.wave and all((kind in ('gen', 'x') and len(targets) == 1) or (kind == 'diag' and len(targets) <= 2)
-                                  for kind, targets, _c, _m in meta)
+                                  for kind, targets, _c, _m, _e in meta)
         fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and (not is128 or wave_ok) and b <= backend.MAX_BATCH
                  and n + 1 >= (g_.fallback.m if g_.fallback is not None else g_.m)
                  and all(len(meta[j][1]) == 1 for j in range(len(mats)) if need[j]))
         if fused:
             # complex128: a matrix that is not computed from parameters or data may be unitary only to float32 rounding
             # (the reference's fixed matrices are, after .to(torch.double)): the sweep then tells U^-1 from U^dagger
-            inexact = [is128 and j in corr and not need[j] and m.grad_fn is None and not m.requires_grad
+            # -- and a user-supplied matrix (UAnyGate: unitary to 1e-4 is all the reference asks) in any precision
+            inexact = [j in corr and not need[j] and m.grad_fn is None and not m.requires_grad and (is128 or not meta[j][4])
                        for j, m in enumerate(mats)]
             raw, lam = _AdjointCircuit._sweep_fused(out, gy, meta, undo, need, b,
                                                     [m.ndim == 2 or m.shape[0] == 1 for m in mats], corr, inexact)
@@ -643,7 +647,7 @@ class _AdjointCircuit(torch.autograd.Function):
                 waiting.clear()
 
         for j in range(len(meta) - 1, -1, -1):
-            kind, targets, controls, mode = meta[j]
+            kind, targets, controls, mode, _exact = meta[j]
             mine = set(targets) | set(controls)
             if need[j]:
                 # sum lambda (x) conj(psi) reduced to this gate's qubits does not change when BOTH states are
@@ -680,7 +684,7 @@ class _AdjointCircuit(torch.autograd.Function):
         scalars: dict[int, int] = {}      # prim index -> gate, for the gates whose U^dagger U is a scalar != 1
         grad_at: dict[int, int] = {}      # prim index of a reduction -> its row
         for j in range(len(meta) - 1, -1, -1):
-            kind, targets, controls, mode = meta[j]
+            kind, targets, controls, mode, _exact = meta[j]
             t1, c1 = tuple(t + 1 for t in targets), tuple(c + 1 for c in controls)
             if need[j]:
                 rows[j] = len(rows)

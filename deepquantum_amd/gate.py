@@ -713,6 +713,8 @@ class UAnyGate(ArbitraryGate):
         assert unitary.shape[-1] == unitary.shape[-2] == 2 ** len(self.wires)
         eye = torch.eye(unitary.shape[-1], dtype=unitary.dtype, device=unitary.device)
         assert torch.allclose(unitary @ unitary.mH, eye, rtol=1e-5, atol=1e-4), 'Please check the unitary matrix'
+        # the reference accepts 1e-4; the adjoint method's reverse sweep must then tell U^-1 from U^dagger (executor)
+        self._exact_unitary = bool(torch.allclose(unitary @ unitary.mH, eye, rtol=0.0, atol=2e-6))
         self.register_buffer('matrix', unitary)
         self._kind_cache: tuple | None = None
 

@@ -168,7 +168,8 @@ class Gate(Operation):
         """The gate as kernel primitives.  ``decompose=True`` may split permutation gates into
         CNOT-like bit flips (exactly equal results, cheaper in the fused kernel)."""
         mode = self._kernel_mode if len(self.wires) == 1 else 0
-        return [Prim(self._kernel_kind, self.update_matrix(), self._bits(self.wires), self._bits(self.controls), mode)]
+        return [Prim(self._kernel_kind, self.update_matrix(), self._bits(self.wires), self._bits(self.controls), mode,
+                     exact=getattr(self, '_exact_unitary', True))]
 
     def dm_prims(self, decompose: bool = True) -> list[Prim]:
         """The gate acting on a vectorised density matrix (row bits n..2n-1, column bits 0..n-1):

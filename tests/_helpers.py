@@ -714,3 +714,49 @@ def check_fuzz_against_oracle(dq, device=None, n=13, seeds=(0, 1, 2), depth=6, b
         for k, o in enumerate(outs):
             err = (o - ref).abs().max().item()
             assert err < (1e-12 if double else 5e-6), (seed, k, err)
+
+
+def check_fused_sweep_with_sloppy_user_matrices(dq, device=None, n=12, tol=2e-5):
+    """UAnyGate accepts matrices that are unitary to 1e-4 (reference gate.py:2745-2788).  The fused reverse sweep undoes
+    those with the exact inverse and corrects the cotangent by U^dagger U -- with the adjoint standing in for the inverse
+    (fine for matrices that are unitary by construction) ten such gates leave psi 1e-3 off."""
+    import math
+
+    def build():
+        torch.manual_seed(11)
+        g = torch.Generator().manual_seed(12)
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        cir.rylayer()
+        for k in range(10):
+            a = torch.randn(2, 2, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 2, generator=g, dtype=torch.float64)
+            u = (torch.linalg.qr(a)[0] * (1 + 4e-5 * (1 if k % 2 else -1))).to(torch.complex64)
+            cir.any(u, wires=[k % n], controls=[(k + 3) % n] if k % 3 == 0 else None)
+            cir.cnot(k % n, (k + 1) % n)
+            cir.rx((k + 2) % n)
+        a = torch.randn(4, 4, generator=g, dtype=torch.float64) + 1j * torch.randn(4, 4, generator=g, dtype=torch.float64)
+        cir.any((torch.linalg.qr(a)[0] * (1 + 3e-5)).to(torch.complex64), wires=[1, n - 2])
+        cir.rxlayer()
+        cir.observable(0)
+        cir.observable([1, n - 1], 'xz')
+        assert sum(1 for op in cir.operators if getattr(op, '_exact_unitary', True) is False) == 11
+        if device is not None:
+            cir.to(device)
+        return cir
+
+    results = {}
+    for mode in ('per_gate', 'adjoint'):
+        dq.executor.CONFIG['grad_mode'] = mode
+        try:
+            cir = build()
+            cir()
+            loss = (cir.expectation() * torch.tensor([1.0, -0.7], device=cir.state.device)).sum()
+            loss.backward()
+            if mode == 'adjoint':
+                assert dq.executor.LAST_SWEEP['fused']
+            results[mode] = [p.grad.cpu() for p in cir.parameters()]
+        finally:
+            dq.executor.CONFIG['grad_mode'] = 'adjoint'
+    worst = max((x - y).abs().max().item() for x, y in zip(results['per_gate'], results['adjoint'], strict=True))
+    assert worst < tol, worst
+    assert math.isfinite(worst)

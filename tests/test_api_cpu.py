@@ -385,3 +385,9 @@ def test_z_expectations_come_out_of_the_last_pass(cpu_backend):
     c.hlayer(); c.rxlayer(); c.observable(0)
     c()                                     # under grad mode: the differentiable reduction
     assert c._expz is None and c.expectation().requires_grad
+
+
+def test_fused_reverse_sweep_with_user_matrices_that_are_unitary_to_1e_4_only(cpu_backend):
+    from _helpers import check_fused_sweep_with_sloppy_user_matrices
+
+    check_fused_sweep_with_sloppy_user_matrices(dq, n=12)

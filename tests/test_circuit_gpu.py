@@ -663,3 +663,10 @@ def test_z_expectations_come_out_of_the_last_pass_on_gpu(n, dt, batch, tol):
         finally:
             dq.executor.CONFIG['fused_expectation'] = True
     assert res[True].shape == res[False].shape and (res[True] - res[False]).abs().max().item() < tol, (res[True], res[False])
+
+
+def test_fused_reverse_sweep_with_user_matrices_that_are_unitary_to_1e_4_only_on_gpu():
+    from _helpers import check_fused_sweep_with_sloppy_user_matrices
+
+    check_fused_sweep_with_sloppy_user_matrices(dq, device=dev(), n=12)
+    check_fused_sweep_with_sloppy_user_matrices(dq, device=dev(), n=16)
