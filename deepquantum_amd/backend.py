@@ -54,6 +54,10 @@ def _stream(t: torch.Tensor) -> C.c_void_p:
 
 
 def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+    # a lazily conjugated / negated view (x.mH of a column-major matrix is "contiguous" AND unconjugated in memory) must
+    # never reach a kernel as a raw pointer
+    if t is not None and (t.is_conj() or t.is_neg()):
+        raise ValueError('tensor with a pending conjugation / negation: resolve_conj() / resolve_neg() it first')
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
@@ -76,7 +80,7 @@ def _check_mats(state: torch.Tensor, mats: torch.Tensor, k: int) -> tuple[torch.
         raise ValueError(f'matrix batch {mats.shape[0]} does not match state batch {state.shape[0]}')
     if mats.dtype != state.dtype or mats.device != state.device:
         mats = mats.to(device=state.device, dtype=state.dtype)
-    mats = mats.contiguous()
+    mats = mats.resolve_conj().resolve_neg().contiguous()     # (.mH of a strided user matrix is contiguous with the conj bit set)
     stride = 0 if mats.shape[0] == 1 else d * d
     return mats, stride
 

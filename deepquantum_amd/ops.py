@@ -46,7 +46,7 @@ class _ApplyGate(torch.autograd.Function):
         gstate = gmats = None
         if ctx.needs_input_grad[0]:
             # d/dx of y = U x  ->  U^H gy on the same targets / controls (other amplitudes: identity)
-            gstate = apply_gate(gy, mats.mH.contiguous(), ctx.targets, ctx.controls)
+            gstate = apply_gate(gy, mats.mH.resolve_conj().contiguous(), ctx.targets, ctx.controls)
         if ctx.needs_input_grad[1]:
             g = backend.gate_grad(state, gy, ctx.targets, ctx.controls)  # (B, D, D) complex128
             if mats.shape[0] == 1 and g.shape[0] > 1:
@@ -66,7 +66,7 @@ class _ApplyGate(torch.autograd.Function):
             mats = mats.expand(v, b, d, d).reshape(v * b, d, d)
         elif mats.shape[0] > 1:
             mats = mats.unsqueeze(0).expand(v, *mats.shape).reshape(v * b, *mats.shape[1:])
-        out = _ApplyGate.apply(state.reshape(v * b, -1).contiguous(), mats.contiguous(), targets, controls)
+        out = _ApplyGate.apply(state.reshape(v * b, -1).contiguous(), mats.resolve_conj().contiguous(), targets, controls)
         return out.reshape(v, b, -1), 0
 
 

@@ -670,3 +670,40 @@ def test_fused_reverse_sweep_with_user_matrices_that_are_unitary_to_1e_4_only_on
 
     check_fused_sweep_with_sloppy_user_matrices(dq, device=dev(), n=12)
     check_fused_sweep_with_sloppy_user_matrices(dq, device=dev(), n=16)
+
+
+def test_user_matrices_with_foreign_strides_and_pending_conjugation():
+    """A user matrix may be column-major (torch.linalg.qr returns such) and its .mH -- the backward of the per-gate
+    path, an inverted UAnyGate -- is then "contiguous" with the conjugation still pending: the kernels take raw pointers,
+    so it has to be resolved first (it was not: silently wrong gradients in 'per_gate' mode)."""
+    n = 7
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(4, 4, generator=g, dtype=torch.float64) + 1j * torch.randn(4, 4, generator=g, dtype=torch.float64)
+    q = torch.linalg.qr(a)[0].to(torch.complex64)
+    u_col = q.t().contiguous().t()                 # same values, column-major strides
+    assert not u_col.is_contiguous() and torch.equal(u_col, q)
+    res = {}
+    for name, u in (('row-major', q.contiguous()), ('column-major', u_col)):
+        for mode in ('per_gate', 'adjoint'):
+            dq.executor.CONFIG['grad_mode'] = mode
+            try:
+                torch.manual_seed(2)
+                cir = dq.QubitCircuit(n)
+                cir.hlayer(); cir.rylayer()
+                cir.any(u, wires=[1, 4], controls=[6])
+                cir.any(torch.tensor([[0.6, 0.8], [-0.8, 0.6]], dtype=torch.complex64), wires=[2])
+                cir.add(dq.UAnyGate(u, nqubit=n, wires=[0, 3]).inverse())
+                cir.rxlayer()
+                cir.observable(0); cir.observable([1, 2], 'xz')
+                cir.to(dev())
+                cir()
+                cir.expectation().sum().backward()
+                res[name, mode] = torch.stack([p.grad.cpu().reshape(-1)[0] for p in cir.parameters()])
+            finally:
+                dq.executor.CONFIG['grad_mode'] = 'adjoint'
+    ref = res['row-major', 'adjoint']
+    for key, v in res.items():
+        assert (v - ref).abs().max().item() < 2e-5, (key, (v - ref).abs().max())
+    with pytest.raises(ValueError, match='pending conjugation'):
+        from deepquantum_amd import backend
+        backend._ptr(u_col.mH)
