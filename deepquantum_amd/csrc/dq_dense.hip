@@ -80,13 +80,18 @@ template <typename T, bool NT> __device__ __forceinline__ void st_amp(cx<T>* p, 
     }
 }
 
-template <typename T, int WM, bool NT>
+// BM x BN = 16 x 16 blocks of a wave's tile: 2 x 2 (32 x 32; 64 x 64 per workgroup) or 4 x 4 (64 x 64; 128 x 128 per
+// workgroup -- half the traffic from the caches per MFMA: every workgroup re-reads its rows of U and its columns of X)
+template <typename T, int WM, bool NT, int BM = 2, int BN = 2>
 __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
                                                                const cx<T>* __restrict__ mats, int64_t mat_bstride,
                                                                DenseGeom g, uint64_t ncols, int col_sample_shift) {
     constexpr int WN = 4 / WM;
-    constexpr int TM = WM * 32, TN = WN * 32;      // workgroup tile: rows of U x columns
-    constexpr int KC = sizeof(T) == 4 ? 16 : 32;    // K chunk (complex columns of U per stage; measured: 32 costs f32 2 %, gains f64 5 %)
+    constexpr int TM = WM * BM * 16, TN = WN * BN * 16;      // workgroup tile: rows of U x columns
+#ifndef DQ_DENSE_KC_F32
+#define DQ_DENSE_KC_F32 16
+#endif
+    constexpr int KC = sizeof(T) == 4 ? DQ_DENSE_KC_F32 : 32;    // K chunk (complex columns of U per stage; measured: 32 costs f32 2 %, gains f64 5 %)
     constexpr int APAD = KC + 1, BPAD = TN + 1;     // padded row lengths of the LDS planes (in elements)
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
@@ -125,70 +130,95 @@ __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __re
         col_base = (sample << g.n) + (insert_zeros(within, g.sorted) | g.cmask);
     }
 
-    cx<T> pa[A_PER], pb[B_PER];
-    auto fetch = [&](int k0) __attribute__((always_inline)) {
+    constexpr int DEPTH = 1;      // chunks in flight (two: measured SLOWER, 104 vs 116 TFLOP/s at k = 10 -- a wave per SIMD less)
+    cx<T> pa[DEPTH][A_PER], pb[DEPTH][B_PER];
+    // offsets of the rows of X a thread fetches: the pattern's bits below KC once per thread, the bits above once per
+    // chunk (uniform) -- computed per load (a loop over the k target bits in 64-bit arithmetic) the addressing cost half
+    // as many issue slots as the MFMAs it feeds
+    uint64_t boff[B_PER];
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) pa[i] = U[(int64_t)(row0 + a_row) * D + k0 + a_k + i];
+    for (int i = 0; i < B_PER; ++i) boff[i] = col_base + target_offset(b_k0 + i * B_KSTEP, g);
+    auto fetch = [&](int k0, cx<T> (&qa)[A_PER], cx<T> (&qb)[B_PER]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int kk = k0 + b_k0 + i * B_KSTEP;                       // (uniform per wave-instruction group)
-            pb[i] = col_ok ? ld_amp<T, NT>(in + col_base + target_offset(kk, g)) : mk<T>(0, 0);
-        }
+        for (int i = 0; i < A_PER; ++i) qa[i] = U[(int64_t)(row0 + a_row) * D + k0 + a_k + i];
+        const uint64_t hi = target_offset(__builtin_amdgcn_readfirstlane(k0), g);      // (k0 is a multiple of KC)
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) qb[i] = col_ok ? ld_amp<T, NT>(in + (boff[i] | hi)) : mk<T>(0, 0);
     };
-    auto stash = [&]() __attribute__((always_inline)) {
+    auto stash = [&](const cx<T> (&qa)[A_PER], const cx<T> (&qb)[B_PER]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            sAr[a_row * APAD + a_k + i] = pa[i].x;
-            sAi[a_row * APAD + a_k + i] = pa[i].y;
+            sAr[a_row * APAD + a_k + i] = qa[i].x;
+            sAi[a_row * APAD + a_k + i] = qa[i].y;
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
-            sBr[(b_k0 + i * B_KSTEP) * BPAD + b_col] = pb[i].x;
-            sBi[(b_k0 + i * B_KSTEP) * BPAD + b_col] = pb[i].y;
+            sBr[(b_k0 + i * B_KSTEP) * BPAD + b_col] = qb[i].x;
+            sBi[(b_k0 + i * B_KSTEP) * BPAD + b_col] = qb[i].y;
         }
     };
 
-    acc_t cr[2][2], ci[2][2];
+    acc_t cr[BM][BN], ci[BM][BN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < BM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) cr[a][b] = ci[a][b] = acc_t{0, 0, 0, 0};
+        for (int b = 0; b < BN; ++b) cr[a][b] = ci[a][b] = acc_t{0, 0, 0, 0};
 
     const int l15 = lane & 15, l4 = lane >> 4;
-    fetch(0);
-    for (int k0 = 0; k0 < D; k0 += KC) {
+    fetch(0, pa[0], pb[0]);
+    if constexpr (DEPTH == 2)
+        if (KC < D) fetch(KC, pa[1], pb[1]);
+    for (int k0 = 0, par = 0; k0 < D; k0 += KC, par ^= (DEPTH - 1)) {
+#ifndef DQ_DENSE_ABL_NOBAR
         __syncthreads();                            // everybody is done with the previous chunk
-        stash();
+#endif
+        if (par == 0) stash(pa[0], pb[0]);
+        else stash(pa[DEPTH - 1], pb[DEPTH - 1]);
+#ifndef DQ_DENSE_ABL_NOBAR
         __syncthreads();
-        if (k0 + KC < D) fetch(k0 + KC);            // in flight while the matrix cores work on this chunk
+#endif
+#ifndef DQ_DENSE_ABL_NOFETCH
+        if (k0 + DEPTH * KC < D) {                  // DEPTH chunks ahead: in flight while the matrix cores work
+            if (par == 0) fetch(k0 + DEPTH * KC, pa[0], pb[0]);
+            else fetch(k0 + DEPTH * KC, pa[DEPTH - 1], pb[DEPTH - 1]);
+        }
+#endif
 #pragma unroll
         for (int ks = 0; ks < KC; ks += 4) {
-            T ar[2], ai[2], nai[2], br[2], bi[2];
+            T ar[BM], ai[BM], nai[BM], br[BN], bi[BN];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {           // A[i = l & 15][k = l >> 4]
-                const int r = wm * 32 + a * 16 + l15;
+            for (int a = 0; a < BM; ++a) {          // A[i = l & 15][k = l >> 4]
+                const int r = wm * BM * 16 + a * 16 + l15;
+#ifdef DQ_DENSE_ABL_NOLDS      // (timing experiment: operands from registers, wrong results)
+                ar[a] = (T)(r + ks) * (T)1e-3, ai[a] = (T)l4;
+#else
                 ar[a] = sAr[r * APAD + ks + l4];
                 ai[a] = sAi[r * APAD + ks + l4];
+#endif
                 nai[a] = -ai[a];
             }
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {           // B[k = l >> 4][j = l & 15]
-                const int c = wn * 32 + b * 16 + l15;
+            for (int b = 0; b < BN; ++b) {          // B[k = l >> 4][j = l & 15]
+                const int c = wn * BN * 16 + b * 16 + l15;
+#ifdef DQ_DENSE_ABL_NOLDS
+                br[b] = (T)c * (T)1e-3, bi[b] = (T)(ks + l4);
+#else
                 br[b] = sBr[(ks + l4) * BPAD + c];
                 bi[b] = sBi[(ks + l4) * BPAD + c];
+#endif
             }
             // 16 MFMAs; consecutive ones never touch the same accumulator
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < BM; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < BN; ++b) {
                     cr[a][b] = M::run(ar[a], br[b], cr[a][b]);
                     ci[a][b] = M::run(ar[a], bi[b], ci[a][b]);
                 }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < BM; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < BN; ++b) {
                     cr[a][b] = M::run(nai[a], bi[b], cr[a][b]);
                     ci[a][b] = M::run(ai[a], br[b], ci[a][b]);
                 }
@@ -197,17 +227,17 @@ __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __re
 
     // ---- scatter: lane holds column (lane & 15) of each block, four rows per block ------------------------------
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const uint64_t c = col0 + (uint64_t)(wn * 32 + b * 16 + l15);
+    for (int b = 0; b < BN; ++b) {
+        const uint64_t c = col0 + (uint64_t)(wn * BN * 16 + b * 16 + l15);
         if (c >= ncols) continue;
         const uint64_t sample = col_sample_shift >= 0 ? (c >> col_sample_shift) : (uint64_t)zb;
         const uint64_t within = col_sample_shift >= 0 ? (c & ((1ull << col_sample_shift) - 1ull)) : c;
         cx<T>* po = out + (sample << g.n) + (insert_zeros(within, g.sorted) | g.cmask);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < BM; ++a)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int r = row0 + wm * 32 + a * 16 + M::row(lane, reg);
+                const int r = row0 + wm * BM * 16 + a * 16 + M::row(lane, reg);
                 st_amp<T, NT>(po + target_offset(r, g), cr[a][b][reg], ci[a][b][reg]);
             }
     }
@@ -374,6 +404,15 @@ int apply_dense_mfma(const cx<T>* in, cx<T>* out, const cx<T>* mats, int64_t mat
         if (nt) hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 1, true>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
         else hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 1, false>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift);
     } else {
+        static const int big_env = [] { const char* e = getenv("DQ_DENSE_BIG"); return e ? atoi(e) : 0; }();      // (measured: 100 vs 116 TFLOP/s at k = 10 -- two waves per SIMD hide less than the halved cache traffic saves)
+        if (sizeof(T) == 4 && D >= 256 && big_env && ncols % 128 == 0) {      // complex64, k >= 8: 128 x 128 per workgroup
+            dim3 grid((unsigned)(ncols / 128), (unsigned)(D / 128), gz);
+            const int shift3 = shift >= 0 ? (shift | 0x40000000) : shift;
+            if (nt) hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2, true, 4, 4>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift3);
+            else hipLaunchKernelGGL((apply_dense_mfma_kernel<T, 2, false, 4, 4>), grid, dim3(256), 0, s, in, out, mats, mat_bstride, g, ncols, shift3);
+            (void)controls;
+            return DQ_OK;
+        }
         constexpr int TN = 64;
         dim3 grid((unsigned)((ncols + TN - 1) / TN), (unsigned)(D / 64), gz);
         static const int rf_env = [] { const char* e = getenv("DQ_DENSE_ROWS_FAST"); return e ? atoi(e) : 1; }();
