@@ -479,3 +479,25 @@ def test_assembly_gate_loop_matches_oracle(is128, n, seed):
         backend.apply_fused(xd, md, 0, st.desc, out=xd)
     err = (xd.cpu() - ref).abs().max().item()
     assert err < TOL[dtype], err
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+@pytest.mark.parametrize('n,batch', [(5, 2), (11, 3), (12, 1), (13, 2), (17, 3), (22, 1)])
+def test_permute_bits_against_index_arithmetic(dtype, n, batch):
+    """dq_permute_bits (the relayout before an all-to-all, the canonical order afterwards): out[i] = in[sigma(i)], every kernel
+    variant -- per-element below 2^12, tiled with 16-byte pairs when bit 0 stays (complex64) and without."""
+    import random
+
+    rng = random.Random(n)
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(batch, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(batch, 1 << n, generator=g, dtype=torch.float64)).to(dtype)
+    idx = torch.arange(1 << n)
+    perms = [list(range(n)), rng.sample(range(n), n), [0] + [1 + q for q in rng.sample(range(n - 1), n - 1)],
+             list(range(1, n)) + [0], [q for q in range(n) if q not in (n - 3, n - 2)] + [n - 3, n - 2]]
+    for src_of_dst in perms:
+        sidx = torch.zeros(1 << n, dtype=torch.long)
+        for p, sp in enumerate(src_of_dst):
+            sidx |= ((idx >> p) & 1) << sp
+        out = torch.empty_like(x, device=dev())
+        backend.permute_bits(x.to(dev()), src_of_dst, out=out)
+        assert torch.equal(out.cpu(), x[:, sidx]), src_of_dst
