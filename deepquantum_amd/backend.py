@@ -232,7 +232,7 @@ def expect_z_multi(state: torch.Tensor, zmasks: Sequence[int]) -> torch.Tensor:
         return torch.stack([_test_backend.expect_pauli(state, 0, z) for z in zmasks], dim=1)
     lib = _lib.load()
     fn = getattr(lib, f'dq_expect_zmulti_{_suffix(state)}')
-    nblocks = max(1, min(1024, (1 << n) // 1024))
+    nblocks = max(1, min(2048, (1 << n) // 1024))
     parts = []
     for lo in range(0, len(zmasks), 32):
         grp = zmasks[lo:lo + 32]
@@ -309,7 +309,7 @@ def marginal(state: torch.Tensor, bits: Sequence[int]) -> torch.Tensor:
     b = state.shape[0]
     lib = _lib.load()
     fn = getattr(lib, f'dq_marginal_{_suffix(state)}')
-    max_b = max(1, 65535 >> nw) if nw <= 12 else 65535      # (more than 12 wires: another kernel, batch on its own grid axis)
+    max_b = 65535                                            # (the batch is a grid axis of its own)
     out = torch.zeros(b, 1 << nw, dtype=torch.float64, device=state.device)
     for lo in range(0, b, max_b):
         hi = min(b, lo + max_b)

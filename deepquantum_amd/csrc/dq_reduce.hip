@@ -7,6 +7,7 @@
 // here one read of the state -- the |psi|^2 / permute / sum of qmath.measure (qmath.py:624-626),
 // inner_product_dist's local part (distributed.py:288-291) and the matmul backward that autograd
 // derives for qmath.py:504.
+#include <cstring>
 #include "dq_common.hpp"
 
 namespace dq {
@@ -202,6 +203,97 @@ __global__ __launch_bounds__(256) void marginal_wide_kernel(const cx<T>* __restr
     }
 }
 
+// Marginals, general kernel: a block owns a "chunk" of 2^c amplitudes (c = min(12, n)) whose index bits are the low L bits
+// (1 KiB of contiguous state) plus the lowest UNMEASURED bits above them, so as much of the sum over the unmeasured bits
+// as possible happens inside the block.  A thread holds the 16 amplitudes that differ in the chunk's top four bits
+// (unmeasured whenever five unmeasured bits exist above L), issues all 16 loads before it uses any, adds them up, and adds
+// the sum into an LDS histogram over the measured chunk bits; the block then adds the histogram to the rows of `out`
+// that the measured bits outside the chunk select: 2^nlo atomics per 4096 amplitudes, whatever the measured wires are.
+struct MargGeom {                       // unused entries are padded so that the kernel needs no guards (see below)
+    int c, nlo, run, exclusive;
+    unsigned qmask;                     // measured ones among the four chunk-local bits a thread holds itself
+    uint8_t pos[12];                    // chunk-local bit i <-> index bit pos[i], ascending          (pad: 62)
+    uint8_t lo_x[12], lo_out[12];       // measured chunk-local bit -> bit of the outcome index       (pad: 31, 0)
+    uint8_t hi_pos[40], hi_out[40];     // measured index bit outside the chunk -> outcome bit        (pad: 63, 0)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void marginal_chunk_kernel(const cx<T>* __restrict__ psi, int n, int nw, MargGeom g,
+                                                             double* __restrict__ out) {
+    extern __shared__ double hist[];
+    const unsigned nloc = 1u << g.nlo;
+    for (unsigned j = threadIdx.x; j < nloc; j += 256) hist[j] = 0.0;
+    __syncthreads();
+    // every loop over the geometry has a constant trip count and no guard: the arrays are kernel arguments, and a
+    // run-time index or a conditional access would turn them into one scalar load (and one wait) per byte
+    // chunk-local index x = threadIdx.x | k << 8: the thread's 16 amplitudes differ in the chunk's top four bits
+    const unsigned xt = threadIdx.x, nx = 1u << g.c;
+    uint64_t off_t = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) off_t |= (uint64_t)((xt >> i) & 1u) << g.pos[i];
+    unsigned jt = 0;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) jt |= ((xt >> g.lo_x[t]) & 1u) << t;
+    uint64_t off_k[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        off_k[k] = 0;
+#pragma unroll
+        for (int i = 8; i < 12; ++i) off_k[k] |= (uint64_t)((k >> (i - 8)) & 1) << g.pos[i];
+    }
+    // 2^run consecutive chunks differ in unmeasured bits only: they go into the same rows of `out`, so one workgroup
+    // takes them all and adds its histogram to `out` once
+    uint64_t base0 = 0;
+    double s = 0;
+    for (uint64_t ci = (uint64_t)blockIdx.x << g.run; ci < ((uint64_t)blockIdx.x + 1) << g.run; ++ci) {
+        uint64_t base = ci;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) base = insert_zero(base, g.pos[i]);
+        if (ci == (uint64_t)blockIdx.x << g.run) base0 = base;
+        const cx<T>* p = psi + ((uint64_t)blockIdx.y << n) + base;
+        cx<T> a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = p[(xt | (k << 8)) < nx ? off_t + off_k[k] : 0];
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            v[k] = (xt | (k << 8)) < nx ? (double)a[k].x * a[k].x + (double)a[k].y * a[k].y : 0.0;
+        if (g.qmask == 0) {             // none of the thread's own bits is measured: one sum, one histogram bin
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                unsigned j = jt;
+#pragma unroll
+                for (int t = 0; t < 12; ++t) j |= ((((unsigned)k << 8) >> g.lo_x[t]) & 1u) << t;
+                if ((xt | (k << 8)) < nx) unsafeAtomicAdd(&hist[j], v[k]);
+            }
+        }
+    }
+    if (g.qmask == 0) {
+        if (g.nlo == 0) {               // no measured bit in the chunk at all: a plain block sum
+            double dummy = 0;
+            block_sum2(s, dummy);
+            if (threadIdx.x == 0) hist[0] = s;
+        } else {
+            unsafeAtomicAdd(&hist[jt], s);
+        }
+    }
+    __syncthreads();
+    uint64_t hi = 0;
+#pragma unroll
+    for (int t = 0; t < 40; ++t) hi |= ((base0 >> g.hi_pos[t]) & 1ull) << g.hi_out[t];
+    double* row = out + ((size_t)blockIdx.y << nw);
+    for (unsigned j = threadIdx.x; j < nloc; j += 256) {
+        uint64_t o = hi;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) o |= (uint64_t)((j >> t) & 1u) << g.lo_out[t];
+        if (g.exclusive) row[o] = hist[j];      // every bit outside the chunk is measured: nobody else adds to this row
+        else unsafeAtomicAdd(row + o, hist[j]);
+    }
+}
+
 struct GradGeom {
     BitList sorted;
     int tpos[2];
@@ -340,6 +432,73 @@ __global__ __launch_bounds__(RED_THREADS) void expect_zmulti_kernel(const cx<T>*
     }
 }
 
+// The same sums as a matrix product on the f64 matrix cores: for the 64 consecutive amplitudes i = i0 + 16 q + j a wave
+// holds (lane 16 q + j), (-1)^{popc(i & m_k)} = s_k(i0 + 16 q) s_k(j), so
+//     D[k][j] += sum_q A[k][q] B[q][j],   A[k][q] = s_k(i0 + 16 q) = +-1,   B[q][j] = |psi_i|^2
+// is one v_mfma_f64_16x16x4_f64 per 16 strings (B is exactly what the lane computed from its own load; A costs a lane an
+// and / popcount of ITS string's mask), and the factor s_k(j) is applied once, after the loop, before the sum over j.
+// Exact +-1 factors and f64 accumulation: the same numbers as the loop above, without its select per string and
+// amplitude -- 32 strings cost two matrix instructions (64 clocks) per 64 amplitudes.
+typedef double zm_f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void expect_zmulti_mfma_kernel(const cx<T>* __restrict__ psi, ZMasks z, int n,
+                                                                          double* __restrict__ out) {
+    __shared__ uint64_t sm[ZM_MAX];
+    __shared__ double part[RED_THREADS / 64][ZM_MAX];
+#pragma unroll
+    for (int k = 0; k < ZM_MAX; ++k)
+        if (threadIdx.x == k) sm[k] = z.m[k];
+    __syncthreads();
+    const int64_t b = blockIdx.y;
+    const cx<T>* p = psi + ((uint64_t)b << n);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const uint64_t m0 = sm[j] & ~15ull, m1 = sm[16 + j] & ~15ull;      // operand A: row = lane & 15
+    const bool two = z.k > 16;
+    zm_f64x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    const uint64_t dim = 1ull << n, stride = (uint64_t)gridDim.x * RED_THREADS;
+    constexpr int U = sizeof(T) == 4 ? 8 : 4;       // loads in flight per lane
+    for (uint64_t i0 = (uint64_t)blockIdx.x * RED_THREADS + wave * 64; i0 < dim; i0 += U * stride) {
+        double pr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + u * stride;
+            if (i < dim) {
+                const cx<T> a = p[i + lane];
+                pr[u] = (double)a.x * a.x + (double)a.y * a.y;
+            } else {
+                pr[u] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = (i0 + u * stride) | (uint64_t)(q << 4);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((__popcll(i & m0) & 1) ? -1.0 : 1.0, pr[u], acc0, 0, 0, 0);
+            if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((__popcll(i & m1) & 1) ? -1.0 : 1.0, pr[u], acc1, 0, 0, 0);
+        }
+    }
+    // D: register r of lane (q, j) = row q + 4 r, column j
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * h + q + 4 * r;
+            double v = h ? acc1[r] : acc0[r];
+            if (__popcll((uint64_t)j & sm[k]) & 1) v = -v;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (j == 0) part[wave][k] = v;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < z.k) {
+        double v = 0;
+#pragma unroll
+        for (int w = 0; w < RED_THREADS / 64; ++w) v += part[w][threadIdx.x];
+        out[((size_t)b * gridDim.x + blockIdx.x) * z.k + threadIdx.x] = v;
+    }
+}
+
 // out_i = psi_i * sum_k coef[b][k] (-1)^{popc(i & zmask_k)}: the backward of the above (and sum_k c_k Z-string |psi>)
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void scale_zsigns_kernel(const cx<T>* __restrict__ psi, cx<T>* __restrict__ out,
@@ -358,6 +517,50 @@ __global__ __launch_bounds__(RED_THREADS) void scale_zsigns_kernel(const cx<T>* 
             if (k < z.k) w += (__popcll(i & z.m[k]) & 1) ? -c[k] : c[k];
         const cx<T> a = p[i];
         q[i] = mk<T>((T)(a.x * w), (T)(a.y * w));
+    }
+}
+
+// ... and its matrix form: for the 256 consecutive amplitudes i = i0 + 16 r + c a wave handles,
+//     w[r][c] = sum_k A[r][k] B[k][c],   A[r][k] = coef_k s_k(i0 + 16 r),   B[k][c] = s_k(c)   (constant per lane),
+// four strings per v_mfma_f64_16x16x4_f64; register t of lane l of the result is the factor of amplitude i0 + 64 t + l,
+// i.e. what the lane's t-th (coalesced) load brought.
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void scale_zsigns_mfma_kernel(const cx<T>* __restrict__ psi, cx<T>* __restrict__ out,
+                                                                         ZMasks z, const double* __restrict__ coef, int n) {
+    __shared__ uint64_t sm[ZM_MAX];
+    __shared__ double sc[ZM_MAX];
+    const int64_t b = blockIdx.y;
+#pragma unroll
+    for (int k = 0; k < ZM_MAX; ++k)
+        if (threadIdx.x == k) sm[k] = z.m[k];
+    if (threadIdx.x < ZM_MAX) sc[threadIdx.x] = (int)threadIdx.x < z.k ? coef[(size_t)b * z.k + threadIdx.x] : 0.0;
+    __syncthreads();
+    const cx<T>* p = psi + ((uint64_t)b << n);
+    cx<T>* po = out + ((uint64_t)b << n);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const int nt = (z.k + 3) >> 2;
+    uint64_t m[ZM_MAX / 4];
+    double c[ZM_MAX / 4], bs[ZM_MAX / 4];
+#pragma unroll
+    for (int t = 0; t < ZM_MAX / 4; ++t) {
+        const uint64_t mk = sm[4 * t + q];
+        m[t] = mk & ~15ull;
+        c[t] = sc[4 * t + q];
+        bs[t] = (__popcll(mk & (uint64_t)j) & 1) ? -1.0 : 1.0;
+    }
+    const uint64_t dim = 1ull << n;
+    for (uint64_t i0 = ((uint64_t)blockIdx.x * (RED_THREADS / 64) + wave) << 8; i0 < dim;
+         i0 += (uint64_t)gridDim.x * (RED_THREADS / 64) << 8) {
+        cx<T> a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = p[i0 + 64 * r + lane];
+        const uint64_t i = i0 | (uint64_t)(j << 4);
+        zm_f64x4 w = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < ZM_MAX / 4; ++t)
+            if (t < nt) w = __builtin_amdgcn_mfma_f64_16x16x4f64((__popcll(i & m[t]) & 1) ? -c[t] : c[t], bs[t], w, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) po[i0 + 64 * r + lane] = mk<T>((T)(a[r].x * w[r]), (T)(a[r].y * w[r]));
     }
 }
 
@@ -387,8 +590,13 @@ static int expect_zmulti_impl(const void* psi, const uint64_t* zmasks, int k, in
     ZMasks z;
     int rc = fill_zmasks(z, zmasks, k, n, "dq_expect_zmulti");
     if (rc) return rc;
-    hipLaunchKernelGGL(expect_zmulti_kernel<T>, dim3((unsigned)nblocks, (unsigned)batch), dim3(RED_THREADS), 0,
-                       as_stream(stream), static_cast<const cx<T>*>(psi), z, n, out);
+    static const int loop_only = [] { const char* e = getenv("DQ_ZMULTI_MFMA"); return e && atoi(e) == 0; }();
+    if (n >= 8 && !loop_only)
+        hipLaunchKernelGGL(expect_zmulti_mfma_kernel<T>, dim3((unsigned)nblocks, (unsigned)batch), dim3(RED_THREADS), 0,
+                           as_stream(stream), static_cast<const cx<T>*>(psi), z, n, out);
+    else
+        hipLaunchKernelGGL(expect_zmulti_kernel<T>, dim3((unsigned)nblocks, (unsigned)batch), dim3(RED_THREADS), 0,
+                           as_stream(stream), static_cast<const cx<T>*>(psi), z, n, out);
     return check_launch("dq_expect_zmulti");
 }
 
@@ -402,6 +610,14 @@ static int scale_zsigns_impl(const void* psi, void* out, const uint64_t* zmasks,
     ZMasks z;
     int rc = fill_zmasks(z, zmasks, k, n, "dq_scale_zsigns");
     if (rc) return rc;
+    static const int loop_only = [] { const char* e = getenv("DQ_ZMULTI_MFMA"); return e && atoi(e) == 0; }();
+    if (n >= 8 && !loop_only) {
+        uint64_t nb = (1ull << n) >> 10;        // four waves of 256 amplitudes per workgroup and iteration
+        nb = nb < 1 ? 1 : nb > 2048 ? 2048 : nb;
+        hipLaunchKernelGGL(scale_zsigns_mfma_kernel<T>, dim3((unsigned)nb, (unsigned)batch), dim3(RED_THREADS), 0,
+                           as_stream(stream), static_cast<const cx<T>*>(psi), static_cast<cx<T>*>(out), z, coef, n);
+        return check_launch("dq_scale_zsigns");
+    }
     const unsigned nb = red_blocks(1ull << n);
     hipLaunchKernelGGL(scale_zsigns_kernel<T>, dim3(nb, (unsigned)batch), dim3(RED_THREADS), 0, as_stream(stream),
                        static_cast<const cx<T>*>(psi), static_cast<cx<T>*>(out), z, coef, n);
@@ -451,6 +667,60 @@ static int marginal_impl(const void* psi, int n, const int* bits, int nw, int64_
     }
     int rc = validate_bits(n, bits, nw, nullptr, 0);
     if (rc) return rc;
+    if (batch > 65535) {
+        set_error("dq_marginal: batch %lld exceeds 65535", (long long)batch);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    static const int legacy = [] { const char* e = getenv("DQ_MARGINAL_LEGACY"); return e ? atoi(e) : 0; }();
+    if (!legacy) {
+        constexpr int VEC = sizeof(T) == 4 ? 2 : 1;
+        const int c = n < 12 ? n : 12;
+        const int low = n < 8 - VEC ? n : 8 - VEC;          // 1 KiB of contiguous state: 7 bits complex64, 6 complex128
+        uint64_t measured = 0, in_chunk = 0;
+        for (int i = 0; i < nw; ++i) measured |= 1ull << bits[i];
+        MargGeom g{};
+        g.c = c;
+        memset(g.pos, 62, sizeof g.pos);
+        memset(g.lo_x, 31, sizeof g.lo_x);
+        memset(g.hi_pos, 63, sizeof g.hi_pos);
+        for (int b = 0; b < low; ++b) in_chunk |= 1ull << b;
+        int have = low;
+        for (int pass = 0; pass < 2 && have < c; ++pass)      // unmeasured bits first, then measured ones
+            for (int b = low; b < n && have < c; ++b)
+                if (!((in_chunk >> b) & 1ull) && (int)((measured >> b) & 1ull) == pass) {
+                    in_chunk |= 1ull << b;
+                    ++have;
+                }
+        int local_of[40], nc = 0, nhi = 0;
+        for (int b = 0; b < n; ++b)
+            if ((in_chunk >> b) & 1ull) {
+                local_of[b] = nc;
+                g.pos[nc++] = (uint8_t)b;
+            }
+        for (int i = 0; i < nw; ++i) {                        // bits[i] <-> outcome bit nw - 1 - i
+            if ((in_chunk >> bits[i]) & 1ull) {
+                const int x = local_of[bits[i]];
+                g.lo_x[g.nlo] = (uint8_t)x;
+                g.lo_out[g.nlo++] = (uint8_t)(nw - 1 - i);
+                if (x >= 8) g.qmask |= 1u << (x - 8);
+            } else {
+                g.hi_pos[nhi] = (uint8_t)bits[i];
+                g.hi_out[nhi++] = (uint8_t)(nw - 1 - i);
+            }
+        }
+        g.exclusive = nhi == n - c;
+        int run = 0;                                          // the lowest bits outside the chunk that are unmeasured
+        for (int b = 0; b < n; ++b) {
+            if ((in_chunk >> b) & 1ull) continue;
+            if ((measured >> b) & 1ull) break;
+            ++run;
+        }
+        while (run > 0 && ((1ull << (n - c - run)) * (uint64_t)batch < 2048)) --run;      // keep the chip busy
+        g.run = run;
+        hipLaunchKernelGGL(marginal_chunk_kernel<T>, dim3((unsigned)(1ull << (n - c - run)), (unsigned)batch), dim3(256),
+                           sizeof(double) << g.nlo, as_stream(stream), static_cast<const cx<T>*>(psi), n, nw, g, out);
+        return check_launch("dq_marginal");
+    }
     if (nw > 12) {
         if (batch > 65535) {
             set_error("dq_marginal: batch %lld exceeds 65535", (long long)batch);

@@ -308,11 +308,13 @@ def test_batches_wider_than_a_grid_dimension_go_in_slices(monkeypatch):
     assert (out.cpu() - one).abs().max().item() < TOL[dtype]
 
 
+@pytest.mark.parametrize('n', [13, 9, 16])
 @pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
-def test_many_z_strings_in_one_read(dtype):
+def test_many_z_strings_in_one_read(dtype, n):
     """dq_expect_zmulti_* / dq_scale_zsigns_*: 40 random Z-type strings (two launches of <= 32) against the
-    single-string kernel and against the diagonal operator applied amplitude by amplitude."""
-    n, b = 13, 3
+    single-string kernel and against the diagonal operator applied amplitude by amplitude (n = 9: the grid stride is
+    more than a quarter of the state, so the kernels take their element-by-element sign path)."""
+    b = 3
     x = rand_state(b, n, dtype, 41)
     xd = x.to(dev())
     rng = random.Random(9)
@@ -361,6 +363,27 @@ def test_reductions(dtype):
         ref = oracle.probabilities(x, wires).to(torch.float64)
         got = backend.marginal(xd, [n - 1 - w for w in sorted(wires)]).cpu()
         assert (got - ref).abs().max().item() < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
+def test_marginals_over_random_wire_sets(dtype):
+    """dq_marginal_*: every size 1 .. n of measured set, in random outcome-bit order, for states smaller and larger than a
+    workgroup's 4096-amplitude chunk, against permute / reshape / sum of |psi|^2 in float64 (reference qmath.py:624-626).
+    The sets cover measured bits inside the chunk's contiguous part, among the bits a thread holds itself, and outside."""
+    rng = random.Random(77)
+    for n, b in ((1, 2), (2, 3), (5, 2), (9, 3), (12, 2), (13, 2), (17, 2)):
+        x = rand_state(b, n, dtype, 60 + n)
+        xd = x.to(dev())
+        p = (x.to(torch.complex128).abs() ** 2).reshape([b] + [2] * n)
+        sets = [rng.sample(range(n), rng.randint(1, n)) for _ in range(6)] + [list(range(min(n, 5))), [n - 1], [0]]
+        if n >= 13:
+            sets += [[0, 9, 10, 11], [8, 9, 10, 11], [12, 0], list(range(7, n)), list(range(12))]
+        for bits in sets:
+            got = backend.marginal(xd, bits).cpu()
+            axes = [1 + (n - 1 - q) for q in bits]
+            ref = p.permute([0] + axes + [a for a in range(1, n + 1) if a not in axes]).reshape(b, 1 << len(bits), -1).sum(-1)
+            assert got.shape == ref.shape
+            assert (got - ref).abs().max().item() < (1e-9 if dtype == torch.complex64 else 1e-13), (n, bits)
 
 
 @pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])

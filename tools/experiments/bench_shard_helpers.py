@@ -30,3 +30,31 @@ for name, src in cases.items():
     print(f'permute_bits {name:40s} {ms:7.2f} ms  {nbytes / ms / 1e6:7.0f} GB/s')
 ms = timeit(lambda: backend.pack(x, 1 << (n - 1), 1 << (n - 1)))
 print(f'pack top bit (incl. its allocation)                    {ms:7.2f} ms  {1.0 * x.numel() * 8 / ms / 1e6:7.0f} GB/s (read half + write half)')
+# ---- reductions (csrc/dq_reduce.hip): bytes = one read of the state(s) ---------------------------------------------------
+x = x / x.norm(dim=-1, keepdim=True)
+y = torch.randn_like(x)
+one = x.numel() * 8
+coefs = torch.randn(x.shape[0], n, dtype=torch.float64, device=x.device)
+for name, fn, nbytes_ in (
+        ('expect_pauli Z0', lambda: backend.expect_pauli(x, 0, 1 << (n - 1)), one),
+        ('expect_pauli X0 Z3', lambda: backend.expect_pauli(x, 1 << (n - 1), 1 << (n - 4)), one),
+        ('expect_pauli X(bit 0)', lambda: backend.expect_pauli(x, 1, 0), one),
+        ('expect_z_multi (8 strings)', lambda: backend.expect_z_multi(x, [1 << q for q in range(8)]), one),
+        ('expect_z_multi (28 ring ZZ strings)', lambda: backend.expect_z_multi(x, [(1 << q) | (1 << ((q + 1) % n)) for q in range(n)]), one),
+        ('scale_z_signs (28 ring ZZ strings)', lambda: backend.scale_z_signs(x, [(1 << q) | (1 << ((q + 1) % n)) for q in range(n)], coefs), 2 * one),
+        ('inner', lambda: backend.inner(x, y), 2 * one),
+        ('probs', lambda: backend.probs(x), one + one // 2),
+        ('marginal 5 low wires', lambda: backend.marginal(x, [0, 1, 2, 3, 4]), one),
+        ('marginal 5 high wires', lambda: backend.marginal(x, [n - 1, n - 2, n - 3, n - 4, n - 5]), one),
+        ('marginal 14 wires (bits 7..20)', lambda: backend.marginal(x, list(range(7, 21))), one),
+        ('marginal 14 low wires', lambda: backend.marginal(x, list(range(14))), one),
+        ('marginal bits 0, 9, 10, 11', lambda: backend.marginal(x, [0, 9, 10, 11]), one),
+        ('marginal 12 spread wires', lambda: backend.marginal(x, list(range(1, 25, 2))), one),
+        ('marginal all wires, batch 1', lambda: backend.marginal(x[:1], list(range(n))), one // x.shape[0]),
+        ('gate_grad target 5', lambda: backend.gate_grad(x, y, [5], []), 2 * one),
+        ('gate_grad target 27 ctrl 3', lambda: backend.gate_grad(x, y, [27], [3]), 2 * one)):
+    try:
+        ms = timeit(fn)
+        print(f'{name:34s} {ms:7.2f} ms  {nbytes_ / ms / 1e6:7.0f} GB/s')
+    except Exception as e:
+        print(f'{name:34s} failed: {type(e).__name__} {str(e)[:80]}')
