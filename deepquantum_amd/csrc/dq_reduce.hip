@@ -458,11 +458,19 @@ __global__ __launch_bounds__(RED_THREADS) void expect_zmulti_mfma_kernel(const c
     zm_f64x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     const uint64_t dim = 1ull << n, stride = (uint64_t)gridDim.x * RED_THREADS;
     constexpr int U = sizeof(T) == 4 ? 8 : 4;       // loads in flight per lane
-    for (uint64_t i0 = (uint64_t)blockIdx.x * RED_THREADS + wave * 64; i0 < dim; i0 += U * stride) {
+    unsigned pu0 = 0, pu1 = 0;                      // bit u: parity of the slice number's bits under the lane's masks
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        pu0 |= (unsigned)(__popcll((uint64_t)(u * RED_THREADS) & m0) & 1) << u;
+        pu1 |= (unsigned)(__popcll((uint64_t)(u * RED_THREADS) & m1) & 1) << u;
+    }
+    // (a workgroup reads U consecutive slices of 256 amplitudes, the grid a contiguous window per iteration: loads that
+    // are in flight together stay within a few DRAM pages instead of U addresses a whole grid stride apart)
+    for (uint64_t i0 = (uint64_t)blockIdx.x * (U * RED_THREADS) + wave * 64; i0 < dim; i0 += U * stride) {
         double pr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint64_t i = i0 + u * stride;
+            const uint64_t i = i0 + u * RED_THREADS;
             if (i < dim) {
                 const cx<T> a = p[i + lane];
                 pr[u] = (double)a.x * a.x + (double)a.y * a.y;
@@ -470,11 +478,17 @@ __global__ __launch_bounds__(RED_THREADS) void expect_zmulti_mfma_kernel(const c
                 pr[u] = 0.0;
             }
         }
+        // +-1.0 with the sign bit = parity of (i & mask); the slice number u only touches bits 8.. of i0 (zero there)
+        const uint64_t iq = i0 | (uint64_t)(q << 4);
+        const unsigned par0 = __popcll(iq & m0), par1 = __popcll(iq & m1);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint64_t i = (i0 + u * stride) | (uint64_t)(q << 4);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((__popcll(i & m0) & 1) ? -1.0 : 1.0, pr[u], acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((__popcll(i & m1) & 1) ? -1.0 : 1.0, pr[u], acc1, 0, 0, 0);
+            const double a0 = __hiloint2double((int)((((par0 ^ (pu0 >> u)) & 1u) << 31) | 0x3ff00000u), 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, pr[u], acc0, 0, 0, 0);
+            if (two) {
+                const double a1 = __hiloint2double((int)((((par1 ^ (pu1 >> u)) & 1u) << 31) | 0x3ff00000u), 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, pr[u], acc1, 0, 0, 0);
+            }
         }
     }
     // D: register r of lane (q, j) = row q + 4 r, column j
