@@ -145,65 +145,7 @@ __global__ __launch_bounds__(256) void probs_kernel(const cx<T>* __restrict__ ps
     }
 }
 
-// One block = (batch sample, outcome o, chunk of the unmeasured bits).  Every amplitude is read once;
-// reads stay coalesced as long as the low index bits are unmeasured.
-template <typename T>
-__global__ __launch_bounds__(RED_THREADS) void marginal_kernel(const cx<T>* __restrict__ psi, int n, BitList sorted,
-                                                                BitList order, int64_t batch, double* __restrict__ out) {
-    const int nw = order.n;
-    const uint64_t o = blockIdx.y % (1u << nw);
-    const int64_t b = blockIdx.y >> nw;
-    uint64_t value = 0;
-    for (int i = 0; i < nw; ++i) value |= ((o >> (nw - 1 - i)) & 1ull) << order.pos[i];
-    const cx<T>* p = psi + ((uint64_t)b << n);
-    const uint64_t rest = 1ull << (n - nw);
-    double acc = 0, dummy = 0;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rest;
-         r += (uint64_t)gridDim.x * blockDim.x) {
-        const cx<T> a = p[insert_zeros(r, sorted) | value];
-        acc += (double)a.x * a.x + (double)a.y * a.y;
-    }
-    block_sum2(acc, dummy);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out + ((size_t)b << nw) + o, acc);
-}
-
-// More than 12 measured bits (up to all n): a block owns 2^c contiguous amplitudes (c = min(12, n)), adds |psi|^2 into an
-// LDS histogram over the measured bits BELOW c -- reads stay coalesced whatever is measured -- and then adds the
-// histogram to the rows of `out` that the measured bits at or above c select (one atomic per local outcome and block:
-// 2^(n - c + measured bits below c) in all, instead of one per amplitude).
-struct WideGeom {
-    int nlo, nhi;
-    uint8_t lo_pos[12], lo_out[12];     // measured index bit < c -> bit of the outcome index
-    uint8_t hi_pos[40], hi_out[40];     // measured index bit >= c
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void marginal_wide_kernel(const cx<T>* __restrict__ psi, int n, int c, int nw, WideGeom g,
-                                                            double* __restrict__ out) {
-    extern __shared__ double hist[];
-    const unsigned nloc = 1u << g.nlo;
-    for (unsigned j = threadIdx.x; j < nloc; j += 256) hist[j] = 0.0;
-    __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x << c;
-    const cx<T>* p = psi + ((uint64_t)blockIdx.y << n) + base;
-    for (unsigned i = threadIdx.x; i < (1u << c); i += 256) {
-        const cx<T> a = p[i];
-        unsigned j = 0;
-        for (int t = 0; t < g.nlo; ++t) j |= ((i >> g.lo_pos[t]) & 1u) << t;
-        unsafeAtomicAdd(&hist[j], (double)a.x * a.x + (double)a.y * a.y);
-    }
-    __syncthreads();
-    uint64_t hi = 0;
-    for (int t = 0; t < g.nhi; ++t) hi |= ((base >> g.hi_pos[t]) & 1ull) << g.hi_out[t];
-    double* row = out + ((size_t)blockIdx.y << nw);
-    for (unsigned j = threadIdx.x; j < nloc; j += 256) {
-        uint64_t o = hi;
-        for (int t = 0; t < g.nlo; ++t) o |= (uint64_t)((j >> t) & 1u) << g.lo_out[t];
-        unsafeAtomicAdd(row + o, hist[j]);
-    }
-}
-
-// Marginals, general kernel: a block owns a "chunk" of 2^c amplitudes (c = min(12, n)) whose index bits are the low L bits
+// Marginals: a block owns a "chunk" of 2^c amplitudes (c = min(12, n)) whose index bits are the low L bits
 // (1 KiB of contiguous state) plus the lowest UNMEASURED bits above them, so as much of the sum over the unmeasured bits
 // as possible happens inside the block.  A thread holds the 16 amplitudes that differ in the chunk's top four bits
 // (unmeasured whenever five unmeasured bits exist above L), issues all 16 loads before it uses any, adds them up, and adds
@@ -685,8 +627,7 @@ static int marginal_impl(const void* psi, int n, const int* bits, int nw, int64_
         set_error("dq_marginal: batch %lld exceeds 65535", (long long)batch);
         return DQ_ERR_UNSUPPORTED;
     }
-    static const int legacy = [] { const char* e = getenv("DQ_MARGINAL_LEGACY"); return e ? atoi(e) : 0; }();
-    if (!legacy) {
+    {
         constexpr int VEC = sizeof(T) == 4 ? 2 : 1;
         const int c = n < 12 ? n : 12;
         const int low = n < 8 - VEC ? n : 8 - VEC;          // 1 KiB of contiguous state: 7 bits complex64, 6 complex128
@@ -735,40 +676,6 @@ static int marginal_impl(const void* psi, int n, const int* bits, int nw, int64_
                            sizeof(double) << g.nlo, as_stream(stream), static_cast<const cx<T>*>(psi), n, nw, g, out);
         return check_launch("dq_marginal");
     }
-    if (nw > 12) {
-        if (batch > 65535) {
-            set_error("dq_marginal: batch %lld exceeds 65535", (long long)batch);
-            return DQ_ERR_UNSUPPORTED;
-        }
-        const int c = n < 12 ? n : 12;
-        WideGeom g{};
-        for (int i = 0; i < nw; ++i) {          // bits[i] <-> outcome bit nw - 1 - i
-            if (bits[i] < c) {
-                g.lo_pos[g.nlo] = (uint8_t)bits[i];
-                g.lo_out[g.nlo++] = (uint8_t)(nw - 1 - i);
-            } else {
-                g.hi_pos[g.nhi] = (uint8_t)(bits[i]);
-                g.hi_out[g.nhi++] = (uint8_t)(nw - 1 - i);
-            }
-        }
-        hipLaunchKernelGGL(marginal_wide_kernel<T>, dim3((unsigned)(1ull << (n - c)), (unsigned)batch), dim3(256),
-                           sizeof(double) << g.nlo, as_stream(stream), static_cast<const cx<T>*>(psi), n, c, nw, g, out);
-        return check_launch("dq_marginal");
-    }
-    if (((uint64_t)batch << nw) > 65535) {
-        set_error("dq_marginal: batch * 2^nw = %llu exceeds 65535", (unsigned long long)((uint64_t)batch << nw));
-        return DQ_ERR_UNSUPPORTED;
-    }
-    BitList sorted, order;
-    sort_bits(bits, nw, sorted);
-    order.n = nw;
-    for (int i = 0; i < nw; ++i) order.pos[i] = bits[i];
-    const uint64_t rest = 1ull << (n - nw);
-    uint64_t nb = (rest + RED_THREADS - 1) / RED_THREADS;
-    if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(marginal_kernel<T>, dim3((unsigned)nb, (unsigned)((uint64_t)batch << nw)), dim3(RED_THREADS), 0,
-                       as_stream(stream), static_cast<const cx<T>*>(psi), n, sorted, order, batch, out);
-    return check_launch("dq_marginal");
 }
 
 

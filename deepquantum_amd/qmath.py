@@ -205,7 +205,7 @@ def measure(
                 all_probs = all_probs.reshape([batch] + [2] * n).permute(pm).reshape(batch, 2 ** len(wires), -1).sum(-1)
         elif wires is None or len(wires) == n:
             all_probs = backend.probs(flat)
-        else:           # one read of the state whatever the number of wires (dq_marginal_*: LDS histograms above 12)
+        else:           # one read of the state whatever the number of wires (dq_marginal_*)
             all_probs = backend.marginal(flat, [n - 1 - w for w in wires]).to(flat.real.dtype)
     results = []
     for i in range(batch):

@@ -350,8 +350,9 @@ int dq_probs_c128(const void* psi, void* probs, int64_t count, dq_stream_t strea
 
 /* Marginal distribution over `nw` bit positions (host array, bits[0] = MSB of the outcome index):
  * out[b, o] = sum over the other bits of |psi|^2, double precision, out must be zeroed by the
- * caller.  1 <= nw <= n (up to 12 bits: one block per outcome and chunk, batch * 2^nw <= 65535; more: a block per 2^12
- * amplitudes with a histogram in LDS over the measured low bits).  Replaces the permute/reshape/sum of qmath.py:626. */
+ * caller.  1 <= nw <= n <= 40, batch <= 65535, psi 16-byte aligned.  A workgroup owns 2^12 amplitudes (the low index
+ * bits plus the lowest unmeasured ones) with a histogram in LDS over the measured bits among them: reads are coalesced
+ * whatever the measured bits are.  Replaces the permute/reshape/sum of qmath.py:626. */
 int dq_marginal_c64(const void* psi, int n, const int* bits, int nw, int64_t batch, double* out,
                     dq_stream_t stream);
 int dq_marginal_c128(const void* psi, int n, const int* bits, int nw, int64_t batch, double* out,

@@ -173,7 +173,7 @@ def test_sampling_a_state_of_more_than_one_block():
     want = {a + '00' + '1' + '0' * (n - 5) + c for a in '01' for c in '01'}
     assert set(res) <= want and sum(res.values()) == 400
     assert all(40 < res.get(k, 0) < 170 for k in want), res
-    res = cir.measure(shots=200, wires=list(range(13)), with_prob=True)          # 13 wires: the wide marginal kernel
+    res = cir.measure(shots=200, wires=list(range(13)), with_prob=True)          # 13 wires
     assert set(res) <= {'0001' + '0' * 9, '1001' + '0' * 9} and all(abs(float(v[1]) - 0.5) < 1e-6 for v in res.values())
 
 

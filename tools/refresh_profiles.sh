@@ -41,4 +41,5 @@ bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
 } > "$root/two_ranks_one_gpu_functional.txt" 2>&1
 python tools/bench_dense.py 2>&1 | grep -v amdgpu.ids > "$root/bench_dense.txt"
 python tools/crosscheck_large.py 2>&1 | grep -v amdgpu.ids > "$root/crosscheck_large.txt"
+python tools/experiments/bench_shard_helpers.py 2>&1 | grep -v amdgpu.ids > "$root/shard_helpers_and_reductions.txt"
 ls -la "$root"
