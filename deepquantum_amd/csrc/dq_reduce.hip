@@ -146,15 +146,19 @@ __global__ __launch_bounds__(256) void probs_kernel(const cx<T>* __restrict__ ps
 }
 
 // Marginals: a block owns a "chunk" of 2^c amplitudes (c = min(12, n)) whose index bits are the low L bits
-// (1 KiB of contiguous state) plus the lowest UNMEASURED bits above them, so as much of the sum over the unmeasured bits
-// as possible happens inside the block.  A thread holds the 16 amplitudes that differ in the chunk's top four bits
-// (unmeasured whenever five unmeasured bits exist above L), issues all 16 loads before it uses any, adds them up, and adds
-// the sum into an LDS histogram over the measured chunk bits; the block then adds the histogram to the rows of `out`
-// that the measured bits outside the chunk select: 2^nlo atomics per 4096 amplitudes, whatever the measured wires are.
+// (1 KiB of contiguous state) plus UNMEASURED bits above them as far as there are any (then measured ones, lowest outcome
+// bit first), so as much of the sum over the unmeasured bits as possible happens inside the block.  A thread holds the
+// 16 amplitudes that differ in the chunk-local bits 8..11 (the unmeasured candidates go there first), issues all 16
+// loads before it uses any, adds them up, and adds the sum into an LDS histogram over the measured chunk bits; the
+// block then adds the histogram to the rows of `out` that the measured bits outside the chunk select.  The chunk NUMBER
+// counts through the unmeasured bits outside the chunk first, wherever they are: a run of 2^run chunk numbers shares its
+// rows of `out`, is taken by one block, and costs one set of 2^nlo atomics.
 struct MargGeom {                       // unused entries are padded so that the kernel needs no guards (see below)
     int c, nlo, run, exclusive;
     unsigned qmask;                     // measured ones among the four chunk-local bits a thread holds itself
-    uint8_t pos[12];                    // chunk-local bit i <-> index bit pos[i], ascending          (pad: 62)
+    uint8_t pos[12];                    // chunk-local bit i <-> index bit pos[i]                     (pad: 62)
+    uint8_t cpos[28];                   // bit t of the chunk number <-> index bit cpos[t]: the unmeasured bits outside
+                                        // the chunk first (a run of chunks shares its result rows)  (pad: 63)
     uint8_t lo_x[12], lo_out[12];       // measured chunk-local bit -> bit of the outcome index       (pad: 31, 0)
     uint8_t hi_pos[40], hi_out[40];     // measured index bit outside the chunk -> outcome bit        (pad: 63, 0)
 };
@@ -188,9 +192,9 @@ __global__ __launch_bounds__(256) void marginal_chunk_kernel(const cx<T>* __rest
     uint64_t base0 = 0;
     double s = 0;
     for (uint64_t ci = (uint64_t)blockIdx.x << g.run; ci < ((uint64_t)blockIdx.x + 1) << g.run; ++ci) {
-        uint64_t base = ci;
+        uint64_t base = 0;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) base = insert_zero(base, g.pos[i]);
+        for (int t = 0; t < 28; ++t) base |= ((ci >> t) & 1ull) << g.cpos[t];
         if (ci == (uint64_t)blockIdx.x << g.run) base0 = base;
         const cx<T>* p = psi + ((uint64_t)blockIdx.y << n) + base;
         cx<T> a[16];
@@ -638,38 +642,52 @@ static int marginal_impl(const void* psi, int n, const int* bits, int nw, int64_
         memset(g.pos, 62, sizeof g.pos);
         memset(g.lo_x, 31, sizeof g.lo_x);
         memset(g.hi_pos, 63, sizeof g.hi_pos);
-        for (int b = 0; b < low; ++b) in_chunk |= 1ull << b;
-        int have = low;
-        for (int pass = 0; pass < 2 && have < c; ++pass)      // unmeasured bits first, then measured ones
-            for (int b = low; b < n && have < c; ++b)
-                if (!((in_chunk >> b) & 1ull) && (int)((measured >> b) & 1ull) == pass) {
-                    in_chunk |= 1ull << b;
-                    ++have;
+        memset(g.cpos, 63, sizeof g.cpos);
+        int out_of[40];                                       // bits[i] <-> outcome bit nw - 1 - i
+        for (int i = 0; i < nw; ++i) out_of[bits[i]] = nw - 1 - i;
+        // candidates for the chunk's bits above the contiguous part: unmeasured ones (ascending), then measured ones by
+        // outcome bit (so that what a workgroup adds to the result is as contiguous as it can be)
+        int cand[40], ncand = 0;
+        for (int b = low; b < n; ++b)
+            if (!((measured >> b) & 1ull)) cand[ncand++] = b;
+        for (int o = 0; o < nw; ++o)
+            for (int b = low; b < n; ++b)
+                if (((measured >> b) & 1ull) && out_of[b] == o) cand[ncand++] = b;
+        // the four bits a thread holds itself (chunk-local 8..11) are served first: unmeasured there = one sum per thread
+        int local_of[40], next = 0;
+        for (int b = 0; b < low; ++b) {
+            g.pos[b] = (uint8_t)b;
+            local_of[b] = b;
+            in_chunk |= 1ull << b;
+        }
+        for (int pass = 0; pass < 2; ++pass)
+            for (int x = pass == 0 ? 8 : low; x < (pass == 0 ? c : (c < 8 ? c : 8)); ++x) {
+                g.pos[x] = (uint8_t)cand[next];
+                local_of[cand[next]] = x;
+                in_chunk |= 1ull << cand[next++];
+            }
+        int nhi = 0;
+        for (int o = 0; o < nw; ++o)                          // histogram bit t <-> the t-th lowest outcome bit of the chunk
+            for (int i = 0; i < nw; ++i) {
+                if (nw - 1 - i != o) continue;
+                if ((in_chunk >> bits[i]) & 1ull) {
+                    const int x = local_of[bits[i]];
+                    g.lo_x[g.nlo] = (uint8_t)x;
+                    g.lo_out[g.nlo++] = (uint8_t)o;
+                    if (x >= 8) g.qmask |= 1u << (x - 8);
+                } else {
+                    g.hi_pos[nhi] = (uint8_t)bits[i];
+                    g.hi_out[nhi++] = (uint8_t)o;
                 }
-        int local_of[40], nc = 0, nhi = 0;
-        for (int b = 0; b < n; ++b)
-            if ((in_chunk >> b) & 1ull) {
-                local_of[b] = nc;
-                g.pos[nc++] = (uint8_t)b;
             }
-        for (int i = 0; i < nw; ++i) {                        // bits[i] <-> outcome bit nw - 1 - i
-            if ((in_chunk >> bits[i]) & 1ull) {
-                const int x = local_of[bits[i]];
-                g.lo_x[g.nlo] = (uint8_t)x;
-                g.lo_out[g.nlo++] = (uint8_t)(nw - 1 - i);
-                if (x >= 8) g.qmask |= 1u << (x - 8);
-            } else {
-                g.hi_pos[nhi] = (uint8_t)bits[i];
-                g.hi_out[nhi++] = (uint8_t)(nw - 1 - i);
-            }
-        }
         g.exclusive = nhi == n - c;
-        int run = 0;                                          // the lowest bits outside the chunk that are unmeasured
-        for (int b = 0; b < n; ++b) {
-            if ((in_chunk >> b) & 1ull) continue;
-            if ((measured >> b) & 1ull) break;
-            ++run;
-        }
+        int run = 0, nt = 0;                                  // the chunk number: unmeasured bits first
+        for (int pass = 0; pass < 2; ++pass)
+            for (int b = 0; b < n; ++b)
+                if (!((in_chunk >> b) & 1ull) && (int)((measured >> b) & 1ull) == pass) {
+                    g.cpos[nt++] = (uint8_t)b;
+                    run += pass == 0;
+                }
         while (run > 0 && ((1ull << (n - c - run)) * (uint64_t)batch < 2048)) --run;      // keep the chip busy
         g.run = run;
         hipLaunchKernelGGL(marginal_chunk_kernel<T>, dim3((unsigned)(1ull << (n - c - run)), (unsigned)batch), dim3(256),

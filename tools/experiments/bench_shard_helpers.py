@@ -50,7 +50,9 @@ for name, fn, nbytes_ in (
         ('marginal 14 low wires', lambda: backend.marginal(x, list(range(14))), one),
         ('marginal bits 0, 9, 10, 11', lambda: backend.marginal(x, [0, 9, 10, 11]), one),
         ('marginal 12 spread wires', lambda: backend.marginal(x, list(range(1, 25, 2))), one),
-        ('marginal all wires, batch 1', lambda: backend.marginal(x[:1], list(range(n))), one // x.shape[0]),
+        ('marginal all wires bit-reversed, batch 1', lambda: backend.marginal(x[:1], list(range(n))), one // x.shape[0] * 2),
+        ('marginal all wires in order, batch 1', lambda: backend.marginal(x[:1], list(range(n - 1, -1, -1))), one // x.shape[0] * 2),
+        ('marginal 27 of 28 wires, batch 1', lambda: backend.marginal(x[:1], [q for q in range(n - 1, -1, -1) if q != 13]), one // x.shape[0] * 3 // 2),
         ('gate_grad target 5', lambda: backend.gate_grad(x, y, [5], []), 2 * one),
         ('gate_grad target 27 ctrl 3', lambda: backend.gate_grad(x, y, [27], [3]), 2 * one)):
     try:
