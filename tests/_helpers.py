@@ -760,3 +760,72 @@ def check_fused_sweep_with_sloppy_user_matrices(dq, device=None, n=12, tol=2e-5)
     worst = max((x - y).abs().max().item() for x, y in zip(results['per_gate'], results['adjoint'], strict=True))
     assert worst < tol, worst
     assert math.isfinite(worst)
+
+
+def check_module_dtype_and_device(dq, device=None):
+    """The reference's tests/test_module.py:7-42, the QubitCircuit part: a circuit inside an nn.Module follows
+    .double() (every buffer float64 / complex128) and .to(device), and still runs afterwards."""
+    from torch import nn
+
+    class Model(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.cir_qubit = dq.QubitCircuit(1)
+            self.cir_qubit.h(0)
+            self.cir_qubit.hamiltonian([[1, 'x0'], [1, 'y0'], [1, 'z0']], encode=True)
+            self.cir_qubit.observable(0)
+            self.cir_two = dq.QubitCircuit(3)
+            self.cir_two.hlayer()
+            self.cir_two.rxlayer(encode=True)
+            self.cir_two.cnot_ring()
+            self.cir_two.observable(1)
+
+    model = Model()
+    model.double()
+    assert len(list(model.buffers())) > 0
+    for buffer in model.buffers():
+        assert buffer.dtype in (torch.double, torch.cdouble)
+    if device is not None:
+        model.to(device)
+        for buffer in model.buffers():
+            assert buffer.device.type == torch.device(device).type
+    data = torch.tensor([0.3, 0.2, 0.1], dtype=torch.double, device=device)
+    state = model.cir_two(data=data)
+    assert state.dtype == torch.cdouble and (device is None or state.device.type == torch.device(device).type)
+    ev = model.cir_two.expectation()
+    # H, Rx(t), CNOT ring: <Z1> by hand from the oracle-free closed form is not needed -- float32 and float64 agree
+    model.float()
+    for buffer in model.buffers():
+        assert buffer.dtype in (torch.float, torch.cfloat)
+    state32 = model.cir_two(data=data.float())
+    assert state32.dtype == torch.cfloat
+    assert (state32.to(torch.cdouble) - state).abs().max().item() < 1e-6
+    assert (model.cir_two.expectation().double() - ev).abs().max().item() < 1e-6
+
+
+# made with the real reference (tests/golden/make_golden.py:import_reference): QubitCircuit(10), per wire h / rx / ry / rz
+# (encode=True), cnot_ring, data = torch.randn(4, 30, generator=manual_seed(3)); get_amplitude('0101010101')
+GET_AMPLITUDE_REF = [(2.5445e-05, 4.693e-05), (-0.001651335, 0.003223858), (0.001179231, 0.000622286),
+                     (0.012580904, 0.012054744)]
+
+
+def check_get_amplitude(dq, device=None):
+    """The reference's tests/test_get_amplitude.py:6-34 (its dense half; the MPS half is out of scope): batched data,
+    one amplitude per sample, against the values the reference returns for the same seed."""
+    n = 10
+    data = torch.randn(4, 3 * n, generator=torch.Generator().manual_seed(3))
+    cir = dq.QubitCircuit(nqubit=n)
+    for i in range(n):
+        cir.h(i)
+        cir.rx(i, encode=True)
+        cir.ry(i, encode=True)
+        cir.rz(i, encode=True)
+    cir.cnot_ring()
+    if device is not None:
+        cir.to(device)
+        data = data.to(device)
+    cir(data=data)
+    amp = cir.get_amplitude('0101010101').reshape(-1).cpu()
+    ref = torch.tensor([complex(*v) for v in GET_AMPLITUDE_REF], dtype=amp.dtype)
+    assert amp.shape == (4,)
+    assert (amp - ref).abs().max().item() < 1e-6

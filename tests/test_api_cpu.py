@@ -7,7 +7,8 @@ import pytest
 import torch
 
 import deepquantum_amd as dq
-from _helpers import CDTYPE, TOL, check_circuit_against_golden, gold, specs
+from _helpers import (CDTYPE, TOL, check_circuit_against_golden, check_get_amplitude, check_module_dtype_and_device, gold,
+                      specs)
 
 
 @pytest.mark.parametrize('name', ['readme', 'zoo5', 'rand4', 'rand8', 'rand12', 'batched10'])
@@ -391,3 +392,11 @@ def test_fused_reverse_sweep_with_user_matrices_that_are_unitary_to_1e_4_only(cp
     from _helpers import check_fused_sweep_with_sloppy_user_matrices
 
     check_fused_sweep_with_sloppy_user_matrices(dq, n=12)
+
+
+def test_circuit_inside_a_module_follows_dtype_and_device(cpu_backend):
+    check_module_dtype_and_device(dq)
+
+
+def test_get_amplitude_matches_reference(cpu_backend):
+    check_get_amplitude(dq)

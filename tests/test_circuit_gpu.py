@@ -707,3 +707,17 @@ def test_user_matrices_with_foreign_strides_and_pending_conjugation():
     with pytest.raises(ValueError, match='pending conjugation'):
         from deepquantum_amd import backend
         backend._ptr(u_col.mH)
+
+
+@pytest.mark.gpu
+def test_circuit_inside_a_module_follows_dtype_and_device_on_gpu():
+    from _helpers import check_module_dtype_and_device
+
+    check_module_dtype_and_device(dq, device=dev())
+
+
+@pytest.mark.gpu
+def test_get_amplitude_matches_reference_on_gpu():
+    from _helpers import check_get_amplitude
+
+    check_get_amplitude(dq, device=dev())

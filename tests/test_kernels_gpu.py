@@ -508,7 +508,8 @@ def test_assembly_gate_loop_matches_oracle(is128, n, seed):
 @pytest.mark.parametrize('n,batch', [(5, 2), (11, 3), (12, 1), (13, 2), (17, 3), (22, 1)])
 def test_permute_bits_against_index_arithmetic(dtype, n, batch):
     """dq_permute_bits (the relayout before an all-to-all, the canonical order afterwards): out[i] = in[sigma(i)], every kernel
-    variant -- per-element below 2^12, tiled with 16-byte pairs when bit 0 stays (complex64) and without."""
+    variant -- per-element below 2^12, tiled with 16-byte pairs when bit 0 stays (complex64) and without, through LDS tiles
+    when the low destination bits come from high source bits."""
     import random
 
     rng = random.Random(n)
@@ -516,7 +517,9 @@ def test_permute_bits_against_index_arithmetic(dtype, n, batch):
     x = (torch.randn(batch, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(batch, 1 << n, generator=g, dtype=torch.float64)).to(dtype)
     idx = torch.arange(1 << n)
     perms = [list(range(n)), rng.sample(range(n), n), [0] + [1 + q for q in rng.sample(range(n - 1), n - 1)],
-             list(range(1, n)) + [0], [q for q in range(n) if q not in (n - 3, n - 2)] + [n - 3, n - 2]]
+             list(range(1, n)) + [0], [q for q in range(n) if q not in (n - 3, n - 2)] + [n - 3, n - 2],
+             list(range(n))[::-1], [n - 1] + list(range(n - 1)), [1, 0] + list(range(2, n))]
+    perms += [rng.sample(range(n), n) for _ in range(5 if n <= 17 else 1)]
     for src_of_dst in perms:
         sidx = torch.zeros(1 << n, dtype=torch.long)
         for p, sp in enumerate(src_of_dst):
