@@ -527,3 +527,43 @@ def test_permute_bits_against_index_arithmetic(dtype, n, batch):
         out = torch.empty_like(x, device=dev())
         backend.permute_bits(x.to(dev()), src_of_dst, out=out)
         assert torch.equal(out.cpu(), x[:, sidx]), src_of_dst
+
+
+def test_reductions_and_relayout_at_full_size():
+    """Size-independent properties at the headline's size (n = 28, complex64, one sample = 2 GiB), where no CPU reference
+    finishes in seconds: marginals are consistent with each other and with the norm whatever bits are measured, the
+    matrix-core sums over Z strings equal the one-string kernel, scale_z_signs is its own inverse for a single string,
+    and permute_bits followed by the inverse permutation is the identity bit for bit (both kernel variants)."""
+    import random
+
+    n = 28
+    g = torch.Generator(device=dev()).manual_seed(28)
+    x = torch.randn(1, 1 << n, 2, generator=g, device=dev(), dtype=torch.float32)
+    x = torch.view_as_complex(x / x.norm()).contiguous()
+    rng = random.Random(28)
+    norm2 = backend.probs(x).double().sum().item()
+    assert abs(norm2 - 1.0) < 1e-5
+    for _ in range(4):
+        big = rng.sample(range(n), rng.randint(6, 14))
+        small = big[: rng.randint(1, 5)]
+        pb = backend.marginal(x, big)                                   # (1, 2^len(big)), bits[0] = MSB
+        ps = backend.marginal(x, small)
+        assert abs(pb.sum().item() - norm2) < 1e-9 and abs(ps.sum().item() - norm2) < 1e-9
+        folded = pb.reshape(1, 1 << len(small), -1).sum(-1)             # the leading bits of `big` are `small`
+        assert (folded - ps).abs().max().item() < 1e-10, (big, small)
+    masks = [rng.randrange(1, 1 << n) for _ in range(20)] + [1, 1 << (n - 1), (1 << n) - 1]
+    many = backend.expect_z_multi(x, masks)
+    for k, z in enumerate(masks):
+        assert abs(many[0, k].item() - backend.expect_pauli(x, 0, z)[0].item()) < 1e-10, hex(z)
+    one = torch.ones(1, 1, dtype=torch.float64, device=dev())
+    y = backend.scale_z_signs(backend.scale_z_signs(x, [masks[0]], one), [masks[0]], one)
+    assert torch.equal(y, x)
+    for perm in (rng.sample(range(n), n), [1, 0] + list(range(2, n)), list(range(1, n)) + [0]):
+        inv = [0] * n
+        for p, sp in enumerate(perm):
+            inv[sp] = p
+        a = torch.empty_like(x)
+        b = torch.empty_like(x)
+        backend.permute_bits(x, perm, out=a)
+        backend.permute_bits(a, inv, out=b)
+        assert torch.equal(b, x), perm
