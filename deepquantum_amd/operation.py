@@ -167,9 +167,20 @@ class Gate(Operation):
     def prims(self, decompose: bool = True) -> list[Prim]:
         """The gate as kernel primitives.  ``decompose=True`` may split permutation gates into
         CNOT-like bit flips (exactly equal results, cheaper in the fused kernel)."""
+        m = self.update_matrix()
+        # the same matrix object (at the same version: no in-place write since) on the same wires as last time: the same
+        # (immutable) primitives -- a gate with fixed
+        # angles costs a forward one dictionary look-up instead of a Prim and two tuples
+        d = self.__dict__
+        c = d.get('_prims_cache')
+        if (c is not None and c[0] is m and c[5] == m._version and c[1] == self.wires and c[2] == self.controls
+                and c[3] == self.nqubit):
+            return c[4]
         mode = self._kernel_mode if len(self.wires) == 1 else 0
-        return [Prim(self._kernel_kind, self.update_matrix(), self._bits(self.wires), self._bits(self.controls), mode,
-                     exact=getattr(self, '_exact_unitary', True))]
+        out = [Prim(self._kernel_kind, m, self._bits(self.wires), self._bits(self.controls), mode,
+                    exact=getattr(self, '_exact_unitary', True))]
+        d['_prims_cache'] = (m, list(self.wires), list(self.controls), self.nqubit, out, m._version)
+        return out
 
     def dm_prims(self, decompose: bool = True) -> list[Prim]:
         """The gate acting on a vectorised density matrix (row bits n..2n-1, column bits 0..n-1):
