@@ -144,7 +144,13 @@ class QubitCircuit(Operation):
             for op in self.operators:
                 prims.extend(op.dm_prims())
             return executor.run(flat, prims)
-        if not any(getattr(op, '_state_dependent', False) for op in self.operators):
+        nops = len(self.operators)
+        last = id(self.operators[-1]) if nops else 0
+        dep = self.__dict__.get('_state_dep')          # (operators it was computed for: how many, the last one; answer)
+        if dep is None or dep[0] != nops or dep[1] != last:
+            dep = self.__dict__['_state_dep'] = (nops, last,
+                                                  any(getattr(op, '_state_dependent', False) for op in self.operators))
+        if not dep[2]:
             # no-grad runs: the Z-type observables' values come out of the last pass (executor.run(expect_z=...))
             self._expz = None
             ez = None

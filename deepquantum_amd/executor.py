@@ -79,6 +79,8 @@ CONFIG = {'fuse': True, 'wave': None,     # None = wave-tile kernel where it tak
           # no-grad forwards of circuits with Z-type observables take <Z..Z> from the registers of the last pass
           # (DQ_FG_EXPZ records; wave-tile kernel): `expectation()` then costs no read of the state
           'fused_expectation': True,
+          # reuse merged runs / plan / matrix buffer while a forward sees the same primitive objects at the same versions
+          'steady_cache': True,
           # states smaller than a tile: fuse (batch folded into the index, or zero-padded) from this many gates on
           'small_fuse_min_gates': 6,
           # no-grad runs on states of at least this many amplitudes (batch included) multiply runs of one-qubit gates
@@ -147,14 +149,49 @@ def _geometry(is128: bool, wave: bool = True) -> fusion.Geometry:
     return g
 
 
+# Steady state of an inference loop: the SAME primitive objects (Gate.prims reuses them while a gate's matrix object is
+# unchanged) with matrices at the same versions as last time.  What depends only on them -- the merged one-qubit runs,
+# the extra reduction records of fused expectation values, the plan, the flat matrix buffer -- is kept per list of
+# primitives instead of being rebuilt per forward (config 2, n = 24: the step is host-bound, 3.0 -> ... ms).
+_STEADY: OrderedDict = OrderedDict()
+_STEADY_SIZE = 8
+
+
+def _steady(prims: Sequence[Prim]) -> dict | None:
+    """The cache entry of exactly these primitives (created empty if new or if a matrix was written in place);
+    None when caching is off or a matrix is not a plain tensor (vmap)."""
+    if not CONFIG.get('steady_cache', True) or len(prims) < 16:
+        return None
+    key = tuple(map(id, prims))
+    try:
+        versions = tuple(-1 if p.matrix is None else p.matrix._version for p in prims)
+    except Exception:
+        return None
+    e = _STEADY.get(key)
+    if e is not None and e['versions'] == versions:
+        _STEADY.move_to_end(key)
+        return e
+    e = {'prims': list(prims), 'versions': versions, 'plans': {}, 'flat': {}, 'extra': {}}     # (holds the objects: ids stay theirs)
+    _STEADY[key] = e
+    if len(_STEADY) > _STEADY_SIZE:
+        _STEADY.popitem(last=False)
+    return e
+
+
 def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
-              out_perm: Sequence[int] | None = None, amps: int = 0) -> Plan:
+              out_perm: Sequence[int] | None = None, amps: int = 0, steady: dict | None = None) -> Plan:
     """``amps`` = amplitudes the plan will be run on (batch included): from ``CONFIG['plan_big_amps']`` on a step
     takes long enough (>= 0.1 s) for a wider search of the pass planner to pay for itself within a few steps
     (measured on the headline: 21 -> 20 passes, -2.7 %, 4.6 s of planning once per circuit structure)."""
     geom = _geometry(is128)
-    if geom.wave and not fusion.wave_supports(prims, is128):
-        geom = _geometry(is128, wave=False)
+    if geom.wave:
+        ok = steady.get(('wave_ok', is128)) if steady is not None else None
+        if ok is None:
+            ok = fusion.wave_supports(prims, is128)
+            if steady is not None:
+                steady[('wave_ok', is128)] = ok
+        if not ok:
+            geom = _geometry(is128, wave=False)
     if amps >= CONFIG['plan_big_amps']:
         for g_ in (geom, geom.fallback):
             if g_ is not None:
@@ -167,12 +204,18 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     geom.permute_store = permute
     if geom.fallback is not None:
         geom.fallback.permute_store = permute
-    key = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
-           geom.plan_branch, geom.plan_restarts, geom.asm_loop, geom.free_low, geom.lane_swaps, geom.swap_lanes, geom.swap_policy, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
-           tuple((p.kind, p.targets, p.controls, p.mode, p.order) for p in prims))
+    head = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
+            geom.plan_branch, geom.plan_restarts, geom.asm_loop, geom.free_low, geom.lane_swaps, geom.swap_lanes, geom.swap_policy, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm))
+    if steady is not None:
+        plan = steady['plans'].get(head)
+        if plan is not None and _PLAN_CACHE.get(plan[0]) is plan[1]:     # (still the plan the global cache would give)
+            return plan[1]
+    key = head + (tuple((p.kind, p.targets, p.controls, p.mode, p.order) for p in prims),)
     plan = _PLAN_CACHE.get(key)
     if plan is not None:
         _PLAN_CACHE.move_to_end(key)
+        if steady is not None:
+            steady['plans'][head] = (key, plan)
         return plan
     prim_ops, off = [], 0
     for p in prims:
@@ -193,6 +236,8 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     _PLAN_CACHE[key] = plan
     if len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
         _PLAN_CACHE.popitem(last=False)
+    if steady is not None:
+        steady['plans'][head] = (key, plan)
     return plan
 
 
@@ -262,21 +307,40 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
         return x
     if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']
             and not ops._is_batched(state)):
-        prims = merge_one_qubit_runs(prims)
+        e = _steady(prims)
+        if e is not None and e.get('merged') is not None:
+            prims = e['merged']
+        else:
+            prims = merge_one_qubit_runs(prims)
+            if e is not None:
+                e['merged'] = prims
     if expect_z is not None and expect_z.get('masks') and CONFIG['fused_expectation'] and CONFIG['fuse'] and out_perm is None:
         # ``expect_z = {'masks': [zmask, ..]}``: the Z strings' expectation values of the FINAL state come out of the last
         # pass (``expect_z['values']``, float64 (B, K)) when the wave-tile kernel runs the circuit; untouched otherwise
         n = state.shape[-1].bit_length() - 1
         is128 = state.dtype == torch.complex128
         g_ = _geometry(is128)
-        ops_ = [fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), 0, p.mode) for p in prims]
-        if (g_.wave and n >= g_.m and len(prims) > 0 and fusion.wave_supports(ops_, is128) and not ops._is_batched(state)
+        e = _steady(prims)
+        wave_ok = e.get(('wave_ok', is128)) if e is not None else None
+        if wave_ok is None:
+            wave_ok = fusion.wave_supports([fusion.PrimOp(p.kind, tuple(p.targets), tuple(p.controls), 0, p.mode) for p in prims],
+                                           is128)
+            if e is not None:
+                e[('wave_ok', is128)] = wave_ok
+        if (g_.wave and n >= g_.m and len(prims) > 0 and wave_ok and not ops._is_batched(state)
                 and state.shape[0] <= backend.MAX_BATCH):
             every = tuple(range(n))
-            extra = [Prim('expz', None, (), tuple(q for q in range(n) if (int(z) >> q) & 1), r, order=every)
-                     for r, z in enumerate(expect_z['masks'])]
-            acc = torch.zeros(state.shape[0], len(extra), 8, dtype=torch.float64, device=state.device)
-            out = _run_nograd(state, list(prims) + extra, inplace, scratch, out_perm, grads=acc, amps=amps)
+            mkey = (n, tuple(int(z) for z in expect_z['masks']))
+            both = e['extra'].get(mkey) if e is not None else None
+            if both is None:
+                extra = [Prim('expz', None, (), tuple(q for q in range(n) if (int(z) >> q) & 1), r, order=every)
+                         for r, z in enumerate(expect_z['masks'])]
+                both = list(prims) + extra
+                if e is not None:
+                    e['extra'][mkey] = both
+            nextra = len(expect_z['masks'])
+            acc = torch.zeros(state.shape[0], nextra, 8, dtype=torch.float64, device=state.device)
+            out = _run_nograd(state, both, inplace, scratch, out_perm, grads=acc, amps=amps)
             expect_z['values'] = acc[:, :, 0]
             return out
     return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps)
@@ -448,7 +512,9 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 # what still has to be allocated: the second buffer, and the private working copy unless the caller's
                 # state is updated in place (never here: `inplace` runs do not permute)
                 permute = 2 * nbytes <= CONFIG['permute_mem_frac'] * total and 2.05 * nbytes <= free
-        plan = make_plan(prims, n, is128, permute, out_perm if permute else None, amps=max(state.numel(), amps or 0))
+        steady = _steady(prims)
+        plan = make_plan(prims, n, is128, permute, out_perm if permute else None, amps=max(state.numel(), amps or 0),
+                         steady=steady)
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies
         shared_in = None
@@ -460,12 +526,19 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
             x = state
         else:
             x = state.detach().clone(memory_format=torch.contiguous_format)
-        flat, stride = _flat_mats(prims, plan.mat_order, x.shape[0], x.dtype, x.device)
-        if plan.rx_defer:       # uncontrolled Rx-like gates of complex64 passes: the deferred form (fusion.defer_rx)
-            idx = plan._rx_index.get(x.device)
-            if idx is None:
-                idx = plan._rx_index[x.device] = torch.tensor(plan.rx_defer, dtype=torch.long, device=x.device)
-            fusion.defer_rx(flat, idx)
+        fkey = (id(plan), x.shape[0], x.dtype, x.device)
+        cached = steady['flat'].get(fkey) if steady is not None else None
+        if cached is not None and cached[0] is plan:
+            flat, stride = cached[1], cached[2]
+        else:
+            flat, stride = _flat_mats(prims, plan.mat_order, x.shape[0], x.dtype, x.device)
+            if plan.rx_defer:       # uncontrolled Rx-like gates of complex64 passes: the deferred form (fusion.defer_rx)
+                idx = plan._rx_index.get(x.device)
+                if idx is None:
+                    idx = plan._rx_index[x.device] = torch.tensor(plan.rx_defer, dtype=torch.long, device=x.device)
+                fusion.defer_rx(flat, idx)
+            if steady is not None:
+                steady['flat'] = {fkey: (plan, flat, stride)}       # (one buffer per entry: the latest shape)
         stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0, 'swaps': 0}
         spare = scratch                      # the caller's second buffer (if any)
         other = spare if permute else None

@@ -80,8 +80,15 @@ class DoubleControlGate(DoubleGate):
                          den_mat=den_mat, tsr_mode=tsr_mode)
 
     def prims(self, decompose: bool = True) -> list[Prim]:
-        m = self.update_matrix()[..., 2:4, 2:4]
-        return [Prim(self._sub_kind, m, self._bits([self.wires[1]]), self._bits([self.wires[0]]))]
+        full = self.update_matrix()
+        d = self.__dict__
+        c = d.get('_prims_cache')          # as in Gate.prims: same matrix object, version and wires -> same primitives
+        if c is not None and c[0] is full and c[3] == full._version and c[1] == self.wires:
+            return c[2]
+        m = full[..., 2:4, 2:4]
+        out = [Prim(self._sub_kind, m, self._bits([self.wires[1]]), self._bits([self.wires[0]]))]
+        d['_prims_cache'] = (full, list(self.wires), out, full._version)
+        return out
 
     _sub_kind = 'gen'
 

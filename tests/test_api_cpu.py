@@ -400,3 +400,61 @@ def test_circuit_inside_a_module_follows_dtype_and_device(cpu_backend):
 
 def test_get_amplitude_matches_reference(cpu_backend):
     check_get_amplitude(dq)
+
+
+def test_steady_state_cache_follows_parameter_updates(cpu_backend):
+    """executor._steady: merged runs / plan / matrix buffer are reused only while the forward sees the same primitive
+    objects at the same versions -- an in-place parameter update, a reloaded state_dict, an appended gate and a changed
+    batch all give what a cold run gives."""
+    from deepquantum_amd import executor
+
+    def build(angles):
+        cir = dq.QubitCircuit(12)
+        cir.hlayer()
+        for q in range(12):
+            cir.rx(q, inputs=angles[q])
+            cir.rz(q, inputs=angles[q] / 2)
+        cir.cnot_ring()
+        for q in range(12):
+            cir.ry(q, inputs=angles[(q + 3) % 12])
+        cir.observable(0)
+        cir.observable([1, 2], 'zz')
+        return cir
+
+    def run(cir, cold=False):
+        keep = dict(executor.CONFIG)
+        executor.CONFIG.update({'merge_min_amps': 0, 'steady_cache': not cold})
+        try:
+            with torch.no_grad():
+                return cir().clone(), cir.expectation().clone()
+        finally:
+            executor.CONFIG.clear()
+            executor.CONFIG.update(keep)
+
+    a0 = [0.1 * (q + 1) for q in range(12)]
+    cir = build(a0)
+    s1, e1 = run(cir)
+    s2, e2 = run(cir)                                           # the warm run
+    assert torch.equal(s1, s2) and torch.equal(e1, e2)
+    assert any(e.get('merged') is not None for e in executor._STEADY.values())
+    sc, ec = run(cir, cold=True)
+    assert torch.equal(s1, sc) and torch.equal(e1, ec)
+    # an optimiser-style in-place update of one angle
+    gate = [op for op in cir.operators if hasattr(op, 'theta')][5]
+    with torch.no_grad():
+        gate.theta.add_(0.37)
+    s3, e3 = run(cir)
+    sc, ec = run(cir, cold=True)
+    assert not torch.equal(s3, s1) and torch.equal(s3, sc) and torch.equal(e3, ec)
+    # a reloaded state_dict
+    other = build([0.05 * (q + 2) for q in range(12)])
+    ref_s, ref_e = run(other, cold=True)
+    cir.load_state_dict(other.state_dict())
+    s4, e4 = run(cir)
+    assert torch.equal(s4, ref_s) and torch.equal(e4, ref_e)
+    # one more gate
+    cir.x(3)
+    other.x(3)
+    s5, _ = run(cir)
+    ref_s, _ = run(other, cold=True)
+    assert torch.equal(s5, ref_s)
