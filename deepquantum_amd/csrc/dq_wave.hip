@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
                                                         const vec2<typename W::real>* mats, int64_t mat_bstride,
                                                         int64_t in_bstride, int n, int tpw_flags, const WaveKernPass p,
                                                         double* grads, int64_t grad_bstride) {
-    (void)tpw_flags;      // (low byte: log2 of the tiles a wave walks; bits 16, 17: streaming loads / stores)
+    // (low byte: log2 of the tiles a wave walks; bits 16, 17: streaming loads / stores)
     (void)in, (void)out, (void)mats, (void)mat_bstride;
     extern __shared__ __attribute__((aligned(16))) unsigned char dq_wave_smem[];
     (void)dq_wave_smem;
@@ -137,6 +137,14 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
   // tiles of one wave lie a whole grid apart, so that the tiles in flight at any time stay neighbours (write locality)
   // (tpw is a power of two and the grid ceil(tiles / (4 tpw)) workgroups: stride and count are re-derived per tile from the
   // kernel arguments instead of living in SGPRs across the assembly)
+    if (const unsigned xv = ((unsigned)tpw_flags >> 18) & 31u) {
+        // workgroups go to the eight XCDs round robin; here XCD j takes the j-th run of 2^(xv-1) consecutive tile groups out
+        // of every eight runs (xv = 31: a contiguous eighth of the whole pass), so that neighbouring 512-byte pieces of
+        // the written state leave through the same L2
+        const unsigned q = blockIdx.x >> 3, j = blockIdx.x & 7u;
+        if (xv == 31u) grp = j * (gridDim.x >> 3) + q;
+        else grp = ((q >> (xv - 1u)) << (xv + 2u)) + (j << (xv - 1u)) + (q & ((1u << (xv - 1u)) - 1u));
+    }
   uint32_t tile32 = grp * 4u + wave;
   for (;;) {      // (ends by the tile count: after `tpw` strides the number is past it)
     const uint64_t tile_id = tile32;
@@ -575,9 +583,19 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
     static const int nt_env = [] { const char* e = getenv("DQ_WAVE_NT"); return e ? atoi(e) & 3 : -1; }();
     const uint64_t state_bytes = ((uint64_t)batch << n) * (uint64_t)W::ELEM;
     const int nt = nt_env >= 0 ? nt_env : (state_bytes >= (1ull << 30) ? 3 : 0);
+    static const int xcd_env = [] { const char* e = getenv("DQ_WAVE_XCD"); return e ? atoi(e) : 1; }();
+    // XCD-aware tile numbers (default on; measured on the headline, two boxes: 240.3 -> 234.7 ms and 248.3 -> 244.7 ms;
+    // runs of 2 .. 512 groups per XCD give the same within 0.2 %).  DQ_WAVE_XCD: 0 off, 1 contiguous eighths, C = 2, 4, ..:
+    // runs of C tile groups per XCD
+    int xcd = 0;
+    if (xcd_env && in_bstride != 0 && tpw == 1) {
+        if (xcd_env == 1 && (grid.x & 7u) == 0) xcd = 31;
+        else if (xcd_env > 1 && (xcd_env & (xcd_env - 1)) == 0 && grid.x % (8u * (unsigned)xcd_env) == 0)
+            xcd = 32 - __builtin_clz((unsigned)xcd_env);       // log2(C) + 1
+    }
     using V = vec2<typename W::real>;
     hipLaunchKernelGGL((wave_pass_kernel<W, GRAD>), grid, dim3(256), lds, s, static_cast<const V*>(in), static_cast<V*>(out),
-                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, (31 - __builtin_clz((unsigned)tpw)) | (nt << 16), kp, grads, ngrads * 8);
+                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, (31 - __builtin_clz((unsigned)tpw)) | (nt << 16) | (xcd << 18), kp, grads, ngrads * 8);
     return check_launch("dq_apply_fused (wave tile)");
 }
 
