@@ -11,6 +11,7 @@ DQ_WAVE_NT=1 run streaming_loads_only
 DQ_WAVE_NT=2 run streaming_stores_only
 DQ_WAVE_TILE_ORDER=read run tile_numbers_in_read_order
 DQ_WAVE_TILE_ORDER=read DQ_WAVE_NT=0 run read_order_and_plain_accesses
+DQ_WAVE_XCD=0 run tile_groups_round_robin_over_the_xcds
 DQ_WAVE_LDS_KB=54 run two_workgroups_per_cu_2_waves_per_simd
 DQ_WAVE_LDS_KB=80 run one_workgroup_per_cu_1_wave_per_simd
 run unmerged_gates --no-merge
