@@ -20,14 +20,34 @@ from . import _lib
 _test_backend: Any = None
 
 
+class _NoGraph:
+    """A test double must not be more capable than the product: the HIP entry points return tensors without an
+    autograd graph, so every call into the double runs under ``no_grad`` as well (a double built from differentiable
+    torch operations once hid a missing second derivative)."""
+
+    def __init__(self, obj: Any):
+        self._obj = obj
+
+    def __getattr__(self, name: str) -> Any:
+        attr = getattr(self._obj, name)
+        if not callable(attr):
+            return attr
+
+        def call(*args, **kwargs):
+            with torch.no_grad():
+                return attr(*args, **kwargs)
+
+        return call
+
+
 def set_test_backend(obj: Any) -> None:
     """Install (or clear with ``None``) a CPU test double.  For ``tests/`` only."""
     global _test_backend
-    _test_backend = obj
+    _test_backend = None if obj is None else _NoGraph(obj)
 
 
 def get_test_backend() -> Any:
-    return _test_backend
+    return None if _test_backend is None else _test_backend._obj
 
 
 def _suffix(t: torch.Tensor) -> str:
@@ -247,15 +267,8 @@ def scale_z_signs(state: torch.Tensor, zmasks: Sequence[int], coef: torch.Tensor
     """(sum_k coef[b, k] Z-string_k) |psi_b>: (B, 2**n) in the state's dtype; coef real (B, K)."""
     n = _nqubit(state)
     if not _use_hip(state):
-        i = torch.arange(1 << n)
-        w = torch.zeros(state.shape[0], 1 << n, dtype=torch.float64)
-        for k, z in enumerate(zmasks):
-            par = torch.zeros_like(i)
-            for p in range(n):
-                if (z >> p) & 1:
-                    par ^= (i >> p) & 1
-            w += coef[:, k : k + 1].to(torch.float64) * (1 - 2 * par).to(torch.float64)
-        return (state * w.to(state.real.dtype)).contiguous()
+        with torch.no_grad():
+            return _scale_z_signs_double(state, zmasks, coef, n)
     lib = _lib.load()
     fn = getattr(lib, f'dq_scale_zsigns_{_suffix(state)}')
     coef = coef.to(torch.float64).contiguous()
@@ -268,6 +281,19 @@ def scale_z_signs(state: torch.Tensor, zmasks: Sequence[int], coef: torch.Tensor
         _lib.check(rc, 'dq_scale_zsigns')
         out = part if out is None else out.add_(part)
     return out
+
+
+def _scale_z_signs_double(state, zmasks, coef, n):
+    """``scale_z_signs`` for the CPU test double (tests only)."""
+    i = torch.arange(1 << n)
+    w = torch.zeros(state.shape[0], 1 << n, dtype=torch.float64)
+    for k, z in enumerate(zmasks):
+        par = torch.zeros_like(i)
+        for p in range(n):
+            if (z >> p) & 1:
+                par ^= (i >> p) & 1
+        w += coef[:, k : k + 1].to(torch.float64) * (1 - 2 * par).to(torch.float64)
+    return (state * w.to(state.real.dtype)).contiguous()
 
 
 def inner(bra: torch.Tensor, ket: torch.Tensor) -> torch.Tensor:

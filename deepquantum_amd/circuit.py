@@ -201,6 +201,13 @@ class QubitCircuit(Operation):
                 touched.append(g)
         return touched
 
+    def __getstate__(self) -> dict:
+        # the expectation values cached by the last pass belong to one state tensor of THIS object (a weak reference
+        # says which): a pickled, saved or copied circuit starts without them
+        d = self.__dict__.copy()
+        d['_expz'] = None
+        return d
+
     def forward(self, data: torch.Tensor | None = None, state: Any = None) -> torch.Tensor:
         """Run the circuit.  ``data``: 1-D (one sample) or 2-D (batch) encoder inputs; ``state``:
         (2**n, 1) or (B, 2**n, 1) initial state (default: the circuit's ``init_state``).  Returns the
@@ -743,7 +750,9 @@ class DistributedQubitCircuit(QubitCircuit):
         touched = self._precompute_matrices()
         try:
             masks = sorted({ob.pauli_masks()[1] for ob in self.observables if ob.pauli_masks()[0] == 0})
-            ez = masks if (masks and len(masks) <= 64 and executor.CONFIG['fused_expectation']) else None
+            # (only a no-grad forward reads the values: the adjoint `expectation()` of a training step never does)
+            ez = masks if (masks and len(masks) <= 64 and executor.CONFIG['fused_expectation']
+                           and not torch.is_grad_enabled()) else None
             self.state = dist_run(self.init_state, self.operators, keep_layout=self.lazy_layout, expect_z=ez)
         finally:
             for g in touched:

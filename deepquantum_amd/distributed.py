@@ -35,6 +35,7 @@ Two execution modes (``CONFIG['mode']``):
 from __future__ import annotations
 
 from collections import Counter
+from dataclasses import replace
 from typing import Sequence
 
 import torch
@@ -206,8 +207,8 @@ def _rows_of(pending: Sequence[Prim], rows: slice, total: int) -> list[Prim]:
         m = p.matrix
         if m is not None and m.ndim == 3 and m.shape[0] == total and total > 1:
             m = m[rows]
-        out.append(Prim(p.kind, m, p.targets, p.controls, p.mode))
-    return out
+        out.append(p if m is p.matrix else replace(p, matrix=m))     # (an unsliced primitive stays the same object:
+    return out                                                         #  the executor's steady cache keys on identity)
 
 
 def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: slice,
@@ -400,7 +401,8 @@ def _is_canonical(state: DistributedQubitState) -> bool:
 
 
 def _translate(p: Prim, ph: list[int]) -> Prim:
-    return Prim(p.kind, p.matrix, tuple(ph[t] for t in p.targets), tuple(ph[c] for c in p.controls), p.mode)
+    return replace(p, targets=tuple(ph[t] for t in p.targets), controls=tuple(ph[c] for c in p.controls),
+                   order=tuple(ph[o] for o in p.order))
 
 
 def _permute_local(state: DistributedQubitState, src_of_dst: list[int]) -> None:

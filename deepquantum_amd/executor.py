@@ -66,7 +66,8 @@ CONFIG = {'fuse': True, 'wave': None,     # None = wave-tile kernel where it tak
           # second state buffer; used when both fit in `permute_mem_frac` of the device memory
           'permute_store': True, 'permute_mem_frac': 0.45, 'permute_min_bits': 20,
           # 'adjoint': fused forward + reverse sweep with recomputation (O(1) states of memory);
-          # 'per_gate': one autograd node per gate (saves every intermediate state; supports double backward)
+          # 'per_gate': one autograd node per gate (saves every intermediate state).  Both differentiate to any order:
+          # under create_graph=True the adjoint node replays its gates as per-gate nodes (_backward_with_graph)
           'grad_mode': 'adjoint',
           # reverse sweeps run as fused passes over psi and the cotangent interleaved along one extra index bit, the
           # reductions for the trainable gates folded into the passes (_AdjointCircuit._sweep_fused); False: the
@@ -94,7 +95,9 @@ CONFIG = {'fuse': True, 'wave': None,     # None = wave-tile kernel where it tak
 PROFILE = {'enabled': False, 'events': []}
 
 # The most recent reverse sweep of _AdjointCircuit: which kind, how many fused passes / reduction records.
-LAST_SWEEP = {'fused': False, 'passes': 0, 'reductions': 0}
+LAST_SWEEP = {'fused': False, 'passes': 0, 'reductions': 0, 'with_graph': False}
+# How often a backward ran under create_graph=True and took the differentiable per-gate route (tests).
+GRAPH_BACKWARDS = {'count': 0}
 
 # Host time spent in the pass planner (fusion.schedule; once per circuit structure, plans are cached) since import.
 PLAN_STATS = {'seconds': 0.0, 'plans': 0}
@@ -163,6 +166,8 @@ def _steady(prims: Sequence[Prim]) -> dict | None:
     if not CONFIG.get('steady_cache', True) or len(prims) < 16:
         return None
     key = tuple(map(id, prims))
+    if any(p.matrix is not None and torch.is_inference(p.matrix) for p in prims):
+        return None                       # (inference tensors track no version: nothing to key a cache on)
     try:
         versions = tuple(-1 if p.matrix is None else p.matrix._version for p in prims)
     except Exception:
@@ -619,13 +624,43 @@ class _AdjointCircuit(torch.autograd.Function):
                 prims = merge_one_qubit_runs(prims)
         out = _run_nograd(state, prims)
         ctx.meta = meta
-        ctx.save_for_backward(out, *mats)
+        # (the input is kept by reference for the second-order route of ``backward``; the sweep itself needs only
+        # ``out``.  It costs no memory as a rule: the initial state belongs to the circuit, the state between two
+        # stretches is the saved output of the stretch before.)
+        ctx.save_for_backward(state, out, *mats)
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
+    def _backward_with_graph(ctx, gy):
+        """``backward`` under ``create_graph=True`` (grad mode is on while the engine runs us): the cotangents must be
+        differentiable functions of ``gy``, the input state and the matrices, which the recomputing sweep is not.  The
+        gates are replayed from the saved input as per-gate nodes -- each of them differentiable to any order
+        (``ops._ApplyGate`` / ``ops._GateGrad``) -- and differentiated there; this is the reference's own cost model
+        (stock autograd, one state per gate, qmath.py:503-505) and is only paid when a graph of the backward is asked
+        for: Hessians (examples/benchmarks/gradient_benchmark.py:147-163), gradient penalties.  First-order
+        ``backward()`` never comes here."""
+        state, _out, *mats = ctx.saved_tensors
+        meta = ctx.meta
+        with torch.enable_grad():
+            # (an alias per slot: one tensor may serve several gates, and every slot gets its own gate's cotangent)
+            mats = [m.view_as(m) if ctx.needs_input_grad[2 + j] else m for j, m in enumerate(mats)]
+            wanted = [state] if ctx.needs_input_grad[0] else []
+            wanted += [m for j, m in enumerate(mats) if ctx.needs_input_grad[2 + j]]
+            x = state
+            for (_kind, targets, controls, _mode, _e), m in zip(meta, mats, strict=True):
+                x = ops.apply_gate(x, m, targets, controls)
+            got = list(torch.autograd.grad(x, wanted, grad_outputs=gy.to(x.dtype), create_graph=True, allow_unused=True))
+        LAST_SWEEP.update(fused=False, passes=0, reductions=0, with_graph=True)
+        GRAPH_BACKWARDS['count'] += 1
+        gstate = got.pop(0) if ctx.needs_input_grad[0] else None
+        grads = [got.pop(0) if ctx.needs_input_grad[2 + j] else None for j in range(len(mats))]
+        return (gstate, None, *grads)
+
+    @staticmethod
     def backward(ctx, gy):
-        out, *mats = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            return _AdjointCircuit._backward_with_graph(ctx, gy)
+        _state, out, *mats = ctx.saved_tensors
         meta = ctx.meta
         b = out.shape[0]
         need = [ctx.needs_input_grad[2 + j] for j in range(len(mats))]
@@ -697,7 +732,7 @@ class _AdjointCircuit(torch.autograd.Function):
         trainable gate's sum lambda (x) conj(psi) is reduced from a snapshot in which no pending gate touches its
         qubits (gate-gradient kernels).  Returns ({gate: (b, D, D) sums}, thunk for lambda_0)."""
         work = torch.cat([out, gy.to(out.dtype)]).contiguous()        # rows [0, b): psi, rows [b, 2b): lambda
-        LAST_SWEEP.update(fused=False, passes=0, reductions=sum(need))
+        LAST_SWEEP.update(fused=False, passes=0, reductions=sum(need), with_graph=False)
         raw: dict = {}                                                  # j -> sum lambda_j (x) conj(psi_j)
         pending: list[Prim] = []
         touched: set[int] = set()             # qubits the not-yet-undone gates act on
@@ -787,7 +822,7 @@ class _AdjointCircuit(torch.autograd.Function):
             if 1.05 * work.numel() * work.element_size() <= free:
                 scratch = torch.empty_like(work)
         work = _run_nograd(work, prims, inplace=True, scratch=scratch, grads=acc)
-        LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=len(rows))
+        LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=len(rows), with_graph=False)
         g = torch.view_as_complex(acc.reshape(b, -1, 4, 2)).reshape(b, -1, 2, 2)
         if scalars and rows:
             # row r was reduced from a psi that is  prod 2 s_k^2  (over the scalar gates executed before it) too large

@@ -18,7 +18,7 @@ from torch import nn
 from torch.autograd.functional import jacobian
 
 from .executor import Prim
-from .operation import Gate
+from .operation import Gate, tensor_version
 from .qmath import multi_kron  # noqa: F401  (re-exported for API parity)
 
 
@@ -83,11 +83,12 @@ class DoubleControlGate(DoubleGate):
         full = self.update_matrix()
         d = self.__dict__
         c = d.get('_prims_cache')          # as in Gate.prims: same matrix object, version and wires -> same primitives
-        if c is not None and c[0] is full and c[3] == full._version and c[1] == self.wires:
+        ver = tensor_version(full)
+        if c is not None and ver is not None and c[0] is full and c[3] == ver and c[1] == self.wires:
             return c[2]
         m = full[..., 2:4, 2:4]
         out = [Prim(self._sub_kind, m, self._bits([self.wires[1]]), self._bits([self.wires[0]]))]
-        d['_prims_cache'] = (full, list(self.wires), out, full._version)
+        d['_prims_cache'] = (full, list(self.wires), out, ver)
         return out
 
     _sub_kind = 'gen'
@@ -173,7 +174,7 @@ class _Parametric:
 
     def _param_key(self) -> tuple:
         """Identity and version of every parameter tensor (+ the inverse flag): what the cached matrix belongs to."""
-        return tuple((t, t._version) for t in (getattr(self, n) for n in self._param_names)) + (self.inv_mode,)
+        return tuple((t, tensor_version(t)) for t in (getattr(self, n) for n in self._param_names)) + (self.inv_mode,)
 
     def _stamp(self) -> None:
         self.__dict__['_matrix_key'] = self._param_key()
@@ -187,7 +188,7 @@ class _Parametric:
         grad = torch.is_grad_enabled()
         for (t, version), name in zip(key[:-1], self._param_names):
             cur = getattr(self, name)
-            if cur is not t or cur._version != version or (grad and cur.requires_grad):
+            if cur is not t or version is None or tensor_version(cur) != version or (grad and cur.requires_grad):
                 return None
         return m
 
@@ -731,8 +732,9 @@ class UAnyGate(ArbitraryGate):
         re-derived whenever the buffer is replaced or written in place (``load_state_dict``, ``.to``): the test
         reads the matrix values, so its result is cached on the buffer's identity and version counter."""
         m = self.matrix
-        key = (m.data_ptr(), m._version, m.device, m.dtype)
-        if self._kind_cache is None or self._kind_cache[0] != key:
+        ver = tensor_version(m)
+        key = (m.data_ptr(), ver, m.device, m.dtype)
+        if ver is None or self._kind_cache is None or self._kind_cache[0] != key:
             diag_only = m.ndim == 2 and len(self.wires) <= 2 and bool(
                 (m == torch.diag_embed(m.diagonal(dim1=-2, dim2=-1))).all())
             self._kind_cache = (key, 'diag' if diag_only else 'gen')

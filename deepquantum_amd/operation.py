@@ -15,6 +15,7 @@ column bits (:meth:`Gate.dm_prims`), a channel is the 4x4 superoperator sum_k K_
 from __future__ import annotations
 
 from copy import copy
+from dataclasses import replace
 from typing import Any
 
 import torch
@@ -23,6 +24,14 @@ from torch import nn
 from . import executor
 from .executor import Prim
 from .utils import complex_apply
+
+
+def tensor_version(t: torch.Tensor) -> int | None:
+    """``t._version``, or None for a tensor that does not track one (a matrix computed under
+    ``torch.inference_mode()``): such a tensor is never served from a cache."""
+    if torch.is_inference(t):
+        return None
+    return t._version
 
 
 class Operation(nn.Module):
@@ -173,13 +182,14 @@ class Gate(Operation):
         # angles costs a forward one dictionary look-up instead of a Prim and two tuples
         d = self.__dict__
         c = d.get('_prims_cache')
-        if (c is not None and c[0] is m and c[5] == m._version and c[1] == self.wires and c[2] == self.controls
-                and c[3] == self.nqubit):
+        ver = tensor_version(m)
+        if (c is not None and ver is not None and c[0] is m and c[5] == ver and c[1] == self.wires
+                and c[2] == self.controls and c[3] == self.nqubit):
             return c[4]
         mode = self._kernel_mode if len(self.wires) == 1 else 0
         out = [Prim(self._kernel_kind, m, self._bits(self.wires), self._bits(self.controls), mode,
                     exact=getattr(self, '_exact_unitary', True))]
-        d['_prims_cache'] = (m, list(self.wires), list(self.controls), self.nqubit, out, m._version)
+        d['_prims_cache'] = (m, list(self.wires), list(self.controls), self.nqubit, out, ver)
         return out
 
     def dm_prims(self, decompose: bool = True) -> list[Prim]:
@@ -248,10 +258,11 @@ def lift_to_density_matrix(prims: list[Prim], nqubit: int) -> list[Prim]:
     rho -> U rho U^dagger is U on the row bits (bit + n) and conj(U) on the column bits."""
     out: list[Prim] = []
     for p in prims:
-        out.append(Prim(p.kind, p.matrix, tuple(t + nqubit for t in p.targets),
-                        tuple(c + nqubit for c in p.controls), p.mode))
+        # (``replace`` keeps every other field: unitary / exact / order travel with the primitive)
+        out.append(replace(p, targets=tuple(t + nqubit for t in p.targets), controls=tuple(c + nqubit for c in p.controls),
+                           order=tuple(o + nqubit for o in p.order)))
         conj = p.matrix if p.kind == 'x' else p.matrix.conj().resolve_conj()
-        out.append(Prim(p.kind, conj, p.targets, p.controls, p.mode))
+        out.append(replace(p, matrix=conj))
     return out
 
 
@@ -308,9 +319,10 @@ class Channel(Operation):
     def superoperator(self) -> torch.Tensor:
         """sum_k K_k (x) conj(K_k): 4x4, index = (row bit, column bit)."""
         theta = self.theta
-        key = (id(theta), theta._version, theta.dtype, theta.device)
+        ver = tensor_version(theta)
+        key = (id(theta), ver, theta.dtype, theta.device)
         cached = self.__dict__.get('_sup_cache')
-        if cached is not None and cached[0] == key and not theta.requires_grad:
+        if ver is not None and cached is not None and cached[0] == key and not theta.requires_grad:
             return cached[1]                                # fixed noise strength: built once, not per forward
         kraus = self.update_matrix()                       # (K, 2, 2) or (K, B, 2, 2)
         sup = torch.einsum('k...ab,k...cd->...acbd', kraus, kraus.conj())

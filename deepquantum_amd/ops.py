@@ -5,6 +5,11 @@ The reference differentiates its dense path with stock autograd through permute/
 again a gate kernel (``U^dagger`` applied to the cotangent) plus a small reduction for the matrix
 gradient, so ``loss.backward()`` through ``QubitCircuit`` works unchanged while every sweep over the
 state stays a single HBM-bound HIP launch.
+
+Every backward here is itself written with differentiable operations of this module (the matrix gradient is the
+``_GateGrad`` node, whose own backward is two gate applications; the cotangent of an expectation value is a gate
+application), so ``create_graph=True`` -- ``torch.autograd.functional.hessian`` over a circuit, which the reference
+gets from stock autograd (examples/benchmarks/gradient_benchmark.py:147-163) -- differentiates to any order.
 """
 
 from __future__ import annotations
@@ -48,7 +53,7 @@ class _ApplyGate(torch.autograd.Function):
             # d/dx of y = U x  ->  U^H gy on the same targets / controls (other amplitudes: identity)
             gstate = apply_gate(gy, mats.mH.resolve_conj().contiguous(), ctx.targets, ctx.controls)
         if ctx.needs_input_grad[1]:
-            g = backend.gate_grad(state, gy, ctx.targets, ctx.controls)  # (B, D, D) complex128
+            g = gate_grad(state, gy, ctx.targets, ctx.controls)  # (B, D, D) complex128; a node of its own
             if mats.shape[0] == 1 and g.shape[0] > 1:
                 g = g.sum(dim=0, keepdim=True)
             gmats = g.to(mats.dtype)
@@ -87,6 +92,65 @@ def apply_gate(
     return _ApplyGate.apply(state, mats, tuple(int(t) for t in targets), tuple(int(c) for c in controls))
 
 
+def apply_masked(
+    state: torch.Tensor, mats: torch.Tensor, targets: Sequence[int], controls: Sequence[int] = ()
+) -> torch.Tensor:
+    """``mats`` applied on the amplitudes whose control bits are all set, ZERO elsewhere (a controlled gate leaves
+    those alone instead): P_c (M on targets) x.  Differentiable.  With controls it is the difference of two controlled
+    applications -- (x + P_c (M - 1) x) - (x - P_c x) -- exact in floating point: outside the controlled subspace both
+    terms are x itself, inside the second one is 0."""
+    if not controls:
+        return apply_gate(state, mats, targets, ())
+    return apply_gate(state, mats, targets, controls) - apply_gate(state, torch.zeros_like(mats), targets, controls)
+
+
+class _GateGrad(torch.autograd.Function):
+    """G[b] = sum over the controlled amplitude groups of gy (outer) conj(x): (B, D, D) complex128 -- the matrix
+    cotangent of ``_ApplyGate`` (one read of both states, ``dq_gate_grad_*``).  G is linear in gy and anti-linear in
+    x, so its own backward is two masked gate applications: the cotangent of gy is (gG on targets) x, the cotangent
+    of x is (gG^H on targets) gy, both on the controlled subspace only."""
+
+    @staticmethod
+    def forward(x: torch.Tensor, gy: torch.Tensor, targets: tuple, controls: tuple) -> torch.Tensor:
+        return backend.gate_grad(x, gy, targets, controls)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        x, gy, ctx.targets, ctx.controls = inputs
+        ctx.save_for_backward(x, gy)
+
+    @staticmethod
+    def backward(ctx, gg: torch.Tensor):
+        x, gy = ctx.saved_tensors
+        gx = ggy = None
+        m = gg.to(x.dtype)
+        if ctx.needs_input_grad[0]:
+            gx = apply_masked(gy, m.mH.resolve_conj().contiguous(), ctx.targets, ctx.controls)
+        if ctx.needs_input_grad[1]:
+            ggy = apply_masked(x, m.contiguous(), ctx.targets, ctx.controls)
+        return gx, ggy, None, None
+
+    @staticmethod
+    def vmap(info, in_dims, x, gy, targets, controls):
+        v = info.batch_size
+        x = x.movedim(in_dims[0], 0) if in_dims[0] is not None else x.unsqueeze(0).expand(v, *x.shape)
+        gy = gy.movedim(in_dims[1], 0) if in_dims[1] is not None else gy.unsqueeze(0).expand(v, *gy.shape)
+        b = x.shape[1]
+        out = _GateGrad.apply(x.reshape(v * b, -1).contiguous(), gy.reshape(v * b, -1).contiguous(), targets, controls)
+        return out.reshape(v, b, *out.shape[1:]), 0
+
+
+def gate_grad(
+    x: torch.Tensor, gy: torch.Tensor, targets: Sequence[int], controls: Sequence[int] = ()
+) -> torch.Tensor:
+    """Differentiable sum gy (outer) conj(x) over the amplitude groups of a gate: complex128 (B, D, D)."""
+    if not _is_batched(x) and not x.is_contiguous():
+        x = x.contiguous()
+    if not _is_batched(gy) and not gy.is_contiguous():
+        gy = gy.contiguous()
+    return _GateGrad.apply(x, gy, tuple(int(t) for t in targets), tuple(int(c) for c in controls))
+
+
 class _ExpectPauli(torch.autograd.Function):
     """Re <psi|P|psi> per batch sample, P a Pauli string given by bit masks."""
 
@@ -104,7 +168,8 @@ class _ExpectPauli(torch.autograd.Function):
         (state,) = ctx.saved_tensors
         # L = psi^H P psi with P Hermitian: dL/d(conj psi) = P psi; PyTorch's convention for a real loss
         # of a complex tensor is grad = 2 * dL/d(conj psi).
-        ppsi = apply_pauli(state, ctx.xmask, ctx.zmask)
+        # (P psi through the differentiable gate applications, so that a second derivative sees it)
+        ppsi = apply_pauli(state, ctx.xmask, ctx.zmask, differentiable=True)
         return (2.0 * g).to(state.real.dtype).unsqueeze(-1) * ppsi, None, None
 
     @staticmethod
@@ -130,8 +195,8 @@ def _pauli_mats(dtype: torch.dtype, device: torch.device) -> dict[str, torch.Ten
     return _PAULI[key]
 
 
-def apply_pauli(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
-    """P|psi> for a Pauli string (no autograd)."""
+def apply_pauli(state: torch.Tensor, xmask: int, zmask: int, differentiable: bool = False) -> torch.Tensor:
+    """P|psi> for a Pauli string (``differentiable``: through the autograd-aware gate applications)."""
     mats = _pauli_mats(state.dtype, state.device)
     n = state.shape[-1].bit_length() - 1
     out = state
@@ -139,7 +204,7 @@ def apply_pauli(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
         xb, zb = (xmask >> p) & 1, (zmask >> p) & 1
         if xb or zb:
             m = mats['y'] if (xb and zb) else (mats['x'] if xb else mats['z'])
-            out = backend.apply_gate(out, m, [p], [])
+            out = apply_gate(out, m, [p], []) if differentiable else backend.apply_gate(out, m, [p], [])
     return out if out is not state else state.clone()
 
 
@@ -168,7 +233,7 @@ class _Marginal(torch.autograd.Function):
         # d p_k / d conj(psi_i) = psi_i [bits(i) = k]; real loss of a complex tensor: grad = 2 * that,
         # i.e. a diagonal "gate" diag(2 g[b, :]) on the measured bits
         diag = (2.0 * g).to(state.dtype).diag_embed()
-        return backend.apply_gate(state, diag.contiguous(), ctx.bits, ()), None
+        return apply_gate(state, diag.contiguous(), ctx.bits, ()), None
 
 
 def marginal(state: torch.Tensor, bits: Sequence[int]) -> torch.Tensor:
@@ -194,7 +259,42 @@ class _ExpectZMulti(torch.autograd.Function):
     def backward(ctx, g: torch.Tensor):
         (state,) = ctx.saved_tensors
         # L = sum_k g_k psi^H P_k psi with P_k diagonal: grad = 2 (sum_k g_k P_k) psi, one read + one write
-        return backend.scale_z_signs(state, ctx.zmasks, 2.0 * g), None
+        return scale_z_signs(state, ctx.zmasks, 2.0 * g), None
+
+
+class _ScaleZSigns(torch.autograd.Function):
+    """out[b, i] = (sum_k w[b, k] s_k(i)) psi[b, i] with s_k(i) = (-1)^popcount(i & zmask_k): the cotangent of
+    ``_ExpectZMulti`` as a node of its own, so that second derivatives exist.  Linear in psi (real diagonal factor:
+    its cotangent is the same scaling of the incoming cotangent) and in w (d/dw_k = Re <g| P_k |psi>, taken by
+    polarisation from the Z-string reduction itself)."""
+
+    @staticmethod
+    def forward(state: torch.Tensor, zmasks: tuple, w: torch.Tensor) -> torch.Tensor:
+        return backend.scale_z_signs(state, zmasks, w)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        state, ctx.zmasks, w = inputs
+        ctx.save_for_backward(state, w)
+
+    @staticmethod
+    def backward(ctx, g: torch.Tensor):
+        state, w = ctx.saved_tensors
+        g = g.contiguous()
+        gstate = gw = None
+        if ctx.needs_input_grad[0]:
+            gstate = scale_z_signs(g, ctx.zmasks, w)
+        if ctx.needs_input_grad[2]:
+            # Re <g| P |psi> = (<g + psi| P |g + psi> - <g - psi| P |g - psi>) / 4
+            gw = ((expect_z_multi(g + state, ctx.zmasks) - expect_z_multi(g - state, ctx.zmasks)) * 0.25).to(w.dtype)
+        return gstate, None, gw
+
+
+def scale_z_signs(state: torch.Tensor, zmasks: Sequence[int], w: torch.Tensor) -> torch.Tensor:
+    """Differentiable (sum_k w_k P_k) psi for Z-type strings P_k, w real (B, K)."""
+    if not state.is_contiguous():
+        state = state.contiguous()
+    return _ScaleZSigns.apply(state, tuple(int(z) for z in zmasks), w)
 
 
 def expect_z_multi(state: torch.Tensor, zmasks: Sequence[int]) -> torch.Tensor:

@@ -109,8 +109,8 @@ class DistributedQubitState(_ComplexBuffers):
             # device the state lives on by then -- gate routines, `cir(state=s)`, load_state_dict all see a usable shard
             d = self.__dict__
             t = super().__getattr__(name)
-            if tuple(t.shape) != tuple(d.get('_shape', t.shape)) and not d.get('_building'):
-                d['_building'] = True
+            if t.numel() == 0 and not d.get('_building'):       # (the LAZY marker; a shard of any other shape is the
+                d['_building'] = True                           #  caller's business and is never replaced)
                 try:
                     self.reset()
                 finally:
@@ -148,10 +148,11 @@ class DistributedQubitState(_ComplexBuffers):
     def reset(self) -> None:
         self.__dict__.pop('_phys', None)   # canonical qubit order (first: ``amps`` below must not trigger an exchange)
         self.__dict__.pop('_expz', None)   # (expectation values cached by a circuit's last pass)
-        if tuple(self.amps.shape) != tuple(self._shape):
-            self.amps = torch.zeros(self._shape, dtype=self.amps.dtype, device=self.amps.device)
-            self.buffer = torch.zeros_like(self.amps)
+        cur = self._buffers['amps']       # (read past the lazy-build hook of __getattr__: it calls us)
+        if tuple(cur.shape) != tuple(self._shape):
+            self.amps = torch.zeros(self._shape, dtype=cur.dtype, device=cur.device)
+            self.buffer = torch.zeros_like(self._buffers['amps'])
         else:
-            self.amps.zero_()       # (the receive buffer is scratch: every use writes all of what it then reads)
+            cur.zero_()             # (the receive buffer is scratch: every use writes all of what it then reads)
         if self.rank == 0:
             self.amps[..., 0] = 1.0

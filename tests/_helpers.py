@@ -829,3 +829,84 @@ def check_get_amplitude(dq, device=None):
     ref = torch.tensor([complex(*v) for v in GET_AMPLITUDE_REF], dtype=amp.dtype)
     assert amp.shape == (4,)
     assert (amp - ref).abs().max().item() < 1e-6
+
+
+_GOLDEN_HESSIAN = None
+
+
+def gold_hessian(key):
+    global _GOLDEN_HESSIAN
+    if _GOLDEN_HESSIAN is None:
+        _GOLDEN_HESSIAN = np.load(os.path.join(HERE, 'golden', 'golden_hessian.npz'))
+    return torch.from_numpy(_GOLDEN_HESSIAN[key])
+
+
+def check_hessian_benchmark_against_golden(dq, n, layer, prec, tag, device=None):
+    """The reference's own Hessian benchmark (examples/benchmarks/gradient_benchmark.py:147-163), taken the way it takes
+    it -- ``torch.autograd.functional.hessian`` over a function that builds the circuit -- in whatever
+    ``executor.CONFIG['grad_mode']`` is current, against the real reference's value, gradient and Hessian."""
+    from torch.autograd.functional import hessian
+
+    key = f'hessian/{n}-{layer}/{prec}/{tag}'
+    x = gold_hessian(f'{key}/params')
+    if device is not None:
+        x = x.to(device)
+
+    def f(params):
+        cir = specs.hessian_benchmark_circuit(dq, n, layer)
+        if device is not None:
+            cir.to(device)
+        if prec == 'c128':
+            cir.to(torch.double)
+        cir(data=params)
+        return cir.expectation()
+
+    xg = x.clone().requires_grad_(True)
+    val = f(xg)
+    (g,) = torch.autograd.grad(val, xg)
+    h = hessian(f, x).reshape(x.numel(), x.numel())
+    tol = TOL[prec]
+    assert (val.detach().cpu() - gold_hessian(f'{key}/value')).abs().max().item() < tol, key
+    assert (g.cpu() - gold_hessian(f'{key}/grad')).abs().max().item() < tol, key
+    err = (h.cpu() - gold_hessian(f'{key}/hessian')).abs().max().item()
+    assert err < tol, (key, err)
+    return err
+
+
+def check_hessian_params_against_golden(dq, prec, device=None):
+    """Hessian with respect to nn.Parameters and data of a circuit with controlled / two-target trainable gates and
+    three observables, by double ``torch.autograd.grad`` (tests/golden/make_golden_hessian.py)."""
+    key = f'hessian_params/{prec}'
+    cir = specs.hessian_param_circuit(dq, 4)
+    if device is not None:
+        cir.to(device)
+    if prec == 'c128':
+        cir.to(torch.double)
+    params = gold_hessian(f'{key}/params')
+    off = 0
+    with torch.no_grad():
+        for p in cir.parameters():
+            p.copy_(params[off : off + p.numel()].reshape(p.shape))
+            off += p.numel()
+    data = gold_hessian(f'{key}/data').clone()
+    if device is not None:
+        data = data.to(device)
+    data.requires_grad_(True)
+    cir(data=data)
+    ev = cir.expectation()
+    tol = TOL[prec]
+    assert (ev.detach().cpu() - gold_hessian(f'{key}/expectation')).abs().max().item() < tol
+    w = torch.tensor(specs.HESSIAN_PARAM_WEIGHTS, dtype=ev.dtype, device=ev.device)
+    loss = (ev.reshape(-1) * w).sum() + (ev.reshape(-1) ** 2).sum()
+    leaves = [data] + list(cir.parameters())
+    gs = torch.autograd.grad(loss, leaves, create_graph=True)
+    gflat = torch.cat([g.reshape(-1) for g in gs])
+    assert (gflat.detach().cpu() - gold_hessian(f'{key}/grad')).abs().max().item() < tol
+    rows = []
+    for i in range(gflat.numel()):
+        r = torch.autograd.grad(gflat[i], leaves, retain_graph=True, allow_unused=True)
+        rows.append(torch.cat([(torch.zeros_like(p) if x is None else x).reshape(-1) for x, p in zip(r, leaves)]))
+    h = torch.stack(rows)
+    err = (h.cpu() - gold_hessian(f'{key}/hessian')).abs().max().item()
+    assert err < tol, (key, err)
+    return err

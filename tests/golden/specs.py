@@ -429,3 +429,47 @@ def extra_gates_circuit(dq):
     cir.observable([0, 1], 'xz')
     cir.observable(3, 'y')
     return cir
+
+
+# ---- second order: the reference's own Hessian benchmark (examples/benchmarks/gradient_benchmark.py:147-163) and a
+# circuit whose Hessian is taken with respect to nn.Parameters --------------------------------------------------
+HESSIAN_CASES = [(4, 2), (4, 4), (6, 2), (6, 4), (8, 2), (8, 4)]
+
+
+def hessian_benchmark_circuit(dq, n, layer):
+    cir = dq.QubitCircuit(n)
+    for _ in range(layer):
+        for i in range(n - 1):
+            cir.cnot(i, i + 1)
+        cir.rxlayer(encode=True)
+        cir.rzlayer(encode=True)
+        cir.rxlayer(encode=True)
+    cir.observable(basis='x')
+    return cir
+
+
+def hessian_params(n, layer):
+    g = torch.Generator().manual_seed(1000 * n + layer)
+    return (torch.rand(3 * n * layer, generator=g, dtype=torch.float64) * 2 - 1) * 3.0
+
+
+HESSIAN_PARAM_WEIGHTS = [0.8, -1.3, 0.5]
+
+
+def hessian_param_circuit(dq, n):
+    """Trainable one-qubit, controlled and two-qubit gates, two encoders, X / Z / Y-type observables."""
+    cir = dq.QubitCircuit(n)
+    cir.hlayer()
+    cir.rx(0, encode=True)
+    cir.rylayer()                      # trainable
+    cir.cnot_ring()
+    cir.crz(1, 2)                      # trainable, controlled
+    cir.rxx([0, 3])                    # trainable, two targets
+    cir.u3(2)                          # trainable, three angles
+    cir.ry(1, encode=True)
+    cir.t(0)
+    cir.rz(3, controls=[0, 2])         # trainable, two controls
+    cir.observable(0)
+    cir.observable([1, 2], 'xz')
+    cir.observable([0, 3], 'zy')
+    return cir

@@ -458,3 +458,92 @@ def test_steady_state_cache_follows_parameter_updates(cpu_backend):
     s5, _ = run(cir)
     ref_s, _ = run(other, cold=True)
     assert torch.equal(s5, ref_s)
+
+
+# ---- round-3 ADVICE items -----------------------------------------------------------------------------------------
+def test_forward_under_inference_mode(cpu_backend):
+    """Matrices computed under ``torch.inference_mode()`` track no version counter: the caches keyed on
+    ``tensor._version`` step aside instead of raising (operation.py / gate.py)."""
+    cir = dq.QubitCircuit(3)
+    cir.h(0)
+    cir.rx(1)
+    cir.cnot(0, 2)
+    cir.crx(0, 1)
+    cir.rzz([1, 2])
+    cir.observable(0)
+    cir.observable([1, 2], 'xz')
+    with torch.no_grad():
+        ref = cir.expectation() if cir() is not None else None
+    with torch.inference_mode():
+        cir.prims() if hasattr(cir, 'prims') else None
+        cir()
+        got = cir.expectation()
+        cir()                                   # (twice: a cache filled under inference mode must not be served)
+        assert torch.equal(got, cir.expectation())
+    assert torch.allclose(ref, got, atol=1e-6)
+    with torch.inference_mode():                # a model BUILT under inference mode: its parameters track no version
+        c2 = dq.QubitCircuit(3)
+        c2.h(0)
+        c2.rx(1)
+        c2.ry(2, 0.3)
+        c2.crx(0, 1, 0.2)
+        c2.observable(0)
+        for _ in range(2):
+            c2()
+            c2.expectation()
+    # the steady-state cache (>= 16 primitives) under inference mode
+    c3 = dq.QubitCircuit(4)
+    for _ in range(5):
+        c3.rxlayer()
+        c3.cnot_ring()
+    c3.observable(0)
+    with torch.inference_mode():
+        c3()
+        a = c3.expectation()
+        c3()
+        assert torch.equal(a, c3.expectation())
+
+
+def test_circuit_pickles_after_a_no_grad_forward(cpu_backend):
+    """The cache of expectation values taken by the last pass holds a weak reference: it must not travel with
+    ``pickle`` / ``torch.save`` / ``copy`` (circuit.py)."""
+    import copy
+    import io
+    import pickle
+
+    n = 12
+    cir = specs.build(dq, n, specs.random_spec(n, 3, 5))
+    cir.observable(0)
+    cir.observable([1, 2], 'zz')
+    with torch.no_grad():
+        cir()
+        ev = cir.expectation()
+    cir._expz = cir._expz or {'state': None}    # (the double may not have filled it: the field must be dropped either way)
+    import weakref
+    cir._expz['state'] = weakref.ref(cir.state)
+    clone = pickle.loads(pickle.dumps(cir))
+    assert clone._expz is None
+    buf = io.BytesIO()
+    torch.save(cir, buf)
+    assert copy.copy(cir)._expz is None and copy.deepcopy(cir)._expz is None
+    with torch.no_grad():
+        clone()
+        assert torch.allclose(clone.expectation(), ev, atol=1e-6)
+
+
+def test_sharded_state_keeps_a_shard_of_another_shape(cpu_backend):
+    """Only the empty LAZY marker triggers the lazy build of a shard; a shard of an equivalent but different shape
+    is left alone (state.py)."""
+    st = dq.DistributedQubitState(4)
+    assert st.amps.shape == (16,) and st.amps[0] == 1
+    col = torch.arange(16, dtype=torch.float32).to(torch.cfloat).reshape(16, 1)
+    st.amps = col
+    assert st.amps.shape == (16, 1) and torch.equal(st.amps, col)
+    old = dq.DistributedQubitState.LAZY_AMPS
+    dq.DistributedQubitState.LAZY_AMPS = 4
+    try:
+        lazy = dq.DistributedQubitState(4)
+        assert lazy._buffers['amps'].numel() == 0
+        assert lazy.amps.shape == (16,) and lazy.amps[0] == 1 and lazy.buffer.shape == (16,)
+    finally:
+        dq.DistributedQubitState.LAZY_AMPS = old

@@ -721,3 +721,60 @@ def test_get_amplitude_matches_reference_on_gpu():
     from _helpers import check_get_amplitude
 
     check_get_amplitude(dq, device=dev())
+
+
+# ---- second order (Hessians were silently wrong in the default grad mode) ------------------------------
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+@pytest.mark.parametrize('case', specs.HESSIAN_CASES)
+def test_hessian_of_the_reference_benchmark_circuit_on_gpu(case, prec):
+    """``torch.autograd.functional.hessian`` over the reference's hessian_dq circuit
+    (examples/benchmarks/gradient_benchmark.py:147-163) in the DEFAULT grad mode, through the HIP kernels, against the
+    real reference's Hessians: 1e-4 (complex64) / 1e-10 (complex128)."""
+    from _helpers import check_hessian_benchmark_against_golden
+
+    assert dq.executor.CONFIG['grad_mode'] == 'adjoint'
+    n, layer = case
+    before = dq.executor.GRAPH_BACKWARDS['count']
+    for tag in ('ones', 'rand'):
+        err = check_hessian_benchmark_against_golden(dq, n, layer, prec, tag, device=dev())
+        print(f'hessian {n}-{layer} {prec} {tag}: max error {err:.2e}')
+    assert dq.executor.GRAPH_BACKWARDS['count'] > before
+
+
+@pytest.mark.parametrize('mode', ['adjoint', 'per_gate'])
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+def test_hessian_with_respect_to_parameters_on_gpu(mode, prec):
+    from _helpers import check_hessian_benchmark_against_golden, check_hessian_params_against_golden
+
+    old = dq.executor.CONFIG['grad_mode']
+    dq.executor.CONFIG['grad_mode'] = mode
+    try:
+        check_hessian_params_against_golden(dq, prec, device=dev())
+        check_hessian_benchmark_against_golden(dq, 4, 4, prec, 'rand', device=dev())
+    finally:
+        dq.executor.CONFIG['grad_mode'] = old
+
+
+def test_gradgradcheck_of_the_autograd_nodes_on_gpu():
+    """Numerical first and second derivatives of the nodes themselves on the kernels (complex128)."""
+    from torch.autograd import gradcheck, gradgradcheck
+
+    from deepquantum_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, dtype=torch.complex128, generator=g).to(dev()).requires_grad_(True)
+    y = torch.randn(2, 32, dtype=torch.complex128, generator=g).to(dev()).requires_grad_(True)
+    m1 = torch.randn(1, 2, 2, dtype=torch.complex128, generator=g).to(dev()).requires_grad_(True)
+    m2 = torch.randn(2, 4, 4, dtype=torch.complex128, generator=g).to(dev()).requires_grad_(True)
+    w = torch.randn(2, 3, dtype=torch.float64, generator=g).to(dev()).requires_grad_(True)
+    zs = (0b00101, 0b01000, 0b10011)
+    for controls in ((), (0,), (0, 3)):
+        assert gradgradcheck(lambda a, b: ops.apply_gate(a, b, (2,), controls), (x, m1))
+        assert gradgradcheck(lambda a, b: ops.apply_gate(a, b, (4, 1), controls), (x, m2))
+        assert gradcheck(lambda a, b: ops.gate_grad(a, b, (2,), controls), (x, y))
+        assert gradgradcheck(lambda a, b: ops.gate_grad(a, b, (4, 1), controls), (x, y))
+    assert gradgradcheck(lambda a: ops.expect_pauli(a, 0b00110, 0b00011), (x,))
+    assert gradgradcheck(lambda a: ops.marginal(a, (3, 0)), (x,))
+    assert gradgradcheck(lambda a: ops.expect_z_multi(a, zs), (x,))
+    assert gradcheck(lambda a, b: ops.scale_z_signs(a, zs, b), (x, w))
+    assert gradgradcheck(lambda a, b: ops.scale_z_signs(a, zs, b), (x, w))

@@ -1,0 +1,95 @@
+"""Second-order autograd against the real reference's Hessians (tests/golden/golden_hessian.npz), host logic on the CPU
+test double -- which, like the HIP entry points, returns tensors WITHOUT an autograd graph (``backend._NoGraph``), so a
+backward that is not built from differentiable nodes shows up here as a wrong Hessian, as it would on the GPU.
+tests/test_circuit_gpu.py repeats the checks through the kernels."""
+
+import pytest
+import torch
+
+import deepquantum_amd as dq
+from _helpers import check_hessian_benchmark_against_golden, check_hessian_params_against_golden
+
+
+@pytest.mark.parametrize('mode', ['adjoint', 'per_gate'])
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+@pytest.mark.parametrize('case', [(4, 2, 'ones'), (4, 4, 'rand'), (6, 2, 'rand')])
+def test_hessian_of_the_reference_benchmark_circuit(cpu_backend, mode, prec, case):
+    old = dq.executor.CONFIG['grad_mode']
+    dq.executor.CONFIG['grad_mode'] = mode
+    try:
+        n, layer, tag = case
+        before = dq.executor.GRAPH_BACKWARDS['count']
+        check_hessian_benchmark_against_golden(dq, n, layer, prec, tag)
+        if mode == 'adjoint':
+            assert dq.executor.GRAPH_BACKWARDS['count'] > before, 'create_graph=True must take the differentiable route'
+    finally:
+        dq.executor.CONFIG['grad_mode'] = old
+
+
+@pytest.mark.parametrize('mode', ['adjoint', 'per_gate'])
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+def test_hessian_with_respect_to_parameters(cpu_backend, mode, prec):
+    old = dq.executor.CONFIG['grad_mode']
+    dq.executor.CONFIG['grad_mode'] = mode
+    try:
+        check_hessian_params_against_golden(dq, prec)
+    finally:
+        dq.executor.CONFIG['grad_mode'] = old
+
+
+def test_first_order_backward_still_takes_the_sweep(cpu_backend):
+    cir = dq.QubitCircuit(4)
+    cir.hlayer()
+    cir.rxlayer()
+    cir.cnot_ring()
+    cir.observable(0)
+    cir()
+    cir.expectation().sum().backward()
+    assert not dq.executor.LAST_SWEEP['with_graph']
+
+
+def test_the_test_double_builds_no_graph(cpu_backend):
+    """The double is no more capable than the kernels: raw backend calls return graph-less tensors."""
+    x = torch.randn(1, 16, dtype=torch.complex128, requires_grad=True)
+    gy = torch.randn(1, 16, dtype=torch.complex128, requires_grad=True)
+    m = torch.eye(2, dtype=torch.complex128).unsqueeze(0).requires_grad_(True)
+    assert not dq.backend.gate_grad(x, gy, [1], [0]).requires_grad
+    assert not dq.backend.apply_gate(x, m, [1], []).requires_grad
+    assert not dq.backend.expect_pauli(x, 1, 2).requires_grad
+    assert not dq.backend.scale_z_signs(x, [3], torch.ones(1, 1, dtype=torch.float64, requires_grad=True)).requires_grad
+
+
+@pytest.mark.parametrize('controls', [(), (0,), (0, 3)])
+def test_gradgradcheck_of_the_gate_nodes(cpu_backend, controls):
+    """torch.autograd.gradcheck / gradgradcheck on the autograd nodes themselves (complex128, numerical Jacobians)."""
+    from torch.autograd import gradcheck, gradgradcheck
+
+    from deepquantum_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, dtype=torch.complex128, generator=g, requires_grad=True)
+    m1 = torch.randn(1, 2, 2, dtype=torch.complex128, generator=g, requires_grad=True)
+    m2 = torch.randn(2, 4, 4, dtype=torch.complex128, generator=g, requires_grad=True)
+    assert gradcheck(lambda a, b: ops.apply_gate(a, b, (2,), controls), (x, m1))
+    assert gradgradcheck(lambda a, b: ops.apply_gate(a, b, (2,), controls), (x, m1))
+    assert gradgradcheck(lambda a, b: ops.apply_gate(a, b, (4, 1), controls), (x, m2))
+    y = torch.randn(2, 32, dtype=torch.complex128, generator=g, requires_grad=True)
+    assert gradcheck(lambda a, b: ops.gate_grad(a, b, (2,), controls), (x, y))
+    assert gradgradcheck(lambda a, b: ops.gate_grad(a, b, (4, 1), controls), (x, y))
+
+
+def test_gradgradcheck_of_the_reductions(cpu_backend):
+    from torch.autograd import gradcheck, gradgradcheck
+
+    from deepquantum_amd import ops
+
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 16, dtype=torch.complex128, generator=g, requires_grad=True)
+    assert gradcheck(lambda a: ops.expect_pauli(a, 0b0110, 0b0011), (x,))
+    assert gradgradcheck(lambda a: ops.expect_pauli(a, 0b0110, 0b0011), (x,))
+    assert gradgradcheck(lambda a: ops.marginal(a, (3, 0)), (x,))
+    assert gradcheck(lambda a: ops.expect_z_multi(a, (0b0101, 0b1000, 0b0011)), (x,))
+    assert gradgradcheck(lambda a: ops.expect_z_multi(a, (0b0101, 0b1000, 0b0011)), (x,))
+    w = torch.randn(2, 3, dtype=torch.float64, generator=g, requires_grad=True)
+    assert gradcheck(lambda a, b: ops.scale_z_signs(a, (0b0101, 0b1000, 0b0011), b), (x, w))
+    assert gradgradcheck(lambda a, b: ops.scale_z_signs(a, (0b0101, 0b1000, 0b0011), b), (x, w))
