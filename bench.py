@@ -405,6 +405,11 @@ def main():
     sync()
     prof['enabled'] = True
     prof['events'].clear()
+    if distributed:            # per-exchange HIP events on the streams of the sample groups; collectives issued
+        dq.distributed.TIMING['enabled'] = True
+        dq.distributed.TIMING['remaps'].clear()
+        for k_ in dq.communication.COMM_STATS:
+            dq.communication.COMM_STATS[k_] = 0
     step_events = []
     t0 = time.perf_counter()
     out = None
@@ -417,6 +422,21 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     prof['enabled'] = False
+    remap_rows, comm_stats = None, None
+    if distributed:
+        dq.distributed.TIMING['enabled'] = False
+        comm_stats = {k_: v / args.steps for k_, v in dq.communication.COMM_STATS.items()}
+        by_remap = {}
+        for row in dq.distributed.remap_timings():
+            by_remap.setdefault(row['remap'], []).append(row)
+        dq.distributed.TIMING['remaps'].clear()
+        remap_rows = []
+        for r_ in sorted(by_remap):
+            rows_ = by_remap[r_]
+            med = lambda key: (sorted(x[key] for x in rows_ if key in x) or [None])[len([x for x in rows_ if key in x]) // 2]   # noqa: E731
+            remap_rows.append({'remap': r_, 'qubits_exchanged': rows_[0]['k'], 'bytes_each_way_per_group': rows_[0]['bytes'],
+                               'local_passes_ms_median': med('local_ms'), 'issue_to_wait_passed_ms_median': med('wire_ms'),
+                               'samples': len(rows_)})
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -608,6 +628,16 @@ def main():
             wire = dstats['wire_bytes']
             links = min(7, world - 1)
             line['config']['exchange_per_step'] = per_step
+            # what the step does NOT pay (lazy_layout): restoring the reference's shard order, which the reference's
+            # forward always pays -- the drop-in figure is the sum
+            line['ms_per_step_with_restore'] = elapsed / args.steps * 1e3 + (restore_ms or 0.0)
+            line['value_with_restore'] = total_gate_applies / (elapsed + args.steps * (restore_ms or 0.0) * 1e-3)
+            line['config']['collectives_per_step'] = comm_stats
+            line['config']['remap_timings'] = {
+                'what': 'per remap of a step (rank 0, medians over steps and sample groups, HIP events on the group\'s '
+                        'stream): the local passes in front of the exchange; exchange issued -> the stream got past the '
+                        'wait for it (with several groups in flight this includes what the stream did in between)',
+                'remaps': remap_rows}
             line['config']['norm2_sample0'] = norm2
             line['xgmi'] = {
                 'wire_bytes_per_rank_per_step': wire,

@@ -34,6 +34,7 @@ namespace dq {
 #include "dq_wave_asm64.inc"
 
 constexpr int WAVE_LANES = 6;
+#define DQ_WAVE_EXP_DEFAULT 0
 constexpr int WAVE_MAX_REC = 112;
 
 // The two precisions: complex64 -- 64 amplitudes per lane, six slots, a 12-bit tile, slot 0 = index bit 0 inside the
@@ -42,7 +43,7 @@ constexpr int WAVE_MAX_REC = 112;
 struct WaveC64 {
     using real = float;
     using acc_t = float;        // the reverse sweep's accumulators in LDS
-    static constexpr int M = 12, R = 6, NA = 64, VB = 1, MAXK = DQ_WAVE_MAXK, ELEM = 8;
+    static constexpr int M = 12, R = 6, NA = 64, VB = 1, MAXK = DQ_WAVE_MAXK, ELEM = 8, GRAD_VARIANTS = DQ_WAVE_GRAD_VARIANTS;
     static constexpr unsigned LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID_GEN_U, ID_GEN_C = DQ_WID_GEN_C, ID_GEN_R = DQ_WID_GEN_R, ID_X_U = DQ_WID_X_U,
                          ID_X_C = DQ_WID_X_C, ID_X_R = DQ_WID_X_R, ID_X_R1 = DQ_WID_X_R1, ID_TRIP0 = DQ_WID_TRIP0,
@@ -57,7 +58,7 @@ struct WaveC64 {
 struct WaveC128 {
     using real = double;
     using acc_t = double;
-    static constexpr int M = 11, R = 5, NA = 32, VB = 0, MAXK = DQ_WAVE64_MAXK, ELEM = 16;
+    static constexpr int M = 11, R = 5, NA = 32, VB = 0, MAXK = DQ_WAVE64_MAXK, ELEM = 16, GRAD_VARIANTS = 1;
     static constexpr unsigned LDS_PER_WAVE = 8704;      // (7 * 68 + 64) * 16 bytes: the k = 3 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID64_GEN_U, ID_GEN_C = DQ_WID64_GEN_C, ID_GEN_R = DQ_WID64_GEN_R, ID_X_U = DQ_WID64_X_U,
                          ID_X_C = DQ_WID64_X_C, ID_X_R = DQ_WID64_X_R, ID_X_R1 = DQ_WID64_X_R1, ID_TRIP0 = DQ_WID64_TRIP0,
@@ -432,7 +433,9 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
                 for (int s = 0; s < W::R; ++s)
                     if ((g.reg_cmask >> s) & 1u) pc |= 1u << x.slot_of(rd.rb[s]);
                 WaveRec rec{};
-                rec.w[0] = (uint32_t)(W::ID_GRAD + q - 1);
+                // (DqFusedGate::loc = which of the sums the gate's gradient needs: see include/dq_hip.h, DQ_FG_GRAD)
+                const int variant = (int)g.loc < W::GRAD_VARIANTS ? (int)g.loc : 0;
+                rec.w[0] = (uint32_t)(W::ID_GRAD + (W::R - 1) * variant + q - 1);
                 rec.w[1] = g.thr_cmask;
                 rec.w[2] = (uint32_t)g.out_cmask, rec.w[3] = (uint32_t)(g.out_cmask >> 32);
                 for (int j = 0, i = 0; j < W::NA; ++j) {         // group i = the i-th pattern with bits q and 0 clear
@@ -593,9 +596,12 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
         else if (xcd_env > 1 && (xcd_env & (xcd_env - 1)) == 0 && grid.x % (8u * (unsigned)xcd_env) == 0)
             xcd = 32 - __builtin_clz((unsigned)xcd_env);       // log2(C) + 1
     }
+    // experiment switches of the generated code (flags bits 7 ..: DQ_WAVE_EXP bit 0 = raised priority while a wave issues
+    // its loads / stores, bit 1 = the deferred factor applied store by store)
+    static const int exp_env = [] { const char* e = getenv("DQ_WAVE_EXP"); return e ? atoi(e) & 0xff : DQ_WAVE_EXP_DEFAULT; }();
     using V = vec2<typename W::real>;
     hipLaunchKernelGGL((wave_pass_kernel<W, GRAD>), grid, dim3(256), lds, s, static_cast<const V*>(in), static_cast<V*>(out),
-                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, (31 - __builtin_clz((unsigned)tpw)) | (nt << 16) | (xcd << 18), kp, grads, ngrads * 8);
+                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, (31 - __builtin_clz((unsigned)tpw)) | (nt << 16) | (xcd << 18) | (exp_env << 23), kp, grads, ngrads * 8);
     return check_launch("dq_apply_fused (wave tile)");
 }
 

@@ -43,7 +43,7 @@ import torch.distributed as dist
 
 from . import backend, executor
 from .bitmath import get_bit
-from .communication import all_to_all_flat, comm_exchange_arrays
+from .communication import comm_exchange_arrays, exchange_chunks
 from .executor import Prim
 from .qmath import block_sample, measure
 from .state import DistributedQubitState
@@ -182,6 +182,45 @@ class _on:
             self.ctx.__exit__(*exc)
 
 
+#: per-exchange timing (bench.py --gpus N): with ``enabled`` every remap records HIP events on the stream of its sample
+#: group -- before its local passes, when its exchange is issued, and when the wait for it has been passed -- so that
+#: `remap_timings` can tell the last local stretch from the time on the wire
+TIMING: dict = {'enabled': False, 'remaps': []}
+
+
+def _mark(stream):
+    """A timing event on the group's stream (None unless timing is on and the state lives on a GPU)."""
+    if not TIMING['enabled'] or not torch.cuda.is_available():
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record(stream if stream is not None else torch.cuda.current_stream())
+    return ev
+
+
+def _wait(work, stream) -> None:
+    """Pass the wait for an exchange in flight (stream-ordered on RCCL) and note when the stream got past it."""
+    work.wait()
+    if TIMING['enabled']:
+        for rec in TIMING['remaps']:
+            if rec.get('exchange') is work and 'done' not in rec:
+                rec['done'] = _mark(stream)
+
+
+def remap_timings() -> list[dict]:
+    """What `TIMING` recorded, in milliseconds (call after a device synchronisation): per remap and sample group the
+    local passes in front of the exchange (``local_ms``) and issue -> wait passed (``wire_ms``: the exchange itself plus
+    whatever the stream did in between -- with several groups that is the overlap)."""
+    out = []
+    for rec in TIMING['remaps']:
+        row = {k: rec[k] for k in ('remap', 'rows', 'k', 'bytes')}
+        if rec.get('start') is not None and rec.get('issued') is not None:
+            row['local_ms'] = rec['start'].elapsed_time(rec['issued'])
+        if rec.get('issued') is not None and rec.get('done') is not None:
+            row['wire_ms'] = rec['issued'].elapsed_time(rec['done'])
+        out.append(row)
+    return out
+
+
 def _settle(state: DistributedQubitState) -> None:
     """Join the group streams: everything in flight for this state (exchanges included) is ordered before whatever the
     current stream does next."""
@@ -190,11 +229,11 @@ def _settle(state: DistributedQubitState) -> None:
         if stream is not None:
             with torch.cuda.stream(stream):
                 for w in works:
-                    w.wait()
+                    _wait(w, stream)
             torch.cuda.current_stream(stream.device).wait_stream(stream)
         else:
             for w in works:
-                w.wait()
+                _wait(w, None)
     del keep        # (the matrices the group streams were reading: only now may their memory be reused)
 
 
@@ -450,12 +489,12 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     # 2. chunk c goes to the peer whose rank bits `rbits` spell c; what comes back from that peer lands in
     #    the same chunk slot.  Peers outside the 2^k group get empty messages.
     chunk = (1 << (L - k))
-    splits = [0] * W
+    peers = []
     for c in range(1 << k):
         peer = state.rank
         for i, r in enumerate(rbits):
             peer = (peer & ~(1 << r)) | (((c >> i) & 1) << r)
-        splits[peer] = chunk * 2                                # complex -> interleaved reals
+        peers.append(peer)
     a, b = _view(state), _bview(state)
     groups = _row_groups(state)
     streams = _group_streams(state, len(groups))
@@ -466,17 +505,29 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     for rows, stream in zip(groups, streams):
         with _on(stream):
             for w in inflight_prev.pop(id(stream), (None, []))[1]:    # this group's previous exchange
-                w.wait()
+                _wait(w, stream)
+            t_start = _mark(stream)
             in_b = _run_rows(a, b, pending, rows, None if identity else out_perm) if (pending or not identity) else False
             src, dst = (b, a) if in_b else (a, b)
             works = []
             if W > 1 and dist.is_initialized():
                 send, recv = torch.view_as_real(src[rows]), torch.view_as_real(dst[rows])     # (rows, 2^L, 2)
-                for i in range(send.shape[0]):                      # one collective per sample: contiguous chunks
-                    w = all_to_all_flat(recv[i].reshape(-1), send[i].reshape(-1), splits, async_op=stream is not None)
-                    if w is not None:
-                        works.append(w)
-                LAST_RUN['wire_bytes'] += send.shape[0] * ((1 << k) - 1) * chunk * send.element_size() * 2
+                nbytes = send.shape[0] * ((1 << k) - 1) * chunk * send.element_size() * 2
+                t_issue = _mark(stream)
+                # ONE coalesced exchange for all samples of the group (communication.exchange_chunks): every chunk is
+                # contiguous where it lies, (rows x (2^k - 1)) send / receive pairs in one group call
+                ex = exchange_chunks(recv.reshape(send.shape[0], -1), send.reshape(send.shape[0], -1), peers, chunk * 2,
+                                     what=(f'shard exchange of remap {LAST_RUN["remaps"] + 1} (logical qubits leaving / entering '
+                                           f'{pairs}, rank bits {rbits}, samples {rows.start}:{rows.stop}, peers '
+                                           f'{sorted(set(peers) - {state.rank})}, {nbytes} bytes each way)'),
+                                     async_op=stream is not None)
+                if ex is not None:
+                    works.append(ex)
+                LAST_RUN['wire_bytes'] += nbytes
+                if TIMING['enabled']:
+                    TIMING['remaps'].append({'remap': LAST_RUN['remaps'] + 1, 'rows': (rows.start, rows.stop), 'k': k,
+                                             'bytes': nbytes, 'start': t_start, 'issued': t_issue, 'exchange': ex,
+                                             'stream': stream})
             else:
                 dst[rows].copy_(src[rows])
             landed_in_a.append(in_b)

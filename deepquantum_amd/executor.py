@@ -74,6 +74,9 @@ CONFIG = {'fuse': True, 'wave': None,     # None = wave-tile kernel where it tak
           # undo-then-reduce sweep (always used for trainable gates on two or more targets, and for complex128
           # circuits the wave-tile kernel cannot run)
           'fused_sweep': True,
+          # the reductions of the fused sweep form only the sums a trainable gate's gradient can need (2 real sums for a
+          # Pauli-X rotation instead of 4 complex ones; A/B switch)
+          'reduced_grad_sums': True,
           # sharded adjoint: all observables of a circuit share ONE reverse sweep (lambda = sum_k g_k O_k psi); False: one
           # sweep and one (psi, lambda) pair per observable, the reference's structure (circuit.py:1706-1738)
           'joint_adjoint': True,
@@ -797,7 +800,12 @@ class _AdjointCircuit(torch.autograd.Function):
             if need[j]:
                 rows[j] = len(rows)
                 grad_at[len(prims)] = rows[j]
-                prims.append(Prim('grad', None, (t1[0], 0), c1, rows[j]))
+                # which sums this gate's gradient can need (DQ_FG_GRAD variants, include/dq_hip.h): a matrix the gate class
+                # promises to be real / of the form a I + i b X / diagonal has no gradient component in the others
+                variant = 3 if kind == 'diag' else (mode if kind == 'gen' and mode in (1, 2) else 0)
+                if not CONFIG['reduced_grad_sums']:
+                    variant = 0
+                prims.append(Prim('grad', None, (t1[0], 0), c1, rows[j] | (variant << fusion.GRAD_VARIANT_SHIFT)))
             if (inexact is not None and inexact[j] and kind == 'gen' and mode == 3 and not controls and shared[j]
                     and len(targets) == 1):
                 # Hadamard-like, s [[1, 1], [1, -1]] with 2 s^2 = 1 only to float32 rounding: U^dagger U = 2 s^2 exactly,

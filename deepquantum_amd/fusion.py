@@ -24,6 +24,12 @@ from typing import Sequence
 from . import _lib
 
 
+# a 'grad' PrimOp carries row + (variant << GRAD_VARIANT_SHIFT) in ``mode`` (include/dq_hip.h, DQ_FG_GRAD: 0 all sums,
+# 1 a real matrix, 2 a I + i b X, 3 diagonal)
+GRAD_VARIANT_SHIFT = 24
+GRAD_ROW_MASK = (1 << GRAD_VARIANT_SHIFT) - 1
+
+
 @dataclass
 class PrimOp:
     """One kernel-level gate: ``kind`` in {'gen', 'x', 'diag'}; ``targets`` in matrix order (MSB
@@ -1057,7 +1063,8 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
     if op.kind == 'grad':
         g.kind = _lib.FG_GRAD
         g.q, g.q2 = slots
-        g.reserved = op.mode
+        g.reserved = op.mode & GRAD_ROW_MASK
+        g.loc = op.mode >> GRAD_VARIANT_SHIFT        # which sums the gate's gradient needs (include/dq_hip.h)
         return
     if op.k == 1:
         g.kind = _lib.FG_X1 if op.kind == 'x' else _lib.FG_GEN1

@@ -212,11 +212,18 @@ class CpuTestBackend:
                         psi = [t[tile_ok][:, e00].astype(np.complex128), t[tile_ok][:, e00 | (1 << tbit)].astype(np.complex128)]
                         lam = [t[tile_ok][:, e00 | (1 << sbit)].astype(np.complex128),
                                t[tile_ok][:, e00 | (1 << sbit) | (1 << tbit)].astype(np.complex128)]
-                        for a_ in range(2):
-                            for b_ in range(2):
-                                v = np.sum(lam[a_] * np.conj(psi[b_]))
-                                grads[b, g.reserved, 2 * (2 * a_ + b_)] += float(v.real)
-                                grads[b, g.reserved, 2 * (2 * a_ + b_) + 1] += float(v.imag)
+                        G = np.array([[np.sum(lam[a_] * np.conj(psi[b_])) for b_ in range(2)] for a_ in range(2)])
+                        # `loc`: the sums the caller will read; like the kernels, the double forms no others
+                        comp = np.array([G[0, 0].real, G[0, 0].imag, G[0, 1].real, G[0, 1].imag,
+                                         G[1, 0].real, G[1, 0].imag, G[1, 1].real, G[1, 1].imag])
+                        assert g.loc in (0, 1, 2, 3)
+                        if g.loc == 1 and wave and not is128:
+                            comp[1::2] = 0.0
+                        elif g.loc == 2 and wave and not is128:
+                            comp = np.array([(G[0, 0] + G[1, 1]).real, 0, 0, (G[0, 1] + G[1, 0]).imag, 0, 0, 0, 0])
+                        elif g.loc == 3 and wave and not is128:
+                            comp[2:6] = 0.0
+                        grads[b, g.reserved] += torch.from_numpy(comp)
                         continue
                     if g.kind in (_lib.FG_GEN1, _lib.FG_X1):
                         tbit = rb[g.q]

@@ -232,9 +232,11 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None):
                             new = sum(m4[r, c].astype(a.dtype) * old[c] for c in range(4))
                             a[active, regs[r]] = new[active]
                     continue
-                if getattr(g, 'ID_GRAD', 1 << 30) <= hid < getattr(g, 'ID_GRAD', 1 << 30) + 5:
-                    # reduction of the reverse sweep (gen_wave_asm.py, grad_code): target slot q, psi / lambda on slot 0
-                    q = 1 + hid - g.ID_GRAD
+                if getattr(g, 'ID_GRAD', 1 << 30) <= hid < getattr(g, 'ID_GRAD', 1 << 30) + (g.R - 1) * getattr(g, 'GRAD_VARIANTS', 1):
+                    # reduction of the reverse sweep (gen_wave_asm.py, grad_code / grad_code_reduced): target slot q,
+                    # psi / lambda on slot 0; the variant says which sums the handler forms
+                    variant, q = divmod(hid - g.ID_GRAD, g.R - 1)
+                    q += 1
                     acc = np.zeros((2, 2), dtype=np.complex128)
                     for gi, j in enumerate(g.grad_groups(q)):
                         if not (w[5] >> gi) & 1:
@@ -246,10 +248,15 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None):
                                 acc[a_, b_] += np.sum(l_[a_].astype(np.complex128) * np.conj(p_[b_].astype(np.complex128)))
                     acc *= abs(scale) ** 2
                     assert grads is not None, 'a reduction record outside a reverse-sweep pass'
-                    for a_ in range(2):
-                        for b_ in range(2):
-                            grads[b, w[6], 2 * (2 * a_ + b_)] += acc[a_, b_].real
-                            grads[b, w[6], 2 * (2 * a_ + b_) + 1] += acc[a_, b_].imag
+                    comp = np.array([acc[0, 0].real, acc[0, 0].imag, acc[0, 1].real, acc[0, 1].imag,
+                                     acc[1, 0].real, acc[1, 0].imag, acc[1, 1].real, acc[1, 1].imag])
+                    if variant == 1:
+                        comp[1::2] = 0.0
+                    elif variant == 2:
+                        comp = np.array([(acc[0, 0] + acc[1, 1]).real, 0, 0, (acc[0, 1] + acc[1, 0]).imag, 0, 0, 0, 0])
+                    elif variant == 3:
+                        comp[2:6] = 0.0
+                    grads[b, w[6]] += comp
                     continue
                 if hid >= g.ID_DIAG1:
                     # diagonal gate (tools/gen_wave_asm.py, diag_code): four phases, candidates by the indices in w5,

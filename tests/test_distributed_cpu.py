@@ -296,6 +296,40 @@ def _case_batched_w4(dq, rank, world):
     _both_modes(dq, run)
 
 
+def _case_grouped_exchange_w4(dq, rank, world):
+    """One coalesced exchange per group of samples (communication.exchange_chunks) against one collective per sample:
+    the same shards, a fraction of the collectives; and the per-remap timing records stay consistent."""
+    import specs
+    from deepquantum_amd import communication as comm
+    from deepquantum_amd import distributed as D
+
+    n, B = 10, 6
+    data = torch.rand(B, specs.build(dq, n, specs.BATCHED10).ndata, generator=torch.Generator().manual_seed(5)) * 6.28
+    per = 2**n // world
+    res, calls = {}, {}
+    for grouped in (True, False):
+        comm.COMM_CONFIG['grouped_exchange'] = grouped
+        for k_ in comm.COMM_STATS:
+            comm.COMM_STATS[k_] = 0
+        shard = dq.DistributedQubitCircuit(n)
+        _apply_spec(shard, specs.BATCHED10)
+        shard.observable(0)
+        with torch.no_grad():
+            st = shard(data)
+            res[grouped] = (st.amps.clone(), shard.expectation().clone())
+        calls[grouped] = (comm.COMM_STATS['collectives'], D.LAST_RUN['remaps'], D.LAST_RUN['groups'])
+    comm.COMM_CONFIG['grouped_exchange'] = True
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    dense = specs.build(dq, n, specs.BATCHED10)
+    with torch.no_grad():
+        ref = dense(data).reshape(B, -1)
+    assert (res[True][0] - ref[:, rank * per:(rank + 1) * per]).abs().max().item() < 1e-5
+    (g_calls, remaps, groups), (s_calls, _, _) = calls[True], calls[False]
+    assert remaps > 0 and s_calls >= B * remaps - B, (calls,)     # (per sample: B collectives per remap, + the restore)
+    assert g_calls <= groups * (remaps + 2), (calls,)              # (grouped: one per sample group and remap)
+    assert g_calls * 2 <= s_calls, (calls,)
+
+
 def _golden_dist_check(dq, rank, world, names, device=None, tol=2e-5):
     """Shards, expectation values and adjoint gradients against what the REAL reference produced under the
     same number of gloo ranks (tests/golden/golden_dist.npz, made by make_golden_dist.py)."""
@@ -469,7 +503,7 @@ def _case_sampled_expectation_w4(dq, rank, world):
                                         ('random_remap_w4', 4), ('remap_w8', 8),
                                         ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4), ('folded_permute_w2', 2),
                                         ('golden_w2', 2), ('golden_w4', 4), ('golden_w8', 8),
-                                        ('fused_sweep_w2', 2), ('fused_sweep_w4', 4)])
+                                        ('fused_sweep_w2', 2), ('fused_sweep_w4', 4), ('grouped_exchange_w4', 4)])
 def test_sharded_circuit(case, world):
     _run(case, world)
 
@@ -573,3 +607,39 @@ def test_gates_reordered_along_the_commutation_dag_need_fewer_exchanges():
         better = D.count_exchange_steps(D._order_for_remaps(big, list(range(nn)), nn, nn - gg), nn, gg)
         assert better['remap_steps'] * 2 <= plain['remap_steps'], (plain, better)
         assert better['remap_volume'] * 2 <= plain['remap_volume'], (plain, better)
+
+
+def test_exchange_watchdog_names_a_stalled_exchange(capfd):
+    """An exchange that does not complete is reported on stderr with what it is, without blocking anybody
+    (communication._watch); one that completes is forgotten silently."""
+    import time
+
+    from deepquantum_amd import communication as comm
+
+    class Work:
+        def __init__(self, done):
+            self.done = done
+
+        def is_completed(self):
+            return self.done
+
+        def wait(self):
+            pass
+
+    old = comm.COMM_CONFIG['watchdog_seconds']
+    comm.COMM_CONFIG['watchdog_seconds'] = 0.2
+    try:
+        stuck = comm.Exchange([Work(False)], 'shard exchange of remap 3 (peers [1, 2], 4096 bytes each way)')
+        fine = comm.Exchange([Work(True)], 'shard exchange of remap 4 (peers [3], 64 bytes each way)')
+        comm._watch(stuck)
+        comm._watch(fine)
+        time.sleep(1.0)
+        err = capfd.readouterr().err
+        assert 'watchdog' in err and 'remap 3' in err and 'peers [1, 2]' in err and 'remap 4' not in err
+        stuck.works[0].done = True              # it completes after all: no further reports
+        time.sleep(0.5)
+        capfd.readouterr()
+        time.sleep(0.6)
+        assert 'remap 3' not in capfd.readouterr().err
+    finally:
+        comm.COMM_CONFIG['watchdog_seconds'] = old

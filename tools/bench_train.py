@@ -21,6 +21,8 @@ ap.add_argument('--no-fused-sweep', action='store_true', help='A/B: the undo-the
 args = ap.parse_args()
 
 dq.executor.CONFIG['fused_sweep'] = not args.no_fused_sweep
+if os.environ.get('DQ_REDUCED_GRAD') == '0':          # A/B: every reduction forms all of G
+    dq.executor.CONFIG['reduced_grad_sums'] = False
 for mode in args.modes.split(','):
     dq.executor.CONFIG['grad_mode'] = mode
     cir = dq.QubitCircuit(args.n)

@@ -198,8 +198,12 @@ ID_DIAG1 = ID_SWAP + len(SWAP_PAIRS)
 ID_DIAG2 = ID_DIAG1 + 14
 # reduction of the adjoint method's reverse sweep: target on slot 1 + (id - ID_GRAD), psi / lambda told apart by slot 0
 ID_GRAD = ID_DIAG2 + 14
+# + 5 * variant + (slot - 1).  Variants (DqFusedGate::loc of a DQ_FG_GRAD record: what the trainable gate's matrix can
+# depend on decides which sums its gradient needs): 0 all of G; 1 Re G only (a real matrix: Ry); 2 Re (G00 + G11) and
+# Im (G01 + G10) only (a I + i b X: Rx, CRx); 3 the diagonal G00, G11 only (a diagonal gate on a slot)
+GRAD_VARIANTS = 4
 # expectation value of a Z string, reduced from the registers (DQ_FG_EXPZ): same accumulators as the reductions above
-ID_EXPZ = ID_GRAD + 5
+ID_EXPZ = ID_GRAD + 5 * GRAD_VARIANTS
 # dense gate on two register slots a < b (index in SWAP_PAIRS): a 4x4 matrix, index = 2 * (bit of slot b) + (bit of slot a)
 ID_GEN2 = ID_EXPZ + 1
 NIDS = ID_GEN2 + 15
@@ -223,6 +227,8 @@ def handlers():
                 h[ID_X_R1 + 5 * q + (c if c < q else c - 1)] = (True, xlines(q, 1 << c))
     for q in range(1, R):
         h[ID_GRAD + q - 1] = (False, grad_code(q))
+        for v in range(1, GRAD_VARIANTS):
+            h[ID_GRAD + 5 * v + q - 1] = (False, grad_code_reduced(q, v))
     h[ID_EXPZ] = (False, expz_code())
     h[ID_TRIP0] = (False, trip(0, 0))
     for i, m in enumerate(TRIP_MASKS):
@@ -353,6 +359,77 @@ def grad_code(q):
     return t
 
 
+def grad_code_reduced(q, variant):
+    """The reduction of `grad_code` for a trainable gate whose matrix is known to be real (variant 1: only Re G is needed,
+    four real sums), of the form a I + i b X (variant 2: only Re (G00 + G11) and Im (G01 + G10), two real sums -- its
+    gradient has no other component) or diagonal (variant 3: G00 and G11).  Per register group four packed operations
+    instead of eight, 2 or 4 sums per lane instead of 8: a reduce-scatter over one or two lane bits, butterflies over the
+    others of a row of 16 lanes, and 2 or 4 lanes of every row add to the record's accumulators.  The sums land in the
+    components of the full layout (G00 G01 G10 G11) x (re, im): variant 2 leaves Re (G00 + G11) in Re G00 and
+    Im (G01 + G10) in Im G01 -- multiplied by the inverse of a matrix of the same form that is all the chain rule reads."""
+    ACC = ['v[10:11]', 'v[12:13]', 'v[14:15]', 'v[16:17]']
+    CROSS = 'op_sel:[0,1,0] op_sel_hi:[1,0,1]'        # (l.re p.im, l.im p.re): Im (l conj p) = hi - lo
+    tag = f'{q}v{variant}'
+    t = [f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc0 .Lnext_%=']
+    t += [f'v_mov_b32 v{r}, 0' for r in range(10, 18)]
+    t += [f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
+          f's_cbranch_execz .Lgz{tag}_%=']
+    for i, j in enumerate(grad_groups(q)):
+        p0, l0, p1, l1 = A(j), A(j | 1), A(j | (1 << q)), A(j | (1 << q) | 1)
+        t += [f's_bitcmp1_b32 s{REC + 5}, {i}', f's_cbranch_scc0 .Lgg{tag}_{i}_%=']
+        if variant == 1:
+            t += [f'v_pk_fma_f32 {g_}, {l_}, {p_}, {g_}' for g_, l_, p_ in ((ACC[0], l0, p0), (ACC[1], l0, p1), (ACC[2], l1, p0), (ACC[3], l1, p1))]
+        elif variant == 2:
+            t += [f'v_pk_fma_f32 {ACC[0]}, {l0}, {p0}, {ACC[0]}', f'v_pk_fma_f32 {ACC[1]}, {l0}, {p1}, {ACC[1]} {CROSS}',
+                  f'v_pk_fma_f32 {ACC[2]}, {l1}, {p1}, {ACC[2]}', f'v_pk_fma_f32 {ACC[3]}, {l1}, {p0}, {ACC[3]} {CROSS}']
+        else:
+            t += [f'v_pk_fma_f32 {ACC[0]}, {l0}, {p0}, {ACC[0]}', f'v_pk_fma_f32 {ACC[1]}, {l0}, {p0}, {ACC[1]} {CROSS}',
+                  f'v_pk_fma_f32 {ACC[2]}, {l1}, {p1}, {ACC[2]}', f'v_pk_fma_f32 {ACC[3]}, {l1}, {p1}, {ACC[3]} {CROSS}']
+        t.append(f'.Lgg{tag}_{i}_%=:')
+    t += [f'.Lgz{tag}_%=:', f's_mov_b64 exec, {SAVE}', f'v_mul_f32 {TT}, {HR}, {HR}', f'v_fma_f32 {TT}, {HI}, {HI}, {TT}']
+    if variant == 1:       # v10, v12, v14, v16 = Re G00, G01, G10, G11
+        t += ['v_add_f32 v10, v10, v11', 'v_add_f32 v12, v12, v13', 'v_add_f32 v14, v14, v15', 'v_add_f32 v16, v16, v17']
+        nval = 4
+    elif variant == 2:     # v10 = Re (G00 + G11), v12 = Im (G01 + G10)
+        t += ['v_pk_add_f32 v[10:11], v[10:11], v[14:15]', 'v_pk_add_f32 v[12:13], v[12:13], v[16:17]', 's_nop 0',
+              'v_add_f32 v10, v10, v11', 'v_sub_f32 v12, v13, v12']
+        nval = 2
+    else:                  # v10, v12 = Re, Im G00; v14, v16 = Re, Im G11
+        t += ['v_add_f32 v10, v10, v11', 'v_sub_f32 v12, v13, v12', 'v_add_f32 v14, v14, v15', 'v_sub_f32 v16, v17, v16']
+        nval = 4
+    dpp = 'row_mask:0xf'
+    # lane bit 2: lanes with the bit clear take over the first sum of each pair, the others the second
+    t += ['s_nop 1', f'v_add_f32_dpp v10, v10, v10 row_shl:4 {dpp} bank_mask:0x5']
+    if nval == 4:
+        t += [f'v_add_f32_dpp v14, v14, v14 row_shl:4 {dpp} bank_mask:0x5']
+    t += [f'v_add_f32_dpp v10, v12, v12 row_shr:4 {dpp} bank_mask:0xa']
+    if nval == 4:
+        t += [f'v_add_f32_dpp v14, v16, v16 row_shr:4 {dpp} bank_mask:0xa',
+              # lane bit 3: the lower half of a row keeps the first pair, the upper half the second
+              's_nop 1', f'v_add_f32_dpp v10, v10, v10 row_shl:8 {dpp} bank_mask:0x3',
+              's_nop 1', f'v_add_f32_dpp v10, v14, v14 row_shr:8 {dpp} bank_mask:0xc']
+    else:
+        t += ['s_nop 1', f'v_add_f32_dpp v10, v10, v10 row_ror:8 {dpp} bank_mask:0xf']
+    t += ['s_nop 1', f'v_add_f32_dpp v10, v10, v10 quad_perm:[1,0,3,2] {dpp} bank_mask:0xf',
+          's_nop 1', f'v_add_f32_dpp v10, v10, v10 quad_perm:[2,3,0,1] {dpp} bank_mask:0xf',
+          's_nop 0', f'v_mul_f32 v10, v10, {TT}']
+    # the lane with bits (b3, b2) holds sum number 2 b3 + b2 (variant 2: number b2); byte offset of its component
+    if variant == 1:       # components 0, 2, 4, 6
+        t += [f'v_bfe_u32 v32, {LANE}, 2, 2', 'v_lshlrev_b32 v32, 3, v32']
+        ex = 0x11111111
+    elif variant == 2:     # components 0, 3
+        t += [f'v_bfe_u32 v32, {LANE}, 2, 1', 'v_mul_u32_u24 v32, 12, v32']
+        ex = 0x00110011
+    else:                  # components 0, 1, 6, 7
+        t += [f'v_bfe_u32 v32, {LANE}, 2, 2', f'v_bfe_u32 v33, {LANE}, 3, 1', 'v_lshlrev_b32 v32, 2, v32', 'v_mad_u32_u24 v32, v33, 16, v32']
+        ex = 0x11111111
+    t += [f'v_add_u32 v32, {GOFF}, v32', f'v_add_u32 v32, {ACC_BASE - 32}, v32',
+          f's_mov_b32 exec_lo, {hex(ex)}', f's_mov_b32 exec_hi, {hex(ex)}',
+          'ds_add_f32 v32, v10',
+          's_mov_b64 exec, -1']
+    return t
+
+
 G2ROW = [88, 40, 80, 72]         # SGPR base of matrix row r (eight dwords: four complex entries)
 
 
@@ -446,7 +523,7 @@ def expz_code():
     return t
 
 
-def gray_walk(op, base_operand, lane_operand, nt=False):
+def gray_walk(op, base_operand, lane_operand, nt=False, scale=None):
     """32 x (address = base + running slot offset + lane offset; op).  The running offset follows a Gray code over the
     slot bits 1..5, so each step is one 64-bit scalar add or subtract."""
     out_ = [f's_mov_b64 {RUN}, {base_operand}']
@@ -462,6 +539,8 @@ def gray_walk(op, base_operand, lane_operand, nt=False):
         ad = ADDR[i % 4]
         out_.append(f'v_lshl_add_u64 {ad}, {RUN}, 0, {lane_operand}')
         regs = f'v[{AMP0 + 4 * g}:{AMP0 + 4 * g + 3}]'
+        if scale is not None:          # (experiment: the deferred factor applied right before each store)
+            out_ += [f'v_pk_mul_f32 {A(2 * g)}, {A(2 * g)}, {scale}', f'v_pk_mul_f32 {A(2 * g + 1)}, {A(2 * g + 1)}, {scale}']
         out_.append((f'global_load_dwordx4 {regs}, {ad}, off' if op == 'load' else f'global_store_dwordx4 {ad}, {regs}, off') + (' nt' if nt else ''))
     return out_
 
@@ -511,8 +590,10 @@ def kernel_body():
     # streaming (non-temporal) loads and stores when the host says so (flags bit 0 / 1: states far bigger than the
     # caches; +10-15 % on the memory side, tools/experiments/mb_wavetile.hip), plain ones otherwise (small states live in
     # the Infinity Cache between passes; the pass that reads ONE shared input state relies on the L2)
+    # (experiment, flags bit 7: the waves that issue memory instructions run at a raised priority)
+    text += ['s_bitcmp1_b32 %[flags], 7', 's_cbranch_scc0 .Lnpl_%=', 's_setprio 3', '.Lnpl_%=:']
     text += ['s_bitcmp1_b32 %[flags], 0', 's_cbranch_scc0 .Lldp_%='] + gray_walk('load', '%[inb]', LLD, nt=True) + ['s_branch .Lldd_%=', '.Lldp_%=:']
-    text += gray_walk('load', '%[inb]', LLD) + ['.Lldd_%=:']
+    text += gray_walk('load', '%[inb]', LLD) + ['.Lldd_%=:', 's_setprio 0']
     # the first record and its matrix arrive with the tile
     text += prefetch('first')
     text += [f's_getpc_b64 {TABLE}', '.Lanchor_%=:', 's_add_u32 s54, s54, .Ltable_%=-.Lanchor_%=', 's_addc_u32 s55, s55, 0',
@@ -534,9 +615,16 @@ def kernel_body():
                                                          's_branch .Ldiag_%=' if i >= ID_DIAG1 else 's_branch .Lnext_%='))
     # ---- epilogue: the pass's deferred factor, then the stores ----
     text += ['.Lexit_%=:', 's_load_dwordx8 s[40:47], %[ks], 40', 's_load_dwordx2 s[48:49], %[ks], 72',
+             's_bitcmp1_b32 %[flags], 7', 's_cbranch_scc0 .Lnps_%=', 's_setprio 3', '.Lnps_%=:',
              's_waitcnt lgkmcnt(0)',          # (the slot offsets -- and the LDS reads of a trip that ended the pass)
              f'v_readfirstlane_b32 {STMP}, {HI}', f'v_mov_b32 v10, {HR}', f'v_mov_b32 v11, {HR}',
              f's_cmp_eq_u32 {STMP}, 0', 's_cbranch_scc0 .Lcplx_%=']
+    # (experiment, flags bit 8, real factor only: scale two amplitudes, store them, scale the next two ... -- the first
+    # stores leave 64 packed multiplications earlier)
+    text += ['s_bitcmp1_b32 %[flags], 8', 's_cbranch_scc0 .Lnil_%=',
+             's_bitcmp1_b32 %[flags], 1', 's_cbranch_scc0 .Lilp_%=']
+    text += gray_walk('store', '%[outb]', LST, nt=True, scale='v[10:11]') + ['s_branch .Ldone_%=', '.Lilp_%=:']
+    text += gray_walk('store', '%[outb]', LST, scale='v[10:11]') + ['s_branch .Ldone_%=', '.Lnil_%=:']
     text += [f'v_pk_mul_f32 {A(j)}, {A(j)}, v[10:11]' for j in range(NA)]
     text += ['s_branch .Lstore_%=', '.Lcplx_%=:', f'v_mov_b32 v12, {HI}', f'v_mov_b32 v13, {HI}']
     for j in range(NA):
@@ -560,7 +648,7 @@ out = ['// GENERATED by tools/gen_wave_asm.py -- do not edit by hand.', '// clan
        f'#define DQ_WID_GEN_U {ID_GEN_U}', f'#define DQ_WID_GEN_C {ID_GEN_C}', f'#define DQ_WID_GEN_R {ID_GEN_R}',
        f'#define DQ_WID_X_U {ID_X_U}', f'#define DQ_WID_X_C {ID_X_C}', f'#define DQ_WID_X_R {ID_X_R}', f'#define DQ_WID_X_R1 {ID_X_R1}',
        f'#define DQ_WID_TRIP0 {ID_TRIP0}', f'#define DQ_WID_TRIP {ID_TRIP}', f'#define DQ_WID_SWAP {ID_SWAP}',
-       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WID_EXPZ {ID_EXPZ}', f'#define DQ_WID_GEN2 {ID_GEN2}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
+       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WAVE_GRAD_VARIANTS {GRAD_VARIANTS}', f'#define DQ_WID_EXPZ {ID_EXPZ}', f'#define DQ_WID_GEN2 {ID_GEN2}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
        '// trip handler id by slot mask (popcount 1..DQ_WAVE_MAXK), -1 otherwise; slot-swap handler id by (i < j)',
        'static const short kWaveTripId[64] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(64)) + '};',
        'static const short kWaveSwapId[6][6] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
