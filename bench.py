@@ -62,7 +62,6 @@ def parse_args():
     ap.add_argument('--backend', default='nccl', help="process-group backend for N > 1 ('nccl' = RCCL; 'gloo' lets "
                     'several ranks share one GPU for a functional check)')
     # A/B knobs
-    ap.add_argument('--tile-bits', type=int, default=None, help='override fused tile size m')
     ap.add_argument('--min-low', type=int, default=None)
     ap.add_argument('--max-gates', type=int, default=None)
     ap.add_argument('--no-fuse', action='store_true')
@@ -72,13 +71,10 @@ def parse_args():
                     help='pass planner beam width (0 = first-come tiles, 1 = greedy; default: library)')
     ap.add_argument('--plan-branch', type=int, default=None, help='pass planner: tiles tried per beam state')
     ap.add_argument('--plan-restarts', type=int, default=None, help='pass planner: beam searches with different seeds')
-    ap.add_argument('--no-asm-loop', action='store_true', help='A/B: gate loop in C++ around the jump table')
     ap.add_argument('--no-fused-expectation', action='store_true',
                     help='A/B: <Z0> from a separate read of the final state instead of the registers of the last pass')
     ap.add_argument('--no-fused-sweep', action='store_true',
                     help='A/B (config 5): gate-by-gate reverse sweep of the sharded adjoint instead of fused passes')
-    ap.add_argument('--no-wave', action='store_true',
-                    help='A/B: complex64 on the workgroup-tile kernels (13-bit tiles, barriers) instead of the wave-tile kernel')
     ap.add_argument('--no-compare', action='store_true',
                     help='skip the extra runs (merging off, single-gate sweep): tools/profile.sh uses it so that the '
                          'profiled launches are the timed ones only')
@@ -86,13 +82,7 @@ def parse_args():
                     help='A/B: in-place passes (every pass gathers its qubits where they canonically live)')
     ap.add_argument('--no-merge', action='store_true',
                     help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
-    ap.add_argument('--no-lane-swaps', action='store_true',
-                    help='A/B: every layout change of a pass goes through LDS (no in-wave permlane / DPP exchanges)')
     ap.add_argument('--no-free-low', action='store_true', help='A/B: the contiguous low bits keep the same qubits in every pass')
-    ap.add_argument('--swap-lanes', default=None, help='A/B: lane bits usable for in-wave exchanges, e.g. 4,5')
-    ap.add_argument('--swap-policy', default=None, choices=['plan', 'chance'])
-    ap.add_argument('--tiles-per-wg', type=int, default=None,
-                    help='A/B: tiles a complex64 workgroup walks with next-tile prefetch (1 = off; default: library)')
     ap.add_argument('--overlap-groups', type=int, default=None, help='N > 1: sample groups of the overlapped remap')
     ap.add_argument('--no-fold-permute', action='store_true',
                     help='N > 1, A/B: the re-labelling before an exchange as a pass of its own')
@@ -328,9 +318,6 @@ def main():
     n = per_gpu + (int(math.log2(world)) if distributed else 0)
     nbatch = batch or 1
 
-    key = 'm_c64' if dtype == torch.complex64 else 'm_c128'
-    if args.tile_bits is not None:
-        dq.executor.CONFIG[key] = args.tile_bits
     if args.min_low is not None:
         dq.executor.CONFIG['min_low_c64' if dtype == torch.complex64 else 'min_low_c128'] = args.min_low
     if args.max_gates is not None:
@@ -342,10 +329,6 @@ def main():
     dq.executor.CONFIG['plan_width'] = args.plan_width
     dq.executor.CONFIG['plan_branch'] = args.plan_branch
     dq.executor.CONFIG['plan_restarts'] = args.plan_restarts
-    if args.no_asm_loop:
-        dq.executor.CONFIG['asm_loop'] = False
-    if args.no_wave:
-        dq.executor.CONFIG['wave'] = False
     if args.no_fused_expectation:
         dq.executor.CONFIG['fused_expectation'] = False
     if args.no_fused_sweep:
@@ -354,22 +337,12 @@ def main():
         dq.executor.CONFIG['merge_min_amps'] = None
     if args.no_permute_store:
         dq.executor.CONFIG['permute_store'] = False
-    if args.no_lane_swaps:
-        dq.executor.CONFIG['lane_swaps'] = False
     if args.no_free_low:
         dq.executor.CONFIG['free_low'] = False
-    if args.swap_policy is not None:
-        dq.executor.CONFIG['swap_policy'] = args.swap_policy
-    if args.swap_lanes is not None:
-        dq.executor.CONFIG['swap_lanes'] = tuple(int(x) for x in args.swap_lanes.split(',') if x != '')
     if args.overlap_groups is not None:
         dq.distributed.CONFIG['overlap_groups'] = args.overlap_groups
     if args.no_fold_permute:
         dq.distributed.CONFIG['fold_permute'] = False
-    if args.tiles_per_wg is not None:
-        from deepquantum_amd import _lib
-
-        _lib.check(_lib.load().dq_fused_set_tiles_per_wg(args.tiles_per_wg), 'dq_fused_set_tiles_per_wg')
 
     spec = random_circuit_spec(n, args.depth, args.seed)
     extra = []
@@ -574,7 +547,6 @@ def main():
                 'ms_restore_canonical_layout': restore_ms,
                 'fused_passes_per_step': stats.get('passes') if not distributed else launches / args.steps,
                 'lds_round_trips_per_step': stats.get('transposes') if not distributed else None,
-                'in_wave_exchange_rounds_per_step': stats.get('swaps') if not distributed else None,
                 # 2x2 matrices the kernel applies per sample after runs of one-qubit gates on the same qubit were
                 # multiplied together (executor.merge_one_qubit_runs; `--no-merge` applies all `ngates` one by one);
                 # `value` counts the circuit's gates, `unmerged_ms_per_step` times them one by one
@@ -589,8 +561,7 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm',
-                'kernel': ('dq::wave_pass_kernel' if dq.executor.CONFIG.get('wave') is not False and not args.tile_bits
-                           else 'dq::fused_pass_kernel'),
+                'kernel': 'dq::wave_pass_kernel',
                 # PHYSICAL rate of the dominant kernel: bytes its launches read + wrote / their summed duration
                 'achieved': physical,
                 'peak': HBM_PEAK_GBS,

@@ -16,10 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DQHIP_LIBRARY') or os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
-FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_SWAP, FG_GRAD, FG_EXPZ = range(8)
+FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_RESERVED5, FG_GRAD, FG_EXPZ = range(8)
 LOC_REG, LOC_THR, LOC_OUT = range(3)
 
 FUSED_MAX_HIGH = 12
@@ -29,10 +29,8 @@ FUSED_MAX_GATES = 80
 FUSED_MAX_SLOTS = 6
 FUSED_MAX_TBITS = 9
 FUSED_MAX_BLK = 24
-ROUND_ALL_FAST = 0x80
 ROUND_TRANSPOSE = 0x01
 ROUND_TRANSPOSE_AFTER = 0x02
-ROUND_SWAP = 0x04
 FAST_NONE = 0xFFFFFFFF
 MAT_PAD = 16
 
@@ -79,7 +77,6 @@ class DqFusedPass(C.Structure):
         ('gates', DqFusedGate * FUSED_MAX_GATES),
         ('load_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),
         ('store_slot_off', C.c_uint64 * FUSED_MAX_SLOTS),
-        ('lds_tab', (C.c_uint16 * 16) * (FUSED_MAX_ROUNDS + 2)),
         ('store_high_pos', C.c_uint8 * FUSED_MAX_HIGH),
         ('store_blk_pos', C.c_uint8 * FUSED_MAX_BLK),
         ('store_low_pos', C.c_uint8 * FUSED_MAX_LOW),
@@ -98,7 +95,6 @@ _SIGNATURES = {
     'dq_struct_layout': (_i, [_ip, _i]),
     'dq_device_info': (_i, [_ip, C.POINTER(_i64), C.POINTER(_i64)]),
     'dq_fused_geometry': (_i, [_i, _i, _ip, _ip, _ip]),
-    'dq_fused_set_tiles_per_wg': (_i, [_i]),
     'dq_wave_descriptor': (_i, [C.POINTER(DqFusedPass), _i, _vp, _i]),
     'dq_dag_create': (_vp, [_i, _vp, _vp, _vp, _vp]),
     'dq_dag_destroy': (None, [_vp]),

@@ -98,7 +98,7 @@ def _sweep_fused_sharded(ctx, grad_out, params):
         return None
     is128 = phi.amps.dtype == torch.complex128
     geom = executor._geometry(is128)
-    if phi.log_num_amps_per_node + 1 < (geom.fallback.m if geom.fallback is not None else geom.m):
+    if phi.log_num_amps_per_node + 1 < geom.m:
         return None
     gates = list(reversed(_flatten_gates(ctx.operators)))
     prims: list[Prim] = []
@@ -125,8 +125,6 @@ def _sweep_fused_sharded(ctx, grad_out, params):
     if not todo:
         return [None] * len(slots)
     ops = [fusion.PrimOp(q.kind, q.targets, q.controls, 0, q.mode) for q in prims]
-    if is128 and not (geom.wave and fusion.wave_supports(ops, is128)):
-        return None
     if any(len(q.targets) > 2 for q in prims):
         return None
     # the pair as a sharded state of n + 1 qubits: bit 0 tells psi from lambda, the rank bits are the same

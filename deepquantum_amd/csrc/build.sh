@@ -5,14 +5,14 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${here}/../libdqhip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-srcs=(dq_capi.hip dq_gate.hip dq_dense.hip dq_fused.hip dq_wave.hip dq_reduce.hip dq_dist.hip dq_plan.hip)
+srcs=(dq_capi.hip dq_gate.hip dq_dense.hip dq_pass.hip dq_wave.hip dq_reduce.hip dq_dist.hip dq_plan.hip)
 objs=()
 mkdir -p "${here}/build"
 pids=()
 for s in "${srcs[@]}"; do
   o="${here}/build/${s%.hip}.o"
   objs+=("$o")
-  if [[ ! -f "$o" || "${here}/$s" -nt "$o" || "${here}/dq_common.hpp" -nt "$o" || "${here}/../../include/dq_hip.h" -nt "$o" || ( "$s" == dq_fused.hip && "${here}/dq_fused_asm.inc" -nt "$o" ) || ( "$s" == dq_wave.hip && ( "${here}/dq_wave_asm.inc" -nt "$o" || "${here}/dq_wave_asm64.inc" -nt "$o" ) ) ]]; then
+  if [[ ! -f "$o" || "${here}/$s" -nt "$o" || "${here}/dq_common.hpp" -nt "$o" || "${here}/../../include/dq_hip.h" -nt "$o" || ( "$s" == dq_wave.hip && ( "${here}/dq_wave_asm.inc" -nt "$o" || "${here}/dq_wave_asm64.inc" -nt "$o" ) ) ]]; then
     if [[ "$s" == dq_wave.hip ]]; then
       "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value -mllvm -simplifycfg-sink-common=false -mllvm -structurizecfg-skip-uniform-regions -Rpass-analysis=kernel-resource-usage ${DQ_HIPCC_EXTRA:-} -c "${here}/$s" -o "$o" 2> "${here}/build/dq_wave.usage" &
     else

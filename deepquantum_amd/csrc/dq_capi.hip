@@ -59,7 +59,7 @@ extern "C" int dq_abi_version(void) { return DQ_ABI_VERSION; }
 extern "C" int dq_struct_layout(int* out, int max) {
     const int v[] = {(int)sizeof(DqFusedGate), (int)sizeof(DqFusedRound), (int)sizeof(DqFusedPass),
                      (int)offsetof(DqFusedPass, rounds), (int)offsetof(DqFusedPass, gates), (int)offsetof(DqFusedPass, load_slot_off),
-                     (int)offsetof(DqFusedPass, lds_tab), (int)offsetof(DqFusedPass, store_high_pos), (int)offsetof(DqFusedPass, store_tb),
+                     (int)offsetof(DqFusedPass, store_high_pos), (int)offsetof(DqFusedPass, store_tb),
                      (int)offsetof(DqFusedPass, slots)};
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < max && out; ++i) out[i] = v[i];

@@ -79,7 +79,7 @@ int check_launch(const char* what);
 
 inline hipStream_t as_stream(dq_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-// The wave-tile geometry of complex64 passes (csrc/dq_wave.hip); `pass` has been validated by dq_fused.hip.
+// The wave-tile geometry of complex64 passes (csrc/dq_wave.hip); `pass` has been validated by dq_pass.hip.
 int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                     const DqFusedPass* pass, hipStream_t s);
 int wave_launch_grad_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,

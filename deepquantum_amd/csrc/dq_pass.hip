@@ -1,0 +1,331 @@
+// Fused pass, host side: the C entry points dq_apply_fused_* / dq_apply_fused_grad_* / dq_apply_fused_bcast_* check a
+// pass descriptor (DqFusedPass, include/dq_hip.h -- the host scheduler deepquantum_amd/fusion.py builds it) and hand it to
+// the wave-tile kernel (csrc/dq_wave.hip), the ONE pass kernel of the library since ABI 21: one wavefront owns a tile,
+// one HBM read + one HBM write of the state applies every gate of the pass.  Replaces a run of consecutive Gate.forward
+// calls of the reference (circuit.py:261 -> operation.py:274-289 -> qmath.py:485-506 / operation.py:203-219), each of
+// which costs the reference >= 2 full read + write passes.
+//
+// (Rounds 1-3 also had workgroup-tile kernels here -- 512 threads sharing a 13-bit tile through LDS, two barriers per
+// layout change; 0.46-0.51 of the HBM peak against the wave tile's 0.67 -- kept for complex128 two-target dense gates
+// until the wave-tile kernel learned them.  DESIGN.md 4.1 keeps their measurements.)
+#include "dq_common.hpp"
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace dq {
+
+struct FusedVariant {
+    int m, slots, logt;
+};
+// the wave tile of each precision (csrc/dq_wave.hip): 64 lanes x 64 complex64 / 32 complex128 amplitudes
+static const FusedVariant kVariantsC64[] = {{12, 6, 6}};
+static const FusedVariant kVariantsC128[] = {{11, 5, 6}};
+static const int kNumVariantsC64 = 1, kNumVariantsC128 = 1;
+
+// ngrads: rows of the caller's accumulator (dq_apply_fused_grad_*), -1 = a plain pass (DQ_FG_GRAD records refused)
+template <typename T>
+static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64_t ngrads = -1) {
+    const int m = slots + logt;
+    if (p->m != m || p->L + p->h != m || p->h > DQ_FUSED_MAX_HIGH || p->L < 1) {
+        set_error("dq_apply_fused: inconsistent geometry (m=%d L=%d h=%d)", p->m, p->L, p->h);
+        return DQ_ERR_ARG;
+    }
+    if (n < m) {
+        set_error("dq_apply_fused: n=%d smaller than tile m=%d", n, m);
+        return DQ_ERR_ARG;
+    }
+    if (p->nrounds == 0 || p->nrounds > DQ_FUSED_MAX_ROUNDS) {
+        set_error("dq_apply_fused: a pass has 1..%d rounds", DQ_FUSED_MAX_ROUNDS);
+        return DQ_ERR_ARG;
+    }
+    uint64_t seen = 0;
+    for (int i = 0; i < p->h; ++i) {
+        const int hp = p->high_pos[i];
+        if (hp < p->L || hp >= n || ((seen >> hp) & 1ull)) {
+            set_error("dq_apply_fused: bad high bit %d", hp);
+            return DQ_ERR_ARG;
+        }
+        seen |= 1ull << hp;
+        if (i > 0 && p->high_sorted[i] <= p->high_sorted[i - 1]) {
+            set_error("dq_apply_fused: high_sorted not ascending");
+            return DQ_ERR_ARG;
+        }
+    }
+    uint64_t seen2 = 0;
+    for (int i = 0; i < p->h; ++i) seen2 |= 1ull << p->high_sorted[i];
+    if (seen != seen2) {
+        set_error("dq_apply_fused: high_sorted is not a permutation of high_pos");
+        return DQ_ERR_ARG;
+    }
+    {   // load layout: tile bit 0 on slot 0 for complex64 (16 bytes per lane), otherwise gathered bits, ascending
+        constexpr int vb = sizeof(T) == 4 ? 1 : 0;
+        for (int s = 0; s < slots; ++s) {
+            const bool ok = (s < vb) ? (p->load_rb[s] == s) : (p->load_rb[s] >= p->L && p->load_rb[s] < m);
+            if (!ok || (s > 0 && p->load_rb[s] <= p->load_rb[s - 1])) {
+                set_error("dq_apply_fused: load layout invalid at slot %d", s);
+                return DQ_ERR_ARG;
+            }
+        }
+    }
+    if (p->L > DQ_FUSED_MAX_LOW) {
+        set_error("dq_apply_fused: L = %d contiguous low bits, at most %d", p->L, DQ_FUSED_MAX_LOW);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    {   // write positions: a permutation of [0, n)
+        const int nblk = n - m;
+        if (nblk > DQ_FUSED_MAX_BLK) {
+            set_error("dq_apply_fused: n - m = %d block bits, at most %d", nblk, DQ_FUSED_MAX_BLK);
+            return DQ_ERR_UNSUPPORTED;
+        }
+        uint64_t wseen = 0;
+        for (int i = 0; i < m + nblk; ++i) {
+            const int pos = i < p->L ? p->store_low_pos[i]
+                                     : (i < m ? p->store_high_pos[i - p->L] : p->store_blk_pos[i - m]);
+            if (pos >= n || ((wseen >> pos) & 1ull)) {
+                set_error("dq_apply_fused: write positions are not a permutation of [0, n) (entry %d = %d)", i, pos);
+                return DQ_ERR_ARG;
+            }
+            wseen |= 1ull << pos;
+        }
+    }
+    {   // store layout: explicit slots and thread bits covering the tile; complex64 stores two adjacent amplitudes per
+        // lane, so the tile bit of slot 0 must be written to global bit 0
+        unsigned used = 0;
+        for (int s = 0; s < slots; ++s) {
+            if (p->store_rb[s] >= m || ((used >> p->store_rb[s]) & 1u)) {
+                set_error("dq_apply_fused: store layout invalid at slot %d", s);
+                return DQ_ERR_ARG;
+            }
+            used |= 1u << p->store_rb[s];
+        }
+        for (int i = 0; i < logt; ++i) {
+            if (p->store_tb[i] >= m || ((used >> p->store_tb[i]) & 1u)) {
+                set_error("dq_apply_fused: store layout invalid at thread bit %d", i);
+                return DQ_ERR_ARG;
+            }
+            used |= 1u << p->store_tb[i];
+        }
+        if (sizeof(T) == 4) {
+            const int tb0 = p->store_rb[0];
+            const int pos = tb0 < p->L ? p->store_low_pos[tb0] : p->store_high_pos[tb0 - p->L];
+            if (pos != 0) {
+                set_error("dq_apply_fused: the tile bit of store slot 0 (%d) is written to bit %d, not bit 0", tb0, pos);
+                return DQ_ERR_ARG;
+            }
+        }
+    }
+    int next_gate = 0;
+    uint32_t next_mat = p->mat_base;
+    for (int r = 0; r < p->nrounds; ++r) {
+        const DqFusedRound& rd = p->rounds[r];
+        unsigned used = 0;
+        for (int s = 0; s < slots; ++s) {
+            if (rd.rb[s] >= m || ((used >> rd.rb[s]) & 1u)) {
+                set_error("dq_apply_fused: round %d slot list invalid", r);
+                return DQ_ERR_ARG;
+            }
+            used |= 1u << rd.rb[s];
+        }
+        for (int i = 0; i < logt; ++i) {
+            if (rd.tb[i] >= m || ((used >> rd.tb[i]) & 1u)) {
+                set_error("dq_apply_fused: round %d thread-bit list invalid", r);
+                return DQ_ERR_ARG;
+            }
+            used |= 1u << rd.tb[i];
+        }
+        {   // the kernel trusts the layout flags: recompute them from the layouts
+            const uint8_t* prb = r == 0 ? p->load_rb : p->rounds[r - 1].rb;
+            // thread bits of an I/O layout: the tile bits that are not slots, ascending
+            auto io_tb = [&](const uint8_t* iorb, uint8_t* tbo) {
+                unsigned slotmask = 0;
+                for (int s = 0; s < slots; ++s) slotmask |= 1u << iorb[s];
+                for (int i = 0, q = 0; i < logt; ++i, ++q) {
+                    while ((slotmask >> q) & 1u) ++q;
+                    tbo[i] = (uint8_t)q;
+                }
+            };
+            uint8_t ptb[DQ_FUSED_MAX_TBITS], stb[DQ_FUSED_MAX_TBITS];
+            if (r == 0) io_tb(p->load_rb, ptb);
+            else for (int i = 0; i < logt; ++i) ptb[i] = p->rounds[r - 1].tb[i];
+            bool differs = false;
+            for (int s = 0; s < slots; ++s) differs = differs || prb[s] != rd.rb[s];
+            for (int i = 0; i < logt; ++i) differs = differs || ptb[i] != rd.tb[i];
+            bool after = false;
+            if (r == p->nrounds - 1) {
+                for (int i = 0; i < logt; ++i) stb[i] = p->store_tb[i];
+                for (int s = 0; s < slots; ++s) after = after || p->store_rb[s] != rd.rb[s];
+                for (int i = 0; i < logt; ++i) {
+                    after = after || rd.tb[i] != stb[i];
+                }
+            }
+            const unsigned want = (differs ? DQ_ROUND_TRANSPOSE : 0u) | (after ? DQ_ROUND_TRANSPOSE_AFTER : 0u);
+            if (rd.flags != want) {
+                set_error("dq_apply_fused: round %d has layout flags %u, expected %u", r, rd.flags, want);
+                return DQ_ERR_ARG;
+            }
+        }
+        const int gate_begin = rd.gate_begin;
+        if (gate_begin > rd.gate_end || rd.gate_end > DQ_FUSED_MAX_GATES) {
+            set_error("dq_apply_fused: round %d gate range invalid", r);
+            return DQ_ERR_ARG;
+        }
+        if (gate_begin != next_gate) {
+            set_error("dq_apply_fused: round %d does not continue the gate list", r);
+            return DQ_ERR_ARG;
+        }
+        next_gate = rd.gate_end;
+        for (int gi = gate_begin; gi < rd.gate_end; ++gi) {
+            const DqFusedGate& g = p->gates[gi];
+            const bool slot_kind = g.kind == DQ_FG_GEN1 || g.kind == DQ_FG_X1 || g.kind == DQ_FG_GEN2;
+            if (g.kind == DQ_FG_RESERVED5 || g.fast != DQ_FAST_NONE) {
+                set_error("dq_apply_fused: record %d uses a handler id or the exchange record of the workgroup-tile kernels "
+                          "(removed with ABI 21)", gi);
+                return DQ_ERR_ARG;
+            }
+            if (g.kind == DQ_FG_GRAD) {
+                if (ngrads < 0 || g.q >= slots || g.q2 >= slots || g.q == g.q2 || (g.reg_cmask >> slots) || g.loc > 3 ||
+                    ((g.reg_cmask >> g.q) & 1u) || ((g.reg_cmask >> g.q2) & 1u) || g.mat != next_mat || g.mat_advance != 0 ||
+                    (int64_t)g.reserved >= ngrads) {
+                    set_error("dq_apply_fused: reduction record %d malformed, or not a dq_apply_fused_grad_* call", gi);
+                    return DQ_ERR_ARG;
+                }
+                continue;
+            }
+            if (g.kind == DQ_FG_EXPZ) {
+                if (ngrads < 0 || (g.reg_cmask >> slots) || g.mat != next_mat || g.mat_advance != 0 || (int64_t)g.reserved >= ngrads) {
+                    set_error("dq_apply_fused: expectation record %d malformed, or not a dq_apply_fused_grad_* call", gi);
+                    return DQ_ERR_ARG;
+                }
+                continue;
+            }
+            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 3) || (g.kind == DQ_FG_GEN2 && g.loc > 1)) ||
+                (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
+                set_error("dq_apply_fused: gate %d malformed", gi);
+                return DQ_ERR_ARG;
+            }
+            // the kernel walks the matrices with a running pointer: they must lie back to back in gate order
+            static const uint32_t kSize[5] = {4, 0, 4, 16, 16};
+            if (g.mat != next_mat || g.mat_advance != kSize[g.kind]) {
+                set_error("dq_apply_fused: gate %d breaks the sequential matrix layout (mat=%u, expected %u)", gi,
+                          g.mat, next_mat);
+                return DQ_ERR_ARG;
+            }
+            next_mat += g.mat_advance;
+        }
+    }
+    return DQ_OK;
+}
+
+template <typename T>
+static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
+                      const DqFusedPass* pass, dq_stream_t stream, bool broadcast_in = false, double* grads = nullptr,
+                      int64_t ngrads = -1) {
+    const int64_t in_bstride = broadcast_in ? 0 : (int64_t)1 << n;
+    if (broadcast_in && in == out) {
+        set_error("dq_apply_fused_bcast: the shared input state cannot be the output buffer");
+        return DQ_ERR_ARG;
+    }
+    if (!in || !out || !mats || !pass) {
+        set_error("dq_apply_fused: null pointer");
+        return DQ_ERR_ARG;
+    }
+    if (batch < 1 || batch > 65535) {
+        set_error("dq_apply_fused: batch %lld out of range [1, 65535]", (long long)batch);
+        return DQ_ERR_ARG;
+    }
+    constexpr bool is128 = sizeof(T) == 8;
+    const FusedVariant* vars = is128 ? kVariantsC128 : kVariantsC64;
+    int vi = -1;
+    for (int i = 0; i < (is128 ? kNumVariantsC128 : kNumVariantsC64); ++i)
+        if (vars[i].m == pass->m && vars[i].slots == pass->slots) vi = i;
+    if (vi < 0) {
+        set_error("dq_apply_fused: no kernel with m=%d and %d register slots (wave tile: m = %d, %d slots)", pass->m, pass->slots,
+                  vars[0].m, vars[0].slots);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    const FusedVariant v = vars[vi];
+    int rc = validate_pass<T>(pass, n, v.slots, v.logt, ngrads);
+    if (rc) return rc;
+    if (in == out) {   // in place: every amplitude must be written where it was read
+        bool same = true;
+        for (int i = 0; i < pass->L; ++i) same = same && pass->store_low_pos[i] == i;
+        for (int i = 0; i < pass->h; ++i) same = same && pass->store_high_pos[i] == pass->high_pos[i];
+        uint64_t tilemask = 0;
+        for (int i = 0; i < pass->h; ++i) tilemask |= 1ull << pass->high_pos[i];
+        for (int j = 0, q = pass->L; j < n - v.m; ++j, ++q) {
+            while ((tilemask >> q) & 1ull) ++q;
+            same = same && pass->store_blk_pos[j] == q;
+        }
+        if (!same) {
+            set_error("dq_apply_fused: a pass that writes to other index bits than it reads needs in != out");
+            return DQ_ERR_ARG;
+        }
+    }
+    if (n - v.m > 31) {
+        set_error("dq_apply_fused: grid too large (n=%d)", n);
+        return DQ_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = as_stream(stream);
+    // one wavefront per tile: csrc/dq_wave.hip
+    if (ngrads >= 0) {
+        if constexpr (is128) return wave_launch_grad_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+        else return wave_launch_grad_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+    }
+    if constexpr (is128) return wave_launch_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+    else return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+}
+
+}  // namespace dq
+
+extern "C" int dq_fused_geometry(int is_c128, int variant, int* m, int* slots, int* threads) {
+    if (variant < 0 || variant >= (is_c128 ? dq::kNumVariantsC128 : dq::kNumVariantsC64)) {
+        dq::set_error("dq_fused_geometry: variant %d out of range", variant);
+        return DQ_ERR_ARG;
+    }
+    const dq::FusedVariant v = is_c128 ? dq::kVariantsC128[variant] : dq::kVariantsC64[variant];
+    if (m) *m = v.m;
+    if (slots) *slots = v.slots;
+    if (threads) *threads = 1 << v.logt;
+    return DQ_OK;
+}
+
+extern "C" int dq_apply_fused_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                  int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
+    return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream);
+}
+extern "C" int dq_apply_fused_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                   int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
+    return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream);
+}
+
+extern "C" int dq_apply_fused_grad_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                       int64_t batch, const DqFusedPass* pass, double* grads, int64_t ngrads,
+                                       dq_stream_t stream) {
+    if (!grads || ngrads < 1) {
+        dq::set_error("dq_apply_fused_grad_c64: no accumulator (grads = %p, ngrads = %lld)", (void*)grads, (long long)ngrads);
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream, false, grads, ngrads);
+}
+
+extern "C" int dq_apply_fused_grad_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                        int64_t batch, const DqFusedPass* pass, double* grads, int64_t ngrads,
+                                        dq_stream_t stream) {
+    if (!grads || ngrads < 1) {
+        dq::set_error("dq_apply_fused_grad_c128: no accumulator (grads = %p, ngrads = %lld)", (void*)grads, (long long)ngrads);
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, false, grads, ngrads);
+}
+
+// Same pass, but `in` is ONE state (2^n amplitudes) shared by all `batch` outputs: the first pass of a batched
+// circuit reads the circuit's initial state directly instead of `batch` materialised copies of it.
+extern "C" int dq_apply_fused_bcast_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                        int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
+    return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream, true);
+}
+extern "C" int dq_apply_fused_bcast_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                         int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
+    return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, true);
+}

@@ -1,10 +1,10 @@
 // Wave-tile fused pass for gfx950 (complex64): ONE wavefront owns a tile of 2^12 amplitudes -- 64 lanes x 64
 // amplitudes in 128 VGPRs -- so a pass has no workgroup barrier at all: every wave loads its tile (32 x 16 bytes per
 // lane), walks the pass's records (gates on the six register-slot bits, layout changes through a small wave-private LDS
-// buffer), and stores.  Replaces the same run of Gate.forward calls as csrc/dq_fused.hip (circuit.py:261 ->
+// buffer), and stores.  Replaces a run of consecutive Gate.forward calls of the reference (circuit.py:261 ->
 // operation.py:274-289 -> qmath.py:485-506 / operation.py:203-219).
 //
-// Why: the workgroup-tile kernel (dq_fused.hip; 512 threads, 64 KiB of LDS, two workgroups per CU) spends a third of a
+// Why: the workgroup-tile kernel of rounds 1-2 (512 threads, 64 KiB of LDS, two workgroups per CU; removed) spent a third of a
 // pass waiting -- its eight waves meet at two barriers per layout change and only two such workgroups fit a CU, so VALU
 // (65 % busy) and HBM (78 %) never overlap fully.  With wave-private tiles there is nothing to wait for: measured on
 // the headline state, 96 Hadamard-sized gates + 4 layout changes per tile run at the speed of the bare load / store
@@ -34,7 +34,6 @@ namespace dq {
 #include "dq_wave_asm64.inc"
 
 constexpr int WAVE_LANES = 6;
-#define DQ_WAVE_EXP_DEFAULT 0
 constexpr int WAVE_MAX_REC = 112;
 
 // The two precisions: complex64 -- 64 amplitudes per lane, six slots, a 12-bit tile, slot 0 = index bit 0 inside the
@@ -62,7 +61,7 @@ struct WaveC128 {
     static constexpr unsigned LDS_PER_WAVE = 8704;      // (7 * 68 + 64) * 16 bytes: the k = 3 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID64_GEN_U, ID_GEN_C = DQ_WID64_GEN_C, ID_GEN_R = DQ_WID64_GEN_R, ID_X_U = DQ_WID64_X_U,
                          ID_X_C = DQ_WID64_X_C, ID_X_R = DQ_WID64_X_R, ID_X_R1 = DQ_WID64_X_R1, ID_TRIP0 = DQ_WID64_TRIP0,
-                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD, ID_EXPZ = DQ_WID64_EXPZ, ID_GEN2 = -1, ID_SWAP = DQ_WID64_SWAP;      // (no two-target dense gates: 64 dwords of matrix)
+                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD, ID_EXPZ = DQ_WID64_EXPZ, ID_GEN2 = DQ_WID64_GEN2, ID_SWAP = DQ_WID64_SWAP;      // (two-target dense gates: the 64 dwords of matrix pass through the scalar registers two rows at a time)
     static int trip_id(unsigned mask) { return kWave64TripId[mask]; }
     static int swap_id(int i, int j) { return kWave64SwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -448,8 +447,8 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
                 continue;
             }
             if (g.kind != DQ_FG_GEN1 && g.kind != DQ_FG_X1 && g.kind != DQ_FG_DIAG1 && g.kind != DQ_FG_DIAG2) {
-                set_error("dq_apply_fused: the wave-tile kernel takes one-target and diagonal gates (and, in complex64, dense gates on two targets; record %d has kind %d); "
-                          "plan this circuit for a workgroup-tile geometry", gi, (int)g.kind);
+                set_error("dq_apply_fused: the pass kernel takes dense gates on one or two targets, X and diagonal gates (record %d has kind %d); "
+                          "such a gate runs on its own (dq_apply_gate_*)", gi, (int)g.kind);
                 return DQ_ERR_UNSUPPORTED;
             }
             unsigned pc = 0;
@@ -596,12 +595,9 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
         else if (xcd_env > 1 && (xcd_env & (xcd_env - 1)) == 0 && grid.x % (8u * (unsigned)xcd_env) == 0)
             xcd = 32 - __builtin_clz((unsigned)xcd_env);       // log2(C) + 1
     }
-    // experiment switches of the generated code (flags bits 7 ..: DQ_WAVE_EXP bit 0 = raised priority while a wave issues
-    // its loads / stores, bit 1 = the deferred factor applied store by store)
-    static const int exp_env = [] { const char* e = getenv("DQ_WAVE_EXP"); return e ? atoi(e) & 0xff : DQ_WAVE_EXP_DEFAULT; }();
     using V = vec2<typename W::real>;
     hipLaunchKernelGGL((wave_pass_kernel<W, GRAD>), grid, dim3(256), lds, s, static_cast<const V*>(in), static_cast<V*>(out),
-                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, (31 - __builtin_clz((unsigned)tpw)) | (nt << 16) | (xcd << 18) | (exp_env << 23), kp, grads, ngrads * 8);
+                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, (31 - __builtin_clz((unsigned)tpw)) | (nt << 16) | (xcd << 18), kp, grads, ngrads * 8);
     return check_launch("dq_apply_fused (wave tile)");
 }
 

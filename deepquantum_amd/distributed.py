@@ -56,7 +56,12 @@ from .state import DistributedQubitState
 CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_groups': 4, 'fold_permute': True,
           # 'remap' mode: gates are first re-ordered along the commutation DAG so that everything that is local under the
           # current placement runs before the next exchange (_order_for_remaps)
-          'reorder': True}
+          'reorder': True,
+          # an UN-BATCHED shard treats its top ``virtual_bits`` local index bits as rank bits of a virtual world: the shard
+          # becomes 2^v rows that move through a remap like the samples of a batch -- row r's amplitudes are on the links
+          # while row r + 1 runs its passes -- at the price of extra stretches: a gate that targets a virtual bit needs a
+          # (local, free) re-labelling of the shard first (`_remap_virtual`).  0 = off.  Forward circuits in 'remap' mode
+          'virtual_bits': 0}
 
 #: the accumulator of the DQ_FG_GRAD reductions while a fused reverse sweep runs on a sharded (psi, lambda) pair
 #: (adjoint._sweep_fused_sharded): every local stretch hands its rows to the passes
@@ -64,7 +69,7 @@ _SWEEP: dict = {'grads': None}
 
 #: statistics of the last ``dist_apply_prims`` call (bench / tests)
 LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_permutes': 0, 'permute_passes': 0,
-            'wire_bytes': 0, 'groups': 1}
+            'wire_bytes': 0, 'groups': 1, 'virtual_bits': 0, 'virtual_remaps': 0}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -86,13 +91,18 @@ class _raw:
         return False
 
 
+def _vbits(state: DistributedQubitState) -> int:
+    """Virtual rank bits the state currently runs with (CONFIG['virtual_bits']; only inside `_dist_apply_prims`)."""
+    return state.__dict__.get('_vbits', 0)
+
+
 def _view(state: DistributedQubitState) -> torch.Tensor:
-    """(batch, 2^L) view of the shard(s)."""
-    return state.amps.view(-1, state.num_amps_per_node)
+    """(batch, 2^L) view of the shard(s) -- with virtual rank bits: (2^v rows, 2^(L - v)) of the one shard."""
+    return state.amps.view(-1, state.num_amps_per_node >> _vbits(state))
 
 
 def _bview(state: DistributedQubitState) -> torch.Tensor:
-    return state.buffer.view(-1, state.num_amps_per_node)
+    return state.buffer.view(-1, state.num_amps_per_node >> _vbits(state))
 
 
 def _rank_controls_ok(state: DistributedQubitState, controls: Sequence[int]) -> bool:
@@ -104,12 +114,42 @@ def _localize(state: DistributedQubitState, p: Prim) -> Prim | None | str:
     """Translate a primitive on global bit positions into what THIS rank has to do locally.
 
     Returns a local ``Prim``, ``None`` (nothing to do on this rank) or ``'exchange'`` (a non-diagonal
-    target is a global qubit: data has to move)."""
+    target is a global qubit: data has to move).  With virtual rank bits every row of the shard is a rank of the
+    virtual world: a primitive whose predicates or phases depend on a virtual bit comes back with one matrix per row
+    (the identity on the rows it does not act on)."""
+    vb = _vbits(state)
+    if vb == 0:
+        return _localize_at(state.log_num_amps_per_node, state.rank, p)
     L = state.log_num_amps_per_node
+    lr = L - vb
+    if p.kind != 'diag' and any(t >= lr for t in p.targets):
+        return 'exchange'
+    on_virtual = any(lr <= c < L for c in p.controls) or (p.kind == 'diag' and any(lr <= t < L for t in p.targets))
+    if not on_virtual:          # (every row sees the same thing: no per-row matrices, no comparison of device tensors)
+        return _localize_at(lr, state.rank << vb, p)
+    per_row = [_localize_at(lr, (state.rank << vb) | r, p) for r in range(1 << vb)]
+    live = [q for q in per_row if q is not None]
+    if not live:
+        return None
+    first = live[0]
+    d = 1 << len(first.targets)
+    dtype, device = state.amps.dtype, state.amps.device
+    if first.kind == 'x':       # an X on some rows only: a dense (real) matrix per row
+        flip = torch.tensor([[0, 1], [1, 0]], dtype=dtype, device=device)
+        eye = torch.eye(2, dtype=dtype, device=device)
+        mats = torch.stack([eye if q is None else flip for q in per_row])
+        return Prim('gen', mats, first.targets, first.controls, 1)
+    eye = torch.eye(d, dtype=dtype, device=device)
+    mats = torch.stack([eye if q is None else q.matrix.reshape(d, d).to(dtype) for q in per_row])
+    return Prim(first.kind, mats, first.targets, first.controls, 0)
+
+
+def _localize_at(L: int, rank: int, p: Prim) -> Prim | None | str:
+    """`_localize` for the rank ``rank`` of a world whose ranks hold 2^L amplitudes."""
     lc = tuple(c for c in p.controls if c < L)
     if p.kind != 'diag' and any(t >= L for t in p.targets):
         return 'exchange'
-    if not _rank_controls_ok(state, p.controls):
+    if not all(get_bit(rank, c - L) for c in p.controls if c >= L):
         return None
     if p.kind != 'diag' or all(t < L for t in p.targets):
         return Prim(p.kind, p.matrix, p.targets, lc, p.mode)
@@ -122,7 +162,7 @@ def _localize(state: DistributedQubitState, p: Prim) -> Prim | None | str:
         full, li = 0, 0
         for i, t in enumerate(p.targets):
             if t >= L:
-                bit = get_bit(state.rank, t - L)
+                bit = get_bit(rank, t - L)
             else:
                 bit = (idx >> (len(local_t) - 1 - li)) & 1
                 li += 1
@@ -472,12 +512,13 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     chunk c of the shard goes to the peer whose rank bits spell c -- issued asynchronously, so that the next group's
     passes run while this group's amplitudes are on the links.  Nothing waits here: ``_settle`` (or the next remap of
     the same group) does."""
-    L, W = state.log_num_amps_per_node, state.world_size
+    vb = _vbits(state)
+    L, W = state.log_num_amps_per_node - vb, state.world_size       # (with virtual rank bits: L = bits of a ROW)
     ph = _phys(state)
     pairs = sorted(pairs, key=lambda pr: ph[pr[0]])          # ascending rank bit -> ascending peer rank
     k = len(pairs)
-    rbits = [ph[lq] - L for lq, _ in pairs]
-    assert all(0 <= r < state.log_num_nodes for r in rbits) and all(ph[eq] < L for _, eq in pairs)
+    rbits = [ph[lq] - L for lq, _ in pairs]                 # bits of the (virtual) world's rank: the low vb are rows
+    assert all(0 <= r < state.log_num_nodes + vb for r in rbits) and all(ph[eq] < L for _, eq in pairs)
     # 1. the entering qubits go to the top k local bits (chunk index = their joint value): destination bit d takes
     #    source bit src_of_dst[d]
     ent_bits = [ph[eq] for _, eq in pairs]
@@ -489,11 +530,18 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     # 2. chunk c goes to the peer whose rank bits `rbits` spell c; what comes back from that peer lands in
     #    the same chunk slot.  Peers outside the 2^k group get empty messages.
     chunk = (1 << (L - k))
+    if vb:
+        # (the planner re-fills ONE class of far positions per remap, `_plan_remap`)
+        assert all(r < vb for r in rbits) or all(r >= vb for r in rbits), 'a remap trades real OR virtual rank bits'
+        if rbits[0] < vb:               # virtual bits trade places: a re-labelling of the shard, no exchange
+            _remap_virtual(state, pairs, pending)
+            return
+        pending[:] = [q for q in (_localize(state, p) for p in pending) if q is not None]      # row by row
     peers = []
     for c in range(1 << k):
         peer = state.rank
         for i, r in enumerate(rbits):
-            peer = (peer & ~(1 << r)) | (((c >> i) & 1) << r)
+            peer = (peer & ~(1 << (r - vb))) | (((c >> i) & 1) << (r - vb))
         peers.append(peer)
     a, b = _view(state), _bview(state)
     groups = _row_groups(state)
@@ -552,8 +600,13 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     if not identity:
         LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
     LAST_RUN['groups'] = len(groups)
-    # 3. bookkeeping: local qubits moved with the permutation; entering qubit i now is rank bit rbits[i]; leaving
-    #    qubit i is local bit L - k + i
+    _remap_bookkeeping(ph, pairs, rbits, out_perm, L)
+
+
+def _remap_bookkeeping(ph: list[int], pairs, rbits, out_perm, L: int) -> None:
+    """Local qubits moved with the permutation; entering qubit i now is rank bit rbits[i]; leaving qubit i is local bit
+    L - k + i."""
+    k = len(pairs)
     for q, p_ in enumerate(ph):
         if p_ < L:
             ph[q] = out_perm[p_]
@@ -561,6 +614,36 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
         ph[eq] = L + rbits[i]
         ph[lq] = L - k + i
     LAST_RUN['remaps'] += 1
+
+
+def _remap_virtual(state: DistributedQubitState, pairs, pending: list[Prim]) -> None:
+    """A remap that trades VIRTUAL rank bits only (CONFIG['virtual_bits']): nothing leaves the GPU -- the qubits on the
+    virtual bits and the entering row-local qubits swap index positions of the ONE shard, and that re-labelling rides on
+    the last pass of the stretch in front of it, which therefore runs on the whole shard (gates controlled by a virtual
+    bit are ordinary local controls there) instead of row by row."""
+    vb = state.__dict__.pop('_vbits')
+    try:
+        _settle(state)
+        L = state.log_num_amps_per_node
+        ph = _phys(state)
+        out_perm = list(range(L))
+        for lq, eq in pairs:
+            assert L - vb <= ph[lq] < L and ph[eq] < L - vb
+            out_perm[ph[lq]], out_perm[ph[eq]] = ph[eq], ph[lq]
+        local = [q for q in (_localize(state, p) for p in pending) if q is not None]
+        if pending:
+            LAST_RUN['local_flushes'] += 1
+        a, b = _view(state), _bview(state)
+        if _run_rows(a, b, local, slice(0, a.shape[0]), out_perm):
+            state.amps, state.buffer = state.buffer, state.amps
+        pending.clear()
+        LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
+        for lq, eq in pairs:
+            ph[lq], ph[eq] = ph[eq], ph[lq]
+        LAST_RUN['remaps'] += 1
+        LAST_RUN['virtual_remaps'] += 1
+    finally:
+        state.__dict__['_vbits'] = vb
 
 
 def _next_use(prims: Sequence[Prim], start: int, n: int) -> list[int]:
@@ -582,19 +665,31 @@ def _next_use(prims: Sequence[Prim], start: int, n: int) -> list[int]:
     return nxt
 
 
-def _plan_remap(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int) -> list[tuple[int, int]]:
+def _plan_remap(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int, v: int = 0) -> list[tuple[int, int]]:
     """Which qubits trade places so that gate ``i`` becomes local: evict to the rank bits the qubits whose
     next non-diagonal use is farthest away (Belady).  Pure function of the gate list: every rank computes
-    the same plan."""
-    g = n - L
+    the same plan.
+
+    ``v`` virtual rank bits (positions L .. L + v - 1; L = bits of a row): the two classes of far positions are
+    re-filled SEPARATELY -- a remap either trades real rank bits only (its wire time hides behind the other rows'
+    passes) or virtual bits only (chunks move between rows of the shard: no wire at all) -- virtual bits first when
+    gate ``i`` waits for one of them; the loop comes back for the other class if the gate still is not local."""
     nxt = _next_use(prims, i, n)
-    is_glob = [ph[q] >= L for q in range(n)]
+    needed = {t for t in prims[i].targets} if prims[i].kind != 'diag' else set()
+    if v:
+        on_virtual = any(L <= ph[t] < L + v for t in needed)
+        mine = (lambda p_: L <= p_ < L + v) if on_virtual else (lambda p_: p_ >= L + v)
+    else:
+        mine = lambda p_: p_ >= L                 # noqa: E731
+    g = sum(1 for q in range(n) if mine(ph[q]))   # far positions of the class that is re-filled
+    is_glob = [mine(ph[q]) for q in range(n)]
+    frozen = [ph[q] >= L and not mine(ph[q]) for q in range(n)]       # the other class: stays where it is
     # farthest next use first; ties: keep what already is global (less traffic), then qubits above the contiguous run
     # of a tile (moving a lower bit cannot ride on a fused pass's permuted store), then canonical order
-    order = sorted(range(n), key=lambda q: (-nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
+    order = sorted((q for q in range(n) if not frozen[q]),
+                   key=lambda q: (-nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
     new_global = set(order[:g])
-    needed = {t for t in prims[i].targets} if prims[i].kind != 'diag' else set()
-    assert not (needed & new_global), 'gate needs more local qubits than a shard has'
+    assert not ({t for t in needed if not frozen[t]} & new_global), 'gate needs more local qubits than a shard has'
     leaving = [q for q in range(n) if is_glob[q] and q not in new_global]
     entering = [q for q in new_global if not is_glob[q]]
     assert len(leaving) == len(entering) and leaving, 'remap requested although the gate is local'
@@ -608,7 +703,7 @@ def _plan_remap(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int) ->
     return pairs
 
 
-def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int) -> list[Prim]:
+def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int, v: int = 0) -> list[Prim]:
     """The gate list in an order that needs far fewer exchanges: list scheduling over the commutation DAG of the
     circuit (`fusion._Dag`: two gates commute when on every shared qubit both act diagonally, or both as functions of
     X) -- every gate that is ready and local under the current placement runs; only when ALL ready gates wait for a
@@ -651,9 +746,17 @@ def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int)
                     left -= 1
             if left == 0:
                 break
-        is_glob = [ph[q] >= L for q in range(n)]
-        cand = sorted(range(n), key=lambda q: (-nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
-        new_global = set(cand[:g])
+        if v:      # (virtual rank bits: one class of far positions is re-filled at a time, as in `_plan_remap`)
+            waits = {t for i in dag.ready if prims[i].kind != 'diag' for t in prims[i].targets}
+            on_virtual = any(L <= ph[t] < L + v for t in waits)
+            mine = (lambda p_: L <= p_ < L + v) if on_virtual else (lambda p_: p_ >= L + v)
+        else:
+            mine = lambda p_: p_ >= L             # noqa: E731
+        is_glob = [mine(ph[q]) for q in range(n)]
+        frozen = [ph[q] >= L and not mine(ph[q]) for q in range(n)]
+        cand = sorted((q for q in range(n) if not frozen[q]),
+                      key=lambda q: (-nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
+        new_global = set(cand[:sum(is_glob)])
         leaving = [q for q in range(n) if is_glob[q] and q not in new_global]
         entering = [q for q in new_global if not is_glob[q]]
         if not leaving:          # (cannot happen: some ready gate has a global target, and its next use is now)
@@ -668,13 +771,21 @@ def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int)
 
 
 def _remap_for(state: DistributedQubitState, prims: Sequence[Prim], i: int, pending: list[Prim]) -> None:
-    pairs = _plan_remap(_phys(state), prims, i, state.nqubit, state.log_num_amps_per_node)
+    pairs = _plan_remap(_phys(state), prims, i, state.nqubit, state.log_num_amps_per_node - _vbits(state), _vbits(state))
     _remap(state, pairs, pending)
 
 
-def count_exchange_steps(prims: Sequence[Prim], n: int, g: int) -> dict:
+def count_exchange_steps(prims: Sequence[Prim], n: int, g: int, virtual_bits: int = 0, reorder: bool = False) -> dict:
     """Dry run of both modes on a gate list (no data): number of exchange steps and the volume each rank
-    sends, in units of one shard.  Used by tests and to size the design."""
+    sends, in units of one shard.  Used by tests and to size the design.
+
+    ``virtual_bits`` = v (CONFIG['virtual_bits']): the remap mode with the top v local bits of every shard as rank bits
+    of a virtual world.  ``remap_steps`` then counts both kinds of step: ``virtual_steps`` of them trade virtual bits
+    only (a re-labelling of the shard that rides on a pass: nothing on the wire), the others trade real rank bits, and
+    their wire volume splits into ``hidden_wire_volume`` -- it travels while the other rows of the shard compute: all
+    but the first row's share, 1 - 2^-v of it -- and ``exposed_wire_volume``.  v = 0: everything is exposed (an
+    un-batched shard has nothing to overlap with).
+    ``reorder``: the gate list in commutation-DAG order first, as `dist_run` runs it."""
     L = n - g
     pw_steps, pw_vol = 0, 0.0
     for p in prims:
@@ -687,28 +798,42 @@ def count_exchange_steps(prims: Sequence[Prim], n: int, g: int) -> dict:
             else:
                 pw_steps += 2 * nglob
                 pw_vol += 2 * nglob * 0.5
+    v = int(virtual_bits)
+    lr = L - v                                   # bits of a row
     ph = list(range(n))
+    if reorder:
+        prims = _order_for_remaps(prims, ph, n, lr, v)
     rm_steps, rm_vol, i = 0, 0.0, 0
+    v_steps, hidden, exposed = 0, 0.0, 0.0
     while i < len(prims):
         p = prims[i]
-        if p.kind != 'diag' and any(ph[t] >= L for t in p.targets):
-            pairs = _plan_remap(ph, prims, i, n, L)
+        if p.kind != 'diag' and any(ph[t] >= lr for t in p.targets):
+            pairs = _plan_remap(ph, prims, i, n, lr, v)
             pairs = sorted(pairs, key=lambda pr: ph[pr[0]])
             k = len(pairs)
             rb = [ph[lq] for lq, _ in pairs]
             ent = [ph[eq] for _, eq in pairs]
-            rest = [b for b in range(L) if b not in ent]
+            rest = [b for b in range(lr) if b not in ent]
             new_local = {sp: d for d, sp in enumerate(rest + ent)}
             for q in range(n):
-                if ph[q] < L:
+                if ph[q] < lr:
                     ph[q] = new_local[ph[q]]
             for j, (lq, eq) in enumerate(pairs):
-                ph[eq], ph[lq] = rb[j], L - k + j
+                ph[eq], ph[lq] = rb[j], lr - k + j
+            k_real = sum(1 for r in rb if r >= L)          # real rank bits among the leaving positions
+            assert k_real in (0, k), 'a remap trades real OR virtual rank bits'
             rm_steps += 1
-            rm_vol += 1 - 0.5**k
+            if k_real == 0:                                  # a local re-labelling (rides on a pass): nothing on the wire
+                v_steps += 1
+                continue
+            wire = 1 - 0.5**k_real                           # of every row, i.e. of the shard
+            rm_vol += wire
+            hidden += wire * (1 - 0.5**v)
+            exposed += wire * 0.5**v
             continue
         i += 1
-    return {'pairwise_steps': pw_steps, 'pairwise_volume': pw_vol, 'remap_steps': rm_steps, 'remap_volume': rm_vol}
+    return {'pairwise_steps': pw_steps, 'pairwise_volume': pw_vol, 'remap_steps': rm_steps, 'remap_volume': rm_vol,
+            'virtual_bits': v, 'virtual_steps': v_steps, 'hidden_wire_volume': hidden, 'exposed_wire_volume': exposed}
 
 
 def canonicalize(state: DistributedQubitState) -> DistributedQubitState:
@@ -768,12 +893,41 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
         mode = 'pairwise'
     if mode == 'pairwise' and not _is_canonical(state):
         canonicalize(state)
+    # virtual rank bits: an un-batched shard of a forward circuit, rows of at least one tile
+    vb = int(CONFIG['virtual_bits'] or 0)
+    if vb and not (mode == 'remap' and state.batch is None and _SWEEP['grads'] is None and state.amps.ndim == 1
+                   and state.log_num_amps_per_node - vb >= executor._geometry(state.amps.dtype == torch.complex128).m):
+        vb = 0
+    LAST_RUN['virtual_bits'] = vb
+    if vb:
+        _settle(state)
+        state.__dict__['_vbits'] = vb
+    try:
+        return _dist_apply_loop(state, prims, mode, keep_layout, expect_z)
+    finally:
+        if vb:
+            _settle(state)
+            state.__dict__.pop('_vbits', None)
+
+
+def _dist_apply_loop(state: DistributedQubitState, prims: Sequence[Prim], mode: str, keep_layout: bool,
+                     expect_z: Sequence[int] | None) -> DistributedQubitState:
+    vb = _vbits(state)
     if mode == 'remap' and CONFIG['reorder']:
-        prims = _order_for_remaps(prims, _phys(state), state.nqubit, state.log_num_amps_per_node)
+        prims = _order_for_remaps(prims, _phys(state), state.nqubit, state.log_num_amps_per_node - vb, vb)
     pending: list[Prim] = []
     i, nprims = 0, len(prims)
     while i < nprims:
         p = prims[i] if mode == 'pairwise' else _translate(prims[i], _phys(state))
+        if vb:
+            # virtual rank bits: what a gate is on THIS rank depends on how its stretch ends -- row by row in front of
+            # an exchange of real rank bits, on the whole shard otherwise -- so it is localized when the stretch runs
+            if p.kind != 'diag' and any(t >= state.log_num_amps_per_node - vb for t in p.targets):
+                _remap_for(state, prims, i, pending)
+            else:
+                pending.append(p)
+                i += 1
+            continue
         local = _localize(state, p)
         if local is None:
             i += 1
@@ -788,6 +942,10 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
             i += 1
         else:
             _remap_for(state, prims, i, pending)     # local gates so far + exchange; then gate i under the new layout
+    if vb:                        # back to ONE shard of 2^L amplitudes (the rows are its top local index bits): the last
+        _settle(state)            # stretch runs on the whole shard
+        state.__dict__.pop('_vbits', None)
+        pending[:] = [q for q in (_localize(state, p) for p in pending) if q is not None]
     if expect_z:
         # the Z-type observables of the circuit: reduced from the registers of the last local pass (DQ_FG_EXPZ)
         holder, signs = _expect_z_local(state, expect_z)

@@ -54,12 +54,11 @@ class Plan:
 _PLAN_CACHE: OrderedDict = OrderedDict()
 _PLAN_CACHE_SIZE = 64
 
-# Tunables (debug / benchmarking): tile bits per precision; None = library default.
-CONFIG = {'fuse': True, 'wave': None,     # None = wave-tile kernel where it takes the circuit, False = workgroup tiles
-          'm_c64': None, 'm_c128': None, 'min_low_c64': None, 'min_low_c128': None,
+# Tunables (debug / benchmarking); None = library default.
+CONFIG = {'fuse': True, 'min_low_c64': None, 'min_low_c128': None,
           'max_gates': None, 'max_far': None, 'far_bit': None,
           # pass planner (fusion._plan_tiles): beam width / tiles tried per state; 0 = first-come tiles, 1 = greedy
-          'plan_width': None, 'plan_branch': None, 'plan_restarts': None, 'asm_loop': None, 'lane_swaps': None, 'swap_lanes': None, 'swap_policy': None,
+          'plan_width': None, 'plan_branch': None, 'plan_restarts': None,
           # permuted stores also re-label the contiguous low bits, so every pass picks all its tile qubits (None = on)
           'free_low': None,
           # out-of-place passes that write the next pass's qubits to cheap index bits (fusion._place_writes): needs a
@@ -106,52 +105,20 @@ GRAPH_BACKWARDS = {'count': 0}
 PLAN_STATS = {'seconds': 0.0, 'plans': 0}
 
 # Statistics of the most recent fused run (for bench.py and tests).
-LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'swaps': 0, 'permute_folded': False}
+LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'permute_folded': False}
 
 
-def _geometry(is128: bool, wave: bool = True) -> fusion.Geometry:
-    """``wave`` = False: a workgroup-tile geometry (what circuits with gates the wave-tile kernel does not take run on)."""
-    m = CONFIG['m_c128'] if is128 else CONFIG['m_c64']
-    if m is not None or not wave or CONFIG['wave'] is False:
-        g = fusion.workgroup_geometry(is128, m)
-    else:
-        g = fusion.default_geometry(is128)
+def _geometry(is128: bool) -> fusion.Geometry:
+    """The wave tile of the precision with the overrides of ``CONFIG``."""
+    g = fusion.default_geometry(is128)
     ml = CONFIG['min_low_c128'] if is128 else CONFIG['min_low_c64']
     if ml is not None:
         g.min_low = ml
-        g.fallback = None
-    if CONFIG['max_gates'] is not None:
-        g.max_gates = CONFIG['max_gates']
-    if CONFIG['max_far'] is not None:
-        g.max_far = CONFIG['max_far']
-    if CONFIG['far_bit'] is not None:
-        g.far_bit = CONFIG['far_bit']
-    if CONFIG['plan_width'] is not None:
-        g.plan_width = CONFIG['plan_width']
-    if CONFIG['plan_branch'] is not None:
-        g.plan_branch = CONFIG['plan_branch']
-    if CONFIG['plan_restarts'] is not None:
-        g.plan_restarts = CONFIG['plan_restarts']
-    if CONFIG['lane_swaps'] is not None:
-        g.lane_swaps = bool(CONFIG['lane_swaps']) and not is128
-        if g.fallback is not None:
-            g.fallback.lane_swaps = g.lane_swaps
-    if CONFIG['swap_policy'] is not None:
-        g.swap_policy = CONFIG['swap_policy']
-        if g.fallback is not None:
-            g.fallback.swap_policy = g.swap_policy
-    if CONFIG['swap_lanes'] is not None:
-        g.swap_lanes = tuple(CONFIG['swap_lanes'])
-        if g.fallback is not None:
-            g.fallback.swap_lanes = g.swap_lanes
+    for key in ('max_gates', 'max_far', 'far_bit', 'plan_width', 'plan_branch', 'plan_restarts'):
+        if CONFIG[key] is not None:
+            setattr(g, key, CONFIG[key])
     if CONFIG['free_low'] is not None:
         g.free_low = CONFIG['free_low'] if CONFIG['free_low'] == 'force' else bool(CONFIG['free_low'])
-        if g.fallback is not None:
-            g.fallback.free_low = g.free_low
-    if CONFIG['asm_loop'] is not None:
-        g.asm_loop = CONFIG['asm_loop']
-        if g.fallback is not None:
-            g.fallback.asm_loop = CONFIG['asm_loop']
     return g
 
 
@@ -192,28 +159,16 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     takes long enough (>= 0.1 s) for a wider search of the pass planner to pay for itself within a few steps
     (measured on the headline: 21 -> 20 passes, -2.7 %, 4.6 s of planning once per circuit structure)."""
     geom = _geometry(is128)
-    if geom.wave:
-        ok = steady.get(('wave_ok', is128)) if steady is not None else None
-        if ok is None:
-            ok = fusion.wave_supports(prims, is128)
-            if steady is not None:
-                steady[('wave_ok', is128)] = ok
-        if not ok:
-            geom = _geometry(is128, wave=False)
     if amps >= CONFIG['plan_big_amps']:
-        for g_ in (geom, geom.fallback):
-            if g_ is not None:
-                if CONFIG['plan_width'] is None:
-                    g_.plan_width = 8
-                if CONFIG['plan_branch'] is None:
-                    g_.plan_branch = 4
-                if CONFIG['plan_restarts'] is None:
-                    g_.plan_restarts = 6
+        if CONFIG['plan_width'] is None:
+            geom.plan_width = 8
+        if CONFIG['plan_branch'] is None:
+            geom.plan_branch = 4
+        if CONFIG['plan_restarts'] is None:
+            geom.plan_restarts = 6
     geom.permute_store = permute
-    if geom.fallback is not None:
-        geom.fallback.permute_store = permute
     head = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
-            geom.plan_branch, geom.plan_restarts, geom.asm_loop, geom.free_low, geom.lane_swaps, geom.swap_lanes, geom.swap_policy, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm))
+            geom.plan_branch, geom.plan_restarts, geom.free_low, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm))
     if steady is not None:
         plan = steady['plans'].get(head)
         if plan is not None and _PLAN_CACHE.get(plan[0]) is plan[1]:     # (still the plan the global cache would give)
@@ -335,7 +290,7 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
                                            is128)
             if e is not None:
                 e[('wave_ok', is128)] = wave_ok
-        if (g_.wave and n >= g_.m and len(prims) > 0 and wave_ok and not ops._is_batched(state)
+        if (n >= g_.m and len(prims) > 0 and wave_ok and not ops._is_batched(state)
                 and state.shape[0] <= backend.MAX_BATCH):
             every = tuple(range(n))
             mkey = (n, tuple(int(z) for z in expect_z['masks']))
@@ -354,8 +309,8 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
     return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps)
 
 
-# Issue slots of a wave per one-qubit gate, by matrix structure, on the workgroup-tile kernels.  They also decide
-# for the wave-tile kernel: with ITS costs (64 / 192 / 128 / 256 packed operations + ~12 slots of dispatch) Hadamard x Rx
+# Issue slots of a wave per one-qubit gate, by matrix structure, measured on the workgroup-tile kernels of round 2 (DESIGN
+# 5-r2).  Kept for the wave-tile kernel: with ITS costs (64 / 192 / 128 / 256 packed operations + ~12 slots of dispatch) Hadamard x Rx
 # would merge into a general matrix -- 20 % fewer gates, the same arithmetic -- and the step gets 5 % SLOWER (measured,
 # one box: 282 vs 268 ms): a general matrix commutes with nothing, so the scheduler loses the freedom the Rx-like factor had.
 _MERGE_COST = {3: 30, 2: 37, 1: 45, 0: 79}
@@ -495,14 +450,12 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
     with torch.no_grad():
         is128 = state.dtype == torch.complex128
         g_ = _geometry(is128)
-        m = g_.fallback.m if g_.fallback is not None else g_.m     # smallest tile a fused pass can run on
+        m = g_.m                 # the tile a fused pass runs on
         if len(prims) == 0:
             LAST_RUN['permute_folded'] = False
             return _permute_after(state, out_perm, scratch)
         if grads is not None:
             assert n >= m and CONFIG['fuse'], 'the fused reverse sweep needs a state of at least one tile'
-            assert not is128 or (g_.wave and fusion.wave_supports(prims, is128)), \
-                'complex128 reverse sweeps run on the wave-tile kernel only (one-target and diagonal gates)'
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):
             out = _run_small(state, prims, n, m)
@@ -547,7 +500,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 fusion.defer_rx(flat, idx)
             if steady is not None:
                 steady['flat'] = {fkey: (plan, flat, stride)}       # (one buffer per entry: the latest shape)
-        stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0, 'swaps': 0}
+        stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0}
         spare = scratch                      # the caller's second buffer (if any)
         other = spare if permute else None
         scratch = None
@@ -576,7 +529,6 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 stats['passes'] += 1
                 stats['rounds'] += st.nrounds
                 stats['transposes'] += st.ntranspose
-                stats['swaps'] = stats.get('swaps', 0) + st.nswaps
             else:
                 op = plan.prim_ops[st.op]
                 assert op.kind not in ('grad', 'expz'), 'a reduction can only run inside a fused pass'
@@ -694,11 +646,10 @@ class _AdjointCircuit(torch.autograd.Function):
 
         n = out.shape[-1].bit_length() - 1
         g_ = _geometry(is128)
-        # complex128: the wave-tile kernel only (one-target dense / X gates, diagonal gates on one or two targets)
-        wave_ok = g_.wave and all((kind in ('gen', 'x') and len(targets) == 1) or (kind == 'diag' and len(targets) <= 2)
-                                  for kind, targets, _c, _m, _e in meta)
-        fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and (not is128 or wave_ok) and b <= backend.MAX_BATCH
-                 and n + 1 >= (g_.fallback.m if g_.fallback is not None else g_.m)
+        # the sweep as fused passes: every gate one the pass kernel takes (at most two targets), the (psi, lambda) pair at
+        # least a tile, every trainable gate on one target
+        fusable = all(len(targets) <= 2 for _k, targets, _c, _m, _e in meta)
+        fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and fusable and b <= backend.MAX_BATCH and n + 1 >= g_.m
                  and all(len(meta[j][1]) == 1 for j in range(len(mats)) if need[j]))
         if fused:
             # complex128: a matrix that is not computed from parameters or data may be unitary only to float32 rounding

@@ -3,14 +3,14 @@
 The reference executes one gate per ``Gate.forward`` call (circuit.py:261, operation.py:274-289), i.e.
 at least two full read+write sweeps of the statevector per gate.  Here gates are grouped so that one
 HBM read + one HBM write applies a whole group ("pass").  The kernel side is described in
-``csrc/dq_fused.hip``; this module only decides *which* gates go together and emits the descriptor
+``csrc/dq_wave.hip``; this module only decides *which* gates go together and emits the descriptor
 structs of ``include/dq_hip.h``.
 
 Vocabulary
   bit      amplitude-index bit position, LSB = 0; wire w of an n-qubit circuit is bit n-1-w.
-  tile     the m index bits a workgroup owns in a pass: the low L bits plus h gathered high bits.
+  tile     the m index bits a wavefront owns in a pass: the low L bits plus h gathered high bits.
   round    a stretch of a pass during which R chosen tile bits are "register slots"; a non-diagonal
-           gate needs its target bit(s) to be slots.  Changing rounds costs one LDS round trip.
+           gate needs its target bit(s) to be slots.  Changing rounds costs a trip through the wave's LDS buffer.
   action   how a gate acts on a qubit: 'D' if it is diagonal in that qubit (controls, targets of
            diagonal gates), 'N' otherwise.  Two gates commute when every shared qubit is 'D' in both,
            which is what lets the scheduler pull later gates forward.
@@ -62,9 +62,7 @@ class FusedStep:
     nrounds: int
     ntranspose: int           # LDS round trips the kernel will do (incl. back to canonical)
     permutes: bool = False    # writes to other index bits than it reads (needs in != out)
-    nswaps: int = 0           # layout changes done by in-wave exchanges instead (DQ_ROUND_SWAP)
     c64: bool = False         # a complex64 pass: uncontrolled Rx-like gates take the deferred form (defer_rx)
-    records: list | None = None   # gate record -> index into the PrimOp list, None for an exchange record
 
 
 @dataclass
@@ -74,81 +72,45 @@ class SingleStep:
 
 @dataclass
 class Geometry:
+    """The tile of a pass: ONE wavefront owns 2^m amplitudes (csrc/dq_wave.hip) -- 2^slots of them per lane in registers,
+    the other six tile bits on the lanes; the library derives slot order, lane order and handlers itself."""
+
     m: int            # tile bits
-    slots: int        # register slots per thread (R)
-    vb: int           # canonical layout keeps tile bits [0, vb) as slots (1 for c64, 0 for c128)
+    slots: int        # register slots per lane (R)
+    vb: int           # the I/O layouts keep tile bits [0, vb) as slots (1 for c64: 16 bytes per lane; 0 for c128)
     min_low: int      # minimum contiguous low bits of a tile (coalescing floor)
     max_gates: int = _lib.FUSED_MAX_GATES
     max_rounds: int = _lib.FUSED_MAX_ROUNDS - 1  # one spare so a trailing round never overflows
-    fallback: 'Geometry | None' = None   # smaller (faster per byte) tile for passes that do not need all gathered bits
     plan_width: int = 4       # gathered bits of every pass from dry runs of the pass (_plan_tiles): beam width
     plan_branch: int = 3      # ... and tiles tried per beam state; plan_width = 0: first-come tiles (no dry runs)
-    lane_swaps: bool = False  # layout changes by in-wave exchanges where possible (DQ_ROUND_SWAP; complex64 kernels)
-    swap_lanes: tuple = (0, 1, 2, 3, 4, 5)    # ... with these lane bits
-    swap_policy: str = 'chance'  # 'plan': LDS trips park the coming rounds' bits on lane bits; 'chance': trip-only layouts
     permute_store: bool = False   # passes may write to other index bits than they read (out-of-place; _place_writes)
     free_low: bool | str = True   # ... including the contiguous low bits: every pass picks ALL its tile qubits (_schedule)
-    asm_loop: bool = True     # mark rounds whose gates all have handler ids (DQ_ROUND_ALL_FAST); off: A/B measurements
     plan_restarts: int = 3    # beam searches with different random branches (states of >= 2^plan_restart_bits amplitudes)
     plan_restart_bits: int = 26
     plan_min_bits: int = 20   # states below 2^plan_min_bits amplitudes: greedy (width 1) -- planning time matters there
     far_bit: int = 19         # index bits >= far_bit are "far": every one gathered doubles the number of
-    max_far: int | None = None  # distant address streams of a tile; None = no limit (tools/sweep_tile_bits*.py)
-    wave: bool = False        # the wave-tile kernel (csrc/dq_wave.hip): one wavefront per tile, the library derives slot
-    #                           order, lane order and handlers itself; one-target 'gen' / 'x' gates only
+    max_far: int | None = None  # distant address streams of a tile; None = no limit
 
     @property
     def logt(self) -> int:
         return self.m - self.slots
 
 
-def default_geometry(is_c128: bool, m: int | None = None, slots: int | None = None) -> Geometry:
-    """Tile geometry per precision.  Without arguments: the WAVE TILE (one wavefront per tile, csrc/dq_wave.hip: m = 12 and
-    six register slots for complex64, m = 11 and five for complex128).  With ``m`` / ``slots`` given: a workgroup tile
-    (`workgroup_geometry`)."""
-    if m is None and slots is None:
-        # records of a pass: gates + 2 per layout change (twice that when it exchanges more bits than one trip moves) <= 112
-        if is_c128:     # 32 amplitudes of 16 bytes per lane: five slots, an 11-bit tile, 128-byte runs = 3 low bits
-            return Geometry(m=11, slots=5, vb=0, min_low=3, wave=True, max_gates=72, max_rounds=8)
-        return Geometry(m=12, slots=6, vb=1, min_low=4, wave=True, max_gates=72, max_rounds=8)
-    return workgroup_geometry(is_c128, m, slots)
+def default_geometry(is_c128: bool) -> Geometry:
+    """The wave tile of a precision: m = 12 and six register slots for complex64 (64 lanes x 64 amplitudes), m = 11 and
+    five for complex128 (64 x 32).  Records of a pass: gates + 2 per layout change (twice that when it exchanges more
+    bits than one trip moves) <= 112."""
+    if is_c128:     # 32 amplitudes of 16 bytes per lane: five slots, an 11-bit tile, 128-byte runs = 3 low bits
+        return Geometry(m=11, slots=5, vb=0, min_low=3, max_gates=72, max_rounds=8)
+    return Geometry(m=12, slots=6, vb=1, min_low=4, max_gates=72, max_rounds=8)
 
 
 def wave_supports(ops: Sequence['PrimOp'], is128: bool = False) -> bool:
     """Can the wave-tile kernel run all of ``ops``?  (One-target dense gates and X, diagonal gates on one or two
-    targets, any controls, the reductions; in complex64 also dense gates on two targets -- the 4x4 matrix of a
-    complex128 one does not fit the scalar registers.)"""
+    targets, dense gates on two targets, any controls, the reductions: everything the scheduler fuses.)"""
     return all((op.kind in ('gen', 'x') and len(op.targets) == 1) or (op.kind == 'diag' and len(op.targets) <= 2)
-               or (op.kind == 'gen' and len(op.targets) == 2 and not is128)
+               or (op.kind == 'gen' and len(op.targets) == 2)
                or op.kind in ('grad', 'expz') for op in ops)
-
-
-def workgroup_geometry(is_c128: bool, m: int | None = None, slots: int | None = None) -> Geometry:
-    """The workgroup-tile kernels (csrc/dq_fused.hip).  ``min_low`` = contiguous low bits every tile keeps: fewer of
-    them leave more tile bits for the qubits the gates need (fewer passes) at the price of shorter contiguous runs
-    (slower passes).  Measured on the headline sizes (ms per step, passes): c64, n = 28, batch 16: min_low 6 / 5 / 4 ->
-    643 (40) / 614 (35) / 596 (32); c128, n = 28, batch 8: min_low 4 / 3 -> 703 (38) / 671 (33).  The optimum is
-    128-byte runs (one cache line per lane group) in both precisions."""
-    if is_c128:
-        explicit = m is not None
-        m = 12 if m is None else m
-        slots = 3 if slots is None else slots
-        geom = Geometry(m=m, slots=slots, vb=0, min_low=max(3, m - _lib.FUSED_MAX_HIGH))
-        if not explicit:       # same trade as complex64: 12-bit tiles of 512 threads, 11-bit ones when 8 gathered bits do
-            geom.fallback = Geometry(m=11, slots=slots, vb=0, min_low=3)
-        return geom
-    # complex64: 13-bit tiles (512 threads, 64 KiB of LDS, two workgroups per CU) with 9 gathered bits: a pass costs
-    # ~14 % more than with 12-bit tiles but there are 15-20 % fewer of them (n = 28, depth 40, batch 16; seeds 1234 /
-    # 7 / 99: 548 -> 528, 593 -> 544, 539 -> 525 ms per step)
-    explicit = m is not None
-    m = 13 if m is None else m
-    slots = 4 if slots is None else slots
-    geom = Geometry(m=m, slots=slots, vb=1, min_low=max(4, m - _lib.FUSED_MAX_HIGH), lane_swaps=True)
-    if not explicit:
-        # a pass that needs no more than 8 gathered bits runs on the 12-bit tile: 5.4 instead of 5.0 TB/s for a
-        # single gate application
-        geom.fallback = Geometry(m=12, slots=slots, vb=1, min_low=4, lane_swaps=True)
-    return geom
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -431,8 +393,6 @@ def schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, fuse: bool = True,
     (distributed._exchange_qubits) rides on a pass that has to be made anyway.  Callers check ``applied_final_perm``
     on the result: False when no pass could take it (last step not fused, or the permutation moves a bit below the
     contiguous run), and they then permute on their own."""
-    if fuse and n < geom.m and geom.fallback is not None and n >= geom.fallback.m:
-        geom = geom.fallback                  # the state is smaller than the big tile but fits the small one
     if not fuse or n < geom.m:
         return Steps(SingleStep(i) for i in range(len(ops)))
     width = geom.plan_width if n >= geom.plan_min_bits else min(geom.plan_width, 1)
@@ -633,11 +593,7 @@ def _schedule_planned(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
             if len(high) + len(missing) > hcap:
                 return None
             high |= missing
-        small = geom.fallback
-        if small is not None and n >= small.m and len(high) <= small.m - small.min_low and small.min_low == geom.min_low:
-            steps.append((small, list(low_list), high, rounds))
-        else:
-            steps.append((geom, list(low_list), high, rounds))
+        steps.append((geom, list(low_list), high, rounds))
         prev_tile = low | high
     return _place_writes(ops, n, steps, geom.permute_store, final_perm)
 
@@ -691,20 +647,12 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
             wphys = [None] * n
             for i, b in enumerate(nlow):
                 wphys[b] = i
-            if geom.wave:
-                # the qubits this pass has in its own tile first: index bits L, L + 1, .. then extend the contiguous
-                # runs it writes (a tile bit written to bit L doubles them to 256 bytes: +5 % on the wave-tile kernel,
-                # tools/experiments/mb_wavetile.hip); which of its bits a tile reads where does not matter to the reader
-                mine = set(low_list) | set(high)
-                for b, pos in zip(sorted(nhigh, key=lambda b: (b not in mine, phys[b])), near):
-                    wphys[b] = pos
-            else:
-                keep = [b for b in nhigh if phys[b] in near]             # already cheap: stay
-                for b in keep:
-                    wphys[b] = phys[b]
-                free = [p_ for p_ in near if p_ not in {phys[b] for b in keep}]
-                for b in sorted(nhigh - set(keep), key=lambda b: phys[b]):
-                    wphys[b] = free.pop(0)
+            # the qubits this pass has in its own tile first: index bits L, L + 1, .. then extend the contiguous runs it
+            # writes (a tile bit written to bit L doubles them to 256 bytes); which of its bits a tile reads where does
+            # not matter to the reader
+            mine = set(low_list) | set(high)
+            for b, pos in zip(sorted(nhigh, key=lambda b: (b not in mine, phys[b])), near):
+                wphys[b] = pos
             taken = {w for w in wphys if w is not None}
             rest = [p_ for p_ in range(n) if p_ not in taken]
             for b in sorted((b for b in range(n) if wphys[b] is None), key=lambda b: phys[b]):
@@ -763,35 +711,17 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         desc.high_sorted[i] = b
 
     needs = [sorted(local[b] for b in rd.slots) for rd in rounds]
-    INF = 1 << 30
 
-    def next_use(bit: int, r0: int) -> int:
-        for r_ in range(r0, len(needs)):
-            if bit in needs[r_]:
-                return r_
-        return INF
-
-    # In-wave exchanges (DQ_ROUND_SWAP; complex64 gate loop): a round whose new register-slot bits all sit on LANE bits
-    # of the thread id gets them by v_permlane*_swap / DPP inside the wavefronts -- no LDS, no workgroup barrier --
-    # and every LDS trip therefore parks the bits the coming rounds need on the lane bits (soonest on bit 5, the
-    # cheapest exchange).  Only rounds of plain one-qubit gates and (C)NOTs qualify: their handlers exist whatever
-    # the layout, and the exchange lives in the assembly gate loop.
-    def simple(rd: _Round) -> bool:
-        return all(ops[oi].k == 1 and ((ops[oi].kind == 'x' and len(ops[oi].controls) <= 1) or
-                                       (ops[oi].kind == 'gen' and not ops[oi].controls)) for oi in rd.ops)
-
-    nreal = sum(len(rd.ops) for rd in rounds)
-    swap_budget = (_lib.FUSED_MAX_GATES - nreal) if geom.lane_swaps else 0     # exchange records share the gate array
-    nlanes = 6
+    # a layout per round: the register slots the round's gates need, topped up with the slots already there (then the top
+    # tile bits); the other tile bits go to the lanes in ascending order -- the kernel's translator (csrc/dq_wave.hip)
+    # picks the lane order of every trip itself
     layouts: list[tuple[tuple[int, ...], tuple[int, ...]]] = []
-    swaps_of: list[list[tuple[int, int]]] = []
     prev: tuple[tuple[int, ...], tuple[int, ...]] | None = None
-    for ri, (rd, need) in enumerate(zip(rounds, needs)):
+    for rd, need in zip(rounds, needs):
         assert len(need) <= R
-        swaps: list[tuple[int, int]] = []
         if prev is not None and set(need) <= set(prev[0]):
             lay = prev
-        elif not geom.lane_swaps:
+        else:
             io = io_layout(need)
             if io is not None:
                 lay = (tuple(io), tuple(ascending_tb(io)))
@@ -804,55 +734,8 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
                     if c not in slots_l:
                         slots_l.append(c)
                 slots_l.sort()
-                lay = (tuple(slots_l), tuple(_thread_bit_order(m, slots_l, geom)))
-        else:
-            io = io_layout(need) if prev is None else None
-            cur = prev
-            if cur is None and io is None:
-                dio = io_layout([])
-                cur = (tuple(dio), tuple(ascending_tb(dio)))      # round 0 starts from the default load layout
-            if io is not None:
-                lay = (tuple(io), tuple(ascending_tb(io)))          # loaded straight from memory
-            else:
-                entering = [b for b in need if b not in cur[0]]
-                lane_of = {b: i for i, b in enumerate(cur[1][:nlanes]) if i in geom.swap_lanes}
-                victims = sorted((s_ for s_, b in enumerate(cur[0]) if b not in need),
-                                 key=lambda s_: (-next_use(cur[0][s_], ri + 1), s_))
-                if (simple(rd) and all(b in lane_of for b in entering) and len(entering) <= len(victims)
-                        and len(entering) <= swap_budget):
-                    new_slots, new_tb = list(cur[0]), list(cur[1])
-                    for b in sorted(entering, key=lambda b: -lane_of[b]):
-                        s_ = victims.pop(0)
-                        swaps.append((s_, lane_of[b]))
-                        new_tb[lane_of[b]], new_slots[s_] = new_slots[s_], b
-                    swap_budget -= len(swaps)
-                    lay = (tuple(new_slots), tuple(new_tb))
-                else:
-                    if geom.swap_policy == 'plan':
-                        # LDS trip: the free slots and the lane bits go to what the coming rounds need soonest: the very
-                        # next one on lane bit 5 (one v_permlane32_swap per register), the others in the order that
-                        # keeps the LDS accesses of this layout free of bank conflicts; the rest on the wave bits
-                        pool = sorted((b for b in range(m) if b not in need),
-                                      key=lambda b: (next_use(b, ri + 1), 0 if b in cur[0] else 1, -b))
-                        slots_l = sorted(list(need) + pool[: R - len(need)])
-                        free = sorted((b for b in range(m) if b not in slots_l), key=lambda b: (next_use(b, ri + 1), b))
-                        lane_set = free[:nlanes]
-                        others = _thread_bit_order(m, sorted(set(range(m)) - set(lane_set[1:])), geom)
-                        lay = (tuple(slots_l), tuple(others + lane_set[:1] + sorted(free[nlanes:])))
-                    else:
-                        # LDS trip with the layout the trip-only scheduler would take (slots: keep what is there, then
-                        # the top bits; thread bits in the bank-conflict-free order): exchanges happen where the next
-                        # round's bits happen to sit on usable lane bits
-                        slots_l = list(need)
-                        for c in list(cur[0])[::-1] + list(range(m - 1, -1, -1)):
-                            if len(slots_l) >= R:
-                                break
-                            if c not in slots_l:
-                                slots_l.append(c)
-                        slots_l.sort()
-                        lay = (tuple(slots_l), tuple(_thread_bit_order(m, slots_l, geom)))
+                lay = (tuple(slots_l), tuple(ascending_tb(slots_l)))
         layouts.append(lay)
-        swaps_of.append(swaps)
         prev = lay
 
     def is_io(lay) -> bool:
@@ -860,7 +743,7 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         return io_layout(sl) == sl and list(lay[1]) == ascending_tb(sl)
 
     default_io = io_layout([])
-    load_rb = list(layouts[0][0]) if is_io(layouts[0]) and not swaps_of[0] else default_io
+    load_rb = list(layouts[0][0]) if is_io(layouts[0]) else default_io
 
     def read_pos(tl: int) -> int:                  # tile-local bit -> index bit on the read side
         return tl if tl < L else order[tl - L]
@@ -880,9 +763,9 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
         # stores two adjacent amplitudes), the tile bits written to index bits vb .. L-1 on the lowest lane bits (128
         # contiguous bytes per 8 lanes), the other thread bits in the order of their write positions
         store_rb = to_low[:vb]
-        # (wave tile: a layout change costs next to nothing, so the slots are simply the tile bits written FARTHEST away
-        # and the lanes of a store instruction cover the longest contiguous runs the write positions allow)
-        prefer = sorted(range(m), key=lambda tl: -wtile[tl]) if geom.wave else list(layouts[-1][0]) + list(range(m - 1, -1, -1))
+        # (a layout change costs next to nothing, so the slots are simply the tile bits written FARTHEST away and the
+        # lanes of a store instruction cover the longest contiguous runs the write positions allow)
+        prefer = sorted(range(m), key=lambda tl: -wtile[tl])
         for c in prefer:
             if len(store_rb) >= R:
                 break
@@ -908,122 +791,37 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
     for j, pos in enumerate(blk):
         desc.store_blk_pos[j] = wpos[pos]
 
-    esz_log = 3 if vb == 1 else 4           # complex64: 8-byte amplitudes; complex128: 16
-
-    def fill_table(index: int, slots_l) -> None:
-        if geom.wave:                       # (the wave-tile kernel addresses its staging buffer on its own)
-            return
-        period = 5 if vb == 1 else 4
-        for j in range(1 << R):
-            e = sum(1 << slots_l[s_] for s_ in range(R) if (j >> s_) & 1)
-            desc.lds_tab[index][j] = lds_swizzle(e, period) << esz_log
-
-    fill_table(0, load_rb)
-    fill_table(_lib.FUSED_MAX_ROUNDS + 1, store_rb)
-
     exec_order: list[int] = []
     gi = 0
     ntrans = 0
     cur = (tuple(load_rb), tuple(ascending_tb(load_rb)))
-    records: list[int | None] = []        # gate record -> op index (None: an exchange record)
-    nswaps = 0
     for ri, (rd, lay) in enumerate(zip(rounds, layouts)):
         r = desc.rounds[ri]
         r.flags = 0
         first = gi
         if lay != cur:
-            if swaps_of[ri]:
-                r.flags |= _lib.ROUND_SWAP
-                for s_, lane in swaps_of[ri]:
-                    g = desc.gates[gi]
-                    g.kind, g.q, g.q2, g.loc, g.loc2 = _lib.FG_SWAP, s_, lane, 0, 0
-                    g.reg_cmask = g.thr_cmask = g.out_cmask = 0
-                    g.mat = g.mat_advance = 0
-                    g.fast = 52 + 6 * s_ + lane
-                    records.append(None)
-                    gi += 1
-                nswaps += 1
-            else:
-                ntrans += 1
-                r.flags |= _lib.ROUND_TRANSPOSE
+            ntrans += 1
+            r.flags |= _lib.ROUND_TRANSPOSE
             cur = lay
         slot_of = {tl: s for s, tl in enumerate(lay[0])}
         for s in range(R):
             r.rb[s] = lay[0][s]
         for i, t in enumerate(lay[1]):
             r.tb[i] = t
-        fill_table(1 + ri, lay[0])
         for oi in rd.ops:
-            _encode_gate(desc.gates[gi], ops[oi], local, slot_of, tile, handlers=not geom.wave)
+            _encode_gate(desc.gates[gi], ops[oi], local, slot_of, tile)
             exec_order.append(oi)
-            records.append(oi)
             gi += 1
-        all_fast = all(desc.gates[k].fast != _lib.FAST_NONE for k in range(first, gi))
-        assert all_fast or not swaps_of[ri], 'an exchange round must consist of straight-line handlers'
-        r.gate_begin = first | (_lib.ROUND_ALL_FAST if all_fast and not geom.wave and (geom.asm_loop or swaps_of[ri]) else 0)
+        r.gate_begin = first
         r.gate_end = gi
     if cur != (tuple(store_rb), tuple(store_tb)):
         ntrans += 1
         desc.rounds[len(rounds) - 1].flags |= _lib.ROUND_TRANSPOSE_AFTER
     desc.nrounds = len(rounds)
-    return FusedStep(desc=desc, ops=exec_order, nrounds=len(rounds), ntranspose=ntrans, nswaps=nswaps, records=records,
-                     c64=vb == 1)
+    return FusedStep(desc=desc, ops=exec_order, nrounds=len(rounds), ntranspose=ntrans, c64=vb == 1)
 
 
-def lds_swizzle(e: int, period: int) -> int:
-    """Element index -> slot in the staging tile (csrc/dq_fused.hip lds_swz): the low ``period`` bits are XORed with
-    every higher group of ``period`` bits, so EVERY tile bit moves the bank; for complex64 (period 5) bit 4 is also
-    folded onto bit 0, so that the lanes of the global-I/O layout (tile bits 1..4 on lane bits 0..3) spread over the
-    16 slots a store group sees.  XOR-linear and bijective."""
-    mask = (1 << period) - 1
-    x, hi = e, e >> period
-    while hi:
-        x ^= hi & mask
-        hi >>= period
-    if period == 5:
-        x ^= (e >> 4) & 1
-    return x
-
-
-def _rank_gf2(vecs: list[int]) -> int:
-    basis: list[int] = []
-    for v in vecs:
-        for b_ in basis:
-            v = min(v, v ^ b_)
-        if v:
-            basis.append(v)
-    return len(basis)
-
-
-def _thread_bit_order(m: int, slots_l: list[int], geom: Geometry) -> list[int]:
-    """Order of the non-slot tile bits over the thread index (bit 0 = lane LSB).  Tile bit b moves the slot of an
-    access by the vector lds_swizzle(1 << b) (low ``period`` bits; period 5 for complex64: 32 eight-byte slots per
-    LDS row).  A store is served in groups of 16 (c64) / 8 (c128) consecutive lanes over HALF a row, a load in
-    groups of 32 / 16 lanes over a full row: conflict-free when the vectors of lane bits 0 .. period-2, cut to
-    period - 1 bits, are linearly independent, and those of lane bits 0 .. period-1 are independent as they are.
-    Every layout is read once (when it is entered) and written once (when it is left): one order serves both.
-    tools/lds_conflicts.py counts the conflicts of a whole schedule (headline circuit: 0.54 -> 0.12 extra LDS cycles
-    per ideal cycle against the round-1 swizzle and order)."""
-    free = [b for b in range(m) if b not in slots_l]
-    period = 5 if geom.vb == 1 else 4
-    full, half = (1 << period) - 1, (1 << (period - 1)) - 1
-    vec = {b: lds_swizzle(1 << b, period) & full for b in free}
-    chosen: list[int] = []
-    for b in free:                                  # lane bits 0 .. period - 2: independent within half a row
-        if len(chosen) < period - 1 and _rank_gf2([vec[c] & half for c in chosen] + [vec[b] & half]) == len(chosen) + 1:
-            chosen.append(b)
-    for b in free:                                  # (fewer than that exist: at least independent in the full row)
-        if len(chosen) < period - 1 and b not in chosen and _rank_gf2([vec[c] for c in chosen] + [vec[b]]) == len(chosen) + 1:
-            chosen.append(b)
-    for b in free:                                  # lane bit period - 1: completes the full row
-        if len(chosen) == period - 1 and b not in chosen and _rank_gf2([vec[c] for c in chosen] + [vec[b]]) == period:
-            chosen.append(b)
-    restb = [b for b in free if b not in chosen]
-    return chosen + restb
-
-
-def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of: dict[int, int], tile: set[int],
-                 handlers: bool = True) -> None:
+def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of: dict[int, int], tile: set[int]) -> None:
     reg_c, thr_c, out_c = 0, 0, 0
     for c in op.controls:
         if c in tile:
@@ -1070,27 +868,10 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         g.kind = _lib.FG_X1 if op.kind == 'x' else _lib.FG_GEN1
         g.q = slots[0]
         g.loc = op.mode if op.kind == 'gen' else 0
-        # straight-line handler id (index of the kernel's jump table): see include/dq_hip.h
-        if handlers:
-            g.fast = fast_id(g.kind, g.loc, slots[0], reg_c, thr_c, out_c)
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots
         g.loc = 1 if op.mode == 1 else 0      # promised real (and usually sparse): channel superoperators
-
-
-def fast_id(kind: int, mode: int, slot: int, reg_c: int, thr_c: int, out_c: int) -> int:
-    """Index of the kernel's straight-line handler for a one-target gate (include/dq_hip.h, DqFusedGate::fast)."""
-    free = reg_c == 0 and thr_c == 0 and out_c == 0
-    if kind == _lib.FG_X1:
-        if reg_c == 0:
-            return (16 if free else 32) + slot
-        if reg_c & (reg_c - 1) == 0:
-            return 36 + 4 * slot + reg_c.bit_length() - 1
-        return _lib.FAST_NONE
-    if kind == _lib.FG_GEN1 and reg_c == 0:
-        return 4 * mode + slot if free else 20 + 4 * (1 if mode == 3 else mode) + slot
-    return _lib.FAST_NONE
 
 
 def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], int]:
@@ -1103,11 +884,8 @@ def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], 
     for st in steps:
         if isinstance(st, FusedStep):
             st.desc.mat_base = off
-            for gi, oi in enumerate(st.records if st.records is not None else st.ops):
+            for gi, oi in enumerate(st.ops):
                 g = st.desc.gates[gi]
-                if oi is None:                      # an exchange record: no matrix
-                    g.mat, g.mat_advance = off, 0
-                    continue
                 op = ops[oi]
                 size = 0 if g.kind in (_lib.FG_X1, _lib.FG_GRAD, _lib.FG_EXPZ) else (1 << op.k) ** 2
                 g.mat, g.mat_advance, op.pos = off, size, off
@@ -1124,20 +902,19 @@ def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], 
 
 def rx_defer_positions(steps: Sequence, ops: Sequence[PrimOp]) -> list[int]:
     """Offsets (kernel matrix buffer, after ``layout_matrices``) of the gates that run on the deferred Rx handlers:
-    uncontrolled Rx-like gates (straight-line handler ids 8..11) of complex64 passes."""
+    uncontrolled Rx-like gates of complex64 passes."""
     pos = []
     for st in steps:
         if isinstance(st, FusedStep) and st.c64:
-            for gi, oi in enumerate(st.records if st.records is not None else st.ops):
-                if oi is not None and deferred_rx(st.desc.gates[gi]):
+            for gi, oi in enumerate(st.ops):
+                if deferred_rx(st.desc.gates[gi]):
                     pos.append(ops[oi].pos)
     return pos
 
 
 def deferred_rx(g) -> bool:
     """Does this record of a complex64 pass read the deferred Rx block (include/dq_hip.h, DQ_MODE_RX)?  An Rx-like 2x2
-    gate without a control of any kind -- handler ids 8..11 of the workgroup-tile kernels, the same rule in the wave-tile
-    kernel."""
+    gate without a control of any kind."""
     return (g.kind == _lib.FG_GEN1 and g.loc == 2 and g.reg_cmask == 0 and g.thr_cmask == 0 and g.out_cmask == 0)
 
 

@@ -21,9 +21,9 @@
  *     circuit.py:232-240).
  *   - Every call enqueues on `stream` (a hipStream_t passed as void*; NULL = default stream) and
  *     returns without synchronising.  The library keeps no device memory and no global mutable
- *     state besides a thread-local error string; it is re-entrant.  The two exceptions are A/B MEASUREMENT
- *     knobs, not part of the data path's contract: dq_set_dense_path and dq_fused_set_tiles_per_wg set a
- *     process-wide (atomic) integer that later launches of every thread read; results never depend on them.
+ *     state besides a thread-local error string; it is re-entrant.  The one exception is an A/B MEASUREMENT
+ *     knob, not part of the data path's contract: dq_set_dense_path sets a process-wide (atomic) integer that
+ *     later launches of every thread read; results never depend on it.
  *   - Return value: DQ_OK (0) or a negative DqStatus; dq_last_error() describes the failure.
  *     No exception crosses the ABI.
  */
@@ -45,13 +45,13 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 20
+#define DQ_ABI_VERSION 21
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
 const char* dq_last_error(void);
 /* What the compiled library believes the descriptor structs below look like: sizeof(DqFusedGate), sizeof(DqFusedRound),
- * sizeof(DqFusedPass), then the offsets of DqFusedPass::rounds, gates, load_slot_off, lds_tab, store_high_pos, store_tb,
+ * sizeof(DqFusedPass), then the offsets of DqFusedPass::rounds, gates, load_slot_off, store_high_pos, store_tb,
  * slots -- at most `max` values written to `out`; returns how many there are.  Lets a binding check its own struct
  * definitions against the library instead of against numbers typed in by hand. */
 int dq_struct_layout(int* out, int max);
@@ -84,16 +84,15 @@ int dq_set_dense_path(int mfma);
  *    R register-slot bits (tile-local positions); gates of the round act on register slots.
  *    The host scheduler (deepquantum_amd/fusion.py) builds these descriptors.
  *
- *    Geometries (dq_fused_geometry).  complex64, variant 0 -- the default -- is the WAVE TILE: m = 12, 6 register
- *    slots, 64 threads: ONE wavefront owns a tile (64 lanes x 64 amplitudes in registers), a workgroup is four
+ *    Geometry (dq_fused_geometry): the WAVE TILE.  complex64: m = 12, 6 register slots; complex128: m = 11, 5 slots;
+ *    64 threads: ONE wavefront owns a tile (64 lanes x 64 / 32 amplitudes in registers), a workgroup is four
  *    independent waves, and a pass has no workgroup barrier at all; a layout change between rounds goes through a small
- *    wave-private LDS buffer.  For such a pass the library derives everything below the level of "which tile bits are
- *    register slots in which round" itself (csrc/dq_wave.hip translates the descriptor into the kernel's records):
- *    the order of a round's slots and of its thread bits, `fast`, DQ_ROUND_ALL_FAST, DQ_ROUND_SWAP and lds_tab are
- *    not used (fast must be DQ_FAST_NONE), and this build takes DQ_FG_GEN1, DQ_FG_X1, DQ_FG_DIAG1 and DQ_FG_DIAG2 records there (anything
- *    else: DQ_ERR_UNSUPPORTED -- plan such circuits for a workgroup-tile geometry).  The workgroup-tile geometries
- *    (complex64 variants 1, 2: m = 13 / 12, 4 slots, 512 / 256 threads; complex128: m = 12 / 11, 3 slots) stage the
- *    tile in LDS between rounds, two barriers per change.
+ *    wave-private LDS buffer.  The library derives everything below the level of "which tile bits are register slots
+ *    in which round" itself (csrc/dq_wave.hip translates the descriptor into the kernel's records): the order of a
+ *    round's slots and of its thread bits is the host's to choose freely.  Every DqFusedKind below runs there, in both
+ *    precisions.  (ABI <= 20 also had workgroup-tile geometries -- m = 13 / 12 with 4 slots, 512 / 256 threads, the
+ *    tile staged in LDS between rounds -- with handler ids, LDS offset tables and in-wave exchange records in this
+ *    descriptor; they went with ABI 21.)
  * ------------------------------------------------------------------------------------------ */
 #define DQ_FUSED_MAX_HIGH 12
 #define DQ_FUSED_MAX_LOW 8      /* contiguous low tile bits: L <= 8 */
@@ -105,12 +104,9 @@ typedef enum {
     DQ_FG_GEN1 = 0,  /* general 2x2 on register slot q                       */
     DQ_FG_X1 = 1,    /* Pauli-X / CNOT / Toffoli: swap the pair of slot q     */
     DQ_FG_DIAG1 = 2, /* diagonal 2x2 (Z,S,T,Rz,P,CZ...) target anywhere      */
-    DQ_FG_GEN2 = 3,  /* general 4x4 on register slots q (matrix MSB) and q2 (wave-tile geometries: complex64 only) */
+    DQ_FG_GEN2 = 3,  /* general 4x4 on register slots q (matrix MSB) and q2 */
     DQ_FG_DIAG2 = 4, /* diagonal 4x4 (Rzz...) both targets anywhere           */
-    DQ_FG_SWAP = 5,  /* not a gate: in-wave exchange of register slot q with lane bit q2 (0..5) of the thread id --
-                        v_permlane32/16_swap for lane bits 5 / 4, DPP row shifts for 3 / 2, DPP quad permutations for
-                        1 / 0 -- a change of layout without LDS and without a workgroup barrier.  Only as the leading
-                        records of a DQ_ROUND_SWAP round of complex64 kernels; fast = 52 + 6 * q + q2 */
+    DQ_FG_RESERVED5 = 5, /* (ABI <= 20: an in-wave exchange record of the workgroup-tile kernels; refused) */
     DQ_FG_GRAD = 6,  /* not a gate: a reduction for the reverse sweep of the adjoint method (dq_apply_fused_grad_c64 / _c128).
                         The state is psi and the cotangent lambda side by side along ONE extra index bit (register slot
                         q2: 0 = psi, 1 = lambda); the record adds  G[a][b] = sum lambda[target = a] conj(psi[target = b])
@@ -156,16 +152,7 @@ typedef struct {
     uint8_t reg_cmask;  /* controls that are register slots (bit s = slot s) */
     uint16_t thr_cmask; /* controls that are thread bits (tile-local bit positions) */
     uint32_t mat;       /* offset (in complex numbers) of this gate's matrix inside `mats` */
-    uint32_t fast;      /* GEN1 / X1 straight-line handler (index of the kernel's jump table), or DQ_FAST_NONE:
-                             0..15  2x2 gate, id = mode * 4 + slot, no control of any kind
-                            16..19  X on slot id - 16, no control of any kind
-                            20..31  2x2 gate, id - 20 = mode * 4 + slot (GENERAL / REAL / RX; HAD counts as REAL),
-                                    thread / outside controls only
-                            32..35  X on slot id - 32, thread / outside controls only
-                            36..51  X on slot q with ONE register-slot control c (plus any thread / outside
-                                    controls): id = 36 + 4 * q + c, c != q  (CNOT with both bits in registers)
-                            52..75  DQ_FG_SWAP of slot q with lane bit q2: id = 52 + 6 * q + q2 (complex64, gate loop only)
-                           anything else (register-controlled 2x2 gates, X with two register controls, ...): NONE */
+    uint32_t fast;      /* must be DQ_FAST_NONE (ABI <= 20: handler id of the workgroup-tile kernels' jump table) */
     uint64_t out_cmask; /* controls outside the tile (global bit positions) */
     uint32_t mat_advance; /* complex numbers this gate occupies in `mats` (0 for X1): the matrices of a pass
                              lie back to back in gate order, mat(i+1) = mat(i) + mat_advance(i), so the kernel
@@ -174,7 +161,6 @@ typedef struct {
                            s_load_dwordx8 per gate) */
 } DqFusedGate;          /* 32 bytes */
 #define DQ_FAST_NONE 0xFFFFFFFFu
-#define DQ_FAST_IDS 76   /* handler ids are < DQ_FAST_IDS */
 /* `mats` must be readable for DQ_MAT_PAD complex numbers past the last matrix of a pass (prefetch). */
 #define DQ_MAT_PAD 16
 
@@ -186,22 +172,13 @@ typedef struct {
     uint8_t tb[DQ_FUSED_MAX_TBITS]; /* tile-local bit position of thread-index bit i (the other m - slots
                                        tile bits, in an order the host picks to avoid LDS bank conflicts) */
     uint8_t flags;                  /* DQ_ROUND_TRANSPOSE: the layout (rb, tb) differs from the one the registers are in
-                                       when the round starts (the previous round's, or the load layout for round 0) ->
-                                       one LDS round trip first; DQ_ROUND_SWAP: it differs by in-wave exchanges; DQ_ROUND_TRANSPOSE_AFTER (last round only): the
-                                       layout differs from the store layout -> one LDS round trip before the store.
-                                       The kernel trusts these flags (it no longer compares layouts per lane);
+                                       when the round starts (the previous round's, or the load layout for round 0);
+                                       DQ_ROUND_TRANSPOSE_AFTER (last round only): it differs from the store layout.
                                        dq_apply_fused_* recomputes and checks them. */
-    uint8_t gate_begin, gate_end;   /* [begin & 0x7f, end) into gates[]; DQ_ROUND_ALL_FAST in gate_begin promises
-                                       that every gate of the round has a handler id (fast != DQ_FAST_NONE): the
-                                       kernel then runs the round's gate loop without leaving its assembly block */
+    uint8_t gate_begin, gate_end;   /* [begin, end) into gates[] */
 } DqFusedRound;                     /* 18 bytes */
-#define DQ_ROUND_ALL_FAST 0x80u
 #define DQ_ROUND_TRANSPOSE 0x01u
 #define DQ_ROUND_TRANSPOSE_AFTER 0x02u
-/* The layout (rb, tb) is the previous one with register slots exchanged against LANE bits of the thread id (thread
- * bits 0..5): the round's leading gate records are DQ_FG_SWAP and carry it out inside the wavefronts; no LDS trip.
- * Excludes DQ_ROUND_TRANSPOSE; needs DQ_ROUND_ALL_FAST (the exchange lives in the assembly gate loop). */
-#define DQ_ROUND_SWAP 0x04u
 
 typedef struct {
     uint8_t m, L, h, nrounds;
@@ -221,13 +198,6 @@ typedef struct {
      * loop per slot per tile. */
     uint64_t load_slot_off[DQ_FUSED_MAX_SLOTS];
     uint64_t store_slot_off[DQ_FUSED_MAX_SLOTS];
-    /* LDS addressing of every layout the pass uses: table 0 = load layout, table 1 + r = round r, table
-     * DQ_FUSED_MAX_ROUNDS + 1 = store layout.  Entry j (j = pattern of register-slot bits) = BYTE offset of
-     * swizzle(sum over the set bits s of j of 2^rb[s]) in the staging tile; swizzle(e) folds every higher group of
-     * 5 (8-byte amplitudes) / 4 (16-byte) index bits onto the low group by XOR -- e ^ ((e >> 5) & 31) ^ ((e >> 10) & 31)
-     * ^ ((e >> 4) & 1) resp. e ^ ((e >> 4) & 15) ^ ((e >> 8) & 15) ^ ((e >> 12) & 15).  It is XOR-linear, so a thread's
-     * address is swizzle(its base) * size XOR the table entry: one VALU op per access instead of five. */
-    uint16_t lds_tab[DQ_FUSED_MAX_ROUNDS + 2][16];
     /* Where the pass WRITES.  A pass may store its tile -- and its block index -- to other index bits (>= L) than
      * it read them from: a bit permutation of the state on the way out, so that the qubits of the NEXT pass already
      * sit in cheap (near) positions when that pass gathers them (scattered writes are nearly free on this memory
@@ -252,13 +222,8 @@ typedef struct {
                                                    (dq_fused_geometry); with m it selects the kernel */
 } DqFusedPass;
 
-/* Tile geometries this build was compiled with (m = slots + log2(threads)); variant 0 is the
- * default, DQ_ERR_ARG past the last one.  The kernel is selected by pass->m. */
+/* The tile geometry of each precision (m = slots + log2(threads)): variant 0; DQ_ERR_ARG for any other. */
 int dq_fused_geometry(int is_c128, int variant, int* m, int* slots, int* threads);
-/* Tuning knob (A/B measurements; not part of the data path's contract): a complex64 workgroup walks `tiles`
- * consecutive tiles of a pass and requests tile t + 1 from HBM while the gates of tile t run.  0 = automatic (4 where
- * the grid stays large enough), 1 = one tile per workgroup (no prefetch), otherwise a power of two <= 64. */
-int dq_fused_set_tiles_per_wg(int tiles);
 /* Host-side core of the pass planner (no device code; deepquantum_amd/fusion.py drives it): dry runs of a pass over the
  * commutation DAG of a gate list.  dq_dag_create copies the DAG: successors of gate i = succ[succ_off[i] .. succ_off[i+1]),
  * target_mask[i] = the qubits gate i needs inside the tile (0: it runs anywhere, e.g. a diagonal gate), fusable[i] = may it

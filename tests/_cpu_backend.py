@@ -36,8 +36,7 @@ class CpuTestBackend:
         return out
 
     def fused_geometry(self, is_c128, variant):
-        table = {(False, 0): (12, 6, 64), (False, 1): (13, 4, 512), (False, 2): (12, 4, 256),
-                 (True, 0): (11, 5, 64), (True, 1): (12, 3, 512), (True, 2): (11, 3, 256)}
+        table = {(False, 0): (12, 6, 64), (True, 0): (11, 5, 64)}
         return table[(bool(is_c128), variant)]
 
     # ---- fused pass interpreter --------------------------------------------------------------------
@@ -48,9 +47,7 @@ class CpuTestBackend:
         is128 = state.dtype == torch.complex128
         m, L, h = desc.m, desc.L, desc.h
         R = desc.slots
-        assert (is128, m, R) in ((False, 12, 6), (False, 12, 4), (False, 13, 4), (True, 11, 5), (True, 11, 3), (True, 12, 3)), 'no such kernel'
-        wave = m - R == 6       # the wave-tile kernels (include/dq_hip.h): no offset tables, no handler ids, no exchanges
-        assert grads is None or wave or not is128, 'complex128 reverse-sweep passes: wave-tile geometry only'
+        assert (is128, m, R) in ((False, 12, 6), (True, 11, 5)), 'no such kernel (the wave tile of the precision)'
         vb = 0 if is128 else 1
         logt = m - R
         assert L + h == m and n >= m
@@ -77,23 +74,6 @@ class CpuTestBackend:
             tl = desc.load_rb[sl_]
             assert desc.load_slot_off[sl_] == 1 << (tl if tl < L else high_pos[tl - L]), 'slot offset table wrong'
             assert desc.store_slot_off[sl_] == 1 << wpos[store_sl[sl_]], 'slot offset table wrong'
-        def want_table(slots_l):
-            out = []       # the kernel's lds_swz (csrc/dq_fused.hip), restated
-            for j in range(1 << R):
-                e_ = sum(1 << slots_l[s_] for s_ in range(R) if (j >> s_) & 1)
-                if is128:
-                    out.append((e_ ^ ((e_ >> 4) & 15) ^ ((e_ >> 8) & 15) ^ ((e_ >> 12) & 15)) * 16)
-                else:
-                    out.append((e_ ^ ((e_ >> 5) & 31) ^ ((e_ >> 10) & 31) ^ ((e_ >> 4) & 1)) * 8)
-            return out
-
-        if not wave:
-            assert [desc.lds_tab[0][j] for j in range(1 << R)] == want_table([desc.load_rb[s] for s in range(R)])
-            assert [desc.lds_tab[_lib.FUSED_MAX_ROUNDS + 1][j] for j in range(1 << R)] == \
-                want_table([desc.store_rb[s] for s in range(R)])
-            for r_ in range(desc.nrounds):
-                assert [desc.lds_tab[1 + r_][j] for j in range(1 << R)] == \
-                    want_table([desc.rounds[r_].rb[s] for s in range(R)]), 'LDS offset table wrong'
         # tile-local index -> global offset, tile index -> base
         e = np.arange(1 << m, dtype=np.int64)
         glob = e & ((1 << L) - 1)
@@ -123,7 +103,7 @@ class CpuTestBackend:
         for gi in range(ngates):
             g = desc.gates[gi]
             assert g.mat == run, 'matrix layout is not sequential'
-            size = {_lib.FG_GEN1: 4, _lib.FG_X1: 0, _lib.FG_DIAG1: 4, _lib.FG_GEN2: 16, _lib.FG_DIAG2: 16, _lib.FG_SWAP: 0, _lib.FG_GRAD: 0, _lib.FG_EXPZ: 0}[g.kind]
+            size = {_lib.FG_GEN1: 4, _lib.FG_X1: 0, _lib.FG_DIAG1: 4, _lib.FG_GEN2: 16, _lib.FG_DIAG2: 16, _lib.FG_GRAD: 0, _lib.FG_EXPZ: 0}[g.kind]
             assert g.mat_advance == size
             run += size
         per_sample = mats.shape[-1] if mats.ndim == 2 else mats.numel()
@@ -142,38 +122,19 @@ class CpuTestBackend:
                 rb = [rd.rb[s] for s in range(R)]
                 tb = [rd.tb[i] for i in range(logt)]
                 assert len(set(rb)) == R and all(q < m for q in rb)
-                first = rd.gate_begin & 0x7F
-                # a layout change is an LDS trip or (include/dq_hip.h, DQ_ROUND_SWAP) the in-wave exchanges that the
-                # round's leading DQ_FG_SWAP records spell out: slot q <-> lane bit q2 of the thread id
-                nswap = 0
-                exp_rb, exp_tb = list(lay[0]), list(lay[1])
-                while first + nswap < rd.gate_end and desc.gates[first + nswap].kind == _lib.FG_SWAP:
-                    g = desc.gates[first + nswap]
-                    assert rd.flags & _lib.ROUND_SWAP and g.q < R and g.q2 < 6, 'exchange record out of place'
-                    assert g.fast == 52 + 6 * g.q + g.q2 and g.mat_advance == 0
-                    assert g.reg_cmask == 0 and g.thr_cmask == 0 and g.out_cmask == 0
-                    exp_rb[g.q], exp_tb[g.q2] = exp_tb[g.q2], exp_rb[g.q]
-                    nswap += 1
-                assert all(desc.gates[k].kind != _lib.FG_SWAP for k in range(first + nswap, rd.gate_end))
-                if wave:
-                    assert nswap == 0 and not rd.flags & _lib.ROUND_SWAP and not rd.gate_begin & _lib.ROUND_ALL_FAST
-                if rd.flags & _lib.ROUND_SWAP:
-                    assert not is128 and nswap > 0 and (rb, tb) == (exp_rb, exp_tb) != lay, 'exchanges do not give the layout'
-                    assert rd.gate_begin & _lib.ROUND_ALL_FAST and not rd.flags & _lib.ROUND_TRANSPOSE
-                else:
-                    assert bool(rd.flags & _lib.ROUND_TRANSPOSE) == ((rb, tb) != lay), 'transposition flag wrong'
+                first = rd.gate_begin
+                assert bool(rd.flags & _lib.ROUND_TRANSPOSE) == ((rb, tb) != lay), 'transposition flag wrong'
+                assert rd.flags & ~(_lib.ROUND_TRANSPOSE | _lib.ROUND_TRANSPOSE_AFTER) == 0
                 lay = (rb, tb)
                 after = r == desc.nrounds - 1 and lay != (store_sl, store_tb)
                 assert bool(rd.flags & _lib.ROUND_TRANSPOSE_AFTER) == after, 'final transposition flag wrong'
                 assert sorted(rb + tb) == list(range(m)), 'slots + thread bits must cover the tile exactly'
                 slotmask = sum(1 << q for q in rb)
-                if rd.gate_begin & _lib.ROUND_ALL_FAST:
-                    assert all(desc.gates[k].fast != _lib.FAST_NONE for k in range(first, rd.gate_end)), \
-                        'round promises handler ids for all gates'
-                for gi in range(first + nswap, rd.gate_end):
+                for gi in range(first, rd.gate_end):
                     g = desc.gates[gi]
                     assert g.thr_cmask & slotmask == 0, 'thread-control on a slot bit'
-                    assert not wave or g.kind in (_lib.FG_GEN1, _lib.FG_X1, _lib.FG_DIAG1, _lib.FG_DIAG2, _lib.FG_GRAD, _lib.FG_EXPZ) or (g.kind == _lib.FG_GEN2 and not is128), 'the wave-tile kernel takes one-target and diagonal gates (complex64: two-target dense ones too)'
+                    assert g.kind in (_lib.FG_GEN1, _lib.FG_X1, _lib.FG_DIAG1, _lib.FG_DIAG2, _lib.FG_GEN2, _lib.FG_GRAD, _lib.FG_EXPZ), 'the pass kernel takes one- and two-target dense gates, X, diagonal gates and the reductions'
+                    assert g.fast == _lib.FAST_NONE, 'no handler ids since ABI 21'
                     assert (g.reg_cmask >> R) == 0
                     cm = g.thr_cmask
                     for s in range(R):
@@ -187,7 +148,7 @@ class CpuTestBackend:
                     if g.kind == _lib.FG_EXPZ:
                         # include/dq_hip.h, DQ_FG_EXPZ: sum (-1)^popc(index & zmask) |a|^2 over the whole state; the Z
                         # bits come as control masks (cm = the tile-local ones, `outside` the others); row `reserved`
-                        assert grads is not None and wave and g.reserved < grads.shape[1], 'expectation record outside a dq_apply_fused_grad call'
+                        assert grads is not None and g.reserved < grads.shape[1], 'expectation record outside a dq_apply_fused_grad call'
                         par_e = np.zeros(e.shape, dtype=np.int64)
                         for bit in range(m):
                             if (cm >> bit) & 1:
@@ -217,30 +178,18 @@ class CpuTestBackend:
                         comp = np.array([G[0, 0].real, G[0, 0].imag, G[0, 1].real, G[0, 1].imag,
                                          G[1, 0].real, G[1, 0].imag, G[1, 1].real, G[1, 1].imag])
                         assert g.loc in (0, 1, 2, 3)
-                        if g.loc == 1 and wave and not is128:
+                        if g.loc == 1 and not is128:
                             comp[1::2] = 0.0
-                        elif g.loc == 2 and wave and not is128:
+                        elif g.loc == 2 and not is128:
                             comp = np.array([(G[0, 0] + G[1, 1]).real, 0, 0, (G[0, 1] + G[1, 0]).imag, 0, 0, 0, 0])
-                        elif g.loc == 3 and wave and not is128:
+                        elif g.loc == 3 and not is128:
                             comp[2:6] = 0.0
                         grads[b, g.reserved] += torch.from_numpy(comp)
                         continue
                     if g.kind in (_lib.FG_GEN1, _lib.FG_X1):
                         tbit = rb[g.q]
                         assert not (cm >> tbit) & 1
-                        # restated from include/dq_hip.h (DqFusedGate::fast), independently of fusion.fast_id
                         free = g.reg_cmask == 0 and g.thr_cmask == 0 and g.out_cmask == 0
-                        want = _lib.FAST_NONE
-                        if wave:
-                            pass
-                        elif g.kind == _lib.FG_X1:
-                            if g.reg_cmask == 0:
-                                want = (16 if free else 32) + g.q
-                            elif bin(g.reg_cmask).count('1') == 1:
-                                want = 36 + 4 * g.q + [1, 2, 4, 8].index(g.reg_cmask)
-                        elif g.reg_cmask == 0:
-                            want = 4 * g.loc + g.q if free else 20 + 4 * (1 if g.loc == 3 else g.loc) + g.q
-                        assert g.fast == want, 'fast-handler id wrong'
                         mat = mb[g.mat : g.mat + 4].reshape(2, 2)
                         if g.kind == _lib.FG_GEN1 and g.loc == 2 and not is128 and free:
                             # uncontrolled Rx-like gate of a complex64 pass: the deferred form (include/dq_hip.h,

@@ -325,7 +325,7 @@ def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5, dtype=torch.floa
             assert (x - y).abs().max().item() < tol, (key, (x - y).abs().max())
 
 
-def check_grad_records(n, m, device, is128=False):
+def check_grad_records(n, device, is128=False):
     """DQ_FG_GRAD records (dq_apply_fused_grad_c64 / _c128) against numpy: psi and lambda interleaved along index bit 0, a
     reduction sum lambda (x) conj(psi) for every target bit, with controls that land on register slots, on thread
     bits and outside the tile, in between gates that leave deferred factors in the registers (Hadamards, Rx); the
@@ -374,7 +374,7 @@ def check_grad_records(n, m, device, is128=False):
                 g[:, a_, b_] = (la * ps.conj()).sum(-1)
         want.append(g)
     mats = torch.cat(mats_l)
-    geom = fusion.default_geometry(is128) if m == 'wave' else fusion.default_geometry(False, m)
+    geom = fusion.default_geometry(is128)
     steps = fusion.schedule(ops, n, geom)
     assert all(isinstance(s, fusion.FusedStep) for s in steps)
     xd, md = x.to(device), fusion.kernel_matrices(steps, ops, mats).to(device)
@@ -683,14 +683,14 @@ def check_fuzz_against_oracle(dq, device=None, n=13, seeds=(0, 1, 2), depth=6, b
         outs = []
         try:
             for cfg in ({'merge_min_amps': None, 'plan_width': 0}, {'merge_min_amps': 0, 'plan_width': 1},
-                        {'merge_min_amps': 0, 'plan_width': 4}, {'merge_min_amps': 0, 'asm_loop': False},
+                        {'merge_min_amps': 0, 'plan_width': 4},
                         {'merge_min_amps': 0, 'permute_store': True, 'permute_min_bits': 0},
                         {'merge_min_amps': None, 'plan_width': 0, 'permute_store': True, 'permute_min_bits': 0},
                         {'merge_min_amps': 0, 'permute_store': True, 'permute_min_bits': 0, 'free_low': False},
                         {'merge_min_amps': 0, 'permute_store': True, 'permute_min_bits': 0, 'free_low': 'force',
                          'plan_width': 4},
                         {'merge_min_amps': None, 'permute_store': True, 'permute_min_bits': 0, 'free_low': 'force',
-                         'plan_width': 2, 'lane_swaps': False}):
+                         'plan_width': 2}):
                 dq.executor.CONFIG.update(keep)
                 dq.executor.CONFIG.update(cfg)
                 dq.executor._PLAN_CACHE.clear()

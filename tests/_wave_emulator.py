@@ -215,7 +215,7 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None):
                     continue
                 if not tile_ok:
                     continue
-                if getattr(g, 'ID_GEN2', 1 << 30) <= hid < getattr(g, 'ID_GEN2', 1 << 30) + 15:
+                if getattr(g, 'ID_GEN2', 1 << 30) <= hid < getattr(g, 'ID_GEN2', 1 << 30) + len(g.SWAP_PAIRS):
                     # dense gate on two slots a < b (gen2_code): matrix index = 2 * bit(b) + bit(a), w6 = swap the two
                     # index bits of the matrix first, w5 = group mask
                     a_, b_ = g.SWAP_PAIRS[hid - g.ID_GEN2]

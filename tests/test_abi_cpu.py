@@ -41,7 +41,7 @@ def test_struct_layout_matches_header():
     cnt = lib.dq_struct_layout(got, 16)
     p = _lib.DqFusedPass
     mine = [ctypes.sizeof(_lib.DqFusedGate), ctypes.sizeof(_lib.DqFusedRound), ctypes.sizeof(p), p.rounds.offset, p.gates.offset,
-            p.load_slot_off.offset, p.lds_tab.offset, p.store_high_pos.offset, p.store_tb.offset, p.slots.offset]
+            p.load_slot_off.offset, p.store_high_pos.offset, p.store_tb.offset, p.slots.offset]
     assert cnt == len(mine) and list(got[:cnt]) == mine
     assert ctypes.sizeof(_lib.DqFusedGate) == 32
     assert _lib.DqFusedGate.fast.offset == 12 and _lib.DqFusedGate.mat_advance.offset == 24

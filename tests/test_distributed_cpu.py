@@ -296,6 +296,72 @@ def _case_batched_w4(dq, rank, world):
     _both_modes(dq, run)
 
 
+def _virtual_bits_check(dq, rank, world, n, double):
+    """CONFIG['virtual_bits']: an un-batched shard as 2^v rows that move through the remaps like the samples of a batch
+    (rows = ranks of a virtual world; a remap that touches a virtual bit exchanges chunks between rows as well).  The
+    same shards and expectation values as without them, for gates with targets, controls and diagonal factors on real
+    rank bits, on virtual bits and on row-local bits."""
+    import specs
+    from deepquantum_amd import distributed as D
+
+    g = world.bit_length() - 1
+    spec = specs.random_spec(n, 6, 99) + [
+        ('rz', [0, 0.37], {}), ('rz', [g, -0.9], {}), ('rz', [g + 1, 1.3], {}),              # diagonal on real / virtual bits
+        ('cnot', [g, n - 1], {}), ('cnot', [g + 1, 0], {}), ('cnot', [n - 1, g], {}),         # controls / targets on virtual bits
+        ('rzz', [[0, g], 0.6], {}), ('rzz', [[g, g + 1], -0.4], {}), ('crz', [g + 1, n - 4, 0.8], {}),
+        ('toffoli', [0, g, n - 2], {}), ('rxx', [[g, n - 1], 0.5], {}), ('swap', [[g + 1, n - 3]], {}),
+    ] + specs.random_spec(n, 3, 7)
+    dense = dq.QubitCircuit(n)
+    _apply_spec(dense, spec)
+    dense.observable(0)
+    dense.observable([g, n - 1], 'zz')
+    dense.observable([g + 1, 2], 'xz')
+    if double:
+        dense.to(torch.double)
+    with torch.no_grad():
+        ref = dense().reshape(-1)
+        ref_ev = dense.expectation()
+    per = 2**n // world
+    tol = 1e-10 if double else 2e-5
+    stats = {}
+    try:
+        for vb in (0, 1, 2):
+            D.CONFIG['virtual_bits'] = vb
+            for lazy in (False, True):
+                shard = dq.DistributedQubitCircuit(n)
+                _apply_spec(shard, spec)
+                shard.observable(0)
+                shard.observable([g, n - 1], 'zz')
+                shard.observable([g + 1, 2], 'xz')
+                shard.lazy_layout = lazy
+                if double:
+                    shard.to(torch.double)
+                with torch.no_grad():
+                    st = shard()
+                    stats[(vb, lazy)] = dict(D.LAST_RUN)
+                    ev = shard.expectation()
+                    amps = st.amps
+                assert (ev - ref_ev).abs().max().item() < tol, (vb, lazy, ev, ref_ev)
+                err = (amps - ref[rank * per:(rank + 1) * per]).abs().max().item()
+                assert err < tol, f'rank {rank}: virtual_bits {vb} lazy {lazy}: shard error {err}'
+    finally:
+        D.CONFIG['virtual_bits'] = 0
+    for vb in (1, 2):
+        st_ = stats[(vb, True)]
+        assert st_['virtual_bits'] == vb and st_['virtual_remaps'] > 0, st_
+        if st_['remaps'] > st_['virtual_remaps']:         # a remap of real rank bits only: the rows move in groups
+            assert st_['groups'] == min(4, 1 << vb), st_
+    assert stats[(0, True)]['virtual_bits'] == 0 and stats[(0, True)]['virtual_remaps'] == 0
+
+
+def _case_virtual_bits_w2(dq, rank, world):
+    _virtual_bits_check(dq, rank, world, 14, double=True)       # complex128: rows of 2^11 amplitudes = one tile
+
+
+def _case_virtual_bits_w4(dq, rank, world):
+    _virtual_bits_check(dq, rank, world, 16, double=False)      # complex64: rows of 2^12
+
+
 def _case_grouped_exchange_w4(dq, rank, world):
     """One coalesced exchange per group of samples (communication.exchange_chunks) against one collective per sample:
     the same shards, a fraction of the collectives; and the per-remap timing records stay consistent."""
@@ -503,7 +569,7 @@ def _case_sampled_expectation_w4(dq, rank, world):
                                         ('random_remap_w4', 4), ('remap_w8', 8),
                                         ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4), ('folded_permute_w2', 2),
                                         ('golden_w2', 2), ('golden_w4', 4), ('golden_w8', 8),
-                                        ('fused_sweep_w2', 2), ('fused_sweep_w4', 4), ('grouped_exchange_w4', 4)])
+                                        ('fused_sweep_w2', 2), ('fused_sweep_w4', 4), ('grouped_exchange_w4', 4), ('virtual_bits_w2', 2), ('virtual_bits_w4', 4)])
 def test_sharded_circuit(case, world):
     _run(case, world)
 

@@ -59,13 +59,13 @@ def run_steps(state, ops, mats, steps):
     return x
 
 
-@pytest.mark.parametrize('is128,m,n', [(False, 12, 12), (False, 12, 14), (True, 11, 13), (False, 13, 14), (True, 12, 13)])
+@pytest.mark.parametrize('is128,n', [(False, 12), (False, 14), (True, 13), (False, 15), (True, 11)])
 @pytest.mark.parametrize('seed', [0, 1])
-def test_schedule_matches_program_order(cpu_backend, is128, m, n, seed):
+def test_schedule_matches_program_order(cpu_backend, is128, n, seed):
     dtype = torch.complex128 if is128 else torch.complex64
     ops, mats = random_ops(n, 60, seed)
     mats = mats.to(dtype)
-    geom = fusion.default_geometry(is128, m)
+    geom = fusion.default_geometry(is128)
     steps = fusion.schedule(ops, n, geom)
     executed = sorted(i for st in steps for i in (st.ops if isinstance(st, fusion.FusedStep) else [st.op]))
     assert executed == list(range(len(ops)))
@@ -146,9 +146,9 @@ def test_planned_tiles_need_fewer_passes_and_keep_the_result(cpu_backend):
                 spec.append(('cnot', q, t + (t >= q)))
 
     def run(width):
-        # (workgroup tiles: with the wave tile's cap of 72 gates per pass this small circuit is bounded by the cap,
-        # not by the tiles, and every rule needs the same five passes)
-        dq.executor.CONFIG['plan_width'], dq.executor.CONFIG['wave'] = width, False
+        # (a cap of 40 gates per pass: with the default 72 this small circuit is bounded by the cap, not by the tiles,
+        # and every rule needs the same passes)
+        dq.executor.CONFIG['plan_width'], dq.executor.CONFIG['max_gates'] = width, 40
         dq.executor._PLAN_CACHE.clear()
         try:
             cir = dq.QubitCircuit(n)
@@ -158,7 +158,7 @@ def test_planned_tiles_need_fewer_passes_and_keep_the_result(cpu_backend):
                 out = cir().clone()
             return out, dq.executor.LAST_RUN['passes']
         finally:
-            dq.executor.CONFIG['plan_width'], dq.executor.CONFIG['wave'] = None, None
+            dq.executor.CONFIG['plan_width'], dq.executor.CONFIG['max_gates'] = None, None
             dq.executor._PLAN_CACHE.clear()
 
     s0, p0 = run(0)
@@ -234,10 +234,9 @@ def test_permuted_stores_make_every_later_tile_contiguous(cpu_backend):
     n = 18
     ops, mats = random_ops(n, 200, 5, kinds=('gen', 'x', 'diag', 'gen2'))
     mats = mats.to(torch.complex64)
-    geom = fusion.workgroup_geometry(False)
+    geom = fusion.default_geometry(False)
     geom.permute_store = True
-    geom.fallback.permute_store = True
-    geom.free_low = geom.fallback.free_low = False      # (the low bits stay put here; the test below moves them too)
+    geom.free_low = False      # (the low bits stay put here; the test below moves them too)
     steps = fusion.schedule(ops, n, geom)
     fused = [s for s in steps if isinstance(s, fusion.FusedStep)]
     assert len(fused) >= 3 and any(s.permutes for s in fused)
@@ -273,66 +272,37 @@ def test_permuted_stores_make_every_later_tile_contiguous(cpu_backend):
     assert (cur - ref).abs().max().item() < 2e-5
 
 
-def test_exchange_seeds_of_the_gpu_test_cover_all_handlers():
-    """tests/test_kernels_gpu.py::test_in_wave_exchanges_of_slots_and_lane_bits relies on seeds whose schedules contain
-    every (register slot, lane bit) exchange: checked here, on the CPU, so that a scheduler change shows up before the
-    GPU run does."""
-    import ast
-    import os
-
-    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'test_kernels_gpu.py')).read()
-    marker = "@pytest.mark.parametrize('m,n,seeds', "
-    cases = ast.literal_eval(src[src.index(marker) + len(marker):src.index(')\ndef test_in_wave_exchanges')])
-    for m, n, seeds in cases:
-        seen = set()
-        for seed in seeds:
-            ops, _mats = random_ops(n, 80, seed, kinds=('gen', 'x'))
-            geom = fusion.default_geometry(False, m)
-            geom.swap_policy = 'plan'
-            for st in fusion.schedule(ops, n, geom):
-                assert isinstance(st, fusion.FusedStep)
-                d = st.desc
-                for gi in range(d.rounds[d.nrounds - 1].gate_end):
-                    if d.gates[gi].kind == _lib.FG_SWAP:
-                        seen.add((d.gates[gi].q, d.gates[gi].q2))
-        assert len(seen) == 24, (m, n, sorted(seen))
-
-
-@pytest.mark.parametrize('n,m', [(13, 13), (12, 12), (13, 'wave'), (12, 'wave')])
-def test_reduction_records_of_the_reverse_sweep(cpu_backend, n, m):
+@pytest.mark.parametrize('n', [13, 12])
+def test_reduction_records_of_the_reverse_sweep(cpu_backend, n):
     """DQ_FG_GRAD records through the descriptor interpreter (the GPU suite runs the same check on the kernel)."""
     from _helpers import check_grad_records
 
-    check_grad_records(n, m, torch.device('cpu'))
+    check_grad_records(n, torch.device('cpu'))
 
 
 @pytest.mark.parametrize('n', [12, 11])
 def test_reduction_records_of_the_reverse_sweep_c128(cpu_backend, n):
     from _helpers import check_grad_records
 
-    check_grad_records(n, 'wave', torch.device('cpu'), is128=True)
+    check_grad_records(n, torch.device('cpu'), is128=True)
 
 
-def free_low_schedule(ops, n, is128, m, width=4):
-    geom = fusion.default_geometry(False) if m == 'wave' else fusion.workgroup_geometry(is128, m)
+def free_low_schedule(ops, n, is128, width=4):
+    geom = fusion.default_geometry(is128)
     geom.permute_store = geom.free_low = True
-    if geom.fallback is not None:
-        geom.fallback.permute_store = geom.fallback.free_low = True
     return fusion._schedule(ops, n, geom, width, None, free_low=True)
 
 
-@pytest.mark.parametrize('n,seed,m,is128', [(18, 5, None, False), (17, 1, None, False), (16, 2, 12, False),
-                                            (15, 3, None, True), (16, 4, 11, True), (18, 5, 'wave', False),
-                                            (17, 1, 'wave', False)])
-def test_stores_that_relabel_the_low_bits(cpu_backend, n, seed, m, is128):
+@pytest.mark.parametrize('n,seed,is128', [(18, 5, False), (17, 1, False), (16, 2, False), (15, 3, True), (16, 4, True)])
+def test_stores_that_relabel_the_low_bits(cpu_backend, n, seed, is128):
     """Schedules in which every pass picks ALL its tile qubits (fusion._schedule(free_low=True)): a pass writes the
     qubits its successor wants on the contiguous low bits there (store_low_pos), which needs them in its own tile;
     the write positions of a pass are a permutation of [0, n), complex64 passes write the tile bit of store slot 0 to
     index bit 0, the passes compose to the canonical order, and the state equals the reference's."""
     dtype = torch.complex128 if is128 else torch.complex64
-    ops, mats = random_ops(n, 300, seed, kinds=('gen', 'x') if m == 'wave' else ('gen', 'x', 'diag'))
+    ops, mats = random_ops(n, 300, seed, kinds=('gen', 'x', 'diag'))
     mats = mats.to(dtype)
-    steps = free_low_schedule(ops, n, is128, m)
+    steps = free_low_schedule(ops, n, is128)
     assert steps is not None and all(isinstance(s, fusion.FusedStep) for s in steps)
     moved = 0
     where = list(range(n))                      # where[p] = which canonical bit currently lives at physical bit p
@@ -385,9 +355,9 @@ def test_free_low_schedules_win_on_deep_layered_circuits():
         off += 4
     counts = {}
     for fl in (False, True):
-        geom = fusion.workgroup_geometry(False)
-        geom.permute_store = geom.fallback.permute_store = True
-        geom.free_low = geom.fallback.free_low = fl
+        geom = fusion.default_geometry(False)
+        geom.permute_store = True
+        geom.free_low = fl
         geom.plan_width, geom.plan_branch, geom.plan_restarts = 4, 3, 1
         steps = fusion.schedule(ops, n, geom)
         counts[fl] = len(steps)
@@ -395,7 +365,7 @@ def test_free_low_schedules_win_on_deep_layered_circuits():
         assert relabelled == fl
     assert counts[True] < counts[False], counts
     big = ops + [fusion.PrimOp('gen', (5, 9, 13), (), off, 0)]          # a three-qubit gate runs on its own
-    geom = fusion.workgroup_geometry(False)
-    geom.permute_store = geom.fallback.permute_store = True
+    geom = fusion.default_geometry(False)
+    geom.permute_store = True
     assert fusion._schedule(big, n, geom, 4, None, free_low=True) is None
     assert any(isinstance(s, fusion.SingleStep) for s in fusion.schedule(big, n, geom))

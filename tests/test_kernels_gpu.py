@@ -108,14 +108,13 @@ def test_apply_gate_rejects_bad_arguments():
         backend.apply_gate(x.cpu(), m.cpu(), [1], [])  # CPU tensors: no fallback
 
 
-@pytest.mark.parametrize('is128,m,n', [(False, 12, 12), (False, 12, 15), (False, 13, 14), (True, 11, 11),
-                                       (True, 11, 14), (True, 12, 13)])
+@pytest.mark.parametrize('is128,n', [(False, 12), (False, 15), (False, 14), (True, 11), (True, 14), (True, 13)])
 @pytest.mark.parametrize('seed', [0, 1, 2])
-def test_fused_passes_match_oracle(is128, m, n, seed):
+def test_fused_passes_match_oracle(is128, n, seed):
     dtype = torch.complex128 if is128 else torch.complex64
     ops, mats = random_ops(n, 80, seed, kinds=('gen', 'x', 'diag', 'gen2', 'diag2'))
     mats = mats.to(dtype)
-    steps = fusion.schedule(ops, n, fusion.default_geometry(is128, m))
+    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
     assert all(isinstance(s, fusion.FusedStep) for s in steps)
     x = rand_state(2, n, dtype, 50 + seed)
     ref = run_reference(x, ops, mats)
@@ -124,37 +123,6 @@ def test_fused_passes_match_oracle(is128, m, n, seed):
         backend.apply_fused(xd, md, 0, st.desc, out=xd)
     err = (xd.cpu() - ref).abs().max().item()
     assert err < TOL[dtype], err
-
-
-@pytest.mark.parametrize('m,n,seeds', [(13, 15, [0, 2, 4, 5, 6, 7, 8, 9, 11, 14, 16, 17, 19, 20, 28, 41, 79, 117]),
-                                       (12, 14, [0, 2, 3, 4, 5, 6, 7, 8, 15, 18, 21, 24, 27, 28, 29, 33, 34, 50, 101, 209])])
-def test_in_wave_exchanges_of_slots_and_lane_bits(m, n, seeds):
-    """DQ_ROUND_SWAP: layout changes carried out inside the wavefronts (v_permlane32/16_swap, DPP row shifts, DPP quad
-    permutations + v_cndmask) instead of through LDS.  The seeds are chosen so that every (register slot, lane bit)
-    pair -- 24 handlers -- occurs in some pass of the 13-bit tile; every run is compared with the oracle."""
-    dtype = torch.complex64
-    seen = set()
-    for seed in seeds:
-        ops, mats = random_ops(n, 80, seed, kinds=('gen', 'x'))
-        mats = mats.to(dtype)
-        geom = fusion.default_geometry(False, m)
-        geom.swap_policy = 'plan'          # LDS trips park the coming rounds' bits on lane bits: many exchanges
-        steps = fusion.schedule(ops, n, geom)
-        for st in steps:
-            if isinstance(st, fusion.FusedStep):
-                d = st.desc
-                for gi in range(d.rounds[d.nrounds - 1].gate_end):
-                    if d.gates[gi].kind == _lib.FG_SWAP:
-                        seen.add((d.gates[gi].q, d.gates[gi].q2))
-        x = rand_state(2, n, dtype, 300 + seed)
-        ref = run_reference(x, ops, mats)
-        assert all(isinstance(st, fusion.FusedStep) for st in steps)
-        xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
-        for st in steps:
-            backend.apply_fused(xd, md, 0, st.desc, out=xd)
-        err = (xd.cpu() - ref).abs().max().item()
-        assert err < TOL[dtype], (seed, err)
-    assert len(seen) == 24, sorted(seen)        # (the seeds come from a dry run of the scheduler; re-derive them if it changes)
 
 
 @pytest.mark.parametrize('is128', [False, True])
@@ -173,7 +141,7 @@ def test_fused_batched_matrices_and_out_of_place(is128):
                 mi[op.mat : op.mat + d2] *= torch.exp(1j * torch.rand(1, generator=g, dtype=torch.float64) * 3)
         per_sample.append(mi)
     mats = torch.stack(per_sample).to(dtype)
-    steps = fusion.schedule(ops, n, fusion.workgroup_geometry(is128))
+    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
     x = rand_state(b, n, dtype, 5)
     ref = torch.cat([run_reference(x[i : i + 1], ops, mats[i]) for i in range(b)])
     xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev()).contiguous()
@@ -202,7 +170,7 @@ def test_fused_pass_with_one_shared_input_state(is128, n, b):
                 mi[op.mat : op.mat + d2] *= torch.exp(1j * torch.rand(1, generator=g, dtype=torch.float64) * 3)
         per_sample.append(mi)
     mats = torch.stack(per_sample).to(dtype)
-    steps = fusion.schedule(ops, n, fusion.workgroup_geometry(is128))
+    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
     assert all(isinstance(s_, fusion.FusedStep) for s_ in steps)
     x = rand_state(1, n, dtype, 77)
     ref = torch.cat([run_reference(x, ops, mats[i]) for i in range(b)])
@@ -216,9 +184,8 @@ def test_fused_pass_with_one_shared_input_state(is128, n, b):
     assert torch.equal(xd.cpu(), x)
 
 
-@pytest.mark.parametrize('n,seed,m,is128', [(18, 5, None, False), (17, 1, None, False), (16, 2, 12, False), (20, 7, None, False),
-                                            (15, 3, None, True), (16, 4, 11, True)])
-def test_stores_that_relabel_the_low_bits_on_gpu(n, seed, m, is128):
+@pytest.mark.parametrize('n,seed,is128', [(18, 5, False), (17, 1, False), (16, 2, False), (20, 7, False), (15, 3, True), (16, 4, True)])
+def test_stores_that_relabel_the_low_bits_on_gpu(n, seed, is128):
     """Passes that write other qubits to the contiguous low bits than they read there (store_low_pos, the explicit store
     layout store_rb / store_tb): schedules in which every pass picks all its tile qubits, against the oracle."""
     from test_fusion_cpu import free_low_schedule
@@ -226,7 +193,7 @@ def test_stores_that_relabel_the_low_bits_on_gpu(n, seed, m, is128):
     dtype = torch.complex128 if is128 else torch.complex64
     ops, mats = random_ops(n, 300, seed, kinds=('gen', 'x', 'diag'))
     mats = mats.to(dtype)
-    steps = free_low_schedule(ops, n, is128, m)
+    steps = free_low_schedule(ops, n, is128)
     assert steps is not None
     assert sum([s.desc.store_low_pos[i] for i in range(s.desc.L)] != list(range(s.desc.L)) for s in steps) >= 2
     x = rand_state(2, n, dtype, 60 + seed)
@@ -242,11 +209,11 @@ def test_stores_that_relabel_the_low_bits_on_gpu(n, seed, m, is128):
     assert err < TOL[dtype], err
 
 
-@pytest.mark.parametrize('n,m', [(15, 13), (14, 12), (12, 12), (15, 'wave'), (13, 'wave'), (12, 'wave')])
-def test_reductions_inside_fused_passes_match_numpy(n, m):
+@pytest.mark.parametrize('n', [15, 13, 12])
+def test_reductions_inside_fused_passes_match_numpy(n):
     from _helpers import check_grad_records
 
-    check_grad_records(n, m, dev())
+    check_grad_records(n, dev())
 
 
 @pytest.mark.parametrize('n', [15, 13, 12, 11])
@@ -254,7 +221,7 @@ def test_reductions_inside_fused_passes_match_numpy_c128(n):
     """dq_apply_fused_grad_c128 (wave-tile kernel, float64 sums all the way): 1e-12 relative."""
     from _helpers import check_grad_records
 
-    check_grad_records(n, 'wave', dev(), is128=True)
+    check_grad_records(n, dev(), is128=True)
 
 
 @pytest.mark.parametrize('dtype,n', [(torch.complex64, 15), (torch.complex64, 11), (torch.complex128, 13),
@@ -289,7 +256,7 @@ def test_batches_wider_than_a_grid_dimension_go_in_slices(monkeypatch):
     for op in ops:      # X-type matrices are not read by the kernels: keep the per-sample phase off them
         if op.kind == 'x':
             mats[:, op.mat:op.mat + 4] = mats0[op.mat:op.mat + 4].to(dtype)
-    steps = fusion.schedule(ops, n, fusion.workgroup_geometry(False))
+    steps = fusion.schedule(ops, n, fusion.default_geometry(False))
     x = rand_state(b, n, dtype, 3)
     ref = torch.cat([run_reference(x[i:i + 1], ops, mats[i]) for i in range(b)])
     xd = x.to(dev())
@@ -422,42 +389,9 @@ def test_pack_unpack(dtype):
         assert torch.equal(a2.cpu(), a1)
 
 
-@pytest.mark.parametrize('is128', [False, True])
-def test_all_handler_round_flag(is128):
-    """DQ_ROUND_ALL_FAST: rounds of handler-only gates run the assembly gate loop, mixed rounds the per-gate path (both
-    in one schedule, results checked by test_fused_passes_match_oracle); a round that carries the flag but holds a
-    gate without a handler id is refused by the C ABI."""
-    import copy
-    dtype = torch.complex128 if is128 else torch.complex64
-    n = 14
-    flagged = plain = 0
-    victim = None
-    for kinds in (('gen', 'x'), ('gen', 'x', 'diag', 'gen2')):
-        ops, mats = random_ops(n, 80, 3, kinds=kinds)
-        steps = fusion.schedule(ops, n, fusion.workgroup_geometry(is128))
-        for st in steps:
-            for r in range(st.desc.nrounds):
-                rd = st.desc.rounds[r]
-                gates = [st.desc.gates[k] for k in range(rd.gate_begin & 0x7F, rd.gate_end)]
-                all_fast = all(g.fast != _lib.FAST_NONE for g in gates)
-                assert bool(rd.gate_begin & _lib.ROUND_ALL_FAST) == all_fast
-                flagged += all_fast
-                plain += not all_fast
-                if not all_fast and victim is None:
-                    victim = (st, r, steps, ops, mats)
-    assert flagged > 0 and plain > 0 and victim is not None
-    st, r, steps, ops, mats = victim
-    md = fusion.kernel_matrices(steps, ops, mats.to(dtype)).to(dev())   # (assigns the matrix offsets of st.desc)
-    bad = copy.deepcopy(st.desc)
-    bad.rounds[r].gate_begin |= _lib.ROUND_ALL_FAST
-    x = rand_state(1, n, dtype, 1).to(dev())
-    with pytest.raises(RuntimeError, match='all-fast'):
-        backend.apply_fused(x, md, 0, bad, out=x)
-
-
 def handler_ops(n, ngates, seed):
-    """Gates that all have straight-line handlers: 2x2 gates of every promised structure (general, real, Rx-like,
-    Hadamard) mostly uncontrolled, X with up to one control -- so most rounds carry DQ_ROUND_ALL_FAST."""
+    """2x2 gates of every promised structure (general, real, Rx-like, Hadamard) mostly uncontrolled, X with up to one
+    control: the bodies specialised by matrix structure and the deferred factors."""
     rng = random.Random(seed)
     g = torch.Generator().manual_seed(seed)
     ops, mats, off = [], [], 0
@@ -487,14 +421,11 @@ def handler_ops(n, ngates, seed):
 
 @pytest.mark.parametrize('is128,n', [(False, 13), (False, 16), (True, 12), (True, 15)])
 @pytest.mark.parametrize('seed', [0, 1])
-def test_assembly_gate_loop_matches_oracle(is128, n, seed):
+def test_structured_gate_bodies_match_oracle(is128, n, seed):
     dtype = torch.complex128 if is128 else torch.complex64
     ops, mats = handler_ops(n, 150, seed)
     mats = mats.to(dtype)
-    steps = fusion.schedule(ops, n, fusion.workgroup_geometry(is128))
-    rounds = [st.desc.rounds[r] for st in steps for r in range(st.desc.nrounds)]
-    flagged = sum(bool(rd.gate_begin & _lib.ROUND_ALL_FAST) for rd in rounds)
-    assert flagged >= 0.5 * len(rounds), (flagged, len(rounds))
+    steps = fusion.schedule(ops, n, fusion.default_geometry(is128))
     x = rand_state(2, n, dtype, 70 + seed)
     ref = run_reference(x, ops, mats)
     xd, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())

@@ -71,7 +71,7 @@ def test_translated_passes_match_the_descriptor_semantics(cpu_backend, n, ngates
     ops, mats = random_ops(n, ngates, seed)
     mats = mats.to(dtype)
     geom = fusion.default_geometry(is128)
-    assert geom.wave and geom.m == (11 if is128 else 12)
+    assert geom.m == (11 if is128 else 12)
     geom.permute_store = permute
     geom.plan_min_bits = 12          # (plan the tiles as for big states, so that free low bits are exercised)
     steps = fusion.schedule(ops, n, geom)
@@ -114,16 +114,17 @@ def test_trips_cover_every_slot_mask_and_stay_inside_the_buffer():
         assert 8 * (S * ((1 << k) - 1) + 63) + 8 <= 8448
 
 
-def test_unsupported_records_are_refused(cpu_backend):
-    # (complex128: the 4x4 matrix of a two-target dense gate does not fit the scalar registers)
+def test_everything_the_scheduler_fuses_runs_on_the_wave_tile(cpu_backend):
+    """One pass kernel: one-target dense gates and X, diagonal gates on one or two targets, dense gates on two targets,
+    in both precisions (complex128 two-target dense gates since round 4)."""
     ops = [fusion.PrimOp('gen', (3,), (), 0, 0), fusion.PrimOp('gen', (5, 7), (), 4, 0)]
-    geom = fusion.default_geometry(True)
-    steps = fusion.schedule(ops, 13, geom)
-    lib = _lib.load()
-    import ctypes as C
-    rc = lib.dq_wave_descriptor(C.byref(steps[0].desc), 13, None, 0)
-    assert rc == -3 and b'one-target and diagonal' in lib.dq_last_error()
-    assert not fusion.wave_supports(ops, True) and fusion.wave_supports(ops[:1], True) and fusion.wave_supports(ops, False)
+    for is128 in (False, True):
+        assert fusion.wave_supports(ops, is128)
+        geom = fusion.default_geometry(is128)
+        steps = fusion.schedule(ops, 13, geom)
+        lib = _lib.load()
+        import ctypes as C
+        assert lib.dq_wave_descriptor(C.byref(steps[0].desc), 13, None, 0) > 0
     assert fusion.wave_supports([fusion.PrimOp('diag', (5, 2), (1,), 0, 0)])
 
 
@@ -203,31 +204,35 @@ def test_z_string_expectations_from_the_registers(cpu_backend, n, seed, is128):
     assert float(acc_d[:, :, 1:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('n,seed', [(12, 0), (13, 1), (15, 2)])
-def test_two_target_dense_gates_on_the_wave_tile_kernel(cpu_backend, n, seed):
-    """complex64: dense 4x4 gates on two register slots (any target order, register / thread / outside controls) among the
-    other records -- the library's translation executed by the emulator, the descriptor interpreter and the oracle."""
+@pytest.mark.parametrize('n,seed,is128', [(12, 0, False), (13, 1, False), (15, 2, False), (11, 3, True), (12, 4, True), (14, 5, True)])
+def test_two_target_dense_gates_on_the_wave_tile_kernel(cpu_backend, n, seed, is128):
+    """Dense 4x4 gates on two register slots (any target order, register / thread / outside controls) among the other
+    records, both precisions -- the library's translation executed by the emulator, the descriptor interpreter and the
+    oracle."""
     from test_fusion_cpu import random_ops as mixed_ops, run_reference
 
     ops, mats = mixed_ops(n, 60, seed, kinds=('gen', 'x', 'diag', 'gen2', 'gen2', 'diag2'))
-    mats = mats.to(torch.complex64)
-    assert fusion.wave_supports(ops, False) and any(op.kind == 'gen' and op.k == 2 for op in ops)
-    geom = fusion.default_geometry(False)
-    geom.plan_min_bits = 12
+    cd = torch.complex128 if is128 else torch.complex64
+    mats = mats.to(cd)
+    assert fusion.wave_supports(ops, is128) and any(op.kind == 'gen' and op.k == 2 for op in ops)
+    geom = fusion.default_geometry(is128)
+    geom.plan_min_bits = geom.m
     steps = fusion.schedule(ops, n, geom)
-    assert all(isinstance(s, fusion.FusedStep) and s.desc.slots == 6 for s in steps)
+    assert all(isinstance(s, fusion.FusedStep) and s.desc.slots == geom.slots for s in steps)
     km = fusion.kernel_matrices(steps, ops, mats)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(2, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 1 << n, generator=g, dtype=torch.float64)
-    x = (x / x.norm(dim=-1, keepdim=True)).to(torch.complex64)
+    x = (x / x.norm(dim=-1, keepdim=True)).to(cd)
     ref = run_reference(x, ops, mats)
     cur_d, cur_e = x.clone(), x.numpy().copy()
     ngen2 = 0
+    gm = emu.gen(is128)
     for st in steps:
         backend.apply_fused(cur_d, km, 0, st.desc, out=cur_d)
         cur_e = emu.run_pass(st.desc, n, cur_e, km.numpy(), 0)
         kp = emu.descriptor(st.desc, n)
-        ngen2 += sum(emu.gen().ID_GEN2 <= kp.rec[i][0] < emu.gen().ID_GEN2 + 15 for i in range(kp.nrec_bytes // 32))
+        ngen2 += sum(gm.ID_GEN2 <= kp.rec[i][0] < gm.ID_GEN2 + len(gm.SWAP_PAIRS) for i in range(kp.nrec_bytes // 32))
     assert ngen2 == sum(op.kind == 'gen' and op.k == 2 for op in ops)
-    assert (cur_d - ref).abs().max().item() < 1e-5
-    assert np.abs(cur_e - ref.numpy()).max() < 1e-5
+    tol = 1e-12 if is128 else 1e-5
+    assert (cur_d - ref).abs().max().item() < tol
+    assert np.abs(cur_e - ref.numpy()).max() < tol

@@ -11,7 +11,7 @@ mkdir -p $csrc/build/ablate
 build() {
   local tag=$1; shift
   $HIPCC $FLAGS "$@" -c $csrc/dq_dense.hip -o $csrc/build/ablate/dq_dense_$tag.o
-  $HIPCC --offload-arch=gfx950 -shared -fPIC $csrc/build/dq_capi.o $csrc/build/dq_gate.o $csrc/build/ablate/dq_dense_$tag.o $csrc/build/dq_fused.o \
+  $HIPCC --offload-arch=gfx950 -shared -fPIC $csrc/build/dq_capi.o $csrc/build/dq_gate.o $csrc/build/ablate/dq_dense_$tag.o $csrc/build/dq_pass.o \
      $csrc/build/dq_wave.o $csrc/build/dq_reduce.o $csrc/build/dq_dist.o $csrc/build/dq_plan.o -o $csrc/build/ablate/libdqhip_dense_$tag.so
   echo "built libdqhip_dense_$tag.so"
 }

@@ -11,10 +11,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import deepquantum_amd as dq  # noqa: E402
-from deepquantum_amd import _lib  # noqa: E402
 
 dev = torch.device('cuda', 0)
-PLAIN = {'merge_min_amps': None, 'permute_store': False, 'lane_swaps': False, 'plan_width': 0, 'free_low': False}
+PLAIN = {'merge_min_amps': None, 'permute_store': False, 'plan_width': 0, 'free_low': False}
 
 
 def run(n, depth, seed, batch, dtype, plain):
@@ -22,7 +21,6 @@ def run(n, depth, seed, batch, dtype, plain):
     try:
         if plain:
             dq.executor.CONFIG.update(PLAIN)
-            _lib.check(_lib.load().dq_fused_set_tiles_per_wg(1), 'tiles')
         else:
             dq.executor.CONFIG['merge_min_amps'] = 1 << 20
             dq.executor.CONFIG['plan_big_amps'] = 1 << 20
@@ -35,7 +33,6 @@ def run(n, depth, seed, batch, dtype, plain):
     finally:
         dq.executor.CONFIG.clear()
         dq.executor.CONFIG.update(keep)
-        _lib.check(_lib.load().dq_fused_set_tiles_per_wg(0), 'tiles')
         dq.executor._PLAN_CACHE.clear()
 
 
@@ -52,7 +49,7 @@ for n, depth, batch, dtype, seeds in ((26, 40, 4, torch.complex64, (7, 99, 2025)
         print(f'n={n} depth={depth} seed={seed} batch={batch} {str(dtype)[-3:]}: max |default - plain| = {err:.2e} (tol {tol:g}); '
               f'<Z0> {eva:+.6e} / {evb:+.6e}; norm {norm[0].item():.7f}; passes {sa["passes"]} (plain {sb["passes"]}), '
               f'kernel gates {sa["gates"]} (plain {sb["gates"]}), LDS trips {sa["transposes"]} (plain {sb["transposes"]}), '
-              f'exchange rounds {sa.get("swaps", 0)}', flush=True)
+              flush=True)
         assert err < tol, 'optimised and plain paths disagree'
         del a, b
         torch.cuda.empty_cache()

@@ -41,6 +41,5 @@ for i, (s, (a, b, ng, _nb)) in enumerate(zip(steps, ev)):
         op = plan.prim_ops[oi]
         k = 'grad' if op.kind == 'grad' else 'x' if op.kind == 'x' else ('h' if op.mode == 3 else 'rx' if op.mode == 2 else 'g')
         kinds[k] = kinds.get(k, 0) + 1
-    allfast = sum(1 for r in range(s.desc.nrounds) if s.desc.rounds[r].gate_begin & 0x80)
-    print(f'pass {i:2d}: m={s.desc.m} records {len(s.ops):3d} {kinds} rounds {s.nrounds} (asm-loop {allfast}) trips {s.ntranspose} swaps {s.nswaps}  {ms:6.2f} ms')
+    print(f'pass {i:2d}: m={s.desc.m} records {len(s.ops):3d} {kinds} rounds {s.nrounds} trips {s.ntranspose}  {ms:6.2f} ms')
 print('sweep total', round(tot, 1), 'ms over', len(steps), 'passes')

@@ -523,7 +523,7 @@ def expz_code():
     return t
 
 
-def gray_walk(op, base_operand, lane_operand, nt=False, scale=None):
+def gray_walk(op, base_operand, lane_operand, nt=False):
     """32 x (address = base + running slot offset + lane offset; op).  The running offset follows a Gray code over the
     slot bits 1..5, so each step is one 64-bit scalar add or subtract."""
     out_ = [f's_mov_b64 {RUN}, {base_operand}']
@@ -539,8 +539,6 @@ def gray_walk(op, base_operand, lane_operand, nt=False, scale=None):
         ad = ADDR[i % 4]
         out_.append(f'v_lshl_add_u64 {ad}, {RUN}, 0, {lane_operand}')
         regs = f'v[{AMP0 + 4 * g}:{AMP0 + 4 * g + 3}]'
-        if scale is not None:          # (experiment: the deferred factor applied right before each store)
-            out_ += [f'v_pk_mul_f32 {A(2 * g)}, {A(2 * g)}, {scale}', f'v_pk_mul_f32 {A(2 * g + 1)}, {A(2 * g + 1)}, {scale}']
         out_.append((f'global_load_dwordx4 {regs}, {ad}, off' if op == 'load' else f'global_store_dwordx4 {ad}, {regs}, off') + (' nt' if nt else ''))
     return out_
 
@@ -590,10 +588,8 @@ def kernel_body():
     # streaming (non-temporal) loads and stores when the host says so (flags bit 0 / 1: states far bigger than the
     # caches; +10-15 % on the memory side, tools/experiments/mb_wavetile.hip), plain ones otherwise (small states live in
     # the Infinity Cache between passes; the pass that reads ONE shared input state relies on the L2)
-    # (experiment, flags bit 7: the waves that issue memory instructions run at a raised priority)
-    text += ['s_bitcmp1_b32 %[flags], 7', 's_cbranch_scc0 .Lnpl_%=', 's_setprio 3', '.Lnpl_%=:']
     text += ['s_bitcmp1_b32 %[flags], 0', 's_cbranch_scc0 .Lldp_%='] + gray_walk('load', '%[inb]', LLD, nt=True) + ['s_branch .Lldd_%=', '.Lldp_%=:']
-    text += gray_walk('load', '%[inb]', LLD) + ['.Lldd_%=:', 's_setprio 0']
+    text += gray_walk('load', '%[inb]', LLD) + ['.Lldd_%=:']
     # the first record and its matrix arrive with the tile
     text += prefetch('first')
     text += [f's_getpc_b64 {TABLE}', '.Lanchor_%=:', 's_add_u32 s54, s54, .Ltable_%=-.Lanchor_%=', 's_addc_u32 s55, s55, 0',
@@ -615,16 +611,9 @@ def kernel_body():
                                                          's_branch .Ldiag_%=' if i >= ID_DIAG1 else 's_branch .Lnext_%='))
     # ---- epilogue: the pass's deferred factor, then the stores ----
     text += ['.Lexit_%=:', 's_load_dwordx8 s[40:47], %[ks], 40', 's_load_dwordx2 s[48:49], %[ks], 72',
-             's_bitcmp1_b32 %[flags], 7', 's_cbranch_scc0 .Lnps_%=', 's_setprio 3', '.Lnps_%=:',
              's_waitcnt lgkmcnt(0)',          # (the slot offsets -- and the LDS reads of a trip that ended the pass)
              f'v_readfirstlane_b32 {STMP}, {HI}', f'v_mov_b32 v10, {HR}', f'v_mov_b32 v11, {HR}',
              f's_cmp_eq_u32 {STMP}, 0', 's_cbranch_scc0 .Lcplx_%=']
-    # (experiment, flags bit 8, real factor only: scale two amplitudes, store them, scale the next two ... -- the first
-    # stores leave 64 packed multiplications earlier)
-    text += ['s_bitcmp1_b32 %[flags], 8', 's_cbranch_scc0 .Lnil_%=',
-             's_bitcmp1_b32 %[flags], 1', 's_cbranch_scc0 .Lilp_%=']
-    text += gray_walk('store', '%[outb]', LST, nt=True, scale='v[10:11]') + ['s_branch .Ldone_%=', '.Lilp_%=:']
-    text += gray_walk('store', '%[outb]', LST, scale='v[10:11]') + ['s_branch .Ldone_%=', '.Lnil_%=:']
     text += [f'v_pk_mul_f32 {A(j)}, {A(j)}, v[10:11]' for j in range(NA)]
     text += ['s_branch .Lstore_%=', '.Lcplx_%=:', f'v_mov_b32 v12, {HI}', f'v_mov_b32 v13, {HI}']
     for j in range(NA):

@@ -150,7 +150,9 @@ ID_DIAG2 = ID_DIAG1 + NV
 # reduction of the adjoint method's reverse sweep: target on slot 1 + (id - ID_GRAD), psi / lambda told apart by slot 0
 ID_GRAD = ID_DIAG2 + NV
 ID_EXPZ = ID_GRAD + R - 1      # expectation value of a Z string (DQ_FG_EXPZ)
-NIDS = ID_EXPZ + 1
+# dense gate on two register slots a < b (index in SWAP_PAIRS): a 4x4 matrix, index = 2 * (bit of slot b) + (bit of slot a)
+ID_GEN2 = ID_EXPZ + 1
+NIDS = ID_GEN2 + len(SWAP_PAIRS)
 ACC_BASE = 4 * 8704       # LDS offset of the reduction accumulators (8 doubles per record): behind the staging buffers
 
 
@@ -180,6 +182,119 @@ def handlers():
 
 
 PH0, PH1 = ('v[6:7]', 'v[8:9]'), ('v[32:33]', 'v[34:35]')        # (re, im) as f64 pairs
+
+
+# ---- dense gates on two targets (DQ_FG_GEN2): a 4x4 complex128 matrix is 64 dwords -- more than the scalar registers the
+# loop can spare -- so it passes through them two rows at a time.  Four register groups per batch: rows 0, 1 resident ->
+# outputs 0, 1 of each group, parked in the wave's staging buffer (the inputs must stay whole for the other rows); rows
+# 2, 3 resident -> outputs 2, 3 into their registers, outputs 0, 1 fetched back.  Two batches: four scalar-load phases.
+G2A = [80, 84, 88, 92]         # SGPR base of entry c of the first resident row (re = +0:+1, im = +2:+3)
+G2B = [40, 44, 72, 76]         # ... of the second one: s[40:47] and s[72:79] (the record's words are copied out first)
+G2MASK, G2MOFF, G2FLAG, G2PAIR, G2OFFA, G2OFFB = STMP, 's69', 's70', 's71', 's56', 's57'
+G2PARK = 'v8'                  # the lane's parking address: LDSB + 16 * lane (+ 1 KiB per parked amplitude)
+
+
+def far_next():
+    """Back to the loop head from code that lies out of the reach of s_branch."""
+    return ['s_sub_u32 vcc_lo, s54, .Ltable_%=-.Lnext_%=', 's_subb_u32 vcc_hi, s55, 0', 's_setpc_b64 vcc']
+
+
+def gen2_groups(a, b):
+    return [j for j in range(NA) if not (j >> a) & 1 and not (j >> b) & 1]
+
+
+def g2_load_rows(off_first, off_second):
+    """Rows at byte offsets (SGPR or literal) `off_first`, `off_second` of this record's matrix -> s[80:95], s[40:47] +
+    s[72:79]; with the swap flag the matrix index bits trade places: columns 1 <-> 2 of both rows."""
+    t = [f's_add_u32 vcc_lo, {G2MOFF}, {off_first}', f's_load_dwordx16 s[80:95], {MB}, vcc_lo',
+         f's_add_u32 vcc_lo, {G2MOFF}, {off_second}', f's_load_dwordx8 s[40:47], {MB}, vcc_lo',
+         's_add_u32 vcc_lo, vcc_lo, 32', f's_load_dwordx8 s[72:79], {MB}, vcc_lo', 's_waitcnt lgkmcnt(0)',
+         f's_cmp_eq_u32 {G2FLAG}, 0', 's_cbranch_scc1 .Lg2ns%=_{n}'.replace('{n}', str(g2_load_rows.n))]
+    for c1, c2 in ((G2A[1], G2A[2]), (G2B[1], G2B[2])):
+        for h_ in (0, 2):
+            t += [f's_mov_b64 vcc, s[{c1 + h_}:{c1 + h_ + 1}]', f's_mov_b64 s[{c1 + h_}:{c1 + h_ + 1}], s[{c2 + h_}:{c2 + h_ + 1}]',
+                  f's_mov_b64 s[{c2 + h_}:{c2 + h_ + 1}], vcc']
+    t.append(f'.Lg2ns%=_{g2_load_rows.n}:')
+    g2_load_rows.n += 1
+    return t
+
+
+g2_load_rows.n = 0
+
+
+def g2_two_rows(regs, outs):
+    """outs[0] (re, im pairs) = first resident row x inputs, outs[1] = second: four independent chains of eight."""
+    def m(base, c, part):
+        return f's[{base[c] + (0 if part == "r" else 2)}:{base[c] + (1 if part == "r" else 3)}]'
+    t = []
+    for c in range(4):
+        x_re, x_im = RE(regs[c]), IM(regs[c])
+        for row, base in enumerate((G2A, G2B)):
+            o_re, o_im = outs[row]
+            if c == 0:
+                t += [f'v_mul_f64 {o_re}, {m(base, c, "r")}, {x_re}', f'v_mul_f64 {o_im}, {m(base, c, "r")}, {x_im}']
+            else:
+                t += [f'v_fma_f64 {o_re}, {m(base, c, "r")}, {x_re}, {o_re}', f'v_fma_f64 {o_im}, {m(base, c, "r")}, {x_im}, {o_im}']
+        for row, base in enumerate((G2A, G2B)):
+            o_re, o_im = outs[row]
+            t += [f'v_fma_f64 {o_re}, -{m(base, c, "i")}, {x_im}, {o_re}', f'v_fma_f64 {o_im}, {m(base, c, "i")}, {x_re}, {o_im}']
+    return t
+
+
+def gen2_body(a, b):
+    groups = gen2_groups(a, b)
+    outs = [('v[10:11]', 'v[12:13]'), ('v[14:15]', 'v[16:17]')]
+    t = []
+    for batch in (0, 1):
+        mine = list(enumerate(groups))[4 * batch:4 * batch + 4]
+        t += g2_load_rows(0, G2OFFA)
+        for gl, (i, j) in enumerate(mine):
+            regs = [j | (((r >> 1) & 1) << b) | ((r & 1) << a) for r in range(4)]
+            t += [f's_bitcmp1_b32 {G2MASK}, {i}', f's_cbranch_scc0 .Lg2a{a}{b}_{i}_%=']
+            t += g2_two_rows(regs, outs)
+            t += [f'ds_write_b128 {G2PARK}, v[10:13] offset:{1024 * (2 * gl)}', f'ds_write_b128 {G2PARK}, v[14:17] offset:{1024 * (2 * gl + 1)}']
+            t.append(f'.Lg2a{a}{b}_{i}_%=:')
+        t += g2_load_rows(G2OFFB, 192)
+        for gl, (i, j) in enumerate(mine):
+            regs = [j | (((r >> 1) & 1) << b) | ((r & 1) << a) for r in range(4)]
+            t += [f's_bitcmp1_b32 {G2MASK}, {i}', f's_cbranch_scc0 .Lg2b{a}{b}_{i}_%=']
+            t += g2_two_rows(regs, outs)
+            t += [f'v_mov_b64 {RE(regs[2])}, v[10:11]', f'v_mov_b64 {IM(regs[2])}, v[12:13]',
+                  f'v_mov_b64 {RE(regs[3])}, v[14:15]', f'v_mov_b64 {IM(regs[3])}, v[16:17]',
+                  f'ds_read_b128 {A(regs[0])}, {G2PARK} offset:{1024 * (2 * gl)}', f'ds_read_b128 {A(regs[1])}, {G2PARK} offset:{1024 * (2 * gl + 1)}']
+            t.append(f'.Lg2b{a}{b}_{i}_%=:')
+        t.append('s_waitcnt lgkmcnt(0)')
+    return t
+
+
+def gen2_code():
+    """Entry of every two-target dense record (within reach of the jump table): controls; what the body needs of the
+    record -> registers of its own (s[72:79] will hold matrix entries); then the body of the slot pair through a second
+    jump table whose entries lead to trampolines (the bodies lie in front of everything, out of the reach of s_branch)."""
+    t = ['.Lgen2_%=:',
+         f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc0 .Lnext_%=',
+         f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
+         's_cbranch_execz .Lrestore_%=',
+         f's_mov_b32 {G2MASK}, s{REC + 5}', f's_mov_b32 {G2FLAG}, s{REC + 6}', f's_sub_u32 {G2PAIR}, s{REC}, {ID_GEN2}',
+         f's_sub_u32 {G2MOFF}, {MOFF}, 256',
+         # rows (0, 1 | 2, 3) of the matrix as the handler indexes it; with the swap flag rows 1 and 2 trade places
+         f's_cmp_eq_u32 {G2FLAG}, 0', f's_cselect_b32 {G2OFFA}, 64, 128', f's_cselect_b32 {G2OFFB}, 128, 64',
+         f'v_lshl_add_u32 {G2PARK}, {LANE}, 4, {LDSB}',
+         's_getpc_b64 vcc', '.Lg2anchor_%=:', f's_lshl3_add_u32 vcc_lo, {G2PAIR}, vcc_lo', 's_addc_u32 vcc_hi, vcc_hi, 0',
+         's_add_u32 vcc_lo, vcc_lo, .Lg2table_%=-.Lg2anchor_%=', 's_addc_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc', '.Lg2table_%=:']
+    for v in range(len(SWAP_PAIRS)):
+        t += [f's_branch .Lg2t{v}_%=', 's_nop 0']
+    for v in range(len(SWAP_PAIRS)):
+        t += [f'.Lg2t{v}_%=:', 's_getpc_b64 vcc', f'.Lg2ta{v}_%=:', f's_sub_u32 vcc_lo, vcc_lo, .Lg2ta{v}_%=-.Lg2b{v}_%=',
+              's_subb_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc']
+    return t
+
+
+def gen2_bodies():
+    t = []
+    for v, (a, b) in enumerate(SWAP_PAIRS):
+        t += [f'.Lg2b{v}_%=:'] + gen2_body(a, b) + [f's_mov_b64 exec, {SAVE}'] + far_next()
+    return t
 
 
 def grad_groups(q):
@@ -348,7 +463,8 @@ def kernel_body():
             out_.append(f's_mov_b64 exec, {SAVE}')
         return out_ + nxt
 
-    text = [f's_mov_b64 {KG}, %[kg]', f's_mov_b32 {GOFF}, 0', f's_mov_b32 {GEND}, %[gend]', f's_mov_b64 {MB}, %[mb]',
+    text = ['s_branch .Lstart_%='] + gen2_bodies() + ['.Lstart_%=:']
+    text += [f's_mov_b64 {KG}, %[kg]', f's_mov_b32 {GOFF}, 0', f's_mov_b32 {GEND}, %[gend]', f's_mov_b64 {MB}, %[mb]',
             f's_mov_b32 {MOFF}, %[moff]', f's_mov_b64 {TG}, %[tg]', f's_mov_b32 {LDSB}, %[ldsb]',
             's_load_dwordx8 s[40:47], %[ks], 0', 's_load_dwordx2 s[48:49], %[ks], 32',
             f's_load_dwordx8 s[{REC}:{REC + 7}], %[ks], 80', 's_load_dwordx8 s[80:87], %[ks], 112',
@@ -380,13 +496,15 @@ def kernel_body():
              f's_lshl2_add_u32 vcc_lo, s{REC}, s54', 's_addc_u32 vcc_hi, s55, 0', 's_setpc_b64 vcc',
              '.Ltable_%=:']
     for i in range(NIDS):
-        text.append(f's_branch .Lh{i}_%=' if i in h else ('s_branch .Ldiag_%=' if i >= ID_DIAG1 else 's_branch .Lnext_%='))
+        text.append(f's_branch .Lh{i}_%=' if i in h else ('s_branch .Lgen2_%=' if i >= ID_GEN2 else
+                                                         's_branch .Ldiag_%=' if i >= ID_DIAG1 else 's_branch .Lnext_%='))
     text += ['.Lexit_%=:', 's_load_dwordx8 s[40:47], %[ks], 40', 's_load_dwordx2 s[48:49], %[ks], 72', 's_waitcnt lgkmcnt(0)']
     for j in range(NA):
         text += [f'v_mul_f64 {RE(j)}, {RE(j)}, {HS}', f'v_mul_f64 {IM(j)}, {IM(j)}, {HS}']
     text += ['s_bitcmp1_b32 %[flags], 1', 's_cbranch_scc0 .Lstp_%='] + gray_walk('store', '%[outb]', LST, nt=True) + ['s_branch .Ldone_%=', '.Lstp_%=:']
     text += gray_walk('store', '%[outb]', LST)
     text += ['s_branch .Ldone_%=']
+    text += gen2_code()
     text += diag_code()
     for i in back:
         text += emit(i)
@@ -400,7 +518,7 @@ if __name__ == '__main__' or os.environ.get('DQ_ASM_OUT'):
            f'#define DQ_WID64_GEN_U {ID_GEN_U}', f'#define DQ_WID64_GEN_C {ID_GEN_C}', f'#define DQ_WID64_GEN_R {ID_GEN_R}',
            f'#define DQ_WID64_X_U {ID_X_U}', f'#define DQ_WID64_X_C {ID_X_C}', f'#define DQ_WID64_X_R {ID_X_R}', f'#define DQ_WID64_X_R1 {ID_X_R1}',
            f'#define DQ_WID64_TRIP0 {ID_TRIP0}', f'#define DQ_WID64_TRIP {ID_TRIP}', f'#define DQ_WID64_SWAP {ID_SWAP}',
-           f'#define DQ_WID64_DIAG1 {ID_DIAG1}', f'#define DQ_WID64_DIAG2 {ID_DIAG2}', f'#define DQ_WID64_GRAD {ID_GRAD}', f'#define DQ_WID64_EXPZ {ID_EXPZ}', f'#define DQ_WAVE64_ACC_BASE {ACC_BASE}',
+           f'#define DQ_WID64_DIAG1 {ID_DIAG1}', f'#define DQ_WID64_DIAG2 {ID_DIAG2}', f'#define DQ_WID64_GRAD {ID_GRAD}', f'#define DQ_WID64_EXPZ {ID_EXPZ}', f'#define DQ_WID64_GEN2 {ID_GEN2}', f'#define DQ_WAVE64_ACC_BASE {ACC_BASE}',
            'static const short kWave64TripId[32] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(NA)) + '};',
            'static const short kWave64SwapId[5][5] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
            '']
