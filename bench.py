@@ -84,6 +84,9 @@ def parse_args():
                     help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
     ap.add_argument('--no-free-low', action='store_true', help='A/B: the contiguous low bits keep the same qubits in every pass')
     ap.add_argument('--overlap-groups', type=int, default=None, help='N > 1: sample groups of the overlapped remap')
+    ap.add_argument('--virtual-bits', type=int, default=None,
+                    help='N > 1, un-batched shards (--strong, --config 4 | 5): top local index bits treated as rank bits of '
+                         'a virtual world, so that the rows of a shard overlap exchange and compute (default: 2 there)')
     ap.add_argument('--no-fold-permute', action='store_true',
                     help='N > 1, A/B: the re-labelling before an exchange as a pass of its own')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
@@ -341,6 +344,9 @@ def main():
         dq.executor.CONFIG['free_low'] = False
     if args.overlap_groups is not None:
         dq.distributed.CONFIG['overlap_groups'] = args.overlap_groups
+    if distributed and not batch:
+        # an un-batched shard has no samples to overlap its exchanges with: its rows take their place
+        dq.distributed.CONFIG['virtual_bits'] = 2 if args.virtual_bits is None else args.virtual_bits
     if args.no_fold_permute:
         dq.distributed.CONFIG['fold_permute'] = False
 
@@ -599,6 +605,15 @@ def main():
             wire = dstats['wire_bytes']
             links = min(7, world - 1)
             line['config']['exchange_per_step'] = per_step
+            # dry run of the exchange schedule (no data): steps that trade real rank bits / virtual ones, and how much
+            # of the wire volume (in shards per rank) travels while other rows of the shard compute
+            vb_ = dstats.get('virtual_bits', 0)
+            prims_ = [p_ for op_ in cir.operators for p_ in op_.prims(decompose=True)]
+            g_ = int(math.log2(world))
+            line['config']['virtual_rank_bits'] = vb_
+            line['config']['exchange_plan'] = {
+                'with_virtual_bits': dq.distributed.count_exchange_steps(prims_, n, g_, virtual_bits=vb_, reorder=True),
+                'without': dq.distributed.count_exchange_steps(prims_, n, g_, virtual_bits=0, reorder=True) if vb_ else None}
             # what the step does NOT pay (lazy_layout): restoring the reference's shard order, which the reference's
             # forward always pays -- the drop-in figure is the sum
             line['ms_per_step_with_restore'] = elapsed / args.steps * 1e3 + (restore_ms or 0.0)

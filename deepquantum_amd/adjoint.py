@@ -105,18 +105,24 @@ def _sweep_fused_sharded(ctx, grad_out, params):
     todo = []                  # (row, gate, parameter, exact inverse matrix) per gradient that is wanted
     idx = 1
     slots: list = []           # per parametrised gate, in sweep order: index into `todo` or None
+    nrows = 0                  # accumulator rows handed out so far
     for gate in gates:
         inv_prims = gate.inverse().prims()
         if gate.npara > 0:
             p = params[-idx]
             if ctx.needs_input_grad[3 + len(params) - idx]:
-                if (len(inv_prims) != 1 or len(inv_prims[0].targets) != 1 or inv_prims[0].kind not in ('gen', 'diag')
+                if (len(inv_prims) != 1 or len(inv_prims[0].targets) > 2 or inv_prims[0].kind not in ('gen', 'diag')
                         or inv_prims[0].matrix.ndim != 2):
                     return None
                 ip = inv_prims[0]
                 slots.append(len(todo))
-                prims.append(Prim('grad', None, (ip.targets[0] + 1, 0), tuple(c + 1 for c in ip.controls), len(todo)))
-                todo.append((gate, p, ip.matrix))
+                # (a gate on two targets -- Rxx, Ryy, Rzz, Rxy of the reference's own test circuit, tests/test_circuit.py:
+                # 87-139 -- takes four one-target records: executor.grad_records)
+                recs, cnt = executor.grad_records(ip.kind, ip.mode, tuple(t + 1 for t in ip.targets),
+                                                  tuple(c + 1 for c in ip.controls), nrows, reduced=False)
+                prims.extend(recs)
+                todo.append((gate, p, ip.matrix, nrows, ip.kind, len(ip.targets)))
+                nrows += cnt
             else:
                 slots.append(None)
             idx += 1
@@ -142,7 +148,7 @@ def _sweep_fused_sharded(ctx, grad_out, params):
         finally:
             DistributedQubitState.LAZY_AMPS = lazy
         pair.amps, pair.buffer = work, torch.empty_like(work)
-        acc = torch.zeros(1, len(todo), 8, dtype=torch.float64, device=work.device)
+        acc = torch.zeros(1, nrows, 8, dtype=torch.float64, device=work.device)
         D._SWEEP['grads'] = acc
         try:
             D.dist_apply_prims(pair, prims, mode='remap', keep_layout=True, force_mode=True)
@@ -152,13 +158,13 @@ def _sweep_fused_sharded(ctx, grad_out, params):
         if pair.world_size > 1:
             dist.all_reduce(acc, dist.ReduceOp.SUM)
         gsum = torch.view_as_complex(acc.reshape(-1, 4, 2)).reshape(-1, 2, 2)       # G' per row
-    LAST_SWEEP.update(fused=True, rows=len(todo), remaps=stats.get('remaps', 0), local_flushes=stats.get('local_flushes', 0))
+    LAST_SWEEP.update(fused=True, rows=nrows, remaps=stats.get('remaps', 0), local_flushes=stats.get('local_flushes', 0))
     vals = []
-    for r, (gate, p, inv) in enumerate(todo):
+    for gate, p, inv, row0, kind, ntargets in todo:
         with torch.enable_grad():
             du = gate.get_derivative(p.detach())
-        du = du.unsqueeze(0).flatten(0, -3).to(torch.complex128)                     # (npara, 2, 2)
-        g = gsum[r] @ inv.to(torch.complex128).mH                                    # G = G' U^-dagger
+        du = du.unsqueeze(0).flatten(0, -3).to(torch.complex128)                     # (npara, D, D)
+        g = executor.assemble_grad_sums(gsum, row0, kind, ntargets) @ inv.to(torch.complex128).mH       # G = G' U^-dagger
         brackets = (du * g.conj()).sum(dim=(-2, -1))
         vals.append((grad_out * 2 * brackets.real.to(grad_out.dtype)).reshape(p.shape))
     return [None if sl is None else vals[sl] for sl in slots]

@@ -562,6 +562,50 @@ def _inverse(kind: str, m: torch.Tensor) -> torch.Tensor:
     return torch.linalg.inv_ex(m)[0]
 
 
+def grad_records(kind: str, mode: int, targets: Sequence[int], controls: Sequence[int], row0: int,
+                 reduced: bool = True) -> tuple[list[Prim], int]:
+    """The reduction records of a reverse sweep for ONE trainable gate (bit positions of the (psi, lambda) pair: bit 0
+    tells the two apart), in front of which they go, and how many accumulator rows they fill from ``row0`` on.
+
+    One target: one DQ_FG_GRAD record, G = sum lambda (x) conj(psi) on the target (with the variant that forms only the
+    sums a rotation's gradient needs).  Two targets (t1, t2): the 4x4 sum in 2x2 blocks over t1, by the values of t2
+    in lambda (a2) and psi (b2) -- all from one-target records: a record controlled by t2 gives the block a2 = b2 = 1,
+    an uncontrolled one the sum of the two blocks a2 = b2; with t2 flipped on the LAMBDA half (an X controlled by bit
+    0, undone afterwards) the same two records give the block a2 = 0, b2 = 1 and the sum of the two blocks a2 != b2.
+    A diagonal gate only needs the diagonal: two records, no flips.  `assemble_grad_sums` puts the rows together."""
+    t = tuple(targets)
+    c = tuple(controls)
+    if len(t) == 1:
+        variant = 3 if kind == 'diag' else (mode if kind == 'gen' and mode in (1, 2) else 0)
+        if not (reduced and CONFIG['reduced_grad_sums']):
+            variant = 0
+        return [Prim('grad', None, (t[0], 0), c, row0 | (variant << fusion.GRAD_VARIANT_SHIFT))], 1
+    assert len(t) == 2, 'reductions inside the passes: trainable gates on one or two targets'
+    v = (3 << fusion.GRAD_VARIANT_SHIFT) if (kind == 'diag' and reduced and CONFIG['reduced_grad_sums']) else 0
+    same = [Prim('grad', None, (t[0], 0), c, row0 | v), Prim('grad', None, (t[0], 0), c + (t[1],), (row0 + 1) | v)]
+    if kind == 'diag':
+        return same, 2
+    flip = Prim('x', None, (t[1],), (0,))
+    return same + [flip, Prim('grad', None, (t[0], 0), c, row0 + 2), Prim('grad', None, (t[0], 0), c + (t[1],), row0 + 3),
+                   Prim('x', None, (t[1],), (0,))], 4
+
+
+def assemble_grad_sums(g: torch.Tensor, row0: int, kind: str, ntargets: int) -> torch.Tensor:
+    """``g``: (.., rows, 2, 2) complex sums of the records of `grad_records` -> the gate's (.., D, D) sum
+    lambda (x) conj(psi) (matrix index = 2 * bit(t1) + bit(t2))."""
+    if ntargets == 1:
+        return g[..., row0, :, :]
+    both, one = g[..., row0, :, :], g[..., row0 + 1, :, :]            # blocks a2 = b2: their sum, and a2 = b2 = 1
+    out = g.new_zeros(g.shape[:-3] + (4, 4))
+    out[..., 0::2, 0::2] = both - one
+    out[..., 1::2, 1::2] = one
+    if kind != 'diag':
+        cross, up = g[..., row0 + 2, :, :], g[..., row0 + 3, :, :]    # a2 != b2: their sum, and a2 = 0, b2 = 1
+        out[..., 0::2, 1::2] = up
+        out[..., 1::2, 0::2] = cross - up
+    return out
+
+
 class _AdjointCircuit(torch.autograd.Function):
     """y = U_K ... U_1 x for reversible gates as ONE autograd node.  Forward: the fused passes.  Backward: a
     reverse sweep over two states stacked as one batch -- psi_j recomputed with the exact inverses, the
@@ -649,8 +693,7 @@ class _AdjointCircuit(torch.autograd.Function):
         # the sweep as fused passes: every gate one the pass kernel takes (at most two targets), the (psi, lambda) pair at
         # least a tile, every trainable gate on one target
         fusable = all(len(targets) <= 2 for _k, targets, _c, _m, _e in meta)
-        fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and fusable and b <= backend.MAX_BATCH and n + 1 >= g_.m
-                 and all(len(meta[j][1]) == 1 for j in range(len(mats)) if need[j]))
+        fused = CONFIG['fused_sweep'] and CONFIG['fuse'] and fusable and b <= backend.MAX_BATCH and n + 1 >= g_.m
         if fused:
             # complex128: a matrix that is not computed from parameters or data may be unitary only to float32 rounding
             # (the reference's fixed matrices are, after .to(torch.double)): the sweep then tells U^-1 from U^dagger
@@ -741,7 +784,8 @@ class _AdjointCircuit(torch.autograd.Function):
         on both halves, and lambda -- the half with bit 0 set -- is multiplied by U^dagger U afterwards (``corr``, a
         gate controlled by bit 0): U^dagger lambda exactly, psi never drifts."""
         work = torch.stack([out, gy.to(out.dtype)], dim=-1).reshape(b, -1)        # bit 0: psi | lambda
-        rows: dict[int, int] = {}
+        rows: dict[int, int] = {}         # gate -> first accumulator row of its reduction records
+        nrows = 0
         prims: list[Prim] = []
         scalars: dict[int, int] = {}      # prim index -> gate, for the gates whose U^dagger U is a scalar != 1
         grad_at: dict[int, int] = {}      # prim index of a reduction -> its row
@@ -749,14 +793,16 @@ class _AdjointCircuit(torch.autograd.Function):
             kind, targets, controls, mode, _exact = meta[j]
             t1, c1 = tuple(t + 1 for t in targets), tuple(c + 1 for c in controls)
             if need[j]:
-                rows[j] = len(rows)
-                grad_at[len(prims)] = rows[j]
-                # which sums this gate's gradient can need (DQ_FG_GRAD variants, include/dq_hip.h): a matrix the gate class
-                # promises to be real / of the form a I + i b X / diagonal has no gradient component in the others
-                variant = 3 if kind == 'diag' else (mode if kind == 'gen' and mode in (1, 2) else 0)
-                if not CONFIG['reduced_grad_sums']:
-                    variant = 0
-                prims.append(Prim('grad', None, (t1[0], 0), c1, rows[j] | (variant << fusion.GRAD_VARIANT_SHIFT)))
+                # (which sums this gate's gradient can need -- DQ_FG_GRAD variants, include/dq_hip.h: a matrix the gate
+                # class promises to be real / of the form a I + i b X / diagonal has no gradient component in the
+                # others; a gate on two targets takes four one-target records, `grad_records`)
+                rows[j] = nrows
+                recs, cnt = grad_records(kind, mode, t1, c1, nrows)
+                for q in recs:
+                    if q.kind == 'grad':
+                        grad_at[len(prims)] = q.mode & fusion.GRAD_ROW_MASK
+                    prims.append(q)
+                nrows += cnt
             if (inexact is not None and inexact[j] and kind == 'gen' and mode == 3 and not controls and shared[j]
                     and len(targets) == 1):
                 # Hadamard-like, s [[1, 1], [1, -1]] with 2 s^2 = 1 only to float32 rounding: U^dagger U = 2 s^2 exactly,
@@ -773,7 +819,7 @@ class _AdjointCircuit(torch.autograd.Function):
                 prims.append(Prim(kind, corr[j][0:1] if shared[j] else corr[j].expand(b, -1, -1), t1, c1 + (0,), 0))
                 continue
             prims.append(Prim(kind, undo[j][b : b + 1] if shared[j] else undo[j][b:], t1, c1, mode))
-        acc = torch.zeros(b, max(len(rows), 1), 8, dtype=torch.float64, device=out.device)
+        acc = torch.zeros(b, max(nrows, 1), 8, dtype=torch.float64, device=out.device)
         scratch = None                    # the partner buffer of the permuted stores, when it fits what is free now
         if work.is_cuda:
             free, _total = torch.cuda.mem_get_info(work.device)
@@ -781,7 +827,7 @@ class _AdjointCircuit(torch.autograd.Function):
             if 1.05 * work.numel() * work.element_size() <= free:
                 scratch = torch.empty_like(work)
         work = _run_nograd(work, prims, inplace=True, scratch=scratch, grads=acc)
-        LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=len(rows), with_graph=False)
+        LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=nrows, with_graph=False)
         g = torch.view_as_complex(acc.reshape(b, -1, 4, 2)).reshape(b, -1, 2, 2)
         if scalars and rows:
             # row r was reduced from a psi that is  prod 2 s_k^2  (over the scalar gates executed before it) too large
@@ -794,7 +840,7 @@ class _AdjointCircuit(torch.autograd.Function):
                     for oi in (st.ops if isinstance(st, fusion.FusedStep) else [st.op]):
                         rank[oi] = len(rank)
                 sc = sorted(scalars)
-                bmat = torch.zeros(max(len(rows), 1), len(sc), dtype=torch.float64)
+                bmat = torch.zeros(max(nrows, 1), len(sc), dtype=torch.float64)
                 for pi, r in grad_at.items():
                     for k, si in enumerate(sc):
                         if rank[si] < rank[pi]:
@@ -806,5 +852,5 @@ class _AdjointCircuit(torch.autograd.Function):
             s00 = torch.stack([undo[scalars[si]][b, 0, 0] for si in sorted(scalars)])      # s of every scalar gate
             logc = torch.log(2.0 * (s00.real * s00.real + s00.imag * s00.imag))
             g = g / torch.exp(before @ logc)[None, :, None, None]
-        raw = {j: g[:, r] for j, r in rows.items()}
+        raw = {j: assemble_grad_sums(g, r, meta[j][0], len(meta[j][1])) for j, r in rows.items()}
         return raw, lambda: work.reshape(b, -1, 2)[:, :, 1].contiguous()

@@ -252,8 +252,8 @@ def check_adjoint_grad_mode(dq, device=None, dtype=torch.float64, n=6, tol=1e-10
 
 
 def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5, dtype=torch.float32):
-    """complex64 circuits whose trainable gates all have one target run their reverse sweep as fused passes over psi
-    and the cotangent interleaved along an extra index bit, the reductions folded into the passes (DQ_FG_GRAD):
+    """Circuits whose trainable gates have one or two targets run their reverse sweep as fused passes over psi and the
+    cotangent interleaved along an extra index bit, the reductions folded into the passes (DQ_FG_GRAD):
     against per-gate autograd and against the undo-then-reduce sweep, with controlled / diagonal / general trainable
     gates, fixed gates of every kind, batched encoded data and an initial state that requires grad."""
     def build():
@@ -274,8 +274,12 @@ def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5, dtype=torch.floa
         cir.rxlayer()
         cir.s(2)
         cir.t(4)
-        if dtype == torch.float32:            # (a two-target gate: complex128 sweeps are fused on the wave-tile kernel only)
-            cir.swap([1, n - 1])
+        cir.swap([1, n - 1])
+        cir.rxx([2, n - 2])                   # trainable gates on TWO targets: four one-target reduction records each
+        cir.ryy([0, 5], controls=[n - 1])
+        cir.rzz([3, 4])                       # ... diagonal: two records
+        cir.rxy([1, 6])
+        cir.rxx([4, n - 3], encode=True)      # ... with one angle per sample
         cir.cry(n - 1, 0)
         cir.hlayer()
         cir.rylayer(encode=True)
@@ -404,8 +408,7 @@ def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, 
         for _ in range(ngates):
             menu = ['h', 'x', 'y', 'z', 's', 't', 'rx', 'ry', 'rz', 'p', 'u3', 'cnot', 'cz', 'crx', 'cry', 'crz',
                     'toffoli', 'rzz_enc', 'rx_enc', 'ry_ctrl', 'u3_ctrl2', 'cp']
-            if dtype == torch.float32:       # (two-target dense gates: complex128 sweeps are fused on the wave-tile kernel only)
-                menu += ['swap', 'rxx_enc', 'fredkin']
+            menu += ['swap', 'rxx_enc', 'fredkin', 'rxx_train', 'ryy_train_ctrl', 'rzz_train']
             kind = rng.choice(menu)
             w = rng.sample(range(n), 3)
             if kind in ('h', 'x', 'y', 'z', 's', 't'):
@@ -420,6 +423,12 @@ def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, 
                 cir.fredkin(w[0], w[1], w[2])
             elif kind == 'swap':
                 cir.swap([w[0], w[1]])
+            elif kind == 'rxx_train':
+                cir.rxx([w[0], w[1]])
+            elif kind == 'ryy_train_ctrl':
+                cir.ryy([w[0], w[1]], controls=[w[2]])
+            elif kind == 'rzz_train':
+                cir.rzz([w[0], w[1]])
             elif kind == 'rxx_enc':
                 cir.rxx([w[0], w[1]], inputs=rng.uniform(0.0, 6.0))       # fixed angle: two-target gates stay untrainable
             elif kind == 'rzz_enc':

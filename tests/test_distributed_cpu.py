@@ -178,7 +178,7 @@ def _case_expectation_grad_w4(dq, rank, world):
 def _fused_sweep_case(dq, rank, world, n, double, device=None):
     """The reverse sweep of the sharded adjoint as fused passes on the (psi, lambda) pair (adjoint._sweep_fused_sharded):
     trainable / encoded one-target gates on local and on global qubits, with local and global controls, fixed gates of
-    every kind in between (two-target ones too in complex64); against the dense circuit's autograd and against the
+    every kind in between, trainable gates on two targets; against the dense circuit's autograd and against the
     gate-by-gate sweep of the reference (adjoint.py:42-83)."""
     from deepquantum_amd import adjoint, executor
 
@@ -194,8 +194,13 @@ def _fused_sweep_case(dq, rank, world, n, double, device=None):
         cir.crx(n - 2, 0, encode=True)             # global target, local control
         cir.u3(1, controls=[0, n - 1])             # trainable, general, a global and a local control
         cir.toffoli(0, 1, n - 3)
-        if not double:
-            cir.swap([0, n - 2])                   # (fixed two-target gate: complex64 only)
+        cir.swap([0, n - 2])                       # fixed two-target gate
+        # trainable / encoded gates on TWO targets, as in the reference's own distributed test circuit
+        # (tests/test_circuit.py:87-139: rxx / ryy / rzz / rxy with controls): four one-target reduction records each
+        cir.rxx([0, 1], controls=[2, n - 1], encode=True)      # global targets, a global and a local control
+        cir.ryy([1, n - 2])                                     # trainable; a global and a local target
+        cir.rzz([n - 3, n - 1])                                 # trainable, diagonal: two records
+        cir.rxy([n - 1, 0], controls=[1], encode=True)
         cir.p(2)
         cir.cnot_ring(reverse=True)
         cir.rxlayer()

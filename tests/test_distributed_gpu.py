@@ -86,6 +86,46 @@ def _case_random_c64(dq, rank, world):
     D.CONFIG['mode'] = 'remap'
 
 
+def _case_virtual_bits(dq, rank, world):
+    """CONFIG['virtual_bits'] with the real kernels: an un-batched shard as 2^v rows (rows = ranks of a virtual world:
+    real exchanges per row on the group streams, virtual trades as re-labellings folded into whole-shard passes) gives
+    the shards and expectation values of v = 0, in both precisions, with and without the lazy layout."""
+    import specs
+    from deepquantum_amd import distributed as D
+
+    g = world.bit_length() - 1
+    for n, double in ((20, False), (19, True)):
+        spec = specs.random_spec(n, 10, 31) + [('rz', [g, 0.4], {}), ('cnot', [g, n - 1], {}), ('cnot', [n - 2, g + 1], {}),
+                                                ('rzz', [[0, g + 1], 0.7], {}), ('toffoli', [0, g, n - 3], {}),
+                                                ('rxx', [[g, n - 1], 0.5], {})] + specs.random_spec(n, 4, 5)
+        dense = _build(dq, dq.QubitCircuit, n, spec)
+        if double:
+            dense.to(torch.double)
+        per = 2**n // world
+        with torch.no_grad():
+            ref = dense().reshape(-1)
+            ref_ev = dense.expectation()
+        tol = 1e-10 if double else 2e-5
+        try:
+            for vb in (1, 2, 0):
+                D.CONFIG['virtual_bits'] = vb
+                for lazy in (True, False):
+                    shard = _build(dq, dq.DistributedQubitCircuit, n, spec)
+                    shard.lazy_layout = lazy
+                    if double:
+                        shard.to(torch.double)
+                    with torch.no_grad():
+                        st = shard()
+                        stats = dict(D.LAST_RUN)
+                        ev = shard.expectation()
+                        err = (st.amps - ref[rank * per:(rank + 1) * per]).abs().max().item()
+                    assert (ev - ref_ev).abs().max().item() < tol, (vb, lazy, ev, ref_ev)
+                    assert err < tol, f'rank {rank}: virtual_bits {vb} lazy {lazy} double {double}: {err}'
+                    assert stats['virtual_bits'] == vb and (vb == 0 or stats['virtual_remaps'] > 0), stats
+        finally:
+            D.CONFIG['virtual_bits'] = 0
+
+
 def _case_batched_c128(dq, rank, world):
     """Batched shards with per-sample matrices, double precision, golden-style tolerance 1e-10."""
     import specs
@@ -334,6 +374,6 @@ def test_reference_dist_tests_on_gpu_world_of_one():
 
 @pytest.mark.parametrize('case,world', [('golden', 2), ('golden', 4), ('golden', 8), ('random_c64', 2), ('random_c64', 4), ('batched_c128', 4), ('adjoint_grad', 2),
                                         ('measure', 2), ('measure', 4), ('folded_permute', 2), ('folded_permute', 4),
-                                        ('fused_sweep', 2), ('fused_sweep', 4)])
+                                        ('fused_sweep', 2), ('fused_sweep', 4), ('virtual_bits', 2), ('virtual_bits', 4)])
 def test_sharded_on_gpu(case, world):
     _run(case, world)
