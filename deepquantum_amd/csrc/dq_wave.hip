@@ -46,7 +46,7 @@ struct WaveC64 {
     static constexpr unsigned LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID_GEN_U, ID_GEN_C = DQ_WID_GEN_C, ID_GEN_R = DQ_WID_GEN_R, ID_X_U = DQ_WID_X_U,
                          ID_X_C = DQ_WID_X_C, ID_X_R = DQ_WID_X_R, ID_X_R1 = DQ_WID_X_R1, ID_TRIP0 = DQ_WID_TRIP0,
-                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2, ID_GRAD = DQ_WID_GRAD, ID_EXPZ = DQ_WID_EXPZ, ID_GEN2 = DQ_WID_GEN2, ID_SWAP = DQ_WID_SWAP;
+                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2, ID_GRAD = DQ_WID_GRAD, ID_EXPZ = DQ_WID_EXPZ, ID_GEN2 = DQ_WID_GEN2, ID_GEN2R = DQ_WID_GEN2R, ID_SWAP = DQ_WID_SWAP;
     static int trip_id(unsigned mask) { return kWaveTripId[mask]; }
     static int swap_id(int i, int j) { return kWaveSwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -57,11 +57,11 @@ struct WaveC64 {
 struct WaveC128 {
     using real = double;
     using acc_t = double;
-    static constexpr int M = 11, R = 5, NA = 32, VB = 0, MAXK = DQ_WAVE64_MAXK, ELEM = 16, GRAD_VARIANTS = 1;
+    static constexpr int M = 11, R = 5, NA = 32, VB = 0, MAXK = DQ_WAVE64_MAXK, ELEM = 16, GRAD_VARIANTS = DQ_WAVE64_GRAD_VARIANTS;
     static constexpr unsigned LDS_PER_WAVE = 8704;      // (7 * 68 + 64) * 16 bytes: the k = 3 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID64_GEN_U, ID_GEN_C = DQ_WID64_GEN_C, ID_GEN_R = DQ_WID64_GEN_R, ID_X_U = DQ_WID64_X_U,
                          ID_X_C = DQ_WID64_X_C, ID_X_R = DQ_WID64_X_R, ID_X_R1 = DQ_WID64_X_R1, ID_TRIP0 = DQ_WID64_TRIP0,
-                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD, ID_EXPZ = DQ_WID64_EXPZ, ID_GEN2 = DQ_WID64_GEN2, ID_SWAP = DQ_WID64_SWAP;      // (two-target dense gates: the 64 dwords of matrix pass through the scalar registers two rows at a time)
+                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD, ID_EXPZ = DQ_WID64_EXPZ, ID_GEN2 = DQ_WID64_GEN2, ID_GEN2R = DQ_WID64_GEN2R, ID_SWAP = DQ_WID64_SWAP;      // (two-target dense gates: the 64 dwords of matrix pass through the scalar registers two rows at a time)
     static int trip_id(unsigned mask) { return kWave64TripId[mask]; }
     static int swap_id(int i, int j) { return kWave64SwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -387,7 +387,9 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
                 for (int s = 0; s < W::R; ++s)
                     if ((g.reg_cmask >> s) & 1u) pc |= 1u << x.slot_of(rd.rb[s]);
                 WaveRec rec{};
-                rec.w[0] = (uint32_t)(W::ID_GEN2 + (W::swap_id(a, b) - W::ID_SWAP));
+                // (loc = DQ_MODE_REAL: a matrix promised real -- channel superoperators -- takes the bodies that spend one
+                // operation per entry instead of two)
+                rec.w[0] = (uint32_t)((g.loc == DQ_MODE_REAL && W::ID_GEN2R >= 0 ? W::ID_GEN2R : W::ID_GEN2) + (W::swap_id(a, b) - W::ID_SWAP));
                 rec.w[1] = g.thr_cmask;
                 rec.w[2] = (uint32_t)g.out_cmask, rec.w[3] = (uint32_t)(g.out_cmask >> 32);
                 rec.w[4] = g.mat_advance;

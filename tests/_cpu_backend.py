@@ -178,11 +178,11 @@ class CpuTestBackend:
                         comp = np.array([G[0, 0].real, G[0, 0].imag, G[0, 1].real, G[0, 1].imag,
                                          G[1, 0].real, G[1, 0].imag, G[1, 1].real, G[1, 1].imag])
                         assert g.loc in (0, 1, 2, 3)
-                        if g.loc == 1 and not is128:
+                        if g.loc == 1:
                             comp[1::2] = 0.0
-                        elif g.loc == 2 and not is128:
+                        elif g.loc == 2:
                             comp = np.array([(G[0, 0] + G[1, 1]).real, 0, 0, (G[0, 1] + G[1, 0]).imag, 0, 0, 0, 0])
-                        elif g.loc == 3 and not is128:
+                        elif g.loc == 3:
                             comp[2:6] = 0.0
                         grads[b, g.reserved] += torch.from_numpy(comp)
                         continue

@@ -215,11 +215,15 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None):
                     continue
                 if not tile_ok:
                     continue
-                if getattr(g, 'ID_GEN2', 1 << 30) <= hid < getattr(g, 'ID_GEN2', 1 << 30) + len(g.SWAP_PAIRS):
+                if getattr(g, 'ID_GEN2', 1 << 30) <= hid < getattr(g, 'ID_GEN2', 1 << 30) + len(g.SWAP_PAIRS) * (2 if hasattr(g, 'ID_GEN2R') else 1):
                     # dense gate on two slots a < b (gen2_code): matrix index = 2 * bit(b) + bit(a), w6 = swap the two
-                    # index bits of the matrix first, w5 = group mask
-                    a_, b_ = g.SWAP_PAIRS[hid - g.ID_GEN2]
+                    # index bits of the matrix first, w5 = group mask; the second range of ids: the bodies for a matrix
+                    # promised real (gen2_body_real: the imaginary parts are never read)
+                    real_body, pair = divmod(hid - g.ID_GEN2, len(g.SWAP_PAIRS))
+                    a_, b_ = g.SWAP_PAIRS[pair]
                     m4 = mb[moff - 16:moff].reshape(4, 4)
+                    if real_body:
+                        m4 = m4.real.astype(m4.dtype)
                     if w[6]:
                         perm = [0, 2, 1, 3]
                         m4 = m4[perm][:, perm]

@@ -206,7 +206,10 @@ GRAD_VARIANTS = 4
 ID_EXPZ = ID_GRAD + 5 * GRAD_VARIANTS
 # dense gate on two register slots a < b (index in SWAP_PAIRS): a 4x4 matrix, index = 2 * (bit of slot b) + (bit of slot a)
 ID_GEN2 = ID_EXPZ + 1
-NIDS = ID_GEN2 + 15
+# ... + 15: the same for a matrix the gate class promises to be REAL (DqFusedGate::loc = 1: the superoperators of noise
+# channels): one packed operation per entry instead of two
+ID_GEN2R = ID_GEN2 + 15
+NIDS = ID_GEN2R + 15
 ACC_BASE = 4 * 8448       # LDS offset of the reduction accumulators: behind the four waves' staging buffers
 
 
@@ -460,6 +463,25 @@ def gen2_body(a, b):
     return out_
 
 
+def gen2_body_real(a, b):
+    """`gen2_body` for a real matrix: out[r] = sum_c M[r][c].re in[c], one packed operation per entry (20 per group instead
+    of 36).  No tests for exact zeros: a taken branch per zero entry and group costs more than the multiplication it
+    saves (measured: the superoperator of a depolarizing channel, six non-zero entries of sixteen, ran no faster with
+    them than the general body)."""
+    out_ = []
+    T = [T0, U0, T1, U1]
+    for i, j in enumerate(gen2_groups(a, b)):
+        rg = [A(j | (((r >> 1) & 1) << b) | ((r & 1) << a)) for r in range(4)]
+        m = lambda r, c: f's[{G2ROW[r] + 2 * c}:{G2ROW[r] + 2 * c + 1}]'      # noqa: E731
+        out_ += [f's_bitcmp1_b32 {STMP}, {i}', f's_cbranch_scc0 .Lg2r{a}{b}_{i}_%=']
+        out_ += [f'v_pk_mul_f32 {T[r]}, {rg[0]}, {m(r, 0)} {RE2}' for r in range(4)]
+        for c in range(1, 4):
+            out_ += [f'v_pk_fma_f32 {T[r]}, {rg[c]}, {m(r, c)}, {T[r]} {RE3}' for r in range(4)]
+        out_ += [f'v_mov_b64 {rg[r]}, {T[r]}' for r in range(4)]
+        out_.append(f'.Lg2r{a}{b}_{i}_%=:')
+    return out_
+
+
 def gen2_code():
     """Entry of every two-target dense record: controls; group mask -> STMP, first-target-on-the-lower-slot flag -> s70,
     pair number -> s71; rows 1 .. 3 of the 4x4 matrix (the look-ahead fetched row 0 as "the matrix") into s[40:47],
@@ -484,9 +506,9 @@ def gen2_code():
           's_add_u32 vcc_lo, vcc_lo, .Lg2table_%=-.Lg2anchor_%=', 's_addc_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc', '.Lg2table_%=:']
     # eight bytes per entry: s_getpc + 64-bit add + s_setpc would not fit four; a long jump is s_getpc_b64 / s_add / s_setpc:
     # instead every entry is an s_branch to a trampoline that sits right behind the table, within reach of nothing but it
-    for v in range(15):
+    for v in range(30):
         t += [f's_branch .Lg2t{v}_%=', 's_nop 0']
-    for v, (a, b) in enumerate(SWAP_PAIRS):
+    for v in range(30):
         t += [f'.Lg2t{v}_%=:', 's_getpc_b64 vcc', f'.Lg2ta{v}_%=:', f's_sub_u32 vcc_lo, vcc_lo, .Lg2ta{v}_%=-.Lg2b{v}_%=',
               's_subb_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc']          # (the bodies lie in front of everything)
     return t
@@ -497,6 +519,9 @@ def gen2_bodies():
     for v, (a, b) in enumerate(SWAP_PAIRS):
         t += [f'.Lg2b{v}_%=:'] + gen2_body(a, b) + [f's_mov_b64 exec, {SAVE}']
         t += prefetch(f'g2{v}') + far_next()
+    for v, (a, b) in enumerate(SWAP_PAIRS):
+        t += [f'.Lg2b{15 + v}_%=:'] + gen2_body_real(a, b) + [f's_mov_b64 exec, {SAVE}']
+        t += prefetch(f'g2r{v}') + far_next()
     return t
 
 
@@ -568,7 +593,8 @@ def kernel_body():
 
     # the bodies of the two-target dense gates first (74 KB, jumped over; reached and left by computed jumps): behind
     # everything else they would push the last labels out of the reach of the store walks' s_branch
-    text = ['s_branch .Lstart_%='] + gen2_bodies() + ['.Lstart_%=:']
+    text = ['s_getpc_b64 vcc', '.Ljs_%=:', 's_add_u32 vcc_lo, vcc_lo, .Lstart_%=-.Ljs_%=', 's_addc_u32 vcc_hi, vcc_hi, 0',
+            's_setpc_b64 vcc'] + gen2_bodies() + ['.Lstart_%=:']      # (a computed jump: the bodies exceed the reach of s_branch)
     text += [f's_mov_b64 {KG}, %[kg]', f's_mov_b32 {GOFF}, 0', f's_mov_b32 {GEND}, %[gend]', f's_mov_b64 {MB}, %[mb]',
             f's_mov_b32 {MOFF}, %[moff]', f's_mov_b64 {TG}, %[tg]', f's_mov_b32 {LDSB}, %[ldsb]',
             # slot offsets of the load layout; byte shifts of the lane bits (load, store) and what they add to the
@@ -637,7 +663,7 @@ out = ['// GENERATED by tools/gen_wave_asm.py -- do not edit by hand.', '// clan
        f'#define DQ_WID_GEN_U {ID_GEN_U}', f'#define DQ_WID_GEN_C {ID_GEN_C}', f'#define DQ_WID_GEN_R {ID_GEN_R}',
        f'#define DQ_WID_X_U {ID_X_U}', f'#define DQ_WID_X_C {ID_X_C}', f'#define DQ_WID_X_R {ID_X_R}', f'#define DQ_WID_X_R1 {ID_X_R1}',
        f'#define DQ_WID_TRIP0 {ID_TRIP0}', f'#define DQ_WID_TRIP {ID_TRIP}', f'#define DQ_WID_SWAP {ID_SWAP}',
-       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WAVE_GRAD_VARIANTS {GRAD_VARIANTS}', f'#define DQ_WID_EXPZ {ID_EXPZ}', f'#define DQ_WID_GEN2 {ID_GEN2}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
+       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WAVE_GRAD_VARIANTS {GRAD_VARIANTS}', f'#define DQ_WID_EXPZ {ID_EXPZ}', f'#define DQ_WID_GEN2 {ID_GEN2}', f'#define DQ_WID_GEN2R {ID_GEN2R}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
        '// trip handler id by slot mask (popcount 1..DQ_WAVE_MAXK), -1 otherwise; slot-swap handler id by (i < j)',
        'static const short kWaveTripId[64] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(64)) + '};',
        'static const short kWaveSwapId[6][6] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',

@@ -148,11 +148,13 @@ ID_SWAP = ID_TRIP + len(TRIP_MASKS)
 ID_DIAG1 = ID_SWAP + len(SWAP_PAIRS)
 ID_DIAG2 = ID_DIAG1 + NV
 # reduction of the adjoint method's reverse sweep: target on slot 1 + (id - ID_GRAD), psi / lambda told apart by slot 0
-ID_GRAD = ID_DIAG2 + NV
-ID_EXPZ = ID_GRAD + R - 1      # expectation value of a Z string (DQ_FG_EXPZ)
+ID_GRAD = ID_DIAG2 + NV        # + (R - 1) * variant + (slot - 1); variants as in the complex64 generator
+GRAD_VARIANTS = 4
+ID_EXPZ = ID_GRAD + (R - 1) * GRAD_VARIANTS      # expectation value of a Z string (DQ_FG_EXPZ)
 # dense gate on two register slots a < b (index in SWAP_PAIRS): a 4x4 matrix, index = 2 * (bit of slot b) + (bit of slot a)
 ID_GEN2 = ID_EXPZ + 1
-NIDS = ID_GEN2 + len(SWAP_PAIRS)
+ID_GEN2R = ID_GEN2 + len(SWAP_PAIRS)      # ... for a matrix promised real (channel superoperators): half the operations
+NIDS = ID_GEN2R + len(SWAP_PAIRS)
 ACC_BASE = 4 * 8704       # LDS offset of the reduction accumulators (8 doubles per record): behind the staging buffers
 
 
@@ -176,7 +178,8 @@ def handlers():
     for i, (a_, b_) in enumerate(SWAP_PAIRS):
         h[ID_SWAP + i] = (False, slotswap(a_, b_))
     for q in range(1, R):
-        h[ID_GRAD + q - 1] = (False, grad_code(q))
+        for v in range(GRAD_VARIANTS):
+            h[ID_GRAD + (R - 1) * v + q - 1] = (False, grad_code(q, v))
     h[ID_EXPZ] = (False, expz_code())
     return h
 
@@ -222,8 +225,9 @@ def g2_load_rows(off_first, off_second):
 g2_load_rows.n = 0
 
 
-def g2_two_rows(regs, outs):
-    """outs[0] (re, im pairs) = first resident row x inputs, outs[1] = second: four independent chains of eight."""
+def g2_two_rows(regs, outs, real=False):
+    """outs[0] (re, im pairs) = first resident row x inputs, outs[1] = second: four independent chains of eight (of four
+    for a matrix promised real: its imaginary parts are never read)."""
     def m(base, c, part):
         return f's[{base[c] + (0 if part == "r" else 2)}:{base[c] + (1 if part == "r" else 3)}]'
     t = []
@@ -236,13 +240,16 @@ def g2_two_rows(regs, outs):
             else:
                 t += [f'v_fma_f64 {o_re}, {m(base, c, "r")}, {x_re}, {o_re}', f'v_fma_f64 {o_im}, {m(base, c, "r")}, {x_im}, {o_im}']
         for row, base in enumerate((G2A, G2B)):
+            if real:
+                continue
             o_re, o_im = outs[row]
             t += [f'v_fma_f64 {o_re}, -{m(base, c, "i")}, {x_im}, {o_re}', f'v_fma_f64 {o_im}, {m(base, c, "i")}, {x_re}, {o_im}']
     return t
 
 
-def gen2_body(a, b):
+def gen2_body(a, b, real=False):
     groups = gen2_groups(a, b)
+    tag = 'r' if real else ''
     outs = [('v[10:11]', 'v[12:13]'), ('v[14:15]', 'v[16:17]')]
     t = []
     for batch in (0, 1):
@@ -250,19 +257,19 @@ def gen2_body(a, b):
         t += g2_load_rows(0, G2OFFA)
         for gl, (i, j) in enumerate(mine):
             regs = [j | (((r >> 1) & 1) << b) | ((r & 1) << a) for r in range(4)]
-            t += [f's_bitcmp1_b32 {G2MASK}, {i}', f's_cbranch_scc0 .Lg2a{a}{b}_{i}_%=']
-            t += g2_two_rows(regs, outs)
+            t += [f's_bitcmp1_b32 {G2MASK}, {i}', f's_cbranch_scc0 .Lg2a{tag}{a}{b}_{i}_%=']
+            t += g2_two_rows(regs, outs, real)
             t += [f'ds_write_b128 {G2PARK}, v[10:13] offset:{1024 * (2 * gl)}', f'ds_write_b128 {G2PARK}, v[14:17] offset:{1024 * (2 * gl + 1)}']
-            t.append(f'.Lg2a{a}{b}_{i}_%=:')
+            t.append(f'.Lg2a{tag}{a}{b}_{i}_%=:')
         t += g2_load_rows(G2OFFB, 192)
         for gl, (i, j) in enumerate(mine):
             regs = [j | (((r >> 1) & 1) << b) | ((r & 1) << a) for r in range(4)]
-            t += [f's_bitcmp1_b32 {G2MASK}, {i}', f's_cbranch_scc0 .Lg2b{a}{b}_{i}_%=']
-            t += g2_two_rows(regs, outs)
+            t += [f's_bitcmp1_b32 {G2MASK}, {i}', f's_cbranch_scc0 .Lg2bb{tag}{a}{b}_{i}_%=']
+            t += g2_two_rows(regs, outs, real)
             t += [f'v_mov_b64 {RE(regs[2])}, v[10:11]', f'v_mov_b64 {IM(regs[2])}, v[12:13]',
                   f'v_mov_b64 {RE(regs[3])}, v[14:15]', f'v_mov_b64 {IM(regs[3])}, v[16:17]',
                   f'ds_read_b128 {A(regs[0])}, {G2PARK} offset:{1024 * (2 * gl)}', f'ds_read_b128 {A(regs[1])}, {G2PARK} offset:{1024 * (2 * gl + 1)}']
-            t.append(f'.Lg2b{a}{b}_{i}_%=:')
+            t.append(f'.Lg2bb{tag}{a}{b}_{i}_%=:')
         t.append('s_waitcnt lgkmcnt(0)')
     return t
 
@@ -282,9 +289,9 @@ def gen2_code():
          f'v_lshl_add_u32 {G2PARK}, {LANE}, 4, {LDSB}',
          's_getpc_b64 vcc', '.Lg2anchor_%=:', f's_lshl3_add_u32 vcc_lo, {G2PAIR}, vcc_lo', 's_addc_u32 vcc_hi, vcc_hi, 0',
          's_add_u32 vcc_lo, vcc_lo, .Lg2table_%=-.Lg2anchor_%=', 's_addc_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc', '.Lg2table_%=:']
-    for v in range(len(SWAP_PAIRS)):
+    for v in range(2 * len(SWAP_PAIRS)):
         t += [f's_branch .Lg2t{v}_%=', 's_nop 0']
-    for v in range(len(SWAP_PAIRS)):
+    for v in range(2 * len(SWAP_PAIRS)):
         t += [f'.Lg2t{v}_%=:', 's_getpc_b64 vcc', f'.Lg2ta{v}_%=:', f's_sub_u32 vcc_lo, vcc_lo, .Lg2ta{v}_%=-.Lg2b{v}_%=',
               's_subb_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc']
     return t
@@ -294,6 +301,8 @@ def gen2_bodies():
     t = []
     for v, (a, b) in enumerate(SWAP_PAIRS):
         t += [f'.Lg2b{v}_%=:'] + gen2_body(a, b) + [f's_mov_b64 exec, {SAVE}'] + far_next()
+    for v, (a, b) in enumerate(SWAP_PAIRS):
+        t += [f'.Lg2b{len(SWAP_PAIRS) + v}_%=:'] + gen2_body(a, b, real=True) + [f's_mov_b64 exec, {SAVE}'] + far_next()
     return t
 
 
@@ -301,8 +310,13 @@ def grad_groups(q):
     return [j for j in range(NA) if not (j >> q) & 1 and not j & 1]
 
 
-def grad_code(q):
-    """DQ_FG_GRAD with the target on slot q, psi (0) / lambda (1) on slot 0: G[a][b] = sum lambda[target = a] conj(psi[target
+def grad_code(q, variant=0):
+    """(variant 1 / 2 / 3 -- DqFusedGate::loc of the record: the trainable gate's matrix is real / of the form a I + i b X
+    / diagonal -- forms only the sums such a gate's gradient can need: Re G; Re (G00 + G11) in the place of Re G00 and
+    Im (G01 + G10) in the place of Im G01; G00 and G11.  Eight operations per register group instead of sixteen; the
+    other accumulators stay zero and take the same way through the reduction.)
+
+    DQ_FG_GRAD with the target on slot q, psi (0) / lambda (1) on slot 0: G[a][b] = sum lambda[target = a] conj(psi[target
     = b]) over the thread's register groups (w5 = mask of the groups whose register controls are set; lanes that fail the
     thread controls contribute nothing), eight float64 sums per lane: (G00, G01, G10, G11) x (re, im).  Across the lanes
     they go through the wave's staging buffer: every lane writes its eight sums (72-byte rows), lane L then adds sum
@@ -312,18 +326,38 @@ def grad_code(q):
     t = [f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc0 .Lnext_%=']
     t += [f'v_mov_b32 v{r}, 0' for r in list(range(10, 18)) + list(range(32, 40))]
     t += [f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
-          f's_cbranch_execz .Lgz{q}_%=']
+          f's_cbranch_execz .Lgz{q}v{variant}_%=']
+    tag = f'{q}v{variant}'
     for i, j in enumerate(grad_groups(q)):
         ps, ls = (j, j | (1 << q)), (j | 1, j | (1 << q) | 1)
-        t += [f's_bitcmp1_b32 s{REC + 5}, {i}', f's_cbranch_scc0 .Lgg{q}_{i}_%=']
+        t += [f's_bitcmp1_b32 s{REC + 5}, {i}', f's_cbranch_scc0 .Lgg{tag}_{i}_%=']
         ab = [(a_, b_) for a_ in range(2) for b_ in range(2)]
-        # term by term over the four entries: four independent chains per term
-        t += [f'v_fma_f64 {G[2 * (2 * a_ + b_)]}, {RE(ls[a_])}, {RE(ps[b_])}, {G[2 * (2 * a_ + b_)]}' for a_, b_ in ab]
-        t += [f'v_fma_f64 {G[2 * (2 * a_ + b_) + 1]}, {IM(ls[a_])}, {RE(ps[b_])}, {G[2 * (2 * a_ + b_) + 1]}' for a_, b_ in ab]
-        t += [f'v_fma_f64 {G[2 * (2 * a_ + b_)]}, {IM(ls[a_])}, {IM(ps[b_])}, {G[2 * (2 * a_ + b_)]}' for a_, b_ in ab]
-        t += [f'v_fma_f64 {G[2 * (2 * a_ + b_) + 1]}, -{RE(ls[a_])}, {IM(ps[b_])}, {G[2 * (2 * a_ + b_) + 1]}' for a_, b_ in ab]
-        t.append(f'.Lgg{q}_{i}_%=:')
-    t += [f'.Lgz{q}_%=:', f's_mov_b64 exec, {SAVE}',
+
+        def re_(c, a_, b_):          # accumulator c += Re (lambda_a conj psi_b), as two terms (interleaved by the caller)
+            return [f'v_fma_f64 {G[c]}, {RE(ls[a_])}, {RE(ps[b_])}, {G[c]}', f'v_fma_f64 {G[c]}, {IM(ls[a_])}, {IM(ps[b_])}, {G[c]}']
+
+        def im_(c, a_, b_):          # accumulator c += Im (lambda_a conj psi_b)
+            return [f'v_fma_f64 {G[c]}, {IM(ls[a_])}, {RE(ps[b_])}, {G[c]}', f'v_fma_f64 {G[c]}, -{RE(ls[a_])}, {IM(ps[b_])}, {G[c]}']
+
+        if variant == 0:
+            # term by term over the four entries: four independent chains per term
+            t += [f'v_fma_f64 {G[2 * (2 * a_ + b_)]}, {RE(ls[a_])}, {RE(ps[b_])}, {G[2 * (2 * a_ + b_)]}' for a_, b_ in ab]
+            t += [f'v_fma_f64 {G[2 * (2 * a_ + b_) + 1]}, {IM(ls[a_])}, {RE(ps[b_])}, {G[2 * (2 * a_ + b_) + 1]}' for a_, b_ in ab]
+            t += [f'v_fma_f64 {G[2 * (2 * a_ + b_)]}, {IM(ls[a_])}, {IM(ps[b_])}, {G[2 * (2 * a_ + b_)]}' for a_, b_ in ab]
+            t += [f'v_fma_f64 {G[2 * (2 * a_ + b_) + 1]}, -{RE(ls[a_])}, {IM(ps[b_])}, {G[2 * (2 * a_ + b_) + 1]}' for a_, b_ in ab]
+        else:
+            if variant == 1:
+                chains = [re_(2 * (2 * a_ + b_), a_, b_) for a_, b_ in ab]
+            elif variant == 2:       # two accumulators, each fed by two chains: (0, 0) then (1, 1); (0, 1) then (1, 0)
+                chains = [re_(0, 0, 0) + re_(0, 1, 1), im_(3, 0, 1) + im_(3, 1, 0)]
+            else:
+                chains = [re_(0, 0, 0), im_(1, 0, 0), re_(6, 1, 1), im_(7, 1, 1)]
+            k_ = 0
+            while any(k_ < len(ch) for ch in chains):
+                t += [ch[k_] for ch in chains if k_ < len(ch)]
+                k_ += 1
+        t.append(f'.Lgg{tag}_{i}_%=:')
+    t += [f'.Lgz{tag}_%=:', f's_mov_b64 exec, {SAVE}',
           f'v_mul_f64 v[6:7], {HS}, {HS}',
           f'v_mul_u32_u24 v8, 72, {LANE}', f'v_add_u32 v8, {LDSB}, v8']
     t += [f'ds_write_b64 v8, {G[c]} offset:{8 * c}' for c in range(8)]
@@ -463,7 +497,8 @@ def kernel_body():
             out_.append(f's_mov_b64 exec, {SAVE}')
         return out_ + nxt
 
-    text = ['s_branch .Lstart_%='] + gen2_bodies() + ['.Lstart_%=:']
+    text = ['s_getpc_b64 vcc', '.Ljs_%=:', 's_add_u32 vcc_lo, vcc_lo, .Lstart_%=-.Ljs_%=', 's_addc_u32 vcc_hi, vcc_hi, 0',
+            's_setpc_b64 vcc'] + gen2_bodies() + ['.Lstart_%=:']
     text += [f's_mov_b64 {KG}, %[kg]', f's_mov_b32 {GOFF}, 0', f's_mov_b32 {GEND}, %[gend]', f's_mov_b64 {MB}, %[mb]',
             f's_mov_b32 {MOFF}, %[moff]', f's_mov_b64 {TG}, %[tg]', f's_mov_b32 {LDSB}, %[ldsb]',
             's_load_dwordx8 s[40:47], %[ks], 0', 's_load_dwordx2 s[48:49], %[ks], 32',
@@ -518,7 +553,7 @@ if __name__ == '__main__' or os.environ.get('DQ_ASM_OUT'):
            f'#define DQ_WID64_GEN_U {ID_GEN_U}', f'#define DQ_WID64_GEN_C {ID_GEN_C}', f'#define DQ_WID64_GEN_R {ID_GEN_R}',
            f'#define DQ_WID64_X_U {ID_X_U}', f'#define DQ_WID64_X_C {ID_X_C}', f'#define DQ_WID64_X_R {ID_X_R}', f'#define DQ_WID64_X_R1 {ID_X_R1}',
            f'#define DQ_WID64_TRIP0 {ID_TRIP0}', f'#define DQ_WID64_TRIP {ID_TRIP}', f'#define DQ_WID64_SWAP {ID_SWAP}',
-           f'#define DQ_WID64_DIAG1 {ID_DIAG1}', f'#define DQ_WID64_DIAG2 {ID_DIAG2}', f'#define DQ_WID64_GRAD {ID_GRAD}', f'#define DQ_WID64_EXPZ {ID_EXPZ}', f'#define DQ_WID64_GEN2 {ID_GEN2}', f'#define DQ_WAVE64_ACC_BASE {ACC_BASE}',
+           f'#define DQ_WID64_DIAG1 {ID_DIAG1}', f'#define DQ_WID64_DIAG2 {ID_DIAG2}', f'#define DQ_WID64_GRAD {ID_GRAD}', f'#define DQ_WAVE64_GRAD_VARIANTS {GRAD_VARIANTS}', f'#define DQ_WID64_EXPZ {ID_EXPZ}', f'#define DQ_WID64_GEN2 {ID_GEN2}', f'#define DQ_WID64_GEN2R {ID_GEN2R}', f'#define DQ_WAVE64_ACC_BASE {ACC_BASE}',
            'static const short kWave64TripId[32] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(NA)) + '};',
            'static const short kWave64SwapId[5][5] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
            '']
