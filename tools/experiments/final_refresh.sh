@@ -1,5 +1,9 @@
+#!/bin/bash
+# the round's evidence in one gpurun call: the GPU suite, refresh_profiles.sh <tag>, smoke.  usage: bash tools/experiments/final_refresh.sh r04
+cd "$(dirname "$0")/../.."
+tag=${1:-r04}
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > gpurun_out/gpu_suite_r03.txt
-timeout 2400 bash tools/refresh_profiles.sh r03 > gpurun_out/refresh.log 2>&1
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.txt 2>&1
-tail -3 gpurun_out/gpu_suite_r03.txt; cat gpurun_out/prof/r03/bench_default.json
+timeout 3000 bash tools/refresh_profiles.sh $tag > gpurun_out/refresh.log 2>&1
+timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -5 > gpurun_out/prof/$tag/gpu_suite.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/prof/$tag/smoke.txt 2>&1
+tail -3 gpurun_out/prof/$tag/gpu_suite.txt; tail -2 gpurun_out/prof/$tag/smoke.txt; cat gpurun_out/prof/$tag/bench_default.json | cut -c1-600

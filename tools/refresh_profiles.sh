@@ -2,7 +2,7 @@
 # Everything profiles/<tag>/ holds, in one go on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
 # then copy gpurun_out/prof/<tag>/{summary.txt,kernel_stats.csv,traffic_*.json,bench_*.json,*.txt} to profiles/<tag>/.
 cd "$(dirname "$0")/.."
-tag=${1:-r02}
+tag=${1:-r04}
 root=$PWD/gpurun_out/prof/$tag
 bash tools/profile.sh "$tag" > /dev/null 2>&1
 cp "$root/traffic.json" "$root/traffic_n28_b16_c64.json" 2>/dev/null
@@ -17,6 +17,9 @@ bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
   python tools/bench_train.py --n 24 --depth 20 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 24 --depth 20 --modes adjoint --no-fused-sweep 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 28 --depth 40 --modes adjoint 2>&1 | grep -v amdgpu.ids
+  echo '# A/B: every reduction record forms all of G (DQ_REDUCED_GRAD=0)'
+  DQ_REDUCED_GRAD=0 python tools/bench_train.py --n 28 --depth 40 --modes adjoint 2>&1 | grep -v amdgpu.ids
+  DQ_REDUCED_GRAD=0 python tools/bench_train.py --n 27 --depth 40 --modes adjoint --dtype c128 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 28 --depth 40 --modes adjoint --no-fused-sweep 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 24 --depth 20 --modes adjoint --dtype c128 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 24 --depth 20 --modes adjoint --dtype c128 --no-fused-sweep 2>&1 | grep -v amdgpu.ids
@@ -26,20 +29,21 @@ bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
   python tools/bench_small.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_density.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_expect.py 2>&1 | grep -v amdgpu.ids
-  python tools/bench_config2.py 2>&1 | grep -v amdgpu.ids
-  python tools/bench_dense.py 2>&1 | grep -v amdgpu.ids
+  python tools/bench_config2.py --cpu 2>&1 | grep -v amdgpu.ids
   python tools/bench_single_gate_kernel.py 2>&1 | grep -v amdgpu.ids
   python bench.py --dtype c128 --batch 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null
   echo "# the one-GPU anchor of the strong-scaling pair (SURVEY 8d): n = 31, batch 1"
   python bench.py --strong --steps 3 --warmup 1 --no-cpu-baseline --no-sweep 2>/dev/null
 } > "$root/secondary_benchmarks.txt" 2>&1
 {
-  for a in "" "--strong" "--config 4" "--config 5" "--batch-shard"; do
-    echo "# bench_two_ranks_one_gpu.sh --nqubit 24 --depth 10 --batch 4 $a (gloo, two ranks sharing one GPU: functional check, not a performance number)"
-    bash tools/bench_two_ranks_one_gpu.sh --nqubit 24 --depth 10 --batch 4 --no-cpu-baseline --no-sweep $a 2>&1 | tail -1
+  for a in "--batch 4" "--strong" "--config 4" "--config 5" "--batch 4 --batch-shard"; do
+    echo "# bench_two_ranks_one_gpu.sh --nqubit 24 --depth 10 $a (gloo, two ranks sharing one GPU: functional check, not a performance number)"
+    bash tools/bench_two_ranks_one_gpu.sh --nqubit 24 --depth 10 --no-cpu-baseline --no-sweep $a 2>&1 | tail -1
   done
 } > "$root/two_ranks_one_gpu_functional.txt" 2>&1
 python tools/bench_dense.py 2>&1 | grep -v amdgpu.ids > "$root/bench_dense.txt"
+python tools/dump_passes.py 2>&1 | grep -v amdgpu.ids > "$root/passes_headline.txt"
+python tools/bench_gradient_reference.py --trials 3 2>&1 | grep -v "amdgpu.ids\|UserWarning\|run_backward" > "$root/bench_gradient_reference.txt"
 python tools/crosscheck_large.py 2>&1 | grep -v amdgpu.ids > "$root/crosscheck_large.txt"
 python tools/experiments/bench_shard_helpers.py 2>&1 | grep -v amdgpu.ids > "$root/shard_helpers_and_reductions.txt"
 ls -la "$root"
