@@ -778,3 +778,9 @@ def test_gradgradcheck_of_the_autograd_nodes_on_gpu():
     assert gradgradcheck(lambda a: ops.expect_z_multi(a, zs), (x,))
     assert gradcheck(lambda a, b: ops.scale_z_signs(a, zs, b), (x, w))
     assert gradgradcheck(lambda a, b: ops.scale_z_signs(a, zs, b), (x, w))
+
+
+def test_hessian_of_a_density_matrix_circuit_with_channels_on_gpu():
+    from test_hessian_cpu import check_noisy_hessian
+
+    check_noisy_hessian(dq, device=dev())

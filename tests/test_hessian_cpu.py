@@ -93,3 +93,49 @@ def test_gradgradcheck_of_the_reductions(cpu_backend):
     w = torch.randn(2, 3, dtype=torch.float64, generator=g, requires_grad=True)
     assert gradcheck(lambda a, b: ops.scale_z_signs(a, (0b0101, 0b1000, 0b0011), b), (x, w))
     assert gradgradcheck(lambda a, b: ops.scale_z_signs(a, (0b0101, 0b1000, 0b0011), b), (x, w))
+
+
+def _noisy_loss(dq, params, device=None):
+    """A density-matrix circuit with encoders, a trainable-strength channel and a Reset-free read-out: everything on the
+    per-gate nodes (channels are not reversible)."""
+    cir = dq.QubitCircuit(3, den_mat=True)
+    cir.hlayer()
+    cir.rx(0, encode=True)
+    cir.cnot(0, 1)
+    cir.ry(1, encode=True)
+    cir.rzz([1, 2], encode=True)
+    cir.amp_damp(1, 0.3)
+    cir.depolarizing(0, 0.1)
+    cir.rx(2, encode=True)
+    cir.observable(0)
+    cir.observable([1, 2], 'xz')
+    cir.to(torch.double)
+    if device is not None:
+        cir.to(device)
+    cir(data=params)
+    ev = cir.expectation().reshape(-1)
+    return ev[0] + 0.5 * ev[1] ** 2
+
+
+def check_noisy_hessian(dq, device=None):
+    from torch.autograd.functional import hessian
+
+    x = torch.tensor([0.3, -0.8, 1.1, 0.5], dtype=torch.float64, device=device)
+    h = hessian(lambda p: _noisy_loss(dq, p, device), x)
+    eps = 1e-4
+    num = torch.zeros(4, 4, dtype=torch.float64)
+    for i in range(4):
+        for sgn in (1, -1):
+            xi = x.clone()
+            xi[i] += sgn * eps
+            xi.requires_grad_(True)
+            (g,) = torch.autograd.grad(_noisy_loss(dq, xi, device), xi)
+            num[i] += sgn * g.detach().cpu() / (2 * eps)
+    assert (h.cpu() - num).abs().max().item() < 1e-6, (h, num)
+    assert (h - h.T).abs().max().item() < 1e-10
+
+
+def test_hessian_of_a_density_matrix_circuit_with_channels(cpu_backend):
+    """Second derivatives through the non-reversible path (channels keep per-gate nodes): against central differences of
+    the first-order gradient."""
+    check_noisy_hessian(dq)

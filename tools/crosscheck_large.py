@@ -48,7 +48,7 @@ for n, depth, batch, dtype, seeds in ((26, 40, 4, torch.complex64, (7, 99, 2025)
         norm = (a.abs() ** 2).sum(-1)
         print(f'n={n} depth={depth} seed={seed} batch={batch} {str(dtype)[-3:]}: max |default - plain| = {err:.2e} (tol {tol:g}); '
               f'<Z0> {eva:+.6e} / {evb:+.6e}; norm {norm[0].item():.7f}; passes {sa["passes"]} (plain {sb["passes"]}), '
-              f'kernel gates {sa["gates"]} (plain {sb["gates"]}), LDS trips {sa["transposes"]} (plain {sb["transposes"]}), '
+              f'kernel gates {sa["gates"]} (plain {sb["gates"]}), LDS trips {sa["transposes"]} (plain {sb["transposes"]})',
               flush=True)
         assert err < tol, 'optimised and plain paths disagree'
         del a, b
