@@ -80,6 +80,9 @@ def parse_args():
                          'profiled launches are the timed ones only')
     ap.add_argument('--no-permute-store', action='store_true',
                     help='A/B: in-place passes (every pass gathers its qubits where they canonically live)')
+    ap.add_argument('--no-zero-state', action='store_true',
+                    help='A/B: the first passes read, compute and write everything although the circuit starts from its '
+                         'own |0..0> (executor.CONFIG["zero_state"])')
     ap.add_argument('--no-merge', action='store_true',
                     help='A/B: do not multiply runs of one-qubit gates on the same qubit into one matrix')
     ap.add_argument('--no-free-low', action='store_true', help='A/B: the contiguous low bits keep the same qubits in every pass')
@@ -336,6 +339,8 @@ def main():
         dq.executor.CONFIG['fused_expectation'] = False
     if args.no_fused_sweep:
         dq.executor.CONFIG['fused_sweep'] = False
+    if args.no_zero_state:
+        dq.executor.CONFIG['zero_state'] = False
     if args.no_merge:
         dq.executor.CONFIG['merge_min_amps'] = None
     if args.no_permute_store:
@@ -444,6 +449,9 @@ def main():
     launches = len(kernel_ms)
     shard_bytes = (2**n >> (int(math.log2(world)) if distributed else 0)) * amp_bytes * nbatch
     avg_ms = (sum(kernel_ms) / launches) if launches else float('nan')
+    # the launches that move the whole state both ways (the first passes of a circuit started from |0..0> do not:
+    # executor.CONFIG['zero_state'])
+    full_ms = [t for t, b_ in zip(kernel_ms, kernel_bytes) if b_ == max(kernel_bytes)] if launches else []
     physical = (sum(kernel_bytes) / (sum(kernel_ms) * 1e-3) / 1e9) if launches else 0.0
     alg_per_launch = (alg_bytes / (world if distributed else 1) * args.steps / launches) if launches else 0.0
     effective = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
@@ -553,6 +561,10 @@ def main():
                 'ms_restore_canonical_layout': restore_ms,
                 'fused_passes_per_step': stats.get('passes') if not distributed else launches / args.steps,
                 'lds_round_trips_per_step': stats.get('transposes') if not distributed else None,
+                # passes that skip what is still known to be zero behind the circuit's own |0..0> (the first one touches one
+                # tile per sample, the last of them is write-only); their launches count in `roofline` with the bytes
+                # they really move
+                'zero_state_passes_per_step': stats.get('zero_passes') if not distributed else None,
                 # 2x2 matrices the kernel applies per sample after runs of one-qubit gates on the same qubit were
                 # multiplied together (executor.merge_one_qubit_runs; `--no-merge` applies all `ngates` one by one);
                 # `value` counts the circuit's gates, `unmerged_ms_per_step` times them one by one
@@ -577,6 +589,8 @@ def main():
                 'traffic_source': traffic_src,
                 'launches': launches,
                 'avg_launch_ms': avg_ms,
+                'full_launches': len(full_ms),
+                'full_launch_avg_ms': (sum(full_ms) / len(full_ms)) if full_ms else None,
                 'physical_bytes_per_launch': (sum(kernel_bytes) / launches) if launches else None,
                 # SURVEY 8(d) accounting: every fused gate counted as its own read + write of the state.  NOT a
                 # fraction of anything physical: effective / achieved = how many gate-passes one physical pass replaces

@@ -152,15 +152,20 @@ def apply_fused(
     desc: _lib.DqFusedPass,
     out: torch.Tensor | None = None,
     grads: torch.Tensor | None = None,
+    known_zero: int = 0,
 ) -> torch.Tensor:
     """Run one fused pass (see fusion.py).  ``mats``: flat complex buffer (Bm * stride or stride).
     ``state`` with ONE row and ``out`` with B rows: the single input state is shared by all outputs.
     ``grads`` (float64, (B, rows, 8), added to): a pass of the adjoint method's reverse sweep -- its DQ_FG_GRAD
-    records reduce into it (include/dq_hip.h, dq_apply_fused_grad_c64 / _c128)."""
+    records reduce into it (include/dq_hip.h, dq_apply_fused_grad_c64 / _c128).
+    ``known_zero``: index bits (read side) known to be |0> in ``state`` -- it is not read where one of them is 1, and
+    ``out`` is not written where such a bit outside the tile is 1 (include/dq_hip.h, dq_apply_fused_zext_*)."""
     n = _nqubit(state)
     if out is None:
         out = state
     broadcast = state.shape[0] == 1 and out.shape[0] > 1
+    if known_zero and grads is not None:
+        raise ValueError('a reducing pass takes no known-zero bits')
     if mats.dtype != state.dtype or mats.device != state.device or not mats.is_contiguous():
         raise ValueError('mats must be a contiguous buffer in the dtype/device of the state')
     if grads is not None:
@@ -171,6 +176,8 @@ def apply_fused(
         src = state.expand(out.shape[0], -1) if broadcast else state
         if grads is not None:
             return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out, grads=grads)
+        if known_zero:
+            return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out, known_zero=known_zero)
         return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out)
     if grads is not None:
         if out.shape[0] > MAX_BATCH:
@@ -186,9 +193,15 @@ def apply_fused(
         for lo in range(0, out.shape[0], MAX_BATCH):
             hi = min(lo + MAX_BATCH, out.shape[0])
             apply_fused(state if broadcast else state[lo:hi], rows[lo:hi].reshape(-1) if rows is not None else mats,
-                        mat_batch_stride, desc, out[lo:hi])
+                        mat_batch_stride, desc, out[lo:hi], known_zero=known_zero)
         return out
     lib = _lib.load()
+    if known_zero:
+        fn = lib.dq_apply_fused_zext_c128 if state.dtype == torch.complex128 else lib.dq_apply_fused_zext_c64
+        rc = fn(_ptr(state), 0 if broadcast else 1 << n, _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0],
+                C.byref(desc), int(known_zero), _stream(state))
+        _lib.check(rc, 'dq_apply_fused_zext')
+        return out
     fn = getattr(lib, f'dq_apply_fused_{"bcast_" if broadcast else ""}{_suffix(state)}')
     rc = fn(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0], C.byref(desc),
             _stream(state))

@@ -136,14 +136,15 @@ class QubitCircuit(Operation):
             out.extend(op.prims(decompose))
         return out
 
-    def _run_operators(self, flat: torch.Tensor) -> torch.Tensor:
+    def _run_operators(self, flat: torch.Tensor, zero: bool = False) -> torch.Tensor:
         """All operators on a (B, 2**n) state: maximal stretches of gates go to the executor (fused passes),
-        state-dependent operations (``Reset``) run between them."""
+        state-dependent operations (``Reset``) run between them.  ``zero``: ``flat`` is |0..0> (vec |0..0><0..0| of a
+        density matrix alike: index 0 is 1, everything else 0)."""
         if self.den_mat:
             prims = []
             for op in self.operators:
                 prims.extend(op.dm_prims())
-            return executor.run(flat, prims)
+            return executor.run(flat, prims, zero_state=zero)
         nops = len(self.operators)
         last = id(self.operators[-1]) if nops else 0
         dep = self.__dict__.get('_state_dep')          # (operators it was computed for: how many, the last one; answer)
@@ -158,7 +159,7 @@ class QubitCircuit(Operation):
                 masks = sorted({ob.pauli_masks()[1] for ob in self.observables if ob.pauli_masks()[0] == 0})
                 if masks and len(masks) <= 64:
                     ez = {'masks': masks}
-            out = executor.run(flat, self.prims(), expect_z=ez)
+            out = executor.run(flat, self.prims(), expect_z=ez, zero_state=zero)
             if ez is not None and ez.get('values') is not None:
                 self._expz = ez
             return out
@@ -166,11 +167,12 @@ class QubitCircuit(Operation):
         for op in self.operators:
             if getattr(op, '_state_dependent', False):
                 if pending:
-                    x, pending = executor.run(x, pending), []
+                    x, pending = executor.run(x, pending, zero_state=zero), []
+                zero = False
                 x = op.apply_flat(x)
             else:
                 pending.extend(op.prims())
-        return executor.run(x, pending) if pending else x
+        return executor.run(x, pending, zero_state=zero) if pending else x
 
     def _precompute_matrices(self) -> list:
         """Evaluate the matrices of all single-parameter gates of one class in ONE vectorised call
@@ -215,14 +217,17 @@ class QubitCircuit(Operation):
         (reference: circuit.py:180-263)."""
         if state is None:
             state = self.init_state
+        zero = False
         if isinstance(state, QubitState):
+            # (the constructor's |0..0>, untouched since: the first passes skip what is still known to be zero)
+            zero = state.is_zero_state()
             state = state.state
         if self.ndata == 0:
             data = None
         self.state = None  # release the previous result first: the caching allocator hands the block back
         self._expz = None
         if data is None or data.ndim == 1:
-            out = self._forward_helper(data, state)
+            out = self._forward_helper(data, state, zero)
             if out.ndim == 2:
                 out = out.unsqueeze(0)
             if state.ndim == 2:
@@ -231,7 +236,7 @@ class QubitCircuit(Operation):
         else:
             assert data.ndim == 2
             assert state.ndim in (2, 3)
-            out = self._forward_helper(data, state)
+            out = self._forward_helper(data, state, zero)
             if out.ndim == 2:          # batch of one sample
                 out = out.unsqueeze(0)
             self.state = out
@@ -240,11 +245,12 @@ class QubitCircuit(Operation):
             self._expz['state'] = weakref.ref(self.state)      # (the values belong to THIS tensor: `expectation` checks)
         return self.state
 
-    def _forward_helper(self, data: torch.Tensor | None = None, state: Any = None) -> torch.Tensor:
+    def _forward_helper(self, data: torch.Tensor | None = None, state: Any = None, zero: bool = False) -> torch.Tensor:
         self.encode(data)
         if state is None:
             state = self.init_state
         if isinstance(state, QubitState):
+            zero = state.is_zero_state()
             state = state.state
         dim = 4**self.nqubit if self.den_mat else 2**self.nqubit
         flat = state.reshape(-1, dim)
@@ -253,7 +259,7 @@ class QubitCircuit(Operation):
             flat = flat.expand(data.shape[0], dim)
         touched = self._precompute_matrices()
         try:
-            x = self._run_operators(flat)
+            x = self._run_operators(flat, zero)
         finally:
             for g in touched:
                 g.__dict__['_precomputed'] = None

@@ -220,7 +220,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
 template <typename T>
 static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
                       const DqFusedPass* pass, dq_stream_t stream, bool broadcast_in = false, double* grads = nullptr,
-                      int64_t ngrads = -1) {
+                      int64_t ngrads = -1, uint64_t known_zero = 0) {
     const int64_t in_bstride = broadcast_in ? 0 : (int64_t)1 << n;
     if (broadcast_in && in == out) {
         set_error("dq_apply_fused_bcast: the shared input state cannot be the output buffer");
@@ -266,14 +266,22 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
         set_error("dq_apply_fused: grid too large (n=%d)", n);
         return DQ_ERR_UNSUPPORTED;
     }
+    if (known_zero) {
+        // index bits known to be |0>: below 2^n, and none of the contiguous low bits (a lane loads them in one piece)
+        if ((n < 64 && (known_zero >> n)) || (known_zero & ((1ull << pass->L) - 1ull)) || ngrads >= 0) {
+            set_error("dq_apply_fused_zext: known_zero = 0x%llx names an index bit >= n = %d or one of the %d contiguous low bits "
+                      "(or the pass is a reverse-sweep pass)", (unsigned long long)known_zero, n, (int)pass->L);
+            return DQ_ERR_ARG;
+        }
+    }
     hipStream_t s = as_stream(stream);
     // one wavefront per tile: csrc/dq_wave.hip
     if (ngrads >= 0) {
         if constexpr (is128) return wave_launch_grad_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
         else return wave_launch_grad_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
     }
-    if constexpr (is128) return wave_launch_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
-    else return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+    if constexpr (is128) return wave_launch_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, known_zero);
+    else return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, known_zero);
 }
 
 }  // namespace dq
@@ -328,4 +336,25 @@ extern "C" int dq_apply_fused_bcast_c64(const void* in, void* out, const void* m
 extern "C" int dq_apply_fused_bcast_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
                                          int64_t batch, const DqFusedPass* pass, dq_stream_t stream) {
     return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, true);
+}
+
+// The same pass on an input in which the index bits of `known_zero` are known to be |0> -- the circuit's own initial
+// state |0..0> and the passes right behind it: the input is not read where one of these bits is 1 (it need not even be
+// initialised there), tiles in which one of them is 1 are skipped altogether, and the output is left untouched where a
+// known-zero bit OUTSIDE the tile is 1 (at its write position: still known zero for the next pass).
+extern "C" int dq_apply_fused_zext_c64(const void* in, int64_t in_batch_stride, void* out, const void* mats, int64_t mat_batch_stride,
+                                       int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, dq_stream_t stream) {
+    if (in_batch_stride != 0 && (n < 0 || n > 62 || in_batch_stride != (int64_t)1 << n)) {
+        dq::set_error("dq_apply_fused_zext_c64: in_batch_stride is 0 (one shared input state) or 2^n");
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream, in_batch_stride == 0, nullptr, -1, known_zero);
+}
+extern "C" int dq_apply_fused_zext_c128(const void* in, int64_t in_batch_stride, void* out, const void* mats, int64_t mat_batch_stride,
+                                        int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, dq_stream_t stream) {
+    if (in_batch_stride != 0 && (n < 0 || n > 62 || in_batch_stride != (int64_t)1 << n)) {
+        dq::set_error("dq_apply_fused_zext_c128: in_batch_stride is 0 (one shared input state) or 2^n");
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, in_batch_stride == 0, nullptr, -1, known_zero);
 }

@@ -86,10 +86,16 @@ struct WaveKernPass {
     uint32_t nrec_bytes, mat_base_bytes;
     uint8_t read_blk_pos[DQ_FUSED_MAX_BLK];    // index bit (read side) of bit j of the tile number; unused entries: any
     uint8_t store_blk_pos[DQ_FUSED_MAX_BLK];   // ... on the write side
+    // bits 0..5: how many bits the tile number has (n - m, less the index bits outside the tile that are known to be |0>
+    // in the input: dq_apply_fused_zext_*); bits 8..13 / 16..21: the physical register slots / lane bits of the load
+    // layout that hold such bits (nothing is loaded where one of them is 1: the registers are zero)
+    uint32_t zext;
+    uint32_t reserved[7];
     WaveRec rec[WAVE_MAX_REC];
 };
 static_assert(offsetof(WaveKernPass, store_off) == 40 && offsetof(WaveKernPass, load_lane_shift) == 80 &&
-                  offsetof(WaveKernPass, tb_contrib) == 128 && offsetof(WaveKernPass, rec) == 208, "descriptor layout");
+                  offsetof(WaveKernPass, tb_contrib) == 128 && offsetof(WaveKernPass, zext) == 208 &&
+                  offsetof(WaveKernPass, rec) == 240, "descriptor layout");
 
 struct WaveKernArgs {
     const void* in;
@@ -157,8 +163,8 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
     asm volatile("" : "+s"(karg));
     const KWords hw = (KWords)(karg + offsetof(WaveKernArgs, p));
     {
-        const uint32_t a_n0 = ((KWords)karg)[offsetof(WaveKernArgs, n) / 4], a_tf0 = ((KWords)karg)[offsetof(WaveKernArgs, tpw) / 4];
-        const uint32_t ntiles = 1u << (a_n0 - (uint32_t)W::M), lper = 2u + (a_tf0 & 0xffu);     // log2(4 tpw)
+        const uint32_t a_tf0 = ((KWords)karg)[offsetof(WaveKernArgs, tpw) / 4];
+        const uint32_t ntiles = 1u << (hw[offsetof(WaveKernPass, zext) / 4] & 63u), lper = 2u + (a_tf0 & 0xffu);     // log2(4 tpw)
         if (tile32 >= ntiles) break;
         tile32 += ((ntiles + (1u << lper) - 1u) >> lper) * 4u;        // (for the next round; `tile_id` holds this one's)
     }
@@ -183,7 +189,8 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
     const uint64_t outb = a_out + (((uint64_t)sample << a_n) + tw) * ES;
     const uint64_t mb = a_mats + (uint64_t)((int64_t)sample * (int64_t)a_mbs) * ES;
     // bit 0 / 1: streaming loads / stores (see wave_launch); a pass whose samples share ONE input keeps it in the L2
-    const unsigned flags = a_ibs == 0 ? (a_tf >> 16) & ~1u : a_tf >> 16;
+    // bits 8..13 / 16..21: register slots / lane bits whose index bit is known to be |0> in the input (not loaded)
+    const unsigned flags = ((a_ibs == 0 ? (a_tf >> 16) & ~1u : a_tf >> 16) & 3u) | (hw[offsetof(WaveKernPass, zext) / 4] & 0x003f3f00u);
     W::body(karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec), hw[offsetof(WaveKernPass, nrec_bytes) / 4], mb,
             hw[offsetof(WaveKernPass, mat_base_bytes) / 4], tg,
             karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, load_off), inb, outb, wave * W::LDS_PER_WAVE, tid,
@@ -325,8 +332,11 @@ struct Xlate {
 
 }  // namespace
 
+// `dead`: index bits (read side) known to be |0> in the input (dq_apply_fused_zext_*; 0 = none).  Outside the tile they
+// drop out of the tile number -- the tiles in which one of them is 1 are all zero: neither read nor written --, inside
+// the tile the loads leave the registers of their 1-halves zero.
 template <class W>
-static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
+static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k, uint64_t dead = 0) {
     memset(k, 0, sizeof(*k));
     const int L = p->L, h = p->h;
     auto rpos = [&](int tl) { return tl < L ? tl : (int)p->high_pos[tl - L]; };
@@ -346,16 +356,20 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
     {   // read side: the tile number's bits fill the index bits outside the tile, in ascending order
         uint64_t tilemask = (1ull << L) - 1ull;
         for (int i = 0; i < h; ++i) tilemask |= 1ull << p->high_pos[i];
-        for (int j = 0, q = 0; j < DQ_FUSED_MAX_BLK; ++j, ++q) {
+        int nb = 0;
+        for (int j = 0, q = 0; j < n - W::M; ++j, ++q) {
             while (q < 64 && ((tilemask >> q) & 1ull)) ++q;
-            k->read_blk_pos[j] = (uint8_t)(q < 63 ? q : 63);
-            k->store_blk_pos[j] = j < n - W::M ? p->store_blk_pos[j] : (uint8_t)63;
+            if ((dead >> q) & 1ull) continue;       // (known |0>: not a bit of the tile number)
+            k->read_blk_pos[nb] = (uint8_t)q;
+            k->store_blk_pos[nb] = p->store_blk_pos[j];
+            ++nb;
         }
+        for (int j = nb; j < DQ_FUSED_MAX_BLK; ++j) k->read_blk_pos[j] = k->store_blk_pos[j] = 63;
+        k->zext = (uint32_t)nb;
         // ... re-ordered by where they land on the WRITE side: tiles that run at the same time (neighbours in the tile
         // number) then write neighbouring runs, i.e. whole DRAM pages between them, while the read side does not care
         // (a tile reads one contiguous 32 KiB block wherever it lies).  DQ_WAVE_TILE_ORDER=read keeps the read order.
         static const bool by_store = [] { const char* e = getenv("DQ_WAVE_TILE_ORDER"); return !(e && e[0] == 'r'); }();
-        const int nb = n - W::M;
         if (by_store)
             for (int i = 1; i < nb; ++i)        // insertion sort of (read, store) pairs by store position
                 for (int j = i; j > 0 && k->store_blk_pos[j] < k->store_blk_pos[j - 1]; --j) {
@@ -363,10 +377,14 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k) {
                     std::swap(k->read_blk_pos[j], k->read_blk_pos[j - 1]);
                 }
     }
-    for (int s = W::VB; s < W::R; ++s) k->load_off[s - W::VB] = (uint64_t)W::ELEM << rpos(x.phys[s]);
+    for (int s = W::VB; s < W::R; ++s) {
+        k->load_off[s - W::VB] = (uint64_t)W::ELEM << rpos(x.phys[s]);
+        if ((dead >> rpos(x.phys[s])) & 1ull) k->zext |= 1u << (8 + s);
+    }
     for (int b = 0; b < WAVE_LANES; ++b) {
         k->load_lane_shift[b] = (W::ELEM == 8 ? 3u : 4u) + (uint32_t)rpos(x.lanes[b]);
         k->tb_contrib[b] = 1u << x.lanes[b];
+        if ((dead >> rpos(x.lanes[b])) & 1ull) k->zext |= 1u << (16 + b);
     }
     k->mat_base_bytes = p->mat_base * (uint32_t)W::ELEM;
 
@@ -563,11 +581,11 @@ fail:
 
 template <class W, bool GRAD = false>
 static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                       const DqFusedPass* pass, hipStream_t s, double* grads = nullptr, int64_t ngrads = 0) {
+                       const DqFusedPass* pass, hipStream_t s, double* grads = nullptr, int64_t ngrads = 0, uint64_t dead = 0) {
     WaveKernPass kp;
-    const int rc = wave_translate<W>(pass, n, &kp);
+    const int rc = wave_translate<W>(pass, n, &kp, dead);
     if (rc) return rc;
-    const uint64_t tiles = 1ull << (n - W::M);
+    const uint64_t tiles = 1ull << (kp.zext & 63u);
     int tpw = 1;
     if (GRAD) {     // tiles per wave: as many as leave >= 2048 workgroups per sample batch
         while (tpw < 64 && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
@@ -604,8 +622,8 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
 }
 
 int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                    const DqFusedPass* pass, hipStream_t s) {
-    return wave_launch<WaveC64>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+                    const DqFusedPass* pass, hipStream_t s, uint64_t dead) {
+    return wave_launch<WaveC64>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, nullptr, 0, dead);
 }
 int wave_launch_grad_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads) {
@@ -616,8 +634,8 @@ int wave_launch_grad_c128(const void* in, void* out, const void* mats, int64_t m
     return wave_launch<WaveC128, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
 }
 int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                     const DqFusedPass* pass, hipStream_t s) {
-    return wave_launch<WaveC128>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s);
+                     const DqFusedPass* pass, hipStream_t s, uint64_t dead) {
+    return wave_launch<WaveC128>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, nullptr, 0, dead);
 }
 
 }  // namespace dq
@@ -625,15 +643,15 @@ int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bs
 // Test hook (no GPU needed): the kernel-side descriptor the library would hand to the wave-tile kernel for `pass` --
 // slot offsets, lane shifts, tile-number positions, records (struct WaveKernPass above) -- as raw bytes.  The precision
 // follows the geometry: m = 12 / 6 slots = complex64, m = 11 / 5 slots = complex128.
-extern "C" int dq_wave_descriptor(const DqFusedPass* pass, int n, void* out, int max_bytes) {
+extern "C" int dq_wave_descriptor(const DqFusedPass* pass, int n, uint64_t known_zero, void* out, int max_bytes) {
     if (!pass) {
         dq::set_error("dq_wave_descriptor: null pointer");
         return DQ_ERR_ARG;
     }
     dq::WaveKernPass kp;
     int rc;
-    if (pass->m == 12 && pass->slots == 6) rc = dq::wave_translate<dq::WaveC64>(pass, n, &kp);
-    else if (pass->m == 11 && pass->slots == 5) rc = dq::wave_translate<dq::WaveC128>(pass, n, &kp);
+    if (pass->m == 12 && pass->slots == 6) rc = dq::wave_translate<dq::WaveC64>(pass, n, &kp, known_zero);
+    else if (pass->m == 11 && pass->slots == 5) rc = dq::wave_translate<dq::WaveC128>(pass, n, &kp, known_zero);
     else {
         dq::set_error("dq_wave_descriptor: not a wave-tile pass (m = %d, %d slots)", pass->m, pass->slots);
         return DQ_ERR_ARG;

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 from collections import OrderedDict
 from dataclasses import dataclass
-from typing import Sequence
+from typing import Any, Sequence
 
 import torch
 
@@ -49,6 +49,7 @@ class Plan:
     rx_defer: list[int] | None = None      # matrix-buffer offsets of the gates on the deferred Rx handlers
     _rx_index: dict | None = None          # ... as a LongTensor per device
     _scale_cache: dict | None = None       # complex128 reverse sweeps: which scalar gates run before which reduction
+    _zero_masks: Any = False               # fusion.zero_state_masks of the steps (False: not computed yet)
 
 
 _PLAN_CACHE: OrderedDict = OrderedDict()
@@ -90,7 +91,12 @@ CONFIG = {'fuse': True, 'min_low_c64': None, 'min_low_c128': None,
           # on the same qubit into one matrix before planning (merge_one_qubit_runs); None = never
           'merge_min_amps': 1 << 27,
           # from this many amplitudes (batch included) on, the pass planner searches wider (make_plan)
-          'plan_big_amps': 1 << 31}
+          'plan_big_amps': 1 << 31,
+          # a circuit started from its own |0..0>: qubits no pass has had in its tile yet factor out as |0>, and the first
+          # passes neither read, compute nor write where such an index bit is 1 (fusion.zero_state_masks,
+          # dq_apply_fused_zext_*): the first two of the headline's nineteen passes cost next to nothing, the third only
+          # its stores.  A/B switch
+          'zero_state': True}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates, bytes read + written) to report the kernel's average duration next to its algorithmic bytes.
@@ -105,7 +111,7 @@ GRAPH_BACKWARDS = {'count': 0}
 PLAN_STATS = {'seconds': 0.0, 'plans': 0}
 
 # Statistics of the most recent fused run (for bench.py and tests).
-LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'permute_folded': False}
+LAST_RUN = {'passes': 0, 'singles': 0, 'gates': 0, 'rounds': 0, 'transposes': 0, 'permute_folded': False, 'zero_passes': 0}
 
 
 def _geometry(is128: bool) -> fusion.Geometry:
@@ -243,8 +249,11 @@ def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
 
 def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
         out_perm: Sequence[int] | None = None, amps: int | None = None, grads: torch.Tensor | None = None,
-        expect_z: dict | None = None) -> torch.Tensor:
+        expect_z: dict | None = None, zero_state: bool = False) -> torch.Tensor:
     """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state.
+
+    ``zero_state``: the caller vouches that ``state`` is |0..0> (every row; ``QubitState.is_zero_state``) -- the first
+    passes then skip what is known to be zero (CONFIG['zero_state']).
 
     ``scratch`` (no-grad runs): a second buffer like ``state`` that the passes may ping-pong with (permuted stores
     without an allocation; the sharded state passes its receive buffer) -- the result then lives in ``state`` OR in
@@ -263,7 +272,7 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
         vmapped = ops._is_batched(state) or any(ops._is_batched(p.matrix) for p in prims)
         if CONFIG['grad_mode'] == 'adjoint' and not vmapped and all(p.unitary for p in prims):
             meta = tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode, p.exact) for p in prims)
-            return _AdjointCircuit.apply(state, meta, *[p.matrix for p in prims])
+            return _AdjointCircuit.apply(state, _Meta(meta, zero_state), *[p.matrix for p in prims])
         x = state
         for p in prims:
             x = ops.apply_gate(x, p.matrix, p.targets, p.controls)
@@ -303,10 +312,22 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
                     e['extra'][mkey] = both
             nextra = len(expect_z['masks'])
             acc = torch.zeros(state.shape[0], nextra, 8, dtype=torch.float64, device=state.device)
-            out = _run_nograd(state, both, inplace, scratch, out_perm, grads=acc, amps=amps)
+            out = _run_nograd(state, both, inplace, scratch, out_perm, grads=acc, amps=amps, zero_state=zero_state)
             expect_z['values'] = acc[:, :, 0]
             return out
-    return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps)
+    return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps, zero_state=zero_state)
+
+
+class _Meta(tuple):
+    """The gate list of an ``_AdjointCircuit`` node (kind, targets, controls, mode, exact per gate) plus what the caller
+    knows about the input state (``zero_state``: it is |0..0>)."""
+
+    zero_state = False
+
+    def __new__(cls, items, zero_state: bool = False):
+        self = super().__new__(cls, items)
+        self.zero_state = bool(zero_state)
+        return self
 
 
 # Issue slots of a wave per one-qubit gate, by matrix structure, measured on the workgroup-tile kernels of round 2 (DESIGN
@@ -444,8 +465,9 @@ def _permute_after(x: torch.Tensor, out_perm: Sequence[int], scratch: torch.Tens
 
 def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
                 out_perm: Sequence[int] | None = None, grads: torch.Tensor | None = None,
-                amps: int | None = None) -> torch.Tensor:
-    """``grads``: the accumulator of the 'grad' prims (the reverse sweep of ``_AdjointCircuit``; complex64, n >= a tile)."""
+                amps: int | None = None, zero_state: bool = False) -> torch.Tensor:
+    """``grads``: the accumulator of the 'grad' prims (the reverse sweep of ``_AdjointCircuit``; complex64, n >= a tile).
+    ``zero_state``: ``state`` is |0..0> (see ``run``)."""
     n = state.shape[-1].bit_length() - 1
     with torch.no_grad():
         is128 = state.dtype == torch.complex128
@@ -479,10 +501,24 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies
         shared_in = None
+        # |0..0> in: the masks of the index bits still known to be zero, per step (None: not applicable)
+        zmasks = None
+        if zero_state and CONFIG['zero_state'] and CONFIG['fuse'] and not inplace and n >= m and plan.steps:
+            if plan._zero_masks is False:
+                plan._zero_masks = fusion.zero_state_masks(plan.steps, n)
+            zmasks = plan._zero_masks
+            if zmasks is not None and grads is not None and any(
+                    zk and any(plan.prim_ops[oi].kind in ('grad', 'expz') for oi in st.ops)
+                    for zk, st in zip(zmasks, plan.steps) if isinstance(st, fusion.FusedStep)):
+                zmasks = None           # (a reducing pass sums over the whole buffer)
         if (state.shape[0] > 1 and state.stride(0) == 0 and state.stride(1) == 1 and plan.steps
                 and isinstance(plan.steps[0], fusion.FusedStep)):
             shared_in = state.detach()[:1]
             x = torch.empty(state.shape, dtype=state.dtype, device=state.device)
+        elif zmasks is not None and state.is_contiguous():
+            # the first pass reads the caller's |0..0> itself -- a few amplitudes of it -- and writes the working buffer: no copy
+            shared_in = state.detach()
+            x = torch.empty_like(shared_in)
         elif inplace and state.is_contiguous():
             x = state
         else:
@@ -500,13 +536,14 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 fusion.defer_rx(flat, idx)
             if steady is not None:
                 steady['flat'] = {fkey: (plan, flat, stride)}       # (one buffer per entry: the latest shape)
-        stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0}
+        stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0, 'zero_passes': 0}
         spare = scratch                      # the caller's second buffer (if any)
         other = spare if permute else None
         scratch = None
-        for st in plan.steps:
+        for si, st in enumerate(plan.steps):
             if isinstance(st, fusion.FusedStep):
                 src, shared_in = (shared_in, None) if shared_in is not None else (x, None)
+                kz = zmasks[si] if zmasks is not None else 0
                 dst = x
                 if st.permutes and src is x:     # writes to other index bits than it reads: the other buffer
                     if other is None:
@@ -516,14 +553,20 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 if gr is not None and src is not x:      # (a reducing pass takes no shared input state: materialise it)
                     x.copy_(src.expand_as(x))
                     src = x
+                if kz:
+                    stats['zero_passes'] += 1
                 if PROFILE['enabled'] and x.is_cuda:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr)
+                    backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr, known_zero=kz)
                     e1.record()
-                    PROFILE['events'].append((e0, e1, len(st.ops), (src.numel() + dst.numel()) * x.element_size()))
+                    # bytes the pass has to move: what it reads (not where a known-zero bit is 1) + what it writes (not
+                    # the tiles in which such a bit outside the tile is 1)
+                    nz = bin(kz).count('1')
+                    nzo = nz - sum(1 for i in range(st.desc.h) if (kz >> st.desc.high_pos[i]) & 1)
+                    PROFILE['events'].append((e0, e1, len(st.ops), ((src.numel() >> nz) + (dst.numel() >> nzo)) * x.element_size()))
                 else:
-                    backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr)
+                    backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr, known_zero=kz)
                 if dst is not x:
                     x, other = dst, x
                 stats['passes'] += 1
@@ -621,7 +664,7 @@ class _AdjointCircuit(torch.autograd.Function):
         if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']):
             with torch.no_grad():
                 prims = merge_one_qubit_runs(prims)
-        out = _run_nograd(state, prims)
+        out = _run_nograd(state, prims, zero_state=getattr(meta, 'zero_state', False))
         ctx.meta = meta
         # (the input is kept by reference for the second-order route of ``backward``; the sweep itself needs only
         # ``out``.  It costs no memory as a rule: the initial state belongs to the circuit, the state between two

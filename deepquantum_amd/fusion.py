@@ -874,6 +874,43 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         g.loc = 1 if op.mode == 1 else 0      # promised real (and usually sparse): channel superoperators
 
 
+def zero_state_masks(steps: Sequence, n: int) -> list[int] | None:
+    """The passes of a schedule run on the initial state |0..0> (the reference's default, circuit.py:49): an index bit no
+    pass has had in its tile yet still factors out as |0>, so the state is zero wherever such a bit is 1 -- nothing there
+    has to be read, computed or written (include/dq_hip.h, dq_apply_fused_zext_*).  Returns, per step, the mask of
+    those bits on the READ side of the step (0 once every bit has been in a tile: from then on the passes are ordinary);
+    None when it does not work out: a gate that runs on its own (it reads the whole buffer) while such bits are left, or
+    bits left at the end (the result would hold uninitialised memory).  The contiguous low bits of a pass never count:
+    a lane loads them in one piece, and they are in every tile from the first pass on (whose input is a real state).
+
+    For the 28-qubit headline circuit: pass 0 touches one tile per sample, pass 1 2^8 of the 2^16, pass 2 reads 2^-8 of
+    the state and writes all of it -- three of nineteen passes for the price of one pass's stores."""
+    live = 0                        # index bits (positions on the read side of the next step) that may be non-zero
+    full = (1 << n) - 1
+    masks: list[int] = []
+    for st in steps:
+        if live == full:
+            masks.append(0)
+            continue
+        if not isinstance(st, FusedStep):
+            return None
+        d = st.desc
+        L, h = d.L, d.h
+        tile = [p_ for p_ in range(L)] + [d.high_pos[i] for i in range(h)]
+        wtile = [d.store_low_pos[i] for i in range(L)] + [d.store_high_pos[i] for i in range(h)]
+        tset = set(tile)
+        blk = [p_ for p_ in range(L, n) if p_ not in tset]
+        wpos = {p_: w for p_, w in zip(tile, wtile)}
+        wpos.update({p_: d.store_blk_pos[j] for j, p_ in enumerate(blk)})
+        low = (1 << L) - 1
+        masks.append(full & ~live & ~low)
+        now = live | sum(1 << p_ for p_ in tile)
+        live = sum(1 << wpos[p_] for p_ in range(n) if (now >> p_) & 1)
+    if live != full:
+        return None
+    return masks if any(masks) else None
+
+
 def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], int]:
     """Assign the kernel-side matrix layout: the matrices of a fused pass lie back to back in gate order
     (the kernel fetches gate i's matrix from a running pointer, together with the gate record), single-gate

@@ -14,6 +14,11 @@ from .qmath import amplitude_encoding, is_density_matrix
 from .utils import complex_apply
 
 
+def tensor_version(t: torch.Tensor):
+    """``t._version``, or None for a tensor that has none (inference tensors)."""
+    return None if torch.is_inference(t) else t._version
+
+
 class _ComplexBuffers(nn.Module):
     """nn.Module whose complex buffers follow ``.to(real dtype)`` to the matching complex dtype."""
 
@@ -63,9 +68,40 @@ class QubitState(_ComplexBuffers):
         if den_mat:
             vec = vec @ vec.mH
         self.register_buffer('state', vec)
+        if isinstance(state, str) and state == 'zeros':
+            self._mark_zero_state()
 
     def forward(self) -> None:
         pass
+
+    # |0..0> (or |0..0><0..0|) as made by the constructor is worth knowing to the executor: the first fused passes of a
+    # circuit skip everything that is still known to be zero (executor.CONFIG['zero_state']).  The mark names the buffer
+    # tensor (weakly) and its version counter, so writing into the buffer or replacing it ends it.
+    def _mark_zero_state(self) -> None:
+        import weakref
+
+        t = self._buffers['state']
+        self.__dict__['_zero_mark'] = (weakref.ref(t), tensor_version(t))
+
+    def is_zero_state(self) -> bool:
+        """True while ``state`` is still the |0..0> the constructor made (``state='zeros'``), on whatever device / in
+        whatever precision ``.to()`` has put it since."""
+        mark = self.__dict__.get('_zero_mark')
+        t = self._buffers.get('state')
+        return mark is not None and t is not None and mark[0]() is t and mark[1] is not None and mark[1] == tensor_version(t)
+
+    def _apply(self, fn: Any, *args, **kwargs):
+        was = self.is_zero_state()
+        super()._apply(fn, *args, **kwargs)
+        self.__dict__.pop('_zero_mark', None)
+        if was:                      # (moving or converting |0..0> keeps it |0..0>)
+            self._mark_zero_state()
+        return self
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop('_zero_mark', None)    # (a weak reference does not pickle; a restored state is checked anew by nobody)
+        return d
 
 
 class DistributedQubitState(_ComplexBuffers):

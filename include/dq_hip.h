@@ -45,7 +45,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 21
+#define DQ_ABI_VERSION 22
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -246,10 +246,11 @@ int dq_dag_grow_step(void* dag, uint64_t tile, int cap, const int* indeg, const 
 /* Test hook, no device needed: the kernel-side descriptor the library derives for a wave-tile pass (`pass`: HOST
  * pointer, complex64, m = 12, 6 slots) as raw bytes -- 80 bytes of slot offsets (load, store: 5 x 8 each), 6 + 6 + 6
  * words (byte shift of every lane bit on the load side / the store side, what it adds to the thread's tile-local base),
- * record bytes, matrix base, 24 + 24 index positions of the tile number's bits (read, write), then the 32-byte records
- * (word 0 = handler id, csrc/dq_wave_asm.inc).  At most `max_bytes` are copied to `out` (may be NULL); returns the size,
+ * record bytes, matrix base, 24 + 24 index positions of the tile number's bits (read, write), one word for
+ * dq_apply_fused_zext_* (`known_zero`; bits 0..5: how many bits the tile number has, 8..13 / 16..21: register slots /
+ * lane bits that are not loaded) + 7 reserved words, then the 32-byte records (word 0 = handler id, csrc/dq_wave_asm.inc).  At most `max_bytes` are copied to `out` (may be NULL); returns the size,
  * or a negative DqStatus.  tests/_wave_emulator.py executes such a descriptor on the CPU. */
-int dq_wave_descriptor(const DqFusedPass* pass, int n, void* out, int max_bytes);
+int dq_wave_descriptor(const DqFusedPass* pass, int n, uint64_t known_zero, void* out, int max_bytes);
 /* `pass` is a HOST pointer; it is copied into the kernel argument segment.  in == out allowed.
  * Requires n >= pass->m. */
 int dq_apply_fused_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
@@ -263,6 +264,24 @@ int dq_apply_fused_bcast_c64(const void* in, void* out, const void* mats, int64_
                              int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
 int dq_apply_fused_bcast_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
                               int64_t batch, const DqFusedPass* pass, dq_stream_t stream);
+
+/* Same pass on an input in which the index bits of `known_zero` (bit mask, READ side of the pass) are known to be |0>:
+ * the circuit's own initial state |0..0> (the reference's default, circuit.py:49 `init_state='zeros'`) and the passes
+ * right behind it, while the qubits the circuit has not touched yet still factor out as |0>.
+ *   - `in` is not read where one of these bits is 1; it need not be initialised there.  Inside the tile the registers of
+ *     those halves are zero; tiles in which a known-zero bit OUTSIDE the tile is 1 are all zero and are skipped: neither
+ *     read, computed nor written.
+ *   - `out` is therefore left untouched where a known-zero bit outside the tile is 1 (at the position the pass writes that
+ *     bit to): those bits are still known zero for the next pass; the tile's own bits are not any more.
+ *   - none of the pass's L contiguous low bits may be named (a lane loads them in one piece), nor a bit >= n.
+ * in_batch_stride: 2^n, or 0 = ONE input state shared by all `batch` outputs (as dq_apply_fused_bcast_*).
+ * The first pass of the 28-qubit headline circuit then touches one tile per sample, the second 2^8, the third is
+ * write-only: three of nineteen passes for the price of the third one's stores (deepquantum_amd/fusion.py,
+ * zero_state_masks). */
+int dq_apply_fused_zext_c64(const void* in, int64_t in_batch_stride, void* out, const void* mats, int64_t mat_batch_stride,
+                            int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, dq_stream_t stream);
+int dq_apply_fused_zext_c128(const void* in, int64_t in_batch_stride, void* out, const void* mats, int64_t mat_batch_stride,
+                             int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, dq_stream_t stream);
 
 /* Reverse sweep of the adjoint method in fused passes (replaces the backward of autograd through circuit.py:261, one
  * matmul backward per gate -- qmath.py:504 -- with one saved state per gate).  `in` / `out` hold, per sample, psi and

@@ -40,7 +40,7 @@ class CpuTestBackend:
         return table[(bool(is_c128), variant)]
 
     # ---- fused pass interpreter --------------------------------------------------------------------
-    def apply_fused(self, state, mats, mat_batch_stride, desc, out, grads=None):
+    def apply_fused(self, state, mats, mat_batch_stride, desc, out, grads=None, known_zero=0):
         self.fused_calls += 1
         n = state.shape[-1].bit_length() - 1
         bsz = state.shape[0]
@@ -110,6 +110,13 @@ class CpuTestBackend:
         assert run + _lib.MAT_PAD <= per_sample, 'matrix buffer lacks the prefetch pad'
 
         x = state.detach().numpy().copy()
+        live_rows = np.ones(len(tiles), dtype=bool)
+        if known_zero:
+            # include/dq_hip.h, dq_apply_fused_zext_*: the input is zero -- and not read: it may hold anything -- where a
+            # known-zero index bit is 1; the tiles in which such a bit OUTSIDE the tile is 1 are not written either
+            assert grads is None and known_zero >> n == 0 and known_zero & ((1 << L) - 1) == 0
+            x[:, (np.arange(1 << n, dtype=np.int64) & known_zero) != 0] = 0
+            live_rows = (tiles & known_zero) == 0
         flat_m = mats.detach().numpy().reshape(-1)
         for b in range(bsz):
             t = x[b][idx]                               # (ntiles, 2^m)
@@ -251,6 +258,12 @@ class CpuTestBackend:
                         ok = tile_ok[:, None] & el_ok[None, :]
                         t = np.where(ok, ph * t, t)
             x[b][idxw] = t          # (every index is written exactly once: idxw partitions the state)
+        if known_zero:
+            # (what the kernel leaves untouched is poisoned here: a later pass that reads it -- a wrong mask -- shows)
+            keep = np.full_like(x, complex(float('nan'), float('nan')))
+            for b in range(bsz):
+                keep[b][idxw[live_rows].reshape(-1)] = x[b][idxw[live_rows].reshape(-1)]
+            x = keep
         out.copy_(torch.from_numpy(x))
         return out
 

@@ -49,13 +49,13 @@ class WaveKernPass(C.Structure):
     _fields_ = [('load_off', C.c_uint64 * 5), ('store_off', C.c_uint64 * 5), ('load_lane_shift', C.c_uint32 * 6),
                 ('store_lane_shift', C.c_uint32 * 6), ('tb_contrib', C.c_uint32 * 6), ('nrec_bytes', C.c_uint32),
                 ('mat_base_bytes', C.c_uint32), ('read_blk_pos', C.c_uint8 * 24), ('store_blk_pos', C.c_uint8 * 24),
-                ('rec', (C.c_uint32 * 8) * 112)]
+                ('zext', C.c_uint32), ('reserved', C.c_uint32 * 7), ('rec', (C.c_uint32 * 8) * 112)]
 
 
-def descriptor(desc, n) -> WaveKernPass:
+def descriptor(desc, n, known_zero: int = 0) -> WaveKernPass:
     lib = _lib.load()
     kp = WaveKernPass()
-    rc = lib.dq_wave_descriptor(C.byref(desc), n, C.byref(kp), C.sizeof(kp))
+    rc = lib.dq_wave_descriptor(C.byref(desc), n, known_zero, C.byref(kp), C.sizeof(kp))
     if rc < 0:
         raise RuntimeError(lib.dq_last_error().decode())
     assert rc == WaveKernPass.rec.offset + kp.nrec_bytes
@@ -127,22 +127,27 @@ def _apply2(a, lo, hi, m, active):
     a[active, hi] = (m[2] * x0 + m[3] * x1)[active]
 
 
-def run_pass(desc, n, state, mats, mat_batch_stride, grads=None):
-    """state (B, 2^n) complex numpy -> the state after the pass, as the wave-tile kernel of its precision computes it."""
+def run_pass(desc, n, state, mats, mat_batch_stride, grads=None, known_zero: int = 0, out=None):
+    """state (B, 2^n) complex numpy -> the state after the pass, as the wave-tile kernel of its precision computes it.
+    ``known_zero`` (dq_apply_fused_zext_*): the index bits known to be |0> in the input -- the kernel's loads and its tile
+    count follow the descriptor's `zext` word; ``out`` (B, 2^n) is then written only where the kernel writes."""
     c128 = state.dtype == np.complex128
     g = gen(c128)
     NA, R, EL, M_ = g.NA, g.R, (16 if c128 else 8), (11 if c128 else 12)
     NV = 2 * (R + 1)
     regs_of = lambda arr: _Regs(g, arr)      # noqa: E731
-    kp = descriptor(desc, n)
+    kp = descriptor(desc, n, known_zero)
     nrec = kp.nrec_bytes // 32
     rec = [list(kp.rec[i]) for i in range(nrec)]
-    out = np.empty_like(state)
+    out = np.empty_like(state) if out is None else out
     lanes = np.arange(64)
     lb = [(lanes >> b) & 1 for b in range(6)]
     lld = sum(lb[b].astype(np.int64) << kp.load_lane_shift[b] for b in range(6))
     lst = sum(lb[b].astype(np.int64) << kp.store_lane_shift[b] for b in range(6))
-    ntiles = 1 << (n - M_)
+    ntiles = 1 << (kp.zext & 63)
+    dead_slots, dead_lanes = (kp.zext >> 8) & 63, (kp.zext >> 16) & 63
+    assert known_zero or (ntiles == 1 << (n - M_) and not dead_slots and not dead_lanes)
+    live_lanes = (lanes & dead_lanes) == 0
     flat_m = np.asarray(mats).reshape(-1)
     trip_of = {g.ID_TRIP + i: (bin(mk).count('1'), mk) for i, mk in enumerate(g.TRIP_MASKS)}
     trip_of[g.ID_TRIP0] = (0, 0)
@@ -155,13 +160,17 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None):
             tw = sum(((tile >> j) & 1) << kp.store_blk_pos[j] for j in range(24))
             a = np.zeros((64, NA), dtype=state.dtype)
             for piece in range(32):
+                # (zero-extended loads: a piece whose slot pattern has a known-zero bit set is not loaded, nor are the
+                # lanes with such a lane bit -- tools/gen_wave_asm.py, zext_load)
+                if (piece << (0 if c128 else 1)) & dead_slots:
+                    continue
                 off = sum(kp.load_off[s] for s in range(5) if (piece >> s) & 1)
-                addr = (tg * EL + off + lld) // EL
+                addr = ((tg * EL + off + lld) // EL)[live_lanes]
                 if c128:
-                    a[:, piece] = flat_in[addr]
+                    a[live_lanes, piece] = flat_in[addr]
                 else:
-                    a[:, 2 * piece] = flat_in[addr]
-                    a[:, 2 * piece + 1] = flat_in[addr + 1]
+                    a[live_lanes, 2 * piece] = flat_in[addr]
+                    a[live_lanes, 2 * piece + 1] = flat_in[addr + 1]
             tb = sum(lb[b_] * kp.tb_contrib[b_] for b_ in range(6))
             scale = np.complex128(1.0)
             moff = kp.mat_base_bytes // EL

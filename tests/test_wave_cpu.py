@@ -124,7 +124,7 @@ def test_everything_the_scheduler_fuses_runs_on_the_wave_tile(cpu_backend):
         steps = fusion.schedule(ops, 13, geom)
         lib = _lib.load()
         import ctypes as C
-        assert lib.dq_wave_descriptor(C.byref(steps[0].desc), 13, None, 0) > 0
+        assert lib.dq_wave_descriptor(C.byref(steps[0].desc), 13, 0, None, 0) > 0
     assert fusion.wave_supports([fusion.PrimOp('diag', (5, 2), (1,), 0, 0)])
 
 

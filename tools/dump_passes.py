@@ -37,5 +37,8 @@ for i, (s, (a, b, ng, _nb)) in enumerate(zip(steps, ev)):
         extra = (f' records {len(ids)} trips k={[bin(t).count("1") for t in trips]} lane-perm {ids.count(g.ID_TRIP0)} '
                  f'swaps {sum(j >= g.ID_SWAP for j in ids)} read {sorted(s.desc.high_sorted[j] for j in range(s.desc.h))} '
                  f'write-lanes {sorted(kp.store_lane_shift[j] - 3 for j in range(6))} write-slots {sorted(int(kp.store_off[j]).bit_length() - 4 for j in range(5))}')
+    zm = plan._zero_masks[plan.steps.index(s)] if plan._zero_masks else 0
+    if zm:      # a circuit started from its own |0..0> (executor.CONFIG['zero_state']): index bits still known to be zero
+        extra = f' known-zero bits {bin(zm).count("1")} ({_nb / 2**30:.2f} GiB moved)' + extra
     print(f'pass {i:2d}: gates {len(s.ops):3d} {kinds} rounds {s.nrounds} trips {s.ntranspose}  {ms:6.2f} ms{extra}')
 print('total', tot)

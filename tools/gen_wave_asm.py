@@ -568,6 +568,33 @@ def gray_walk(op, base_operand, lane_operand, nt=False):
     return out_
 
 
+def zext_load(base_operand, lane_operand):
+    """The loads of a pass whose input has index bits KNOWN TO BE |0> (dq_apply_fused_zext_c64: the circuit's own |0..0>
+    and the passes right behind it).  flags bits 8..13 / 16..21 = the register slots / lane bits of the load layout
+    that hold such bits: where one of them is 1 nothing is read -- the memory there is not even initialised -- and the
+    registers are zero.  Falls through to the ordinary loads when no such bit is in the tile."""
+    t = ['s_bfe_u32 s69, %[flags], 0x000e0008', 's_cmp_eq_u32 s69, 0', 's_cbranch_scc1 .Lldn_%=']
+    t += [f'v_mov_b64 {A(j)}, 0' for j in range(NA)]
+    t += ['s_lshr_b32 s70, s69, 8', 's_and_b32 s69, s69, 0x3f', f'v_and_b32 {TT}, s70, {LANE}', f'v_cmp_eq_u32 vcc, 0, {TT}',
+          f's_and_saveexec_b64 {SAVE}, vcc', f's_mov_b64 {RUN}, {base_operand}']
+    for i in range(32):
+        g = i ^ (i >> 1)
+        if i:
+            b = (i & -i).bit_length() - 1
+            lo, hi = f's{40 + 2 * b}', f's{41 + 2 * b}'
+            if (g >> b) & 1:
+                t += [f's_add_u32 s50, s50, {lo}', f's_addc_u32 s51, s51, {hi}']
+            else:
+                t += [f's_sub_u32 s50, s50, {lo}', f's_subb_u32 s51, s51, {hi}']
+        if g:       # (the walk covers slots 1..5; slot 0 = index bit 0 inside the 16-byte piece, never such a bit)
+            t += [f's_and_b32 s70, s69, {g << 1}', f's_cbranch_scc1 .Lzx{i}_%=']
+        ad = ADDR[i % 4]
+        t += [f'v_lshl_add_u64 {ad}, {RUN}, 0, {lane_operand}', f'global_load_dwordx4 v[{AMP0 + 4 * g}:{AMP0 + 4 * g + 3}], {ad}, off']
+        if g:
+            t.append(f'.Lzx{i}_%=:')
+    return t + [f's_mov_b64 exec, {SAVE}', 's_branch .Lldd_%=', '.Lldn_%=:']
+
+
 def kernel_body():
     h = handlers()
     ids = sorted(h)
@@ -614,6 +641,7 @@ def kernel_body():
     # streaming (non-temporal) loads and stores when the host says so (flags bit 0 / 1: states far bigger than the
     # caches; +10-15 % on the memory side, tools/experiments/mb_wavetile.hip), plain ones otherwise (small states live in
     # the Infinity Cache between passes; the pass that reads ONE shared input state relies on the L2)
+    text += zext_load('%[inb]', LLD)
     text += ['s_bitcmp1_b32 %[flags], 0', 's_cbranch_scc0 .Lldp_%='] + gray_walk('load', '%[inb]', LLD, nt=True) + ['s_branch .Lldd_%=', '.Lldp_%=:']
     text += gray_walk('load', '%[inb]', LLD) + ['.Lldd_%=:']
     # the first record and its matrix arrive with the tile

@@ -477,6 +477,32 @@ def gray_walk(op, base_operand, lane_operand, nt=False):
     return out_
 
 
+def zext_load(base_operand, lane_operand):
+    """The loads of a pass whose input has index bits KNOWN TO BE |0> (dq_apply_fused_zext_c128; see tools/gen_wave_asm.py):
+    flags bits 8..12 / 16..21 = the register slots / lane bits of the load layout that hold such bits."""
+    t = ['s_bfe_u32 s69, %[flags], 0x000e0008', 's_cmp_eq_u32 s69, 0', 's_cbranch_scc1 .Lldn_%=']
+    for j in range(NA):
+        t += [f'v_mov_b64 {RE(j)}, 0', f'v_mov_b64 {IM(j)}, 0']
+    t += ['s_lshr_b32 s70, s69, 8', 's_and_b32 s69, s69, 0x3f', f'v_and_b32 {TT}, s70, {LANE}', f'v_cmp_eq_u32 vcc, 0, {TT}',
+          f's_and_saveexec_b64 {SAVE}, vcc', f's_mov_b64 {RUN}, {base_operand}']
+    for i in range(NA):
+        g = i ^ (i >> 1)
+        if i:
+            b = (i & -i).bit_length() - 1
+            lo, hi = f's{40 + 2 * b}', f's{41 + 2 * b}'
+            if (g >> b) & 1:
+                t += [f's_add_u32 s50, s50, {lo}', f's_addc_u32 s51, s51, {hi}']
+            else:
+                t += [f's_sub_u32 s50, s50, {lo}', f's_subb_u32 s51, s51, {hi}']
+        if g:
+            t += [f's_and_b32 s70, s69, {g}', f's_cbranch_scc1 .Lzx{i}_%=']
+        ad = ADDR[i % 4]
+        t += [f'v_lshl_add_u64 {ad}, {RUN}, 0, {lane_operand}', f'global_load_dwordx4 {A(g)}, {ad}, off']
+        if g:
+            t.append(f'.Lzx{i}_%=:')
+    return t + [f's_mov_b64 exec, {SAVE}', 's_branch .Lldd_%=', '.Lldn_%=:']
+
+
 def kernel_body():
     h = handlers()
     ids = sorted(h)
@@ -515,6 +541,7 @@ def kernel_body():
     # streaming (non-temporal) loads and stores when the host says so (flags bit 0 / 1: states far bigger than the
     # caches; +10-15 % on the memory side, tools/experiments/mb_wavetile.hip), plain ones otherwise (small states live in
     # the Infinity Cache between passes; the pass that reads ONE shared input state relies on the L2)
+    text += zext_load('%[inb]', LLD)
     text += ['s_bitcmp1_b32 %[flags], 0', 's_cbranch_scc0 .Lldp_%='] + gray_walk('load', '%[inb]', LLD, nt=True) + ['s_branch .Lldd_%=', '.Lldp_%=:']
     text += gray_walk('load', '%[inb]', LLD) + ['.Lldd_%=:']
     text += [f's_getpc_b64 {TABLE}', '.Lanchor_%=:', 's_add_u32 s54, s54, .Ltable_%=-.Lanchor_%=', 's_addc_u32 s55, s55, 0',
