@@ -749,8 +749,10 @@ class DistributedQubitCircuit(QubitCircuit):
                 old = self.init_state._buffers['amps']
                 self.init_state = DistributedQubitState(self.nqubit, batch, device=old.device, dtype=old.dtype)
             self.init_state.reset()
+            fresh = True
         else:
             self.init_state = state
+            fresh = False
         with torch.enable_grad():
             self.encode(data)
         touched = self._precompute_matrices()
@@ -759,7 +761,7 @@ class DistributedQubitCircuit(QubitCircuit):
             # (only a no-grad forward reads the values: the adjoint `expectation()` of a training step never does)
             ez = masks if (masks and len(masks) <= 64 and executor.CONFIG['fused_expectation']
                            and not torch.is_grad_enabled()) else None
-            self.state = dist_run(self.init_state, self.operators, keep_layout=self.lazy_layout, expect_z=ez)
+            self.state = dist_run(self.init_state, self.operators, keep_layout=self.lazy_layout, expect_z=ez, fresh_zero=fresh)
         finally:
             for g in touched:
                 g.__dict__['_precomputed'] = None

@@ -69,7 +69,7 @@ _SWEEP: dict = {'grads': None}
 
 #: statistics of the last ``dist_apply_prims`` call (bench / tests)
 LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_permutes': 0, 'permute_passes': 0,
-            'wire_bytes': 0, 'groups': 1, 'virtual_bits': 0, 'virtual_remaps': 0}
+            'wire_bytes': 0, 'groups': 1, 'virtual_bits': 0, 'virtual_remaps': 0, 'zero_shard_stretches': 0}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -291,9 +291,11 @@ def _rows_of(pending: Sequence[Prim], rows: slice, total: int) -> list[Prim]:
 
 
 def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: slice,
-              out_perm: Sequence[int] | None = None, expect_z: dict | None = None) -> bool:
+              out_perm: Sequence[int] | None = None, expect_z: dict | None = None, zero: bool = False) -> bool:
     """Fused local passes on rows ``rows`` of the shard ``a`` with the receive buffer ``b`` as the second buffer of the
-    permuted stores; afterwards local bit q sits at position out_perm[q].  Returns True if the result lives in ``b``."""
+    permuted stores; afterwards local bit q sits at position out_perm[q].  Returns True if the result lives in ``b``.
+    ``zero``: the rows are |0..0> (rank 0's shard right after ``reset()``): the first passes skip what is still known to be
+    zero (executor.CONFIG['zero_state'])."""
     total = a.shape[0]
     x, y = a[rows], b[rows]
     if _SWEEP['grads'] is not None:               # a stretch of a fused reverse sweep: reductions inside the passes
@@ -301,7 +303,7 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
                            grads=_SWEEP['grads'][rows])
     elif CONFIG['fold_permute'] or out_perm is None:
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel(),
-                           expect_z=expect_z)
+                           expect_z=expect_z, zero_state=zero)
     else:                                         # A/B: the re-labelling as a pass of its own
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y)
         if out.data_ptr() not in (x.data_ptr(), y.data_ptr()):
@@ -317,11 +319,12 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
 
 def _flush(state: DistributedQubitState, pending: list[Prim], expect_z: dict | None = None) -> None:
     _settle(state)
+    fresh = state.__dict__.pop('_fresh_zero', False)
     if not pending:
         return
     LAST_RUN['local_flushes'] += 1
     a, b = _view(state), _bview(state)
-    if _run_rows(a, b, pending, slice(0, a.shape[0]), expect_z=expect_z):
+    if _run_rows(a, b, pending, slice(0, a.shape[0]), expect_z=expect_z, zero=fresh and state.rank == 0):
         state.amps, state.buffer = state.buffer, state.amps
     pending.clear()
 
@@ -546,6 +549,11 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     a, b = _view(state), _bview(state)
     groups = _row_groups(state)
     streams = _group_streams(state, len(groups))
+    # the first stretch behind reset(): rank 0 holds |0..0> -- its first passes skip what is still known to be zero --
+    # and every other rank holds nothing but zeros, which stay zeros under any gates and in any layout: no pass at all
+    fresh = state.__dict__.pop('_fresh_zero', False) and not vb
+    if fresh and state.rank != 0:
+        LAST_RUN['zero_shard_stretches'] += 1
     inflight_prev = {id(st): (st, works) for st, works in state.__dict__.pop('_inflight', [])}
     inflight, landed_in_a = [], []
     if pending:
@@ -555,7 +563,11 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
             for w in inflight_prev.pop(id(stream), (None, []))[1]:    # this group's previous exchange
                 _wait(w, stream)
             t_start = _mark(stream)
-            in_b = _run_rows(a, b, pending, rows, None if identity else out_perm) if (pending or not identity) else False
+            if fresh and state.rank != 0:
+                in_b = False
+            else:
+                in_b = (_run_rows(a, b, pending, rows, None if identity else out_perm, zero=fresh)
+                        if (pending or not identity) else False)
             src, dst = (b, a) if in_b else (a, b)
             works = []
             if W > 1 and dist.is_initialized():
@@ -875,12 +887,19 @@ def _canonicalize(state: DistributedQubitState) -> DistributedQubitState:
 # public entry points
 def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None = None,
                      keep_layout: bool = False, force_mode: bool = False,
-                     expect_z: Sequence[int] | None = None) -> DistributedQubitState:
+                     expect_z: Sequence[int] | None = None, fresh_zero: bool = False) -> DistributedQubitState:
     """Apply kernel primitives (logical bit positions) to the sharded state, fusing local stretches.
     Unless ``keep_layout`` is set the canonical qubit order is restored before returning.  ``force_mode``: ``mode`` also
-    for short gate lists (which otherwise go gate by gate, pairwise exchanges)."""
+    for short gate lists (which otherwise go gate by gate, pairwise exchanges).  ``fresh_zero``: the caller has just
+    ``reset()`` the state -- it is |0..0>: rank 0 holds one 1, everybody else zeros -- and the first local stretch makes
+    use of it (`_remap`, `_flush`)."""
     with _raw(state):
-        return _dist_apply_prims(state, prims, mode, keep_layout, force_mode, expect_z)
+        if fresh_zero and executor.CONFIG['zero_state'] and _SWEEP['grads'] is None and _is_canonical(state):
+            state.__dict__['_fresh_zero'] = True
+        try:
+            return _dist_apply_prims(state, prims, mode, keep_layout, force_mode, expect_z)
+        finally:
+            state.__dict__.pop('_fresh_zero', None)
 
 
 def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None, keep_layout: bool,
@@ -899,6 +918,8 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
                    and state.log_num_amps_per_node - vb >= executor._geometry(state.amps.dtype == torch.complex128).m):
         vb = 0
     LAST_RUN['virtual_bits'] = vb
+    if vb or mode != 'remap':
+        state.__dict__.pop('_fresh_zero', None)       # (rows of an un-batched shard, gate-by-gate exchanges: not for them)
     if vb:
         _settle(state)
         state.__dict__['_vbits'] = vb
@@ -969,14 +990,14 @@ def dist_gate(state: DistributedQubitState, gate) -> DistributedQubitState:
 
 
 def dist_run(state: DistributedQubitState, operators, keep_layout: bool = False,
-             expect_z: Sequence[int] | None = None) -> DistributedQubitState:
+             expect_z: Sequence[int] | None = None, fresh_zero: bool = False) -> DistributedQubitState:
     """Whole circuit on the sharded state (reference: circuit.py:1655-1675).  ``keep_layout``: the qubits stay where
     the last remap put them; ``state.amps`` restores the reference's order when somebody reads it."""
     prims: list[Prim] = []
     for op in operators:
         prims.extend(op.prims(decompose=True))
     with torch.no_grad():
-        return dist_apply_prims(state, prims, keep_layout=keep_layout, expect_z=expect_z)
+        return dist_apply_prims(state, prims, keep_layout=keep_layout, expect_z=expect_z, fresh_zero=fresh_zero)
 
 
 def dist_swap_gate(state: DistributedQubitState, qb1: int, qb2: int) -> DistributedQubitState:

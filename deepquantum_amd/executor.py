@@ -503,7 +503,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         shared_in = None
         # |0..0> in: the masks of the index bits still known to be zero, per step (None: not applicable)
         zmasks = None
-        if zero_state and CONFIG['zero_state'] and CONFIG['fuse'] and not inplace and n >= m and plan.steps:
+        if zero_state and CONFIG['zero_state'] and CONFIG['fuse'] and n >= m and plan.steps:
             if plan._zero_masks is False:
                 plan._zero_masks = fusion.zero_state_masks(plan.steps, n)
             zmasks = plan._zero_masks
@@ -515,7 +515,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 and isinstance(plan.steps[0], fusion.FusedStep)):
             shared_in = state.detach()[:1]
             x = torch.empty(state.shape, dtype=state.dtype, device=state.device)
-        elif zmasks is not None and state.is_contiguous():
+        elif zmasks is not None and not inplace and state.is_contiguous():
             # the first pass reads the caller's |0..0> itself -- a few amplitudes of it -- and writes the working buffer: no copy
             shared_in = state.detach()
             x = torch.empty_like(shared_in)

@@ -401,6 +401,72 @@ def _case_grouped_exchange_w4(dq, rank, world):
     assert g_calls * 2 <= s_calls, (calls,)
 
 
+def _zero_state_check(dq, rank, world, n, batch, dtype=torch.complex64, device=None, depth=8):
+    """The first local stretch behind ``reset()``: rank 0 holds |0..0> and its first passes skip what is still known to be
+    zero (dq_apply_fused_zext_*), every other rank holds zeros and runs no pass at all.  On / off equality of the shards
+    and of <Z0>, against the dense circuit too."""
+    import bench
+    from deepquantum_amd import distributed as D
+    from deepquantum_amd import executor
+
+    spec = bench.random_circuit_spec(n, depth, seed=31)
+    dense, data = bench.build_circuit(dq, n, spec, batch, dtype, device or 'cpu')
+    with torch.no_grad():
+        ref = dense(data).reshape(-1, 1 << n)
+        ref_ev = dense.expectation()
+    per = (1 << n) // world
+    calls = {'zext': 0}
+    be = dq.backend.get_test_backend()
+    if be is not None and device is None:
+        inner = be.apply_fused
+
+        def counting(*a, **kw):
+            calls['zext'] += bool(kw.get('known_zero'))
+            return inner(*a, **kw)
+
+        be.apply_fused = counting
+    old = dict(executor.CONFIG)
+    executor.CONFIG['permute_min_bits'] = 12
+    try:
+        out = {}
+        for on in (True, False):
+            executor.CONFIG['zero_state'] = on
+            calls['zext'] = 0
+            cir, _ = bench.build_circuit(dq, n, spec, batch, dtype, device or 'cpu', distributed=True)
+            cir.lazy_layout = False
+            with torch.no_grad():
+                st = cir(data)
+                ev = cir.expectation()
+            stats = dict(D.LAST_RUN)
+            amps = st.amps.reshape(-1, per).clone()
+            out[on] = (amps, ev.clone())
+            assert stats['remaps'] >= 1, stats
+            if on:
+                assert stats['zero_shard_stretches'] == (1 if rank else 0), (rank, stats)
+                if be is not None and device is None:
+                    assert (calls['zext'] >= 1) == (rank == 0), (rank, calls)
+            else:
+                assert stats['zero_shard_stretches'] == 0 and calls['zext'] == 0
+            tol = 1e-10 if dtype == torch.complex128 else 2e-5
+            err = (amps - ref[:, rank * per:(rank + 1) * per].to(amps.device)).abs().max().item()
+            assert err < tol, f'rank {rank}, zero_state {on}: shard error {err}'
+            assert (ev.reshape(-1) - ref_ev.reshape(-1).to(ev.device)).abs().max().item() < 10 * tol
+        assert torch.equal(out[True][0], out[False][0]) or (out[True][0] - out[False][0]).abs().max().item() < 1e-6
+    finally:
+        executor.CONFIG.update(old)
+        if be is not None and device is None:
+            be.apply_fused = inner
+
+
+def _case_zero_state_w2(dq, rank, world):
+    _zero_state_check(dq, rank, world, 16, 3)
+    _zero_state_check(dq, rank, world, 15, None, dtype=torch.complex128)
+
+
+def _case_zero_state_w4(dq, rank, world):
+    _zero_state_check(dq, rank, world, 16, 2)
+
+
 def _golden_dist_check(dq, rank, world, names, device=None, tol=2e-5):
     """Shards, expectation values and adjoint gradients against what the REAL reference produced under the
     same number of gloo ranks (tests/golden/golden_dist.npz, made by make_golden_dist.py)."""
@@ -574,7 +640,8 @@ def _case_sampled_expectation_w4(dq, rank, world):
                                         ('random_remap_w4', 4), ('remap_w8', 8),
                                         ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4), ('folded_permute_w2', 2),
                                         ('golden_w2', 2), ('golden_w4', 4), ('golden_w8', 8),
-                                        ('fused_sweep_w2', 2), ('fused_sweep_w4', 4), ('grouped_exchange_w4', 4), ('virtual_bits_w2', 2), ('virtual_bits_w4', 4)])
+                                        ('fused_sweep_w2', 2), ('fused_sweep_w4', 4), ('grouped_exchange_w4', 4), ('virtual_bits_w2', 2), ('virtual_bits_w4', 4),
+                                        ('zero_state_w2', 2), ('zero_state_w4', 4)])
 def test_sharded_circuit(case, world):
     _run(case, world)
 

@@ -126,6 +126,16 @@ def _case_virtual_bits(dq, rank, world):
             D.CONFIG['virtual_bits'] = 0
 
 
+def _case_zero_state(dq, rank, world):
+    """The first local stretch behind ``reset()`` with the real kernels: rank 0's first passes skip what is still known
+    to be zero, the other ranks -- all zeros -- run no pass at all (tests/test_distributed_cpu.py, _zero_state_check)."""
+    from test_distributed_cpu import _zero_state_check
+
+    dev = torch.device('cuda', 0)
+    _zero_state_check(dq, rank, world, 21, 3, device=dev, depth=10)
+    _zero_state_check(dq, rank, world, 20, None, dtype=torch.complex128, device=dev, depth=10)
+
+
 def _case_batched_c128(dq, rank, world):
     """Batched shards with per-sample matrices, double precision, golden-style tolerance 1e-10."""
     import specs
@@ -374,6 +384,7 @@ def test_reference_dist_tests_on_gpu_world_of_one():
 
 @pytest.mark.parametrize('case,world', [('golden', 2), ('golden', 4), ('golden', 8), ('random_c64', 2), ('random_c64', 4), ('batched_c128', 4), ('adjoint_grad', 2),
                                         ('measure', 2), ('measure', 4), ('folded_permute', 2), ('folded_permute', 4),
-                                        ('fused_sweep', 2), ('fused_sweep', 4), ('virtual_bits', 2), ('virtual_bits', 4)])
+                                        ('fused_sweep', 2), ('fused_sweep', 4), ('virtual_bits', 2), ('virtual_bits', 4),
+                                        ('zero_state', 2), ('zero_state', 4)])
 def test_sharded_on_gpu(case, world):
     _run(case, world)
