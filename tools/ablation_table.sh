@@ -6,6 +6,7 @@ run() { tag=$1; shift; python bench.py --steps 3 --warmup 1 --no-cpu-baseline --
   python -c "import json;d=json.load(open('/tmp/abl_$tag.json'));r=d['roofline'];print('%-44s %7.1f ms/step  %2d passes  %6.2f ms/pass  %5.0f GB/s  %.3f of peak' % ('$tag', d['ms_per_step'], d['config']['fused_passes_per_step'], r['avg_launch_ms'], r['achieved'], r['frac']))" || tail -2 /tmp/abl_$tag.err; }
 echo "# headline workload (n=28, depth 40, c64, batch 16), 3 steps each, same box"
 run full_kernel
+run every_pass_moves_the_whole_state --no-zero-state
 DQ_WAVE_NT=0 run plain_loads_and_stores
 DQ_WAVE_NT=1 run streaming_loads_only
 DQ_WAVE_NT=2 run streaming_stores_only
