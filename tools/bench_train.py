@@ -18,6 +18,7 @@ ap.add_argument('--modes', default='adjoint,per_gate')
 ap.add_argument('--dtype', default='c64')
 ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--no-fused-sweep', action='store_true', help='A/B: the undo-then-reduce reverse sweep')
+ap.add_argument('--graph', action='store_true', help='also: the whole step captured as ONE HIP graph (dq.CapturedGraph) and replayed')
 args = ap.parse_args()
 
 dq.executor.CONFIG['fused_sweep'] = not args.no_fused_sweep
@@ -71,5 +72,24 @@ for mode in args.modes.split(','):
     print(f'{mode:9s} {sweep} n={args.n} depth={args.depth} ({args.n * args.depth} gates, {nrx} trainable) {args.dtype}: '
           f'step {dt * 1e3:8.1f} ms back to back, {lat * 1e3:6.1f} ms alone (no-grad forward {fwd * 1e3:6.1f} ms), peak {torch.cuda.max_memory_allocated() / sb:6.1f} states '
           f'= {torch.cuda.max_memory_allocated() / 2**30:6.1f} GiB')
+    if args.graph and mode == 'adjoint':
+        # the same step as one HIP graph: no host work between the kernels at all (what the device alone needs)
+        cir.zero_grad(set_to_none=True)
+
+        def gstep():
+            cir()
+            cir.expectation().sum().backward()
+
+        try:
+            graph = dq.CapturedGraph(gstep)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                graph.replay()
+            torch.cuda.synchronize()
+            print(f'          the step as ONE HIP graph: {(time.perf_counter() - t0) / args.reps * 1e3:8.1f} ms per replay')
+            del graph
+        except Exception as e:       # noqa: BLE001
+            print(f'          the step as ONE HIP graph: failed ({type(e).__name__}: {e})')
     del cir
     torch.cuda.empty_cache()
