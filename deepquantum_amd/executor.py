@@ -142,8 +142,9 @@ def _steady(prims: Sequence[Prim]) -> dict | None:
     if not CONFIG.get('steady_cache', True) or len(prims) < 16:
         return None
     key = tuple(map(id, prims))
-    if any(p.matrix is not None and torch.is_inference(p.matrix) for p in prims):
-        return None                       # (inference tensors track no version: nothing to key a cache on)
+    if any(p.matrix is not None and (torch.is_inference(p.matrix) or p.matrix.requires_grad) for p in prims):
+        return None                       # (inference tensors track no version: nothing to key a cache on; matrices of a
+                                          #  training step are new every time, and the entry would keep their graphs alive)
     try:
         versions = tuple(-1 if p.matrix is None else p.matrix._version for p in prims)
     except Exception:

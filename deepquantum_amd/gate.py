@@ -88,7 +88,9 @@ class DoubleControlGate(DoubleGate):
             return c[2]
         m = full[..., 2:4, 2:4]
         out = [Prim(self._sub_kind, m, self._bits([self.wires[1]]), self._bits([self.wires[0]]))]
-        d['_prims_cache'] = (full, list(self.wires), out, ver)
+        # (a matrix that carries an autograd graph is a new object every forward: keeping it would only keep that graph --
+        # and the AccumulateGrad nodes of its parameters, with the stream they were made on -- alive until the next one)
+        d['_prims_cache'] = None if full.requires_grad else (full, list(self.wires), out, ver)
         return out
 
     _sub_kind = 'gen'

@@ -189,7 +189,11 @@ class Gate(Operation):
         mode = self._kernel_mode if len(self.wires) == 1 else 0
         out = [Prim(self._kernel_kind, m, self._bits(self.wires), self._bits(self.controls), mode,
                     exact=getattr(self, '_exact_unitary', True))]
-        d['_prims_cache'] = (m, list(self.wires), list(self.controls), self.nqubit, out, ver)
+        # (not a matrix that carries an autograd graph: it is a new object every forward, and keeping it would keep its graph
+        # -- with the AccumulateGrad nodes of the parameters and the stream they were made on -- alive until the next forward,
+        # by which time the next graph has already picked the same nodes up: a training step captured into a HIP graph after
+        # eager steps on the default stream then drags the default stream into the capture)
+        d['_prims_cache'] = None if m.requires_grad else (m, list(self.wires), list(self.controls), self.nqubit, out, ver)
         return out
 
     def dm_prims(self, decompose: bool = True) -> list[Prim]:

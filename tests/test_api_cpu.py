@@ -547,3 +547,33 @@ def test_sharded_state_keeps_a_shard_of_another_shape(cpu_backend):
         assert lazy.amps.shape == (16,) and lazy.amps[0] == 1 and lazy.buffer.shape == (16,)
     finally:
         dq.DistributedQubitState.LAZY_AMPS = old
+
+
+def test_caches_do_not_keep_autograd_graphs_alive(cpu_backend):
+    """A matrix that carries an autograd graph is a new object every forward; a cache entry for it can never hit and would
+    only keep the graph -- and the parameters' AccumulateGrad nodes, with the stream they were made on -- alive until the
+    next forward has already built its graph on the same nodes (a training step captured into a HIP graph after eager
+    steps on the default stream then drags the default stream into the capture: tests/test_circuit_gpu.py)."""
+    from deepquantum_amd import executor
+
+    cir = dq.QubitCircuit(13)
+    for q in range(13):
+        cir.h(q)
+        cir.rx(q)
+        cir.cnot(q, (q + 1) % 13)
+        cir.ry(q)
+    cir.crx(0, 5)
+    cir.observable(0)
+    cir()
+    loss = cir.expectation().sum()
+    loss.backward()
+    for g in cir.modules():
+        c = g.__dict__.get('_prims_cache')
+        assert c is None or not c[0].requires_grad, type(g).__name__
+    for e in executor._STEADY.values():
+        assert not any(p.matrix is not None and p.matrix.requires_grad for p in e['prims'])
+    with torch.no_grad():                   # ... while fixed matrices are still served from the caches
+        cir()
+        a = [id(p) for p in cir.prims()]
+        cir()
+        assert a == [id(p) for p in cir.prims()]

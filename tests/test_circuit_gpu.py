@@ -426,6 +426,45 @@ def test_hip_graph_capture_of_forward_and_training_step(n):
             dq.executor.CONFIG['grad_mode'] = 'adjoint'
 
 
+@pytest.mark.parametrize('n', [12, 22])
+def test_training_step_captured_after_eager_steps_on_the_default_stream(n):
+    """What a user does: train eagerly for a while (default stream), then capture the step.  The gates used to keep the last
+    matrices -- with their autograd graphs -- in their primitive caches, so the parameters' AccumulateGrad nodes (made on
+    the default stream) lived on into the capture and dragged the legacy stream into it: hipStreamEndCapture died.
+    n = 22: the state is far beyond the launch-bound sizes (permuted stores, second buffer from the graph's pool)."""
+    torch.manual_seed(3)
+    train = _qml_circuit(n, trainable=True)
+    torch.manual_seed(3)
+    eager = _qml_circuit(n, trainable=True)
+
+    def step():
+        train()
+        loss = train.expectation().sum()
+        loss.backward()
+        return loss
+
+    for _ in range(3):                      # eager steps on the default stream, grads zeroed in place
+        train.zero_grad()
+        step()
+    with torch.no_grad():
+        train()                             # and a no-grad forward, as a validation loop would do
+    torch.cuda.synchronize()
+    for g in train.modules():               # nothing of those steps' graphs is kept by the gates
+        c = g.__dict__.get('_prims_cache')
+        assert c is None or not c[0].requires_grad
+    train.zero_grad(set_to_none=True)
+    graph = dq.CapturedGraph(step)
+    for p in train.parameters():
+        p.grad.zero_()
+    loss = graph.replay()
+    eager()
+    ref = eager.expectation().sum()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5
+    for p, q in zip(train.parameters(), eager.parameters(), strict=True):
+        assert (p.grad - q.grad).abs().max().item() < 1e-4
+
+
 def test_edge_cases_on_gpu():
     from _helpers import check_edge_cases
 

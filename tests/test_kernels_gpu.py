@@ -436,7 +436,7 @@ def test_structured_gate_bodies_match_oracle(is128, n, seed):
 
 
 @pytest.mark.parametrize('dtype', [torch.complex64, torch.complex128])
-@pytest.mark.parametrize('n,batch', [(5, 2), (11, 3), (12, 1), (13, 2), (17, 3), (22, 1)])
+@pytest.mark.parametrize('n,batch', [(5, 2), (11, 3), (12, 1), (13, 2), (17, 3), (20, 1)])
 def test_permute_bits_against_index_arithmetic(dtype, n, batch):
     """dq_permute_bits (the relayout before an all-to-all, the canonical order afterwards): out[i] = in[sigma(i)], every kernel
     variant -- per-element below 2^12, tiled with 16-byte pairs when bit 0 stays (complex64) and without, through LDS tiles

@@ -39,7 +39,7 @@ def wave_steps(ops, n, permute=False, is128=False):
 
 
 @PREC
-@pytest.mark.parametrize('n,ngates,seed', [(12, 60, 0), (13, 120, 1), (14, 200, 2), (15, 300, 3), (17, 300, 4), (20, 400, 5)])
+@pytest.mark.parametrize('n,ngates,seed', [(12, 60, 0), (13, 120, 1), (14, 200, 2), (15, 300, 3), (17, 300, 4), (19, 400, 5)])
 def test_wave_passes_match_oracle_in_place(n, ngates, seed, is128):
     ops, mats = random_ops(n, ngates, seed)
     mats = mats.to(cdtype(is128))
@@ -54,7 +54,7 @@ def test_wave_passes_match_oracle_in_place(n, ngates, seed, is128):
 
 
 @PREC
-@pytest.mark.parametrize('n,ngates,seed', [(14, 150, 5), (16, 260, 4), (18, 300, 6), (21, 500, 7)])
+@pytest.mark.parametrize('n,ngates,seed', [(14, 150, 5), (16, 260, 4), (18, 300, 6), (20, 400, 7)])
 def test_wave_passes_with_permuted_stores(n, ngates, seed, is128):
     """Out-of-place passes that re-label index bits on the way out (every tile after the first is contiguous on the
     read side, the low bits move too): the store layout is reached by a trip, a lane permutation or a slot swap."""
@@ -161,7 +161,7 @@ def test_z_string_expectations_from_the_registers_on_gpu(n, seed, is128):
 
 
 @PREC
-@pytest.mark.parametrize('n,ngates,seed,permute', [(12, 60, 0, False), (14, 150, 1, True), (17, 250, 2, True), (21, 400, 3, True)])
+@pytest.mark.parametrize('n,ngates,seed,permute', [(12, 60, 0, False), (14, 150, 1, True), (17, 250, 2, True), (20, 300, 3, True)])
 def test_two_target_dense_gates_on_the_wave_tile_kernel_on_gpu(n, ngates, seed, permute, is128):
     """4x4 gates on two register slots (DQ_FG_GEN2 on the wave-tile geometries; complex128: the matrix passes through the
     scalar registers two rows at a time) with controls of every kind, among one-target, X and diagonal gates, against the
