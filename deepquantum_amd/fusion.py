@@ -436,16 +436,23 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
     plans = [_plan_tiles(dag, set(range(L)), geom.m - L, geom.max_gates, width, geom.plan_branch, 20250929 + r, far,
                          free_low=L if free_low else 0) for r in range(restarts)]
     seen = []
+    best = None
     for plan in sorted(plans, key=len):
         if plan in seen:
             continue
+        if best is not None and len(plan) > len(best[1]):
+            break                       # (longer plans cannot give fewer passes)
         seen.append(plan)
         out = _schedule_planned(ops, n, geom, width, final_perm, free_low, list(plan))
         if out is not None:
-            return out
-        if len(seen) >= 4:
+            # among schedules of as many passes: the one that moves the least behind |0..0> (most circuits start there:
+            # `zero_state_masks`), then the one with the fewest layout changes
+            key = (len(out), zero_state_cost(out, n), sum(s_.ntranspose for s_ in out if isinstance(s_, FusedStep)))
+            if best is None or key < best[0]:
+                best = (key, out)
+        if len(seen) >= 4 and best is not None or len(seen) >= 8:
             break
-    return None
+    return None if best is None else best[1]
 
 
 def _schedule_planned(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int, final_perm: Sequence[int] | None,
@@ -909,6 +916,23 @@ def zero_state_masks(steps: Sequence, n: int) -> list[int] | None:
     if live != full:
         return None
     return masks if any(masks) else None
+
+
+def zero_state_cost(steps: Sequence, n: int) -> float:
+    """What the passes of a schedule move when the circuit starts from |0..0>, in units of a full pass (one read + one write
+    of the state): `zero_state_masks` says which index bits are still known to be zero at every pass."""
+    masks = zero_state_masks(steps, n)
+    if masks is None:
+        return float(len(steps))
+    cost = 0.0
+    for st, kz in zip(steps, masks):
+        if not kz:
+            cost += 1.0
+            continue
+        nz = bin(kz).count('1')
+        inside = sum(1 for i in range(st.desc.h) if (kz >> st.desc.high_pos[i]) & 1)
+        cost += (2.0 ** -nz + 2.0 ** -(nz - inside)) / 2
+    return cost
 
 
 def layout_matrices(steps: Sequence, ops: Sequence[PrimOp]) -> tuple[list[int], int]:
