@@ -192,3 +192,37 @@ def test_who_may_say_a_state_is_zero():
     assert cir.init_state.is_zero_state()
     cir.to(torch.double)
     assert cir.init_state.is_zero_state()
+
+
+def test_circuits_the_masks_do_not_apply_to_fall_back(cpu_backend):
+    """A qubit no gate ever touches (bits would be left at the end), and a gate that runs on its own while bits are left
+    (it reads the whole buffer): the step runs as if nobody knew about |0..0>, same results."""
+    old = dict(executor.CONFIG)
+    executor.CONFIG['permute_min_bits'] = 12
+    try:
+        for kind in ('untouched', 'single'):
+            res = []
+            for on in (True, False):
+                executor.CONFIG['zero_state'] = on
+                n = 14
+                cir = dq.QubitCircuit(n)
+                if kind == 'single':
+                    g = torch.Generator().manual_seed(1)
+                    u, _ = torch.linalg.qr(torch.randn(8, 8, generator=g, dtype=torch.complex64))
+                    cir.any(u, [0, 5, 9])                       # three targets: not a record of the pass kernel
+                for q in range(n - 1 if kind == 'untouched' else n):
+                    cir.h(q)
+                    cir.rx(q, inputs=0.1 * (q + 1))
+                for q in range(n - 2):
+                    cir.cnot(q, q + 1)
+                for q in range(n - 1 if kind == 'untouched' else n):
+                    cir.ry(q, inputs=0.2 * (q + 1))
+                cir.observable(1)
+                with torch.no_grad():
+                    out = cir().clone()
+                    res.append((out, cir.expectation().clone(), executor.LAST_RUN['zero_passes']))
+            assert res[0][2] == 0 and res[1][2] == 0, kind
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+            assert not torch.isnan(res[0][0].real).any()
+    finally:
+        executor.CONFIG.update(old)
