@@ -616,13 +616,13 @@ def main():
             line['config']['expectation_Z0_sample0'] = z0
         if distributed:
             per_step = {k: dstats[k] for k in ('remaps', 'folded_permutes', 'permute_passes', 'pairwise_exchanges')}
-            vb_early = dstats.get('virtual_bits', 0)
             wire = dstats['wire_bytes']
             links = min(7, world - 1)
             line['config']['exchange_per_step'] = per_step
             # the first local stretch behind reset(): rank 0 (this one) runs it with the known-zero masks, the other ranks --
             # all zeros -- not at all; --no-zero-state switches both off
-            line['config']['first_stretch_uses_the_zero_state'] = bool(dq.executor.CONFIG['zero_state'] and not vb_early)
+            line['config']['first_stretch_uses_the_zero_state'] = bool(dq.executor.CONFIG['zero_state'])
+            line['config']['zero_shard_stretches_rank0'] = dstats.get('zero_shard_stretches')
             # dry run of the exchange schedule (no data): steps that trade real rank bits / virtual ones, and how much
             # of the wire volume (in shards per rank) travels while other rows of the shard compute
             vb_ = dstats.get('virtual_bits', 0)

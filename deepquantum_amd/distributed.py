@@ -320,6 +320,7 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
 def _flush(state: DistributedQubitState, pending: list[Prim], expect_z: dict | None = None) -> None:
     _settle(state)
     fresh = state.__dict__.pop('_fresh_zero', False)
+    state.__dict__.pop('_zero_shard', None)      # (a shard of zeros runs its passes here like anybody: zeros in, zeros out)
     if not pending:
         return
     LAST_RUN['local_flushes'] += 1
@@ -551,8 +552,12 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     streams = _group_streams(state, len(groups))
     # the first stretch behind reset(): rank 0 holds |0..0> -- its first passes skip what is still known to be zero --
     # and every other rank holds nothing but zeros, which stay zeros under any gates and in any layout: no pass at all
-    fresh = state.__dict__.pop('_fresh_zero', False) and not vb
-    if fresh and state.rank != 0:
+    # (with virtual rank bits the rows of rank 0's shard are |0..0> and zeros: the masks hold for both; the other ranks
+    # have skipped every stretch since reset() -- `_remap_virtual` -- and receive their first amplitudes now)
+    fresh = state.__dict__.pop('_fresh_zero', False)
+    zeros = state.rank != 0 and (fresh or state.__dict__.pop('_zero_shard', False))
+    state.__dict__.pop('_zero_shard', None)
+    if zeros:
         LAST_RUN['zero_shard_stretches'] += 1
     inflight_prev = {id(st): (st, works) for st, works in state.__dict__.pop('_inflight', [])}
     inflight, landed_in_a = [], []
@@ -563,7 +568,7 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
             for w in inflight_prev.pop(id(stream), (None, []))[1]:    # this group's previous exchange
                 _wait(w, stream)
             t_start = _mark(stream)
-            if fresh and state.rank != 0:
+            if zeros:
                 in_b = False
             else:
                 in_b = (_run_rows(a, b, pending, rows, None if identity else out_perm, zero=fresh)
@@ -642,12 +647,20 @@ def _remap_virtual(state: DistributedQubitState, pairs, pending: list[Prim]) -> 
         for lq, eq in pairs:
             assert L - vb <= ph[lq] < L and ph[eq] < L - vb
             out_perm[ph[lq]], out_perm[ph[eq]] = ph[eq], ph[lq]
-        local = [q for q in (_localize(state, p) for p in pending) if q is not None]
+        # behind reset(): rank 0's shard is |0..0> (the first stretch runs with the known-zero masks), everybody else's is
+        # all zeros and stays so -- under any gates, in any order of the index bits -- until the first REAL exchange
+        fresh = state.__dict__.pop('_fresh_zero', False)
+        zeros = state.rank != 0 and (fresh or state.__dict__.get('_zero_shard', False))
         if pending:
             LAST_RUN['local_flushes'] += 1
-        a, b = _view(state), _bview(state)
-        if _run_rows(a, b, local, slice(0, a.shape[0]), out_perm):
-            state.amps, state.buffer = state.buffer, state.amps
+        if zeros:
+            state.__dict__['_zero_shard'] = True
+            LAST_RUN['zero_shard_stretches'] += 1
+        else:
+            local = [q for q in (_localize(state, p) for p in pending) if q is not None]
+            a, b = _view(state), _bview(state)
+            if _run_rows(a, b, local, slice(0, a.shape[0]), out_perm, zero=fresh):
+                state.amps, state.buffer = state.buffer, state.amps
         pending.clear()
         LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
         for lq, eq in pairs:
@@ -900,6 +913,7 @@ def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: 
             return _dist_apply_prims(state, prims, mode, keep_layout, force_mode, expect_z)
         finally:
             state.__dict__.pop('_fresh_zero', None)
+            state.__dict__.pop('_zero_shard', None)
 
 
 def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None, keep_layout: bool,
@@ -918,8 +932,8 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
                    and state.log_num_amps_per_node - vb >= executor._geometry(state.amps.dtype == torch.complex128).m):
         vb = 0
     LAST_RUN['virtual_bits'] = vb
-    if vb or mode != 'remap':
-        state.__dict__.pop('_fresh_zero', None)       # (rows of an un-batched shard, gate-by-gate exchanges: not for them)
+    if mode != 'remap':
+        state.__dict__.pop('_fresh_zero', None)       # (gate-by-gate exchanges: not for them)
     if vb:
         _settle(state)
         state.__dict__['_vbits'] = vb

@@ -357,6 +357,11 @@ def _virtual_bits_check(dq, rank, world, n, double):
         if st_['remaps'] > st_['virtual_remaps']:         # a remap of real rank bits only: the rows move in groups
             assert st_['groups'] == min(4, 1 << vb), st_
     assert stats[(0, True)]['virtual_bits'] == 0 and stats[(0, True)]['virtual_remaps'] == 0
+    # behind reset() every rank but the first holds zeros until the first exchange of REAL rank bits: it runs none of the
+    # stretches before it, however many re-labellings of virtual bits come first
+    for key, st_ in stats.items():
+        if st_['remaps'] > st_['virtual_remaps']:
+            assert (st_['zero_shard_stretches'] >= 1) == (rank != 0), (key, rank, st_)
 
 
 def _case_virtual_bits_w2(dq, rank, world):
