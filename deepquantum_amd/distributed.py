@@ -69,7 +69,8 @@ _SWEEP: dict = {'grads': None}
 
 #: statistics of the last ``dist_apply_prims`` call (bench / tests)
 LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_permutes': 0, 'permute_passes': 0,
-            'wire_bytes': 0, 'groups': 1, 'virtual_bits': 0, 'virtual_remaps': 0, 'zero_shard_stretches': 0}
+            'wire_bytes': 0, 'groups': 1, 'virtual_bits': 0, 'virtual_remaps': 0, 'zero_shard_stretches': 0,
+            'known_zero_stretches': 0}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -321,11 +322,13 @@ def _flush(state: DistributedQubitState, pending: list[Prim], expect_z: dict | N
     _settle(state)
     fresh = state.__dict__.pop('_fresh_zero', False)
     state.__dict__.pop('_zero_shard', None)      # (a shard of zeros runs its passes here like anybody: zeros in, zeros out)
+    kz = state.__dict__.pop('_known_zero_local', 0)
     if not pending:
         return
     LAST_RUN['local_flushes'] += 1
+    LAST_RUN['known_zero_stretches'] += bool(kz)
     a, b = _view(state), _bview(state)
-    if _run_rows(a, b, pending, slice(0, a.shape[0]), expect_z=expect_z, zero=fresh and state.rank == 0):
+    if _run_rows(a, b, pending, slice(0, a.shape[0]), expect_z=expect_z, zero=(fresh and state.rank == 0) or kz):
         state.amps, state.buffer = state.buffer, state.amps
     pending.clear()
 
@@ -557,8 +560,12 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     fresh = state.__dict__.pop('_fresh_zero', False)
     zeros = state.rank != 0 and (fresh or state.__dict__.pop('_zero_shard', False))
     state.__dict__.pop('_zero_shard', None)
+    kz = state.__dict__.pop('_known_zero_local', 0)
+    first_exchange = state.__dict__.pop('_behind_reset', False)
     if zeros:
         LAST_RUN['zero_shard_stretches'] += 1
+    elif pending:
+        LAST_RUN['known_zero_stretches'] += bool(kz)
     inflight_prev = {id(st): (st, works) for st, works in state.__dict__.pop('_inflight', [])}
     inflight, landed_in_a = [], []
     if pending:
@@ -571,7 +578,7 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
             if zeros:
                 in_b = False
             else:
-                in_b = (_run_rows(a, b, pending, rows, None if identity else out_perm, zero=fresh)
+                in_b = (_run_rows(a, b, pending, rows, None if identity else out_perm, zero=fresh or kz)
                         if (pending or not identity) else False)
             src, dst = (b, a) if in_b else (a, b)
             works = []
@@ -618,6 +625,12 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
         LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
     LAST_RUN['groups'] = len(groups)
     _remap_bookkeeping(ph, pairs, rbits, out_perm, L)
+    if first_exchange and W > 1 and dist.is_initialized():
+        # The first exchange behind reset(): only rank 0 had anything to send, so on every rank (and in every row) what
+        # arrived lies in chunk 0 and the other chunks hold the zeros the other ranks sent -- the qubits that came from
+        # the rank bits, now on the top k local bits, are still |0>, and the next stretch starts with their mask
+        # (executor.run(zero_state=mask): its first passes move 2^-k of the shard)
+        state.__dict__['_known_zero_local'] = ((1 << k) - 1) << (L - k)
 
 
 def _remap_bookkeeping(ph: list[int], pairs, rbits, out_perm, L: int) -> None:
@@ -650,6 +663,7 @@ def _remap_virtual(state: DistributedQubitState, pairs, pending: list[Prim]) -> 
         # behind reset(): rank 0's shard is |0..0> (the first stretch runs with the known-zero masks), everybody else's is
         # all zeros and stays so -- under any gates, in any order of the index bits -- until the first REAL exchange
         fresh = state.__dict__.pop('_fresh_zero', False)
+        kz = state.__dict__.pop('_known_zero_local', 0)      # (positions of a row: the same bits of the whole shard)
         zeros = state.rank != 0 and (fresh or state.__dict__.get('_zero_shard', False))
         if pending:
             LAST_RUN['local_flushes'] += 1
@@ -657,9 +671,10 @@ def _remap_virtual(state: DistributedQubitState, pairs, pending: list[Prim]) -> 
             state.__dict__['_zero_shard'] = True
             LAST_RUN['zero_shard_stretches'] += 1
         else:
+            LAST_RUN['known_zero_stretches'] += bool(kz)
             local = [q for q in (_localize(state, p) for p in pending) if q is not None]
             a, b = _view(state), _bview(state)
-            if _run_rows(a, b, local, slice(0, a.shape[0]), out_perm, zero=fresh):
+            if _run_rows(a, b, local, slice(0, a.shape[0]), out_perm, zero=fresh or kz):
                 state.amps, state.buffer = state.buffer, state.amps
         pending.clear()
         LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
@@ -909,11 +924,12 @@ def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: 
     with _raw(state):
         if fresh_zero and executor.CONFIG['zero_state'] and _SWEEP['grads'] is None and _is_canonical(state):
             state.__dict__['_fresh_zero'] = True
+            state.__dict__['_behind_reset'] = True      # (until the first exchange of real rank bits)
         try:
             return _dist_apply_prims(state, prims, mode, keep_layout, force_mode, expect_z)
         finally:
-            state.__dict__.pop('_fresh_zero', None)
-            state.__dict__.pop('_zero_shard', None)
+            for key in ('_fresh_zero', '_zero_shard', '_behind_reset', '_known_zero_local'):
+                state.__dict__.pop(key, None)
 
 
 def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: str | None, keep_layout: bool,
@@ -934,6 +950,7 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
     LAST_RUN['virtual_bits'] = vb
     if mode != 'remap':
         state.__dict__.pop('_fresh_zero', None)       # (gate-by-gate exchanges: not for them)
+        state.__dict__.pop('_behind_reset', None)
     if vb:
         _settle(state)
         state.__dict__['_vbits'] = vb

@@ -250,11 +250,13 @@ def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
 
 def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
         out_perm: Sequence[int] | None = None, amps: int | None = None, grads: torch.Tensor | None = None,
-        expect_z: dict | None = None, zero_state: bool = False) -> torch.Tensor:
+        expect_z: dict | None = None, zero_state: bool | int = False) -> torch.Tensor:
     """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state.
 
     ``zero_state``: the caller vouches that ``state`` is |0..0> (every row; ``QubitState.is_zero_state``) -- the first
-    passes then skip what is known to be zero (CONFIG['zero_state']).
+    passes then skip what is known to be zero (CONFIG['zero_state']).  An int (in-place runs of the sharded state only):
+    the mask of the index bits that are known to be |0> in an otherwise arbitrary state whose memory holds real zeros
+    there (a shard after its first exchange).
 
     ``scratch`` (no-grad runs): a second buffer like ``state`` that the passes may ping-pong with (permuted stores
     without an allocation; the sharded state passes its receive buffer) -- the result then lives in ``state`` OR in
@@ -466,7 +468,7 @@ def _permute_after(x: torch.Tensor, out_perm: Sequence[int], scratch: torch.Tens
 
 def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
                 out_perm: Sequence[int] | None = None, grads: torch.Tensor | None = None,
-                amps: int | None = None, zero_state: bool = False) -> torch.Tensor:
+                amps: int | None = None, zero_state: bool | int = False) -> torch.Tensor:
     """``grads``: the accumulator of the 'grad' prims (the reverse sweep of ``_AdjointCircuit``; complex64, n >= a tile).
     ``zero_state``: ``state`` is |0..0> (see ``run``)."""
     n = state.shape[-1].bit_length() - 1
@@ -505,9 +507,17 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         # |0..0> in: the masks of the index bits still known to be zero, per step (None: not applicable)
         zmasks = None
         if zero_state and CONFIG['zero_state'] and CONFIG['fuse'] and n >= m and plan.steps:
-            if plan._zero_masks is False:
-                plan._zero_masks = fusion.zero_state_masks(plan.steps, n)
-            zmasks = plan._zero_masks
+            if zero_state is True:
+                if plan._zero_masks is False:
+                    plan._zero_masks = fusion.zero_state_masks(plan.steps, n)
+                zmasks = plan._zero_masks
+            else:                   # some index bits known to be |0> (the memory there holds real zeros)
+                assert inplace, 'a mask of known-zero bits comes with an in-place run'
+                key = ('kz', int(zero_state))
+                cache = plan.__dict__.setdefault('_kz_masks', {})
+                if key not in cache:
+                    cache[key] = fusion.zero_state_masks(plan.steps, n, int(zero_state))
+                zmasks = cache[key]
             if zmasks is not None and grads is not None and any(
                     zk and any(plan.prim_ops[oi].kind in ('grad', 'expz') for oi in st.ops)
                     for zk, st in zip(zmasks, plan.steps) if isinstance(st, fusion.FusedStep)):

@@ -881,7 +881,7 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
         g.loc = 1 if op.mode == 1 else 0      # promised real (and usually sparse): channel superoperators
 
 
-def zero_state_masks(steps: Sequence, n: int) -> list[int] | None:
+def zero_state_masks(steps: Sequence, n: int, known_zero: int | None = None) -> list[int] | None:
     """The passes of a schedule run on the initial state |0..0> (the reference's default, circuit.py:49): an index bit no
     pass has had in its tile yet still factors out as |0>, so the state is zero wherever such a bit is 1 -- nothing there
     has to be read, computed or written (include/dq_hip.h, dq_apply_fused_zext_*).  Returns, per step, the mask of
@@ -891,9 +891,13 @@ def zero_state_masks(steps: Sequence, n: int) -> list[int] | None:
     a lane loads them in one piece, and they are in every tile from the first pass on (whose input is a real state).
 
     For the 28-qubit headline circuit: pass 0 touches one tile per sample, pass 1 2^8 of the 2^16, pass 2 reads 2^-8 of
-    the state and writes all of it -- three of nineteen passes for the price of one pass's stores."""
-    live = 0                        # index bits (positions on the read side of the next step) that may be non-zero
+    the state and writes all of it -- three of nineteen passes for the price of one pass's stores.
+
+    ``known_zero``: not |0..0> but a state in which THESE index bits (positions before the first step) are known to be
+    |0> -- a shard right after its first exchange: the qubits that came from the rank bits (`distributed._remap`)."""
     full = (1 << n) - 1
+    # index bits (positions on the read side of the next step) that may be non-zero
+    live = 0 if known_zero is None else full & ~known_zero
     masks: list[int] = []
     for st in steps:
         if live == full:

@@ -448,10 +448,13 @@ def _zero_state_check(dq, rank, world, n, batch, dtype=torch.complex64, device=N
             assert stats['remaps'] >= 1, stats
             if on:
                 assert stats['zero_shard_stretches'] == (1 if rank else 0), (rank, stats)
+                # ... and behind the first exchange EVERY rank knows that the qubits that came from the rank bits are still
+                # |0>: the stretch after it starts with their mask
+                assert stats['known_zero_stretches'] == 1, (rank, stats)
                 if be is not None and device is None:
-                    assert (calls['zext'] >= 1) == (rank == 0), (rank, calls)
+                    assert calls['zext'] >= 1, (rank, calls)
             else:
-                assert stats['zero_shard_stretches'] == 0 and calls['zext'] == 0
+                assert stats['zero_shard_stretches'] == 0 and stats['known_zero_stretches'] == 0 and calls['zext'] == 0
             tol = 1e-10 if dtype == torch.complex128 else 2e-5
             err = (amps - ref[:, rank * per:(rank + 1) * per].to(amps.device)).abs().max().item()
             assert err < tol, f'rank {rank}, zero_state {on}: shard error {err}'
