@@ -496,6 +496,19 @@ def main():
         sync()
         unmerged_ms = (time.perf_counter() - t0) / 2 * 1e3
         dq.executor.CONFIG['merge_min_amps'] = keep
+    # the same step with every pass moving the whole state (the first passes behind |0..0> read, compute and write what is
+    # known to be zero, as the reference does): the A/B figure next to `ms_per_step`
+    whole_state_ms = None
+    if extras and not distributed and dq.executor.CONFIG['zero_state']:
+        dq.executor.CONFIG['zero_state'] = False
+        step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        sync()
+        whole_state_ms = (time.perf_counter() - t0) / 3 * 1e3
+        dq.executor.CONFIG['zero_state'] = True
     copy_gbs = device_copy_bandwidth(device) if rank == 0 else None
     sweep = None
     if extras and not args.no_sweep and n >= 13:
@@ -570,6 +583,8 @@ def main():
                 # `value` counts the circuit's gates, `unmerged_ms_per_step` times them one by one
                 'kernel_gates_per_step': stats.get('gates') if not distributed else None,
                 'unmerged_ms_per_step': unmerged_ms,
+                # ... and with every pass moving the whole state (executor.CONFIG['zero_state'] off; merged gates)
+                'ms_per_step_every_pass_moves_the_whole_state': whole_state_ms,
                 # what a ONE-SHOT run pays on top of a steady-state step: the pass planner (host, once per circuit
                 # structure, cached afterwards) and the whole first step including it and the allocations
                 'plan_seconds': plan_s,
