@@ -50,6 +50,7 @@ class Plan:
     _rx_index: dict | None = None          # ... as a LongTensor per device
     _scale_cache: dict | None = None       # complex128 reverse sweeps: which scalar gates run before which reduction
     _zero_masks: Any = False               # fusion.zero_state_masks of the steps (False: not computed yet)
+    _kz_masks: dict | None = None          # ... for a given mask of index bits known to be |0> at the start (sharded state)
 
 
 _PLAN_CACHE: OrderedDict = OrderedDict()
@@ -513,11 +514,12 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 zmasks = plan._zero_masks
             else:                   # some index bits known to be |0> (the memory there holds real zeros)
                 assert inplace, 'a mask of known-zero bits comes with an in-place run'
-                key = ('kz', int(zero_state))
-                cache = plan.__dict__.setdefault('_kz_masks', {})
-                if key not in cache:
-                    cache[key] = fusion.zero_state_masks(plan.steps, n, int(zero_state))
-                zmasks = cache[key]
+                if plan._kz_masks is None:
+                    plan._kz_masks = {}
+                key = int(zero_state)
+                if key not in plan._kz_masks:
+                    plan._kz_masks[key] = fusion.zero_state_masks(plan.steps, n, key)
+                zmasks = plan._kz_masks[key]
             if zmasks is not None and grads is not None and any(
                     zk and any(plan.prim_ops[oi].kind in ('grad', 'expz') for oi in st.ops)
                     for zk, st in zip(zmasks, plan.steps) if isinstance(st, fusion.FusedStep)):
