@@ -76,19 +76,20 @@ class QubitState(_ComplexBuffers):
 
     # |0..0> (or |0..0><0..0|) as made by the constructor is worth knowing to the executor: the first fused passes of a
     # circuit skip everything that is still known to be zero (executor.CONFIG['zero_state']).  The mark names the buffer
-    # tensor (weakly) and its version counter, so writing into the buffer or replacing it ends it.
+    # tensor (weakly), its version counter and its storage, so writing into the buffer or replacing it ends it.
     def _mark_zero_state(self) -> None:
         import weakref
 
         t = self._buffers['state']
-        self.__dict__['_zero_mark'] = (weakref.ref(t), tensor_version(t))
+        self.__dict__['_zero_mark'] = (weakref.ref(t), tensor_version(t), t.data_ptr())
 
     def is_zero_state(self) -> bool:
         """True while ``state`` is still the |0..0> the constructor made (``state='zeros'``), on whatever device / in
         whatever precision ``.to()`` has put it since."""
         mark = self.__dict__.get('_zero_mark')
         t = self._buffers.get('state')
-        return mark is not None and t is not None and mark[0]() is t and mark[1] is not None and mark[1] == tensor_version(t)
+        return (mark is not None and t is not None and mark[0]() is t and mark[1] is not None and mark[1] == tensor_version(t)
+                and mark[2] == t.data_ptr())
 
     def _apply(self, fn: Any, *args, **kwargs):
         was = self.is_zero_state()

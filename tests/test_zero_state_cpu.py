@@ -183,6 +183,9 @@ def test_who_may_say_a_state_is_zero():
     qs2 = dq.QubitState(4)
     qs2.state = torch.zeros(16, 1, dtype=torch.cfloat)        # replaced
     assert not qs2.is_zero_state()
+    qs4 = dq.QubitState(4)
+    qs4.state.data = torch.ones(16, 1, dtype=torch.cfloat)   # (no version bump, but another storage)
+    assert not qs4.is_zero_state()
     with torch.inference_mode():
         qs3 = dq.QubitState(3)
     assert not qs3.is_zero_state()                     # (an inference tensor has no version counter to watch)
