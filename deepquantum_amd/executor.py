@@ -88,6 +88,9 @@ CONFIG = {'fuse': True, 'min_low_c64': None, 'min_low_c128': None,
           'steady_cache': True,
           # states smaller than a tile: fuse (batch folded into the index, or zero-padded) from this many gates on
           'small_fuse_min_gates': 6,
+          # ... and their reverse sweeps run fused on the zero-padded (psi, lambda) pair (A/B switch; False: undo-then-reduce,
+          # a pass per circuit layer and a reduction launch per trainable gate)
+          'small_fused_sweep': True,
           # no-grad runs on states of at least this many amplitudes (batch included) multiply runs of one-qubit gates
           # on the same qubit into one matrix before planning (merge_one_qubit_runs); None = never
           'merge_min_amps': 1 << 27,
@@ -749,7 +752,10 @@ class _AdjointCircuit(torch.autograd.Function):
         # the sweep as fused passes: every gate one the pass kernel takes (at most two targets), the (psi, lambda) pair at
         # least a tile, every trainable gate on one target
         fusable = all(len(targets) <= 2 for _k, targets, _c, _m, _e in meta)
-        fused = CONFIG['fused_sweep'] and CONFIG['fuse'] and fusable and b <= backend.MAX_BATCH and n + 1 >= g_.m
+        # (a pair smaller than a tile is zero-padded to one, like the forward of such a state (`_run_small`): one launch
+        # with the reductions inside instead of a pass per circuit layer and a reduction kernel per trainable gate)
+        fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and fusable and b <= backend.MAX_BATCH
+                 and (n + 1 >= g_.m or (CONFIG['small_fused_sweep'] and len(meta) >= CONFIG['small_fuse_min_gates'])))
         if fused:
             # complex128: a matrix that is not computed from parameters or data may be unitary only to float32 rounding
             # (the reference's fixed matrices are, after .to(torch.double)): the sweep then tells U^-1 from U^dagger
@@ -840,6 +846,12 @@ class _AdjointCircuit(torch.autograd.Function):
         on both halves, and lambda -- the half with bit 0 set -- is multiplied by U^dagger U afterwards (``corr``, a
         gate controlled by bit 0): U^dagger lambda exactly, psi never drifts."""
         work = torch.stack([out, gy.to(out.dtype)], dim=-1).reshape(b, -1)        # bit 0: psi | lambda
+        pair = work.shape[-1]
+        tile = 1 << _geometry(out.dtype == torch.complex128).m
+        if pair < tile:                   # launch-bound sizes: |0..0> (x) the pair, the pad qubits are never touched
+            padded = work.new_zeros(b, tile)
+            padded[:, :pair] = work
+            work = padded
         rows: dict[int, int] = {}         # gate -> first accumulator row of its reduction records
         nrows = 0
         prims: list[Prim] = []
@@ -909,4 +921,4 @@ class _AdjointCircuit(torch.autograd.Function):
             logc = torch.log(2.0 * (s00.real * s00.real + s00.imag * s00.imag))
             g = g / torch.exp(before @ logc)[None, :, None, None]
         raw = {j: assemble_grad_sums(g, r, meta[j][0], len(meta[j][1])) for j, r in rows.items()}
-        return raw, lambda: work.reshape(b, -1, 2)[:, :, 1].contiguous()
+        return raw, lambda: work[:, :pair].reshape(b, -1, 2)[:, :, 1].contiguous()

@@ -149,7 +149,8 @@ class _Parametric:
         while isinstance(inputs, list):
             inputs = inputs[0]
         if inputs is None:
-            return torch.rand(1)[0] * 4 * torch.pi
+            # (= torch.rand(1)[0] * 4 * torch.pi to the last bit, same draw from the generator; two tiny ops instead of four)
+            return torch.rand(()).mul_(4 * torch.pi)
         return _as_param_tensor(inputs)
 
     # ``matrix`` is evaluated lazily: the reference recomputes it inside every ``init_para`` /
@@ -336,9 +337,9 @@ class U3Gate(ParametricSingleGate):
 
     def inputs_to_tensor(self, inputs: Any = None):
         if inputs is None:
-            theta = torch.rand(1)[0] * torch.pi
-            phi = torch.rand(1)[0] * 2 * torch.pi
-            lambd = torch.rand(1)[0] * 2 * torch.pi
+            theta = torch.rand(()).mul_(torch.pi)          # (the reference's torch.rand(1)[0] * .., bit for bit)
+            phi = torch.rand(()).mul_(2 * torch.pi)
+            lambd = torch.rand(()).mul_(2 * torch.pi)
         elif isinstance(inputs, torch.Tensor) and inputs.ndim == 2:  # (batch, 3): one triple per sample
             theta, phi, lambd = inputs.unbind(-1)
         else:

@@ -34,6 +34,9 @@ def tensor_version(t: torch.Tensor) -> int | None:
     return t._version
 
 
+_PLAIN_ATTRIBUTE_TYPES = frozenset((int, bool, float, str, list, tuple, dict, type(None)))
+
+
 class Operation(nn.Module):
     r"""A quantum operation on ``nqubit`` qubits acting on ``wires``.
 
@@ -55,6 +58,18 @@ class Operation(nn.Module):
         self.den_mat = den_mat
         self.tsr_mode = tsr_mode
         self.npara = 0
+
+    def __setattr__(self, name: str, value: Any) -> None:
+        # A gate is a module with a dozen plain attributes, and building circuits is part of what the reference's own
+        # benchmark times (examples/benchmarks/gradient_benchmark.py:127-144): numbers, strings, lists and None skip
+        # nn.Module's search for parameters / buffers / submodules (6 us per assignment) unless the name is one of those.
+        if type(value) in _PLAIN_ATTRIBUTE_TYPES:
+            d = self.__dict__
+            if name in d or not ('_parameters' in d and (name in d['_parameters'] or name in d['_buffers']
+                                                         or name in d['_modules'])):
+                object.__setattr__(self, name, value)
+                return
+        nn.Module.__setattr__(self, name, value)
 
     # ---- representations ----------------------------------------------------------------------------
     def tensor_rep(self, x: torch.Tensor) -> torch.Tensor:

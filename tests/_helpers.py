@@ -394,7 +394,8 @@ def check_grad_records(n, device, is128=False):
         assert np.abs(got[:, r_ + 1] - g).max() < (1e-12 if is128 else 2e-5) * max(1.0, np.abs(g).max()), (r_, ops[2 * r_ + 1])
 
 
-def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, tol=5e-5, dtype=torch.float32):
+def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, tol=5e-5, dtype=torch.float32,
+                             expect_fused=True):
     """Fuzz of the fused reverse sweep: a random sequence from the whole gate menu -- fixed, trainable and encoded
     (batched) gates, controls of every arity, diagonal and two-qubit gates in between -- differentiated by the fused
     sweep and by per-gate autograd."""
@@ -461,7 +462,7 @@ def check_fused_sweep_random(dq, device=None, n=13, batch=2, seed=0, ngates=90, 
             loss = (cir.expectation() * torch.tensor([1.0, -0.7], device=data.device, dtype=dtype)).sum()
             loss.backward()
             if mode == 'adjoint':
-                assert dq.executor.LAST_SWEEP['fused'] and dq.executor.LAST_SWEEP['reductions'] > 0
+                assert dq.executor.LAST_SWEEP['fused'] == expect_fused and dq.executor.LAST_SWEEP['reductions'] > 0
             results[mode] = (loss.detach().cpu(), data.grad.cpu() if cir.ndata else None,
                              [p.grad.cpu() for p in cir.parameters()])
         finally:

@@ -344,6 +344,23 @@ def test_fused_reverse_sweep_matches_per_gate_autograd(cpu_backend):
     check_fused_sweep(dq, n=10, batch=2, tol=1e-10, dtype=torch.float64)      # complex128: wave-tile geometry
 
 
+def test_fused_reverse_sweep_of_states_smaller_than_a_tile(cpu_backend):
+    """The (psi, lambda) pair of a state below a tile is zero-padded to one and swept fused (reference sweep:
+    adjoint.py:42-83; executor.CONFIG['small_fused_sweep'])."""
+    from _helpers import check_fused_sweep, check_fused_sweep_random
+
+    check_fused_sweep(dq, n=8, batch=2)
+    check_fused_sweep(dq, n=9, batch=1, tol=1e-10, dtype=torch.float64)
+    for seed, n in enumerate((3, 4, 6, 9)):
+        check_fused_sweep_random(dq, n=n, batch=1 + seed % 2, seed=seed, ngates=40)
+        check_fused_sweep_random(dq, n=n, batch=1 + seed % 2, seed=seed, ngates=40, tol=1e-10, dtype=torch.float64)
+    dq.executor.CONFIG['small_fused_sweep'] = False
+    try:
+        check_fused_sweep_random(dq, n=6, batch=2, seed=9, ngates=40, expect_fused=False)
+    finally:
+        dq.executor.CONFIG['small_fused_sweep'] = True
+
+
 @pytest.mark.parametrize('seed', [0, 1])
 def test_fused_reverse_sweep_on_random_circuits(cpu_backend, seed):
     from _helpers import check_fused_sweep_random

@@ -309,6 +309,27 @@ def test_fused_reverse_sweep_c128_on_gpu():
     check_fused_sweep(dq, device=dev(), n=20, batch=2, tol=1e-10, dtype=torch.float64)
 
 
+@pytest.mark.gpu
+def test_fused_reverse_sweep_of_states_smaller_than_a_tile():
+    """n + 1 < m: the (psi, lambda) pair is zero-padded to one tile and swept in fused passes with the reductions inside
+    (executor.CONFIG['small_fused_sweep']) instead of a pass per layer and a reduction launch per trainable gate: against
+    per-gate autograd and against the undo-then-reduce sweep, both precisions, with and without a batch."""
+    from _helpers import check_fused_sweep, check_fused_sweep_random
+
+    check_fused_sweep(dq, device=dev(), n=8, batch=2)
+    check_fused_sweep(dq, device=dev(), n=10, batch=1)
+    check_fused_sweep(dq, device=dev(), n=8, batch=3, tol=1e-10, dtype=torch.float64)
+    check_fused_sweep(dq, device=dev(), n=9, batch=1, tol=1e-10, dtype=torch.float64)
+    for seed, n in enumerate((3, 4, 6, 9)):
+        check_fused_sweep_random(dq, device=dev(), n=n, batch=1 + seed % 2, seed=seed, ngates=40)
+        check_fused_sweep_random(dq, device=dev(), n=n, batch=1 + seed % 2, seed=seed, ngates=40, tol=1e-10, dtype=torch.float64)
+    dq.executor.CONFIG['small_fused_sweep'] = False
+    try:
+        check_fused_sweep_random(dq, device=dev(), n=6, batch=2, seed=9, ngates=40, expect_fused=False)
+    finally:
+        dq.executor.CONFIG['small_fused_sweep'] = True
+
+
 @pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
 def test_fused_reverse_sweep_on_random_circuits_on_gpu(seed):
     from _helpers import check_fused_sweep_random
@@ -374,8 +395,9 @@ def _qml_circuit(n, trainable, seed=1234):
 
 @pytest.mark.parametrize('n', [7, 12])
 def test_hip_graph_capture_of_forward_and_training_step(n):
-    """Launch-bound sizes: the whole evaluation (and the whole forward + backward) replays as one HIP graph; n = 12:
-    the backward is the fused reverse sweep (dq_apply_fused_grad_c64) inside the captured graph."""
+    """Launch-bound sizes: the whole evaluation (and the whole forward + backward) replays as one HIP graph; the
+    backward is the fused reverse sweep (dq_apply_fused_grad_c64) inside the captured graph -- at n = 7 on the (psi, lambda)
+    pair zero-padded to one tile."""
     cir = _qml_circuit(n, trainable=False)
     data = torch.zeros(16, cir.ndata, device=dev())
     with torch.no_grad():
@@ -406,7 +428,7 @@ def test_hip_graph_capture_of_forward_and_training_step(n):
 
             train.zero_grad(set_to_none=True)
             graph = dq.CapturedGraph(step)
-            assert mode != 'adjoint' or dq.executor.LAST_SWEEP['fused'] == (n >= 11)
+            assert mode != 'adjoint' or dq.executor.LAST_SWEEP['fused']      # (n = 7: on the zero-padded pair)
             for it in range(2):
                 for p in train.parameters():
                     p.grad.zero_()

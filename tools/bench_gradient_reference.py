@@ -23,8 +23,10 @@ ap.add_argument('--trials', type=int, default=5)
 ap.add_argument('--no-hessian', action='store_true')
 ap.add_argument('--max-hessian-params', type=int, default=216)
 ap.add_argument('--device', default='cuda')
+ap.add_argument('--no-small-fused-sweep', action='store_true', help='A/B: reverse sweeps below a tile as undo-then-reduce')
 args = ap.parse_args()
 dev = torch.device(args.device)
+dq.executor.CONFIG['small_fused_sweep'] = not args.no_small_fused_sweep
 
 
 def circuit(n, layer):

@@ -43,8 +43,10 @@ def timeit(fn):
     return (time.perf_counter() - t0) / args.reps * 1e3
 
 
-for label, thresh in (('fused (small-state path)', 6), ('one launch per gate', 10**9)):
+for label, thresh, sweep in (('fused (small-state path)', 6, True), ('fused, sweep: undo-then-reduce', 6, False),
+                             ('one launch per gate', 10**9, True)):
     dq.executor.CONFIG['small_fuse_min_gates'] = thresh
+    dq.executor.CONFIG['small_fused_sweep'] = sweep      # the reverse sweep on the zero-padded (psi, lambda) pair
     cir = build(trainable=False)
     data = torch.rand(args.batch, cir.ndata, device='cuda') * 6.28
     with torch.no_grad():
@@ -72,6 +74,6 @@ for label, thresh in (('fused (small-state path)', 6), ('one launch per gate', 1
     cir3.zero_grad(set_to_none=True)
     gt = dq.CapturedGraph(step3)
     tr_g = timeit(gt.replay)
-    print(f'{label:26s} n={args.n} depth={args.depth} ({args.n * args.depth} gates) batch={args.batch}: '
+    print(f'{label:30s} n={args.n} depth={args.depth} ({args.n * args.depth} gates) batch={args.batch}: '
           f'no-grad forward+<Z0> {fwd:7.2f} ms eager / {fwd_g:6.3f} ms HIP graph (per-sample angles); '
           f'training step (batch 1, every Rx trainable) {tr:7.2f} ms eager / {tr_g:6.3f} ms HIP graph')
