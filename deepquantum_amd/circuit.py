@@ -276,14 +276,31 @@ class QubitCircuit(Operation):
         width = data.shape[-1]
         if not self.reupload:
             assert width >= self.ndata, 'The circuit needs more data, or consider data re-uploading'
+        # Differentiated data: the columns come from ONE unbind -- one autograd node whose backward stacks the gates'
+        # angle gradients in one kernel -- instead of a slice per layer and a slice per gate, whose backwards are a zero
+        # fill, a copy and an add EACH (the reference's gradient benchmark at n = 8, 4 layers: 207 of a gradient's 365
+        # launches).  Same views, same shapes, same values.
+        cols = data.unbind(-1) if (data.requires_grad and torch.is_grad_enabled() and width > 1) else None
+
+        def piece(src: torch.Tensor, a: int, b: int) -> torch.Tensor:      # src[..., a:b]
+            if cols is None or src is not data or b <= a:
+                return src[..., a:b]
+            return cols[a].unsqueeze(-1) if b - a == 1 else torch.stack(cols[a:b], dim=-1)
+
         count = 0
         for op in self.encoders:
             count_up = count + op.npara
+            src = data
             if self.reupload and count_up > width:
                 reps = int(np.ceil(count_up / width))
-                op.init_para(torch.cat([data] * reps, dim=-1)[..., count:count_up])
+                src = torch.cat([data] * reps, dim=-1)
+            if type(op).init_para is Layer.init_para and count_up <= src.shape[-1]:
+                at = count                 # (what Layer.init_para does with src[..., count:count_up], gate by gate)
+                for gate in op.gates:
+                    gate.init_para(piece(src, at, at + gate.npara))
+                    at += gate.npara
             else:
-                op.init_para(data[..., count:count_up])
+                op.init_para(piece(src, count, count_up))
             count = count_up % width
 
     # ---- read-out -----------------------------------------------------------------------------------

@@ -594,3 +594,42 @@ def test_caches_do_not_keep_autograd_graphs_alive(cpu_backend):
         a = [id(p) for p in cir.prims()]
         cir()
         assert a == [id(p) for p in cir.prims()]
+
+
+@pytest.mark.parametrize('batch', [None, 3])
+def test_gradient_with_respect_to_encoded_data_by_finite_differences(cpu_backend, batch):
+    """``encode`` hands the columns of differentiated data to the gates from one unbind (one autograd node, one kernel in
+    the backward) instead of a slice per layer and gate: gates of one and of three parameters, single encoder gates,
+    with and without data re-uploading (reference: circuit.py:265-293), against central differences in float64."""
+    for reupload, width in ((False, 4 * 3 + 4 + 1 + 3), (True, 5)):
+        cir = dq.QubitCircuit(4, reupload=reupload)
+        cir.hlayer()
+        cir.u3layer(encode=True)
+        cir.cnot_ring()
+        cir.rxlayer(encode=True)
+        cir.rzz([0, 2], encode=True)
+        cir.u3(1, encode=True)
+        cir.rylayer()
+        cir.observable(0)
+        cir.observable([1, 3], 'xz')
+        cir.to(torch.double)
+        g = torch.Generator().manual_seed(3)
+        shape = (width,) if batch is None else (batch, width)
+        data = torch.rand(shape, generator=g, dtype=torch.double) * 3.0
+
+        def f(x):
+            cir(data=x)
+            return (cir.expectation() * torch.tensor([1.0, -0.5], dtype=torch.double)).sum()
+
+        x = data.clone().requires_grad_(True)
+        f(x).backward()
+        num = torch.zeros_like(data)
+        flat = data.reshape(-1)
+        eps = 1e-6
+        with torch.no_grad():
+            for i in range(flat.numel()):
+                up, dn = flat.clone(), flat.clone()
+                up[i] += eps
+                dn[i] -= eps
+                num.reshape(-1)[i] = (f(up.reshape(shape)) - f(dn.reshape(shape))) / (2 * eps)
+        assert (x.grad - num).abs().max().item() < 1e-7, (reupload, (x.grad - num).abs().max())

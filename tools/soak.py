@@ -1,7 +1,9 @@
 """Randomised soak of the product path on the GPU, beyond what the test-suite runs every time: circuits over the whole
 gate vocabulary under every scheduler configuration against the oracle (tests/_helpers.check_fuzz_against_oracle) and
 fused reverse sweeps against per-gate autograd (check_fused_sweep_random), many seeds.
-usage (GPU box): python tools/soak.py [first_seed] [count]"""
+usage (GPU box): python tools/soak.py [first_seed] [count] [small]
+``small``: states below a tile only (n = 3 .. 11) -- the zero-padded forward and the reverse sweep on the zero-padded
+(psi, lambda) pair (executor.CONFIG['small_fused_sweep']), both precisions every seed."""
 import os
 import sys
 import time
@@ -16,8 +18,21 @@ from _helpers import check_fused_sweep_random, check_fuzz_against_oracle  # noqa
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+small = len(sys.argv) > 3 and sys.argv[3] == 'small'
 dev = torch.device('cuda', 0)
 t0 = time.time()
+for k in range(count if small else 0):
+    seed = first + k
+    n = 3 + seed % 9
+    check_fused_sweep_random(dq, device=dev, n=n, batch=1 + seed % 3, seed=seed, ngates=20 + 10 * (seed % 7))
+    check_fused_sweep_random(dq, device=dev, n=n, batch=1 + seed % 3, seed=seed, ngates=20 + 10 * (seed % 7), tol=1e-10,
+                             dtype=torch.float64)
+    if n >= 6:
+        check_fuzz_against_oracle(dq, device=dev, n=n, seeds=(seed,), depth=5 + seed % 4, batch=1 + seed % 3, double=(seed % 2 == 1))
+    print(f'seed {seed}: n = {n} ok ({time.time() - t0:.0f} s)', flush=True)
+if small:
+    print(f'{count} seeds from {first} (states below a tile): all agree')
+    sys.exit(0)
 for k in range(count):
     seed = first + k
     n = 13 + seed % 5
