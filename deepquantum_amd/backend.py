@@ -480,6 +480,25 @@ def unpack_axpby(
     return amps
 
 
+def defer_rx(flat: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """The deferred form of the uncontrolled Rx-like gates of complex64 passes (include/dq_hip.h, DQ_MODE_RX), in place in
+    the kernel matrix buffer ``flat`` (Bm, total): the blocks at the offsets ``index`` (LongTensor on the buffer's
+    device; fusion.rx_defer_positions).  One launch (dq_defer_rx_c64); `fusion.defer_rx` is the same rewrite in tensor
+    operations (tests and tools compare the two)."""
+    if index is None or index.numel() == 0:
+        return flat
+    if not _use_hip(flat):
+        return _test_backend.defer_rx(flat, index)
+    assert flat.dtype == torch.complex64 and flat.ndim == 2 and flat.stride(1) == 1 and index.dtype == torch.long
+    assert index.device == flat.device and index.is_contiguous()
+    lib = _lib.load()
+    for lo in range(0, flat.shape[0], MAX_BATCH):          # (the batch is a grid dimension)
+        rows = flat[lo : lo + MAX_BATCH]
+        _lib.check(lib.dq_defer_rx_c64(_ptr(rows), flat.stride(0), _ptr(index), index.numel(), rows.shape[0],
+                                       _stream(flat)), 'dq_defer_rx_c64')
+    return flat
+
+
 def permute_bits(amps: torch.Tensor, src_of_dst: Sequence[int], out: torch.Tensor | None = None) -> torch.Tensor:
     """out[b, i] = amps[b, sigma(i)], sigma(i) = sum_p bit_p(i) << src_of_dst[p]: re-label the local qubits
     (destination bit p takes the role of source bit src_of_dst[p]).  Out of place."""

@@ -358,3 +358,33 @@ extern "C" int dq_apply_fused_zext_c128(const void* in, int64_t in_batch_stride,
     }
     return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, in_batch_stride == 0, nullptr, -1, known_zero);
 }
+
+// ---- the deferred-Rx form of a pass's matrix buffer (DQ_MODE_RX, include/dq_hip.h) ----------------------------------
+// One thread per (sample, gate): the block { a, i b, -, - } of a matrix a I + i b X becomes { f, i t, -, flag }.  At
+// launch-bound sizes the same rewrite in tensor operations was 25 launches per pass sequence (50 of a gradient's 163).
+namespace dq {
+__global__ void defer_rx_kernel(float2* __restrict__ mats, int64_t bstride, const int64_t* __restrict__ index, int64_t count) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    float2* blk = mats + (int64_t)blockIdx.y * bstride + index[k];
+    const float a = blk[0].x, b = blk[1].y;
+    const bool form1 = fabsf(a) < fabsf(b);
+    // (IEEE divisions: the same quotients, bit for bit, as the element-wise tensor formulation this replaces)
+    const float t = form1 ? __fdiv_rn(-a, b) : __fdiv_rn(b, a);
+    blk[0] = form1 ? make_float2(0.0f, b) : make_float2(a, 0.0f);
+    blk[1] = make_float2(0.0f, t);
+    blk[3] = make_float2(form1 ? 1.0f : 0.0f, 0.0f);
+}
+}  // namespace dq
+
+extern "C" int dq_defer_rx_c64(void* mats, int64_t mat_batch_stride, const int64_t* index, int64_t count, int64_t batch,
+                               dq_stream_t stream) {
+    if (count == 0) return DQ_OK;
+    if (!mats || !index || count < 0 || batch < 1 || batch > 65535 || mat_batch_stride < 0) {
+        dq::set_error("dq_defer_rx_c64: bad argument");
+        return DQ_ERR_ARG;
+    }
+    hipLaunchKernelGGL(dq::defer_rx_kernel, dim3((unsigned)((count + 127) / 128), (unsigned)batch), dim3(128), 0,
+                       dq::as_stream(stream), static_cast<float2*>(mats), mat_batch_stride, index, count);
+    return dq::check_launch("dq_defer_rx_c64");
+}

@@ -549,7 +549,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 idx = plan._rx_index.get(x.device)
                 if idx is None:
                     idx = plan._rx_index[x.device] = torch.tensor(plan.rx_defer, dtype=torch.long, device=x.device)
-                fusion.defer_rx(flat, idx)
+                backend.defer_rx(flat, idx)
             if steady is not None:
                 steady['flat'] = {fkey: (plan, flat, stride)}       # (one buffer per entry: the latest shape)
         stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0, 'zero_passes': 0}

@@ -45,7 +45,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 22
+#define DQ_ABI_VERSION 23
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -242,6 +242,15 @@ int dq_dag_rank(void* dag, uint64_t tile, int cap, const int* indeg, const int* 
  * Returns the number of candidates (0 when the pass is full: *base >= cap). */
 int dq_dag_grow_step(void* dag, uint64_t tile, int cap, const int* indeg, const int* ready, int nready, int* base, int* cand_q,
                      int* cand_w, int* cand_count);
+
+/* The deferred form of the uncontrolled Rx-like gates of a complex64 pass (DQ_MODE_RX above), in place, in the matrix
+ * buffer the passes will read: for every sample b < batch and every k < count the block of four complex numbers at
+ * mats[b * mat_batch_stride + index[k]] -- { a, i b, i b, a } of the matrix a I + i b X -- becomes { f, i t, -, flag }.
+ * `index`: DEVICE array of int64 offsets (complex numbers), e.g. fusion.rx_defer_positions of a schedule.  One launch;
+ * host code that prepares matrix buffers for dq_apply_fused_c64 itself calls this instead of re-deriving the form
+ * (no reference counterpart: the reference multiplies by the full matrix, gate.py:1443-1448). */
+int dq_defer_rx_c64(void* mats, int64_t mat_batch_stride, const int64_t* index, int64_t count, int64_t batch,
+                    dq_stream_t stream);
 
 /* Test hook, no device needed: the kernel-side descriptor the library derives for a wave-tile pass (`pass`: HOST
  * pointer, complex64, m = 12, 6 slots) as raw bytes -- 80 bytes of slot offsets (load, store: 5 x 8 each), 6 + 6 + 6

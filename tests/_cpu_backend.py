@@ -267,6 +267,11 @@ class CpuTestBackend:
         out.copy_(torch.from_numpy(x))
         return out
 
+    def defer_rx(self, flat, index):
+        from deepquantum_amd import fusion
+
+        return fusion.defer_rx(flat, index)          # (the tensor formulation the kernel is tested against)
+
     # ---- reductions ---------------------------------------------------------------------------------
     def expect_pauli(self, state, xmask, zmask):
         n = state.shape[-1].bit_length() - 1

@@ -498,3 +498,32 @@ def test_reductions_and_relayout_at_full_size():
         backend.permute_bits(x, perm, out=a)
         backend.permute_bits(a, inv, out=b)
         assert torch.equal(b, x), perm
+
+
+@pytest.mark.parametrize('batch', [1, 5])
+def test_deferred_rx_blocks_bit_for_bit(batch):
+    """dq_defer_rx_c64 (one launch) against the same rewrite in tensor operations (fusion.defer_rx): every block
+    { f, i t, -, flag } of include/dq_hip.h's DQ_MODE_RX, both forms (|a| >= |b| and |a| < |b|), the rest of the buffer
+    untouched -- bit for bit."""
+    g = torch.Generator().manual_seed(11)
+    ngates, total = 300, 4 * 300 + 64
+    theta = torch.rand(batch, ngates, generator=g) * 12.566
+    theta[:, :4] = torch.tensor([0.0, torch.pi, torch.pi / 2, 3 * torch.pi / 2])       # a = +-1, b = 0 / a ~ 0 / |a| ~ |b|
+    flat = torch.randn(batch, total, 2, generator=g).view(torch.float32)
+    flat = torch.view_as_complex(flat.reshape(batch, total, 2).contiguous())
+    perm = torch.randperm(ngates + 10, generator=g)[:ngates] * 4                       # blocks in any order, with gaps
+    c, s = torch.cos(theta / 2), torch.sin(theta / 2)
+    for k in range(ngates):
+        o = int(perm[k])
+        flat[:, o] = torch.complex(c[:, k], torch.zeros(batch))
+        flat[:, o + 1] = torch.complex(torch.zeros(batch), -s[:, k])
+        flat[:, o + 2] = flat[:, o + 1]
+        flat[:, o + 3] = flat[:, o]
+    flat = flat.to(dev())
+    index = perm.to(torch.long).to(dev())
+    want = fusion.defer_rx(flat.clone(), index)
+    got = backend.defer_rx(flat.clone(), index)
+    assert torch.equal(torch.view_as_real(got), torch.view_as_real(want))
+    assert not torch.equal(torch.view_as_real(got), torch.view_as_real(flat))
+    flags = got[:, index + 3].real
+    assert 0 < flags.sum().item() < flags.numel()                                      # both forms occurred
