@@ -719,9 +719,15 @@ class _AdjointCircuit(torch.autograd.Function):
         if torch.is_grad_enabled():
             return _AdjointCircuit._backward_with_graph(ctx, gy)
         _state, out, *mats = ctx.saved_tensors
-        meta = ctx.meta
-        b = out.shape[0]
         need = [ctx.needs_input_grad[2 + j] for j in range(len(mats))]
+        gstate, grads = _AdjointCircuit._first_order(out, gy, ctx.meta, mats, ctx.needs_input_grad[0], need)
+        return (gstate, None, *grads)
+
+    @staticmethod
+    def _first_order(out, gy, meta, mats, need_state, need):
+        """The reverse sweep from the saved output: (cotangent of the input state or None, [cotangent of every matrix or
+        None]).  No graph is built (``backward`` of the circuit node; forward of ``_SweepGrads``)."""
+        b = out.shape[0]
         # Inverses / adjoints of ALL gates in a few vectorised calls (grouped by kind, size and batchness): at
         # launch-bound sizes a handful of tiny kernels per gate would dominate the whole sweep.
         groups: dict = {}
@@ -755,7 +761,8 @@ class _AdjointCircuit(torch.autograd.Function):
         # (a pair smaller than a tile is zero-padded to one, like the forward of such a state (`_run_small`): one launch
         # with the reductions inside instead of a pass per circuit layer and a reduction kernel per trainable gate)
         fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and fusable and b <= backend.MAX_BATCH
-                 and (n + 1 >= g_.m or (CONFIG['small_fused_sweep'] and len(meta) >= CONFIG['small_fuse_min_gates'])))
+                 and (n + 1 >= g_.m or (CONFIG['small_fused_sweep'] and len(meta) >= CONFIG['small_fuse_min_gates']))
+                 and not getattr(meta, 'tangent', False))     # (trainable gates that are not unitary: exact inverses only)
         if fused:
             # complex128: a matrix that is not computed from parameters or data may be unitary only to float32 rounding
             # (the reference's fixed matrices are, after .to(torch.double)): the sweep then tells U^-1 from U^dagger
@@ -782,8 +789,8 @@ class _AdjointCircuit(torch.autograd.Function):
                 g = g.to(mats[js[0]].dtype)         # one conversion for the group, not one per gate
             for k, j in enumerate(js):
                 grads[j] = g[k].to(mats[j].dtype).reshape(mats[j].shape)
-        gstate = lam() if ctx.needs_input_grad[0] else None
-        return (gstate, None, *grads)
+        gstate = lam() if need_state else None
+        return gstate, grads
 
     @staticmethod
     def _sweep_undo_reduce(out, gy, meta, undo, need, b):
