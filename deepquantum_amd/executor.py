@@ -91,6 +91,10 @@ CONFIG = {'fuse': True, 'min_low_c64': None, 'min_low_c128': None,
           # ... and their reverse sweeps run fused on the zero-padded (psi, lambda) pair (A/B switch; False: undo-then-reduce,
           # a pass per circuit layer and a reduction launch per trainable gate)
           'small_fused_sweep': True,
+          # backward of a circuit node under create_graph=True (Hessians): 'tangent' -- the sweep is a node whose own backward
+          # runs the tangent circuit (_SweepGrads: two sweeps per Hessian row); 'replay' -- the gates as per-gate nodes
+          # (two Python nodes per gate and row; always used where 'tangent' does not apply, and for third order)
+          'second_order': 'tangent',
           # no-grad runs on states of at least this many amplitudes (batch included) multiply runs of one-qubit gates
           # on the same qubit into one matrix before planning (merge_one_qubit_runs); None = never
           'merge_min_amps': 1 << 27,
@@ -109,7 +113,7 @@ PROFILE = {'enabled': False, 'events': []}
 # The most recent reverse sweep of _AdjointCircuit: which kind, how many fused passes / reduction records.
 LAST_SWEEP = {'fused': False, 'passes': 0, 'reductions': 0, 'with_graph': False}
 # How often a backward ran under create_graph=True and took the differentiable per-gate route (tests).
-GRAPH_BACKWARDS = {'count': 0}
+GRAPH_BACKWARDS = {'count': 0, 'tangent_rows': 0}     # backwards under create_graph; rows run by the tangent circuit
 
 # Host time spent in the pass planner (fusion.schedule; once per circuit structure, plans are cached) since import.
 PLAN_STATS = {'seconds': 0.0, 'plans': 0}
@@ -330,10 +334,12 @@ class _Meta(tuple):
     knows about the input state (``zero_state``: it is |0..0>)."""
 
     zero_state = False
+    tangent = False           # a tangent circuit (``_SweepGrads.backward``): trainable gates that are not unitary
 
-    def __new__(cls, items, zero_state: bool = False):
+    def __new__(cls, items, zero_state: bool = False, tangent: bool = False):
         self = super().__new__(cls, items)
         self.zero_state = bool(zero_state)
+        self.tangent = bool(tangent)
         return self
 
 
@@ -665,6 +671,108 @@ def assemble_grad_sums(g: torch.Tensor, row0: int, kind: str, ntargets: int) -> 
     return out
 
 
+class _SweepGrads(torch.autograd.Function):
+    """F(gy, state, U_1..U_K) = (U^dagger gy, [sum lambda_j (x) conj(psi_{j-1})]_j): the backward of a circuit node as a node
+    of its own, for ``create_graph=True``.  Forward: the (fused) reverse sweep, as in a first-order backward.  Backward --
+    one row of a Hessian: F is the gradient of Re<gy, U state>, so its vector-Jacobian product with cotangents (c_0, C_j) is
+    the gradient of Re<gy, alpha_K>, alpha_K = d/de U(U_j + e C_j)(state + e c_0) -- the output of the TANGENT CIRCUIT:
+    the pair (psi, alpha) as one state with one more qubit on top, gate j as the block matrix [[U_j, 0], [C_j, U_j]] on
+    (that qubit, the gate's targets), built from U_j and C_j by tensor operations.  One forward of that circuit gives
+    alpha_K (the cotangent of gy), one reverse sweep of it -- with exact inverses, the blocks are not unitary -- the
+    cotangents of the state and of every U_j (autograd reads them off the blocks): two circuit nodes per row instead of
+    two Python nodes per gate (reference: stock autograd through qmath.py:503-505, one node per gate and order).  Under
+    ``create_graph=True`` (third order) the backward differentiates the per-gate formulation instead."""
+
+    @staticmethod
+    def takes(meta, mats, need) -> bool:
+        # trainable gates: dense or diagonal matrices (a block on one more target must still be a gate the sweeps take)
+        return all(not nd or (kind in ('gen', 'diag') and len(t) <= 2) for (kind, t, _c, _m, _e), nd in zip(meta, need, strict=True))
+
+    @staticmethod
+    def forward(ctx, gy, state, out, meta, need_state, need, *mats):
+        with torch.no_grad():
+            gstate, grads = _AdjointCircuit._first_order(out, gy, meta, list(mats), need_state, list(need))
+        ctx.meta, ctx.need_state, ctx.need = meta, need_state, need
+        ctx.save_for_backward(gy, state, *mats)
+        res = ([gstate] if need_state else []) + [g for g in grads if g is not None]
+        return tuple(res)
+
+    @staticmethod
+    def _replay(gy, state, meta, mats, need_state, need):
+        """F by per-gate nodes (differentiable to any order)."""
+        mats = [m.view_as(m) if nd else m for m, nd in zip(mats, need, strict=True)]
+        wanted = ([state] if need_state else []) + [m for m, nd in zip(mats, need, strict=True) if nd]
+        x = state
+        for (_kind, targets, controls, _mode, _e), m in zip(meta, mats, strict=True):
+            x = ops.apply_gate(x, m, targets, controls)
+        return list(torch.autograd.grad(x, wanted, grad_outputs=gy.to(x.dtype), create_graph=True, allow_unused=True))
+
+    @staticmethod
+    def backward(ctx, *cots):
+        gy, state, *mats = ctx.saved_tensors
+        meta, need_state, need = ctx.meta, ctx.need_state, ctx.need
+        k = len(mats)
+        wants = ctx.needs_input_grad                 # (gy, state, out, meta, need_state, need, *mats)
+        if torch.is_grad_enabled():
+            # third order and beyond: differentiate the per-gate formulation of F
+            with torch.enable_grad():
+                outs = _SweepGrads._replay(gy, state, meta, mats, need_state, need)
+                pairs = [(o, c) for o, c in zip(outs, cots, strict=True) if o is not None and c is not None]
+                inputs = [gy, state] + list(mats)
+                sel = [i for i, t in enumerate(inputs) if wants[0 if i == 0 else (1 if i == 1 else 6 + i - 2)]]
+                got = torch.autograd.grad([o for o, _ in pairs], [inputs[i] for i in sel],
+                                          grad_outputs=[c for _, c in pairs], create_graph=True, allow_unused=True)
+            full = [None] * len(inputs)
+            for i, g in zip(sel, got, strict=True):
+                full[i] = g
+            return (full[0], full[1], None, None, None, None, *full[2:])
+        GRAPH_BACKWARDS['tangent_rows'] += 1
+        cots = list(cots)
+        c0 = cots.pop(0) if need_state else None
+        cmat = [cots.pop(0) if nd else None for nd in need]
+        b, dim = state.shape
+        n = dim.bit_length() - 1
+        dt = state.dtype
+        with torch.enable_grad():
+            state_l = state.detach().requires_grad_(bool(wants[1]))
+            mats_l = [m.detach().requires_grad_(bool(wants[6 + j])) for j, m in enumerate(mats)]
+            alpha0 = torch.zeros_like(state) if c0 is None else c0.to(dt).expand_as(state)
+            pair = torch.cat([state_l, alpha0], dim=-1)              # index bit n: psi | alpha
+            meta2 = [(kind, targets, controls, mode, True) for kind, targets, controls, mode, _e in meta]
+            mats2 = list(mats_l)              # (a gate without a cotangent: the same gate on both halves)
+            groups: dict = {}                 # the blocks [[U, 0], [C, U]] of all gates of one shape in a few calls
+            for j, ((kind, targets, _c, _m, _e), m) in enumerate(zip(meta, mats_l, strict=True)):
+                if cmat[j] is not None:
+                    nb = max(m.shape[0] if m.ndim == 3 else 1, cmat[j].shape[0] if cmat[j].ndim == 3 else 1)
+                    groups.setdefault((kind == 'diag', m.shape[-1], nb), []).append(j)
+            for (diag, d, nb), js in groups.items():
+                us = torch.stack([(mats_l[j] if mats_l[j].ndim == 3 else mats_l[j].unsqueeze(0)).to(dt).expand(nb, d, d)
+                                  for j in js])
+                cs = torch.stack([(cmat[j] if cmat[j].ndim == 3 else cmat[j].unsqueeze(0)).to(dt).expand(nb, d, d)
+                                  for j in js])
+                if diag:                      # (F's output for a diagonal gate has no off-diagonal entries)
+                    cs = torch.diag_embed(cs.diagonal(dim1=-2, dim2=-1))
+                top = torch.cat([us, torch.zeros_like(us)], dim=-1)
+                blk = torch.cat([top, torch.cat([cs, us], dim=-1)], dim=-2)     # on (bit n, the gate's targets)
+                parts = (blk if nb > 1 else blk[:, 0]).unbind(0)
+                for j, part in zip(js, parts, strict=True):
+                    meta2[j] = ('gen', (n,) + tuple(meta[j][1]), meta[j][2], 0, False)
+                    mats2[j] = part
+            out2 = _AdjointCircuit.apply(pair, _Meta(tuple(meta2), tangent=True), *mats2)
+            g_gy = out2[:, dim:] if wants[0] else None                        # alpha_K
+            leaves = ([state_l] if wants[1] else []) + [m for j, m in enumerate(mats_l) if wants[6 + j]]
+            got = []
+            if leaves:
+                seed = torch.cat([torch.zeros_like(gy, dtype=dt), gy.to(dt)], dim=-1)
+                with torch.no_grad():
+                    got = list(torch.autograd.grad(out2, leaves, grad_outputs=seed, allow_unused=True))
+        g_state = got.pop(0) if wants[1] else None
+        g_mats = [got.pop(0) if wants[6 + j] else None for j in range(k)]
+        if g_gy is not None:
+            g_gy = g_gy.detach().to(gy.dtype)
+        return (g_gy, g_state, None, None, None, None, *g_mats)
+
+
 class _AdjointCircuit(torch.autograd.Function):
     """y = U_K ... U_1 x for reversible gates as ONE autograd node.  Forward: the fused passes.  Backward: a
     reverse sweep over two states stacked as one batch -- psi_j recomputed with the exact inverses, the
@@ -697,8 +805,19 @@ class _AdjointCircuit(torch.autograd.Function):
         (stock autograd, one state per gate, qmath.py:503-505) and is only paid when a graph of the backward is asked
         for: Hessians (examples/benchmarks/gradient_benchmark.py:147-163), gradient penalties.  First-order
         ``backward()`` never comes here."""
-        state, _out, *mats = ctx.saved_tensors
+        state, out, *mats = ctx.saved_tensors
         meta = ctx.meta
+        need = tuple(bool(ctx.needs_input_grad[2 + j]) for j in range(len(mats)))
+        if CONFIG['second_order'] == 'tangent' and _SweepGrads.takes(meta, mats, need) and not getattr(meta, 'tangent', False):
+            # the sweep as a node of its own: its value by the fused sweep, ITS backward -- what a Hessian row costs -- by
+            # one forward and one reverse sweep of the tangent circuit instead of two Python nodes per gate
+            res = _SweepGrads.apply(gy, state, out, meta, bool(ctx.needs_input_grad[0]), need, *mats)
+            LAST_SWEEP.update(with_graph=True)
+            GRAPH_BACKWARDS['count'] += 1
+            res = list(res)
+            gstate = res.pop(0) if ctx.needs_input_grad[0] else None
+            grads = [res.pop(0) if nd else None for nd in need]
+            return (gstate, None, *grads)
         with torch.enable_grad():
             # (an alias per slot: one tensor may serve several gates, and every slot gets its own gate's cotangent)
             mats = [m.view_as(m) if ctx.needs_input_grad[2 + j] else m for j, m in enumerate(mats)]
@@ -761,13 +880,14 @@ class _AdjointCircuit(torch.autograd.Function):
         # (a pair smaller than a tile is zero-padded to one, like the forward of such a state (`_run_small`): one launch
         # with the reductions inside instead of a pass per circuit layer and a reduction kernel per trainable gate)
         fused = (CONFIG['fused_sweep'] and CONFIG['fuse'] and fusable and b <= backend.MAX_BATCH
-                 and (n + 1 >= g_.m or (CONFIG['small_fused_sweep'] and len(meta) >= CONFIG['small_fuse_min_gates']))
-                 and not getattr(meta, 'tangent', False))     # (trainable gates that are not unitary: exact inverses only)
+                 and (n + 1 >= g_.m or (CONFIG['small_fused_sweep'] and len(meta) >= CONFIG['small_fuse_min_gates'])))
+        tangent = getattr(meta, 'tangent', False)     # (a tangent circuit's blocks are trainable AND not unitary)
         if fused:
             # complex128: a matrix that is not computed from parameters or data may be unitary only to float32 rounding
             # (the reference's fixed matrices are, after .to(torch.double)): the sweep then tells U^-1 from U^dagger
             # -- and a user-supplied matrix (UAnyGate: unitary to 1e-4 is all the reference asks) in any precision
-            inexact = [j in corr and not need[j] and m.grad_fn is None and not m.requires_grad and (is128 or not meta[j][4])
+            inexact = [j in corr and ((not need[j] and m.grad_fn is None and not m.requires_grad and (is128 or not meta[j][4]))
+                                      or (tangent and not meta[j][4]))
                        for j, m in enumerate(mats)]
             raw, lam = _AdjointCircuit._sweep_fused(out, gy, meta, undo, need, b,
                                                     [m.ndim == 2 or m.shape[0] == 1 for m in mats], corr, inexact)
@@ -927,5 +1047,22 @@ class _AdjointCircuit(torch.autograd.Function):
             s00 = torch.stack([undo[scalars[si]][b, 0, 0] for si in sorted(scalars)])      # s of every scalar gate
             logc = torch.log(2.0 * (s00.real * s00.real + s00.imag * s00.imag))
             g = g / torch.exp(before @ logc)[None, :, None, None]
-        raw = {j: assemble_grad_sums(g, r, meta[j][0], len(meta[j][1])) for j, r in rows.items()}
+        raw = {}
+        # dense gates on two targets whose records lie four rows apart (every block of a tangent circuit, the Rxx layers of
+        # an ansatz): assembled together -- a handful of launches for all of them instead of six per gate
+        two = [(j, r) for j, r in rows.items() if len(meta[j][1]) == 2 and meta[j][0] != 'diag']
+        if len(two) >= 4 and all(r == two[0][1] + 4 * k for k, (_j, r) in enumerate(two)):
+            r0, cnt = two[0][1], len(two)
+            g4 = g[:, r0 : r0 + 4 * cnt].reshape(b, cnt, 4, 2, 2)
+            both, one, cross, up = g4[:, :, 0], g4[:, :, 1], g4[:, :, 2], g4[:, :, 3]
+            full = g.new_zeros(b, cnt, 4, 4)
+            full[..., 0::2, 0::2] = both - one
+            full[..., 1::2, 1::2] = one
+            full[..., 0::2, 1::2] = up
+            full[..., 1::2, 0::2] = cross - up
+            for k, (j, _r) in enumerate(two):
+                raw[j] = full[:, k]
+        for j, r in rows.items():
+            if j not in raw:
+                raw[j] = assemble_grad_sums(g, r, meta[j][0], len(meta[j][1]))
         return raw, lambda: work[:, :pair].reshape(b, -1, 2)[:, :, 1].contiguous()

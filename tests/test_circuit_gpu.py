@@ -845,3 +845,19 @@ def test_hessian_of_a_density_matrix_circuit_with_channels_on_gpu():
     from test_hessian_cpu import check_noisy_hessian
 
     check_noisy_hessian(dq, device=dev())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+def test_hessian_by_the_tangent_circuit_on_gpu(prec):
+    """executor._SweepGrads on the kernels: Hessian rows as sweeps of the tangent circuit against the per-gate replay."""
+    from test_hessian_cpu import check_hessian_by_the_tangent_circuit
+
+    check_hessian_by_the_tangent_circuit(dq, prec, device=dev())
+
+
+@pytest.mark.gpu
+def test_third_order_through_the_sweep_node_on_gpu():
+    from test_hessian_cpu import check_third_order_through_the_sweep_node
+
+    check_third_order_through_the_sweep_node(dq, device=dev())

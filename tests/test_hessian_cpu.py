@@ -139,3 +139,116 @@ def test_hessian_of_a_density_matrix_circuit_with_channels(cpu_backend):
     """Second derivatives through the non-reversible path (channels keep per-gate nodes): against central differences of
     the first-order gradient."""
     check_noisy_hessian(dq)
+
+
+def _hessian_both_routes(build, x, tol):
+    res = {}
+    for mode in ('tangent', 'replay'):
+        dq.executor.CONFIG['second_order'] = mode
+        try:
+            before, rows = dq.executor.GRAPH_BACKWARDS['count'], dq.executor.GRAPH_BACKWARDS['tangent_rows']
+            res[mode] = torch.autograd.functional.hessian(build, x)
+            assert dq.executor.GRAPH_BACKWARDS['count'] > before
+            assert (dq.executor.GRAPH_BACKWARDS['tangent_rows'] - rows >= x.numel()) == (mode == 'tangent')
+        finally:
+            dq.executor.CONFIG['second_order'] = 'tangent'
+    err = (res['tangent'] - res['replay']).abs().max().item()
+    assert err < tol, err
+    assert res['replay'].abs().max().item() > 1e-3
+    return res['tangent']
+
+
+def check_hessian_by_the_tangent_circuit(dq, prec, device=None):
+    """``executor._SweepGrads``: a row of a Hessian as one forward and one reverse sweep of the tangent circuit (blocks
+    [[U, 0], [C, U]] on one more qubit) against the per-gate formulation -- general, diagonal and controlled trainable
+    gates on one and two targets, fixed gates of every kind in between, data and ``nn.Parameter``s."""
+    dt = torch.float64 if prec == 'c128' else torch.float32
+    n = 5
+
+    def circuit():
+        torch.manual_seed(3)
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        cir.rxlayer(encode=True)
+        cir.cnot_ring()
+        cir.u3(1, encode=True)                 # general 2x2
+        cir.rz(2, encode=True)                 # diagonal
+        cir.p(0, encode=True)
+        cir.crx(0, 3, encode=True)             # with a control
+        cir.toffoli(0, 1, 4)
+        cir.rzz([1, 3], encode=True)           # diagonal on two targets
+        cir.rxx([0, 2], encode=True)           # dense on two targets
+        cir.s(2)
+        cir.swap([1, 4])
+        cir.ry(4, encode=True)
+        cir.ry(3, controls=[0, 1], encode=True)
+        cir.rylayer()                          # nn.Parameters (constants here)
+        cir.observable(0)
+        cir.observable([1, 2], 'xy')
+        cir = cir.to(torch.double) if prec == 'c128' else cir
+        return cir if device is None else cir.to(device)
+
+    def f(p):
+        cir = circuit()
+        cir(data=p)
+        return (cir.expectation() * torch.tensor([1.0, -0.5], dtype=dt, device=device)).sum()
+
+    x = (torch.rand(circuit().ndata, dtype=dt, generator=torch.Generator().manual_seed(5)) * 3.0).to(device)
+    h = _hessian_both_routes(f, x, 1e-10 if prec == 'c128' else 2e-5)
+    assert (h - h.T).abs().max().item() < (1e-10 if prec == 'c128' else 2e-5)
+
+    # a batch of data, every angle a function of two numbers
+    cir = circuit()
+    data = (torch.rand(2, cir.ndata, dtype=dt, generator=torch.Generator().manual_seed(6)) * 3.0).to(device)
+
+    def loss_of(theta):
+        cir2 = circuit()
+        # the trainable layer's angles come from ``theta`` through the data path of a second circuit with the same gates
+        cir2(data=data * theta.sum())
+        return cir2.expectation().sum()
+
+    theta = torch.tensor([0.7, -0.3], dtype=dt, device=device)
+    _hessian_both_routes(loss_of, theta, 1e-9 if prec == 'c128' else 1e-3)
+
+
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+def test_hessian_by_the_tangent_circuit_equals_the_per_gate_replay(cpu_backend, prec):
+    check_hessian_by_the_tangent_circuit(dq, prec)
+
+
+def check_third_order_through_the_sweep_node(dq, device=None):
+    """Under create_graph=True the sweep node's own backward differentiates the per-gate formulation: third derivatives."""
+    def f(t):
+        cir = dq.QubitCircuit(3)
+        cir.hlayer()
+        cir.rx(0, encode=True)
+        cir.cnot(0, 1)
+        cir.ry(1, encode=True)
+        cir.cnot(1, 2)
+        cir.rx(2, encode=True)
+        cir.rz(0, encode=True)
+        cir.observable([0, 2], 'zx')
+        cir.to(torch.double)
+        if device is not None:
+            cir.to(device)
+        cir(data=t.expand(4) * torch.tensor([1.0, 2.0, 0.5, 1.5], dtype=torch.double, device=device))
+        return cir.expectation().sum()
+
+    t = torch.tensor([0.4], dtype=torch.double, device=device, requires_grad=True)
+    d1, = torch.autograd.grad(f(t), t, create_graph=True)
+    d2, = torch.autograd.grad(d1.sum(), t, create_graph=True)
+    d3, = torch.autograd.grad(d2.sum(), t)
+    eps = 1e-4
+
+    def second(v):
+        tv = torch.tensor([v], dtype=torch.double, device=device, requires_grad=True)
+        a, = torch.autograd.grad(f(tv), tv, create_graph=True)
+        b, = torch.autograd.grad(a.sum(), tv)
+        return b.item()
+
+    num = (second(0.4 + eps) - second(0.4 - eps)) / (2 * eps)
+    assert abs(d3.item() - num) < 1e-6, (d3.item(), num)
+
+
+def test_third_order_through_the_sweep_node(cpu_backend):
+    check_third_order_through_the_sweep_node(dq)

@@ -23,10 +23,12 @@ ap.add_argument('--trials', type=int, default=5)
 ap.add_argument('--no-hessian', action='store_true')
 ap.add_argument('--max-hessian-params', type=int, default=216)
 ap.add_argument('--device', default='cuda')
+ap.add_argument('--second-order', default='tangent', choices=['tangent', 'replay'], help='A/B: Hessian rows by the tangent circuit or by per-gate nodes')
 ap.add_argument('--no-small-fused-sweep', action='store_true', help='A/B: reverse sweeps below a tile as undo-then-reduce')
 args = ap.parse_args()
 dev = torch.device(args.device)
 dq.executor.CONFIG['small_fused_sweep'] = not args.no_small_fused_sweep
+dq.executor.CONFIG['second_order'] = args.second_order
 
 
 def circuit(n, layer):
