@@ -627,6 +627,15 @@ def _inverse(kind: str, m: torch.Tensor) -> torch.Tensor:
     return torch.linalg.inv_ex(m)[0]
 
 
+def _inverse_block(m: torch.Tensor) -> torch.Tensor:
+    """Inverse of the blocks [[U, 0], [C, U]] of a tangent circuit (``_SweepGrads``): [[V, 0], [-V C V, V]], V = U^-1 --
+    closed form for one-target gates (a batched LU of hundreds of 4x4 matrices costs more than the sweep it serves)."""
+    d = m.shape[-1] // 2
+    v = _inverse('gen', m[..., :d, :d])
+    low = -(v @ m[..., d:, :d] @ v)
+    return torch.cat([torch.cat([v, torch.zeros_like(v)], dim=-1), torch.cat([low, v], dim=-1)], dim=-2)
+
+
 def grad_records(kind: str, mode: int, targets: Sequence[int], controls: Sequence[int], row0: int,
                  reduced: bool = True) -> tuple[list[Prim], int]:
     """The reduction records of a reverse sweep for ONE trainable gate (bit positions of the (psi, lambda) pair: bit 0
@@ -744,12 +753,11 @@ class _SweepGrads(torch.autograd.Function):
             for j, ((kind, targets, _c, _m, _e), m) in enumerate(zip(meta, mats_l, strict=True)):
                 if cmat[j] is not None:
                     nb = max(m.shape[0] if m.ndim == 3 else 1, cmat[j].shape[0] if cmat[j].ndim == 3 else 1)
-                    groups.setdefault((kind == 'diag', m.shape[-1], nb), []).append(j)
-            for (diag, d, nb), js in groups.items():
-                us = torch.stack([(mats_l[j] if mats_l[j].ndim == 3 else mats_l[j].unsqueeze(0)).to(dt).expand(nb, d, d)
-                                  for j in js])
-                cs = torch.stack([(cmat[j] if cmat[j].ndim == 3 else cmat[j].unsqueeze(0)).to(dt).expand(nb, d, d)
-                                  for j in js])
+                    groups.setdefault((kind == 'diag', m.shape[-1], nb, m.shape, cmat[j].shape, m.dtype, cmat[j].dtype), []).append(j)
+            for (diag, d, nb, _su, _sc, _du, _dc), js in groups.items():
+                # (ONE stack per group and side: its backward hands every gate its cotangent as a view)
+                us = torch.stack([mats_l[j] for j in js]).to(dt).reshape(len(js), -1, d, d).expand(len(js), nb, d, d)
+                cs = torch.stack([cmat[j] for j in js]).to(dt).reshape(len(js), -1, d, d).expand(len(js), nb, d, d)
                 if diag:                      # (F's output for a diagonal gate has no off-diagonal entries)
                     cs = torch.diag_embed(cs.diagonal(dim1=-2, dim2=-1))
                 top = torch.cat([us, torch.zeros_like(us)], dim=-1)
@@ -850,17 +858,19 @@ class _AdjointCircuit(torch.autograd.Function):
         # Inverses / adjoints of ALL gates in a few vectorised calls (grouped by kind, size and batchness): at
         # launch-bound sizes a handful of tiny kernels per gate would dominate the whole sweep.
         groups: dict = {}
-        for j, ((kind, _t, _c, _mode, _e), m) in enumerate(zip(meta, mats, strict=True)):
+        tangent = getattr(meta, 'tangent', False)     # (a tangent circuit's blocks are trainable AND not unitary)
+        for j, ((kind, _t, _c, _mode, exact), m) in enumerate(zip(meta, mats, strict=True)):
             u = m if m.ndim == 3 else m.unsqueeze(0)
-            groups.setdefault((kind, u.shape[-1], u.shape[0]), []).append((j, u))
+            # (the blocks [[U, 0], [C, U]] of a tangent circuit: a group of their own, inverted block-wise)
+            groups.setdefault((kind, u.shape[-1], u.shape[0]) + (('block',) if tangent and not exact else ()), []).append((j, u))
         undo: list = [None] * len(mats)       # (2b, D, D): rows [0, b) the inverse, rows [b, 2b) the adjoint
         inv_h: dict = {}                      # group key -> (positions, inverse^dagger stack) for the gradients
         is128 = out.dtype == torch.complex128
         corr: dict = {}
         for key, members in groups.items():
-            kind, d, nb = key
+            kind, d, nb = key[:3]
             us = torch.stack([u for _, u in members]).to(out.dtype)           # (K, nb, D, D)
-            inv = us if kind == 'x' else _inverse(kind, us)
+            inv = us if kind == 'x' else (_inverse_block(us) if len(key) > 3 else _inverse(kind, us))
             both = torch.cat([inv.expand(-1, b, d, d), us.mH.expand(-1, b, d, d)], dim=1).contiguous()
             for k, (j, _u) in enumerate(members):
                 undo[j] = both[k]
@@ -896,7 +906,7 @@ class _AdjointCircuit(torch.autograd.Function):
 
         grads: list = [None] * len(mats)
         for key, (pos, ih) in inv_h.items():
-            kind, d, nb = key
+            kind, d, nb = key[:3]
             js = [j for j in pos if need[j]]
             ks = [pos[j] for j in js]
             ihs = ih if ks == list(range(ih.shape[0])) else torch.stack([ih[k] for k in ks])   # no host index tensors
