@@ -920,3 +920,88 @@ def check_hessian_params_against_golden(dq, prec, device=None):
     err = (h.cpu() - gold_hessian(f'{key}/hessian')).abs().max().item()
     assert err < tol, (key, err)
     return err
+
+
+def check_hvp_random(dq, device=None, n=6, batch=1, seed=0, ngates=40, tol=1e-9, dtype=torch.float64):
+    """Fuzz of the second-order routes: Hessian-vector products of a random circuit over the whole gate menu -- fixed,
+    trainable and encoded gates, controls of every arity, diagonal and two-target trainable gates -- with respect to its
+    parameters AND its data, by the tangent circuit (executor._SweepGrads) and by the per-gate replay."""
+    import random
+
+    def build():
+        rng = random.Random(seed)
+        torch.manual_seed(seed)
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        for _ in range(ngates):
+            kind = rng.choice(['h', 'x', 'y', 'z', 's', 't', 'rx', 'ry', 'rz', 'p', 'u3', 'cnot', 'cz', 'crx', 'cry', 'crz',
+                               'toffoli', 'rzz_enc', 'rx_enc', 'ry_ctrl', 'u3_ctrl2', 'cp', 'swap', 'rxx_enc', 'fredkin',
+                               'rxx_train', 'ryy_train_ctrl', 'rzz_train', 'u3_enc', 'rzz_data'])
+            w = rng.sample(range(n), 3)
+            if kind in ('h', 'x', 'y', 'z', 's', 't'):
+                getattr(cir, kind)(w[0], controls=[w[1]] if rng.random() < 0.2 else None)
+            elif kind in ('rx', 'ry', 'rz', 'p', 'u3'):
+                getattr(cir, kind)(w[0])
+            elif kind in ('cnot', 'cz', 'crx', 'cry', 'crz', 'cp'):
+                getattr(cir, kind)(w[0], w[1])
+            elif kind == 'toffoli':
+                cir.toffoli(w[0], w[1], w[2])
+            elif kind == 'fredkin':
+                cir.fredkin(w[0], w[1], w[2])
+            elif kind == 'swap':
+                cir.swap([w[0], w[1]])
+            elif kind == 'rxx_train':
+                cir.rxx([w[0], w[1]])
+            elif kind == 'ryy_train_ctrl':
+                cir.ryy([w[0], w[1]], controls=[w[2]])
+            elif kind == 'rzz_train':
+                cir.rzz([w[0], w[1]])
+            elif kind == 'rxx_enc':
+                cir.rxx([w[0], w[1]], inputs=rng.uniform(0.0, 6.0))
+            elif kind == 'rzz_enc':
+                cir.rzz([w[0], w[1]], inputs=rng.uniform(0.0, 6.0))
+            elif kind == 'rx_enc':
+                cir.rx(w[0], encode=True)
+            elif kind == 'u3_enc':
+                cir.u3(w[0], encode=True)
+            elif kind == 'rzz_data':
+                cir.rzz([w[0], w[1]], encode=True)
+            elif kind == 'ry_ctrl':
+                cir.ry(w[0], controls=[w[1]])
+            else:
+                cir.u3(w[0], controls=[w[1], w[2]])
+        cir.observable(0)
+        cir.observable([1, n - 1], 'xz')
+        if device is not None:
+            cir.to(device)
+        if dtype == torch.float64:
+            cir.to(torch.double)
+        return cir
+
+    results = {}
+    for mode in ('tangent', 'replay'):
+        dq.executor.CONFIG['second_order'] = mode
+        try:
+            rows = dq.executor.GRAPH_BACKWARDS['tangent_rows']
+            cir = build()
+            g = torch.Generator().manual_seed(200 + seed)
+            data = torch.rand(batch, max(cir.ndata, 1), generator=g, dtype=dtype) * 6.0
+            if device is not None:
+                data = data.to(device)
+            data.requires_grad_(True)
+            leaves = [data] + list(cir.parameters()) if cir.ndata else list(cir.parameters())
+            cir(data=data if cir.ndata else None)
+            loss = (cir.expectation() * torch.tensor([1.0, -0.7], device=data.device, dtype=dtype)).sum()
+            first = torch.autograd.grad(loss, leaves, create_graph=True, allow_unused=True)
+            vs = [torch.randn(f.shape, generator=g, dtype=dtype).to(f.device) for f in first if f is not None]
+            dot = sum((f * v).sum() for f, v in zip([f for f in first if f is not None], vs, strict=True))
+            second = torch.autograd.grad(dot, leaves, allow_unused=True)
+            assert (dq.executor.GRAPH_BACKWARDS['tangent_rows'] > rows) == (mode == 'tangent'), mode
+            results[mode] = [None if s_ is None else s_.detach().cpu() for s_ in second]
+        finally:
+            dq.executor.CONFIG['second_order'] = 'tangent'
+    scale = max(1.0, max(r.abs().max().item() for r in results['replay'] if r is not None))
+    for a, b in zip(results['tangent'], results['replay'], strict=True):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert (a - b).abs().max().item() < tol * scale, (seed, (a - b).abs().max().item(), scale)

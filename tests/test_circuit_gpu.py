@@ -861,3 +861,15 @@ def test_third_order_through_the_sweep_node_on_gpu():
     from test_hessian_cpu import check_third_order_through_the_sweep_node
 
     check_third_order_through_the_sweep_node(dq, device=dev())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_hessian_vector_products_of_random_circuits_on_gpu(seed):
+    """Second order on the kernels over the whole gate menu: the tangent circuit against the per-gate replay, states below
+    and above a tile, both precisions."""
+    from _helpers import check_hvp_random
+
+    n = (4, 7, 10, 12, 13, 14)[seed]
+    check_hvp_random(dq, device=dev(), n=n, batch=1 + seed % 3, seed=seed, ngates=30 + 5 * seed)
+    check_hvp_random(dq, device=dev(), n=n, batch=1 + seed % 3, seed=seed, ngates=30 + 5 * seed, tol=3e-4, dtype=torch.float32)

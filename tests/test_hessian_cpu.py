@@ -252,3 +252,12 @@ def check_third_order_through_the_sweep_node(dq, device=None):
 
 def test_third_order_through_the_sweep_node(cpu_backend):
     check_third_order_through_the_sweep_node(dq)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_hessian_vector_products_of_random_circuits_by_both_routes(cpu_backend, seed):
+    from _helpers import check_hvp_random
+
+    n = 4 + seed
+    check_hvp_random(dq, n=n, batch=1 + seed % 3, seed=seed, ngates=30)
+    check_hvp_random(dq, n=n, batch=1 + seed % 3, seed=seed, ngates=30, tol=2e-4, dtype=torch.float32)

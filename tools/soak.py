@@ -1,7 +1,9 @@
 """Randomised soak of the product path on the GPU, beyond what the test-suite runs every time: circuits over the whole
 gate vocabulary under every scheduler configuration against the oracle (tests/_helpers.check_fuzz_against_oracle) and
 fused reverse sweeps against per-gate autograd (check_fused_sweep_random), many seeds.
-usage (GPU box): python tools/soak.py [first_seed] [count] [small]
+usage (GPU box): python tools/soak.py [first_seed] [count] [small | hvp]
+``hvp``: Hessian-vector products of random circuits by the tangent circuit (executor._SweepGrads) against the per-gate
+replay, n = 3 .. 14, both precisions.
 ``small``: states below a tile only (n = 3 .. 11) -- the zero-padded forward and the reverse sweep on the zero-padded
 (psi, lambda) pair (executor.CONFIG['small_fused_sweep']), both precisions every seed."""
 import os
@@ -14,13 +16,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import deepquantum_amd as dq  # noqa: E402
-from _helpers import check_fused_sweep_random, check_fuzz_against_oracle  # noqa: E402
+from _helpers import check_fused_sweep_random, check_fuzz_against_oracle, check_hvp_random  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 small = len(sys.argv) > 3 and sys.argv[3] == 'small'
+hvp = len(sys.argv) > 3 and sys.argv[3] == 'hvp'
 dev = torch.device('cuda', 0)
 t0 = time.time()
+for k in range(count if hvp else 0):
+    seed = first + k
+    n = 3 + seed % 12
+    check_hvp_random(dq, device=dev, n=n, batch=1 + seed % 3, seed=seed, ngates=15 + 5 * (seed % 8))
+    check_hvp_random(dq, device=dev, n=n, batch=1 + seed % 3, seed=seed, ngates=15 + 5 * (seed % 8), tol=3e-4, dtype=torch.float32)
+    print(f'seed {seed}: n = {n} ok ({time.time() - t0:.0f} s)', flush=True)
+if hvp:
+    print(f'{count} seeds from {first} (Hessian-vector products, tangent circuit vs per-gate replay): all agree')
+    sys.exit(0)
 for k in range(count if small else 0):
     seed = first + k
     n = 3 + seed % 9
