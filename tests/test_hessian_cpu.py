@@ -261,3 +261,45 @@ def test_hessian_vector_products_of_random_circuits_by_both_routes(cpu_backend, 
     n = 4 + seed
     check_hvp_random(dq, n=n, batch=1 + seed % 3, seed=seed, ngates=30)
     check_hvp_random(dq, n=n, batch=1 + seed % 3, seed=seed, ngates=30, tol=2e-4, dtype=torch.float32)
+
+
+def test_second_order_with_an_initial_state_that_requires_grad(cpu_backend):
+    """The cotangent of the sweep node's first output (d loss / d initial state) seeds the alpha half of the tangent
+    circuit: Hessian-vector products with respect to the state's real and imaginary parts, the data and the parameters, by
+    both routes."""
+    n = 4
+    res = {}
+    for mode in ('tangent', 'replay'):
+        dq.executor.CONFIG['second_order'] = mode
+        try:
+            torch.manual_seed(1)
+            cir = dq.QubitCircuit(n)
+            cir.hlayer()
+            cir.rxlayer(encode=True)
+            cir.cnot_ring()
+            cir.u3(1, encode=True)
+            cir.crx(0, 2, encode=True)
+            cir.rzz([1, 3], encode=True)
+            cir.rylayer()
+            cir.observable(0)
+            cir.observable([1, 2], 'xy')
+            cir.to(torch.double)
+            g = torch.Generator().manual_seed(2)
+            a = torch.randn(2, 2**n, generator=g, dtype=torch.double).requires_grad_()
+            b = torch.randn(2, 2**n, generator=g, dtype=torch.double).requires_grad_()
+            data = (torch.rand(2, cir.ndata, generator=g, dtype=torch.double) * 3).requires_grad_()
+            psi = torch.complex(a, b)
+            psi = psi / psi.norm(dim=-1, keepdim=True)
+            cir(data=data, state=psi.unsqueeze(-1))
+            loss = (cir.expectation() * torch.tensor([1.0, -0.5], dtype=torch.double)).sum()
+            leaves = [a, b, data] + list(cir.parameters())
+            first = torch.autograd.grad(loss, leaves, create_graph=True)
+            vs = [torch.randn(f.shape, generator=g, dtype=torch.double) for f in first]
+            rows = dq.executor.GRAPH_BACKWARDS['tangent_rows']
+            res[mode] = torch.autograd.grad(sum((f * v).sum() for f, v in zip(first, vs, strict=True)), leaves)
+            assert (dq.executor.GRAPH_BACKWARDS['tangent_rows'] > rows) == (mode == 'tangent')
+        finally:
+            dq.executor.CONFIG['second_order'] = 'tangent'
+    for x, y in zip(res['tangent'], res['replay'], strict=True):
+        assert (x - y).abs().max().item() < 1e-12
+    assert res['replay'][0].abs().max().item() > 1e-2
