@@ -263,7 +263,7 @@ class QubitCircuit(Operation):
         finally:
             for g in touched:
                 g.__dict__['_precomputed'] = None
-        if x is flat or (not executor.ops._is_batched(x) and not executor.ops._is_batched(state)
+        if x is flat or (not executor.ops._is_wrapped(x) and not executor.ops._is_wrapped(state)
                          and x.data_ptr() == state.data_ptr()):
             x = x.clone()
         return (self.matrix_rep(x) if self.den_mat else self.vector_rep(x)).squeeze(0)

@@ -249,7 +249,7 @@ def _lib_pad() -> int:
 def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
     """Eager per-gate path: when autograd must see every gate, or inside a ``torch.vmap`` transform (the
     per-gate Function carries the vmap rule; raw pointers of BatchedTensors are not available)."""
-    if ops._is_batched(state) or any(ops._is_batched(p.matrix) for p in prims):
+    if ops._is_wrapped(state) or any(ops._is_wrapped(p.matrix) for p in prims):
         return True
     if not torch.is_grad_enabled():
         return False
@@ -280,7 +280,8 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
         return _run_nograd(state, prims, inplace=inplace, scratch=scratch, out_perm=out_perm, grads=grads, amps=amps)
     if needs_autograd(state, prims):
         assert scratch is None and out_perm is None, 'scratch / out_perm are for no-grad runs'
-        vmapped = ops._is_batched(state) or any(ops._is_batched(p.matrix) for p in prims)
+        # (inside a torch.func transform -- vmap, grad, jacrev -- only the per-gate nodes compose)
+        vmapped = ops._is_wrapped(state) or any(ops._is_wrapped(p.matrix) for p in prims)
         if CONFIG['grad_mode'] == 'adjoint' and not vmapped and all(p.unitary for p in prims):
             meta = tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode, p.exact) for p in prims)
             return _AdjointCircuit.apply(state, _Meta(meta, zero_state), *[p.matrix for p in prims])
@@ -843,6 +844,11 @@ class _AdjointCircuit(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if torch._C._functorch.is_legacy_batchedtensor(gy) or ops._is_wrapped(gy):
+            raise RuntimeError('deepquantum_amd: a batch of cotangents reached the circuit node (is_grads_batched / '
+                               'torch.autograd.functional.*(vectorize=True)): its sweep runs on raw buffers.  Use '
+                               'torch.func.jacrev / torch.func.vmap over the function instead -- inside those transforms '
+                               'the gates run as per-gate nodes with vmap rules.')
         if torch.is_grad_enabled():
             return _AdjointCircuit._backward_with_graph(ctx, gy)
         _state, out, *mats = ctx.saved_tensors

@@ -26,6 +26,12 @@ def _is_batched(t: torch.Tensor) -> bool:
     return torch._C._functorch.is_batchedtensor(t)
 
 
+def _is_wrapped(t: torch.Tensor | None) -> bool:
+    """True inside any ``torch.func`` transform (vmap, grad, vjp, jacrev ...): the tensor is a functorch wrapper -- no data
+    pointer, and only the per-gate nodes (``setup_context`` style, with ``vmap`` rules) may see it."""
+    return t is not None and torch._C._functorch.is_functorch_wrapped_tensor(t)
+
+
 class _ApplyGate(torch.autograd.Function):
     """y = (U on targets | controls) x  for x: (B, 2**n), U: (Bm, D, D).
 

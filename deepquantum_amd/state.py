@@ -81,6 +81,9 @@ class QubitState(_ComplexBuffers):
         import weakref
 
         t = self._buffers['state']
+        if torch._C._functorch.is_functorch_wrapped_tensor(t):      # (made inside a torch.func transform: no storage to name)
+            self.__dict__['_zero_mark'] = None
+            return
         self.__dict__['_zero_mark'] = (weakref.ref(t), tensor_version(t), t.data_ptr())
 
     def is_zero_state(self) -> bool:

@@ -633,3 +633,57 @@ def test_gradient_with_respect_to_encoded_data_by_finite_differences(cpu_backend
                 dn[i] -= eps
                 num.reshape(-1)[i] = (f(up.reshape(shape)) - f(dn.reshape(shape))) / (2 * eps)
         assert (x.grad - num).abs().max().item() < 1e-7, (reupload, (x.grad - num).abs().max())
+
+
+def check_torch_func_transforms(dq, device=None):
+    """``torch.func`` transforms over a circuit -- the reference composes with them because it is made of tensor
+    operations (qmath.py:485-506); here the gates of a call that sees functorch wrappers run as per-gate nodes
+    (``setup_context`` style, ``vmap`` rules): grad, jacrev, reverse-over-reverse Hessians (all rows in ONE traversal),
+    vmap(grad) over data rows -- against plain autograd; circuits kept and built inside the function."""
+    import torch.func as tf
+
+    n, layer = 4, 2
+
+    def circuit():
+        torch.manual_seed(2)
+        cir = dq.QubitCircuit(n)
+        for _ in range(layer):
+            for i in range(n - 1):
+                cir.cnot(i, i + 1)
+            cir.rxlayer(encode=True)
+            cir.rzlayer(encode=True)
+            cir.u3(1, controls=[0], encode=True)        # (no nn.Parameter: .to() inside a transform may not touch one)
+            cir.rxx([0, 2], encode=True)
+        cir.observable(basis='x')
+        cir.observable([1, 3], 'zy')
+        cir.to(torch.double)
+        return cir if device is None else cir.to(device)
+
+    kept = circuit()
+
+    def f_kept(p):
+        kept(data=p)
+        return kept.expectation().sum()
+
+    def f_new(p):
+        cir = circuit()
+        cir(data=p)
+        return cir.expectation().sum()
+
+    x = torch.rand(kept.ndata, dtype=torch.float64, generator=torch.Generator().manual_seed(4)).to(device)
+    jac = torch.autograd.functional.jacobian(f_kept, x)
+    hes = torch.autograd.functional.hessian(f_kept, x)
+    for f in (f_kept, f_new):
+        assert (tf.grad(f)(x) - jac).abs().max().item() < 1e-10
+        assert (tf.jacrev(f)(x) - jac).abs().max().item() < 1e-10
+        assert (tf.jacrev(tf.jacrev(f))(x) - hes).abs().max().item() < 1e-9
+    rows = torch.stack([x, 0.5 * x, x + 0.1])
+    want = torch.stack([torch.autograd.functional.jacobian(f_kept, r) for r in rows])
+    assert (tf.vmap(tf.grad(f_kept))(rows) - want).abs().max().item() < 1e-10
+    # a batch of cotangents at the circuit node itself is refused by name, not by a cryptic batching-rule error
+    with pytest.raises(RuntimeError, match='torch.func.jacrev'):
+        torch.autograd.functional.jacobian(f_kept, x, vectorize=True)
+
+
+def test_torch_func_transforms_over_a_circuit(cpu_backend):
+    check_torch_func_transforms(dq)

@@ -873,3 +873,10 @@ def test_hessian_vector_products_of_random_circuits_on_gpu(seed):
     n = (4, 7, 10, 12, 13, 14)[seed]
     check_hvp_random(dq, device=dev(), n=n, batch=1 + seed % 3, seed=seed, ngates=30 + 5 * seed)
     check_hvp_random(dq, device=dev(), n=n, batch=1 + seed % 3, seed=seed, ngates=30 + 5 * seed, tol=3e-4, dtype=torch.float32)
+
+
+@pytest.mark.gpu
+def test_torch_func_transforms_over_a_circuit_on_gpu():
+    from test_api_cpu import check_torch_func_transforms
+
+    check_torch_func_transforms(dq, device=dev())

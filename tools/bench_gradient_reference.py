@@ -56,7 +56,7 @@ def timed(fn, trials):
 
 
 print('# reference (chart, hardware not stated): gradient 0.02 s (4-2) .. 0.28 s (12-6); Hessian 0.25 s (4-2) .. 58 s (12-6)')
-print(f'# {"n-layers":>8s} {"params":>6s} | gradient eager (build + fwd + bwd) | same circuit kept | HIP graph | Hessian (functional.hessian)')
+print(f'# {"n-layers":>8s} {"params":>6s} | gradient eager (build + fwd + bwd) | same circuit kept | HIP graph | Hessian (functional.hessian) | Hessian (torch.func.jacrev(jacrev))')
 for n in (4, 6, 8, 10, 12):
     for layer in (2, 4, 6):
         npar = 3 * n * layer
@@ -109,5 +109,14 @@ for n in (4, 6, 8, 10, 12):
 
             hs_min, _ = timed(lambda: hessian(f, x), max(1, args.trials // 2))
             hs_txt = f'{hs_min:8.3f} s'
+            # all rows in ONE traversal: reverse over reverse with torch.func (the gates run as per-gate nodes with vmap rules)
+            try:
+                import torch.func as tf
+
+                hv_min, _ = timed(lambda: tf.jacrev(tf.jacrev(f))(x), max(1, args.trials // 2))
+                same = (tf.jacrev(tf.jacrev(f))(x) - hessian(f, x)).abs().max().item()
+                hs_txt += f' | {hv_min:8.3f} s (max difference {same:.1e})'
+            except Exception as e:               # noqa: BLE001
+                hs_txt += f' | failed: {type(e).__name__}: {str(e)[:60]}'
         print(f'  {n:>2d}-{layer:<5d} {npar:>6d} | {g_min * 1e3:9.2f} ms (avg {g_avg * 1e3:8.2f}) | {k_min * 1e3:9.2f} ms | {graph_txt} | {hs_txt}',
               flush=True)
