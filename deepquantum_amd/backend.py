@@ -23,7 +23,8 @@ _test_backend: Any = None
 class _NoGraph:
     """A test double must not be more capable than the product: the HIP entry points return tensors without an
     autograd graph, so every call into the double runs under ``no_grad`` as well (a double built from differentiable
-    torch operations once hid a missing second derivative)."""
+    torch operations once hid a missing second derivative) -- and with forward-mode tangents switched off: a kernel
+    that reads raw buffers carries none, the nodes' ``jvp`` rules do."""
 
     def __init__(self, obj: Any):
         self._obj = obj
@@ -34,8 +35,13 @@ class _NoGraph:
             return attr
 
         def call(*args, **kwargs):
-            with torch.no_grad():
-                return attr(*args, **kwargs)
+            was = torch._C._is_fwd_grad_enabled()
+            torch._C._set_fwd_grad_enabled(False)
+            try:
+                with torch.no_grad():
+                    return attr(*args, **kwargs)
+            finally:
+                torch._C._set_fwd_grad_enabled(was)
 
         return call
 

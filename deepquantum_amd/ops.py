@@ -18,6 +18,8 @@ from typing import Sequence
 
 import torch
 
+from torch.autograd import forward_ad as _fwad
+
 from . import backend
 
 
@@ -26,10 +28,29 @@ def _is_batched(t: torch.Tensor) -> bool:
     return torch._C._functorch.is_batchedtensor(t)
 
 
+def _single_forward_level() -> None:
+    """Called by every ``jvp`` rule.  Forward over forward (``jacfwd(jacfwd(f))``, a ``jvp`` inside a ``jvp``) through ANY
+    ``autograd.Function`` gives silently wrong numbers in this PyTorch (2.10: the tensors a rule saved for forward mode
+    lose the outer level's tangents -- a two-line Function that multiplies shows it), so it is refused by name; forward
+    over reverse (``torch.func.hessian``), reverse over forward and reverse over reverse are right."""
+    from torch._functorch.pyfunctorch import retrieve_all_functorch_interpreters
+
+    levels = sum('Jvp' in str(i.key()) for i in retrieve_all_functorch_interpreters())
+    if levels >= 2:
+        raise RuntimeError('deepquantum_amd: nested forward-mode differentiation (jacfwd(jacfwd(f)), jvp inside jvp) through '
+                           'autograd.Function nodes is not reliable in this PyTorch; use torch.func.hessian(f) (forward over '
+                           'reverse) or torch.func.jacrev(torch.func.jacrev(f)) instead.')
+
+
 def _is_wrapped(t: torch.Tensor | None) -> bool:
-    """True inside any ``torch.func`` transform (vmap, grad, vjp, jacrev ...): the tensor is a functorch wrapper -- no data
-    pointer, and only the per-gate nodes (``setup_context`` style, with ``vmap`` rules) may see it."""
-    return t is not None and torch._C._functorch.is_functorch_wrapped_tensor(t)
+    """True inside any ``torch.func`` transform (vmap, grad, vjp, jacrev, jvp ...): the tensor is a functorch wrapper -- no
+    data pointer, and only the per-gate nodes (``setup_context`` style, with ``vmap`` and ``jvp`` rules) may see it.  Also
+    True for a dual tensor of plain forward-mode AD (``torch.autograd.forward_ad``): a raw kernel would drop its tangent."""
+    if t is None:
+        return False
+    if torch._C._functorch.is_functorch_wrapped_tensor(t):
+        return True
+    return _fwad._current_level >= 0 and _fwad.unpack_dual(t).tangent is not None
 
 
 class _ApplyGate(torch.autograd.Function):
@@ -49,6 +70,21 @@ class _ApplyGate(torch.autograd.Function):
         state, mats, targets, controls = inputs
         ctx.targets, ctx.controls = targets, controls
         ctx.save_for_backward(state, mats)
+        ctx.save_for_forward(state, mats)
+
+    @staticmethod
+    def jvp(ctx, state_t, mats_t, _targets_t, _controls_t):
+        _single_forward_level()
+        # forward mode (torch.func.jvp / jacfwd / hessian): d(U x) = U dx + dU x, the second term on the controlled
+        # subspace only -- two gate applications
+        state, mats = ctx.saved_tensors
+        out = None
+        if state_t is not None:
+            out = apply_gate(state_t, mats, ctx.targets, ctx.controls)
+        if mats_t is not None:
+            term = apply_masked(state, mats_t, ctx.targets, ctx.controls)
+            out = term if out is None else out + term
+        return out
 
     @staticmethod
     def backward(ctx, gy: torch.Tensor):
@@ -124,6 +160,19 @@ class _GateGrad(torch.autograd.Function):
     def setup_context(ctx, inputs, output):
         x, gy, ctx.targets, ctx.controls = inputs
         ctx.save_for_backward(x, gy)
+        ctx.save_for_forward(x, gy)
+
+    @staticmethod
+    def jvp(ctx, x_t, gy_t, _targets_t, _controls_t):
+        _single_forward_level()
+        x, gy = ctx.saved_tensors           # G is linear in gy and anti-linear in x
+        out = None
+        if gy_t is not None:
+            out = gate_grad(x, gy_t, ctx.targets, ctx.controls)
+        if x_t is not None:
+            term = gate_grad(x_t, gy, ctx.targets, ctx.controls)
+            out = term if out is None else out + term
+        return out
 
     @staticmethod
     def backward(ctx, gg: torch.Tensor):
@@ -168,6 +217,14 @@ class _ExpectPauli(torch.autograd.Function):
     def setup_context(ctx, inputs, output):
         state, ctx.xmask, ctx.zmask = inputs
         ctx.save_for_backward(state)
+        ctx.save_for_forward(state)
+
+    @staticmethod
+    def jvp(ctx, state_t, _xmask_t, _zmask_t):
+        _single_forward_level()
+        (state,) = ctx.saved_tensors        # d Re<psi|P|psi> = 2 Re <P psi|d psi>
+        ppsi = apply_pauli(state, ctx.xmask, ctx.zmask, differentiable=True)
+        return (2.0 * (ppsi.conj() * state_t).sum(dim=-1).real).to(state.real.dtype)
 
     @staticmethod
     def backward(ctx, g: torch.Tensor):
@@ -241,6 +298,21 @@ class _Marginal(torch.autograd.Function):
     def setup_context(ctx, inputs, output):
         state, ctx.bits = inputs
         ctx.save_for_backward(state)
+        ctx.save_for_forward(state)
+
+    @staticmethod
+    def jvp(ctx, state_t, _bits_t):
+        _single_forward_level()
+        (state,) = ctx.saved_tensors        # by polarisation: |psi + d|^2 - |psi - d|^2 = 4 Re conj(psi) d
+        return 0.5 * (marginal(state + state_t, ctx.bits) - marginal(state - state_t, ctx.bits))
+
+    @staticmethod
+    def vmap(info, in_dims, state, bits):
+        v = info.batch_size
+        state = state.movedim(in_dims[0], 0)
+        b = state.shape[1]
+        out = _Marginal.apply(state.reshape(v * b, -1).contiguous(), bits)
+        return out.reshape(v, b, -1), 0
 
     @staticmethod
     def backward(ctx, g: torch.Tensor):
@@ -269,6 +341,21 @@ class _ExpectZMulti(torch.autograd.Function):
     def setup_context(ctx, inputs, output):
         state, ctx.zmasks = inputs
         ctx.save_for_backward(state)
+        ctx.save_for_forward(state)
+
+    @staticmethod
+    def jvp(ctx, state_t, _zmasks_t):
+        _single_forward_level()
+        (state,) = ctx.saved_tensors        # P_k real diagonal: d <psi|P_k|psi> = 2 Re <psi|P_k|d psi>, by polarisation
+        return 0.5 * (expect_z_multi(state + state_t, ctx.zmasks) - expect_z_multi(state - state_t, ctx.zmasks))
+
+    @staticmethod
+    def vmap(info, in_dims, state, zmasks):
+        v = info.batch_size
+        state = state.movedim(in_dims[0], 0)
+        b = state.shape[1]
+        out = _ExpectZMulti.apply(state.reshape(v * b, -1).contiguous(), zmasks)
+        return out.reshape(v, b, -1), 0
 
     @staticmethod
     def backward(ctx, g: torch.Tensor):
@@ -291,6 +378,28 @@ class _ScaleZSigns(torch.autograd.Function):
     def setup_context(ctx, inputs, output):
         state, ctx.zmasks, w = inputs
         ctx.save_for_backward(state, w)
+        ctx.save_for_forward(state, w)
+
+    @staticmethod
+    def jvp(ctx, state_t, _zmasks_t, w_t):
+        _single_forward_level()
+        state, w = ctx.saved_tensors        # linear in psi and in w
+        out = None
+        if state_t is not None:
+            out = scale_z_signs(state_t, ctx.zmasks, w)
+        if w_t is not None:
+            term = scale_z_signs(state, ctx.zmasks, w_t)
+            out = term if out is None else out + term
+        return out
+
+    @staticmethod
+    def vmap(info, in_dims, state, zmasks, w):
+        v = info.batch_size
+        state = state.movedim(in_dims[0], 0) if in_dims[0] is not None else state.unsqueeze(0).expand(v, *state.shape)
+        w = w.movedim(in_dims[2], 0) if in_dims[2] is not None else w.unsqueeze(0).expand(v, *w.shape)
+        b = state.shape[1]
+        out = _ScaleZSigns.apply(state.reshape(v * b, -1).contiguous(), zmasks, w.reshape(v * b, -1).contiguous())
+        return out.reshape(v, b, -1), 0
 
     @staticmethod
     def backward(ctx, g: torch.Tensor):

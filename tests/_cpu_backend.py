@@ -283,7 +283,7 @@ class CpuTestBackend:
                 basis += 'y' if (xb and zb) else ('x' if xb else 'z')
         if not wires:
             return (torch.abs(state) ** 2).sum(-1).to(torch.float64)
-        return oracle.expectation_pauli(state, wires, basis).to(torch.float64)
+        return oracle.expectation_pauli(state, wires, basis).to(torch.float64).clone()     # (a fresh tensor, like a kernel's output)
 
     def inner(self, bra, ket):
         return (bra.conj() * ket).sum(-1).to(torch.complex128)
@@ -298,7 +298,7 @@ class CpuTestBackend:
         p = oracle.probabilities(state, wires).reshape([state.shape[0]] + [2] * len(wires))
         # oracle returns outcomes indexed by sorted wires; re-order axes to the requested bit order
         inv = [order.index(i) + 1 for i in range(len(wires))]
-        return p.permute([0] + inv).reshape(state.shape[0], -1).to(torch.float64)
+        return p.permute([0] + inv).reshape(state.shape[0], -1).to(torch.float64).clone()
 
     def gate_grad(self, x, gy, targets, controls):
         n = x.shape[-1].bit_length() - 1

@@ -680,6 +680,39 @@ def check_torch_func_transforms(dq, device=None):
     rows = torch.stack([x, 0.5 * x, x + 0.1])
     want = torch.stack([torch.autograd.functional.jacobian(f_kept, r) for r in rows])
     assert (tf.vmap(tf.grad(f_kept))(rows) - want).abs().max().item() < 1e-10
+    # forward mode: every node has a jvp rule (the tangent of a gate application is two gate applications) -- jvp, jacfwd,
+    # torch.func.hessian (forward over reverse), reverse over forward; Z-type strings (the multi-string reduction and its
+    # cotangent node) as well as general Pauli strings
+    v = torch.randn(x.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(5)).to(device)
+    assert abs(tf.jvp(f_kept, (x,), (v,))[1].item() - (jac * v).sum().item()) < 1e-10
+    assert (tf.jacfwd(f_kept)(x) - jac).abs().max().item() < 1e-10
+    assert (tf.hessian(f_kept)(x) - hes).abs().max().item() < 1e-9
+    assert (tf.jacrev(tf.jacfwd(f_kept))(x) - hes).abs().max().item() < 1e-9
+    zcir = circuit()
+    zcir.observables = torch.nn.ModuleList()
+    zcir.observable(0)
+    zcir.observable([1, 2], 'zz')
+    zcir.observable(3)
+
+    def f_z(p):
+        zcir(data=p)
+        return (zcir.expectation() * torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64, device=device)).sum()
+
+    zjac = torch.autograd.functional.jacobian(f_z, x)
+    zhes = torch.autograd.functional.hessian(f_z, x)
+    assert (tf.jacfwd(f_z)(x) - zjac).abs().max().item() < 1e-10
+    assert (tf.jacrev(f_z)(x) - zjac).abs().max().item() < 1e-10
+    assert (tf.hessian(f_z)(x) - zhes).abs().max().item() < 1e-9
+    assert (tf.jacrev(tf.jacrev(f_z))(x) - zhes).abs().max().item() < 1e-9
+    # plain forward-mode AD (torch.autograd.forward_ad): a dual tensor is routed like a wrapper, its tangent survives
+    import torch.autograd.forward_ad as fwad
+
+    with fwad.dual_level():
+        tangent = fwad.unpack_dual(f_z(fwad.make_dual(x, v))).tangent
+    assert abs(tangent.item() - (zjac * v).sum().item()) < 1e-10
+    # forward over forward through autograd.Function nodes is wrong in this PyTorch (any Function): refused by name
+    with pytest.raises(RuntimeError, match='nested forward-mode'):
+        tf.jacfwd(tf.jacfwd(f_kept))(x)
     # a batch of cotangents at the circuit node itself is refused by name, not by a cryptic batching-rule error
     with pytest.raises(RuntimeError, match='torch.func.jacrev'):
         torch.autograd.functional.jacobian(f_kept, x, vectorize=True)
