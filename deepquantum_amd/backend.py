@@ -35,6 +35,9 @@ class _NoGraph:
             return attr
 
         def call(*args, **kwargs):
+            for a in list(args) + list(kwargs.values()):      # (what `_ptr` refuses, the double refuses)
+                if isinstance(a, torch.Tensor) and (a.is_conj() or a.is_neg()):
+                    raise ValueError('tensor with a pending conjugation / negation: resolve_conj() / resolve_neg() it first')
             was = torch._C._is_fwd_grad_enabled()
             torch._C._set_fwd_grad_enabled(False)
             try:

@@ -42,6 +42,12 @@ def _single_forward_level() -> None:
                            'reverse) or torch.func.jacrev(torch.func.jacrev(f)) instead.')
 
 
+def _plain(t: torch.Tensor) -> torch.Tensor:
+    """The tensor with no pending conjugation / negation (cotangents that passed through ``conj()`` or ``.real`` of a
+    forward-mode rule carry them lazily): what a kernel may read through a raw pointer.  Free when there is none."""
+    return t.resolve_conj().resolve_neg()
+
+
 def _is_wrapped(t: torch.Tensor | None) -> bool:
     """True inside any ``torch.func`` transform (vmap, grad, vjp, jacrev, jvp ...): the tensor is a functorch wrapper -- no
     data pointer, and only the per-gate nodes (``setup_context`` style, with ``vmap`` and ``jvp`` rules) may see it.  Also
@@ -63,7 +69,7 @@ class _ApplyGate(torch.autograd.Function):
 
     @staticmethod
     def forward(state: torch.Tensor, mats: torch.Tensor, targets: tuple, controls: tuple) -> torch.Tensor:
-        return backend.apply_gate(state, mats, targets, controls)
+        return backend.apply_gate(_plain(state), _plain(mats), targets, controls)
 
     @staticmethod
     def setup_context(ctx, inputs, output):
@@ -154,7 +160,7 @@ class _GateGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(x: torch.Tensor, gy: torch.Tensor, targets: tuple, controls: tuple) -> torch.Tensor:
-        return backend.gate_grad(x, gy, targets, controls)
+        return backend.gate_grad(_plain(x), _plain(gy), targets, controls)
 
     @staticmethod
     def setup_context(ctx, inputs, output):
@@ -211,7 +217,7 @@ class _ExpectPauli(torch.autograd.Function):
 
     @staticmethod
     def forward(state: torch.Tensor, xmask: int, zmask: int) -> torch.Tensor:
-        return backend.expect_pauli(state, xmask, zmask).to(state.real.dtype)
+        return backend.expect_pauli(_plain(state), xmask, zmask).to(state.real.dtype)
 
     @staticmethod
     def setup_context(ctx, inputs, output):
@@ -292,7 +298,7 @@ class _Marginal(torch.autograd.Function):
 
     @staticmethod
     def forward(state: torch.Tensor, bits: tuple) -> torch.Tensor:
-        return backend.marginal(state, bits).to(state.real.dtype)
+        return backend.marginal(_plain(state), bits).to(state.real.dtype)
 
     @staticmethod
     def setup_context(ctx, inputs, output):
@@ -335,7 +341,7 @@ class _ExpectZMulti(torch.autograd.Function):
 
     @staticmethod
     def forward(state: torch.Tensor, zmasks: tuple) -> torch.Tensor:
-        return backend.expect_z_multi(state, zmasks).to(state.real.dtype)
+        return backend.expect_z_multi(_plain(state), zmasks).to(state.real.dtype)
 
     @staticmethod
     def setup_context(ctx, inputs, output):
@@ -372,7 +378,7 @@ class _ScaleZSigns(torch.autograd.Function):
 
     @staticmethod
     def forward(state: torch.Tensor, zmasks: tuple, w: torch.Tensor) -> torch.Tensor:
-        return backend.scale_z_signs(state, zmasks, w)
+        return backend.scale_z_signs(_plain(state), zmasks, w)
 
     @staticmethod
     def setup_context(ctx, inputs, output):
