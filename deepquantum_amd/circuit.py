@@ -220,8 +220,7 @@ class QubitCircuit(Operation):
         zero = False
         if isinstance(state, QubitState):
             # (the constructor's |0..0>, untouched since: the first passes skip what is still known to be zero)
-            zero = state.is_zero_state()
-            state = state.state
+            state, zero = state._state_and_claim()
         if self.ndata == 0:
             data = None
         self.state = None  # release the previous result first: the caching allocator hands the block back
@@ -250,8 +249,7 @@ class QubitCircuit(Operation):
         if state is None:
             state = self.init_state
         if isinstance(state, QubitState):
-            zero = state.is_zero_state()
-            state = state.state
+            state, zero = state._state_and_claim()
         dim = 4**self.nqubit if self.den_mat else 2**self.nqubit
         flat = state.reshape(-1, dim)
         if data is not None and data.ndim == 2 and flat.shape[0] != data.shape[0]:

@@ -173,7 +173,10 @@ def exchange_chunks(recv: torch.Tensor, send: torch.Tensor, peers: list[int], ch
     world = dist.get_world_size()
     me = dist.get_rank()
     rows = send.shape[0]
-    assert send.shape == recv.shape and send.shape[1] == len(peers) * chunk and send.is_contiguous() is not None
+    assert send.shape == recv.shape and send.shape[1] == len(peers) * chunk
+    # every piece handed to a point-to-point operation is a slice [i, c * chunk : (c + 1) * chunk]: contiguous exactly
+    # when the elements of a row are (rows themselves may lie apart: a group of samples is a slice of the batch)
+    assert send.stride(1) == 1 and recv.stride(1) == 1, 'exchange_chunks: the rows of send / recv must be contiguous'
     staged = send.is_cuda and dist.get_backend() == 'gloo'
     if staged or not COMM_CONFIG['grouped_exchange']:
         splits = [0] * world
@@ -193,6 +196,7 @@ def exchange_chunks(recv: torch.Tensor, send: torch.Tensor, peers: list[int], ch
     for i in range(rows):
         for c, peer in enumerate(peers):
             piece_s, piece_r = send[i, c * chunk:(c + 1) * chunk], recv[i, c * chunk:(c + 1) * chunk]
+            assert piece_s.is_contiguous() and piece_r.is_contiguous()
             if peer == me:
                 piece_r.copy_(piece_s)
             else:

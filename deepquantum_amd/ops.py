@@ -59,6 +59,19 @@ def _is_wrapped(t: torch.Tensor | None) -> bool:
     return _fwad._current_level >= 0 and _fwad.unpack_dual(t).tangent is not None
 
 
+def _polar_scale(ref: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    """Per-sample factor s (a constant: detached) that brings ``d`` to the size of ``ref``, for the forward-mode rules
+    that get a bilinear quantity by polarisation, f(ref + s d) - f(ref - s d) = 4 s Re <ref| . |d>: taken with s = 1 the
+    difference of two quadratics cancels catastrophically when |d| << |ref| (complex64: a tangent scaled by 1e-7 came
+    back 49 % off); with |s d| = |ref| the round-off is that of one reduction, relative to |ref| |d|, whatever the
+    tangent's scale -- a JVP has to be linear in its tangent."""
+    with torch.no_grad():
+        nr = torch.linalg.vector_norm(ref.detach(), dim=-1, keepdim=True)
+        nd = torch.linalg.vector_norm(d.detach(), dim=-1, keepdim=True)
+        ok = (nd > 0) & (nr > 0)
+        return torch.where(ok, nr / torch.where(ok, nd, torch.ones_like(nd)), torch.ones_like(nd))
+
+
 class _ApplyGate(torch.autograd.Function):
     """y = (U on targets | controls) x  for x: (B, 2**n), U: (Bm, D, D).
 
@@ -309,8 +322,10 @@ class _Marginal(torch.autograd.Function):
     @staticmethod
     def jvp(ctx, state_t, _bits_t):
         _single_forward_level()
-        (state,) = ctx.saved_tensors        # by polarisation: |psi + d|^2 - |psi - d|^2 = 4 Re conj(psi) d
-        return 0.5 * (marginal(state + state_t, ctx.bits) - marginal(state - state_t, ctx.bits))
+        (state,) = ctx.saved_tensors        # by polarisation: |psi + s d|^2 - |psi - s d|^2 = 4 s Re conj(psi) d
+        s = _polar_scale(state, state_t)    # (|s d| = |psi|: see `_polar_scale`)
+        d = state_t * s
+        return (marginal(state + d, ctx.bits) - marginal(state - d, ctx.bits)) * (0.5 / s)
 
     @staticmethod
     def vmap(info, in_dims, state, bits):
@@ -353,7 +368,9 @@ class _ExpectZMulti(torch.autograd.Function):
     def jvp(ctx, state_t, _zmasks_t):
         _single_forward_level()
         (state,) = ctx.saved_tensors        # P_k real diagonal: d <psi|P_k|psi> = 2 Re <psi|P_k|d psi>, by polarisation
-        return 0.5 * (expect_z_multi(state + state_t, ctx.zmasks) - expect_z_multi(state - state_t, ctx.zmasks))
+        s = _polar_scale(state, state_t)    # (|s d| = |psi|: see `_polar_scale`)
+        d = state_t * s
+        return (expect_z_multi(state + d, ctx.zmasks) - expect_z_multi(state - d, ctx.zmasks)) * (0.5 / s)
 
     @staticmethod
     def vmap(info, in_dims, state, zmasks):
@@ -415,8 +432,10 @@ class _ScaleZSigns(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gstate = scale_z_signs(g, ctx.zmasks, w)
         if ctx.needs_input_grad[2]:
-            # Re <g| P |psi> = (<g + psi| P |g + psi> - <g - psi| P |g - psi>) / 4
-            gw = ((expect_z_multi(g + state, ctx.zmasks) - expect_z_multi(g - state, ctx.zmasks)) * 0.25).to(w.dtype)
+            # Re <g| P |psi> = (<s g + psi| P |s g + psi> - <s g - psi| P |s g - psi>) / (4 s), |s g| = |psi|
+            s = _polar_scale(state, g)
+            gs = g * s
+            gw = ((expect_z_multi(gs + state, ctx.zmasks) - expect_z_multi(gs - state, ctx.zmasks)) * (0.25 / s)).to(w.dtype)
         return gstate, None, gw
 
 

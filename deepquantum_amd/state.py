@@ -40,6 +40,7 @@ class QubitState(_ComplexBuffers):
 
     def __init__(self, nqubit: int = 1, state: Any = 'zeros', den_mat: bool = False) -> None:
         super().__init__()
+        self.__dict__['_buffers'] = _WatchedBuffers()       # (who is handed the buffer decides the |0..0> claim: below)
         self.nqubit = nqubit
         self.den_mat = den_mat
         dim = 2**nqubit
@@ -75,37 +76,162 @@ class QubitState(_ComplexBuffers):
         pass
 
     # |0..0> (or |0..0><0..0|) as made by the constructor is worth knowing to the executor: the first fused passes of a
-    # circuit skip everything that is still known to be zero (executor.CONFIG['zero_state']).  The mark names the buffer
-    # tensor (weakly), its version counter and its storage, so writing into the buffer or replacing it ends it.
+    # circuit skip everything that is still known to be zero (executor.CONFIG['zero_state']).  The claim has to survive
+    # what a version counter does not see -- ``state.data[i] = 1``, a numpy alias: writes that bump nothing -- so it is
+    # tied to WHO HOLDS THE TENSOR instead: the buffer lives in a watched ``_buffers`` dict (`_WatchedBuffers`), and
+    # handing it out to anybody but this package (``qs.state``, ``buffers()``, ``state_dict()``, ``_buffers['state']``)
+    # or replacing it ends the claim.  It comes back at the next forward only if nobody holds the tensor or an alias of
+    # its storage any more AND a look at the device memory says it still is |0..0> (`_rearm`: one reduction and one
+    # host synchronisation, once per such event).
     def _mark_zero_state(self) -> None:
         import weakref
 
-        t = self._buffers['state']
-        if torch._C._functorch.is_functorch_wrapped_tensor(t):      # (made inside a torch.func transform: no storage to name)
-            self.__dict__['_zero_mark'] = None
+        bufs = self.__dict__['_buffers']
+        t = dict.get(bufs, 'state')
+        if t is None or torch._C._functorch.is_functorch_wrapped_tensor(t):      # (made inside a torch.func transform)
+            bufs.zero_mark = None
             return
-        self.__dict__['_zero_mark'] = (weakref.ref(t), tensor_version(t), t.data_ptr())
+        bufs.zero_mark = (weakref.ref(t), tensor_version(t), t.data_ptr())
+        bufs.rearm = False
+        bufs.was_zero = True
 
     def is_zero_state(self) -> bool:
         """True while ``state`` is still the |0..0> the constructor made (``state='zeros'``), on whatever device / in
-        whatever precision ``.to()`` has put it since."""
-        mark = self.__dict__.get('_zero_mark')
-        t = self._buffers.get('state')
+        whatever precision ``.to()`` has put it since, and nobody outside the package has been handed the tensor."""
+        bufs = self.__dict__['_buffers']
+        if getattr(bufs, 'zero_mark', None) is None and getattr(bufs, 'rearm', False):
+            self._rearm()
+        mark = getattr(bufs, 'zero_mark', None)
+        t = dict.get(bufs, 'state')
         return (mark is not None and t is not None and mark[0]() is t and mark[1] is not None and mark[1] == tensor_version(t)
                 and mark[2] == t.data_ptr())
 
+    def invalidate(self) -> None:
+        """Say that the buffer may have been written to behind PyTorch's back: ends the |0..0> claim until a forward
+        has verified the memory again (see `_rearm`).  Never needed for writes through the tensor API."""
+        bufs = self.__dict__['_buffers']
+        bufs.zero_mark = None
+        bufs.rearm = bufs.was_zero
+
+    def _rearm(self) -> None:
+        """The claim was ended by somebody who looked at the buffer.  It is taken up again iff (i) nobody holds the tensor
+        object (Python reference count) or another view of its storage (storage use count) any more -- so that from here
+        on every way to the memory leads through the watched dict again -- and (ii) the memory IS |0..0>: exactly one
+        non-zero real component, and it is the real part of element 0, equal to 1."""
+        import sys
+
+        bufs = self.__dict__['_buffers']
+        t = dict.get(bufs, 'state')
+        use_count = getattr(torch._C, '_storage_Use_Count', None)
+        if (t is None or use_count is None or t.numel() == 0 or not t.is_complex() or torch.is_inference(t)
+                or torch._C._functorch.is_functorch_wrapped_tensor(t) or t.requires_grad):
+            bufs.rearm = False
+            return
+        if sys.getrefcount(t) != 3:                  # the dict, ``t`` and the argument of getrefcount: somebody else holds it
+            return                                   # (stays pending: cheap, no device work)
+        storage = t.untyped_storage()
+        if use_count(storage._cdata) != 2:           # the tensor and ``storage``: a view / .data / numpy alias is alive
+            return
+        del storage
+        bufs.rearm = False
+        flat = torch.view_as_real(t.detach().reshape(-1))
+        ok = bool(((torch.count_nonzero(flat) == 1) & (flat[0, 0] == 1)).item())
+        del flat
+        if ok:
+            self._mark_zero_state()
+
+    def _state_and_claim(self) -> tuple[torch.Tensor, bool]:
+        """(the buffer, whether it is known to be |0..0>) for the package's own use: does not count as handing it out."""
+        zero = self.is_zero_state()
+        return dict.get(self.__dict__['_buffers'], 'state'), zero
+
     def _apply(self, fn: Any, *args, **kwargs):
         was = self.is_zero_state()
-        super()._apply(fn, *args, **kwargs)
-        self.__dict__.pop('_zero_mark', None)
+        bufs = self.__dict__['_buffers']
+        with bufs.internal():
+            super()._apply(fn, *args, **kwargs)
+        bufs.zero_mark = None
         if was:                      # (moving or converting |0..0> keeps it |0..0>)
             self._mark_zero_state()
         return self
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        d.pop('_zero_mark', None)    # (a weak reference does not pickle; a restored state is checked anew by nobody)
-        return d
+        d['_buffers'] = _WatchedBuffers(dict.items(d['_buffers']))    # (no claim travels: a weak reference does not
+        return d                                                        #  pickle; a copy starts without one)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if not isinstance(self.__dict__['_buffers'], _WatchedBuffers):
+            self.__dict__['_buffers'] = _WatchedBuffers(self.__dict__['_buffers'])
+
+
+class _WatchedBuffers(dict):
+    """``_buffers`` of a `QubitState`.  Reading the ``'state'`` entry, iterating over the values or replacing the entry
+    from outside an `internal` section ends the owner's |0..0> claim (``zero_mark``) and asks for a verification at
+    the next forward (``rearm``)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.zero_mark = None       # (weak reference to the tensor, its version, its address) while the claim stands
+        self.rearm = False          # the claim was ended from outside: verify at the next forward
+        self.was_zero = False       # the owner has held |0..0> at some point
+        self.depth = 0              # nesting of `internal` sections
+
+    class _Section:
+        def __init__(self, d):
+            self.d = d
+
+        def __enter__(self):
+            self.d.depth += 1
+
+        def __exit__(self, *exc):
+            self.d.depth -= 1
+            return False
+
+    def internal(self):
+        return _WatchedBuffers._Section(self)
+
+    def _handed_out(self, key='state') -> None:
+        if key == 'state' and not self.depth:
+            self.zero_mark = None
+            self.rearm = self.was_zero       # (a state that never was |0..0> is not looked at)
+
+    def __getitem__(self, key):
+        self._handed_out(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._handed_out(key)
+        return dict.get(self, key, default)
+
+    def pop(self, key, *default):
+        self._handed_out(key)
+        return dict.pop(self, key, *default)
+
+    def __setitem__(self, key, value):
+        self._handed_out(key)
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        self._handed_out(key)
+        dict.__delitem__(self, key)
+
+    def items(self):
+        self._handed_out()
+        return dict.items(self)
+
+    def values(self):
+        self._handed_out()
+        return dict.values(self)
+
+    def copy(self):
+        self._handed_out()
+        return dict(dict.items(self))
+
+    def __reduce__(self):
+        self._handed_out()
+        return (_WatchedBuffers, (list(dict.items(self)),))
 
 
 class DistributedQubitState(_ComplexBuffers):

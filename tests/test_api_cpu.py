@@ -710,6 +710,29 @@ def check_torch_func_transforms(dq, device=None):
     with fwad.dual_level():
         tangent = fwad.unpack_dual(f_z(fwad.make_dual(x, v))).tangent
     assert abs(tangent.item() - (zjac * v).sum().item()) < 1e-10
+    # a JVP is linear in its tangent, in complex64 too: the rules that polarise a quadratic reduction (Z strings,
+    # marginals) scale the tangent to the state's size first -- at scale 1 a tangent of 1e-6 came back per cent off
+    zc64 = circuit().to(torch.float)
+    zc64.observables = torch.nn.ModuleList()
+    zc64.observable(0)
+    zc64.observable([1, 2], 'zz')
+
+    def f_z32(p):
+        zc64(data=p)
+        return zc64.expectation().sum()
+
+    def f_m32(p):      # the differentiable marginal of a Reset-free circuit: through ops.marginal
+        from deepquantum_amd import ops as dq_ops
+
+        out = zc64(data=p)
+        return dq_ops.marginal(out.reshape(1, -1), (0, 2))[0, 1]
+
+    x32, v32 = x.float(), v.float()
+    for f32 in (f_z32, f_m32):
+        full = tf.jvp(f32, (x32,), (v32,))[1].item()
+        for eps in (1e-3, 1e-6):
+            small = tf.jvp(f32, (x32,), (eps * v32,))[1].item()
+            assert abs(small / eps - full) < 2e-5 * max(1.0, abs(full)), (f32.__name__, eps, small / eps, full)
     # forward over forward through autograd.Function nodes is wrong in this PyTorch (any Function): refused by name
     with pytest.raises(RuntimeError, match='nested forward-mode'):
         tf.jacfwd(tf.jacfwd(f_kept))(x)

@@ -195,6 +195,61 @@ def test_who_may_say_a_state_is_zero():
     assert cir.init_state.is_zero_state()
     cir.to(torch.double)
     assert cir.init_state.is_zero_state()
+    # writes the version counter does not see: the claim follows who HOLDS the buffer, and comes back only
+    # after a look at the memory
+    qs5 = dq.QubitState(6)
+    held = qs5.state
+    assert not qs5.is_zero_state()                     # somebody outside holds the tensor: they may write any time
+    del held
+    assert qs5.is_zero_state()                         # nobody does any more, and the memory still is |0..0>
+    qs5.state.data.zero_()
+    qs5.state.data[1 << 4] = 1                         # (.data: no version bump, the temporaries are gone afterwards)
+    assert not qs5.is_zero_state()
+    qs5.state.data.zero_()
+    qs5.state.data[0] = 1
+    assert qs5.is_zero_state()                         # verified again
+    alias = qs5.state.numpy()
+    assert not qs5.is_zero_state()
+    alias[5] = 1
+    del alias
+    assert not qs5.is_zero_state()
+    sd = qs5.state_dict()                              # (a state dict holds aliases of the buffers)
+    qs6 = dq.QubitState(6)
+    _ = list(qs6.buffers())
+    assert not qs6.is_zero_state()
+    del _
+    assert qs6.is_zero_state()
+    qs6.invalidate()
+    assert qs6.is_zero_state()                         # (memory untouched: verified and taken up again)
+    del sd
+
+
+def test_a_buffer_tampered_with_behind_the_version_counter_is_not_taken_for_zero(cpu_backend):
+    """The advisor's reproduction: ``init_state.state.data`` rewritten to another basis state -- the forward must give
+    what the run without the known-zero passes gives."""
+    old = dict(executor.CONFIG)
+    executor.CONFIG['permute_min_bits'] = 12
+    try:
+        res = []
+        for on in (True, False):
+            executor.CONFIG['zero_state'] = on
+            n = 14
+            cir = dq.QubitCircuit(n)
+            for q in range(n):
+                cir.h(q)
+                cir.rx(q, inputs=0.1 * (q + 1))
+            for q in range(n - 1):
+                cir.cnot(q, q + 1)
+            cir.observable(1)
+            cir.init_state.state.data.zero_()
+            cir.init_state.state.data[1 << 12] = 1
+            with torch.no_grad():
+                res.append(cir().clone())
+            assert executor.LAST_RUN.get('zero_passes', 0) == 0
+        assert torch.allclose(res[0], res[1], atol=1e-6)
+        assert abs(res[0].abs().pow(2).sum().item() - 1) < 1e-4
+    finally:
+        executor.CONFIG.update(old)
 
 
 def test_circuits_the_masks_do_not_apply_to_fall_back(cpu_backend):
