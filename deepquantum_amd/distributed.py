@@ -60,8 +60,15 @@ CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_gr
           # an UN-BATCHED shard treats its top ``virtual_bits`` local index bits as rank bits of a virtual world: the shard
           # becomes 2^v rows that move through a remap like the samples of a batch -- row r's amplitudes are on the links
           # while row r + 1 runs its passes -- at the price of extra stretches: a gate that targets a virtual bit needs a
-          # (local, free) re-labelling of the shard first (`_remap_virtual`).  0 = off.  Forward circuits in 'remap' mode
-          'virtual_bits': 0}
+          # (local, free) re-labelling of the shard first (`_remap_virtual`).  0 = off.  Forward circuits in 'remap' mode.
+          # None = 2 where an exchange can overlap with compute at all -- RCCL on device shards (asynchronous, on the
+          # group's own stream) -- and 0 elsewhere (gloo: synchronous and host-staged, the extra stretches would only cost)
+          'virtual_bits': None,
+          # REHEARSAL of one rank of a world that is not there (bench.py --rehearse-rank; `DistributedQubitState.REHEARSE`):
+          # every exchange and every all-reduce is left out -- the receive buffer keeps whatever it held, so the amplitudes
+          # are meaningless -- while schedule, passes, re-labellings and streams are exactly this rank's: the timing of the
+          # kernels does not depend on the data, so the compute half of a multi-GPU step can be MEASURED on one GPU
+          'elide_exchange': False}
 
 #: the accumulator of the DQ_FG_GRAD reductions while a fused reverse sweep runs on a sharded (psi, lambda) pair
 #: (adjoint._sweep_fused_sharded): every local stretch hands its rows to the passes
@@ -104,6 +111,17 @@ def _view(state: DistributedQubitState) -> torch.Tensor:
 
 def _bview(state: DistributedQubitState) -> torch.Tensor:
     return state.buffer.view(-1, state.num_amps_per_node >> _vbits(state))
+
+
+def _live(state: DistributedQubitState) -> bool:
+    """More than one rank, and either a process group or a rehearsal of one of its ranks (CONFIG['elide_exchange'])."""
+    return state.world_size > 1 and (dist.is_initialized() or bool(CONFIG['elide_exchange']))
+
+
+def _all_reduce(t: torch.Tensor) -> None:
+    """Sum over the ranks (left out in a rehearsal: this rank's share stands for the whole)."""
+    if not CONFIG['elide_exchange']:
+        dist.all_reduce(t, dist.ReduceOp.SUM)
 
 
 def _rank_controls_ok(state: DistributedQubitState, controls: Sequence[int]) -> bool:
@@ -356,7 +374,7 @@ def _expect_z_finish(state: DistributedQubitState, zmasks: Sequence[int], holder
         buf[:, :k] = holder['values'] * torch.tensor(signs, dtype=torch.float64, device=buf.device)
         buf[:, k] = 1.0
     if state.world_size > 1 and dist.is_initialized():
-        dist.all_reduce(buf, dist.ReduceOp.SUM)
+        _all_reduce(buf)
     # (whether every rank contributed is a number on the device: `expectation()` looks at it -- no host sync in the forward)
     state.__dict__['_expz'] = {'masks': [int(z) for z in zmasks], 'values': buf[:, :k], 'ranks': buf[0, k]}
 
@@ -582,17 +600,19 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
                         if (pending or not identity) else False)
             src, dst = (b, a) if in_b else (a, b)
             works = []
-            if W > 1 and dist.is_initialized():
+            if _live(state):
                 send, recv = torch.view_as_real(src[rows]), torch.view_as_real(dst[rows])     # (rows, 2^L, 2)
                 nbytes = send.shape[0] * ((1 << k) - 1) * chunk * send.element_size() * 2
                 t_issue = _mark(stream)
-                # ONE coalesced exchange for all samples of the group (communication.exchange_chunks): every chunk is
-                # contiguous where it lies, (rows x (2^k - 1)) send / receive pairs in one group call
-                ex = exchange_chunks(recv.reshape(send.shape[0], -1), send.reshape(send.shape[0], -1), peers, chunk * 2,
-                                     what=(f'shard exchange of remap {LAST_RUN["remaps"] + 1} (logical qubits leaving / entering '
-                                           f'{pairs}, rank bits {rbits}, samples {rows.start}:{rows.stop}, peers '
-                                           f'{sorted(set(peers) - {state.rank})}, {nbytes} bytes each way)'),
-                                     async_op=stream is not None)
+                ex = None
+                if not CONFIG['elide_exchange']:
+                    # ONE coalesced exchange for all samples of the group (communication.exchange_chunks): every chunk is
+                    # contiguous where it lies, (rows x (2^k - 1)) send / receive pairs in one group call
+                    ex = exchange_chunks(recv.reshape(send.shape[0], -1), send.reshape(send.shape[0], -1), peers, chunk * 2,
+                                         what=(f'shard exchange of remap {LAST_RUN["remaps"] + 1} (logical qubits leaving / entering '
+                                               f'{pairs}, rank bits {rbits}, samples {rows.start}:{rows.stop}, peers '
+                                               f'{sorted(set(peers) - {state.rank})}, {nbytes} bytes each way)'),
+                                         async_op=stream is not None)
                 if ex is not None:
                     works.append(ex)
                 LAST_RUN['wire_bytes'] += nbytes
@@ -625,7 +645,7 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
         LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
     LAST_RUN['groups'] = len(groups)
     _remap_bookkeeping(ph, pairs, rbits, out_perm, L)
-    if first_exchange and W > 1 and dist.is_initialized():
+    if first_exchange and _live(state):
         # The first exchange behind reset(): only rank 0 had anything to send, so on every rank (and in every row) what
         # arrived lies in chunk 0 and the other chunks hold the zeros the other ranks sent -- the qubits that came from
         # the rank bits, now on the top k local bits, are still |0>, and the next stretch starts with their mask
@@ -943,7 +963,10 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
     if mode == 'pairwise' and not _is_canonical(state):
         canonicalize(state)
     # virtual rank bits: an un-batched shard of a forward circuit, rows of at least one tile
-    vb = int(CONFIG['virtual_bits'] or 0)
+    vb = CONFIG['virtual_bits']
+    if vb is None:
+        vb = 2 if (state.amps.is_cuda and dist.is_initialized() and dist.get_backend() == 'nccl') else 0
+    vb = int(vb or 0)
     if vb and not (mode == 'remap' and state.batch is None and _SWEEP['grads'] is None and state.amps.ndim == 1
                    and state.log_num_amps_per_node - vb >= executor._geometry(state.amps.dtype == torch.complex128).m):
         vb = 0
@@ -1064,7 +1087,7 @@ def expect_pauli_dist(state: DistributedQubitState, observable) -> torch.Tensor:
             sign = -1.0 if bin((pz >> L) & state.rank).count('1') & 1 else 1.0
             val = backend.expect_pauli(_view(state), px, pz & ((1 << L) - 1)) * sign     # (B,) float64
             if state.world_size > 1:
-                dist.all_reduce(val, dist.ReduceOp.SUM)
+                _all_reduce(val)
             val = val.to(state.amps.real.dtype)
         return val[0] if state.batch is None else val
     from copy import deepcopy
@@ -1081,7 +1104,7 @@ def inner_product_dist(bra: DistributedQubitState, ket: DistributedQubitState) -
     val = backend.inner(_view(bra), _view(ket))                       # (B,) complex128
     if bra.world_size > 1:
         buf = torch.view_as_real(val.clone())
-        dist.all_reduce(buf, dist.ReduceOp.SUM)
+        _all_reduce(buf)
         val = torch.view_as_complex(buf)
     val = val.to(bra.amps.dtype)
     return val[0] if bra.batch is None else val

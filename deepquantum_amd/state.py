@@ -246,10 +246,18 @@ class DistributedQubitState(_ComplexBuffers):
     #: allocated in host memory by every rank first and copied over PCIe
     LAZY_AMPS = 1 << 24
 
+    #: (world size, rank) of a world that is NOT there: states made while this is set are the shard of that rank -- for
+    #: rehearsing one rank's schedule of a multi-GPU run on one GPU with the exchanges left out
+    #: (distributed.CONFIG['elide_exchange'], bench.py --rehearse-rank).  None = ask the process group.
+    REHEARSE: tuple[int, int] | None = None
+
     def __init__(self, nqubit: int, batch: int | None = None, device: Any = None, dtype: torch.dtype = torch.cfloat) -> None:
         super().__init__()
-        self.world_size = comm_get_world_size()
-        self.rank = comm_get_rank()
+        if self.REHEARSE is not None:
+            self.world_size, self.rank = self.REHEARSE
+        else:
+            self.world_size = comm_get_world_size()
+            self.rank = comm_get_rank()
         assert is_power_of_2(self.world_size)
         assert power_of_2(nqubit) >= self.world_size
         assert 0 <= self.rank < self.world_size
