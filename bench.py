@@ -93,6 +93,15 @@ def parse_args():
     ap.add_argument('--no-fold-permute', action='store_true',
                     help='N > 1, A/B: the re-labelling before an exchange as a pass of its own')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
+    ap.add_argument('--rehearse-rank', type=int, default=None,
+                    help='ONE process, one GPU: run rank R\'s schedule of the --gpus N job (shard, passes, re-labellings, '
+                         'streams) with every exchange left out -- the compute half of the multi-GPU step, measured; prints '
+                         'its own JSON line (amplitudes are meaningless, timing is data-independent)')
+    ap.add_argument('--no-qaoa', action='store_true', help='config 5: the generator circuit only')
+    ap.add_argument('--qaoa-nqubit', type=int, default=None,
+                    help='config 5: qubits of the QAOA ring (default: the generator circuit\'s n).  The sharded adjoint holds '
+                         'eight shard-sized buffers per rank: eight ranks SHARING one 288-GB GPU fit n = 31, not 33')
+    ap.add_argument('--no-parity', action='store_true', help='skip the pin check after the timed steps')
     return ap.parse_args()
 
 
@@ -252,29 +261,104 @@ def cpu_baseline(n, dtype, budget_s):
     }
 
 
-def check_pin(cir, n, depth, seed, dtype):
-    """Parity of the TIMED workload: sample 0 of config 3 against what the real reference computed for it
-    (tests/golden/pin28.npz, made by tests/golden/make_golden_pin28.py): 4096 amplitudes, the squared norm and <Z_q>
-    of every wire, at the north star's complex64 tolerance 1e-4."""
+def find_pin(n, depth, seed, dtype, extra_cx):
+    """(npz, description) of the pin of this workload's sample 0, or (None, why not).  n = 28 without the cx pair: made by
+    the REAL reference (tests/golden/make_golden_pin28.py).  n = 29 .. 34: made on one MI355X by the plain one-GPU route
+    of the HIP path -- in place, canonical order, unmerged gates -- which that same script validates against the
+    reference's n = 28 pin first (tools/make_pins_large.py, profiles/r05/pins_log.json)."""
     import numpy as np
 
+    gold = os.environ.get('DQ_PIN_DIR') or os.path.join(ROOT, 'tests', 'golden')      # (the harness's own tests: a temp dir)
+    if not (depth == 40 and seed == 1234 and dtype == torch.complex64):
+        return None, 'no pin for this workload (pins are depth 40, seed 1234, complex64)'
+    if n == 28 and not extra_cx:
+        path, what = os.path.join(gold, 'pin28.npz'), 'tests/golden/pin28.npz (real reference, batch element 0)'
+    else:
+        name = f'pin_n{n}{"_cx" if extra_cx else ""}.npz'
+        path, what = os.path.join(gold, name), (f'tests/golden/{name} (one-GPU HIP path, plain route validated against the '
+                                                f'reference pin at n = 28: tools/make_pins_large.py)')
+    if not os.path.exists(path):
+        return None, f'no pin for n = {n}{" + cx pair" if extra_cx else ""}'
+    return np.load(path), what
+
+
+def pin_verdict(amp, ref_amp, norm2, ref_norm2, ez, ref_ez):
+    """The parity criterion of every bench line.  Amplitudes are the strong check and it is RELATIVE: the largest
+    deviation against the largest pinned amplitude, and the l2 deviation against the l2 norm of the pinned sample (an
+    all-zero or scrambled result fails both however small the amplitudes are).  <Z_q> and the squared norm at the north
+    star's absolute 1e-4."""
+    import numpy as np
+
+    amp_err = float(np.abs(amp - ref_amp).max())
+    rel_max = amp_err / float(np.abs(ref_amp).max())
+    rel_l2 = float(np.linalg.norm(amp - ref_amp) / np.linalg.norm(ref_amp))
+    z_err = float(np.abs(np.asarray(ez) - np.asarray(ref_ez)).max())
+    ok = rel_max < 1e-3 and rel_l2 < 1e-3 and amp_err < 1e-4 and z_err < 1e-4 and abs(norm2 - ref_norm2) < 1e-4
+    return ok, {'amplitudes_checked': int(len(ref_amp)), 'max_amplitude_error': amp_err,
+                'max_amplitude_error_relative_to_largest_amplitude': rel_max, 'l2_error_relative': rel_l2,
+                'max_expectation_z_error': z_err, 'norm2': norm2, 'norm2_reference': ref_norm2,
+                'tolerance': {'amplitudes_relative': 1e-3, 'expectation_z': 1e-4, 'norm2': 1e-4}}
+
+
+def check_pin(cir, n, depth, seed, dtype, extra_cx=False):
+    """Parity of the TIMED workload on one GPU: sample 0 against its pin (`find_pin`)."""
     from deepquantum_amd import backend
 
-    path = os.path.join(ROOT, 'tests', 'golden', 'pin28.npz')
-    if not (n == 28 and depth == 40 and seed == 1234 and dtype == torch.complex64 and os.path.exists(path)):
-        return False, {'reason': 'no reference pin for this workload (the pin is config 3: n=28, depth 40, seed 1234, c64)'}
-    pin = np.load(path)
+    pin, what = find_pin(n, depth, seed, dtype, extra_cx)
+    if pin is None:
+        return False, {'reason': what}
     state = cir.state.reshape(-1, 1 << n)[:1].contiguous()        # sample 0 = the generator's own angles
     idx = torch.from_numpy(pin['indices']).to(state.device)
     amp = state[0, idx].cpu().numpy()
-    amp_err = float(np.abs(amp - pin['amplitudes']).max())
     norm2 = float(backend.expect_pauli(state, 0, 0)[0])
     ez = [float(backend.expect_pauli(state, 0, 1 << (n - 1 - q))[0]) for q in range(n)]
-    z_err = float(np.abs(np.array(ez) - pin['expectation_z']).max())
-    ok = amp_err < 1e-4 and z_err < 1e-4 and abs(norm2 - float(pin['norm2'])) < 1e-4
-    return ok, {'source': 'tests/golden/pin28.npz (real reference, batch element 0)', 'amplitudes_checked': int(idx.numel()),
-                'max_amplitude_error': amp_err, 'max_expectation_z_error': z_err, 'norm2': norm2,
-                'norm2_reference': float(pin['norm2']), 'tolerance': 1e-4}
+    ok, rep = pin_verdict(amp, pin['amplitudes'], norm2, float(pin['norm2']), ez, pin['expectation_z'])
+    rep['source'] = what
+    return ok, rep
+
+
+def check_pin_sharded(cir, n, depth, seed, dtype, extra_cx=False):
+    """The same for the index-bit-sharded state (collective: every rank calls it).  The shards are read in the
+    reference's layout (``state.amps``: rank r owns global indices [r 2^L, (r + 1) 2^L)); every rank compares the pinned
+    amplitudes that fall into its shard, <Z_q> and the norm are summed over the ranks."""
+    import numpy as np
+    import torch.distributed as dist
+
+    from deepquantum_amd import backend
+
+    pin, what = find_pin(n, depth, seed, dtype, extra_cx)
+    if pin is None:
+        return False, {'reason': what}
+    st = cir.state
+    amps = st.amps                                  # canonical order (an exchange if the layout was lazy)
+    L, rank = st.log_num_amps_per_node, st.rank
+    view = amps.reshape(-1, 1 << L)[:1].contiguous()      # sample 0
+    idx = pin['indices']
+    mine = (idx >> L) == rank
+    loc = torch.from_numpy(idx[mine] & ((1 << L) - 1)).to(view.device)
+    got = np.zeros(len(idx), dtype=np.complex128)
+    got[mine] = view[0, loc].cpu().numpy()
+    vals = torch.zeros(n + 1, dtype=torch.float64, device=view.device)
+    vals[n] = backend.expect_pauli(view, 0, 0)[0]
+    for q in range(n):
+        p_ = n - 1 - q
+        if p_ < L:
+            vals[q] = backend.expect_pauli(view, 0, 1 << p_)[0]
+        else:
+            vals[q] = vals[n] * (-1.0 if (rank >> (p_ - L)) & 1 else 1.0)
+    buf = torch.from_numpy(np.concatenate([got.real, got.imag, [float(mine.sum())]])).to(view.device)
+    if dist.is_initialized():
+        dist.all_reduce(vals)
+        dist.all_reduce(buf)
+    buf = buf.cpu().numpy()
+    k = len(idx)
+    amp = buf[:k] + 1j * buf[k:2 * k]
+    vals = vals.cpu().numpy()
+    ok, rep = pin_verdict(amp, pin['amplitudes'], float(vals[n]), float(pin['norm2']), vals[:n], pin['expectation_z'])
+    ok = ok and int(round(buf[2 * k])) == k
+    rep['source'] = what
+    rep['amplitudes_checked_per_rank_sum'] = int(round(buf[2 * k]))
+    return ok, rep
 
 
 def qaoa_ring(dq, n, device, distributed):
@@ -294,23 +378,130 @@ def qaoa_ring(dq, n, device, distributed):
     return cir.to(device), pairs
 
 
+def self_launch(args) -> int:
+    """``--gpus N`` (N > 1) outside a torchrun environment: start the N ranks here -- one process per GPU, the same
+    command line -- instead of silently measuring one rank.  RCCL needs one GPU per rank (exit 2 if the box has
+    fewer); with ``--backend gloo`` the ranks may share GPUs (device = LOCAL_RANK modulo the device count): the
+    functional check of the sharded paths on a one-GPU box.  Returns the exit code of the job."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if args.backend == 'nccl' and have < n:
+        print(f'bench.py: --gpus {n} over RCCL needs {n} GPUs, this box has {have}; nothing was measured '
+              f'(--backend gloo lets the ranks share a GPU for a functional check)', file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable] + list(getattr(sys, 'orig_argv', [sys.executable] + sys.argv)[1:])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    return rc
+
+
+class _Clock:
+    """A HIP event on the current stream -- or, on a box without a GPU (the CPU tests of this harness; the product
+    itself refuses CPU tensors), the host clock."""
+
+    def __init__(self, device):
+        self.ev = torch.cuda.Event(enable_timing=True) if device.type == 'cuda' else None
+        self.t = None
+
+    def record(self):
+        if self.ev is not None:
+            self.ev.record()
+        else:
+            self.t = time.perf_counter()
+
+    def elapsed_time(self, other) -> float:
+        return self.ev.elapsed_time(other.ev) if self.ev is not None else (other.t - self.t) * 1e3
+
+
+def rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed, step_ms, remap_rows, events, setup_s, plan_s):
+    """What `--rehearse-rank R` prints: the COMPUTE half of rank R's step of the `--gpus N` job, measured on this one GPU
+    (every exchange left out), next to the modelled wire time of the exchanges it would have issued."""
+    D = dq.distributed
+    st = dict(D.LAST_RUN)
+    W, R = args.gpus, args.rehearse_rank
+    shard_bytes = (1 << per_gpu) * amp_bytes * nbatch
+    kernel_ms = [ev[0].elapsed_time(ev[1]) for ev in events]
+    kernel_bytes = [ev[3] for ev in events]
+    per_step = len(kernel_ms) / args.steps
+    vb = st.get('virtual_bits', 0)
+    wire = []
+    for row in remap_rows or []:
+        k = row['qubits_exchanged']
+        # a k-qubit remap: 2^k - 1 peers, one chunk of shard / 2^k to each over its own link, both directions at once
+        t_ms = shard_bytes / (1 << k) / (XGMI_LINK_GBS * 1e9) * 1e3
+        wire.append({'remap': row['remap'], 'qubits_exchanged': k, 'links': (1 << k) - 1,
+                     'wire_ms_at_peak_link_rate': t_ms,
+                     # with 2^v rows of the shard in flight one after the other only the first row's share is not hidden
+                     'exposed_ms_model': t_ms / (1 << vb) if vb else t_ms,
+                     'local_passes_ms_median_per_row_group': row['local_passes_ms_median'], 'row_groups': row['samples'] // args.steps})
+    ms = elapsed / args.steps * 1e3
+    return {
+        'rehearsal': f'rank {R} of {W}: its shard, schedule, passes, re-labellings and streams on ONE GPU, every exchange and '
+                     f'all-reduce left out (amplitudes meaningless; kernel timing is data-independent)',
+        'workload': f'QubitCircuit({n}) depth {args.depth} ({ngates} gates), {"c64" if amp_bytes == 8 else "c128"}, batch {nbatch}, '
+                    f'{per_gpu} local qubits per rank' + (' (--strong)' if args.strong else f' (config {args.config})'),
+        'rank': R, 'world': W, 'steps': args.steps, 'warmup': args.warmup,
+        'compute_ms_per_step': ms,
+        'compute_ms_per_step_hip_events_median': statistics.median(step_ms) if step_ms else None,
+        'fused_launches_per_step': per_step,
+        'fused_launch_ms_sum_per_step': sum(kernel_ms) / args.steps if kernel_ms else None,
+        'fused_launch_GBs': (sum(kernel_bytes) / (sum(kernel_ms) * 1e-3) / 1e9) if kernel_ms else None,
+        'virtual_rank_bits': vb,
+        'schedule': {k_: st[k_] for k_ in ('remaps', 'virtual_remaps', 'folded_permutes', 'permute_passes', 'local_flushes',
+                                           'zero_shard_stretches', 'known_zero_stretches')},
+        'wire_model': {'peak_GBs_per_link': XGMI_LINK_GBS, 'remaps': wire,
+                       'wire_ms_per_step_all_exposed': sum(w['wire_ms_at_peak_link_rate'] for w in wire),
+                       'wire_ms_per_step_exposed_model': sum(w['exposed_ms_model'] for w in wire)},
+        'modelled_step_ms': ms + sum(w['exposed_ms_model'] for w in wire),
+        'plan_seconds': plan_s, 'first_step_seconds': setup_s,
+    }
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and args.rehearse_rank is None:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
+    if args.rehearse_rank is not None:
+        world, rank, local_rank = 1, 0, 0
+    elif world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     import deepquantum_amd as dq
 
     dtype = torch.complex64 if args.dtype == 'c64' else torch.complex128
     amp_bytes = 8 if dtype == torch.complex64 else 16
     multi = world > 1
-    distributed = multi and not args.batch_shard      # index-bit-sharded state; otherwise the batch is sharded
+    rehearse = args.rehearse_rank is not None
+    distributed = (multi and not args.batch_shard) or rehearse      # index-bit-sharded state; otherwise the batch is sharded
+    have_gpu = torch.cuda.is_available()
+    if have_gpu:
+        if args.backend == 'gloo':
+            local_rank %= torch.cuda.device_count()      # (ranks may share a GPU: functional check)
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+    else:
+        device = torch.device('cpu')
     if multi:
         dq.setup_distributed(args.backend)
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    if rehearse:
+        assert args.gpus > 1 and 0 <= args.rehearse_rank < args.gpus
+        dq.DistributedQubitState.REHEARSE = (args.gpus, args.rehearse_rank)
+        dq.distributed.CONFIG['elide_exchange'] = True
+    nshards = args.gpus if rehearse else world        # ranks the index bits are sharded over
 
     # ---- which workload -------------------------------------------------------------------------------------
     per_gpu = {3: 28, 4: 30, 5: 31}[args.config]
@@ -321,7 +512,7 @@ def main():
         per_gpu = args.nqubit
     if args.batch is not None:
         batch = args.batch if args.batch > 0 else None
-    n = per_gpu + (int(math.log2(world)) if distributed else 0)
+    n = per_gpu + (int(math.log2(nshards)) if distributed else 0)
     nbatch = batch or 1
 
     if args.min_low is not None:
@@ -349,8 +540,9 @@ def main():
         dq.executor.CONFIG['free_low'] = False
     if args.overlap_groups is not None:
         dq.distributed.CONFIG['overlap_groups'] = args.overlap_groups
-    if distributed and not batch:
-        # an un-batched shard has no samples to overlap its exchanges with: its rows take their place
+    if distributed and (args.virtual_bits is not None or rehearse):
+        # an un-batched shard has no samples to overlap its exchanges with: its rows take their place (the library's
+        # default under RCCL: 2; a rehearsal runs what the RCCL job would)
         dq.distributed.CONFIG['virtual_bits'] = 2 if args.virtual_bits is None else args.virtual_bits
     if args.no_fold_permute:
         dq.distributed.CONFIG['fold_permute'] = False
@@ -371,13 +563,17 @@ def main():
     def step():
         with torch.no_grad():
             cir(data)      # N > 1: (batch, 2^L) shards on every rank, one exchange schedule for the whole batch
+            if rehearse:   # (<Z0> comes out of the last pass + one all-reduce of a few numbers: nothing to rehearse)
+                return None
             return cir.expectation()
 
     def sync():
-        torch.cuda.synchronize(device)
+        if have_gpu:
+            torch.cuda.synchronize(device)
         if multi:
             torch.distributed.barrier()
-            torch.cuda.synchronize(device)
+            if have_gpu:
+                torch.cuda.synchronize(device)
 
     t_setup = time.perf_counter()
     step()          # setup, not warm-up: pass plans (host work once per circuit structure), second state buffer
@@ -398,7 +594,7 @@ def main():
     t0 = time.perf_counter()
     out = None
     for _ in range(args.steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = _Clock(device), _Clock(device)
         e0.record()
         out = step()
         e1.record()
@@ -426,6 +622,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
     step_ms = [a.elapsed_time(b) for a, b in step_events]      # HIP events around every step (this rank)
+    if rehearse:
+        print(json.dumps(rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed, step_ms, remap_rows,
+                                        prof['events'], setup_s, plan_s)))
+        return
     # The sharded circuit runs with lazy_layout = True: the qubits stay where the last remap put them, <Z0> is taken
     # from the shards as they lie, and the exchange(s) that restore the reference's shard order are paid by whoever
     # reads state.amps.  The reference's forward always pays them: timed here once, outside the step, so that the
@@ -447,13 +647,13 @@ def main():
     kernel_ms = [ev[0].elapsed_time(ev[1]) for ev in prof['events']]
     kernel_bytes = [ev[3] for ev in prof['events']]
     launches = len(kernel_ms)
-    shard_bytes = (2**n >> (int(math.log2(world)) if distributed else 0)) * amp_bytes * nbatch
+    shard_bytes = (2**n >> (int(math.log2(nshards)) if distributed else 0)) * amp_bytes * nbatch
     avg_ms = (sum(kernel_ms) / launches) if launches else float('nan')
     # the launches that move the whole state both ways (the first passes of a circuit started from |0..0> do not:
     # executor.CONFIG['zero_state'])
     full_ms = [t for t, b_ in zip(kernel_ms, kernel_bytes) if b_ == max(kernel_bytes)] if launches else []
     physical = (sum(kernel_bytes) / (sum(kernel_ms) * 1e-3) / 1e9) if launches else 0.0
-    alg_per_launch = (alg_bytes / (world if distributed else 1) * args.steps / launches) if launches else 0.0
+    alg_per_launch = (alg_bytes / (nshards if distributed else 1) * args.steps / launches) if launches else 0.0
     effective = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
     # HBM bytes per launch from the PMC counters: measured by separate rocprofv3 --pmc runs of this same command
     # (tools/profile.sh; summaries committed under profiles/), NOT during this run -- reported with its source, and
@@ -473,9 +673,14 @@ def main():
     dstats = dict(dq.distributed.LAST_RUN) if distributed else None
     z0 = float(out.reshape(-1)[0]) if out is not None else None
 
+    # parity of the timed workload: sample 0 against its pin -- one GPU: the real reference's (n = 28); sharded: every
+    # rank checks the pinned amplitudes of ITS shard (a collective: all ranks take part), relative criterion
     parity_ok, parity = None, None
-    if rank == 0 and not multi:
-        parity_ok, parity = check_pin(cir, n, args.depth, args.seed, dtype)
+    if not args.no_parity:
+        if distributed:
+            parity_ok, parity = check_pin_sharded(cir, n, args.depth, args.seed, dtype, bool(extra))
+        elif rank == 0 and not multi:
+            parity_ok, parity = check_pin(cir, n, args.depth, args.seed, dtype, bool(extra))
     norm2 = None
     if distributed:
         from deepquantum_amd.distributed import inner_product_dist
@@ -509,32 +714,47 @@ def main():
         sync()
         whole_state_ms = (time.perf_counter() - t0) / 3 * 1e3
         dq.executor.CONFIG['zero_state'] = True
-    copy_gbs = device_copy_bandwidth(device) if rank == 0 else None
+    copy_gbs = device_copy_bandwidth(device) if rank == 0 and have_gpu else None
     sweep = None
     if extras and not args.no_sweep and n >= 13:
         out = None
         cir.state = None
-        torch.cuda.empty_cache()
-        sweep = single_gate_sweep(dq, n, nbatch, dtype, device)
+        if have_gpu:
+            torch.cuda.empty_cache()
+        sweep = single_gate_sweep(dq, n, nbatch, dtype, device) if have_gpu else None
 
     qaoa = None
-    if args.config == 5:            # QAOA ring, one step: gradient of sum <Z_i Z_j> w.r.t. (gamma, beta)
+    if args.config == 5 and not args.no_qaoa:   # QAOA ring, one step: gradient of sum <Z_i Z_j> w.r.t. (gamma, beta)
         cir.state = None
+        cir.init_state = None          # (the generator circuit's shard and receive buffer: the ring needs the room)
         out = None
-        torch.cuda.empty_cache()
-        qc, pairs = qaoa_ring(dq, n, device, distributed)
+        if have_gpu:
+            torch.cuda.empty_cache()
+        nq = args.qaoa_nqubit or n
+        qc, pairs = qaoa_ring(dq, nq, device, distributed)
         gamma = torch.tensor(0.1, device=device, requires_grad=True)
         beta = torch.tensor(1.0, device=device, requires_grad=True)
-        params = torch.cat([(2 * gamma).repeat(len(pairs)), (2 * beta).repeat(n)])
+        params = torch.cat([(2 * gamma).repeat(len(pairs)), (2 * beta).repeat(nq)])
         sync()
         t0 = time.perf_counter()
         qc(params)
         cost = qc.expectation().sum()
         cost.backward()
         sync()
-        qaoa = {'edges': len(pairs), 'gates': len(qc.operators), 'cost': float(cost.detach()), 'dcost_dgamma': float(gamma.grad),
+        # known answer (one QAOA layer on a triangle-free 2-regular graph, n >= 5): every edge has
+        # <Z_i Z_j> = sin(4 beta) sin(4 gamma) / 2 with exp(-i gamma ZZ) per edge and exp(-i beta X) per qubit
+        g_, b_ = 0.1, 1.0
+        exact = {'cost': nq * 0.5 * math.sin(4 * b_) * math.sin(4 * g_),
+                 'dcost_dgamma': nq * 2.0 * math.sin(4 * b_) * math.cos(4 * g_),
+                 'dcost_dbeta': nq * 2.0 * math.cos(4 * b_) * math.sin(4 * g_)}
+        qaoa = {'nqubit': nq, 'edges': len(pairs), 'gates': len(qc.operators), 'cost': float(cost.detach()), 'dcost_dgamma': float(gamma.grad),
                 'dcost_dbeta': float(beta.grad), 'seconds_forward_backward': time.perf_counter() - t0,
-                'fused_reverse_sweep': bool(distributed and dq.adjoint.LAST_SWEEP.get('fused'))}
+                'fused_reverse_sweep': bool(distributed and dq.adjoint.LAST_SWEEP.get('fused')),
+                'closed_form': exact}
+        qaoa['max_relative_error_vs_closed_form'] = max(abs(qaoa[k_] - v_) / abs(v_) for k_, v_ in exact.items())
+        qaoa['matches_closed_form'] = qaoa['max_relative_error_vs_closed_form'] < 1e-3
+        if parity_ok is not None:
+            parity_ok = bool(parity_ok) and qaoa['matches_closed_form']
 
     if rank == 0:
         total_gate_applies = ngates * nbatch * args.steps * (world if multi and not distributed else 1)
@@ -633,6 +853,7 @@ def main():
             per_step = {k: dstats[k] for k in ('remaps', 'folded_permutes', 'permute_passes', 'pairwise_exchanges')}
             wire = dstats['wire_bytes']
             links = min(7, world - 1)
+            assert nshards == world
             line['config']['exchange_per_step'] = per_step
             # the first local stretch behind reset(): rank 0 (this one) runs it with the known-zero masks, the other ranks --
             # all zeros -- not at all; --no-zero-state switches both off
