@@ -68,7 +68,10 @@ CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_gr
           # every exchange and every all-reduce is left out -- the receive buffer keeps whatever it held, so the amplitudes
           # are meaningless -- while schedule, passes, re-labellings and streams are exactly this rank's: the timing of the
           # kernels does not depend on the data, so the compute half of a multi-GPU step can be MEASURED on one GPU
-          'elide_exchange': False}
+          'elide_exchange': False,
+          # a circuit that starts from reset() picks its FIRST qubit placement freely (`initial_placement`: |0..0> is the
+          # same vector under every permutation of the qubits): the qubits needed last start on the rank bits.  A/B switch
+          'initial_placement': True}
 
 #: the accumulator of the DQ_FG_GRAD reductions while a fused reverse sweep runs on a sharded (psi, lambda) pair
 #: (adjoint._sweep_fused_sharded): every local stretch hands its rows to the passes
@@ -830,12 +833,87 @@ def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int,
     return [prims[i] for i in order]
 
 
+_PLACEMENTS: dict = {}
+
+
+def _dry_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, lr: int, v: int) -> tuple[int, float]:
+    """(exchanges of real rank bits, their volume in shards) of the remap schedule started from placement ``ph0`` -- the
+    loop of `count_exchange_steps` without the statistics."""
+    L = lr + v
+    ph = list(ph0)
+    order = _order_for_remaps(prims, ph, n, lr, v)
+    steps, vol, i = 0, 0.0, 0
+    while i < len(order):
+        p = order[i]
+        if p.kind != 'diag' and any(ph[t] >= lr for t in p.targets):
+            pairs = sorted(_plan_remap(ph, order, i, n, lr, v), key=lambda pr: ph[pr[0]])
+            k = len(pairs)
+            rb = [ph[lq] for lq, _ in pairs]
+            ent = [ph[eq] for _, eq in pairs]
+            new_local = {sp: d for d, sp in enumerate([b for b in range(lr) if b not in ent] + ent)}
+            for q in range(n):
+                if ph[q] < lr:
+                    ph[q] = new_local[ph[q]]
+            for j, (lq, eq) in enumerate(pairs):
+                ph[eq], ph[lq] = rb[j], lr - k + j
+            if rb[0] >= L:
+                steps += 1
+                vol += 1 - 0.5**k
+            continue
+        i += 1
+    return steps, vol
+
+
+def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0) -> list[int]:
+    """Where the qubits of a circuit that starts from |0..0> should sit at the start: |0..0> is the same vector under
+    every permutation of the qubits (rank 0 holds the one non-zero amplitude at local index 0 in any of them), so the
+    FIRST placement costs nothing -- no exchange, not even a re-labelling pass.  Candidates: the reference layout
+    (wires 0 .. g-1 on the rank bits -- a layered circuit needs them within its first layer) and the placements that put
+    g of the g + 3 qubits whose first non-diagonal gate comes last (farthest next use, asked at gate 0) on the rank bits
+    and the next v on the virtual ones (CONFIG['virtual_bits']); each is dry-run through the whole remap schedule
+    (`_dry_remaps`, ~10 ms) and the one with the fewest exchanges, then the least volume, wins -- the reference layout on
+    ties.  Never worse than the reference start, typically one exchange and one stretch boundary less (n = 34 on 8 ranks:
+    5 -> 4 exchanges, 35 -> 33 passes).  A pure function of the gate list, cached by its structure: every rank computes
+    the same placement.  ``canonicalize`` restores the reference's order whenever somebody asks for it."""
+    from itertools import combinations
+
+    g = n - L
+    canonical = list(range(n))
+    if g <= 0 or not prims:
+        return canonical
+    key = (n, L, v, hash(tuple((p.kind, tuple(p.targets), tuple(p.controls)) for p in prims)))
+    hit = _PLACEMENTS.get(key)
+    if hit is not None:
+        return list(hit)
+    nxt = _next_use(prims, 0, n)
+    order = sorted(range(n), key=lambda q: (-nxt[q], 0 if q >= L else 1, -q))
+    lr = L - v
+    best = (_dry_remaps(prims, canonical, n, lr, v), 0, canonical)
+    for ci, pick in enumerate(combinations(order[:g + 3], g)):
+        ph = list(canonical)
+        rest = [q for q in order if q not in pick]
+        for positions, want in ((range(L, n), list(pick)), (range(lr, L), rest[:v])):
+            have = [q for q in range(n) if ph[q] in positions]
+            leaving = [q for q in have if q not in want]
+            entering = [q for q in want if q not in have]
+            for lq, eq in zip(leaving, entering):
+                ph[lq], ph[eq] = ph[eq], ph[lq]
+        cand = (_dry_remaps(prims, ph, n, lr, v), ci + 1, ph)
+        if cand[:2] < best[:2]:
+            best = cand
+    if len(_PLACEMENTS) >= 32:
+        _PLACEMENTS.pop(next(iter(_PLACEMENTS)))
+    _PLACEMENTS[key] = list(best[2])
+    return list(best[2])
+
+
 def _remap_for(state: DistributedQubitState, prims: Sequence[Prim], i: int, pending: list[Prim]) -> None:
     pairs = _plan_remap(_phys(state), prims, i, state.nqubit, state.log_num_amps_per_node - _vbits(state), _vbits(state))
     _remap(state, pairs, pending)
 
 
-def count_exchange_steps(prims: Sequence[Prim], n: int, g: int, virtual_bits: int = 0, reorder: bool = False) -> dict:
+def count_exchange_steps(prims: Sequence[Prim], n: int, g: int, virtual_bits: int = 0, reorder: bool = False,
+                         placement: bool = False) -> dict:
     """Dry run of both modes on a gate list (no data): number of exchange steps and the volume each rank
     sends, in units of one shard.  Used by tests and to size the design.
 
@@ -845,7 +923,8 @@ def count_exchange_steps(prims: Sequence[Prim], n: int, g: int, virtual_bits: in
     their wire volume splits into ``hidden_wire_volume`` -- it travels while the other rows of the shard compute: all
     but the first row's share, 1 - 2^-v of it -- and ``exposed_wire_volume``.  v = 0: everything is exposed (an
     un-batched shard has nothing to overlap with).
-    ``reorder``: the gate list in commutation-DAG order first, as `dist_run` runs it."""
+    ``reorder``: the gate list in commutation-DAG order first, as `dist_run` runs it.  ``placement``: the free first
+    placement of a circuit that starts from |0..0> (`initial_placement`)."""
     L = n - g
     pw_steps, pw_vol = 0, 0.0
     for p in prims:
@@ -860,7 +939,7 @@ def count_exchange_steps(prims: Sequence[Prim], n: int, g: int, virtual_bits: in
                 pw_vol += 2 * nglob * 0.5
     v = int(virtual_bits)
     lr = L - v                                   # bits of a row
-    ph = list(range(n))
+    ph = initial_placement(prims, n, L, v) if placement else list(range(n))
     if reorder:
         prims = _order_for_remaps(prims, ph, n, lr, v)
     rm_steps, rm_vol, i = 0, 0.0, 0
@@ -988,6 +1067,10 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
 def _dist_apply_loop(state: DistributedQubitState, prims: Sequence[Prim], mode: str, keep_layout: bool,
                      expect_z: Sequence[int] | None) -> DistributedQubitState:
     vb = _vbits(state)
+    if (mode == 'remap' and CONFIG['initial_placement'] and state.__dict__.get('_fresh_zero') and _is_canonical(state)
+            and state.world_size > 1):
+        # behind reset(): the first placement is free (see `initial_placement`)
+        state.__dict__['_phys'] = initial_placement(prims, state.nqubit, state.log_num_amps_per_node, vb)
     if mode == 'remap' and CONFIG['reorder']:
         prims = _order_for_remaps(prims, _phys(state), state.nqubit, state.log_num_amps_per_node - vb, vb)
     pending: list[Prim] = []

@@ -1,0 +1,72 @@
+"""Per-pass instruction counts of a schedule from the library's own records (dq_wave_descriptor: no GPU needed) and the
+generator's handler bodies: VALU / DS / SALU instructions a wave executes for every record of every pass of the headline
+circuit, next to the durations measured on the GPU (profiles/r04/passes_headline.txt), and a least-squares model
+ms = max(floor, a + b * valu) fitted to them.  usage: python tools/pass_cost_model.py [measured.txt]"""
+import os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import bench
+from deepquantum_amd import fusion, executor
+import _wave_emulator as emu
+
+
+def handler_costs(g):
+    """{handler id: (VALU, DS, SALU) instructions of its body} -- the straight-line count (masked bodies run whole)."""
+    out = {}
+    for i, (ctl, lines) in g.handlers().items():
+        v = sum(1 for ln in lines if ln.lstrip().startswith('v_'))
+        d = sum(1 for ln in lines if ln.lstrip().startswith('ds_'))
+        s = sum(1 for ln in lines if ln.lstrip().startswith('s_'))
+        out[i] = (v + (2 if ctl else 0), d, s + (6 if ctl else 0))
+    return out
+
+
+def headline_steps(n=28, depth=40, seed=1234, wide=True):
+    prims = []
+    for op in bench.random_circuit_spec(n, depth, seed):
+        if op[0] == 'cnot':
+            prims.append(executor.Prim('x', None, (n - 1 - op[2],), (n - 1 - op[1],), 0))
+        else:
+            prims.append(executor.Prim('gen', None, (n - 1 - op[1],), (), 3 if op[0] == 'h' else 2))
+    groups, order, multi, levels = executor._merge_structure(prims)
+    merged = []
+    for kind, idx in order:
+        merged.append(prims[idx] if kind == 'p' else executor.Prim('gen', None, prims[groups[idx][0][0]].targets, (), groups[idx][1]))
+    ops = [fusion.PrimOp(p.kind, p.targets, p.controls, 4 * i, p.mode) for i, p in enumerate(merged)]
+    geom = fusion.default_geometry(False)
+    geom.permute_store = True
+    if wide:
+        geom.plan_width, geom.plan_branch, geom.plan_restarts = 8, 4, 6
+    return fusion.schedule(ops, n, geom), ops
+
+
+def pass_counts(steps, n):
+    g = emu.gen()
+    hc = handler_costs(g)
+    rows = []
+    for st in steps:
+        kp = emu.descriptor(st.desc, n)
+        ids = [kp.rec[j][0] for j in range(kp.nrec_bytes // 32)]
+        v = sum(hc.get(i, (0, 0, 0))[0] for i in ids)
+        d = sum(hc.get(i, (0, 0, 0))[1] for i in ids)
+        unknown = [i for i in ids if i not in hc]
+        rows.append({'records': len(ids), 'valu': v, 'ds': d, 'unknown': len(unknown), 'ids': ids})
+    return rows
+
+
+if __name__ == '__main__':
+    steps, ops = headline_steps()
+    rows = pass_counts(steps, 28)
+    meas = None
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'r04', 'passes_headline.txt')
+    if os.path.exists(path):
+        meas = [float(m.group(1)) for m in re.finditer(r'trips \d+\s+([\d.]+) ms', open(path).read())]
+    for i, r in enumerate(rows):
+        print(f'pass {i:2d}: records {r["records"]:3d} valu {r["valu"]:5d} ds {r["ds"]:4d} unknown-handlers {r["unknown"]}'
+              + (f'  measured {meas[i]:6.2f} ms' if meas and i < len(meas) else ''))
+    if meas and len(meas) == len(rows):
+        x = np.array([r['valu'] for r in rows[4:-1]], float); y = np.array(meas[4:-1])
+        A = np.stack([np.ones_like(x), x], 1)
+        coef, res, *_ = np.linalg.lstsq(A, y, rcond=None)
+        print('fit full passes 4..17: ms =', coef[0], '+', coef[1], '* valu; residual rms', float(np.sqrt(((A @ coef - y) ** 2).mean())))
