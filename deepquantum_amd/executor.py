@@ -104,7 +104,11 @@ CONFIG = {'fuse': True, 'min_low_c64': None, 'min_low_c128': None,
           # passes neither read, compute nor write where such an index bit is 1 (fusion.zero_state_masks,
           # dq_apply_fused_zext_*): the first two of the headline's nineteen passes cost next to nothing, the third only
           # its stores.  A/B switch
-          'zero_state': True}
+          'zero_state': True,
+          # a call that sees torch.func wrappers (vmap over the circuit, grad / jacrev around it) runs as ONE node whose
+          # vmap rules fold the mapped dimension into the kernels' batch (_FusedCircuit); False, or a transform stack it
+          # does not take (forward mode, two grad levels): one node per gate, as in round 4
+          'fused_transforms': True}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates, bytes read + written) to report the kernel's average duration next to its algorithmic bytes.
@@ -285,6 +289,13 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
         if CONFIG['grad_mode'] == 'adjoint' and not vmapped and all(p.unitary for p in prims):
             meta = tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode, p.exact) for p in prims)
             return _AdjointCircuit.apply(state, _Meta(meta, zero_state), *[p.matrix for p in prims])
+        if vmapped and CONFIG['grad_mode'] == 'adjoint' and CONFIG['fused_transforms'] and _fused_under_transforms(state, prims):
+            # torch.vmap over the circuit -- the reference's own batching, circuit.py:232-240 -- and one level of
+            # torch.func.grad / vjp / jacrev around it: ONE node with vmap rules of its own (the mapped dimension folds
+            # into the kernels' batch), so the gates keep their fused passes
+            meta = tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode, p.exact) for p in prims)
+            LAST_RUN['fused_transform_nodes'] = LAST_RUN.get('fused_transform_nodes', 0) + 1
+            return _FusedCircuit.apply(state, _Meta(meta, zero_state), *[p.matrix for p in prims])
         x = state
         for p in prims:
             x = ops.apply_gate(x, p.matrix, p.targets, p.controls)
@@ -780,6 +791,152 @@ class _SweepGrads(torch.autograd.Function):
         if g_gy is not None:
             g_gy = g_gy.detach().to(gy.dtype)
         return (g_gy, g_state, None, None, None, None, *g_mats)
+
+
+def _fused_under_transforms(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
+    """May a call that sees functorch wrappers run as `_FusedCircuit`?  Only under transform stacks its rules cover:
+    any number of ``vmap`` levels and at most ONE reverse-mode level (``grad`` / ``vjp`` / ``jacrev``); no forward mode
+    (``jvp``, ``jacfwd``, ``torch.func.hessian``, plain forward_ad: the per-gate nodes carry jvp rules), no second
+    reverse level (``jacrev(jacrev(f))``: the per-gate nodes differentiate to any order).  Unknown stack: no."""
+    stack = ops.transform_stack()
+    if stack is None or ops.forward_ad_active() is not False:
+        return False
+    if any(t not in ('Vmap', 'Grad') for t in stack) or sum(t == 'Grad' for t in stack) > 1:
+        return False
+    if not all(p.unitary and len(p.targets) <= 2 for p in prims):
+        return False
+    n = state.shape[-1].bit_length() - 1
+    return n + 1 >= _geometry(state.dtype == torch.complex128).m or len(prims) >= CONFIG['small_fuse_min_gates']
+
+
+def _fold(t: torch.Tensor, dim: int | None, v: int, rows: int, lead: int) -> torch.Tensor:
+    """A (possibly mapped) operand as ``v * rows`` consecutive samples: ``t`` has ``lead`` trailing dims that are not
+    batch ((2^n,) -> 1, (D, D) -> 2); its own batch dim, if any, is 1 or ``rows``."""
+    if dim is not None:
+        t = t.movedim(dim, 0)
+    else:
+        t = t.unsqueeze(0)
+    if t.ndim == lead + 1:                       # no batch dim of its own
+        t = t.unsqueeze(1)
+    tail = t.shape[2:]
+    return t.expand(v, rows, *tail).reshape(v * rows, *tail)
+
+
+class _FusedCircuit(torch.autograd.Function):
+    """`_AdjointCircuit` for calls that run under ``torch.func`` transforms: the same fused forward and the same fused
+    reverse sweep, written in the ``setup_context`` style with a ``vmap`` rule -- the mapped dimension is folded into the
+    kernels' batch dimension and per-sample matrix stride, exactly as `ops._ApplyGate.vmap` does for one gate -- so that
+    ``torch.vmap(circuit)`` (the reference's batching mechanism, circuit.py:232-240) and ``jacrev`` / ``grad`` around a
+    circuit keep their passes instead of one launch per gate.  The backward is the node `_FusedSweep`, which has the same
+    kind of rule (``jacrev`` maps over cotangents).  First order only: `_fused_under_transforms` sends everything else to
+    the per-gate nodes."""
+
+    @staticmethod
+    def forward(state, meta, *mats):
+        prims = [Prim(k, m, t, c, mode) for (k, t, c, mode, _e), m in zip(meta, mats, strict=True)]
+        with torch.no_grad():
+            if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']):
+                prims = merge_one_qubit_runs(prims)
+            return _run_nograd(ops._plain(state), prims, zero_state=getattr(meta, 'zero_state', False))
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        state, meta, *mats = inputs
+        ctx.meta = meta
+        ctx.save_for_backward(state, output, *mats)
+
+    @staticmethod
+    def vmap(info, in_dims, state, meta, *mats):
+        v = info.batch_size
+        rows = state.shape[0] if in_dims[0] is None else state.movedim(in_dims[0], 0).shape[1]
+        fstate = _fold(state, in_dims[0], v, rows, 1)
+        mdims = in_dims[2:]
+        fmats = []
+        for m, d in zip(mats, mdims, strict=True):
+            if d is None and (m.ndim == 2 or m.shape[0] == 1):
+                fmats.append(m)                  # shared by every sample: stays one matrix
+            else:
+                fmats.append(_fold(m, d, v, rows, 2).contiguous())
+        meta2 = meta
+        if getattr(meta, 'zero_state', False) and in_dims[0] is not None:
+            meta2 = _Meta(tuple(meta), False)    # (only the circuit's own un-mapped |0..0> is vouched for)
+        out = _FusedCircuit.apply(fstate, meta2, *fmats)
+        return out.reshape(v, rows, out.shape[-1]), 0
+
+    @staticmethod
+    def backward(ctx, gy):
+        state, out, *mats = ctx.saved_tensors
+        need_state = bool(ctx.needs_input_grad[0])
+        need = tuple(bool(ctx.needs_input_grad[2 + j]) for j in range(len(mats)))
+        wrapped = ops._is_wrapped(gy) or ops._is_wrapped(out) or any(ops._is_wrapped(m) for m in mats)
+        if not wrapped:
+            if torch.is_grad_enabled() and not ops.transform_stack():
+                # plain autograd with create_graph=True on a node that was made under vmap: the differentiable routes
+                return _AdjointCircuit._backward_with_graph(ctx, gy)
+            with torch.no_grad():
+                gstate, grads = _AdjointCircuit._first_order(out, gy.contiguous(), ctx.meta, list(mats), need_state, list(need))
+            return (gstate, None, *grads)
+        mask = sum(1 << j for j, nd in enumerate(need) if nd)       # (an int: a leaf for the transforms' pytrees)
+        res = list(_FusedSweep.apply(gy, out, ctx.meta, need_state, mask, *mats))
+        gstate = res.pop(0) if need_state else None
+        grads = [res.pop(0) if nd else None for nd in need]
+        return (gstate, None, *grads)
+
+
+class _FusedSweep(torch.autograd.Function):
+    """(U^dagger gy, the matrix cotangents) by the fused reverse sweep, as a node with a ``vmap`` rule: ``jacrev`` maps over
+    cotangents -- every basis cotangent becomes a sample of ONE sweep (per-sample matrices, so that every sample gets
+    its own matrix cotangents)."""
+
+    @staticmethod
+    def forward(gy, out, meta, need_state, mask, *mats):
+        need = [bool((mask >> j) & 1) for j in range(len(mats))]
+        with torch.no_grad():
+            gstate, grads = _AdjointCircuit._first_order(ops._plain(out), ops._plain(gy).contiguous(), meta, list(mats),
+                                                         need_state, list(need))
+        return tuple(([gstate] if need_state else []) + [g for g in grads if g is not None])
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        pass
+
+    @staticmethod
+    def vmap(info, in_dims, gy, out, meta, need_state, mask, *mats):
+        need = [bool((mask >> j) & 1) for j in range(len(mats))]
+        v = info.batch_size
+        rows = out.shape[0] if in_dims[1] is None else out.movedim(in_dims[1], 0).shape[1]
+        fgy = _fold(gy, in_dims[0], v, rows, 1).contiguous()
+        fout = _fold(out, in_dims[1], v, rows, 1).contiguous()
+        mdims = in_dims[5:]
+        fmats, shared = [], []
+        for m, d, nd in zip(mats, mdims, need, strict=True):
+            one = m.ndim == 2 or (m.shape[0] if d is None else m.movedim(d, 0).shape[1] if m.ndim == 4 else 1) == 1
+            if d is None and one and not nd:
+                fmats.append(m)
+                shared.append(None)
+                continue
+            shared.append(one)               # its cotangent is summed over the rows of a sample (not over the mapped dim)
+            fmats.append(_fold(m, d, v, rows, 2).contiguous())
+        res = list(_FusedSweep.apply(fgy, fout, meta, need_state, mask, *fmats))
+        outs = []
+        if need_state:
+            g = res.pop(0)
+            outs.append(g.reshape(v, rows, g.shape[-1]))
+        for m, nd, one in zip(mats, need, shared, strict=True):
+            if not nd:
+                continue
+            g = res.pop(0)
+            g = g.reshape(v, rows, *g.shape[-2:])
+            if one:
+                g = g.sum(dim=1, keepdim=m.ndim != 2)
+            outs.append(g)
+        return tuple(outs), tuple(0 for _ in outs)
+
+    @staticmethod
+    def backward(ctx, *cots):
+        raise NotImplementedError('deepquantum_amd: a second derivative through a circuit node that ran under torch.func '
+                                  'transforms -- wrap BOTH derivatives in torch.func (jacrev(jacrev(f)), hessian(f)): the '
+                                  'gates then run as per-gate nodes, which differentiate to any order')
 
 
 class _AdjointCircuit(torch.autograd.Function):

@@ -741,5 +741,116 @@ def check_torch_func_transforms(dq, device=None):
         torch.autograd.functional.jacobian(f_kept, x, vectorize=True)
 
 
+def check_fused_node_under_transforms(dq, device=None, n=13):
+    """``torch.vmap`` over the circuit (the reference's batching, circuit.py:232-240), ``grad`` / ``jacrev`` /
+    ``vmap(grad)`` around it: ONE node with vmap rules (executor._FusedCircuit / _FusedSweep) -- fused passes and a fused
+    reverse sweep, not a launch per gate -- against the native batch and plain autograd; a vmapped forward differentiated
+    by plain autograd afterwards; second order still takes the per-gate nodes."""
+    import torch.func as tf
+
+    from deepquantum_amd import executor
+
+    def circuit():
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        for i in range(n):
+            cir.rx(i, encode=True)
+        for i in range(n - 1):
+            cir.cnot(i, i + 1)
+        for i in range(n):
+            cir.ry(i, encode=True)
+        cir.crx(1, 5, encode=True)
+        cir.rzz([0, 3], encode=True)
+        cir.observable(0)
+        cir.observable([1, 3], 'zz')
+        cir.observable(2, 'x')
+        return cir if device is None else cir.to(device)
+
+    cir = circuit()
+    data = torch.rand(5, cir.ndata, generator=torch.Generator().manual_seed(0)).to(device)
+    count = lambda: executor.LAST_RUN.get('fused_transform_nodes', 0)      # noqa: E731
+    with torch.no_grad():
+        native = cir(data).clone()
+        c0 = count()
+        vm = tf.vmap(cir._forward_helper, in_dims=(0, None))(data, cir.init_state.state)
+    assert (vm.reshape(native.shape) - native).abs().max().item() < 1e-6
+    assert count() == c0 + 1 and executor.LAST_RUN['passes'] > 0        # one node, fused passes
+
+    def f(p):
+        cir(data=p)
+        return cir.expectation().sum()
+
+    def fvec(p):
+        cir(data=p)
+        return cir.expectation().reshape(-1)
+
+    x = data[0].clone()
+    jac = torch.autograd.functional.jacobian(fvec, x)
+    c0 = count()
+    assert (tf.grad(f)(x) - jac.sum(0)).abs().max().item() < 1e-5
+    assert count() == c0 + 1
+    executor.LAST_SWEEP.update(fused=False, reductions=0)
+    assert (tf.jacrev(fvec)(x) - jac).abs().max().item() < 1e-5
+    assert count() == c0 + 2 and executor.LAST_SWEEP['fused'] and executor.LAST_SWEEP['reductions'] > 0
+    rows = torch.stack([x, 0.5 * x, x + 0.1])
+    want = torch.stack([torch.autograd.functional.jacobian(f, r) for r in rows])
+    assert (tf.vmap(tf.grad(f))(rows) - want).abs().max().item() < 1e-5
+    # vmap over the forward, plain autograd afterwards (the reference's training step: vmap inside forward, backward outside)
+    w = torch.arange(1 << n, dtype=torch.float32, device=device).reshape(1, -1, 1) / (1 << n)
+    d2 = data.clone().requires_grad_(True)
+    (tf.vmap(cir._forward_helper, in_dims=(0, None))(d2, cir.init_state.state).abs() ** 2 * w).sum().backward()
+    d3 = data.clone().requires_grad_(True)
+    (cir(d3).abs() ** 2 * w).sum().backward()
+    assert (d2.grad - d3.grad).abs().max().item() < 1e-5
+    # two reverse levels, forward mode: the per-gate nodes, as before
+    hes = torch.autograd.functional.hessian(f, x)
+    c0 = count()
+    assert (tf.jacrev(tf.jacrev(f))(x) - hes).abs().max().item() < 1e-4
+    assert (tf.hessian(f)(x) - hes).abs().max().item() < 1e-4
+    assert count() == c0
+    # A/B switch
+    executor.CONFIG['fused_transforms'] = False
+    try:
+        c0 = count()
+        assert (tf.jacrev(fvec)(x) - jac).abs().max().item() < 1e-5 and count() == c0
+    finally:
+        executor.CONFIG['fused_transforms'] = True
+
+
 def test_torch_func_transforms_over_a_circuit(cpu_backend):
     check_torch_func_transforms(dq)
+
+
+def test_fused_node_under_torch_func_transforms(cpu_backend):
+    from deepquantum_amd import executor
+
+    old = executor.CONFIG['permute_min_bits']
+    executor.CONFIG['permute_min_bits'] = 12
+    try:
+        check_fused_node_under_transforms(dq)
+    finally:
+        executor.CONFIG['permute_min_bits'] = old
+
+
+def test_functorch_probes_are_guarded(monkeypatch):
+    """The probes into functorch's interpreter stack (ops.transform_stack) are private API: checked on the releases
+    ops.FUNCTORCH_PROBES_CHECKED_ON names; where they fail, callers get None and take the conservative route."""
+    import torch.func as tf
+
+    from deepquantum_amd import ops
+
+    if any(torch.__version__.startswith(v) for v in ops.FUNCTORCH_PROBES_CHECKED_ON):
+        seen = []
+
+        def f(x):
+            seen.append(ops.transform_stack())
+            return (x * x).sum()
+
+        tf.vmap(tf.grad(f))(torch.ones(2, 3))
+        tf.jacfwd(f)(torch.ones(3))
+        assert seen[0] == ['Vmap', 'Grad'] and 'Jvp' in seen[1] and ops.transform_stack() == []
+    import torch._functorch.pyfunctorch as pf
+
+    monkeypatch.delattr(pf, 'retrieve_all_functorch_interpreters')
+    assert ops.transform_stack() is None
+    ops._single_forward_level()          # (no refusal without the probe: it goes ahead)

@@ -880,3 +880,14 @@ def test_torch_func_transforms_over_a_circuit_on_gpu():
     from test_api_cpu import check_torch_func_transforms
 
     check_torch_func_transforms(dq, device=dev())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [13, 20])
+def test_fused_node_under_torch_func_transforms_on_gpu(n):
+    """``torch.vmap(circuit)`` -- the reference's batching (circuit.py:232-240) -- ``grad``, ``jacrev`` and ``vmap(grad)``
+    around a circuit keep their fused passes on the GPU (executor._FusedCircuit: LAST_RUN['passes'] > 0 is asserted
+    inside), at a size where a launch per gate is an order of magnitude off (n = 20)."""
+    from test_api_cpu import check_fused_node_under_transforms
+
+    check_fused_node_under_transforms(dq, device=dev(), n=n)
