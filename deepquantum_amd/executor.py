@@ -108,7 +108,10 @@ CONFIG = {'fuse': True, 'min_low_c64': None, 'min_low_c128': None,
           # a call that sees torch.func wrappers (vmap over the circuit, grad / jacrev around it) runs as ONE node whose
           # vmap rules fold the mapped dimension into the kernels' batch (_FusedCircuit); False, or a transform stack it
           # does not take (forward mode, two grad levels): one node per gate, as in round 4
-          'fused_transforms': True}
+          'fused_transforms': True,
+          # a circuit node keeps its INPUT state for the second-order routes of its backward only if that is free (shared,
+          # differentiated) or the state is at most this big; otherwise the routes recompute it from the output
+          'keep_input_bytes': 64 << 20}
 
 # When enabled, every fused launch is bracketed by HIP events on the launch stream; bench.py reads
 # (start, stop, ngates, bytes read + written) to report the kernel's average duration next to its algorithmic bytes.
@@ -737,6 +740,9 @@ class _SweepGrads(torch.autograd.Function):
         if torch.is_grad_enabled():
             # third order and beyond: differentiate the per-gate formulation of F
             with torch.enable_grad():
+                # (an alias per slot: one tensor may serve several gates, and every slot gets its own cotangent instead
+                # of the sum over all of them)
+                mats = [m.view_as(m) for m in mats]
                 outs = _SweepGrads._replay(gy, state, meta, mats, need_state, need)
                 pairs = [(o, c) for o, c in zip(outs, cots, strict=True) if o is not None and c is not None]
                 inputs = [gy, state] + list(mats)
@@ -759,7 +765,9 @@ class _SweepGrads(torch.autograd.Function):
             mats_l = [m.detach().requires_grad_(bool(wants[6 + j])) for j, m in enumerate(mats)]
             alpha0 = torch.zeros_like(state) if c0 is None else c0.to(dt).expand_as(state)
             pair = torch.cat([state_l, alpha0], dim=-1)              # index bit n: psi | alpha
-            meta2 = [(kind, targets, controls, mode, True) for kind, targets, controls, mode, _e in meta]
+            # (a gate without a cotangent block keeps its own `exact` flag: a user matrix that is unitary to 1e-4 only is
+            # undone with its inverse here as in the first-order sweep)
+            meta2 = [(kind, targets, controls, mode, _e) for kind, targets, controls, mode, _e in meta]
             mats2 = list(mats_l)              # (a gate without a cotangent: the same gate on both halves)
             groups: dict = {}                 # the blocks [[U, 0], [C, U]] of all gates of one shape in a few calls
             for j, ((kind, targets, _c, _m, _e), m) in enumerate(zip(meta, mats_l, strict=True)):
@@ -776,7 +784,7 @@ class _SweepGrads(torch.autograd.Function):
                 blk = torch.cat([top, torch.cat([cs, us], dim=-1)], dim=-2)     # on (bit n, the gate's targets)
                 parts = (blk if nb > 1 else blk[:, 0]).unbind(0)
                 for j, part in zip(js, parts, strict=True):
-                    meta2[j] = ('gen', (n,) + tuple(meta[j][1]), meta[j][2], 0, False)
+                    meta2[j] = ('gen', (n,) + tuple(meta[j][1]), meta[j][2], 0, 'block')
                     mats2[j] = part
             out2 = _AdjointCircuit.apply(pair, _Meta(tuple(meta2), tangent=True), *mats2)
             g_gy = out2[:, dim:] if wants[0] else None                        # alpha_K
@@ -843,7 +851,8 @@ class _FusedCircuit(torch.autograd.Function):
     def setup_context(ctx, inputs, output):
         state, meta, *mats = inputs
         ctx.meta = meta
-        ctx.save_for_backward(state, output, *mats)
+        ctx.kept_input = ops._is_wrapped(state) or _keep_input(state, ctx.needs_input_grad[0])
+        ctx.save_for_backward(state if ctx.kept_input else state.new_empty(0), output, *mats)
 
     @staticmethod
     def vmap(info, in_dims, state, meta, *mats):
@@ -939,6 +948,25 @@ class _FusedSweep(torch.autograd.Function):
                                   'gates then run as per-gate nodes, which differentiate to any order')
 
 
+def _keep_input(state: torch.Tensor, differentiated: bool) -> bool:
+    return bool(differentiated or state.requires_grad or (state.ndim == 2 and state.stride(0) == 0)
+                or state.numel() * state.element_size() <= CONFIG['keep_input_bytes'])
+
+
+def _input_of(ctx, state: torch.Tensor, out: torch.Tensor, mats: Sequence[torch.Tensor]) -> torch.Tensor:
+    """The input state of a circuit node for its second-order routes: the saved one, or -- where the forward did not pin
+    it (`_keep_input`) -- recomputed from the output by the exact inverses of the gates in reverse order (fused passes;
+    equal to the input to the rounding of the state's precision)."""
+    if getattr(ctx, 'kept_input', True):
+        return state
+    with torch.no_grad():
+        prims = []
+        for (kind, targets, controls, mode, _e), m in reversed(list(zip(ctx.meta, mats, strict=True))):
+            u = m.detach() if m.ndim == 3 else m.detach().unsqueeze(0)
+            prims.append(Prim(kind, u if kind == 'x' else _inverse(kind, u.to(out.dtype)), targets, controls, mode))
+        return _run_nograd(out.detach(), prims)
+
+
 class _AdjointCircuit(torch.autograd.Function):
     """y = U_K ... U_1 x for reversible gates as ONE autograd node.  Forward: the fused passes.  Backward: a
     reverse sweep over two states stacked as one batch -- psi_j recomputed with the exact inverses, the
@@ -956,10 +984,13 @@ class _AdjointCircuit(torch.autograd.Function):
                 prims = merge_one_qubit_runs(prims)
         out = _run_nograd(state, prims, zero_state=getattr(meta, 'zero_state', False))
         ctx.meta = meta
-        # (the input is kept by reference for the second-order route of ``backward``; the sweep itself needs only
-        # ``out``.  It costs no memory as a rule: the initial state belongs to the circuit, the state between two
-        # stretches is the saved output of the stretch before.)
-        ctx.save_for_backward(state, out, *mats)
+        # The input is kept for the second-order route of ``backward`` only (the sweep itself needs ``out`` alone) -- and
+        # only where keeping it is free or needed: a shared (stride-0) or small state, or one the caller differentiates
+        # with respect to.  A big input of somebody else's -- an amplitude-encoded batch, the state behind a Reset -- would
+        # be pinned for the whole first-order training step (2-4 GB at n >= 28); the second-order route
+        # recomputes it from ``out`` with the exact inverses instead (`_input_of`).
+        ctx.kept_input = _keep_input(state, ctx.needs_input_grad[0])
+        ctx.save_for_backward(state if ctx.kept_input else state.new_empty(0), out, *mats)
         return out
 
     @staticmethod
@@ -972,6 +1003,7 @@ class _AdjointCircuit(torch.autograd.Function):
         for: Hessians (examples/benchmarks/gradient_benchmark.py:147-163), gradient penalties.  First-order
         ``backward()`` never comes here."""
         state, out, *mats = ctx.saved_tensors
+        state = _input_of(ctx, state, out, mats)
         meta = ctx.meta
         need = tuple(bool(ctx.needs_input_grad[2 + j]) for j in range(len(mats)))
         if CONFIG['second_order'] == 'tangent' and _SweepGrads.takes(meta, mats, need) and not getattr(meta, 'tangent', False):
@@ -1025,7 +1057,7 @@ class _AdjointCircuit(torch.autograd.Function):
         for j, ((kind, _t, _c, _mode, exact), m) in enumerate(zip(meta, mats, strict=True)):
             u = m if m.ndim == 3 else m.unsqueeze(0)
             # (the blocks [[U, 0], [C, U]] of a tangent circuit: a group of their own, inverted block-wise)
-            groups.setdefault((kind, u.shape[-1], u.shape[0]) + (('block',) if tangent and not exact else ()), []).append((j, u))
+            groups.setdefault((kind, u.shape[-1], u.shape[0]) + (('block',) if tangent and exact == 'block' else ()), []).append((j, u))
         undo: list = [None] * len(mats)       # (2b, D, D): rows [0, b) the inverse, rows [b, 2b) the adjoint
         inv_h: dict = {}                      # group key -> (positions, inverse^dagger stack) for the gradients
         is128 = out.dtype == torch.complex128
@@ -1038,7 +1070,7 @@ class _AdjointCircuit(torch.autograd.Function):
             for k, (j, _u) in enumerate(members):
                 undo[j] = both[k]
             # U^dagger U: what the fused sweep multiplies lambda by after U^-1 (complex128; user matrices in any precision)
-            if kind != 'x' and (is128 or any(not meta[j][4] for j, _ in members)):
+            if kind != 'x' and (is128 or any(meta[j][4] is not True for j, _ in members)):
                 cs = us.mH @ us
                 for k, (j, _u) in enumerate(members):
                     corr[j] = cs[k]
@@ -1059,8 +1091,8 @@ class _AdjointCircuit(torch.autograd.Function):
             # complex128: a matrix that is not computed from parameters or data may be unitary only to float32 rounding
             # (the reference's fixed matrices are, after .to(torch.double)): the sweep then tells U^-1 from U^dagger
             # -- and a user-supplied matrix (UAnyGate: unitary to 1e-4 is all the reference asks) in any precision
-            inexact = [j in corr and ((not need[j] and m.grad_fn is None and not m.requires_grad and (is128 or not meta[j][4]))
-                                      or (tangent and not meta[j][4]))
+            inexact = [j in corr and ((not need[j] and m.grad_fn is None and not m.requires_grad
+                                       and (is128 or meta[j][4] is not True)) or (tangent and meta[j][4] == 'block'))
                        for j, m in enumerate(mats)]
             raw, lam = _AdjointCircuit._sweep_fused(out, gy, meta, undo, need, b,
                                                     [m.ndim == 2 or m.shape[0] == 1 for m in mats], corr, inexact)
@@ -1157,6 +1189,7 @@ class _AdjointCircuit(torch.autograd.Function):
         prims: list[Prim] = []
         scalars: dict[int, int] = {}      # prim index -> gate, for the gates whose U^dagger U is a scalar != 1
         grad_at: dict[int, int] = {}      # prim index of a reduction -> its row
+        variants: dict[int, int] = {}     # row -> which sums its record forms (DQ_FG_GRAD `loc`)
         for j in range(len(meta) - 1, -1, -1):
             kind, targets, controls, mode, _exact = meta[j]
             t1, c1 = tuple(t + 1 for t in targets), tuple(c + 1 for c in controls)
@@ -1169,6 +1202,7 @@ class _AdjointCircuit(torch.autograd.Function):
                 for q in recs:
                     if q.kind == 'grad':
                         grad_at[len(prims)] = q.mode & fusion.GRAD_ROW_MASK
+                        variants[q.mode & fusion.GRAD_ROW_MASK] = q.mode >> fusion.GRAD_VARIANT_SHIFT
                     prims.append(q)
                 nrows += cnt
             if (inexact is not None and inexact[j] and kind == 'gen' and mode == 3 and not controls and shared[j]
@@ -1196,6 +1230,15 @@ class _AdjointCircuit(torch.autograd.Function):
                 scratch = torch.empty_like(work)
         work = _run_nograd(work, prims, inplace=True, scratch=scratch, grads=acc)
         LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=nrows, with_graph=False)
+        if CONFIG.get('check_grad_rows'):
+            # (tests) the ABI's promise for reduced records: the components a variant does not form are left untouched --
+            # zero, since the accumulator was zeroed -- which is what lets `_first_order` multiply whole rows by U^-dagger
+            keep = {0: range(8), 1: (0, 2, 4, 6), 2: (0, 3), 3: (0, 1, 6, 7)}       # (Re, Im) of G00 G01 G10 G11
+            for r, v_ in variants.items():
+                idle = [c for c in range(8) if c not in keep[v_]]
+                if idle and float(acc[:, r, idle].abs().max()) != 0.0:
+                    raise AssertionError(f'DQ_FG_GRAD variant {v_}, row {r}: components {idle} were written to')
+            LAST_SWEEP['checked_rows'] = len(variants)
         g = torch.view_as_complex(acc.reshape(b, -1, 4, 2)).reshape(b, -1, 2, 2)
         if scalars and rows:
             # row r was reduced from a psi that is  prod 2 s_k^2  (over the scalar gates executed before it) too large

@@ -112,10 +112,12 @@ typedef enum {
                         q2: 0 = psi, 1 = lambda); the record adds  G[a][b] = sum lambda[target = a] conj(psi[target = b])
                         (target = register slot q; the sum runs over everything else, restricted to the controls being
                         1) to row `reserved` of the caller's accumulator.  No matrix, no handler id.
-                        `loc` says which of the eight real sums the caller will read (a kernel may compute all of them):
+                        `loc` says which of the eight real sums the record forms:
                         0 all; 1 Re G only (the trainable gate's matrix is real); 2 Re (G00 + G11), left in Re G00, and
                         Im (G01 + G10), left in Im G01 (a matrix a I + i b X: a Pauli-X rotation); 3 G00 and G11 only
-                        (a diagonal matrix).  The other components of the row are then unspecified */
+                        (a diagonal matrix).  The OTHER components of the row are left untouched -- nothing is added to
+                        them, so a caller that zeroed the accumulator reads zeros there and may use the whole row in
+                        linear algebra (executor._first_order multiplies the 2x2 row by U^-dagger) */
     DQ_FG_EXPZ = 7   /* not a gate: the expectation value of a Z string taken from the registers, so that a circuit's
                         <Z..Z> observables cost no extra read of the state (replaces qmath.expectation qmath.py:830-860
                         for Z-type observables): adds  sum_i (-1)^popc(i & zmask) |a_i|^2  to component 0 of row

@@ -256,6 +256,7 @@ def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5, dtype=torch.floa
     cotangent interleaved along an extra index bit, the reductions folded into the passes (DQ_FG_GRAD):
     against per-gate autograd and against the undo-then-reduce sweep, with controlled / diagonal / general trainable
     gates, fixed gates of every kind, batched encoded data and an initial state that requires grad."""
+    dq.executor.CONFIG['check_grad_rows'] = True      # (ADVICE r4: reduced DQ_FG_GRAD rows leave the other components zero)
     def build():
         torch.manual_seed(5)
         cir = dq.QubitCircuit(n)

@@ -303,3 +303,43 @@ def test_second_order_with_an_initial_state_that_requires_grad(cpu_backend):
     for x, y in zip(res['tangent'], res['replay'], strict=True):
         assert (x - y).abs().max().item() < 1e-12
     assert res['replay'][0].abs().max().item() > 1e-2
+
+
+def test_second_order_with_an_input_state_the_node_did_not_keep(cpu_backend):
+    """A circuit node pins its INPUT state only where that is free (shared, small, differentiated:
+    executor._keep_input); the second-order routes of its backward otherwise recompute it from the output with the
+    exact inverses (executor._input_of): same Hessian either way."""
+    from deepquantum_amd import executor
+
+    old = dict(executor.CONFIG)
+    executor.CONFIG['permute_min_bits'] = 12
+    try:
+        n = 13
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        for i in range(n):
+            cir.rx(i, encode=True)
+        for i in range(n - 1):
+            cir.cnot(i, i + 1)
+        for i in range(4):
+            cir.ry(i, encode=True)
+        cir.observable(0)
+        cir.observable([1, 3], 'zz')
+        cir.to(torch.double)
+        g = torch.Generator().manual_seed(3)
+        st = torch.randn(2, 1 << n, 1, dtype=torch.complex128, generator=g)
+        st = st / st.norm(dim=1, keepdim=True)
+        x = torch.rand(cir.ndata, dtype=torch.float64, generator=g)
+
+        def f(p):
+            cir(data=p, state=st)
+            return cir.expectation().sum()
+
+        res = {}
+        for kb in (64 << 20, 0):
+            executor.CONFIG['keep_input_bytes'] = kb
+            res[kb] = torch.autograd.functional.hessian(f, x)
+        assert res[0].abs().max().item() > 1e-3
+        assert (res[64 << 20] - res[0]).abs().max().item() < 1e-12
+    finally:
+        executor.CONFIG.update(old)
