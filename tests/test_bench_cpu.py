@@ -67,6 +67,8 @@ def test_gpus_2_without_torchrun_runs_two_ranks_and_checks_their_shards(tmp_path
     par = line['parity']
     assert par['amplitudes_checked_per_rank_sum'] == 4096 and par['l2_error_relative'] < 1e-4
     assert line['config']['exchange_per_step']['remaps'] > 0
+    # `value` is the drop-in step (the reference's shard order restored by every forward); the lazy layout is beside it
+    assert line['config']['lazy_layout'] is False and line['value_lazy_layout'] > 0 and line['ms_per_step_lazy_layout'] > 0
 
 
 def test_sharded_config_with_the_cx_pair_and_a_wrong_pin(tmp_path):
