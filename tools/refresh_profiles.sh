@@ -2,7 +2,7 @@
 # Everything profiles/<tag>/ holds, in one go on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
 # then copy gpurun_out/prof/<tag>/{summary.txt,kernel_stats.csv,traffic_*.json,bench_*.json,*.txt} to profiles/<tag>/.
 cd "$(dirname "$0")/.."
-tag=${1:-r04}
+tag=${1:-r05}
 root=$PWD/gpurun_out/prof/$tag
 bash tools/profile.sh "$tag" > /dev/null 2>&1
 cp "$root/traffic.json" "$root/traffic_n28_b16_c64.json" 2>/dev/null
@@ -37,10 +37,19 @@ bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
 } > "$root/secondary_benchmarks.txt" 2>&1
 {
   for a in "--batch 4" "--strong" "--config 4" "--config 5" "--batch 4 --batch-shard"; do
-    echo "# bench_two_ranks_one_gpu.sh --nqubit 24 --depth 10 $a (gloo, two ranks sharing one GPU: functional check, not a performance number)"
-    bash tools/bench_two_ranks_one_gpu.sh --nqubit 24 --depth 10 --no-cpu-baseline --no-sweep $a 2>&1 | tail -1
+    echo "# python bench.py --gpus 2 --backend gloo --nqubit 24 --depth 10 $a (self-launched; two gloo ranks sharing one GPU: functional check, not a performance number)"
+    python bench.py --gpus 2 --backend gloo --steps 1 --warmup 1 --nqubit 24 --depth 10 --no-cpu-baseline --no-sweep $a 2>&1 | grep '^{' | tail -1
   done
 } > "$root/two_ranks_one_gpu_functional.txt" 2>&1
+{
+  echo "# bench.py --rehearse-rank R: the COMPUTE half of rank R's step of the strong-scaling job (n = 34 on 8 ranks), measured on this one GPU"
+  for r in 0 1; do for v in 0 2; do
+    python bench.py --gpus 8 --strong --rehearse-rank $r --virtual-bits $v --steps 5 --warmup 1 2>/dev/null | grep '^{'
+  done; done
+  echo "# ... and of config 4 (n = 32 on 4 ranks), rank 0 and rank 1"
+  for r in 0 1; do python bench.py --gpus 4 --config 4 --rehearse-rank $r --virtual-bits 0 --steps 5 --warmup 1 2>/dev/null | grep '^{'; done
+} > "$root/strong_rehearsal.txt" 2>&1
+python tools/bench_vmap.py 20 16 2>&1 | grep -v amdgpu.ids > "$root/bench_vmap.txt"
 python tools/bench_dense.py 2>&1 | grep -v amdgpu.ids > "$root/bench_dense.txt"
 python tools/dump_passes.py 2>&1 | grep -v amdgpu.ids > "$root/passes_headline.txt"
 python tools/bench_gradient_reference.py --trials 3 2>&1 | grep -v "amdgpu.ids\|UserWarning\|run_backward" > "$root/bench_gradient_reference.txt"
