@@ -12,10 +12,13 @@ import _wave_emulator as emu
 
 
 def handler_costs(g):
-    """{handler id: (VALU, DS, SALU) instructions of its body} -- the straight-line count (masked bodies run whole)."""
+    """{handler id: (VALU, DS, SALU) instructions a wave EXECUTES in its body}: masked bodies run whole; of the two variants
+    of a deferred Rx body (f [[1, it], [it, 1]] / f [[it, 1], [1, it]]) one runs."""
     out = {}
     for i, (ctl, lines) in g.handlers().items():
         v = sum(1 for ln in lines if ln.lstrip().startswith('v_'))
+        if g.ID_GEN_U + 12 <= i < g.ID_GEN_U + 18:
+            v = v // 2 - 1
         d = sum(1 for ln in lines if ln.lstrip().startswith('ds_'))
         s = sum(1 for ln in lines if ln.lstrip().startswith('s_'))
         out[i] = (v + (2 if ctl else 0), d, s + (6 if ctl else 0))
@@ -69,4 +72,21 @@ if __name__ == '__main__':
         x = np.array([r['valu'] for r in rows[4:-1]], float); y = np.array(meas[4:-1])
         A = np.stack([np.ones_like(x), x], 1)
         coef, res, *_ = np.linalg.lstsq(A, y, rcond=None)
-        print('fit full passes 4..17: ms =', coef[0], '+', coef[1], '* valu; residual rms', float(np.sqrt(((A @ coef - y) ** 2).mean())))
+        print(f'fit over the full passes 4..17: ms = {coef[0]:.2f} + {coef[1] * 1e3:.3f}e-3 * VALU; residual rms '
+              f'{float(np.sqrt(((A @ coef - y) ** 2).mean())):.2f} ms   (a purely VALU-bound kernel: 1024 tiles per SIMD x 2.07 ns = 2.12e-3)')
+        g = emu.gen()
+        hc = handler_costs(g)
+        names = sorted((getattr(g, k), k) for k in dir(g) if k.startswith('ID_'))
+        cls = lambda i: [k for v_, k in names if v_ <= i][-1]         # noqa: E731
+        from collections import Counter
+        cv, cn = Counter(), Counter()
+        for r in rows[4:]:
+            for i in r['ids']:
+                key = cls(i) + (f' mode {i // 6}' if i < 24 else '')
+                cv[key] += hc.get(i, (0, 0, 0))[0]
+                cn[key] += 1
+        tot = sum(cv.values())
+        print(f'VALU instructions executed per tile over the full passes of a step: {tot}')
+        for k, v_ in cv.most_common():
+            if v_:
+                print(f'  {k:18s} {cn[k]:4d} records  {v_:6d}  {v_ / tot:.3f}  ({v_ / cn[k]:.0f} per record)')
