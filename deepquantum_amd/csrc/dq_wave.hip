@@ -587,8 +587,9 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
     if (rc) return rc;
     const uint64_t tiles = 1ull << (kp.zext & 63u);
     int tpw = 1;
-    if (GRAD) {     // tiles per wave: as many as leave >= 2048 workgroups per sample batch
-        while (tpw < 64 && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
+    if (GRAD) {     // tiles per wave: as many as leave >= 2048 workgroups per sample batch (DQ_WAVE_GRAD_TPW: a cap, experiments)
+        static const int gcap = [] { const char* e = getenv("DQ_WAVE_GRAD_TPW"); return e ? atoi(e) : 64; }();
+        while (tpw < gcap && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
     } else {
         static const int tpw_env = [] { const char* e = getenv("DQ_WAVE_TPW"); return e ? atoi(e) : 1; }();
         while (tpw < tpw_env && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
