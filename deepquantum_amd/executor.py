@@ -919,25 +919,28 @@ class _FusedSweep(torch.autograd.Function):
         mdims = in_dims[5:]
         fmats, shared = [], []
         for m, d, nd in zip(mats, mdims, need, strict=True):
-            one = m.ndim == 2 or (m.shape[0] if d is None else m.movedim(d, 0).shape[1] if m.ndim == 4 else 1) == 1
+            logical = m.ndim - (d is not None)                     # (D, D) or (bm, D, D) as the caller sees it
+            bm = 1 if logical == 2 else (m.shape[0] if d is None else m.movedim(d, 0).shape[1])
+            one = bm == 1
             if d is None and one and not nd:
                 fmats.append(m)
                 shared.append(None)
                 continue
-            shared.append(one)               # its cotangent is summed over the rows of a sample (not over the mapped dim)
+            # (its cotangent is summed over the rows of a sample, never over the mapped dimension; True: keep a batch dim of 1)
+            shared.append((logical != 2) if one else None)
             fmats.append(_fold(m, d, v, rows, 2).contiguous())
         res = list(_FusedSweep.apply(fgy, fout, meta, need_state, mask, *fmats))
         outs = []
         if need_state:
             g = res.pop(0)
             outs.append(g.reshape(v, rows, g.shape[-1]))
-        for m, nd, one in zip(mats, need, shared, strict=True):
+        for nd, keep in zip(need, shared, strict=True):
             if not nd:
                 continue
             g = res.pop(0)
             g = g.reshape(v, rows, *g.shape[-2:])
-            if one:
-                g = g.sum(dim=1, keepdim=m.ndim != 2)
+            if keep is not None:
+                g = g.sum(dim=1, keepdim=keep)
             outs.append(g)
         return tuple(outs), tuple(0 for _ in outs)
 

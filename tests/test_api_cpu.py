@@ -795,6 +795,9 @@ def check_fused_node_under_transforms(dq, device=None, n=13):
     rows = torch.stack([x, 0.5 * x, x + 0.1])
     want = torch.stack([torch.autograd.functional.jacobian(f, r) for r in rows])
     assert (tf.vmap(tf.grad(f))(rows) - want).abs().max().item() < 1e-5
+    # (two vmap levels in the sweep: the data rows outside, the basis cotangents of jacrev inside)
+    wantj = torch.stack([torch.autograd.functional.jacobian(fvec, r) for r in rows])
+    assert (tf.vmap(tf.jacrev(fvec))(rows) - wantj).abs().max().item() < 1e-5
     # vmap over the forward, plain autograd afterwards (the reference's training step: vmap inside forward, backward outside)
     w = torch.arange(1 << n, dtype=torch.float32, device=device).reshape(1, -1, 1) / (1 << n)
     d2 = data.clone().requires_grad_(True)
