@@ -252,11 +252,21 @@ def check_adjoint_grad_mode(dq, device=None, dtype=torch.float64, n=6, tol=1e-10
 
 
 def check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5, dtype=torch.float32):
+    # (reduced DQ_FG_GRAD rows leave the other components zero -- checked inside the sweep while this runs; the
+    # check reads the accumulator on the host, so it must not stay on for the HIP-graph tests that follow)
+    dq.executor.CONFIG['check_grad_rows'] = True
+    try:
+        _check_fused_sweep(dq, device, n, batch, tol, dtype)
+        assert dq.executor.LAST_SWEEP.get('checked_rows', 0) > 0
+    finally:
+        dq.executor.CONFIG['check_grad_rows'] = False
+
+
+def _check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5, dtype=torch.float32):
     """Circuits whose trainable gates have one or two targets run their reverse sweep as fused passes over psi and the
     cotangent interleaved along an extra index bit, the reductions folded into the passes (DQ_FG_GRAD):
     against per-gate autograd and against the undo-then-reduce sweep, with controlled / diagonal / general trainable
     gates, fixed gates of every kind, batched encoded data and an initial state that requires grad."""
-    dq.executor.CONFIG['check_grad_rows'] = True      # (ADVICE r4: reduced DQ_FG_GRAD rows leave the other components zero)
     def build():
         torch.manual_seed(5)
         cir = dq.QubitCircuit(n)

@@ -20,6 +20,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _bench(*args, need_gib, timeout=900):
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()        # (what this pytest process still caches from earlier tests is not free for the ranks)
+    torch.cuda.synchronize()
     free, _total = torch.cuda.mem_get_info()
     if free < need_gib * 2**30:
         pytest.skip(f'needs {need_gib} GiB of free device memory')
