@@ -639,7 +639,7 @@ def main():
     # ... and the same step with the lazy layout (no restore of the reference's shard order at the end of the forward: what
     # a training or benchmark step that only takes <Z..Z> from the state needs), a few steps, max over ranks
     lazy_ms = None
-    if distributed and not rehearse:
+    if distributed and not rehearse and not args.functional:     # (a functional run checks the drop-in step only)
         cir.lazy_layout = True
         step()
         sync()
