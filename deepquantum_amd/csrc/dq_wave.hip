@@ -587,8 +587,10 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
     if (rc) return rc;
     const uint64_t tiles = 1ull << (kp.zext & 63u);
     int tpw = 1;
-    if (GRAD) {     // tiles per wave: as many as leave >= 2048 workgroups per sample batch (DQ_WAVE_GRAD_TPW: a cap, experiments)
-        static const int gcap = [] { const char* e = getenv("DQ_WAVE_GRAD_TPW"); return e ? atoi(e) : 64; }();
+    if (GRAD) {     // tiles per wave: up to 2 while >= 2048 workgroups per sample batch are left.  More tiles per wave save atomics
+        // on the caller's sums but leave a longer tail: training step n = 28 (32 sweep passes) 89.3 ms at a cap of 64 (rounds
+        // 3-4), 87.8 at 8, 87.4 at 2, 86.5 at 1 (profiles/r05/exp_grad_tpw.txt).  DQ_WAVE_GRAD_TPW overrides the cap
+        static const int gcap = [] { const char* e = getenv("DQ_WAVE_GRAD_TPW"); return e ? atoi(e) : 2; }();
         while (tpw < gcap && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
     } else {
         static const int tpw_env = [] { const char* e = getenv("DQ_WAVE_TPW"); return e ? atoi(e) : 1; }();
