@@ -136,6 +136,14 @@ class QubitCircuit(Operation):
             out.extend(op.prims(decompose))
         return out
 
+    def _apply(self, fn: Any, *args, **kwargs):
+        # (the tiny buffers of all gates move in one copy per dtype: utils.BulkMove)
+        from .utils import BulkMove
+
+        if not isinstance(fn, BulkMove) and len(self.operators) >= 8:
+            fn = BulkMove(fn, self)
+        return super()._apply(fn, *args, **kwargs)
+
     def _run_operators(self, flat: torch.Tensor, zero: bool = False) -> torch.Tensor:
         """All operators on a (B, 2**n) state: maximal stretches of gates go to the executor (fused passes),
         state-dependent operations (``Reset``) run between them.  ``zero``: ``flat`` is |0..0> (vec |0..0><0..0| of a

@@ -857,3 +857,32 @@ def test_functorch_probes_are_guarded(monkeypatch):
     monkeypatch.delattr(pf, 'retrieve_all_functorch_interpreters')
     assert ops.transform_stack() is None
     ops._single_forward_level()          # (no refusal without the probe: it goes ahead)
+
+
+def test_a_circuit_moves_its_small_buffers_in_bulk():
+    """``cir.to(device)``: the tiny buffers of all gates travel as one copy per dtype (utils.BulkMove) -- same shapes, dtypes
+    and values, every buffer a view of the moved block; dtype-only conversions and parameters go the ordinary way."""
+    def build():
+        torch.manual_seed(1)
+        cir = dq.QubitCircuit(6)
+        for _ in range(3):
+            for i in range(5):
+                cir.cnot(i, i + 1)
+            cir.rxlayer(encode=True)
+            cir.rzlayer()                       # trainable: nn.Parameters, never part of the bulk move
+            cir.u3layer(encode=True)
+        cir.observable(0)
+        return cir
+
+    cir = build()
+    before = {k: (v.shape, v.dtype) for k, v in cir.state_dict().items()}
+    cir.to('meta')
+    after = {k: (v.shape, v.dtype, v.device.type) for k, v in cir.state_dict().items()}
+    assert {k: v[:2] for k, v in after.items()} == before and all(v[2] == 'meta' for v in after.values())
+    views = [op.matrix for op in cir.operators if type(op).__name__ == 'CNOT']
+    assert all(m._base is not None for m in views)                         # slices of ONE moved block
+    assert all(p._base is None for p in cir.parameters())
+    cir2 = build().to(torch.double)                                          # (no device move: nothing batched)
+    assert cir2.operators[0].matrix.dtype == torch.complex128 and cir2.operators[0].matrix._base is None
+    ref = build()
+    assert all(torch.equal(a, b) for a, b in zip(cir2.to(torch.float).state_dict().values(), ref.state_dict().values()))
