@@ -1016,3 +1016,65 @@ def check_hvp_random(dq, device=None, n=6, batch=1, seed=0, ngates=40, tol=1e-9,
         assert (a is None) == (b is None)
         if a is not None:
             assert (a - b).abs().max().item() < tol * scale, (seed, (a - b).abs().max().item(), scale)
+
+
+def check_transforms_random(dq, device=None, n=10, seed=0, ngates=40, dtype=torch.float32, tol=5e-5):
+    """Fuzz of the fused node under ``torch.func`` transforms (executor._FusedCircuit / _FusedSweep): a random circuit over
+    the gate menu whose parametric gates are all data-encoded -- ``vmap`` over the circuit against the native batch,
+    ``jacrev`` against ``torch.autograd.functional.jacobian``, ``vmap(grad)`` against a loop, ``vmap(jacrev)``."""
+    import random
+
+    import torch.func as tf
+
+    rng = random.Random(seed)
+    cir = dq.QubitCircuit(n)
+    cir.hlayer()
+    for _ in range(ngates):
+        kind = rng.choice(['h', 'x', 's', 't', 'cnot', 'cz', 'toffoli', 'swap', 'rx', 'ry', 'rz', 'u3', 'crx', 'cry', 'p', 'cp',
+                           'rxx', 'ryy', 'rzz', 'rx2c'])
+        w = rng.sample(range(n), 3)
+        if kind in ('h', 'x', 's', 't'):
+            getattr(cir, kind)(w[0], controls=[w[1]] if rng.random() < 0.2 else None)
+        elif kind in ('cnot', 'cz'):
+            getattr(cir, kind)(w[0], w[1])
+        elif kind == 'toffoli':
+            cir.toffoli(w[0], w[1], w[2])
+        elif kind == 'swap':
+            cir.swap([w[0], w[1]])
+        elif kind in ('rx', 'ry', 'rz', 'u3', 'p'):
+            getattr(cir, kind)(w[0], encode=True)
+        elif kind in ('crx', 'cry', 'cp'):
+            getattr(cir, kind)(w[0], w[1], encode=True)
+        elif kind in ('rxx', 'ryy', 'rzz'):
+            getattr(cir, kind)([w[0], w[1]], encode=True)
+        else:
+            cir.rx(w[0], controls=[w[1], w[2]], encode=True)
+    cir.observable(0)
+    cir.observable([1, n - 1], 'zz')
+    cir.observable([2, 3], 'xy')
+    if device is not None:
+        cir.to(device)
+    real = torch.float32
+    if dtype == torch.float64:
+        cir.to(torch.double)
+        real = torch.float64
+    if cir.ndata == 0:
+        return
+    g = torch.Generator().manual_seed(seed)
+    data = (torch.rand(3, cir.ndata, generator=g, dtype=real) * 6.28).to(device)
+    with torch.no_grad():
+        native = cir(data).clone()
+        vm = tf.vmap(cir._forward_helper, in_dims=(0, None))(data, cir.init_state.state)
+    assert (vm.reshape(native.shape) - native).abs().max().item() < tol, ('vmap', seed)
+
+    def fvec(p):
+        cir(data=p)
+        return cir.expectation().reshape(-1)
+
+    x = data[0].clone()
+    jac = torch.autograd.functional.jacobian(fvec, x)
+    assert (tf.jacrev(fvec)(x) - jac).abs().max().item() < tol, ('jacrev', seed)
+    want = torch.stack([torch.autograd.functional.jacobian(lambda p: fvec(p).sum(), r) for r in data])
+    assert (tf.vmap(tf.grad(lambda p: fvec(p).sum()))(data) - want).abs().max().item() < tol, ('vmap(grad)', seed)
+    wantj = torch.stack([torch.autograd.functional.jacobian(fvec, r) for r in data])
+    assert (tf.vmap(tf.jacrev(fvec))(data) - wantj).abs().max().item() < tol, ('vmap(jacrev)', seed)

@@ -886,3 +886,18 @@ def test_a_circuit_moves_its_small_buffers_in_bulk():
     assert cir2.operators[0].matrix.dtype == torch.complex128 and cir2.operators[0].matrix._base is None
     ref = build()
     assert all(torch.equal(a, b) for a, b in zip(cir2.to(torch.float).state_dict().values(), ref.state_dict().values()))
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_torch_func_transforms_over_random_circuits(cpu_backend, seed):
+    from _helpers import check_transforms_random
+    from deepquantum_amd import executor
+
+    old = executor.CONFIG['permute_min_bits']
+    executor.CONFIG['permute_min_bits'] = 12
+    try:
+        n = (5, 8, 11, 13)[seed]
+        check_transforms_random(dq, n=n, seed=seed, ngates=24 + 6 * seed)
+        check_transforms_random(dq, n=n, seed=seed, ngates=24 + 6 * seed, dtype=torch.float64, tol=1e-10)
+    finally:
+        executor.CONFIG['permute_min_bits'] = old

@@ -891,3 +891,15 @@ def test_fused_node_under_torch_func_transforms_on_gpu(n):
     from test_api_cpu import check_fused_node_under_transforms
 
     check_fused_node_under_transforms(dq, device=dev(), n=n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [10, 11, 12, 13, 14, 15])
+def test_torch_func_transforms_over_random_circuits_on_gpu(seed):
+    """Fuzz of the fused node under torch.func transforms over the gate menu (controls of every arity, two-target encoded
+    gates), below and above a tile, both precisions."""
+    from _helpers import check_transforms_random
+
+    n = (5, 9, 12, 14, 16, 18)[seed - 10]
+    check_transforms_random(dq, device=dev(), n=n, seed=seed, ngates=30 + 6 * (seed - 10))
+    check_transforms_random(dq, device=dev(), n=n, seed=seed, ngates=30 + 6 * (seed - 10), dtype=torch.float64, tol=1e-10)
