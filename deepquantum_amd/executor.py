@@ -803,13 +803,14 @@ class _SweepGrads(torch.autograd.Function):
 
 def _fused_under_transforms(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
     """May a call that sees functorch wrappers run as `_FusedCircuit`?  Only under transform stacks its rules cover:
-    any number of ``vmap`` levels and at most ONE reverse-mode level (``grad`` / ``vjp`` / ``jacrev``); no forward mode
-    (``jvp``, ``jacfwd``, ``torch.func.hessian``, plain forward_ad: the per-gate nodes carry jvp rules), no second
-    reverse level (``jacrev(jacrev(f))``: the per-gate nodes differentiate to any order).  Unknown stack: no."""
+    any number of ``vmap`` levels and at most TWO reverse-mode levels (``grad`` / ``vjp`` / ``jacrev``; the second one runs
+    the tangent circuit: `_FusedSweep.backward`); no forward mode (``jvp``, ``jacfwd``, ``torch.func.hessian``, plain
+    forward_ad: the per-gate nodes carry jvp rules), no third reverse level (the per-gate nodes differentiate to any
+    order).  Unknown stack: no."""
     stack = ops.transform_stack()
     if stack is None or ops.forward_ad_active() is not False:
         return False
-    if any(t not in ('Vmap', 'Grad') for t in stack) or sum(t == 'Grad' for t in stack) > 1:
+    if any(t not in ('Vmap', 'Grad') for t in stack) or sum(t == 'Grad' for t in stack) > 2:
         return False
     if not all(p.unitary and len(p.targets) <= 2 for p in prims):
         return False
@@ -851,7 +852,7 @@ class _FusedCircuit(torch.autograd.Function):
     def setup_context(ctx, inputs, output):
         state, meta, *mats = inputs
         ctx.meta = meta
-        ctx.kept_input = ops._is_wrapped(state) or _keep_input(state, ctx.needs_input_grad[0])
+        ctx.kept_input = ops._is_wrapped(state) or bool(ops.transform_stack()) or _keep_input(state, ctx.needs_input_grad[0])
         ctx.save_for_backward(state if ctx.kept_input else state.new_empty(0), output, *mats)
 
     @staticmethod
@@ -886,19 +887,27 @@ class _FusedCircuit(torch.autograd.Function):
                 gstate, grads = _AdjointCircuit._first_order(out, gy.contiguous(), ctx.meta, list(mats), need_state, list(need))
             return (gstate, None, *grads)
         mask = sum(1 << j for j, nd in enumerate(need) if nd)       # (an int: a leaf for the transforms' pytrees)
-        res = list(_FusedSweep.apply(gy, out, ctx.meta, need_state, mask, *mats))
+        res = list(_FusedSweep.apply(gy, state, out, ctx.meta, need_state, mask, *mats))
         gstate = res.pop(0) if need_state else None
         grads = [res.pop(0) if nd else None for nd in need]
         return (gstate, None, *grads)
 
 
 class _FusedSweep(torch.autograd.Function):
-    """(U^dagger gy, the matrix cotangents) by the fused reverse sweep, as a node with a ``vmap`` rule: ``jacrev`` maps over
-    cotangents -- every basis cotangent becomes a sample of ONE sweep (per-sample matrices, so that every sample gets
-    its own matrix cotangents)."""
+    """F(gy, state, U_1..U_K) = (U^dagger gy, the matrix cotangents) by the fused reverse sweep, as a node with a ``vmap`` rule:
+    ``jacrev`` maps over cotangents -- every basis cotangent becomes a sample of ONE sweep (per-sample matrices, so that every
+    sample gets its own matrix cotangents).  ``state`` (the circuit's input) and ``out`` (= U state) ride along: the sweep
+    itself starts from ``out``; ``state`` is what the node's own backward needs.
+
+    Its backward -- a second reverse level: ``jacrev(jacrev(f))``, all rows of a Hessian in one traversal -- is the TANGENT
+    CIRCUIT of `_SweepGrads` (the pair (psi, alpha) on one more qubit, gate j as the block [[U_j, 0], [C_j, U_j]] of U_j and
+    the incoming cotangent C_j), written with the two fused nodes themselves: one `_FusedCircuit` forward gives alpha_K (the
+    cotangent of gy), one `_FusedSweep` of it the cotangents of the state and -- read off the blocks -- of every U_j.
+    Everything in between is tensor algebra, so the transforms' wrappers pass through (the rows of the outer ``jacrev``
+    become samples of both)."""
 
     @staticmethod
-    def forward(gy, out, meta, need_state, mask, *mats):
+    def forward(gy, state, out, meta, need_state, mask, *mats):
         need = [bool((mask >> j) & 1) for j in range(len(mats))]
         with torch.no_grad():
             gstate, grads = _AdjointCircuit._first_order(ops._plain(out), ops._plain(gy).contiguous(), meta, list(mats),
@@ -907,16 +916,18 @@ class _FusedSweep(torch.autograd.Function):
 
     @staticmethod
     def setup_context(ctx, inputs, output):
-        pass
+        gy, state, out, ctx.meta, ctx.need_state, ctx.mask, *mats = inputs
+        ctx.save_for_backward(gy, state, out, *mats)
 
     @staticmethod
-    def vmap(info, in_dims, gy, out, meta, need_state, mask, *mats):
+    def vmap(info, in_dims, gy, state, out, meta, need_state, mask, *mats):
         need = [bool((mask >> j) & 1) for j in range(len(mats))]
         v = info.batch_size
-        rows = out.shape[0] if in_dims[1] is None else out.movedim(in_dims[1], 0).shape[1]
+        rows = out.shape[0] if in_dims[2] is None else out.movedim(in_dims[2], 0).shape[1]
         fgy = _fold(gy, in_dims[0], v, rows, 1).contiguous()
-        fout = _fold(out, in_dims[1], v, rows, 1).contiguous()
-        mdims = in_dims[5:]
+        fstate = state if state.numel() == 0 else _fold(state, in_dims[1], v, rows, 1)
+        fout = _fold(out, in_dims[2], v, rows, 1).contiguous()
+        mdims = in_dims[6:]
         fmats, shared = [], []
         for m, d, nd in zip(mats, mdims, need, strict=True):
             logical = m.ndim - (d is not None)                     # (D, D) or (bm, D, D) as the caller sees it
@@ -929,7 +940,7 @@ class _FusedSweep(torch.autograd.Function):
             # (its cotangent is summed over the rows of a sample, never over the mapped dimension; True: keep a batch dim of 1)
             shared.append((logical != 2) if one else None)
             fmats.append(_fold(m, d, v, rows, 2).contiguous())
-        res = list(_FusedSweep.apply(fgy, fout, meta, need_state, mask, *fmats))
+        res = list(_FusedSweep.apply(fgy, fstate, fout, meta, need_state, mask, *fmats))
         outs = []
         if need_state:
             g = res.pop(0)
@@ -946,9 +957,69 @@ class _FusedSweep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *cots):
-        raise NotImplementedError('deepquantum_amd: a second derivative through a circuit node that ran under torch.func '
-                                  'transforms -- wrap BOTH derivatives in torch.func (jacrev(jacrev(f)), hessian(f)): the '
-                                  'gates then run as per-gate nodes, which differentiate to any order')
+        gy, state, out, *mats = ctx.saved_tensors
+        meta, need_state, mask = ctx.meta, ctx.need_state, ctx.mask
+        need = [bool((mask >> j) & 1) for j in range(len(mats))]
+        if state.numel() == 0 or getattr(meta, 'tangent', False) or not _SweepGrads.takes(meta, mats, need):
+            raise NotImplementedError('deepquantum_amd: this derivative of a circuit node that ran under torch.func transforms is '
+                                      'not available on the fused route (third order, or a trainable gate on more than two '
+                                      'targets at second order): set executor.CONFIG["fused_transforms"] = False -- the gates '
+                                      'then run as per-gate nodes, which differentiate to any order')
+        GRAPH_BACKWARDS['tangent_rows'] += 1
+        wants = ctx.needs_input_grad                 # (gy, state, out, meta, need_state, mask, *mats)
+        cots = list(cots)
+        c0 = cots.pop(0) if need_state else None
+        cmat = [cots.pop(0) if nd else None for nd in need]
+        dim = state.shape[-1]
+        n = dim.bit_length() - 1
+        dt = state.dtype
+        alpha0 = torch.zeros_like(state) if c0 is None else c0.to(dt).expand_as(state)
+        pair = torch.cat([state, alpha0], dim=-1)                # index bit n: psi | alpha
+        meta2 = [(kind, targets, controls, mode, _e) for kind, targets, controls, mode, _e in meta]
+        mats2 = list(mats)                   # (a gate without a cotangent: the same gate on both halves)
+        groups: dict = {}                    # the blocks [[U, 0], [C, U]] of all gates of one shape in a few calls
+        for j, ((kind, _t, _c, _m, _e), m) in enumerate(zip(meta, mats, strict=True)):
+            if cmat[j] is not None:
+                nb = max(m.shape[0] if m.ndim == 3 else 1, cmat[j].shape[0] if cmat[j].ndim == 3 else 1)
+                groups.setdefault((kind == 'diag', m.shape[-1], nb, tuple(m.shape), tuple(cmat[j].shape)), []).append(j)
+        for (diag, d, nb, _su, _sc), js in groups.items():
+            us = torch.stack([mats[j] for j in js]).to(dt).reshape(len(js), -1, d, d).expand(len(js), nb, d, d)
+            cs = torch.stack([cmat[j] for j in js]).to(dt).reshape(len(js), -1, d, d).expand(len(js), nb, d, d)
+            if diag:                         # (F's output for a diagonal gate has no off-diagonal entries)
+                cs = torch.diag_embed(cs.diagonal(dim1=-2, dim2=-1))
+            blk = torch.cat([torch.cat([us, torch.zeros_like(us)], dim=-1), torch.cat([cs, us], dim=-1)], dim=-2)
+            parts = (blk if nb > 1 else blk[:, 0]).unbind(0)
+            for j, part in zip(js, parts, strict=True):
+                meta2[j] = ('gen', (n,) + tuple(meta[j][1]), meta[j][2], 0, 'block')
+                mats2[j] = part
+        meta2 = _Meta(tuple(meta2), tangent=True)
+        out2 = _FusedCircuit.apply(pair, meta2, *mats2)
+        g_gy = out2[..., dim:].to(gy.dtype) if wants[0] else None           # alpha_K
+        g_state, g_mats = None, [None] * len(mats)
+        want_mats = [bool(wants[6 + j]) for j in range(len(mats))]
+        if wants[1] or any(want_mats):
+            seed = torch.cat([torch.zeros_like(gy, dtype=dt), gy.to(dt)], dim=-1)
+            mask2 = sum(1 << j for j, w in enumerate(want_mats) if w)
+            res = list(_FusedSweep.apply(seed, pair, out2, meta2, bool(wants[1]), mask2, *mats2))
+            if wants[1]:
+                g_state = res.pop(0)[..., :dim]
+            for j, w in enumerate(want_mats):
+                if not w:
+                    continue
+                g = res.pop(0)
+                if cmat[j] is not None:      # U_j sits on both diagonal blocks of [[U, 0], [C, U]]
+                    d = mats[j].shape[-1]
+                    g = g[..., :d, :d] + g[..., d:, d:]
+                    if g.ndim == 3 and g.shape[0] > 1 and (mats[j].ndim == 2 or mats[j].shape[0] == 1):
+                        g = g.sum(dim=0, keepdim=mats[j].ndim == 3)      # (a shared U under per-sample cotangents)
+                    if diag_like(meta[j][0]):
+                        g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))
+                g_mats[j] = g.reshape(mats[j].shape).to(mats[j].dtype)
+        return (g_gy, g_state, None, None, None, None, *g_mats)
+
+
+def diag_like(kind: str) -> bool:
+    return kind == 'diag'
 
 
 def _keep_input(state: torch.Tensor, differentiated: bool) -> bool:

@@ -1078,3 +1078,7 @@ def check_transforms_random(dq, device=None, n=10, seed=0, ngates=40, dtype=torc
     assert (tf.vmap(tf.grad(lambda p: fvec(p).sum()))(data) - want).abs().max().item() < tol, ('vmap(grad)', seed)
     wantj = torch.stack([torch.autograd.functional.jacobian(fvec, r) for r in data])
     assert (tf.vmap(tf.jacrev(fvec))(data) - wantj).abs().max().item() < tol, ('vmap(jacrev)', seed)
+    if cir.ndata <= 48:       # two reverse levels: the tangent circuit inside the fused nodes (executor._FusedSweep.backward)
+        fs = lambda p: (fvec(p) * torch.arange(1, 4, dtype=real, device=p.device)).sum()       # noqa: E731
+        hes = torch.autograd.functional.hessian(fs, x)
+        assert (tf.jacrev(tf.jacrev(fs))(x) - hes).abs().max().item() < 20 * tol, ('jacrev(jacrev)', seed)

@@ -805,10 +805,17 @@ def check_fused_node_under_transforms(dq, device=None, n=13):
     d3 = data.clone().requires_grad_(True)
     (cir(d3).abs() ** 2 * w).sum().backward()
     assert (d2.grad - d3.grad).abs().max().item() < 1e-5
-    # two reverse levels, forward mode: the per-gate nodes, as before
+    # two reverse levels: still ONE node -- the second level runs the tangent circuit (executor._FusedSweep.backward), all
+    # rows of the Hessian as samples of one forward and one sweep; forward mode (torch.func.hessian = jacfwd(jacrev)): the
+    # per-gate nodes, as before
     hes = torch.autograd.functional.hessian(f, x)
-    c0 = count()
+    c0, r0 = count(), executor.GRAPH_BACKWARDS['tangent_rows']
     assert (tf.jacrev(tf.jacrev(f))(x) - hes).abs().max().item() < 1e-4
+    assert count() == c0 + 1 and executor.GRAPH_BACKWARDS['tangent_rows'] == r0 + 1
+    v = torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).to(device)
+    hv = tf.grad(lambda p: (tf.grad(f)(p) * v).sum())(x)             # a Hessian-vector product: grad of grad
+    assert (hv - hes @ v).abs().max().item() < 1e-4
+    c0 = count()
     assert (tf.hessian(f)(x) - hes).abs().max().item() < 1e-4
     assert count() == c0
     # A/B switch

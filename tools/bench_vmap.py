@@ -9,6 +9,7 @@ import bench
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+hess = len(sys.argv) > 3 and sys.argv[3] == 'hessian'
 dev = torch.device('cuda', 0)
 spec = bench.random_circuit_spec(n, 20, 1234)
 cir, data = bench.build_circuit(dq, n, spec, batch, torch.complex64, dev)
@@ -57,6 +58,9 @@ for on in (True, False):
     rows[f'torch.vmap(circuit), {tag}'] = timed(vmapped)
     rows[f'torch.func.jacrev, 5 observables x {cir.ndata} angles, {tag}'] = timed(lambda: tf.jacrev(fvec)(x), reps=3)
     rows[f'torch.func.vmap(grad) over {batch} rows, {tag}'] = timed(lambda: tf.vmap(tf.grad(lambda p: fvec(p).sum()))(data), reps=3)
+    if hess:
+        rows[f'torch.func.jacrev(jacrev): the {cir.ndata} x {cir.ndata} Hessian of sum <Z_q>, {tag}'] = timed(
+            lambda: tf.jacrev(tf.jacrev(lambda p: fvec(p).sum()))(x), reps=2)
 dq.executor.CONFIG['fused_transforms'] = True
 print(f'n = {n}, depth 20 ({len(spec)} gates), complex64, batch {batch}')
 for k, v in rows.items():
