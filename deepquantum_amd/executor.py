@@ -14,6 +14,8 @@ This replaces the Python loop ``nn.Sequential(self.operators)(x)`` of the refere
 
 from __future__ import annotations
 
+import functools
+
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Any, Sequence
@@ -653,6 +655,14 @@ def _inverse_block(m: torch.Tensor) -> torch.Tensor:
 
 def grad_records(kind: str, mode: int, targets: Sequence[int], controls: Sequence[int], row0: int,
                  reduced: bool = True) -> tuple[list[Prim], int]:
+    """`_grad_records`, remembered per argument tuple: the records carry no matrix, and a Hessian by rows asks for the same
+    two thousand of them in every row (a third of a row's host time was their construction)."""
+    recs, cnt = _grad_records(kind, int(mode), tuple(targets), tuple(controls), int(row0), bool(reduced and CONFIG['reduced_grad_sums']))
+    return list(recs), cnt
+
+
+@functools.lru_cache(maxsize=1 << 16)
+def _grad_records(kind: str, mode: int, targets: tuple, controls: tuple, row0: int, reduced: bool) -> tuple[tuple, int]:
     """The reduction records of a reverse sweep for ONE trainable gate (bit positions of the (psi, lambda) pair: bit 0
     tells the two apart), in front of which they go, and how many accumulator rows they fill from ``row0`` on.
 
@@ -666,17 +676,17 @@ def grad_records(kind: str, mode: int, targets: Sequence[int], controls: Sequenc
     c = tuple(controls)
     if len(t) == 1:
         variant = 3 if kind == 'diag' else (mode if kind == 'gen' and mode in (1, 2) else 0)
-        if not (reduced and CONFIG['reduced_grad_sums']):
+        if not reduced:
             variant = 0
-        return [Prim('grad', None, (t[0], 0), c, row0 | (variant << fusion.GRAD_VARIANT_SHIFT))], 1
+        return (Prim('grad', None, (t[0], 0), c, row0 | (variant << fusion.GRAD_VARIANT_SHIFT)),), 1
     assert len(t) == 2, 'reductions inside the passes: trainable gates on one or two targets'
-    v = (3 << fusion.GRAD_VARIANT_SHIFT) if (kind == 'diag' and reduced and CONFIG['reduced_grad_sums']) else 0
-    same = [Prim('grad', None, (t[0], 0), c, row0 | v), Prim('grad', None, (t[0], 0), c + (t[1],), (row0 + 1) | v)]
+    v = (3 << fusion.GRAD_VARIANT_SHIFT) if (kind == 'diag' and reduced) else 0
+    same = (Prim('grad', None, (t[0], 0), c, row0 | v), Prim('grad', None, (t[0], 0), c + (t[1],), (row0 + 1) | v))
     if kind == 'diag':
         return same, 2
     flip = Prim('x', None, (t[1],), (0,))
-    return same + [flip, Prim('grad', None, (t[0], 0), c, row0 + 2), Prim('grad', None, (t[0], 0), c + (t[1],), row0 + 3),
-                   Prim('x', None, (t[1],), (0,))], 4
+    return same + (flip, Prim('grad', None, (t[0], 0), c, row0 + 2), Prim('grad', None, (t[0], 0), c + (t[1],), row0 + 3),
+                   Prim('x', None, (t[1],), (0,))), 4
 
 
 def assemble_grad_sums(g: torch.Tensor, row0: int, kind: str, ntargets: int) -> torch.Tensor:
