@@ -365,6 +365,7 @@ class _Meta(tuple):
 # would merge into a general matrix -- 20 % fewer gates, the same arithmetic -- and the step gets 5 % SLOWER (measured,
 # one box: 282 vs 268 ms): a general matrix commutes with nothing, so the scheduler loses the freedom the Rx-like factor had.
 _MERGE_COST = {3: 30, 2: 37, 1: 45, 0: 79}
+SCALAR_MODE = 4          # (host-side only: a product of an even number of Hadamard-like matrices, c I)
 
 
 _MERGE_CACHE: OrderedDict = OrderedDict()
@@ -379,8 +380,8 @@ def _merge_structure(prims: Sequence[Prim]):
     if hit is not None:
         _MERGE_CACHE.move_to_end(key)
         return hit
-    groups: list[list] = []            # [members (prim indices, in order of application), mode]
-    order: list[tuple[str, int]] = []  # ('g', group) | ('p', prim)
+    groups: list[list] = []            # [members (prim indices, in order of application), mode, Hadamard-like members or -1]
+    order: list[tuple[str, int]] = []  # ('g', group) | ('p', prim) | ('s', group whose product is a SCALAR: see below)
     last: dict[int, int] = {}          # qubit -> open group
     nothing: dict[int, bool] = {}      # no gate has touched the qubit since the group's last member
     only_x: dict[int, bool] = {}       # ... only X-type actions have
@@ -389,14 +390,27 @@ def _merge_structure(prims: Sequence[Prim]):
             q = p.targets[0]
             g = last.get(q)
             if g is not None:
-                mode = groups[g][1]
+                mode, nh = groups[g][1], groups[g][2]
                 if nothing[q] or (only_x[q] and mode == 2 and p.mode == 2):
+                    if nh >= 0 and p.mode == 3:
+                        # Hadamard-like times Hadamard-like: (s1 H0)(s2 H0) = 2 s1 s2 I EXACTLY in floating point (equal
+                        # products added, equal products subtracted) -- a scalar (SCALAR_MODE) -- and a third factor
+                        # makes it Hadamard-like again.  Round 4 applied the pair as a "real" matrix: 128 packed operations
+                        # per tile for a multiplication by one number
+                        groups[g][0].append(i)
+                        groups[g][2] = nh + 1
+                        groups[g][1] = 3 if (nh + 1) % 2 else SCALAR_MODE
+                        continue
+                    if mode == SCALAR_MODE:            # c I times anything: the other factor's structure
+                        groups[g][0].append(i)
+                        groups[g][1], groups[g][2] = p.mode, -1
+                        continue
                     new = 2 if (mode == 2 and p.mode == 2) else 1 if (mode in (1, 3) and p.mode in (1, 3)) else 0
                     if cost[new] <= cost[mode] + cost[p.mode] - 5:
                         groups[g][0].append(i)
-                        groups[g][1] = new
+                        groups[g][1], groups[g][2] = new, -1
                         continue
-            groups.append([[i], p.mode])
+            groups.append([[i], p.mode, 1 if p.mode == 3 else -1])
             order.append(('g', len(groups) - 1))
             last[q], nothing[q], only_x[q] = len(groups) - 1, True, True
             continue
@@ -409,6 +423,19 @@ def _merge_structure(prims: Sequence[Prim]):
                 nothing[q] = False
             else:
                 last.pop(q, None)
+    # a product that is a scalar c I is no gate at all: it commutes with everything and belongs to the whole state, so it is
+    # multiplied into the matrix of a CARRIER -- the nearest following product or one-qubit gate (any structure survives a
+    # real factor), else the nearest one before -- and only a circuit with no such gate at all keeps it as a real matrix
+    carriers = [k for k, (kind, idx) in enumerate(order) if kind == 'g' and groups[idx][1] != SCALAR_MODE]
+    for k, (kind, idx) in enumerate(order):
+        if kind == 'g' and groups[idx][1] == SCALAR_MODE:
+            after = [c for c in carriers if c > k]
+            before = [c for c in carriers if c < k]
+            if after or before:
+                order[k] = ('s', idx)
+                groups[idx].append(order[after[0] if after else before[-1]][1])       # [3] = the carrier group
+            else:
+                groups[idx][1] = 1
     # the products with most factors first: at every level of the stacked multiplication the groups still growing are
     # then a PREFIX of the stack (a slice: no index tensor, which would be a host-to-device copy and a stream sync)
     multi = sorted((gi for gi, g in enumerate(groups) if len(g[0]) > 1), key=lambda gi: -len(groups[gi][0]))
@@ -453,16 +480,28 @@ def merge_one_qubit_runs(prims: Sequence[Prim]) -> list[Prim]:
         return any(prims[i].matrix.ndim == 3 and prims[i].matrix.shape[0] > 1 for i in g[0])
 
     merged = {gi: acc[k] if batched(groups[gi]) else acc[k, 0] for k, gi in enumerate(multi)}
+    # scalar products (an even number of Hadamard-like factors: c I exactly) ride on their carrier's matrix
+    scale: dict[int, torch.Tensor] = {}
+    for kind, idx in order:
+        if kind == 's':
+            c = merged[idx][..., 0, 0]
+            tgt = groups[idx][3]
+            scale[tgt] = c if tgt not in scale else scale[tgt] * c
     out: list[Prim] = []
     for kind, idx in order:
         if kind == 'p':
             out.append(prims[idx])
-        else:
+        elif kind == 'g':
             g = groups[idx]
-            if len(g[0]) == 1:
-                out.append(prims[g[0][0]])
+            first = prims[g[0][0]]
+            m = first.matrix if len(g[0]) == 1 else merged[idx]
+            c = scale.get(idx)
+            if c is not None:
+                m = m * (c if c.ndim == 0 else c.reshape(-1, 1, 1))
+            if len(g[0]) == 1 and c is None:
+                out.append(first)
             else:
-                out.append(Prim('gen', merged[idx], prims[g[0][0]].targets, (), g[1]))
+                out.append(Prim('gen', m, first.targets, (), g[1]))
     return out
 
 

@@ -185,19 +185,35 @@ def test_one_qubit_runs_are_merged_and_the_state_is_unchanged(cpu_backend):
 
     P = lambda m, q, mode: Prim('gen', m, (q,), (), mode)           # noqa: E731
     cx = lambda c, t: Prim('x', x, (t,), (c,), 0)                   # noqa: E731
-    prims = [P(h, 0, 3), P(h, 0, 3),                                 # H H          -> one real matrix
+    prims = [P(h, 0, 3), P(h, 0, 3),                                 # H H = 2 s^2 I: a SCALAR, which rides on the next factor
              P(rx(0.3), 1, 2), cx(2, 1), P(rx([0.1, 0.2]), 1, 2),    # Rx . CX-target . Rx (batched) -> one Rx-like
              P(h, 2, 3), P(rx(0.5), 2, 2),                           # H Rx         -> stays two gates
-             P(rx(0.4), 0, 2), cx(0, 1), P(rx(0.6), 0, 2)]           # Rx . control . Rx -> stays (Z-type in between)
+             P(rx(0.4), 0, 2), cx(0, 1), P(rx(0.6), 0, 2)]           # (H H) Rx -> one Rx-like; control; Rx stays (Z-type in between)
     out = merge_one_qubit_runs(prims)
     kinds = [(p.kind, p.targets, p.mode, tuple(p.matrix.shape)) for p in out]
-    assert kinds == [('gen', (0,), 1, (2, 2)),          # (H H) -> one real matrix; the Rx(0.4) behind it stays on its own:
-                     ('gen', (1,), 2, (2, 2, 2)), ('x', (1,), 0, (2, 2)),       # a general matrix costs the kernel more
-                     ('gen', (2,), 3, (2, 2)), ('gen', (2,), 2, (2, 2)),        # than a real one + a deferred Rx
-                     ('gen', (0,), 2, (2, 2)), ('x', (1,), 0, (2, 2)), ('gen', (0,), 2, (2, 2))]
-    assert torch.allclose(out[0].matrix, h @ h, atol=1e-6)
+    assert kinds == [('gen', (0,), 2, (2, 2)),          # H H Rx(0.4): the scalar times an Rx-like matrix is Rx-like
+                     ('gen', (1,), 2, (2, 2, 2)), ('x', (1,), 0, (2, 2)),
+                     ('gen', (2,), 3, (2, 2)), ('gen', (2,), 2, (2, 2)),        # (a general matrix would cost the kernel more)
+                     ('x', (1,), 0, (2, 2)), ('gen', (0,), 2, (2, 2))]
+    assert torch.allclose(out[0].matrix, rx(0.4) @ h @ h, atol=1e-6)
     assert torch.allclose(out[1].matrix, rx([0.1, 0.2]) @ rx(0.3), atol=1e-6)
     assert bool((out[1].matrix[..., 0, 0].imag == 0).all()) and bool((out[1].matrix[..., 0, 1].real == 0).all())
+    # an even number of Hadamard-like factors with nothing to merge into on ITS qubit: no gate at all -- the scalar is
+    # multiplied into a carrier, the nearest following one-qubit gate (else the nearest one before); an odd number stays
+    # Hadamard-like; a circuit that has no other one-qubit gate keeps the pair as a real matrix
+    two = merge_one_qubit_runs([P(h, 0, 3), P(h, 0, 3), cx(0, 1), P(rx(0.3), 2, 2), P(h, 1, 3)])
+    assert [(p.kind, p.targets, p.mode) for p in two] == [('x', (1,), 0), ('gen', (2,), 2), ('gen', (1,), 3)]
+    assert torch.allclose(two[1].matrix, (h @ h)[0, 0] * rx(0.3), atol=1e-7) and torch.equal(two[2].matrix, h)
+    last = merge_one_qubit_runs([P(rx(0.3), 2, 2), cx(2, 0), P(h, 0, 3), P(h, 0, 3), P(h, 0, 3), P(h, 0, 3)])
+    assert [(p.kind, p.targets, p.mode) for p in last] == [('gen', (2,), 2), ('x', (0,), 0)]
+    assert torch.allclose(last[0].matrix, (h @ h @ h @ h)[0, 0] * rx(0.3), atol=1e-7)
+    three = merge_one_qubit_runs([P(h, 0, 3), P(h, 0, 3), P(h, 0, 3)])
+    assert [(p.kind, p.targets, p.mode) for p in three] == [('gen', (0,), 3)] and torch.allclose(three[0].matrix, h @ h @ h, atol=1e-7)
+    assert (three[0].matrix[0, 0] == three[0].matrix[0, 1]) and (three[0].matrix[1, 0] == -three[0].matrix[1, 1])    # exactly s [[1, 1], [1, -1]]
+    alone = merge_one_qubit_runs([P(h, 0, 3), P(h, 0, 3), cx(0, 1)])
+    assert [(p.kind, p.targets, p.mode) for p in alone] == [('gen', (0,), 1), ('x', (1,), 0)]
+    hh = h @ h
+    assert hh[0, 1] == 0 and hh[1, 0] == 0 and hh[0, 0] == hh[1, 1]       # the pair IS a scalar, to the last bit
 
     import random
     n, rng = 13, random.Random(11)

@@ -22,6 +22,8 @@ def merged(prims):
     groups, order, multi, levels = executor._merge_structure(prims)
     out = []
     for kind, idx in order:
+        if kind == 's':          # (a scalar product rides on another gate's matrix: executor._merge_structure)
+            continue
         out.append(prims[idx] if kind == 'p' else executor.Prim('gen', None, prims[groups[idx][0][0]].targets, (), groups[idx][1]))
     return out
 

@@ -35,6 +35,8 @@ def headline_steps(n=28, depth=40, seed=1234, wide=True):
     groups, order, multi, levels = executor._merge_structure(prims)
     merged = []
     for kind, idx in order:
+        if kind == 's':          # (a scalar product rides on another gate's matrix: executor._merge_structure)
+            continue
         merged.append(prims[idx] if kind == 'p' else executor.Prim('gen', None, prims[groups[idx][0][0]].targets, (), groups[idx][1]))
     ops = [fusion.PrimOp(p.kind, p.targets, p.controls, 4 * i, p.mode) for i, p in enumerate(merged)]
     geom = fusion.default_geometry(False)

@@ -14,6 +14,8 @@ for op in bench.random_circuit_spec(n, 40, 1234):
 groups, order, multi, levels = executor._merge_structure(prims)
 merged = []
 for kind, idx in order:
+    if kind == 's':
+        continue
     if kind == 'p':
         merged.append(prims[idx])
     else:
