@@ -852,14 +852,18 @@ class _SweepGrads(torch.autograd.Function):
 
 def _fused_under_transforms(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
     """May a call that sees functorch wrappers run as `_FusedCircuit`?  Only under transform stacks its rules cover:
-    any number of ``vmap`` levels and at most TWO reverse-mode levels (``grad`` / ``vjp`` / ``jacrev``; the second one runs
-    the tangent circuit: `_FusedSweep.backward`); no forward mode (``jvp``, ``jacfwd``, ``torch.func.hessian``, plain
-    forward_ad: the per-gate nodes carry jvp rules), no third reverse level (the per-gate nodes differentiate to any
-    order).  Unknown stack: no."""
+    any number of ``vmap`` levels and at most TWO differentiation levels -- reverse (``grad`` / ``vjp`` / ``jacrev``) or
+    forward (``torch.func.jvp`` / ``jacfwd``, at most one), in any order (plain ``torch.autograd.forward_ad`` keeps the per-gate
+    nodes): the second level runs the tangent
+    circuit (`_second_order`).  Third order: the per-gate nodes, which differentiate to any order.  Unknown stack: no."""
     stack = ops.transform_stack()
-    if stack is None or ops.forward_ad_active() is not False:
+    fwad = ops.forward_ad_active()
+    if stack is None or fwad is None:
         return False
-    if any(t not in ('Vmap', 'Grad') for t in stack) or sum(t == 'Grad' for t in stack) > 2:
+    if fwad and 'Jvp' not in stack:          # (plain torch.autograd.forward_ad, no torch.func.jvp around it: the per-gate nodes)
+        return False
+    levels = sum(t in ('Grad', 'Jvp') for t in stack)
+    if any(t not in ('Vmap', 'Grad', 'Jvp') for t in stack) or levels > 2 or sum(t == 'Jvp' for t in stack) > 1:
         return False
     if not all(p.unitary and len(p.targets) <= 2 for p in prims):
         return False
@@ -878,6 +882,70 @@ def _fold(t: torch.Tensor, dim: int | None, v: int, rows: int, lead: int) -> tor
         t = t.unsqueeze(1)
     tail = t.shape[2:]
     return t.expand(v, rows, *tail).reshape(v * rows, *tail)
+
+
+def _tangent_circuit(meta, mats, state, c0, dirs):
+    """The TANGENT CIRCUIT of (state, U_1 .. U_K) in the direction (c0, C_1 .. C_K) (None = no direction): the pair
+    (psi, alpha) as one state with one more qubit on top, alpha_0 = c0, gate j as the block [[U_j, 0], [C_j, U_j]] on (that
+    qubit, the gate's targets) -- its output is (U psi, d/de U(U_j + e C_j)(psi + e c0)).  Tensor algebra only (wrappers of
+    ``torch.func`` transforms pass through): the blocks of all gates of one shape in a few stack / cat calls.  Returns
+    (pair, meta of the tangent circuit, its matrices)."""
+    dim = state.shape[-1]
+    n = dim.bit_length() - 1
+    dt = state.dtype
+    alpha0 = torch.zeros_like(state) if c0 is None else c0.to(dt).expand_as(state)
+    pair = torch.cat([state, alpha0], dim=-1)                # index bit n: psi | alpha
+    meta2 = [(kind, targets, controls, mode, _e) for kind, targets, controls, mode, _e in meta]
+    mats2 = list(mats)                   # (a gate without a direction: the same gate on both halves)
+    groups: dict = {}
+    for j, ((kind, _t, _c, _m, _e), m) in enumerate(zip(meta, mats, strict=True)):
+        if dirs[j] is not None:
+            nb = max(m.shape[0] if m.ndim == 3 else 1, dirs[j].shape[0] if dirs[j].ndim == 3 else 1)
+            groups.setdefault((kind == 'diag', m.shape[-1], nb, tuple(m.shape), tuple(dirs[j].shape)), []).append(j)
+    for (diag, d, nb, _su, _sc), js in groups.items():
+        us = torch.stack([mats[j] for j in js]).to(dt).reshape(len(js), -1, d, d).expand(len(js), nb, d, d)
+        cs = torch.stack([dirs[j] for j in js]).to(dt).reshape(len(js), -1, d, d).expand(len(js), nb, d, d)
+        if diag:                         # (a diagonal gate moves along its diagonal only)
+            cs = torch.diag_embed(cs.diagonal(dim1=-2, dim2=-1))
+        blk = torch.cat([torch.cat([us, torch.zeros_like(us)], dim=-1), torch.cat([cs, us], dim=-1)], dim=-2)
+        parts = (blk if nb > 1 else blk[:, 0]).unbind(0)
+        for j, part in zip(js, parts, strict=True):
+            meta2[j] = ('gen', (n,) + tuple(meta[j][1]), meta[j][2], 0, 'block')
+            mats2[j] = part
+    return pair, _Meta(tuple(meta2), tangent=True), mats2
+
+
+def _second_order(gy, state, meta, mats, c0, dirs, want_alpha: bool, want_state: bool, want_mats: Sequence[bool]):
+    """With L = Re <gy, U_K .. U_1 state>: the gradient, with respect to (state, U_j), of the derivative of L in the direction
+    (c0, C_j) -- one forward of the tangent circuit (alpha_K, which is also the gradient with respect to gy) and one reverse
+    sweep of it, read off the blocks.  The Hessian of L is symmetric, so this is both the vector-Jacobian product of the
+    sweep node F = grad L (`_FusedSweep.backward`: the direction is the incoming cotangent) and its Jacobian-vector product
+    (`_FusedSweep.jvp`: the direction is the incoming tangent).  Returns (alpha_K or None, g_state or None, [g_U_j or None])."""
+    dim = state.shape[-1]
+    dt = state.dtype
+    pair, meta2, mats2 = _tangent_circuit(meta, mats, state, c0, dirs)
+    out2 = _FusedCircuit.apply(pair, meta2, *mats2)
+    alpha = out2[..., dim:].to(gy.dtype) if want_alpha else None
+    g_state, g_mats = None, [None] * len(mats)
+    if want_state or any(want_mats):
+        seed = torch.cat([torch.zeros_like(gy, dtype=dt), gy.to(dt)], dim=-1)
+        mask2 = sum(1 << j for j, w in enumerate(want_mats) if w)
+        res = list(_FusedSweep.apply(seed, pair, out2, meta2, bool(want_state), mask2, *mats2))
+        if want_state:
+            g_state = res.pop(0)[..., :dim]
+        for j, w in enumerate(want_mats):
+            if not w:
+                continue
+            g = res.pop(0)
+            if dirs[j] is not None:      # U_j sits on both diagonal blocks of [[U, 0], [C, U]]
+                d = mats[j].shape[-1]
+                g = g[..., :d, :d] + g[..., d:, d:]
+                if g.ndim == 3 and g.shape[0] > 1 and (mats[j].ndim == 2 or mats[j].shape[0] == 1):
+                    g = g.sum(dim=0, keepdim=mats[j].ndim == 3)      # (a shared U under per-sample directions)
+                if meta[j][0] == 'diag':
+                    g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))
+            g_mats[j] = g.reshape(mats[j].shape).to(mats[j].dtype)
+    return alpha, g_state, g_mats
 
 
 class _FusedCircuit(torch.autograd.Function):
@@ -901,8 +969,20 @@ class _FusedCircuit(torch.autograd.Function):
     def setup_context(ctx, inputs, output):
         state, meta, *mats = inputs
         ctx.meta = meta
-        ctx.kept_input = ops._is_wrapped(state) or bool(ops.transform_stack()) or _keep_input(state, ctx.needs_input_grad[0])
+        ctx.kept_input = (ops._is_wrapped(state) or bool(ops.transform_stack()) or ops.forward_ad_active() is not False
+                          or _keep_input(state, ctx.needs_input_grad[0]))
         ctx.save_for_backward(state if ctx.kept_input else state.new_empty(0), output, *mats)
+        ctx.save_for_forward(state if ctx.kept_input else state.new_empty(0), output, *mats)
+
+    @staticmethod
+    def jvp(ctx, state_t, _meta_t, *mats_t):
+        # forward mode (torch.func.jvp / jacfwd, forward_ad): the tangent of U state is the tangent circuit's alpha_K -- ONE
+        # fused forward on one more qubit, directions (state_t, dU_j)
+        ops._single_forward_level()
+        state, _out, *mats = ctx.saved_tensors
+        assert state.numel() > 0, 'forward mode needs the input state of the node'
+        pair, meta2, mats2 = _tangent_circuit(ctx.meta, mats, state, state_t, list(mats_t))
+        return _FusedCircuit.apply(pair, meta2, *mats2)[..., state.shape[-1]:].contiguous()      # (a tangent is no view of anything)
 
     @staticmethod
     def vmap(info, in_dims, state, meta, *mats):
@@ -967,6 +1047,25 @@ class _FusedSweep(torch.autograd.Function):
     def setup_context(ctx, inputs, output):
         gy, state, out, ctx.meta, ctx.need_state, ctx.mask, *mats = inputs
         ctx.save_for_backward(gy, state, out, *mats)
+        ctx.save_for_forward(gy, state, out, *mats)
+
+    @staticmethod
+    def jvp(ctx, gy_t, state_t, _out_t, _meta_t, _ns_t, _mask_t, *mats_t):
+        # forward over reverse (torch.func.hessian = jacfwd(jacrev)): F = grad L is linear in gy, and its derivative in the
+        # direction (state_t, dU_j) is -- the Hessian of L being symmetric -- what `backward` computes from cotangents
+        ops._single_forward_level()
+        gy, state, out, *mats = ctx.saved_tensors
+        meta, need_state, mask = ctx.meta, ctx.need_state, ctx.mask
+        need = [bool((mask >> j) & 1) for j in range(len(mats))]
+        total = None
+        if gy_t is not None:
+            total = list(_FusedSweep.apply(gy_t, state, out, meta, need_state, mask, *mats))
+        if state_t is not None or any(t is not None for t in mats_t):
+            assert state.numel() > 0 and not getattr(meta, 'tangent', False), 'forward mode needs the input state of the node'
+            _a, g_state, g_mats = _second_order(gy, state, meta, mats, state_t, list(mats_t), False, need_state, need)
+            part = ([g_state] if need_state else []) + [g for g, nd in zip(g_mats, need) if nd]
+            total = part if total is None else [x + y for x, y in zip(total, part, strict=True)]
+        return tuple(total)
 
     @staticmethod
     def vmap(info, in_dims, gy, state, out, meta, need_state, mask, *mats):
@@ -1019,56 +1118,9 @@ class _FusedSweep(torch.autograd.Function):
         cots = list(cots)
         c0 = cots.pop(0) if need_state else None
         cmat = [cots.pop(0) if nd else None for nd in need]
-        dim = state.shape[-1]
-        n = dim.bit_length() - 1
-        dt = state.dtype
-        alpha0 = torch.zeros_like(state) if c0 is None else c0.to(dt).expand_as(state)
-        pair = torch.cat([state, alpha0], dim=-1)                # index bit n: psi | alpha
-        meta2 = [(kind, targets, controls, mode, _e) for kind, targets, controls, mode, _e in meta]
-        mats2 = list(mats)                   # (a gate without a cotangent: the same gate on both halves)
-        groups: dict = {}                    # the blocks [[U, 0], [C, U]] of all gates of one shape in a few calls
-        for j, ((kind, _t, _c, _m, _e), m) in enumerate(zip(meta, mats, strict=True)):
-            if cmat[j] is not None:
-                nb = max(m.shape[0] if m.ndim == 3 else 1, cmat[j].shape[0] if cmat[j].ndim == 3 else 1)
-                groups.setdefault((kind == 'diag', m.shape[-1], nb, tuple(m.shape), tuple(cmat[j].shape)), []).append(j)
-        for (diag, d, nb, _su, _sc), js in groups.items():
-            us = torch.stack([mats[j] for j in js]).to(dt).reshape(len(js), -1, d, d).expand(len(js), nb, d, d)
-            cs = torch.stack([cmat[j] for j in js]).to(dt).reshape(len(js), -1, d, d).expand(len(js), nb, d, d)
-            if diag:                         # (F's output for a diagonal gate has no off-diagonal entries)
-                cs = torch.diag_embed(cs.diagonal(dim1=-2, dim2=-1))
-            blk = torch.cat([torch.cat([us, torch.zeros_like(us)], dim=-1), torch.cat([cs, us], dim=-1)], dim=-2)
-            parts = (blk if nb > 1 else blk[:, 0]).unbind(0)
-            for j, part in zip(js, parts, strict=True):
-                meta2[j] = ('gen', (n,) + tuple(meta[j][1]), meta[j][2], 0, 'block')
-                mats2[j] = part
-        meta2 = _Meta(tuple(meta2), tangent=True)
-        out2 = _FusedCircuit.apply(pair, meta2, *mats2)
-        g_gy = out2[..., dim:].to(gy.dtype) if wants[0] else None           # alpha_K
-        g_state, g_mats = None, [None] * len(mats)
         want_mats = [bool(wants[6 + j]) for j in range(len(mats))]
-        if wants[1] or any(want_mats):
-            seed = torch.cat([torch.zeros_like(gy, dtype=dt), gy.to(dt)], dim=-1)
-            mask2 = sum(1 << j for j, w in enumerate(want_mats) if w)
-            res = list(_FusedSweep.apply(seed, pair, out2, meta2, bool(wants[1]), mask2, *mats2))
-            if wants[1]:
-                g_state = res.pop(0)[..., :dim]
-            for j, w in enumerate(want_mats):
-                if not w:
-                    continue
-                g = res.pop(0)
-                if cmat[j] is not None:      # U_j sits on both diagonal blocks of [[U, 0], [C, U]]
-                    d = mats[j].shape[-1]
-                    g = g[..., :d, :d] + g[..., d:, d:]
-                    if g.ndim == 3 and g.shape[0] > 1 and (mats[j].ndim == 2 or mats[j].shape[0] == 1):
-                        g = g.sum(dim=0, keepdim=mats[j].ndim == 3)      # (a shared U under per-sample cotangents)
-                    if diag_like(meta[j][0]):
-                        g = torch.diag_embed(g.diagonal(dim1=-2, dim2=-1))
-                g_mats[j] = g.reshape(mats[j].shape).to(mats[j].dtype)
+        g_gy, g_state, g_mats = _second_order(gy, state, meta, mats, c0, cmat, bool(wants[0]), bool(wants[1]), want_mats)
         return (g_gy, g_state, None, None, None, None, *g_mats)
-
-
-def diag_like(kind: str) -> bool:
-    return kind == 'diag'
 
 
 def _keep_input(state: torch.Tensor, differentiated: bool) -> bool:

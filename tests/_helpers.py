@@ -1082,3 +1082,5 @@ def check_transforms_random(dq, device=None, n=10, seed=0, ngates=40, dtype=torc
         fs = lambda p: (fvec(p) * torch.arange(1, 4, dtype=real, device=p.device)).sum()       # noqa: E731
         hes = torch.autograd.functional.hessian(fs, x)
         assert (tf.jacrev(tf.jacrev(fs))(x) - hes).abs().max().item() < 20 * tol, ('jacrev(jacrev)', seed)
+        assert (tf.hessian(fs)(x) - hes).abs().max().item() < 40 * tol, ('hessian = jacfwd(jacrev)', seed)
+        assert (tf.jacfwd(fvec)(x) - jac).abs().max().item() < 20 * tol, ('jacfwd', seed)

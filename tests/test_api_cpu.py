@@ -815,9 +815,23 @@ def check_fused_node_under_transforms(dq, device=None, n=13):
     v = torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).to(device)
     hv = tf.grad(lambda p: (tf.grad(f)(p) * v).sum())(x)             # a Hessian-vector product: grad of grad
     assert (hv - hes @ v).abs().max().item() < 1e-4
+    # forward mode: the node's jvp rule is the tangent circuit's forward, the sweep node's jvp the same second-order routine
+    # (executor._second_order) -- torch.func.jvp, jacfwd, hessian (= jacfwd(jacrev)), jacrev(jacfwd): one node each
+    for name, fn in (('hessian', lambda: tf.hessian(f)(x)), ('jacrev(jacfwd)', lambda: tf.jacrev(tf.jacfwd(f))(x))):
+        c0 = count()
+        assert (fn() - hes).abs().max().item() < 1e-4, name
+        assert count() == c0 + 1, name
     c0 = count()
-    assert (tf.hessian(f)(x) - hes).abs().max().item() < 1e-4
-    assert count() == c0
+    assert (tf.jacfwd(fvec)(x) - jac).abs().max().item() < 1e-4 and count() == c0 + 1
+    assert (tf.jvp(fvec, (x,), (v,))[1] - jac @ v).abs().max().item() < 1e-4 and count() == c0 + 2
+    import torch.autograd.forward_ad as fwad
+
+    with fwad.dual_level():          # plain forward_ad (no torch.func.jvp around it): the per-gate nodes, as before
+        c0 = count()
+        tangent = fwad.unpack_dual(fvec(fwad.make_dual(x, v))).tangent
+    assert (tangent - jac @ v).abs().max().item() < 1e-4 and count() == c0
+    with pytest.raises(RuntimeError, match='nested forward-mode'):
+        tf.jacfwd(tf.jacfwd(f))(x)
     # A/B switch
     executor.CONFIG['fused_transforms'] = False
     try:
