@@ -58,7 +58,9 @@ for on in (True, False):
     rows[f'torch.vmap(circuit), {tag}'] = timed(vmapped)
     rows[f'torch.func.jacrev, 5 observables x {cir.ndata} angles, {tag}'] = timed(lambda: tf.jacrev(fvec)(x), reps=3)
     rows[f'torch.func.vmap(grad) over {batch} rows, {tag}'] = timed(lambda: tf.vmap(tf.grad(lambda p: fvec(p).sum()))(data), reps=3)
+    rows[f'torch.func.jvp (one direction), {tag}'] = timed(lambda: tf.jvp(fvec, (x,), (torch.ones_like(x),)), reps=3)
     if hess:
+        rows[f'torch.func.hessian (jacfwd over jacrev), {tag}'] = timed(lambda: tf.hessian(lambda p: fvec(p).sum())(x), reps=2)
         rows[f'torch.func.jacrev(jacrev): the {cir.ndata} x {cir.ndata} Hessian of sum <Z_q>, {tag}'] = timed(
             lambda: tf.jacrev(tf.jacrev(lambda p: fvec(p).sum()))(x), reps=2)
 dq.executor.CONFIG['fused_transforms'] = True
