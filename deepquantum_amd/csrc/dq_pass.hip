@@ -184,7 +184,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
                 return DQ_ERR_ARG;
             }
             if (g.kind == DQ_FG_GRAD) {
-                if (ngrads < 0 || g.q >= slots || g.q2 >= slots || g.q == g.q2 || (g.reg_cmask >> slots) || g.loc > 3 ||
+                if (ngrads < 0 || g.q >= slots || g.q2 >= slots || g.q == g.q2 || (g.reg_cmask >> slots) || g.loc > 4 ||
                     ((g.reg_cmask >> g.q) & 1u) || ((g.reg_cmask >> g.q2) & 1u) || g.mat != next_mat || g.mat_advance != 0 ||
                     (int64_t)g.reserved >= ngrads) {
                     set_error("dq_apply_fused: reduction record %d malformed, or not a dq_apply_fused_grad_* call", gi);

@@ -80,6 +80,8 @@ CONFIG = {'fuse': True, 'min_low_c64': None, 'min_low_c128': None,
           # the reductions of the fused sweep form only the sums a trainable gate's gradient can need (2 real sums for a
           # Pauli-X rotation instead of 4 complex ones; A/B switch)
           'reduced_grad_sums': True,
+          # a backward that records no graph: ONE sum for a rotation about X (`_grad_records`, DQ_FG_GRAD variant 4)
+          'terminal_grad_sums': True,
           # sharded adjoint: all observables of a circuit share ONE reverse sweep (lambda = sum_k g_k O_k psi); False: one
           # sweep and one (psi, lambda) pair per observable, the reference's structure (circuit.py:1706-1738)
           'joint_adjoint': True,
@@ -693,20 +695,26 @@ def _inverse_block(m: torch.Tensor) -> torch.Tensor:
 
 
 def grad_records(kind: str, mode: int, targets: Sequence[int], controls: Sequence[int], row0: int,
-                 reduced: bool = True) -> tuple[list[Prim], int]:
+                 reduced: bool = True, terminal: bool = False) -> tuple[list[Prim], int]:
     """`_grad_records`, remembered per argument tuple: the records carry no matrix, and a Hessian by rows asks for the same
     two thousand of them in every row (a third of a row's host time was their construction)."""
-    recs, cnt = _grad_records(kind, int(mode), tuple(targets), tuple(controls), int(row0), bool(reduced and CONFIG['reduced_grad_sums']))
+    reduced = bool(reduced and CONFIG['reduced_grad_sums'])
+    recs, cnt = _grad_records(kind, int(mode), tuple(targets), tuple(controls), int(row0), reduced,
+                              bool(terminal and reduced and CONFIG['terminal_grad_sums']))
     return list(recs), cnt
 
 
 @functools.lru_cache(maxsize=1 << 16)
-def _grad_records(kind: str, mode: int, targets: tuple, controls: tuple, row0: int, reduced: bool) -> tuple[tuple, int]:
+def _grad_records(kind: str, mode: int, targets: tuple, controls: tuple, row0: int, reduced: bool,
+                  terminal: bool = False) -> tuple[tuple, int]:
     """The reduction records of a reverse sweep for ONE trainable gate (bit positions of the (psi, lambda) pair: bit 0
     tells the two apart), in front of which they go, and how many accumulator rows they fill from ``row0`` on.
 
     One target: one DQ_FG_GRAD record, G = sum lambda (x) conj(psi) on the target (with the variant that forms only the
-    sums a rotation's gradient needs).  Two targets (t1, t2): the 4x4 sum in 2x2 blocks over t1, by the values of t2
+    sums a rotation's gradient needs).  ``terminal``: the cotangent is only ever contracted with dM/dtheta (a backward that
+    records no graph).  For a unitary M = a I + i b X that tangent is -i X M / 2, and in <cotangent, dM> = <G, dM M^-1> the
+    trace part Re (G00 + G11) drops out: ONE real sum per gate (variant 4) instead of two.  With a graph the value of the
+    cotangent itself is differentiated again (d2M/dtheta2 = -M / 4 is radial, not tangent), so the full variant stays.  Two targets (t1, t2): the 4x4 sum in 2x2 blocks over t1, by the values of t2
     in lambda (a2) and psi (b2) -- all from one-target records: a record controlled by t2 gives the block a2 = b2 = 1,
     an uncontrolled one the sum of the two blocks a2 = b2; with t2 flipped on the LAMBDA half (an X controlled by bit
     0, undone afterwards) the same two records give the block a2 = 0, b2 = 1 and the sum of the two blocks a2 != b2.
@@ -717,6 +725,8 @@ def _grad_records(kind: str, mode: int, targets: tuple, controls: tuple, row0: i
         variant = 3 if kind == 'diag' else (mode if kind == 'gen' and mode in (1, 2) else 0)
         if not reduced:
             variant = 0
+        elif terminal and variant == 2:
+            variant = 4
         return (Prim('grad', None, (t[0], 0), c, row0 | (variant << fusion.GRAD_VARIANT_SHIFT)),), 1
     assert len(t) == 2, 'reductions inside the passes: trainable gates on one or two targets'
     v = (3 << fusion.GRAD_VARIANT_SHIFT) if (kind == 'diag' and reduced) else 0
@@ -1012,8 +1022,10 @@ class _FusedCircuit(torch.autograd.Function):
             if torch.is_grad_enabled() and not ops.transform_stack():
                 # plain autograd with create_graph=True on a node that was made under vmap: the differentiable routes
                 return _AdjointCircuit._backward_with_graph(ctx, gy)
+            terminal = not torch.is_grad_enabled() and not ops.transform_stack()
             with torch.no_grad():
-                gstate, grads = _AdjointCircuit._first_order(out, gy.contiguous(), ctx.meta, list(mats), need_state, list(need))
+                gstate, grads = _AdjointCircuit._first_order(out, gy.contiguous(), ctx.meta, list(mats), need_state, list(need),
+                                                             terminal=terminal)
             return (gstate, None, *grads)
         mask = sum(1 << j for j, nd in enumerate(need) if nd)       # (an int: a leaf for the transforms' pytrees)
         res = list(_FusedSweep.apply(gy, state, out, ctx.meta, need_state, mask, *mats))
@@ -1217,13 +1229,14 @@ class _AdjointCircuit(torch.autograd.Function):
             return _AdjointCircuit._backward_with_graph(ctx, gy)
         _state, out, *mats = ctx.saved_tensors
         need = [ctx.needs_input_grad[2 + j] for j in range(len(mats))]
-        gstate, grads = _AdjointCircuit._first_order(out, gy, ctx.meta, mats, ctx.needs_input_grad[0], need)
+        gstate, grads = _AdjointCircuit._first_order(out, gy, ctx.meta, mats, ctx.needs_input_grad[0], need, terminal=True)
         return (gstate, None, *grads)
 
     @staticmethod
-    def _first_order(out, gy, meta, mats, need_state, need):
+    def _first_order(out, gy, meta, mats, need_state, need, terminal=False):
         """The reverse sweep from the saved output: (cotangent of the input state or None, [cotangent of every matrix or
-        None]).  No graph is built (``backward`` of the circuit node; forward of ``_SweepGrads``)."""
+        None]).  No graph is built (``backward`` of the circuit node; forward of ``_SweepGrads``).  ``terminal``: nothing will
+        differentiate the result again (`grad_records`)."""
         b = out.shape[0]
         # Inverses / adjoints of ALL gates in a few vectorised calls (grouped by kind, size and batchness): at
         # launch-bound sizes a handful of tiny kernels per gate would dominate the whole sweep.
@@ -1270,7 +1283,8 @@ class _AdjointCircuit(torch.autograd.Function):
                                        and (is128 or meta[j][4] is not True)) or (tangent and meta[j][4] == 'block'))
                        for j, m in enumerate(mats)]
             raw, lam = _AdjointCircuit._sweep_fused(out, gy, meta, undo, need, b,
-                                                    [m.ndim == 2 or m.shape[0] == 1 for m in mats], corr, inexact)
+                                                    [m.ndim == 2 or m.shape[0] == 1 for m in mats], corr, inexact,
+                                                    terminal=terminal and not tangent)
         else:
             raw, lam = _AdjointCircuit._sweep_undo_reduce(out, gy, meta, undo, need, b)
 
@@ -1342,7 +1356,7 @@ class _AdjointCircuit(torch.autograd.Function):
         return raw, lambda: work[b:].clone()
 
     @staticmethod
-    def _sweep_fused(out, gy, meta, undo, need, b, shared, corr=None, inexact=None):
+    def _sweep_fused(out, gy, meta, undo, need, b, shared, corr=None, inexact=None, terminal=False):
         """The same sweep as ONE gate list run in fused passes: psi and lambda are interleaved along an
         extra index bit 0 -- every thread of a pass then holds both halves of an amplitude pair of both states -- every
         gate's adjoint acts on both at once (adjoint = inverse to the rounding of the state's precision, the precision psi
@@ -1373,7 +1387,10 @@ class _AdjointCircuit(torch.autograd.Function):
                 # class promises to be real / of the form a I + i b X / diagonal has no gradient component in the
                 # others; a gate on two targets takes four one-target records, `grad_records`)
                 rows[j] = nrows
-                recs, cnt = grad_records(kind, mode, t1, c1, nrows)
+                # (one sum instead of two for a rotation about X: only a gate that IS unitary to the working precision -- a
+                # matrix computed from parameters, `exact` -- and only when nothing differentiates the cotangent again)
+                recs, cnt = grad_records(kind, mode, t1, c1, nrows, terminal=terminal and _exact is True and not (
+                    inexact is not None and inexact[j]))
                 for q in recs:
                     if q.kind == 'grad':
                         grad_at[len(prims)] = q.mode & fusion.GRAD_ROW_MASK
@@ -1404,11 +1421,12 @@ class _AdjointCircuit(torch.autograd.Function):
             if 1.05 * work.numel() * work.element_size() <= free:
                 scratch = torch.empty_like(work)
         work = _run_nograd(work, prims, inplace=True, scratch=scratch, grads=acc)
-        LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=nrows, with_graph=False)
+        LAST_SWEEP.update(fused=True, passes=LAST_RUN['passes'], reductions=nrows, with_graph=False,
+                          variants=tuple(sorted(set(variants.values()))))
         if CONFIG.get('check_grad_rows'):
             # (tests) the ABI's promise for reduced records: the components a variant does not form are left untouched --
             # zero, since the accumulator was zeroed -- which is what lets `_first_order` multiply whole rows by U^-dagger
-            keep = {0: range(8), 1: (0, 2, 4, 6), 2: (0, 3), 3: (0, 1, 6, 7)}       # (Re, Im) of G00 G01 G10 G11
+            keep = {0: range(8), 1: (0, 2, 4, 6), 2: (0, 3), 3: (0, 1, 6, 7), 4: (3,)}       # (Re, Im) of G00 G01 G10 G11
             for r, v_ in variants.items():
                 idle = [c for c in range(8) if c not in keep[v_]]
                 if idle and float(acc[:, r, idle].abs().max()) != 0.0:

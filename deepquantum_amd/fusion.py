@@ -25,7 +25,7 @@ from . import _lib
 
 
 # a 'grad' PrimOp carries row + (variant << GRAD_VARIANT_SHIFT) in ``mode`` (include/dq_hip.h, DQ_FG_GRAD: 0 all sums,
-# 1 a real matrix, 2 a I + i b X, 3 diagonal)
+# 1 a real matrix, 2 a I + i b X, 3 diagonal, 4 a unitary a I + i b X in a backward that records no graph)
 GRAD_VARIANT_SHIFT = 24
 GRAD_ROW_MASK = (1 << GRAD_VARIANT_SHIFT) - 1
 

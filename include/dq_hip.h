@@ -115,7 +115,8 @@ typedef enum {
                         `loc` says which of the eight real sums the record forms:
                         0 all; 1 Re G only (the trainable gate's matrix is real); 2 Re (G00 + G11), left in Re G00, and
                         Im (G01 + G10), left in Im G01 (a matrix a I + i b X: a Pauli-X rotation); 3 G00 and G11 only
-                        (a diagonal matrix).  The OTHER components of the row are left untouched -- nothing is added to
+                        (a diagonal matrix); 4 Im (G01 + G10) alone, left in Im G01 (a UNITARY a I + i b X whose gradient
+                        is only ever taken along the rotation: the trace part cancels).  The OTHER components of the row are left untouched -- nothing is added to
                         them, so a caller that zeroed the accumulator reads zeros there and may use the whole row in
                         linear algebra (executor._first_order multiplies the 2x2 row by U^-dagger) */
     DQ_FG_EXPZ = 7   /* not a gate: the expectation value of a Z string taken from the registers, so that a circuit's

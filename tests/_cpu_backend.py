@@ -184,8 +184,10 @@ class CpuTestBackend:
                         # `loc`: the sums the caller will read; like the kernels, the double forms no others
                         comp = np.array([G[0, 0].real, G[0, 0].imag, G[0, 1].real, G[0, 1].imag,
                                          G[1, 0].real, G[1, 0].imag, G[1, 1].real, G[1, 1].imag])
-                        assert g.loc in (0, 1, 2, 3)
-                        if g.loc == 1:
+                        assert g.loc in (0, 1, 2, 3, 4)
+                        if g.loc == 4:
+                            comp = np.array([0, 0, 0, (G[0, 1] + G[1, 0]).imag, 0, 0, 0, 0])
+                        elif g.loc == 1:
                             comp[1::2] = 0.0
                         elif g.loc == 2:
                             comp = np.array([(G[0, 0] + G[1, 1]).real, 0, 0, (G[0, 1] + G[1, 0]).imag, 0, 0, 0, 0])

@@ -324,6 +324,8 @@ def _check_fused_sweep(dq, device=None, n=12, batch=2, tol=3e-5, dtype=torch.flo
             if mode == 'adjoint':
                 assert dq.executor.LAST_SWEEP['fused'] == fused
                 assert not fused or (dq.executor.LAST_SWEEP['reductions'] > 5 * n and dq.executor.LAST_SWEEP['passes'] >= 1)
+                # a backward that records no graph: the Rx / CRx rotations reduce ONE sum each (DQ_FG_GRAD variant 4)
+                assert not fused or (4 in dq.executor.LAST_SWEEP['variants'] and 2 not in dq.executor.LAST_SWEEP['variants'])
             results[mode, fused] = (loss.detach().cpu(), data.grad.cpu(), psi0.grad.cpu(),
                                     [p.grad.cpu() for p in cir.parameters()])
         finally:

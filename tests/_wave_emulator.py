@@ -269,6 +269,8 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None, known_zero: int
                         comp = np.array([(acc[0, 0] + acc[1, 1]).real, 0, 0, (acc[0, 1] + acc[1, 0]).imag, 0, 0, 0, 0])
                     elif variant == 3:
                         comp[2:6] = 0.0
+                    elif variant == 4:
+                        comp = np.array([0, 0, 0, (acc[0, 1] + acc[1, 0]).imag, 0, 0, 0, 0])
                     grads[b, w[6]] += comp
                     continue
                 if hid >= g.ID_DIAG1:

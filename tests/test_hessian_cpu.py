@@ -48,6 +48,69 @@ def test_first_order_backward_still_takes_the_sweep(cpu_backend):
     assert not dq.executor.LAST_SWEEP['with_graph']
 
 
+@pytest.mark.parametrize('prec', ['c64', 'c128'])
+def test_one_sum_per_x_rotation_only_when_nothing_differentiates_the_cotangent_again(cpu_backend, prec):
+    """DQ_FG_GRAD variant 4 (ONE real sum for a unitary a I + i b X): the trace part of sum lambda (x) conj(psi) cancels against
+    the tangent of a rotation, so a backward that records no graph leaves it out.  Under ``create_graph=True`` the VALUE of
+    the matrix cotangent is differentiated again (d2M/dtheta2 is radial, not tangent): the two-sum variant stays, and the
+    Hessian agrees with the per-gate nodes."""
+    n = 12
+    dt = torch.float64 if prec == 'c128' else torch.float32
+    tol = 1e-11 if prec == 'c128' else 2e-5
+
+    def build():
+        torch.manual_seed(11)
+        cir = dq.QubitCircuit(n)
+        cir.hlayer()
+        cir.rxlayer(encode=True)
+        cir.cnot_ring()
+        cir.rxlayer()
+        cir.crx(0, 5)
+        cir.rx(3, controls=[1, 7])
+        cir.cnot_ring(reverse=True)
+        cir.rxlayer(encode=True)
+        cir.observable(0)
+        cir.observable([2, 5], 'zx')
+        if prec == 'c128':
+            cir.to(torch.double)
+        return cir
+
+    data = torch.rand(n * 2, generator=torch.Generator().manual_seed(1), dtype=dt)
+    out = {}
+    for key, (mode, terminal_sums) in {'per_gate': ('per_gate', True), 'two': ('adjoint', False), 'one': ('adjoint', True)}.items():
+        dq.executor.CONFIG['grad_mode'] = mode
+        dq.executor.CONFIG['terminal_grad_sums'] = terminal_sums
+        try:
+            cir = build()
+            x = data.clone().requires_grad_(True)
+            cir(data=x)
+            cir.expectation().sum().backward()
+            if mode == 'adjoint':
+                assert dq.executor.LAST_SWEEP['fused']
+                assert dq.executor.LAST_SWEEP['variants'] == ((4,) if terminal_sums else (2,))
+            out[key] = torch.cat([x.grad] + [p.grad.reshape(-1) for p in cir.parameters()])
+        finally:
+            dq.executor.CONFIG['grad_mode'] = 'adjoint'
+            dq.executor.CONFIG['terminal_grad_sums'] = True
+    assert (out['one'] - out['per_gate']).abs().max().item() < tol
+    assert (out['two'] - out['one']).abs().max().item() < tol
+    # with a graph: the full sums, and a Hessian-vector product equal to the per-gate nodes'
+    hv = {}
+    for mode in ('per_gate', 'adjoint'):
+        dq.executor.CONFIG['grad_mode'] = mode
+        try:
+            cir = build()
+            x = data.clone().requires_grad_(True)
+            cir(data=x)
+            (g,) = torch.autograd.grad(cir.expectation().sum(), x, create_graph=True)
+            if mode == 'adjoint':
+                assert 4 not in dq.executor.LAST_SWEEP.get('variants', ())
+            (hv[mode],) = torch.autograd.grad((g * torch.linspace(-1, 1, g.numel(), dtype=dt)).sum(), x)
+        finally:
+            dq.executor.CONFIG['grad_mode'] = 'adjoint'
+    assert (hv['adjoint'] - hv['per_gate']).abs().max().item() < 20 * tol
+
+
 def test_the_test_double_builds_no_graph(cpu_backend):
     """The double is no more capable than the kernels: raw backend calls return graph-less tensors."""
     x = torch.randn(1, 16, dtype=torch.complex128, requires_grad=True)

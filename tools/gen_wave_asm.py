@@ -200,8 +200,10 @@ ID_DIAG2 = ID_DIAG1 + 14
 ID_GRAD = ID_DIAG2 + 14
 # + 5 * variant + (slot - 1).  Variants (DqFusedGate::loc of a DQ_FG_GRAD record: what the trainable gate's matrix can
 # depend on decides which sums its gradient needs): 0 all of G; 1 Re G only (a real matrix: Ry); 2 Re (G00 + G11) and
-# Im (G01 + G10) only (a I + i b X: Rx, CRx); 3 the diagonal G00, G11 only (a diagonal gate on a slot)
-GRAD_VARIANTS = 4
+# Im (G01 + G10) only (a I + i b X: Rx, CRx); 3 the diagonal G00, G11 only (a diagonal gate on a slot); 4 Im (G01 + G10)
+# alone (a UNITARY a I + i b X whose cotangent is only ever contracted with a tangent of the rotation: dM M^-1 = -i X / 2, the
+# trace part drops out -- a first-order backward that records no graph)
+GRAD_VARIANTS = 5
 # expectation value of a Z string, reduced from the registers (DQ_FG_EXPZ): same accumulators as the reductions above
 ID_EXPZ = ID_GRAD + 5 * GRAD_VARIANTS
 # dense gate on two register slots a < b (index in SWAP_PAIRS): a 4x4 matrix, index = 2 * (bit of slot b) + (bit of slot a)
@@ -374,7 +376,7 @@ def grad_code_reduced(q, variant):
     CROSS = 'op_sel:[0,1,0] op_sel_hi:[1,0,1]'        # (l.re p.im, l.im p.re): Im (l conj p) = hi - lo
     tag = f'{q}v{variant}'
     t = [f's_and_b64 vcc, s[{REC + 2}:{REC + 3}], {TG}', f's_cmp_eq_u64 vcc, s[{REC + 2}:{REC + 3}]', 's_cbranch_scc0 .Lnext_%=']
-    t += [f'v_mov_b32 v{r}, 0' for r in range(10, 18)]
+    t += [f'v_mov_b32 v{r}, 0' for r in ((12, 13, 16, 17) if variant == 4 else range(10, 18))]
     t += [f'v_and_b32 {TT}, s{REC + 1}, {TB}', f'v_cmp_eq_u32 vcc, s{REC + 1}, {TT}', f's_and_saveexec_b64 {SAVE}, vcc',
           f's_cbranch_execz .Lgz{tag}_%=']
     for i, j in enumerate(grad_groups(q)):
@@ -382,6 +384,8 @@ def grad_code_reduced(q, variant):
         t += [f's_bitcmp1_b32 s{REC + 5}, {i}', f's_cbranch_scc0 .Lgg{tag}_{i}_%=']
         if variant == 1:
             t += [f'v_pk_fma_f32 {g_}, {l_}, {p_}, {g_}' for g_, l_, p_ in ((ACC[0], l0, p0), (ACC[1], l0, p1), (ACC[2], l1, p0), (ACC[3], l1, p1))]
+        elif variant == 4:
+            t += [f'v_pk_fma_f32 {ACC[1]}, {l0}, {p1}, {ACC[1]} {CROSS}', f'v_pk_fma_f32 {ACC[3]}, {l1}, {p0}, {ACC[3]} {CROSS}']
         elif variant == 2:
             t += [f'v_pk_fma_f32 {ACC[0]}, {l0}, {p0}, {ACC[0]}', f'v_pk_fma_f32 {ACC[1]}, {l0}, {p1}, {ACC[1]} {CROSS}',
                   f'v_pk_fma_f32 {ACC[2]}, {l1}, {p1}, {ACC[2]}', f'v_pk_fma_f32 {ACC[3]}, {l1}, {p0}, {ACC[3]} {CROSS}']
@@ -390,6 +394,18 @@ def grad_code_reduced(q, variant):
                   f'v_pk_fma_f32 {ACC[2]}, {l1}, {p1}, {ACC[2]}', f'v_pk_fma_f32 {ACC[3]}, {l1}, {p1}, {ACC[3]} {CROSS}']
         t.append(f'.Lgg{tag}_{i}_%=:')
     t += [f'.Lgz{tag}_%=:', f's_mov_b64 exec, {SAVE}', f'v_mul_f32 {TT}, {HR}, {HR}', f'v_fma_f32 {TT}, {HI}, {HI}, {TT}']
+    if variant == 4:       # one sum: butterflies over the four lane bits of a row, lane 0 of every row adds to Im G01
+        dpp = 'row_mask:0xf bank_mask:0xf'
+        return t + ['v_pk_add_f32 v[12:13], v[12:13], v[16:17]', 's_nop 0', 'v_sub_f32 v10, v13, v12',
+                    's_nop 1', f'v_add_f32_dpp v10, v10, v10 row_ror:4 {dpp}',
+                    's_nop 1', f'v_add_f32_dpp v10, v10, v10 row_ror:8 {dpp}',
+                    's_nop 1', f'v_add_f32_dpp v10, v10, v10 quad_perm:[1,0,3,2] {dpp}',
+                    's_nop 1', f'v_add_f32_dpp v10, v10, v10 quad_perm:[2,3,0,1] {dpp}',
+                    's_nop 0', f'v_mul_f32 v10, v10, {TT}',
+                    f'v_mov_b32 v32, {ACC_BASE - 32 + 12}', f'v_add_u32 v32, {GOFF}, v32',
+                    's_mov_b32 exec_lo, 0x00010001', 's_mov_b32 exec_hi, 0x00010001',
+                    'ds_add_f32 v32, v10',
+                    's_mov_b64 exec, -1']
     if variant == 1:       # v10, v12, v14, v16 = Re G00, G01, G10, G11
         t += ['v_add_f32 v10, v10, v11', 'v_add_f32 v12, v12, v13', 'v_add_f32 v14, v14, v15', 'v_add_f32 v16, v16, v17']
         nval = 4

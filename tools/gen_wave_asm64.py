@@ -149,7 +149,7 @@ ID_DIAG1 = ID_SWAP + len(SWAP_PAIRS)
 ID_DIAG2 = ID_DIAG1 + NV
 # reduction of the adjoint method's reverse sweep: target on slot 1 + (id - ID_GRAD), psi / lambda told apart by slot 0
 ID_GRAD = ID_DIAG2 + NV        # + (R - 1) * variant + (slot - 1); variants as in the complex64 generator
-GRAD_VARIANTS = 4
+GRAD_VARIANTS = 5
 ID_EXPZ = ID_GRAD + (R - 1) * GRAD_VARIANTS      # expectation value of a Z string (DQ_FG_EXPZ)
 # dense gate on two register slots a < b (index in SWAP_PAIRS): a 4x4 matrix, index = 2 * (bit of slot b) + (bit of slot a)
 ID_GEN2 = ID_EXPZ + 1
@@ -314,7 +314,8 @@ def grad_code(q, variant=0):
     """(variant 1 / 2 / 3 -- DqFusedGate::loc of the record: the trainable gate's matrix is real / of the form a I + i b X
     / diagonal -- forms only the sums such a gate's gradient can need: Re G; Re (G00 + G11) in the place of Re G00 and
     Im (G01 + G10) in the place of Im G01; G00 and G11.  Eight operations per register group instead of sixteen; the
-    other accumulators stay zero and take the same way through the reduction.)
+    other accumulators stay zero and take the same way through the reduction.  Variant 4: Im (G01 + G10) alone -- a unitary
+    a I + i b X in a backward that records no graph, as in the complex64 generator.)
 
     DQ_FG_GRAD with the target on slot q, psi (0) / lambda (1) on slot 0: G[a][b] = sum lambda[target = a] conj(psi[target
     = b]) over the thread's register groups (w5 = mask of the groups whose register controls are set; lanes that fail the
@@ -350,6 +351,8 @@ def grad_code(q, variant=0):
                 chains = [re_(2 * (2 * a_ + b_), a_, b_) for a_, b_ in ab]
             elif variant == 2:       # two accumulators, each fed by two chains: (0, 0) then (1, 1); (0, 1) then (1, 0)
                 chains = [re_(0, 0, 0) + re_(0, 1, 1), im_(3, 0, 1) + im_(3, 1, 0)]
+            elif variant == 4:       # Im (G01 + G10) alone: two chains, the second in a scratch accumulator folded in below
+                chains = [im_(3, 0, 1), im_(5, 1, 0)]
             else:
                 chains = [re_(0, 0, 0), im_(1, 0, 0), re_(6, 1, 1), im_(7, 1, 1)]
             k_ = 0
@@ -357,8 +360,10 @@ def grad_code(q, variant=0):
                 t += [ch[k_] for ch in chains if k_ < len(ch)]
                 k_ += 1
         t.append(f'.Lgg{tag}_{i}_%=:')
-    t += [f'.Lgz{tag}_%=:', f's_mov_b64 exec, {SAVE}',
-          f'v_mul_f64 v[6:7], {HS}, {HS}',
+    t += [f'.Lgz{tag}_%=:', f's_mov_b64 exec, {SAVE}']
+    if variant == 4:
+        t += [f'v_add_f64 {G[3]}, {G[3]}, {G[5]}', 'v_mov_b32 v34, 0', 'v_mov_b32 v35, 0']
+    t += [f'v_mul_f64 v[6:7], {HS}, {HS}',
           f'v_mul_u32_u24 v8, 72, {LANE}', f'v_add_u32 v8, {LDSB}, v8']
     t += [f'ds_write_b64 v8, {G[c]} offset:{8 * c}' for c in range(8)]
     t += [f'v_lshrrev_b32 v9, 3, {LANE}', 'v_mul_u32_u24 v9, 576, v9', f'v_and_b32 {TT}, 7, {LANE}', f'v_lshl_add_u32 v9, {TT}, 3, v9',
