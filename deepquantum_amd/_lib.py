@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DQHIP_LIBRARY') or os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_RESERVED5, FG_GRAD, FG_EXPZ = range(8)
@@ -25,7 +25,7 @@ LOC_REG, LOC_THR, LOC_OUT = range(3)
 FUSED_MAX_HIGH = 12
 FUSED_MAX_LOW = 8
 FUSED_MAX_ROUNDS = 24
-FUSED_MAX_GATES = 80
+FUSED_MAX_GATES = 160
 FUSED_MAX_SLOTS = 6
 FUSED_MAX_TBITS = 9
 FUSED_MAX_BLK = 24
@@ -110,6 +110,8 @@ _SIGNATURES = {
     'dq_defer_rx_c64': (_i, [_vp, _i64, _vp, _i64, _i64, _vp]),
     'dq_apply_fused_grad_c64': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp, _i64, _vp]),
     'dq_apply_fused_grad_c128': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp, _i64, _vp]),
+    'dq_wave_records': (_i64, [C.POINTER(DqFusedPass), _i, _vp, _i64]),
+    'dq_apply_fused_grad_ext_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp, _i64, _vp, _i64, _vp]),
     'dq_expect_pauli_{s}': (_i, [_vp, _u64, _u64, _i, _i64, _vp, _vp, _vp]),
     'dq_inner_{s}': (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'dq_probs_{s}': (_i, [_vp, _vp, _i64, _vp]),

@@ -154,6 +154,44 @@ def apply_gate(
     return out
 
 
+#: records of a pass that travel in the kernel-argument segment (csrc/dq_wave.hip, WAVE_MAX_REC); a pass with more keeps them
+#: in device memory (include/dq_hip.h, dq_wave_records / dq_apply_fused_grad_ext_*)
+KERNARG_RECORDS = 112
+#: device copies of records that a HIP graph under capture has baked in: they must outlive the plan that made them
+_CAPTURED_RECORDS: list = []
+
+
+def _device_records(desc: _lib.DqFusedPass, n: int, device: torch.device) -> torch.Tensor | None:
+    """The records of ``desc`` on ``device`` (a uint8 tensor, cached on the descriptor) when they do not fit the
+    kernel-argument segment, else None.  Only passes with many gates can need them: up to 72 gates and reductions (the cap
+    of every pass before ABI 24) the planner's bound on layout changes keeps a pass within the segment, and the count is not
+    even asked for."""
+    if desc.rounds[desc.nrounds - 1].gate_end <= 72:
+        return None
+    cache = desc.__dict__.setdefault('_dev_records', {})
+    key = (n, device)
+    hit = cache.get(key, False)
+    if hit is False:
+        lib = _lib.load()
+        nbytes = lib.dq_wave_records(C.byref(desc), n, None, 0)
+        if nbytes < 0:
+            _lib.check(int(nbytes), 'dq_wave_records')
+        if nbytes <= 32 * KERNARG_RECORDS:
+            hit = None
+        else:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('deepquantum_amd: the first run of a pass with more than 112 records copies them to the '
+                                   'device; run the step once before capturing it (dq.CapturedGraph warms up by itself)')
+            host = torch.empty(int(nbytes), dtype=torch.uint8)
+            got = lib.dq_wave_records(C.byref(desc), n, host.data_ptr(), int(nbytes))
+            assert got == nbytes
+            hit = host.to(device)
+        cache[key] = hit
+    if hit is not None and torch.cuda.is_current_stream_capturing() and not any(t is hit for t in _CAPTURED_RECORDS):
+        _CAPTURED_RECORDS.append(hit)
+    return hit
+
+
 def apply_fused(
     state: torch.Tensor,
     mats: torch.Tensor,
@@ -192,6 +230,13 @@ def apply_fused(
         if out.shape[0] > MAX_BATCH:
             raise ValueError(f'reverse-sweep passes take at most {MAX_BATCH} samples')
         lib = _lib.load()
+        rec = _device_records(desc, n, state.device)
+        if rec is not None:       # more records than the kernel-argument segment holds: the kernel reads them from device memory
+            fn = lib.dq_apply_fused_grad_ext_c128 if state.dtype == torch.complex128 else lib.dq_apply_fused_grad_ext_c64
+            rc = fn(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0], C.byref(desc), _ptr(rec),
+                    rec.numel(), _ptr(grads), grads.shape[1], _stream(state))
+            _lib.check(rc, 'dq_apply_fused_grad_ext')
+            return out
         fn = lib.dq_apply_fused_grad_c128 if state.dtype == torch.complex128 else lib.dq_apply_fused_grad_c64
         rc = fn(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0], C.byref(desc), _ptr(grads),
                 grads.shape[1], _stream(state))

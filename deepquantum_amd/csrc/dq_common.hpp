@@ -84,9 +84,11 @@ inline hipStream_t as_stream(dq_stream_t s) { return reinterpret_cast<hipStream_
 int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                     const DqFusedPass* pass, hipStream_t s, uint64_t known_zero = 0);
 int wave_launch_grad_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                         const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads);
+                         const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads, const void* ext_rec = nullptr,
+                         int64_t ext_bytes = 0);
 int wave_launch_grad_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads);
+                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads, const void* ext_rec = nullptr,
+                          int64_t ext_bytes = 0);
 int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                      const DqFusedPass* pass, hipStream_t s, uint64_t known_zero = 0);
 

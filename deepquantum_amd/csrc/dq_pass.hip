@@ -220,7 +220,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
 template <typename T>
 static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
                       const DqFusedPass* pass, dq_stream_t stream, bool broadcast_in = false, double* grads = nullptr,
-                      int64_t ngrads = -1, uint64_t known_zero = 0) {
+                      int64_t ngrads = -1, uint64_t known_zero = 0, const void* ext_rec = nullptr, int64_t ext_bytes = 0) {
     const int64_t in_bstride = broadcast_in ? 0 : (int64_t)1 << n;
     if (broadcast_in && in == out) {
         set_error("dq_apply_fused_bcast: the shared input state cannot be the output buffer");
@@ -277,8 +277,8 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
     hipStream_t s = as_stream(stream);
     // one wavefront per tile: csrc/dq_wave.hip
     if (ngrads >= 0) {
-        if constexpr (is128) return wave_launch_grad_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
-        else return wave_launch_grad_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+        if constexpr (is128) return wave_launch_grad_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads, ext_rec, ext_bytes);
+        else return wave_launch_grad_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads, ext_rec, ext_bytes);
     }
     if constexpr (is128) return wave_launch_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, known_zero);
     else return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, known_zero);
@@ -325,6 +325,30 @@ extern "C" int dq_apply_fused_grad_c128(const void* in, void* out, const void* m
         return DQ_ERR_ARG;
     }
     return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, false, grads, ngrads);
+}
+
+// A reverse-sweep pass whose records (dq_wave_records) the caller keeps in DEVICE memory: more of them than the
+// kernel-argument segment holds.  `records` must stay valid until the pass has run (a HIP graph: until its last replay).
+extern "C" int dq_apply_fused_grad_ext_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                           int64_t batch, const DqFusedPass* pass, const void* records, int64_t records_bytes,
+                                           double* grads, int64_t ngrads, dq_stream_t stream) {
+    if (!grads || ngrads < 1 || !records || records_bytes < 32 || (records_bytes & 31)) {
+        dq::set_error("dq_apply_fused_grad_ext_c64: no accumulator or no records (grads = %p, ngrads = %lld, records = %p, %lld bytes)",
+                      (void*)grads, (long long)ngrads, records, (long long)records_bytes);
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream, false, grads, ngrads, 0, records, records_bytes);
+}
+
+extern "C" int dq_apply_fused_grad_ext_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
+                                            int64_t batch, const DqFusedPass* pass, const void* records, int64_t records_bytes,
+                                            double* grads, int64_t ngrads, dq_stream_t stream) {
+    if (!grads || ngrads < 1 || !records || records_bytes < 32 || (records_bytes & 31)) {
+        dq::set_error("dq_apply_fused_grad_ext_c128: no accumulator or no records (grads = %p, ngrads = %lld, records = %p, %lld bytes)",
+                      (void*)grads, (long long)ngrads, records, (long long)records_bytes);
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, false, grads, ngrads, 0, records, records_bytes);
 }
 
 // Same pass, but `in` is ONE state (2^n amplitudes) shared by all `batch` outputs: the first pass of a batched

@@ -34,7 +34,8 @@ namespace dq {
 #include "dq_wave_asm64.inc"
 
 constexpr int WAVE_LANES = 6;
-constexpr int WAVE_MAX_REC = 112;
+constexpr int WAVE_MAX_REC = 112;      // records that travel in the kernel-argument segment (4 KiB)
+constexpr int WAVE_EXT_REC = 256;      // ... of a pass whose records the caller keeps in DEVICE memory (dq_apply_fused_grad_ext_*)
 
 // The two precisions: complex64 -- 64 amplitudes per lane, six slots, a 12-bit tile, slot 0 = index bit 0 inside the
 // 16-byte piece a lane loads -- and complex128 -- 32 amplitudes per lane, five slots, an 11-bit tile, every slot a
@@ -108,6 +109,7 @@ struct WaveKernArgs {
     WaveKernPass p;
     double* grads;
     int64_t grad_bstride;
+    const void* ext_rec;        // the records in device memory (a pass with more than WAVE_MAX_REC of them), or null
 };
 static_assert(sizeof(WaveKernArgs) <= 4096 && (offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec)) % 32 == 0, "kernel-argument segment");
 
@@ -118,14 +120,14 @@ template <class W, bool GRAD>
 __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::real>* in, vec2<typename W::real>* out,
                                                         const vec2<typename W::real>* mats, int64_t mat_bstride,
                                                         int64_t in_bstride, int n, int tpw_flags, const WaveKernPass p,
-                                                        double* grads, int64_t grad_bstride) {
+                                                        double* grads, int64_t grad_bstride, const void* ext_rec) {
     // (low byte: log2 of the tiles a wave walks; bits 16, 17: streaming loads / stores)
     (void)in, (void)out, (void)mats, (void)mat_bstride;
     extern __shared__ __attribute__((aligned(16))) unsigned char dq_wave_smem[];
     (void)dq_wave_smem;
     const unsigned tid = threadIdx.x;
     if constexpr (GRAD) {
-        for (unsigned i = tid; i < WAVE_MAX_REC * 8u; i += 256u)
+        for (unsigned i = tid; i < p.nrec_bytes / 4u; i += 256u)        // (eight accumulators per record)
             *(__attribute__((address_space(3))) typename W::acc_t*)(uintptr_t)(4u * W::LDS_PER_WAVE + (unsigned)sizeof(typename W::acc_t) * i) = 0;
         __syncthreads();
     }
@@ -183,6 +185,8 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
     typedef const __attribute__((address_space(4))) uint64_t* KQuads;
     const KQuads kq = (KQuads)karg;
     const uint64_t a_in = kq[0], a_out = kq[1], a_mats = kq[2], a_mbs = kq[3], a_ibs = kq[4];
+    const uint64_t a_ext = kq[offsetof(WaveKernArgs, ext_rec) / 8];
+    const uint64_t rec_base = a_ext ? a_ext : karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec);
     const uint32_t a_n = ((KWords)karg)[offsetof(WaveKernArgs, n) / 4], a_tf = ((KWords)karg)[offsetof(WaveKernArgs, tpw) / 4];
     constexpr uint64_t ES = W::ELEM;
     const uint64_t inb = a_in + ((uint64_t)sample * a_ibs + tg) * ES;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
     // bit 0 / 1: streaming loads / stores (see wave_launch); a pass whose samples share ONE input keeps it in the L2
     // bits 8..13 / 16..21: register slots / lane bits whose index bit is known to be |0> in the input (not loaded)
     const unsigned flags = ((a_ibs == 0 ? (a_tf >> 16) & ~1u : a_tf >> 16) & 3u) | (hw[offsetof(WaveKernPass, zext) / 4] & 0x003f3f00u);
-    W::body(karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec), hw[offsetof(WaveKernPass, nrec_bytes) / 4], mb,
+    W::body(rec_base, hw[offsetof(WaveKernPass, nrec_bytes) / 4], mb,
             hw[offsetof(WaveKernPass, mat_base_bytes) / 4], tg,
             karg + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, load_off), inb, outb, wave * W::LDS_PER_WAVE, tid,
             flags);
@@ -199,7 +203,8 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
     if constexpr (GRAD) {
         __syncthreads();
         typedef const __attribute__((address_space(4))) uint32_t* KW;
-        const KW rw = (KW)((uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec));
+        const KW rw = ext_rec ? (KW)(uint64_t)ext_rec
+                              : (KW)((uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WaveKernArgs, p) + offsetof(WaveKernPass, rec));
         const unsigned nrec = p.nrec_bytes / 32u;
         double* const grow = grads + (uint64_t)sample * (uint64_t)grad_bstride;
         for (unsigned i = tid; i < nrec * 8u; i += 256u) {
@@ -222,10 +227,12 @@ struct Xlate {
     int phys[W::R];        // tile-local bit held by physical slot s (register-index bit s)
     int lanes[WAVE_LANES];   // tile-local bit on lane bit b
     int nrec = 0;
+    WaveRec* recs = nullptr;   // where the records go: k->rec (WAVE_MAX_REC of them) or the caller's array
+    int cap = WAVE_MAX_REC;
 
     bool push(const WaveRec& r) {
-        if (nrec >= WAVE_MAX_REC) return false;
-        k->rec[nrec++] = r;
+        if (nrec >= cap) return false;
+        recs[nrec++] = r;
         return true;
     }
     int slot_of(int tile_bit) const {
@@ -336,7 +343,7 @@ struct Xlate {
 // drop out of the tile number -- the tiles in which one of them is 1 are all zero: neither read nor written --, inside
 // the tile the loads leave the registers of their 1-halves zero.
 template <class W>
-static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k, uint64_t dead = 0) {
+static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k, uint64_t dead = 0, WaveRec* ext = nullptr, int ext_cap = 0) {
     memset(k, 0, sizeof(*k));
     const int L = p->L, h = p->h;
     auto rpos = [&](int tl) { return tl < L ? tl : (int)p->high_pos[tl - L]; };
@@ -344,6 +351,8 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k, uint64_t
     Xlate<W> x;
     x.p = p;
     x.k = k;
+    x.recs = ext ? ext : k->rec;
+    x.cap = ext ? ext_cap : WAVE_MAX_REC;
     unsigned slotmask = 0;
     for (int s = 0; s < W::R; ++s) {
         x.phys[s] = p->load_rb[s];
@@ -581,9 +590,21 @@ fail:
 
 template <class W, bool GRAD = false>
 static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                       const DqFusedPass* pass, hipStream_t s, double* grads = nullptr, int64_t ngrads = 0, uint64_t dead = 0) {
+                       const DqFusedPass* pass, hipStream_t s, double* grads = nullptr, int64_t ngrads = 0, uint64_t dead = 0,
+                       const void* ext_rec = nullptr, int64_t ext_bytes = 0) {
     WaveKernPass kp;
-    const int rc = wave_translate<W>(pass, n, &kp, dead);
+    int rc;
+    if (ext_rec) {      // the records lie in device memory (dq_wave_records wrote them, the caller copied them there): translate
+        // again for the header, and hold the caller to the size this pass has
+        static thread_local WaveRec scratch[WAVE_EXT_REC];
+        rc = wave_translate<W>(pass, n, &kp, dead, scratch, WAVE_EXT_REC);
+        if (!rc && (int64_t)kp.nrec_bytes != ext_bytes) {
+            set_error("dq_apply_fused_grad_ext: %lld bytes of records in device memory, this pass has %u", (long long)ext_bytes, kp.nrec_bytes);
+            return DQ_ERR_ARG;
+        }
+    } else {
+        rc = wave_translate<W>(pass, n, &kp, dead);
+    }
     if (rc) return rc;
     const uint64_t tiles = 1ull << (kp.zext & 63u);
     int tpw = 1;
@@ -597,7 +618,9 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
         while (tpw < tpw_env && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
     }
     dim3 grid((unsigned)((tiles + 4ull * tpw - 1) / (4ull * tpw)), (unsigned)batch);
-    size_t lds = 4 * W::LDS_PER_WAVE + (GRAD ? WAVE_MAX_REC * 8 * sizeof(typename W::acc_t) : 0);
+    // (the accumulators of the reductions: eight per record, behind the four waves' staging buffers)
+    const size_t acc_rec = ext_rec ? (size_t)kp.nrec_bytes / 32u : (size_t)WAVE_MAX_REC;
+    size_t lds = 4 * W::LDS_PER_WAVE + (GRAD ? acc_rec * 8 * sizeof(typename W::acc_t) : 0);
     if (const char* kb = getenv("DQ_WAVE_LDS_KB")) {      // occupancy experiments: workgroups per CU = 160 KiB / this
         lds = (size_t)atoi(kb) << 10;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_pass_kernel<W, GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -620,7 +643,8 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
     }
     using V = vec2<typename W::real>;
     hipLaunchKernelGGL((wave_pass_kernel<W, GRAD>), grid, dim3(256), lds, s, static_cast<const V*>(in), static_cast<V*>(out),
-                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, (31 - __builtin_clz((unsigned)tpw)) | (nt << 16) | (xcd << 18), kp, grads, ngrads * 8);
+                       static_cast<const V*>(mats), mat_bstride, in_bstride, n, (31 - __builtin_clz((unsigned)tpw)) | (nt << 16) | (xcd << 18), kp, grads, ngrads * 8,
+                       ext_rec);
     return check_launch("dq_apply_fused (wave tile)");
 }
 
@@ -629,12 +653,12 @@ int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bst
     return wave_launch<WaveC64>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, nullptr, 0, dead);
 }
 int wave_launch_grad_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                         const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads) {
-    return wave_launch<WaveC64, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+                         const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads, const void* ext_rec, int64_t ext_bytes) {
+    return wave_launch<WaveC64, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads, 0, ext_rec, ext_bytes);
 }
 int wave_launch_grad_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads) {
-    return wave_launch<WaveC128, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads);
+                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads, const void* ext_rec, int64_t ext_bytes) {
+    return wave_launch<WaveC128, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads, 0, ext_rec, ext_bytes);
 }
 int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                      const DqFusedPass* pass, hipStream_t s, uint64_t dead) {
@@ -642,6 +666,29 @@ int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bs
 }
 
 }  // namespace dq
+
+// The records of a pass as the kernel reads them (32 bytes each), for a caller that keeps them in DEVICE memory: a pass with
+// more records than the kernel-argument segment holds (dq_apply_fused_grad_ext_*).  Returns their size in bytes (or a
+// negative error code); writes min(size, max_bytes) bytes to `out` (may be null: just the size).  No GPU needed.
+extern "C" int64_t dq_wave_records(const DqFusedPass* pass, int n, void* out, int64_t max_bytes) {
+    if (!pass) {
+        dq::set_error("dq_wave_records: null pointer");
+        return DQ_ERR_ARG;
+    }
+    static thread_local dq::WaveRec scratch[dq::WAVE_EXT_REC];
+    dq::WaveKernPass kp;
+    int rc;
+    if (pass->m == 12 && pass->slots == 6) rc = dq::wave_translate<dq::WaveC64>(pass, n, &kp, 0, scratch, dq::WAVE_EXT_REC);
+    else if (pass->m == 11 && pass->slots == 5) rc = dq::wave_translate<dq::WaveC128>(pass, n, &kp, 0, scratch, dq::WAVE_EXT_REC);
+    else {
+        dq::set_error("dq_wave_records: not a wave-tile pass (m = %d, %d slots)", pass->m, pass->slots);
+        return DQ_ERR_ARG;
+    }
+    if (rc) return rc;
+    const int64_t bytes = kp.nrec_bytes;
+    if (out && max_bytes > 0) memcpy(out, scratch, (size_t)(bytes < max_bytes ? bytes : max_bytes));
+    return bytes;
+}
 
 // Test hook (no GPU needed): the kernel-side descriptor the library would hand to the wave-tile kernel for `pass` --
 // slot offsets, lane shifts, tile-number positions, records (struct WaveKernPass above) -- as raw bytes.  The precision
@@ -651,16 +698,23 @@ extern "C" int dq_wave_descriptor(const DqFusedPass* pass, int n, uint64_t known
         dq::set_error("dq_wave_descriptor: null pointer");
         return DQ_ERR_ARG;
     }
+    // (header + records back to back, as in the kernel-argument segment -- also for a pass whose records would travel
+    // through device memory: up to WAVE_EXT_REC of them)
+    static thread_local dq::WaveRec scratch[dq::WAVE_EXT_REC];
     dq::WaveKernPass kp;
     int rc;
-    if (pass->m == 12 && pass->slots == 6) rc = dq::wave_translate<dq::WaveC64>(pass, n, &kp, known_zero);
-    else if (pass->m == 11 && pass->slots == 5) rc = dq::wave_translate<dq::WaveC128>(pass, n, &kp, known_zero);
+    if (pass->m == 12 && pass->slots == 6) rc = dq::wave_translate<dq::WaveC64>(pass, n, &kp, known_zero, scratch, dq::WAVE_EXT_REC);
+    else if (pass->m == 11 && pass->slots == 5) rc = dq::wave_translate<dq::WaveC128>(pass, n, &kp, known_zero, scratch, dq::WAVE_EXT_REC);
     else {
         dq::set_error("dq_wave_descriptor: not a wave-tile pass (m = %d, %d slots)", pass->m, pass->slots);
         return DQ_ERR_ARG;
     }
     if (rc) return rc;
-    const int bytes = (int)(offsetof(dq::WaveKernPass, rec) + kp.nrec_bytes);
-    if (out) memcpy(out, &kp, bytes < max_bytes ? bytes : max_bytes);
+    const int head = (int)offsetof(dq::WaveKernPass, rec);
+    const int bytes = head + (int)kp.nrec_bytes;
+    if (out && max_bytes > 0) {
+        memcpy(out, &kp, head < max_bytes ? head : max_bytes);
+        if (max_bytes > head) memcpy((char*)out + head, scratch, (size_t)((bytes < max_bytes ? bytes : max_bytes) - head));
+    }
     return bytes;
 }

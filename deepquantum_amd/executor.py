@@ -61,6 +61,8 @@ _PLAN_CACHE_SIZE = 64
 # Tunables (debug / benchmarking); None = library default.
 CONFIG = {'fuse': True, 'min_low_c64': None, 'min_low_c128': None,
           'max_gates': None, 'max_far': None, 'far_bit': None,
+          # gates + reductions in a pass of a reverse sweep (ABI 24: records in device memory; 72 as everywhere: 0 or None)
+          'sweep_max_gates': 104,
           # pass planner (fusion._plan_tiles): beam width / tiles tried per state; 0 = first-come tiles, 1 = greedy
           'plan_width': None, 'plan_branch': None, 'plan_restarts': None,
           # permuted stores also re-label the contiguous low bits, so every pass picks all its tile qubits (None = on)
@@ -185,6 +187,11 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
     takes long enough (>= 0.1 s) for a wider search of the pass planner to pay for itself within a few steps
     (measured on the headline: 21 -> 20 passes, -2.7 %, 4.6 s of planning once per circuit structure)."""
     geom = _geometry(is128)
+    if CONFIG['max_gates'] is None and CONFIG['sweep_max_gates'] and any(p.kind == 'grad' for p in prims):
+        # a reverse sweep: a reduction in front of every trainable gate -- the NUMBER of records bounded its passes, not the
+        # tile (n = 28, depth 40: 1120 gates + 420 reductions = 32 passes of at most 72, 23 of at most 104).  Such a pass
+        # keeps its records in device memory (backend._device_records)
+        geom.max_gates = CONFIG['sweep_max_gates']
     if amps >= CONFIG['plan_big_amps']:
         if CONFIG['plan_width'] is None:
             geom.plan_width = 8

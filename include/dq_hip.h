@@ -45,7 +45,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 23
+#define DQ_ABI_VERSION 24
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -97,7 +97,7 @@ int dq_set_dense_path(int mfma);
 #define DQ_FUSED_MAX_HIGH 12
 #define DQ_FUSED_MAX_LOW 8      /* contiguous low tile bits: L <= 8 */
 #define DQ_FUSED_MAX_ROUNDS 24
-#define DQ_FUSED_MAX_GATES 80
+#define DQ_FUSED_MAX_GATES 160   /* (ABI <= 23: 80) */
 #define DQ_FUSED_MAX_SLOTS 6
 
 typedef enum {
@@ -307,6 +307,25 @@ int dq_apply_fused_grad_c64(const void* in, void* out, const void* mats, int64_t
                             int64_t batch, const DqFusedPass* pass, double* grads, int64_t ngrads, dq_stream_t stream);
 int dq_apply_fused_grad_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n,
                              int64_t batch, const DqFusedPass* pass, double* grads, int64_t ngrads, dq_stream_t stream);
+
+/* ABI 24: a pass with more records than the kernel-argument segment holds (112: gates and reductions, two or four per
+ * layout change).  A reverse sweep has a reduction in front of every trainable gate, and what bounded its passes was
+ * the NUMBER of records, not the tile: the 28-qubit training step takes 23 passes of up to 104 instead of 32 of up to 72.
+ * The kernel reads such a pass's records from DEVICE memory:
+ *   dq_wave_records   (host, no GPU needed) writes the records of `pass` as the kernel reads them -- 32 bytes each -- to
+ *                     the HOST buffer `out` (at most max_bytes; out = NULL: none) and returns their size in bytes, or a
+ *                     negative DqStatus;
+ *   dq_apply_fused_grad_ext_*   run the pass with those records at the DEVICE address `records` (the caller copied them
+ *                     there; `records_bytes` must be what dq_wave_records returned for this pass and n).  They must stay
+ *                     valid until the pass has run -- captured in a HIP graph: until its last replay.
+ * Everything else as dq_apply_fused_grad_*. */
+int64_t dq_wave_records(const DqFusedPass* pass, int n, void* out, int64_t max_bytes);
+int dq_apply_fused_grad_ext_c64(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n, int64_t batch,
+                                const DqFusedPass* pass, const void* records, int64_t records_bytes, double* grads,
+                                int64_t ngrads, dq_stream_t stream);
+int dq_apply_fused_grad_ext_c128(const void* in, void* out, const void* mats, int64_t mat_batch_stride, int n, int64_t batch,
+                                 const DqFusedPass* pass, const void* records, int64_t records_bytes, double* grads,
+                                 int64_t ngrads, dq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Reductions.  Results are written to DEVICE memory in double precision.

@@ -49,7 +49,7 @@ class WaveKernPass(C.Structure):
     _fields_ = [('load_off', C.c_uint64 * 5), ('store_off', C.c_uint64 * 5), ('load_lane_shift', C.c_uint32 * 6),
                 ('store_lane_shift', C.c_uint32 * 6), ('tb_contrib', C.c_uint32 * 6), ('nrec_bytes', C.c_uint32),
                 ('mat_base_bytes', C.c_uint32), ('read_blk_pos', C.c_uint8 * 24), ('store_blk_pos', C.c_uint8 * 24),
-                ('zext', C.c_uint32), ('reserved', C.c_uint32 * 7), ('rec', (C.c_uint32 * 8) * 112)]
+                ('zext', C.c_uint32), ('reserved', C.c_uint32 * 7), ('rec', (C.c_uint32 * 8) * 256)]     # (WAVE_EXT_REC: the test hook's cap)
 
 
 def descriptor(desc, n, known_zero: int = 0) -> WaveKernPass:

@@ -165,6 +165,72 @@ def test_reduction_records_of_the_reverse_sweep_translate(cpu_backend, n, seed, 
     assert float(acc_d.abs().max()) > 0
 
 
+def long_sweep_ops(n, ngates, seed):
+    """A reverse sweep's gate list with a reduction in front of every dense one-target gate (bit 0 tells psi from lambda),
+    scheduled with the record cap of a sweep (executor.CONFIG['sweep_max_gates']): passes of more than 112 records."""
+    rng = random.Random(seed)
+    base_ops, base_mats = random_ops(n - 1, ngates, seed)
+    ops, mats, off, rows = [], [], 0, 0
+    for op in base_ops:
+        d = 1 << op.k
+        if op.kind == 'gen':
+            ctrl = tuple(c + 1 for c in rng.sample([c for c in range(n - 1) if c not in op.targets], rng.choice([0, 0, 0, 1])))
+            variant = {2: rng.choice([2, 4]), 1: 1}.get(op.mode, 0)
+            ops.append(fusion.PrimOp('grad', (op.targets[0] + 1, 0), ctrl, 0, rows | (variant << fusion.GRAD_VARIANT_SHIFT)))
+            rows += 1
+        ops.append(fusion.PrimOp(op.kind, tuple(t + 1 for t in op.targets), tuple(c + 1 for c in op.controls), off, op.mode))
+        mats.append(base_mats[op.mat:op.mat + d * d])
+        off += d * d
+    return ops, torch.cat(mats), rows
+
+
+def long_sweep_steps(ops, n, is128):
+    geom = fusion.default_geometry(is128)
+    geom.plan_min_bits = 11
+    geom.max_gates = 104
+    steps = fusion.schedule(ops, n, geom)
+    assert all(isinstance(s, fusion.FusedStep) for s in steps)
+    return steps
+
+
+@pytest.mark.parametrize('n,seed,is128,ngates', [(13, 0, False, 260), (14, 1, False, 260), (13, 2, True, 400), (14, 3, True, 400)])
+def test_sweep_passes_with_more_records_than_the_kernel_arguments_hold(cpu_backend, n, seed, is128, ngates):
+    """ABI 24: a pass of a reverse sweep may hold up to 104 gates + reductions; with its layout changes that is more than
+    the 112 records of the kernel-argument segment, and the kernel reads them from device memory (dq_wave_records /
+    dq_apply_fused_grad_ext_*).  Here: the records hook against the descriptor hook, the emulator (which executes the
+    records) against the descriptor interpreter (which does not know about records), states and sums."""
+    import ctypes as C
+
+    ops, mats, rows = long_sweep_ops(n, ngates, seed)
+    cdt = torch.complex128 if is128 else torch.complex64
+    mats = mats.to(cdt)
+    steps = long_sweep_steps(ops, n, is128)
+    lib = _lib.load()
+    sizes = []
+    for st in steps:
+        nb = lib.dq_wave_records(C.byref(st.desc), n, None, 0)
+        assert nb > 0 and nb % 32 == 0
+        buf = (C.c_uint8 * nb)()
+        assert lib.dq_wave_records(C.byref(st.desc), n, buf, nb) == nb
+        kp = emu.descriptor(st.desc, n)
+        assert kp.nrec_bytes == nb and bytes(buf) == bytes(kp)[emu.WaveKernPass.rec.offset:emu.WaveKernPass.rec.offset + nb]
+        sizes.append(nb // 32)
+    assert max(sizes) > backend.KERNARG_RECORDS, sizes
+    km = fusion.kernel_matrices(steps, ops, mats)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 1 << n, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 1 << n, generator=g, dtype=torch.float64)
+    x = (x / x.norm(dim=-1, keepdim=True)).to(cdt)
+    acc_d = torch.zeros(2, rows, 8, dtype=torch.float64)
+    acc_e = np.zeros((2, rows, 8))
+    cur_d, cur_e = x.clone(), x.numpy().copy()
+    for st in steps:
+        backend.apply_fused(cur_d, km, 0, st.desc, out=cur_d, grads=acc_d)
+        cur_e = emu.run_pass(st.desc, n, cur_e, km.numpy(), 0, grads=acc_e)
+    assert np.abs(cur_e - cur_d.numpy()).max() < (1e-13 if is128 else 2e-6)
+    assert np.abs(acc_e - acc_d.numpy()).max() < (1e-12 if is128 else 2e-5) * max(1.0, float(acc_d.abs().max()))
+    assert float(acc_d.abs().max()) > 0
+
+
 @pytest.mark.parametrize('n,seed,is128', [(12, 0, False), (14, 1, False), (15, 2, False), (11, 3, True), (13, 4, True)])
 def test_z_string_expectations_from_the_registers(cpu_backend, n, seed, is128):
     """DQ_FG_EXPZ records: <Z..Z> of several strings reduced inside the last pass, descriptor interpreter and emulator

@@ -7,7 +7,7 @@ import torch
 
 from deepquantum_amd import backend, fusion
 
-from test_wave_cpu import random_ops, reference
+from test_wave_cpu import long_sweep_ops, long_sweep_steps, random_ops, reference
 
 pytestmark = pytest.mark.gpu
 TOL = {False: 1e-4, True: 1e-10}
@@ -179,3 +179,32 @@ def test_two_target_dense_gates_on_the_wave_tile_kernel_on_gpu(n, ngates, seed, 
         backend.apply_fused(cur, md, 0, st.desc, out=nxt)
         cur = nxt
     assert (cur.cpu() - ref).abs().max().item() < TOL[is128]
+
+
+@PREC
+@pytest.mark.parametrize('n,seed', [(13, 0), (14, 4), (15, 5)])
+def test_sweep_passes_with_their_records_in_device_memory_on_gpu(n, seed, is128):
+    """ABI 24 on the GPU: passes of a reverse sweep with more than 112 records (dq_apply_fused_grad_ext_*: the kernel reads
+    them from device memory) against the same passes on the descriptor interpreter -- states and the reductions' sums."""
+    from _cpu_backend import CpuTestBackend
+
+    ops, mats, rows = long_sweep_ops(n, 400, seed)
+    mats = mats.to(cdtype(is128))
+    steps = long_sweep_steps(ops, n, is128)
+    km = fusion.kernel_matrices(steps, ops, mats)
+    x = rand_state(2, n, seed, is128)
+    cur, acc = x.to(dev()), torch.zeros(2, rows, 8, dtype=torch.float64, device=dev())
+    md = km.to(dev())
+    ext = 0
+    for st in steps:
+        backend.apply_fused(cur, md, 0, st.desc, out=cur, grads=acc)
+        ext += any(t is not None for t in st.desc.__dict__.get('_dev_records', {}).values())
+    assert ext > 0, 'no pass took the device-memory records'
+    double = CpuTestBackend()
+    ref, racc = x.clone(), torch.zeros(2, rows, 8, dtype=torch.float64)
+    for st in steps:
+        double.apply_fused(ref, km, 0, st.desc, ref, grads=racc)
+    assert (cur.cpu() - ref).abs().max().item() < (1e-12 if is128 else 3e-6)
+    scale = max(1.0, float(racc.abs().max()))
+    assert (acc.cpu() - racc).abs().max().item() < (1e-11 if is128 else 3e-5) * scale
+    assert float(racc.abs().max()) > 0

@@ -24,6 +24,8 @@ args = ap.parse_args()
 dq.executor.CONFIG['fused_sweep'] = not args.no_fused_sweep
 if os.environ.get('DQ_REDUCED_GRAD') == '0':          # A/B: every reduction forms all of G
     dq.executor.CONFIG['reduced_grad_sums'] = False
+if os.environ.get('DQ_MAX_GATES'):                    # A/B: gates + reductions a pass may hold (72 in rounds 3-5)
+    dq.executor.CONFIG['max_gates'] = int(os.environ['DQ_MAX_GATES'])
 if os.environ.get('DQ_TERMINAL_GRAD') == '0':         # A/B: two sums per X rotation (round 4) instead of one
     dq.executor.CONFIG['terminal_grad_sums'] = False
 for mode in args.modes.split(','):
