@@ -118,8 +118,10 @@ def _sweep_fused_sharded(ctx, grad_out, params):
                 slots.append(len(todo))
                 # (a gate on two targets -- Rxx, Ryy, Rzz, Rxy of the reference's own test circuit, tests/test_circuit.py:
                 # 87-139 -- takes four one-target records: executor.grad_records)
+                # (only the sums the gate's derivative can read -- a real / a I + i b X / diagonal matrix has a derivative of
+                # the same form -- and ONE sum for a rotation about X: nothing differentiates these brackets again)
                 recs, cnt = executor.grad_records(ip.kind, ip.mode, tuple(t + 1 for t in ip.targets),
-                                                  tuple(c + 1 for c in ip.controls), nrows, reduced=False)
+                                                  tuple(c + 1 for c in ip.controls), nrows, terminal=ip.exact is True)
                 prims.extend(recs)
                 todo.append((gate, p, ip.matrix, nrows, ip.kind, len(ip.targets)))
                 nrows += cnt
