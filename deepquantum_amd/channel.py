@@ -48,6 +48,7 @@ class _OneParameter(Channel):
 class BitFlip(_OneParameter):
     r""":math:`\rho \to (1-p)\rho + p X\rho X` (reference: channel.py:16-55)."""
     _name = 'BitFlip'
+    _kernel_mode = 4      # I, X (Y, Z): diagonal or anti-diagonal Kraus operators -> a real X-shaped superoperator
 
     def get_matrix(self, theta: Any) -> torch.Tensor:
         p = self._prob(theta)
@@ -67,6 +68,7 @@ class PhaseFlip(_OneParameter):
 class Depolarizing(_OneParameter):
     r""":math:`\rho \to (1-p)\rho + \tfrac p3 (X\rho X + Y\rho Y + Z\rho Z)` (reference: channel.py:100-149)."""
     _name = 'Depolarizing'
+    _kernel_mode = 4      # I, X (Y, Z): diagonal or anti-diagonal Kraus operators -> a real X-shaped superoperator
 
     def get_matrix(self, theta: Any) -> torch.Tensor:
         p = self._prob(theta)
@@ -79,6 +81,7 @@ class AmplitudeDamping(_OneParameter):
     r""":math:`K_0 = \mathrm{diag}(1, \sqrt{1-p})`, :math:`K_1 = \sqrt p\,|0\rangle\langle 1|`
     (reference: channel.py:215-263)."""
     _name = 'AmplitudeDamping'
+    _kernel_mode = 4      # diag(1, .) and |0><1|: diagonal / anti-diagonal
 
     def get_matrix(self, theta: Any) -> torch.Tensor:
         p = self._prob(theta)
@@ -103,6 +106,7 @@ class PhaseDamping(_OneParameter):
 class Pauli(Channel):
     r""":math:`\rho \to p_i\rho + p_x X\rho X + p_y Y\rho Y + p_z Z\rho Z` with the four probabilities
     :math:`\sin^2\theta_j` normalised to one (reference: channel.py:152-212)."""
+    _kernel_mode = 4
 
     def __init__(self, inputs: Any = None, nqubit: int = 1, wires: int | list[int] | None = None,
                  tsr_mode: bool = False, requires_grad: bool = False) -> None:
@@ -138,6 +142,7 @@ class Pauli(Channel):
 class GeneralizedAmplitudeDamping(Channel):
     r"""Amplitude damping towards a thermal state: the first parameter gives the probability :math:`p` of the
     zero-temperature branch, the second the damping rate :math:`\gamma` (reference: channel.py:317-383)."""
+    _kernel_mode = 4      # four Kraus operators, each diagonal or anti-diagonal
 
     def __init__(self, inputs: Any = None, nqubit: int = 1, wires: int | list[int] | None = None,
                  tsr_mode: bool = False, requires_grad: bool = False) -> None:

@@ -878,7 +878,7 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots
-        g.loc = 1 if op.mode == 1 else 0      # promised real (and usually sparse): channel superoperators
+        g.loc = op.mode if op.mode in (1, 4) else 0      # promised real (4: and X-shaped, DQ_MODE_XREAL): channel superoperators
 
 
 def zero_state_masks(steps: Sequence, n: int, known_zero: int | None = None) -> list[int] | None:

@@ -353,11 +353,16 @@ class Channel(Operation):
     #: 'gen': dense real superoperator (the kernels skip its exact zeros); 'diag' for channels whose Kraus
     #: operators are all diagonal (phase flip, phase damping): a diagonal two-"qubit" gate, no tile constraint
     _kernel_kind = 'gen'
+    #: structure of the 4x4 superoperator promised by the class (include/dq_hip.h, DqFusedMode): 1 real; 4 real and X-shaped
+    #: -- every Kraus operator diagonal or anti-diagonal, so that K (x) conj(K) keeps or flips BOTH bits of the (row, column)
+    #: pair: a 2x2 block on (00, 11) and one on (01, 10).  The classes of channel.py say 4; a subclass with other Kraus
+    #: operators inherits 1
+    _kernel_mode = 1
 
     def dm_prims(self, decompose: bool = True) -> list[Prim]:
         bit = self.nqubit - 1 - self.wires[0]
         # every channel of channel.py has a REAL superoperator (K (x) conj(K) of Pauli / damping operators)
-        return [Prim(self._kernel_kind, self.superoperator(), (bit + self.nqubit, bit), (), 1, unitary=False)]
+        return [Prim(self._kernel_kind, self.superoperator(), (bit + self.nqubit, bit), (), self._kernel_mode, unitary=False)]
 
     def prims(self, decompose: bool = True) -> list[Prim]:
         raise NotImplementedError('a channel acts on density matrices only')

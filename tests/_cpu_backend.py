@@ -229,8 +229,11 @@ class CpuTestBackend:
                         b1, b2 = rb[g.q], rb[g.q2]
                         assert b1 != b2 and not (cm >> b1) & 1 and not (cm >> b2) & 1
                         mat = mb[g.mat : g.mat + 16].reshape(4, 4)
-                        if g.loc == 1:
+                        if g.loc in (1, 4):
                             assert np.all(mat.imag == 0), 'gate promised a real 4x4 matrix'
+                        if g.loc == 4:      # (DQ_MODE_XREAL: the entries off the two 2x2 blocks are never read)
+                            keep = np.array([[(i ^ j) in (0, 3) for j in range(4)] for i in range(4)])
+                            mat = np.where(keep, mat, 0)
                         e00 = e[el_ok & (((e >> b1) & 1) == 0) & (((e >> b2) & 1) == 0)]
                         es = [e00, e00 | (1 << b2), e00 | (1 << b1), e00 | (1 << b1) | (1 << b2)]
                         a = [t[:, q].copy() for q in es]

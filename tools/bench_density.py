@@ -17,7 +17,15 @@ ap.add_argument('--n', type=int, default=14)
 ap.add_argument('--depth', type=int, default=10)
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--p', type=float, default=0.05)
+ap.add_argument('--no-zero-state', action='store_true', help="every pass moves the whole matrix (as from any state but 'zeros')")
+ap.add_argument('--real-bodies', action='store_true', help='A/B: channel superoperators on the real 4x4 bodies of round 4 (not the X-shaped ones)')
 args = ap.parse_args()
+if args.no_zero_state:
+    dq.executor.CONFIG['zero_state'] = False
+if args.real_bodies:
+    from deepquantum_amd import channel
+    for cls in (channel.BitFlip, channel.Depolarizing, channel.AmplitudeDamping, channel.Pauli, channel.GeneralizedAmplitudeDamping):
+        cls._kernel_mode = 1
 
 n = args.n
 cir = dq.QubitCircuit(n, den_mat=True)
