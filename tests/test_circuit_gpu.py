@@ -487,6 +487,52 @@ def test_training_step_captured_after_eager_steps_on_the_default_stream(n):
         assert (p.grad - q.grad).abs().max().item() < 1e-4
 
 
+def test_captured_training_step_keeps_the_device_records_of_its_long_sweep_passes_alive():
+    """ABI 24 + HIP graphs: the reverse sweep of the reference's chart circuit (10 qubits x 6 layers: 180 reductions + 234
+    gates) has passes of more than 112 records, whose records live in device memory, copied there on the first (eager) run.
+    A captured graph has their addresses baked in: they must survive the plan that made them."""
+    import gc
+
+    n, layers = 10, 6
+    cir = dq.QubitCircuit(n)
+    for _ in range(layers):
+        for i in range(n - 1):
+            cir.cnot(i, i + 1)
+        cir.rxlayer(encode=True)
+        cir.rzlayer(encode=True)
+        cir.rxlayer(encode=True)
+    cir.observable(basis='x')
+    cir.to(dev())
+    params = torch.linspace(0.1, 2.9, 3 * n * layers, device=dev()).requires_grad_(True)
+
+    def step():
+        if params.grad is not None:
+            params.grad.zero_()
+        cir(data=params)
+        cir.expectation().backward()
+        return params.grad
+
+    # (no eager step on the default stream first: its AccumulateGrad node would live on into the capture -- see
+    # test_training_step_captured_after_eager_steps_on_the_default_stream; the graph's own warm-up copies the records)
+    before = len(dq.backend._CAPTURED_RECORDS)
+    graph = dq.CapturedGraph(step)
+    assert dq.executor.LAST_SWEEP['fused']
+    assert len(dq.backend._CAPTURED_RECORDS) > before, 'no pass of the captured sweep kept its records in device memory'
+    first = graph.replay().clone()
+    dq.executor._PLAN_CACHE.clear()         # the plans (and with them the descriptors' own references) go away ...
+    dq.executor._STEADY.clear()
+    gc.collect()
+    junk = [torch.full((1 << 20,), 7, dtype=torch.uint8, device=dev()) for _ in range(64)]      # ... and freed memory is reused
+    del junk
+    for _ in range(2):
+        got = graph.replay()
+        assert torch.equal(got, first)
+    got = got.clone()
+    params.grad = None
+    ref = step()                            # eager, after the graph: the same numbers
+    assert (got - ref).abs().max().item() < 1e-5 and float(ref.abs().max()) > 1e-3
+
+
 def test_edge_cases_on_gpu():
     from _helpers import check_edge_cases
 
