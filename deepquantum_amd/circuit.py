@@ -286,6 +286,21 @@ class QubitCircuit(Operation):
         # angle gradients in one kernel -- instead of a slice per layer and a slice per gate, whose backwards are a zero
         # fill, a copy and an add EACH (the reference's gradient benchmark at n = 8, 4 layers: 207 of a gradient's 365
         # launches).  Same views, same shapes, same values.
+        if data.requires_grad and torch.is_grad_enabled():
+            # The angles of the previous call are views into ITS autograd graph.  While one of them lives, so does the
+            # AccumulateGrad node of the caller's leaf -- and the new graph made below would reuse that node, stream and all:
+            # after eager steps on the default stream a capture of the step on another stream then dies in
+            # hipStreamEndCapture (PyTorch warns about the mismatch; tests/test_circuit_gpu.py).  Let go of them first.
+            for op in self.encoders:
+                for gate in (op.gates if isinstance(op, Layer) else (op,)):
+                    bufs = gate.__dict__.get('_buffers')
+                    if bufs:
+                        for name in getattr(gate, '_param_names', ()):
+                            t = bufs.get(name)
+                            if t is not None and t.grad_fn is not None:
+                                bufs[name] = t.detach()
+                                gate.__dict__['_matrix_key'] = None        # (it names the old tensors; `init_para` drops it anyway)
+                            t = None                                        # (this frame must not be the last holder either)
         cols = data.unbind(-1) if (data.requires_grad and torch.is_grad_enabled() and width > 1) else None
 
         def piece(src: torch.Tensor, a: int, b: int) -> torch.Tensor:      # src[..., a:b]

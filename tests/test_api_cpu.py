@@ -922,3 +922,32 @@ def test_torch_func_transforms_over_random_circuits(cpu_backend, seed):
         check_transforms_random(dq, n=n, seed=seed, ngates=24 + 6 * seed, dtype=torch.float64, tol=1e-10)
     finally:
         executor.CONFIG['permute_min_bits'] = old
+
+
+def test_a_new_forward_lets_go_of_the_previous_autograd_graph_first(cpu_backend):
+    """The encoders hold views of the caller's data; while one of the previous call's views lives, the leaf's AccumulateGrad
+    node does too and the next graph reuses it -- created on whatever stream the FIRST step ran on.  After eager steps on the
+    default stream, capturing the step in a HIP graph on a side stream then dies in hipStreamEndCapture
+    (tests/test_circuit_gpu.py::test_captured_training_step_...).  Here, without a GPU: every step gets a fresh node."""
+    cir = dq.QubitCircuit(4)
+    for _ in range(2):
+        cir.cnot_ring()
+        cir.rxlayer(encode=True)
+        cir.u3(1, encode=True)
+        cir.rzlayer(encode=True)
+    cir.observable(basis='x')
+    params = torch.linspace(0.1, 2.9, cir.ndata).requires_grad_(True)
+
+    def accumulator():
+        return params.view_as(params).grad_fn.next_functions[0][0]
+
+    for it in range(3):
+        if params.grad is not None:
+            params.grad.zero_()
+        cir(data=params)
+        cir.expectation().backward()
+        node = accumulator()
+        assert 'seen' not in node.metadata, f'step {it} reused the AccumulateGrad node of the step before'
+        node.metadata['seen'] = True
+        del node
+    assert params.grad.abs().max().item() > 0

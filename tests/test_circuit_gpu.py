@@ -512,8 +512,12 @@ def test_captured_training_step_keeps_the_device_records_of_its_long_sweep_passe
         cir.expectation().backward()
         return params.grad
 
-    # (no eager step on the default stream first: its AccumulateGrad node would live on into the capture -- see
-    # test_training_step_captured_after_eager_steps_on_the_default_stream; the graph's own warm-up copies the records)
+    # eager steps on the default stream first, as a user would: the encoders let go of the previous call's angles before a
+    # new graph is made, so that no AccumulateGrad node of the leaf lives on into the capture
+    # (test_training_step_captured_after_eager_steps_on_the_default_stream has the same story for trainable gates)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
     before = len(dq.backend._CAPTURED_RECORDS)
     graph = dq.CapturedGraph(step)
     assert dq.executor.LAST_SWEEP['fused']
