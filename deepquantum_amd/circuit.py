@@ -286,7 +286,7 @@ class QubitCircuit(Operation):
         # angle gradients in one kernel -- instead of a slice per layer and a slice per gate, whose backwards are a zero
         # fill, a copy and an add EACH (the reference's gradient benchmark at n = 8, 4 layers: 207 of a gradient's 365
         # launches).  Same views, same shapes, same values.
-        if data.requires_grad and torch.is_grad_enabled():
+        if data.requires_grad and torch.is_grad_enabled() and not torch._C._functorch.is_functorch_wrapped_tensor(data):
             # The angles of the previous call are views into ITS autograd graph.  While one of them lives, so does the
             # AccumulateGrad node of the caller's leaf -- and the new graph made below would reuse that node, stream and all:
             # after eager steps on the default stream a capture of the step on another stream then dies in
@@ -297,7 +297,8 @@ class QubitCircuit(Operation):
                     if bufs:
                         for name in getattr(gate, '_param_names', ()):
                             t = bufs.get(name)
-                            if t is not None and t.grad_fn is not None:
+                            # (plain autograd only: a wrapper that a torch.func transform left behind is not touched)
+                            if t is not None and not torch._C._functorch.is_functorch_wrapped_tensor(t) and t.grad_fn is not None:
                                 bufs[name] = t.detach()
                                 gate.__dict__['_matrix_key'] = None        # (it names the old tensors; `init_para` drops it anyway)
                             t = None                                        # (this frame must not be the last holder either)
