@@ -20,6 +20,8 @@ bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
   echo '# A/B: every reduction record forms all of G (DQ_REDUCED_GRAD=0)'
   DQ_REDUCED_GRAD=0 python tools/bench_train.py --n 28 --depth 40 --modes adjoint 2>&1 | grep -v amdgpu.ids
   DQ_REDUCED_GRAD=0 python tools/bench_train.py --n 27 --depth 40 --modes adjoint --dtype c128 2>&1 | grep -v amdgpu.ids
+  echo '# A/B: the sweep of rounds 3-5a -- at most 72 gates + reductions per pass (DQ_MAX_GATES=72), two sums per X rotation (DQ_TERMINAL_GRAD=0)'
+  DQ_MAX_GATES=72 DQ_TERMINAL_GRAD=0 python tools/bench_train.py --n 28 --depth 40 --modes adjoint 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 28 --depth 40 --modes adjoint --no-fused-sweep 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 24 --depth 20 --modes adjoint --dtype c128 2>&1 | grep -v amdgpu.ids
   python tools/bench_train.py --n 24 --depth 20 --modes adjoint --dtype c128 --no-fused-sweep 2>&1 | grep -v amdgpu.ids
@@ -28,6 +30,9 @@ bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
   python tools/dump_sweep_passes.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_small.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_density.py 2>&1 | grep -v amdgpu.ids
+  echo '# ... from a state that is not |0><0| (every pass moves the whole matrix); then with the real 4x4 bodies of round 4 in place of the X-shaped ones'
+  python tools/bench_density.py --no-zero-state 2>&1 | grep -v amdgpu.ids
+  python tools/bench_density.py --no-zero-state --real-bodies 2>&1 | grep -v amdgpu.ids
   python tools/bench_expect.py 2>&1 | grep -v amdgpu.ids
   python tools/bench_config2.py --cpu 2>&1 | grep -v amdgpu.ids
   python tools/bench_single_gate_kernel.py 2>&1 | grep -v amdgpu.ids
@@ -50,6 +55,7 @@ bash tools/mb_counters.sh > "$root/microbench.txt" 2>&1
   for r in 0 1; do python bench.py --gpus 4 --config 4 --rehearse-rank $r --virtual-bits 0 --steps 5 --warmup 1 2>/dev/null | grep '^{'; done
 } > "$root/strong_rehearsal.txt" 2>&1
 python tools/bench_vmap.py 20 16 2>&1 | grep -v amdgpu.ids > "$root/bench_vmap.txt"
+python tools/bench_vmap.py 16 8 hessian 2>&1 | grep -v amdgpu.ids > "$root/bench_vmap_hessian_n16.txt"
 python tools/bench_dense.py 2>&1 | grep -v amdgpu.ids > "$root/bench_dense.txt"
 python tools/dump_passes.py 2>&1 | grep -v amdgpu.ids > "$root/passes_headline.txt"
 python tools/bench_gradient_reference.py --trials 3 2>&1 | grep -v "amdgpu.ids\|UserWarning\|run_backward" > "$root/bench_gradient_reference.txt"
