@@ -199,7 +199,7 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
                 }
                 continue;
             }
-            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 3) || (g.kind == DQ_FG_GEN2 && g.loc > 1 && g.loc != DQ_MODE_XREAL)) ||
+            if (g.kind > DQ_FG_DIAG2 || (slot_kind && g.q >= slots) || ((g.kind == DQ_FG_GEN1 && g.loc > 3) || (g.kind == DQ_FG_GEN2 && g.loc > 1 && g.loc != DQ_MODE_XREAL && g.loc != DQ_MODE_XCPLX)) ||
                 (g.kind == DQ_FG_GEN2 && (g.q2 >= slots || g.q2 == g.q)) || (g.reg_cmask >> slots)) {
                 set_error("dq_apply_fused: gate %d malformed", gi);
                 return DQ_ERR_ARG;

@@ -47,7 +47,7 @@ struct WaveC64 {
     static constexpr unsigned LDS_PER_WAVE = 8448;      // (15 * 66 + 64) * 8 bytes: the k = 4 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID_GEN_U, ID_GEN_C = DQ_WID_GEN_C, ID_GEN_R = DQ_WID_GEN_R, ID_X_U = DQ_WID_X_U,
                          ID_X_C = DQ_WID_X_C, ID_X_R = DQ_WID_X_R, ID_X_R1 = DQ_WID_X_R1, ID_TRIP0 = DQ_WID_TRIP0,
-                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2, ID_GRAD = DQ_WID_GRAD, ID_EXPZ = DQ_WID_EXPZ, ID_GEN2 = DQ_WID_GEN2, ID_GEN2R = DQ_WID_GEN2R, ID_GEN2X = DQ_WID_GEN2X, ID_SWAP = DQ_WID_SWAP;
+                         ID_DIAG1 = DQ_WID_DIAG1, ID_DIAG2 = DQ_WID_DIAG2, ID_GRAD = DQ_WID_GRAD, ID_EXPZ = DQ_WID_EXPZ, ID_GEN2 = DQ_WID_GEN2, ID_GEN2R = DQ_WID_GEN2R, ID_GEN2X = DQ_WID_GEN2X, ID_GEN2XC = DQ_WID_GEN2XC, ID_SWAP = DQ_WID_SWAP;
     static int trip_id(unsigned mask) { return kWaveTripId[mask]; }
     static int swap_id(int i, int j) { return kWaveSwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -62,7 +62,7 @@ struct WaveC128 {
     static constexpr unsigned LDS_PER_WAVE = 8704;      // (7 * 68 + 64) * 16 bytes: the k = 3 sub-tile buffer
     static constexpr int ID_GEN_U = DQ_WID64_GEN_U, ID_GEN_C = DQ_WID64_GEN_C, ID_GEN_R = DQ_WID64_GEN_R, ID_X_U = DQ_WID64_X_U,
                          ID_X_C = DQ_WID64_X_C, ID_X_R = DQ_WID64_X_R, ID_X_R1 = DQ_WID64_X_R1, ID_TRIP0 = DQ_WID64_TRIP0,
-                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD, ID_EXPZ = DQ_WID64_EXPZ, ID_GEN2 = DQ_WID64_GEN2, ID_GEN2R = DQ_WID64_GEN2R, ID_GEN2X = -1, ID_SWAP = DQ_WID64_SWAP;      // (two-target dense gates: the 64 dwords of matrix pass through the scalar registers two rows at a time)
+                         ID_DIAG1 = DQ_WID64_DIAG1, ID_DIAG2 = DQ_WID64_DIAG2, ID_GRAD = DQ_WID64_GRAD, ID_EXPZ = DQ_WID64_EXPZ, ID_GEN2 = DQ_WID64_GEN2, ID_GEN2R = DQ_WID64_GEN2R, ID_GEN2X = -1, ID_GEN2XC = -1, ID_SWAP = DQ_WID64_SWAP;      // (two-target dense gates: the 64 dwords of matrix pass through the scalar registers two rows at a time)
     static int trip_id(unsigned mask) { return kWave64TripId[mask]; }
     static int swap_id(int i, int j) { return kWave64SwapId[i][j]; }
     __device__ static __forceinline__ void body(uint64_t kg, uint32_t gend, uint64_t mb, uint32_t moff, uint64_t tg, uint64_t ks,
@@ -418,7 +418,9 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k, uint64_t
                 // operation per entry instead of two)
                 // loc = DQ_MODE_XREAL: real AND non-zero only on the two 2x2 blocks (00, 11) / (01, 10) -- the superoperators of
                 // the reference's channels: half the operations again (complex64; complex128 takes the real bodies)
-                const int body = g.loc == DQ_MODE_XREAL && W::ID_GEN2X >= 0 ? W::ID_GEN2X
+                // loc = DQ_MODE_XCPLX: the same shape with complex entries (Rxx, Ryy, Rxy): complex64 bodies of their own
+                const int body = g.loc == DQ_MODE_XCPLX && W::ID_GEN2XC >= 0 ? W::ID_GEN2XC
+                                 : g.loc == DQ_MODE_XREAL && W::ID_GEN2X >= 0 ? W::ID_GEN2X
                                  : (g.loc == DQ_MODE_REAL || g.loc == DQ_MODE_XREAL) && W::ID_GEN2R >= 0 ? W::ID_GEN2R : W::ID_GEN2;
                 rec.w[0] = (uint32_t)(body + (W::swap_id(a, b) - W::ID_SWAP));
                 rec.w[1] = g.thr_cmask;

@@ -878,7 +878,8 @@ def _encode_gate(g: _lib.DqFusedGate, op: PrimOp, local: dict[int, int], slot_of
     else:
         g.kind = _lib.FG_GEN2
         g.q, g.q2 = slots
-        g.loc = op.mode if op.mode in (1, 4) else 0      # promised real (4: and X-shaped, DQ_MODE_XREAL): channel superoperators
+        # promised real (1; 4: and X-shaped, DQ_MODE_XREAL): channel superoperators; 5: X-shaped with complex entries (Rxx ...)
+        g.loc = op.mode if op.mode in (1, 4, 5) else 0
 
 
 def zero_state_masks(steps: Sequence, n: int, known_zero: int | None = None) -> list[int] | None:

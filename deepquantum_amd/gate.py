@@ -610,7 +610,7 @@ class ImaginarySwap(DoubleGate):
         self.register_buffer('matrix', torch.tensor([[1, 0, 0, 0], [0, 0, 1j, 0], [0, 1j, 0, 0], [0, 0, 0, 1]]))
 
 
-def _param_double(cls_name: str, gate_name: str, builder, kind: str = 'gen', doc: str = ''):
+def _param_double(cls_name: str, gate_name: str, builder, kind: str = 'gen', doc: str = '', mode2: int = 0):
     def __init__(self, inputs=None, nqubit=2, wires=None, controls=None, condition=False, den_mat=False,
                  tsr_mode=False, requires_grad=False):
         ParametricDoubleGate.__init__(self, name=gate_name, inputs=inputs, nqubit=nqubit, wires=wires,
@@ -621,7 +621,7 @@ def _param_double(cls_name: str, gate_name: str, builder, kind: str = 'gen', doc
         return builder(_prep(self.inputs_to_tensor(theta)))
 
     return type(cls_name, (ParametricDoubleGate,),
-                {'__init__': __init__, 'get_matrix': get_matrix, '_kernel_kind': kind, '__doc__': doc})
+                {'__init__': __init__, 'get_matrix': get_matrix, '_kernel_kind': kind, '_kernel_mode2': mode2, '__doc__': doc})
 
 
 def _antidiag(entries: list[torch.Tensor]) -> torch.Tensor:
@@ -667,13 +667,15 @@ def _rbs(theta):
     return _embed_middle(_mat([cos, sin, -sin, cos], 2) + 0j, theta)
 
 
-Rxx = _param_double('Rxx', 'Rxx', _rxx, doc='exp(-i theta XX / 2) (reference: gate.py:2085-2155, matrix :2139-2146).')
-Ryy = _param_double('Ryy', 'Ryy', _ryy, doc='exp(-i theta YY / 2) (reference: gate.py:2158-2238, matrix :2212-2219).')
+# (mode2: the structure of the 4x4 matrix the class promises -- include/dq_hip.h, DQ_MODE_XCPLX = 5: non-zero only on the
+# blocks (00, 11) and (01, 10); DQ_MODE_XREAL = 4: and real)
+Rxx = _param_double('Rxx', 'Rxx', _rxx, mode2=5, doc='exp(-i theta XX / 2) (reference: gate.py:2085-2155, matrix :2139-2146).')
+Ryy = _param_double('Ryy', 'Ryy', _ryy, mode2=5, doc='exp(-i theta YY / 2) (reference: gate.py:2158-2238, matrix :2212-2219).')
 Rzz = _param_double('Rzz', 'Rzz', _rzz, kind='diag',
                     doc='exp(-i theta ZZ / 2) (reference: gate.py:2241-2309, matrix :2295-2300).')
-Rxy = _param_double('Rxy', 'Rxy', _rxy, doc='exp(-i theta (XX+YY) / 4) (reference: gate.py:2312-2390, :2366-2373).')
+Rxy = _param_double('Rxy', 'Rxy', _rxy, mode2=5, doc='exp(-i theta (XX+YY) / 4) (reference: gate.py:2312-2390, :2366-2373).')
 ReconfigurableBeamSplitter = _param_double(
-    'ReconfigurableBeamSplitter', 'ReconfigurableBeamSplitter', _rbs,
+    'ReconfigurableBeamSplitter', 'ReconfigurableBeamSplitter', _rbs, mode2=4,
     doc='RBS gate (reference: gate.py:2393-2479, matrix :2455-2462).')
 
 

@@ -134,6 +134,8 @@ class Gate(Operation):
     _kernel_kind = 'gen'
     #: structure of a 2x2 matrix known from the class: 0 general, 1 all real, 2 real diag + imaginary off-diag
     _kernel_mode = 0
+    #: structure of a 4x4 matrix known from the class (gates on two wires): 0 general, 4 / 5 X-shaped real / complex
+    _kernel_mode2 = 0
 
     def __init__(
         self,
@@ -201,7 +203,7 @@ class Gate(Operation):
         if (c is not None and ver is not None and c[0] is m and c[5] == ver and c[1] == self.wires
                 and c[2] == self.controls and c[3] == self.nqubit):
             return c[4]
-        mode = self._kernel_mode if len(self.wires) == 1 else 0
+        mode = self._kernel_mode if len(self.wires) == 1 else (self._kernel_mode2 if len(self.wires) == 2 else 0)
         out = [Prim(self._kernel_kind, m, self._bits(self.wires), self._bits(self.controls), mode,
                     exact=getattr(self, '_exact_unitary', True))]
         # (not a matrix that carries an autograd graph: it is a new object every forward, and keeping it would keep its graph

@@ -142,11 +142,14 @@ typedef enum {
                          multiplies the pass's deferred scalar by f (fusion.defer_rx builds the block) */
     DQ_MODE_HAD = 3,  /* s * [[1, 1], [1, -1]], s real: Hadamard.  The kernel takes sums and differences and
                          applies the product of the factors s of a pass once, at its end */
-    DQ_MODE_XREAL = 4 /* GEN2 only (ABI 24): a REAL 4x4 matrix that is non-zero only where the parities of the row and
+    DQ_MODE_XREAL = 4, /* GEN2 only (ABI 24): a REAL 4x4 matrix that is non-zero only where the parities of the row and
                          the column index agree -- a 2x2 block on (00, 11) and one on (01, 10).  The superoperator
                          sum K (x) conj(K) of every non-diagonal channel of channel.py:16-383 (bit flip, bit-phase flip,
                          depolarizing, Pauli, amplitude damping, generalized amplitude damping) on the (row, column) bit
                          pair of its wire.  The other entries are never read */
+    DQ_MODE_XCPLX = 5 /* GEN2 only (ABI 24): the same shape -- a 2x2 block on (00, 11), one on (01, 10) -- with COMPLEX
+                         entries: exp(-i theta XX / 2), exp(-i theta YY / 2), exp(-i theta (XX + YY) / 4)
+                         (gate.py:2085-2390) and their controlled forms */
 } DqFusedMode;
 
 typedef struct {

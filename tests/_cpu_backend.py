@@ -231,7 +231,7 @@ class CpuTestBackend:
                         mat = mb[g.mat : g.mat + 16].reshape(4, 4)
                         if g.loc in (1, 4):
                             assert np.all(mat.imag == 0), 'gate promised a real 4x4 matrix'
-                        if g.loc == 4:      # (DQ_MODE_XREAL: the entries off the two 2x2 blocks are never read)
+                        if g.loc in (4, 5):      # (DQ_MODE_XREAL / _XCPLX: the entries off the two 2x2 blocks are never read)
                             keep = np.array([[(i ^ j) in (0, 3) for j in range(4)] for i in range(4)])
                             mat = np.where(keep, mat, 0)
                         e00 = e[el_ok & (((e >> b1) & 1) == 0) & (((e >> b2) & 1) == 0)]

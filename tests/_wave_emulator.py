@@ -224,16 +224,16 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None, known_zero: int
                     continue
                 if not tile_ok:
                     continue
-                if getattr(g, 'ID_GEN2', 1 << 30) <= hid < getattr(g, 'ID_GEN2', 1 << 30) + len(g.SWAP_PAIRS) * (3 if hasattr(g, 'ID_GEN2X') else 2 if hasattr(g, 'ID_GEN2R') else 1):
+                if getattr(g, 'ID_GEN2', 1 << 30) <= hid < getattr(g, 'ID_GEN2', 1 << 30) + len(g.SWAP_PAIRS) * (4 if hasattr(g, 'ID_GEN2XC') else 3 if hasattr(g, 'ID_GEN2X') else 2 if hasattr(g, 'ID_GEN2R') else 1):
                     # dense gate on two slots a < b (gen2_code): matrix index = 2 * bit(b) + bit(a), w6 = swap the two
                     # index bits of the matrix first, w5 = group mask; the second range of ids: the bodies for a matrix
                     # promised real (gen2_body_real: the imaginary parts are never read)
                     real_body, pair = divmod(hid - g.ID_GEN2, len(g.SWAP_PAIRS))
                     a_, b_ = g.SWAP_PAIRS[pair]
                     m4 = mb[moff - 16:moff].reshape(4, 4)
-                    if real_body:
+                    if real_body in (1, 2):
                         m4 = m4.real.astype(m4.dtype)
-                    if real_body == 2:       # gen2_body_xreal: only the blocks (00, 11) and (01, 10) are read
+                    if real_body in (2, 3):       # gen2_body_xreal: only the blocks (00, 11) and (01, 10) are read
                         m4 = np.where(np.array([[(i ^ j) in (0, 3) for j in range(4)] for i in range(4)]), m4, 0).astype(m4.dtype)
                     if w[6]:
                         perm = [0, 2, 1, 3]

@@ -951,3 +951,32 @@ def test_a_new_forward_lets_go_of_the_previous_autograd_graph_first(cpu_backend)
         node.metadata['seen'] = True
         del node
     assert params.grad.abs().max().item() > 0
+
+
+def test_structure_promises_of_two_wire_gates_and_channels_hold(cpu_backend):
+    """DQ_MODE_XREAL / DQ_MODE_XCPLX are promises of a CLASS (the kernels never look at values): every gate and channel that
+    makes one has a matrix that is non-zero only on the blocks (00, 11) and (01, 10) -- and real where it says so -- for any
+    angle, inverted, batched, and as the row / column pair of a density matrix."""
+    from deepquantum_amd import channel
+
+    keep = torch.tensor([[(i ^ j) in (0, 3) for j in range(4)] for i in range(4)])
+    g = torch.Generator().manual_seed(0)
+    seen = 0
+    for cls in (dq.Rxx, dq.Ryy, dq.Rxy, dq.ReconfigurableBeamSplitter):
+        assert cls._kernel_mode2 in (4, 5)
+        for gate in (cls(float(torch.rand(1, generator=g) * 6), nqubit=3, wires=[0, 2]),
+                     cls(float(torch.rand(1, generator=g) * 6), nqubit=3, wires=[2, 1], controls=[0]).inverse()):
+            for prims in (gate.prims(), gate.dm_prims()):
+                for p in prims:
+                    assert p.kind == 'gen' and p.mode == cls._kernel_mode2 and len(p.targets) == 2
+                    m = p.matrix.reshape(-1, 4, 4)
+                    assert float(m[:, ~keep].abs().max()) == 0.0, cls.__name__
+                    assert cls._kernel_mode2 == 5 or float(m.imag.abs().max()) == 0.0, cls.__name__
+                    seen += 1
+    for cls, inp in ((channel.BitFlip, 0.3), (channel.Depolarizing, 0.4), (channel.AmplitudeDamping, 0.5),
+                     (channel.Pauli, [0.3, 0.5, 0.7, 0.9]), (channel.GeneralizedAmplitudeDamping, [0.3, 0.6])):
+        (p,) = cls(inp, nqubit=2, wires=[1]).dm_prims()
+        m = p.matrix.reshape(4, 4)
+        assert p.mode == 4 and float(m[~keep].abs().max()) == 0.0 and float(m.imag.abs().max()) == 0.0, cls.__name__
+        seen += 1
+    assert seen == 4 * 2 * 3 + 5

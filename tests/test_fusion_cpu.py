@@ -19,7 +19,7 @@ def random_ops(n, ngates, seed, kinds=('gen', 'x', 'diag', 'gen2', 'diag2', 'big
     ops, mats, off = [], [], 0
     for _ in range(ngates):
         kind = rng.choice(kinds)
-        k = {'gen': 1, 'x': 1, 'diag': 1, 'gen2': 2, 'gen2real': 2, 'gen2x': 2, 'diag2': 2, 'big': 3}[kind]
+        k = {'gen': 1, 'x': 1, 'diag': 1, 'gen2': 2, 'gen2real': 2, 'gen2x': 2, 'gen2xc': 2, 'diag2': 2, 'big': 3}[kind]
         nc = rng.choice([0, 0, 0, 1, 1, 2])
         bits = rng.sample(range(n), k + nc)
         d = 1 << k
@@ -34,11 +34,19 @@ def random_ops(n, ngates, seed, kinds=('gen', 'x', 'diag', 'gen2', 'diag2', 'big
             keep = torch.tensor([[(i ^ j) in (0, 3) for j in range(4)] for i in range(4)])
             m = torch.randn(d, d, generator=g, dtype=torch.float64) * keep
             m = (m / max(float(m.abs().sum(dim=1).max()), 1e-3)).to(torch.complex128)
+        elif kind == 'gen2xc':        # X-shaped with complex entries (mode 5, DQ_MODE_XCPLX): a unitary 2x2 on each block
+            m = torch.zeros(4, 4, dtype=torch.complex128)
+            for blk in ((0, 3), (1, 2)):
+                a = torch.randn(2, 2, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 2, generator=g, dtype=torch.float64)
+                q2, _ = torch.linalg.qr(a)
+                for i_ in range(2):
+                    for j_ in range(2):
+                        m[blk[i_], blk[j_]] = q2[i_, j_]
         else:
             a = torch.randn(d, d, generator=g, dtype=torch.float64) + 1j * torch.randn(d, d, generator=g, dtype=torch.float64)
             m, _ = torch.linalg.qr(a)
-        pk = {'gen': 'gen', 'x': 'x', 'diag': 'diag', 'gen2': 'gen', 'gen2real': 'gen', 'gen2x': 'gen', 'diag2': 'diag', 'big': 'gen'}[kind]
-        ops.append(fusion.PrimOp(pk, tuple(bits[:k]), tuple(bits[k:]), off, {'gen2real': 1, 'gen2x': 4}.get(kind, 0)))
+        pk = {'gen': 'gen', 'x': 'x', 'diag': 'diag', 'gen2': 'gen', 'gen2real': 'gen', 'gen2x': 'gen', 'gen2xc': 'gen', 'diag2': 'diag', 'big': 'gen'}[kind]
+        ops.append(fusion.PrimOp(pk, tuple(bits[:k]), tuple(bits[k:]), off, {'gen2real': 1, 'gen2x': 4, 'gen2xc': 5}.get(kind, 0)))
         mats.append(m.reshape(-1))
         off += d * d
     return ops, torch.cat(mats)

@@ -277,7 +277,7 @@ def test_two_target_dense_gates_on_the_wave_tile_kernel(cpu_backend, n, seed, is
     oracle."""
     from test_fusion_cpu import random_ops as mixed_ops, run_reference
 
-    ops, mats = mixed_ops(n, 60, seed, kinds=('gen', 'x', 'diag', 'gen2', 'gen2', 'gen2real', 'gen2x', 'gen2x', 'diag2'))
+    ops, mats = mixed_ops(n, 60, seed, kinds=('gen', 'x', 'diag', 'gen2', 'gen2', 'gen2real', 'gen2x', 'gen2x', 'gen2xc', 'gen2xc', 'diag2'))
     cd = torch.complex128 if is128 else torch.complex64
     mats = mats.to(cd)
     assert fusion.wave_supports(ops, is128) and any(op.kind == 'gen' and op.k == 2 for op in ops)
@@ -291,7 +291,7 @@ def test_two_target_dense_gates_on_the_wave_tile_kernel(cpu_backend, n, seed, is
     x = (x / x.norm(dim=-1, keepdim=True)).to(cd)
     ref = run_reference(x, ops, mats)
     cur_d, cur_e = x.clone(), x.numpy().copy()
-    ngen2 = nreal = nx = 0
+    ngen2 = nreal = nx = nxc = 0
     gm = emu.gen(is128)
     xid = getattr(gm, 'ID_GEN2X', None)      # (complex128 has no X-shaped bodies: such a matrix takes the real ones)
     for st in steps:
@@ -302,8 +302,10 @@ def test_two_target_dense_gates_on_the_wave_tile_kernel(cpu_backend, n, seed, is
         ngen2 += sum(gm.ID_GEN2 <= i_ < gm.ID_GEN2R for i_ in ids)
         nreal += sum(gm.ID_GEN2R <= i_ < gm.ID_GEN2R + len(gm.SWAP_PAIRS) for i_ in ids)
         nx += 0 if xid is None else sum(xid <= i_ < xid + len(gm.SWAP_PAIRS) for i_ in ids)
+        nxc += 0 if xid is None else sum(gm.ID_GEN2XC <= i_ < gm.ID_GEN2XC + len(gm.SWAP_PAIRS) for i_ in ids)
     count = lambda modes: sum(op.kind == 'gen' and op.k == 2 and op.mode in modes for op in ops)      # noqa: E731
-    assert ngen2 == count((0,))
+    assert ngen2 == (count((0,)) if xid is not None else count((0, 5)))
+    assert nxc == (count((5,)) if xid is not None else 0) and count((5,)) > 0
     assert nreal == (count((1,)) if xid is not None else count((1, 4))) > 0
     assert nx == (count((4,)) if xid is not None else 0) and count((4,)) > 0
     tol = 1e-12 if is128 else 1e-5

@@ -168,7 +168,7 @@ def test_two_target_dense_gates_on_the_wave_tile_kernel_on_gpu(n, ngates, seed, 
     oracle."""
     from test_fusion_cpu import random_ops as mixed_ops, run_reference
 
-    ops, mats = mixed_ops(n, ngates, seed, kinds=('gen', 'x', 'diag', 'gen2', 'gen2', 'gen2real', 'gen2x', 'gen2x', 'diag2'))
+    ops, mats = mixed_ops(n, ngates, seed, kinds=('gen', 'x', 'diag', 'gen2', 'gen2', 'gen2real', 'gen2x', 'gen2x', 'gen2xc', 'gen2xc', 'diag2'))
     mats = mats.to(cdtype(is128))
     steps = wave_steps(ops, n, permute=permute, is128=is128)
     x = rand_state(2, n, 50 + seed, is128)

@@ -216,7 +216,10 @@ ID_GEN2R = ID_GEN2 + 15
 # bit-phase flip, depolarizing, Pauli, amplitude damping, generalized amplitude damping) has such a superoperator on its
 # (row, column) bit pair: ten packed operations per register group instead of twenty
 ID_GEN2X = ID_GEN2R + 15
-NIDS = ID_GEN2X + 15
+# ... + 15: X-SHAPED, complex (DqFusedGate::loc = 5): the same two 2x2 blocks with complex entries -- exp(-i theta XX / 2),
+# exp(-i theta YY / 2), exp(-i theta (XX + YY) / 4) and their controlled forms: twenty operations per group instead of forty
+ID_GEN2XC = ID_GEN2X + 15
+NIDS = ID_GEN2XC + 15
 ACC_BASE = 4 * 8448       # LDS offset of the reduction accumulators: behind the four waves' staging buffers
 
 
@@ -522,6 +525,25 @@ def gen2_body_xreal(a, b):
     return out_
 
 
+def gen2_body_xcplx(a, b):
+    """`gen2_body` for an X-shaped matrix with complex entries: a complex 2x2 product on the registers (00, 11) and one on
+    (01, 10) per group -- sixteen packed operations and four moves."""
+    out_ = []
+    T = [T0, U0, T1, U1]
+    for i, j in enumerate(gen2_groups(a, b)):
+        rg = [A(j | (((r >> 1) & 1) << b) | ((r & 1) << a)) for r in range(4)]
+        m = lambda r, c: f's[{G2ROW[r] + 2 * c}:{G2ROW[r] + 2 * c + 1}]'      # noqa: E731
+        out_ += [f's_bitcmp1_b32 {STMP}, {i}', f's_cbranch_scc0 .Lg2c{a}{b}_{i}_%=']
+        first = {0: 0, 1: 1, 2: 1, 3: 0}       # output r reads the inputs r and 3 - r: the lower of the two first
+        out_ += [f'v_pk_mul_f32 {T[r]}, {rg[first[r]]}, {m(r, first[r])} {RE2}' for r in range(4)]
+        out_ += [f'v_pk_fma_f32 {T[r]}, {rg[first[r]]}, {m(r, first[r])}, {T[r]} {I3}' for r in range(4)]
+        out_ += [f'v_pk_fma_f32 {T[r]}, {rg[3 - first[r]]}, {m(r, 3 - first[r])}, {T[r]} {RE3}' for r in range(4)]
+        out_ += [f'v_pk_fma_f32 {T[r]}, {rg[3 - first[r]]}, {m(r, 3 - first[r])}, {T[r]} {I3}' for r in range(4)]
+        out_ += [f'v_mov_b64 {rg[r]}, {T[r]}' for r in range(4)]
+        out_.append(f'.Lg2c{a}{b}_{i}_%=:')
+    return out_
+
+
 def gen2_code():
     """Entry of every two-target dense record: controls; group mask -> STMP, first-target-on-the-lower-slot flag -> s70,
     pair number -> s71; rows 1 .. 3 of the 4x4 matrix (the look-ahead fetched row 0 as "the matrix") into s[40:47],
@@ -546,9 +568,9 @@ def gen2_code():
           's_add_u32 vcc_lo, vcc_lo, .Lg2table_%=-.Lg2anchor_%=', 's_addc_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc', '.Lg2table_%=:']
     # eight bytes per entry: s_getpc + 64-bit add + s_setpc would not fit four; a long jump is s_getpc_b64 / s_add / s_setpc:
     # instead every entry is an s_branch to a trampoline that sits right behind the table, within reach of nothing but it
-    for v in range(45):
+    for v in range(60):
         t += [f's_branch .Lg2t{v}_%=', 's_nop 0']
-    for v in range(45):
+    for v in range(60):
         t += [f'.Lg2t{v}_%=:', 's_getpc_b64 vcc', f'.Lg2ta{v}_%=:', f's_sub_u32 vcc_lo, vcc_lo, .Lg2ta{v}_%=-.Lg2b{v}_%=',
               's_subb_u32 vcc_hi, vcc_hi, 0', 's_setpc_b64 vcc']          # (the bodies lie in front of everything)
     return t
@@ -565,6 +587,9 @@ def gen2_bodies():
     for v, (a, b) in enumerate(SWAP_PAIRS):
         t += [f'.Lg2b{30 + v}_%=:'] + gen2_body_xreal(a, b) + [f's_mov_b64 exec, {SAVE}']
         t += prefetch(f'g2x{v}') + far_next()
+    for v, (a, b) in enumerate(SWAP_PAIRS):
+        t += [f'.Lg2b{45 + v}_%=:'] + gen2_body_xcplx(a, b) + [f's_mov_b64 exec, {SAVE}']
+        t += prefetch(f'g2c{v}') + far_next()
     return t
 
 
@@ -734,7 +759,7 @@ out = ['// GENERATED by tools/gen_wave_asm.py -- do not edit by hand.', '// clan
        f'#define DQ_WID_GEN_U {ID_GEN_U}', f'#define DQ_WID_GEN_C {ID_GEN_C}', f'#define DQ_WID_GEN_R {ID_GEN_R}',
        f'#define DQ_WID_X_U {ID_X_U}', f'#define DQ_WID_X_C {ID_X_C}', f'#define DQ_WID_X_R {ID_X_R}', f'#define DQ_WID_X_R1 {ID_X_R1}',
        f'#define DQ_WID_TRIP0 {ID_TRIP0}', f'#define DQ_WID_TRIP {ID_TRIP}', f'#define DQ_WID_SWAP {ID_SWAP}',
-       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WAVE_GRAD_VARIANTS {GRAD_VARIANTS}', f'#define DQ_WID_EXPZ {ID_EXPZ}', f'#define DQ_WID_GEN2 {ID_GEN2}', f'#define DQ_WID_GEN2R {ID_GEN2R}', f'#define DQ_WID_GEN2X {ID_GEN2X}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
+       f'#define DQ_WID_DIAG1 {ID_DIAG1}', f'#define DQ_WID_DIAG2 {ID_DIAG2}', f'#define DQ_WID_GRAD {ID_GRAD}', f'#define DQ_WAVE_GRAD_VARIANTS {GRAD_VARIANTS}', f'#define DQ_WID_EXPZ {ID_EXPZ}', f'#define DQ_WID_GEN2 {ID_GEN2}', f'#define DQ_WID_GEN2R {ID_GEN2R}', f'#define DQ_WID_GEN2X {ID_GEN2X}', f'#define DQ_WID_GEN2XC {ID_GEN2XC}', f'#define DQ_WAVE_ACC_BASE {ACC_BASE}',
        '// trip handler id by slot mask (popcount 1..DQ_WAVE_MAXK), -1 otherwise; slot-swap handler id by (i < j)',
        'static const short kWaveTripId[64] = {' + ', '.join(str(ID_TRIP + TRIP_MASKS.index(m)) if m in TRIP_MASKS else '-1' for m in range(64)) + '};',
        'static const short kWaveSwapId[6][6] = {' + ', '.join('{' + ', '.join(str(ID_SWAP + SWAP_PAIRS.index((min(i, j), max(i, j)))) if i != j else '-1' for j in range(R)) + '}' for i in range(R)) + '};',
