@@ -301,8 +301,9 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
         # (inside a torch.func transform -- vmap, grad, jacrev -- only the per-gate nodes compose)
         vmapped = ops._is_wrapped(state) or any(ops._is_wrapped(p.matrix) for p in prims)
         if CONFIG['grad_mode'] == 'adjoint' and not vmapped and all(p.unitary for p in prims):
-            meta = tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode, p.exact) for p in prims)
-            return _AdjointCircuit.apply(state, _Meta(meta, zero_state), *[p.matrix for p in prims])
+            meta = _Meta(((p.kind, tuple(p.targets), tuple(p.controls), p.mode, p.exact) for p in prims), zero_state)
+            meta.prims = prims          # (the node's forward runs these very primitives: not one more of each, `_AdjointCircuit.forward`)
+            return _AdjointCircuit.apply(state, meta, *[p.matrix for p in prims])
         if vmapped and CONFIG['grad_mode'] == 'adjoint' and CONFIG['fused_transforms'] and _fused_under_transforms(state, prims):
             # torch.vmap over the circuit -- the reference's own batching, circuit.py:232-240 -- and one level of
             # torch.func.grad / vjp / jacrev around it: ONE node with vmap rules of its own (the mapped dimension folds
@@ -1171,7 +1172,9 @@ class _AdjointCircuit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, state, meta, *mats):
-        prims = [Prim(k, m, t, c, mode) for (k, t, c, mode, _e), m in zip(meta, mats, strict=True)]
+        prims = meta.__dict__.pop('prims', None)       # (the caller's primitives, for this one use: the node must not hold them)
+        if prims is None or len(prims) != len(mats) or any(p.matrix is not m for p, m in zip(prims, mats)):
+            prims = [Prim(k, m, t, c, mode) for (k, t, c, mode, _e), m in zip(meta, mats, strict=True)]
         # the sweep recomputes from `out` gate by gate, so the forward itself may run the merged gate list
         if (CONFIG['merge_min_amps'] is not None and CONFIG['fuse'] and state.numel() >= CONFIG['merge_min_amps']):
             with torch.no_grad():

@@ -203,9 +203,14 @@ class Gate(Operation):
         if (c is not None and ver is not None and c[0] is m and c[5] == ver and c[1] == self.wires
                 and c[2] == self.controls and c[3] == self.nqubit):
             return c[4]
-        mode = self._kernel_mode if len(self.wires) == 1 else (self._kernel_mode2 if len(self.wires) == 2 else 0)
-        out = [Prim(self._kernel_kind, m, self._bits(self.wires), self._bits(self.controls), mode,
-                    exact=getattr(self, '_exact_unitary', True))]
+        # (what does not depend on the matrix -- bit positions, mode -- once per gate: a trainable gate gets a new matrix, and
+        # with it a new primitive, every forward)
+        st = d.get('_prim_struct')
+        if st is None or st[0] != self.wires or st[1] != self.controls or st[2] != self.nqubit or st[3] != self._kernel_kind:
+            mode = self._kernel_mode if len(self.wires) == 1 else (self._kernel_mode2 if len(self.wires) == 2 else 0)
+            st = d['_prim_struct'] = (list(self.wires), list(self.controls), self.nqubit, self._kernel_kind,
+                                      self._bits(self.wires), self._bits(self.controls), mode)
+        out = [Prim(st[3], m, st[4], st[5], st[6], exact=d.get('_exact_unitary', True))]
         # (not a matrix that carries an autograd graph: it is a new object every forward, and keeping it would keep its graph
         # -- with the AccumulateGrad nodes of the parameters and the stream they were made on -- alive until the next forward,
         # by which time the next graph has already picked the same nodes up: a training step captured into a HIP graph after
