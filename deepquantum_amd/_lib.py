@@ -25,7 +25,7 @@ LOC_REG, LOC_THR, LOC_OUT = range(3)
 FUSED_MAX_HIGH = 12
 FUSED_MAX_LOW = 8
 FUSED_MAX_ROUNDS = 24
-FUSED_MAX_GATES = 160
+FUSED_MAX_GATES = 128
 FUSED_MAX_SLOTS = 6
 FUSED_MAX_TBITS = 9
 FUSED_MAX_BLK = 24

@@ -403,7 +403,7 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k, uint64_t
         unsigned want = 0;
         for (int s = 0; s < W::R; ++s) want |= 1u << rd.rb[s];
         if (!x.go(want, nullptr)) goto fail;
-        for (int gi = rd.gate_begin & 0x7f; gi < rd.gate_end; ++gi) {
+        for (int gi = rd.gate_begin; gi < rd.gate_end; ++gi) {
             const DqFusedGate& g = p->gates[gi];
             if (g.kind == DQ_FG_GEN2 && W::ID_GEN2 >= 0) {
                 // dense gate on two slots: the handler of the slot pair a < b reads the matrix index as 2 * bit(b) + bit(a);

@@ -97,7 +97,7 @@ int dq_set_dense_path(int mfma);
 #define DQ_FUSED_MAX_HIGH 12
 #define DQ_FUSED_MAX_LOW 8      /* contiguous low tile bits: L <= 8 */
 #define DQ_FUSED_MAX_ROUNDS 24
-#define DQ_FUSED_MAX_GATES 160   /* (ABI <= 23: 80) */
+#define DQ_FUSED_MAX_GATES 128   /* (ABI <= 23: 80) */
 #define DQ_FUSED_MAX_SLOTS 6
 
 typedef enum {

@@ -123,7 +123,7 @@ def test_descriptor_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.DqFusedRound) == _lib.FUSED_MAX_SLOTS + _lib.FUSED_MAX_TBITS + 3
     # (a HOST struct, handed over by pointer; what travels in the 4 KiB kernel-argument segment is the kernel-side descriptor
     # of csrc/dq_wave.hip, and from ABI 24 on the records of a long pass lie in device memory)
-    assert ctypes.sizeof(_lib.DqFusedPass) <= 8192 and _lib.FUSED_MAX_GATES == 160
+    assert ctypes.sizeof(_lib.DqFusedPass) <= 8192 and _lib.FUSED_MAX_GATES == 128
 
 
 def test_x_type_gates_commute_in_the_dag():
