@@ -123,6 +123,8 @@ _SIGNATURES = {
     'dq_pack_{s}': (_i, [_vp, _vp, _i, _u64, _u64, _i64, _vp]),
     'dq_unpack_axpby_{s}': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _u64, _u64, _i64, _vp]),
     'dq_permute_bits_{s}': (_i, [_vp, _vp, _i, _ip, _i64, _vp]),
+    'dq_interleave_{s}': (_i, [_vp, _vp, _vp, _i64, _vp]),
+    'dq_deinterleave_{s}': (_i, [_vp, _vp, _i64, _i, _vp]),
 }
 
 

@@ -139,7 +139,7 @@ def _sweep_fused_sharded(ctx, grad_out, params):
     from .state import DistributedQubitState
 
     with torch.no_grad():
-        work = torch.stack([phi.amps.reshape(-1), lam.amps.reshape(-1)], dim=-1).reshape(-1)
+        work = backend.interleave(phi.amps.reshape(1, -1), lam.amps.reshape(1, -1)).reshape(-1)
         empty = work.new_zeros(0)
         phi.amps = phi.buffer = lam.amps = lam.buffer = empty        # (three states regardless of depth, not five)
         phi._shape = lam._shape = (0,)

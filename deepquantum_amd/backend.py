@@ -157,8 +157,20 @@ def apply_gate(
 #: records of a pass that travel in the kernel-argument segment (csrc/dq_wave.hip, WAVE_MAX_REC); a pass with more keeps them
 #: in device memory (include/dq_hip.h, dq_wave_records / dq_apply_fused_grad_ext_*)
 KERNARG_RECORDS = 112
-#: device copies of records that a HIP graph under capture has baked in: they must outlive the plan that made them
-_CAPTURED_RECORDS: list = []
+#: Device tensors that launches of a HIP graph UNDER CAPTURE read and that a plan or a cache owns -- the kernel matrix buffer
+#: of a circuit with fixed gates, the offsets of its deferred Rx blocks, the records of a long pass: the graph has their
+#: addresses baked in, so they must outlive the plan cache's evictions.  (What a capture allocates itself comes from the
+#: graph's own pool and lives with it.)  Never shrinks: a few KiB per captured circuit.
+_CAPTURE_PINS: dict = {}
+
+
+def pin_if_capturing(*tensors: torch.Tensor | None) -> None:
+    first = next((t for t in tensors if t is not None), None)
+    if first is None or not first.is_cuda or not torch.cuda.is_current_stream_capturing():
+        return
+    for t in tensors:
+        if t is not None:
+            _CAPTURE_PINS.setdefault(id(t), t)
 
 
 def _device_records(desc: _lib.DqFusedPass, n: int, device: torch.device) -> torch.Tensor | None:
@@ -187,8 +199,6 @@ def _device_records(desc: _lib.DqFusedPass, n: int, device: torch.device) -> tor
             assert got == nbytes
             hit = host.to(device)
         cache[key] = hit
-    if hit is not None and torch.cuda.is_current_stream_capturing() and not any(t is hit for t in _CAPTURED_RECORDS):
-        _CAPTURED_RECORDS.append(hit)
     return hit
 
 
@@ -231,6 +241,7 @@ def apply_fused(
             raise ValueError(f'reverse-sweep passes take at most {MAX_BATCH} samples')
         lib = _lib.load()
         rec = _device_records(desc, n, state.device)
+        pin_if_capturing(mats, rec)
         if rec is not None:       # more records than the kernel-argument segment holds: the kernel reads them from device memory
             fn = lib.dq_apply_fused_grad_ext_c128 if state.dtype == torch.complex128 else lib.dq_apply_fused_grad_ext_c64
             rc = fn(_ptr(state), _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0], C.byref(desc), _ptr(rec),
@@ -250,6 +261,7 @@ def apply_fused(
                         mat_batch_stride, desc, out[lo:hi], known_zero=known_zero)
         return out
     lib = _lib.load()
+    pin_if_capturing(mats)
     if known_zero:
         fn = lib.dq_apply_fused_zext_c128 if state.dtype == torch.complex128 else lib.dq_apply_fused_zext_c64
         rc = fn(_ptr(state), 0 if broadcast else 1 << n, _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0],
@@ -545,6 +557,7 @@ def defer_rx(flat: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
         return _test_backend.defer_rx(flat, index)
     assert flat.dtype == torch.complex64 and flat.ndim == 2 and flat.stride(1) == 1 and index.dtype == torch.long
     assert index.device == flat.device and index.is_contiguous()
+    pin_if_capturing(index)
     lib = _lib.load()
     for lo in range(0, flat.shape[0], MAX_BATCH):          # (the batch is a grid dimension)
         rows = flat[lo : lo + MAX_BATCH]
@@ -567,4 +580,34 @@ def permute_bits(amps: torch.Tensor, src_of_dst: Sequence[int], out: torch.Tenso
     lib = _lib.load()
     fn = getattr(lib, f'dq_permute_bits_{_suffix(amps)}')
     _lib.check(fn(_ptr(amps), _ptr(out), nl, _lib.int_array(src_of_dst), amps.shape[0], _stream(amps)), 'dq_permute_bits')
+    return out
+
+
+def interleave(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """(B, N), (B, N) -> (B, 2 N) with out[:, 2 i] = a[:, i], out[:, 2 i + 1] = b[:, i]: psi and the cotangent side by side
+    along a new index bit 0, as a fused reverse sweep wants them (include/dq_hip.h, dq_interleave_*).  On the test double
+    (CPU tensors): torch.stack."""
+    if a.shape != b.shape or a.dtype != b.dtype or a.device != b.device or a.ndim != 2:
+        raise ValueError('interleave: two (batch, N) tensors of one dtype on one device')
+    if not _use_hip(a) or (a.numel() & 1):
+        return torch.stack([a, b], dim=-1).reshape(a.shape[0], -1)
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty(a.shape[0], 2 * a.shape[1], dtype=a.dtype, device=a.device)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_interleave_{_suffix(a)}')
+    _lib.check(fn(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream(a)), 'dq_interleave')
+    return out
+
+
+def deinterleave(pair: torch.Tensor, which: int) -> torch.Tensor:
+    """(B, 2 N) -> (B, N): out[:, i] = pair[:, 2 i + which] (dq_deinterleave_*)."""
+    if pair.ndim != 2 or pair.shape[1] & 1 or which not in (0, 1):
+        raise ValueError('deinterleave: a (batch, 2 N) tensor, which = 0 or 1')
+    half = pair.shape[1] // 2
+    if not _use_hip(pair) or not pair.is_contiguous() or ((pair.shape[0] * half) & 1):
+        return pair.reshape(pair.shape[0], -1, 2)[:, :, which].contiguous()
+    out = torch.empty(pair.shape[0], half, dtype=pair.dtype, device=pair.device)
+    lib = _lib.load()
+    fn = getattr(lib, f'dq_deinterleave_{_suffix(pair)}')
+    _lib.check(fn(_ptr(pair), _ptr(out), out.numel(), int(which), _stream(pair)), 'dq_deinterleave')
     return out

@@ -314,7 +314,95 @@ static int unpack_impl(void* amps, const void* x, const void* y, const void* coe
     return check_launch("dq_unpack_axpby");
 }
 
+// ---- two states side by side along a NEW index bit 0: the (psi, lambda) pair of a fused reverse sweep -------------------
+// out[2 i] = a[i], out[2 i + 1] = b[i] (interleave) and back (which = 0 / 1 picks the half).  16-byte pieces in, 32-byte
+// pieces out per thread: every access a full, coalesced line -- torch.stack([a, b], dim=-1) of two 2-GiB states ran at
+// 1.75 TB/s (CatArrayBatchedCopy, 4.9 ms of the 71-ms training step at n = 28).
+template <typename T>
+__global__ __launch_bounds__(256) void interleave_kernel(const cx<T>* __restrict__ a, const cx<T>* __restrict__ b,
+                                                         cx<T>* __restrict__ out, uint64_t count) {
+    constexpr int V = 16 / sizeof(cx<T>);       // amplitudes per 16-byte piece: 2 (complex64) or 1 (complex128)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    const f4* pa = reinterpret_cast<const f4*>(a);
+    const f4* pb = reinterpret_cast<const f4*>(b);
+    f4* po = reinterpret_cast<f4*>(out);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count / V; i += stride) {
+        const f4 x = __builtin_nontemporal_load(pa + i), y = __builtin_nontemporal_load(pb + i);
+        if constexpr (V == 2) {
+            f4 lo, hi;
+            lo.x = x.x, lo.y = x.y, lo.z = y.x, lo.w = y.y;
+            hi.x = x.z, hi.y = x.w, hi.z = y.z, hi.w = y.w;
+            __builtin_nontemporal_store(lo, po + 2 * i);
+            __builtin_nontemporal_store(hi, po + 2 * i + 1);
+        } else {
+            __builtin_nontemporal_store(x, po + 2 * i);
+            __builtin_nontemporal_store(y, po + 2 * i + 1);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void deinterleave_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, uint64_t count,
+                                                           int which) {
+    constexpr int V = 16 / sizeof(cx<T>);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    const f4* pi = reinterpret_cast<const f4*>(in);
+    f4* po = reinterpret_cast<f4*>(out);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count / V; i += stride) {
+        if constexpr (V == 2) {
+            const f4 lo = __builtin_nontemporal_load(pi + 2 * i), hi = __builtin_nontemporal_load(pi + 2 * i + 1);
+            f4 r;
+            if (which) r.x = lo.z, r.y = lo.w, r.z = hi.z, r.w = hi.w;
+            else r.x = lo.x, r.y = lo.y, r.z = hi.x, r.w = hi.y;
+            __builtin_nontemporal_store(r, po + i);
+        } else {
+            __builtin_nontemporal_store(__builtin_nontemporal_load(pi + 2 * i + which), po + i);
+        }
+    }
+}
+
+template <typename T>
+static int interleave_impl(const void* a, const void* b, void* out, int64_t count, dq_stream_t stream) {
+    if (!a || !b || !out || count < 2 || (count & 1) || a == out || b == out) {
+        set_error("dq_interleave: bad argument (count = %lld amplitudes per input: even, >= 2; out of place)", (long long)count);
+        return DQ_ERR_ARG;
+    }
+    uint64_t nb = ((uint64_t)count / (16 / sizeof(cx<T>)) + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(interleave_kernel<T>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), static_cast<const cx<T>*>(a),
+                       static_cast<const cx<T>*>(b), static_cast<cx<T>*>(out), (uint64_t)count);
+    return check_launch("dq_interleave");
+}
+
+template <typename T>
+static int deinterleave_impl(const void* in, void* out, int64_t count, int which, dq_stream_t stream) {
+    if (!in || !out || count < 2 || (count & 1) || in == out || which < 0 || which > 1) {
+        set_error("dq_deinterleave: bad argument (count = %lld amplitudes per output: even, >= 2; which = %d)", (long long)count, which);
+        return DQ_ERR_ARG;
+    }
+    uint64_t nb = ((uint64_t)count / (16 / sizeof(cx<T>)) + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(deinterleave_kernel<T>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), static_cast<const cx<T>*>(in),
+                       static_cast<cx<T>*>(out), (uint64_t)count, which);
+    return check_launch("dq_deinterleave");
+}
+
 }  // namespace dq
+
+extern "C" int dq_interleave_c64(const void* a, const void* b, void* out, int64_t count, dq_stream_t stream) {
+    return dq::interleave_impl<float>(a, b, out, count, stream);
+}
+extern "C" int dq_interleave_c128(const void* a, const void* b, void* out, int64_t count, dq_stream_t stream) {
+    return dq::interleave_impl<double>(a, b, out, count, stream);
+}
+extern "C" int dq_deinterleave_c64(const void* in, void* out, int64_t count, int which, dq_stream_t stream) {
+    return dq::deinterleave_impl<float>(in, out, count, which, stream);
+}
+extern "C" int dq_deinterleave_c128(const void* in, void* out, int64_t count, int which, dq_stream_t stream) {
+    return dq::deinterleave_impl<double>(in, out, count, which, stream);
+}
 
 extern "C" int dq_pack_c64(const void* amps, void* packed, int nl, uint64_t mask, uint64_t value, int64_t batch,
                            dq_stream_t stream) {

@@ -1376,7 +1376,7 @@ class _AdjointCircuit(torch.autograd.Function):
         against gates that are unitary only to float32 rounding (``inexact``): those are undone with the exact inverse
         on both halves, and lambda -- the half with bit 0 set -- is multiplied by U^dagger U afterwards (``corr``, a
         gate controlled by bit 0): U^dagger lambda exactly, psi never drifts."""
-        work = torch.stack([out, gy.to(out.dtype)], dim=-1).reshape(b, -1)        # bit 0: psi | lambda
+        work = backend.interleave(out.reshape(b, -1), gy.to(out.dtype).reshape(b, -1))        # bit 0: psi | lambda
         pair = work.shape[-1]
         tile = 1 << _geometry(out.dtype == torch.complex128).m
         if pair < tile:                   # launch-bound sizes: |0..0> (x) the pair, the pad qubits are never touched
@@ -1463,6 +1463,7 @@ class _AdjointCircuit(torch.autograd.Function):
                 if plan._scale_cache is None:
                     plan._scale_cache = {}
                 plan._scale_cache[(key, work.device)] = before
+            backend.pin_if_capturing(before)
             s00 = torch.stack([undo[scalars[si]][b, 0, 0] for si in sorted(scalars)])      # s of every scalar gate
             logc = torch.log(2.0 * (s00.real * s00.real + s00.imag * s00.imag))
             g = g / torch.exp(before @ logc)[None, :, None, None]
@@ -1484,4 +1485,4 @@ class _AdjointCircuit(torch.autograd.Function):
         for j, r in rows.items():
             if j not in raw:
                 raw[j] = assemble_grad_sums(g, r, meta[j][0], len(meta[j][1]))
-        return raw, lambda: work[:, :pair].reshape(b, -1, 2)[:, :, 1].contiguous()
+        return raw, lambda: backend.deinterleave(work[:, :pair] if work.shape[1] != pair else work, 1)

@@ -518,10 +518,15 @@ def test_captured_training_step_keeps_the_device_records_of_its_long_sweep_passe
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    before = len(dq.backend._CAPTURED_RECORDS)
     graph = dq.CapturedGraph(step)
     assert dq.executor.LAST_SWEEP['fused']
-    assert len(dq.backend._CAPTURED_RECORDS) > before, 'no pass of the captured sweep kept its records in device memory'
+    # (the sweep is the last fused run of the step: its long passes keep their records in device memory, and the capture has
+    # put exactly those tensors on the list that outlives the plans)
+    held = [t for st in dq.executor.LAST_RUN['plan'].steps if hasattr(st, 'desc')
+            for t in st.desc.__dict__.get('_dev_records', {}).values() if t is not None]
+    assert held, 'no pass of the captured sweep kept its records in device memory'
+    assert all(id(t) in dq.backend._CAPTURE_PINS for t in held)
+    del held
     first = graph.replay().clone()
     dq.executor._PLAN_CACHE.clear()         # the plans (and with them the descriptors' own references) go away ...
     dq.executor._STEADY.clear()

@@ -208,3 +208,14 @@ def test_sweep_passes_with_their_records_in_device_memory_on_gpu(n, seed, is128)
     scale = max(1.0, float(racc.abs().max()))
     assert (acc.cpu() - racc).abs().max().item() < (1e-11 if is128 else 3e-5) * scale
     assert float(racc.abs().max()) > 0
+
+
+@PREC
+@pytest.mark.parametrize('b,n', [(1, 1), (1, 12), (3, 13), (2, 24)])
+def test_interleave_and_back_on_gpu(b, n, is128):
+    """dq_interleave_* / dq_deinterleave_*: psi and lambda side by side along a new index bit 0 (the pair state of a fused
+    reverse sweep) -- bit-exact against torch.stack."""
+    x, y = rand_state(b, n, 1, is128).to(dev()), rand_state(b, n, 2, is128).to(dev())
+    pair = backend.interleave(x, y)
+    assert torch.equal(pair, torch.stack([x, y], dim=-1).reshape(b, -1))
+    assert torch.equal(backend.deinterleave(pair, 0), x) and torch.equal(backend.deinterleave(pair, 1), y)
