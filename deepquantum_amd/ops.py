@@ -282,6 +282,10 @@ class _ExpectPauli(torch.autograd.Function):
         # of a complex tensor is grad = 2 * dL/d(conj psi).
         # (P psi through the differentiable gate applications, so that a second derivative sees it)
         # (under create_graph only; a first-order backward takes all factors in one fused pass)
+        legacy = torch._C._functorch.is_legacy_batchedtensor
+        if (not torch.is_grad_enabled() and state.ndim == 2 and not _is_batched(state) and not _is_wrapped(g)
+                and not _is_wrapped(state) and not legacy(g) and not legacy(state) and not transform_stack()):
+            return apply_pauli(state, ctx.xmask, ctx.zmask, scale=2.0 * g), None, None
         ppsi = apply_pauli(state, ctx.xmask, ctx.zmask, differentiable=torch.is_grad_enabled())
         return (2.0 * g).to(state.real.dtype).unsqueeze(-1) * ppsi, None, None
 
@@ -308,12 +312,28 @@ def _pauli_mats(dtype: torch.dtype, device: torch.device) -> dict[str, torch.Ten
     return _PAULI[key]
 
 
-def apply_pauli(state: torch.Tensor, xmask: int, zmask: int, differentiable: bool = False) -> torch.Tensor:
-    """P|psi> for a Pauli string (``differentiable``: through the autograd-aware gate applications)."""
+def apply_pauli(state: torch.Tensor, xmask: int, zmask: int, differentiable: bool = False,
+                scale: torch.Tensor | None = None) -> torch.Tensor:
+    """P|psi> for a Pauli string (``differentiable``: through the autograd-aware gate applications).  ``scale`` (real, one
+    number per sample; not with ``differentiable``): s P|psi> -- the factor rides on the matrix of the first Pauli instead
+    of costing a read and a write of the state of its own (the cotangent 2 g P psi of an expectation value)."""
     mats = _pauli_mats(state.dtype, state.device)
     n = state.shape[-1].bit_length() - 1
     factors = [(p, 'y' if (xmask >> p) & (zmask >> p) & 1 else ('x' if (xmask >> p) & 1 else 'z'))
                for p in range(n) if ((xmask | zmask) >> p) & 1]
+    if scale is not None:
+        assert not differentiable and state.ndim == 2 and not _is_batched(state)
+        if not factors:
+            return state * scale.to(state.real.dtype).reshape(-1, 1)
+        from . import executor
+
+        s_ = scale.to(state.real.dtype).reshape(-1, 1, 1)
+        kinds = {'x': 'gen', 'y': 'gen', 'z': 'diag'}          # (a scaled X is no bit flip any more)
+        first = mats[factors[0][1]] * s_                         # (B, 2, 2), or (1, 2, 2)
+        prims = [executor.Prim(kinds[factors[0][1]], first if first.shape[0] > 1 else first[0], (factors[0][0],), (), unitary=False)]
+        prims += [executor.Prim({'x': 'x', 'y': 'gen', 'z': 'diag'}[c], mats[c], (p,), ()) for p, c in factors[1:]]
+        with torch.no_grad():
+            return executor.run(state.detach(), prims)
     if not differentiable and len(factors) >= 2 and not _is_batched(state) and state.ndim == 2:
         # all factors in one fused pass (the reference applies them one after the other, qmath.py:846-856: a read and a
         # write of the state EACH -- <X..X> on n qubits, the observable of its own gradient benchmark, cost n of them)
