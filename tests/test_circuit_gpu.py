@@ -542,6 +542,42 @@ def test_captured_training_step_keeps_the_device_records_of_its_long_sweep_passe
     assert (got - ref).abs().max().item() < 1e-5 and float(ref.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize('n', [8, 14])
+def test_captured_inference_survives_the_eviction_of_its_plans_and_caches(n):
+    """A no-grad evaluation captured as a HIP graph reads what the steady-state caches own -- the flat matrix buffer of the
+    fixed gates, the offsets of the deferred Rx blocks: dropped caches and reused memory must not reach the replay."""
+    import gc
+
+    torch.manual_seed(2)
+    cir = dq.QubitCircuit(n)
+    cir.hlayer()
+    for _ in range(4):
+        cir.rxlayer()
+        cir.cnot_ring()
+        cir.rylayer(encode=True)
+    cir.observable(0)
+    cir.observable([1, 2], 'zz')
+    cir.to(dev())
+    data = torch.rand(3, cir.ndata, device=dev())
+
+    def evaluate():
+        with torch.no_grad():
+            cir(data)
+            return cir.expectation()
+
+    graph = dq.CapturedGraph(evaluate)
+    first = graph.replay().clone()
+    dq.executor._PLAN_CACHE.clear()
+    dq.executor._STEADY.clear()
+    gc.collect()
+    junk = [torch.full((1 << 18,), 5, dtype=torch.uint8, device=dev()) for _ in range(256)]
+    junk += [torch.full((1 << 10,), 5, dtype=torch.uint8, device=dev()) for _ in range(4096)]
+    del junk
+    for _ in range(2):       # (the reductions add with atomics: equal to rounding, not bit for bit)
+        assert (graph.replay() - first).abs().max().item() < 1e-6
+    assert (evaluate() - first).abs().max().item() < 1e-5 and float(first.abs().max()) > 1e-3
+
+
 def test_edge_cases_on_gpu():
     from _helpers import check_edge_cases
 
