@@ -26,7 +26,7 @@ def timed(reps=30):
     ts.sort()
     return ts[0] * 1e3, ts[len(ts) // 2] * 1e3
 import cProfile, pstats
-for tag in ('plain', 'plain again', 'after _PLAN_CACHE.clear()', 'again'):
+for tag in ('plain', 'plain again'):
     if tag.startswith('after'):
         dq.executor._PLAN_CACHE.clear()
     lo, med = timed()
@@ -34,4 +34,4 @@ for tag in ('plain', 'plain again', 'after _PLAN_CACHE.clear()', 'again'):
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20): step()
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats('tottime').print_stats(14)
+st = pstats.Stats(pr); st.sort_stats('cumulative').print_stats(48); st.sort_stats('tottime').print_stats(22)
