@@ -574,7 +574,7 @@ def test_captured_inference_survives_the_eviction_of_its_plans_and_caches(n):
     junk += [torch.full((1 << 10,), 5, dtype=torch.uint8, device=dev()) for _ in range(4096)]
     del junk
     for _ in range(2):       # (the reductions add with atomics: equal to rounding, not bit for bit)
-        assert (graph.replay() - first).abs().max().item() < 1e-6
+        assert (graph.replay() - first).abs().max().item() < 1e-5
     assert (evaluate() - first).abs().max().item() < 1e-5 and float(first.abs().max()) > 1e-3
 
 
