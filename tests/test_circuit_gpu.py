@@ -535,7 +535,7 @@ def test_captured_training_step_keeps_the_device_records_of_its_long_sweep_passe
     del junk
     for _ in range(2):
         got = graph.replay()
-        assert torch.equal(got, first)
+        assert (got - first).abs().max().item() < 1e-6      # (sums of atomics: equal to rounding)
     got = got.clone()
     params.grad = None
     ref = step()                            # eager, after the graph: the same numbers
