@@ -165,7 +165,9 @@ def build_circuit(dq, n, spec, batch, dtype, device, distributed=False, shard=0)
 
 
 def device_copy_bandwidth(device, nbytes=1 << 32, reps=5):
-    """Read+write GB/s of a plain device-to-device copy of ``nbytes`` (the achievable-HBM yardstick)."""
+    """Read+write GB/s of torch's device-to-device copy of ``nbytes``.  NOT the yardstick (round 5: the fused pass ran at
+    1.07 x this figure -- it measures the copy's implementation, not the memory); reported as `torch_copy_GBs` for the
+    record.  The measured ceiling is the pass kernel's own skeleton: `single_gate_sweep(...)['skeleton']`."""
     a = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
     b = torch.empty_like(a)
     b.copy_(a)
@@ -179,7 +181,7 @@ def device_copy_bandwidth(device, nbytes=1 << 32, reps=5):
     return 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def single_gate_sweep(dq, n, batch, dtype, device, reps=2):
+def single_gate_sweep(dq, n, batch, dtype, device, reps=2, only_skeleton=False):
     """Physical read+write GB/s of ONE gate application over a resident (batch, 2^n) state -- the un-fused figure the
     north star's ">= 60 % of the HBM roofline" refers to -- for H on EVERY target bit and for CNOT pairs (near / far,
     control above / below the target).  Returns {'h': {bit: GB/s}, 'cnot': {'c->t': GB/s}}; a CNOT launch is charged
@@ -208,6 +210,12 @@ def single_gate_sweep(dq, n, batch, dtype, device, reps=2):
         return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
     out = {'h': {}, 'cnot': {}}
+    # the kernel's SKELETON -- load the tile, one uncontrolled X on a register bit (64-bit moves, no arithmetic), store
+    # in place -- is the measured ceiling of a pass on this box (an in-framework copy figure); best of 3
+    skel = [fusion.PrimOp('x', (1,), (), 0, 0)]
+    out['skeleton'] = max(time_ops(skel, h) for _ in range(3))
+    if only_skeleton:
+        return out
     for t in range(n):
         out['h'][t] = time_ops([fusion.PrimOp('gen', (t,), (), 0, 3)], h)
     pairs = [(0, 1), (1, 0), (0, n - 1), (n - 1, 0), (n // 2, n // 2 + 1), (n // 2 + 1, n // 2), (3, n - 2), (n - 2, 3),
@@ -300,11 +308,11 @@ def pin_verdict(amp, ref_amp, norm2, ref_norm2, ez, ref_ez):
     rel_max = amp_err / float(np.abs(ref_amp).max())
     rel_l2 = float(np.linalg.norm(amp - ref_amp) / np.linalg.norm(ref_amp))
     z_err = float(np.abs(np.asarray(ez) - np.asarray(ref_ez)).max())
-    ok = rel_max < 1e-3 and rel_l2 < 1e-3 and amp_err < 1e-4 and z_err < 1e-4 and abs(norm2 - ref_norm2) < 1e-4
+    ok = rel_max < 1e-4 and rel_l2 < 1e-4 and amp_err < 1e-4 and z_err < 1e-4 and abs(norm2 - ref_norm2) < 1e-4
     return ok, {'amplitudes_checked': int(len(ref_amp)), 'max_amplitude_error': amp_err,
                 'max_amplitude_error_relative_to_largest_amplitude': rel_max, 'l2_error_relative': rel_l2,
                 'max_expectation_z_error': z_err, 'norm2': norm2, 'norm2_reference': ref_norm2,
-                'tolerance': {'amplitudes_relative': 1e-3, 'expectation_z': 1e-4, 'norm2': 1e-4}}
+                'tolerance': {'amplitudes_relative': 1e-4, 'expectation_z': 1e-4, 'norm2': 1e-4}}
 
 
 def check_pin(cir, n, depth, seed, dtype, extra_cx=False):
@@ -321,6 +329,26 @@ def check_pin(cir, n, depth, seed, dtype, extra_cx=False):
     ez = [float(backend.expect_pauli(state, 0, 1 << (n - 1 - q))[0]) for q in range(n)]
     ok, rep = pin_verdict(amp, pin['amplitudes'], norm2, float(pin['norm2']), ez, pin['expectation_z'])
     rep['source'] = what
+    # further samples of the timed batch pinned to the real reference (make_golden_pin28.py --sample K: row K of the same
+    # data matrix through the reference's un-batched forward)
+    import glob
+
+    import numpy as np
+    gold = os.environ.get('DQ_PIN_DIR') or os.path.join(ROOT, 'tests', 'golden')
+    full = cir.state.reshape(-1, 1 << n)
+    for path in sorted(glob.glob(os.path.join(gold, f'pin{n}_s*.npz'))) if not extra_cx else []:
+        pk = np.load(path)
+        k = int(pk['sample'])
+        if k >= full.shape[0] or int(pk['depth']) != depth:
+            continue
+        row = full[k:k + 1].contiguous()
+        ampk = row[0, torch.from_numpy(pk['indices']).to(row.device)].cpu().numpy()
+        ezk = [float(backend.expect_pauli(row, 0, 1 << (n - 1 - q))[0]) for q in range(n)]
+        okk, repk = pin_verdict(ampk, pk['amplitudes'], float(backend.expect_pauli(row, 0, 0)[0]), float(pk['norm2']),
+                                ezk, pk['expectation_z'])
+        repk['source'] = f'tests/golden/{os.path.basename(path)} (real reference, batch element {k})'
+        rep.setdefault('more_samples', {})[str(k)] = repk
+        ok = ok and okk
     return ok, rep
 
 
@@ -737,6 +765,11 @@ def main():
         if have_gpu:
             torch.cuda.empty_cache()
         sweep = single_gate_sweep(dq, n, nbatch, dtype, device) if have_gpu else None
+    elif extras and n >= 13 and have_gpu:
+        out = None
+        cir.state = None
+        torch.cuda.empty_cache()
+        sweep = single_gate_sweep(dq, n, nbatch, dtype, device, only_skeleton=True)
 
     qaoa = None
     if args.config == 5 and not args.no_qaoa:   # QAOA ring, one step: gradient of sum <Z_i Z_j> w.r.t. (gamma, beta)
@@ -850,11 +883,20 @@ def main():
                 'algorithmic_bytes_per_launch': alg_per_launch,
                 'effective_GBs': effective,
                 'fusion_factor': (effective / physical) if physical else None,
-                'device_copy_GBs': copy_gbs,
-                'frac_of_device_copy': (physical / copy_gbs) if copy_gbs else None,
+                'torch_copy_GBs': copy_gbs,
             },
         }
         if sweep is not None:
+            # the measured ceiling: the pass kernel's own skeleton (one register-move record, in place) and the best
+            # single-H pass of the same run; `frac` stays against the 8 TB/s of the microarchitecture guide
+            ceil_ = max([sweep['skeleton']] + list(sweep['h'].values()))
+            line['roofline']['measured_ceiling_GBs'] = ceil_
+            line['roofline']['measured_ceiling_what'] = (
+                'best of: the pass kernel with ONE uncontrolled-X record (register moves) in place over the same resident '
+                'state' + ('' if not sweep['h'] else ', single-H passes on every target bit') + '; measured in this run')
+            line['roofline']['skeleton_pass_GBs'] = sweep['skeleton']
+            line['roofline']['frac_of_measured_ceiling'] = (physical / ceil_) if ceil_ else None
+        if sweep is not None and sweep['h']:
             hs, cs = list(sweep['h'].values()), list(sweep['cnot'].values())
             line['roofline']['single_gate'] = {
                 'what': 'one un-fused gate per pass over the same resident state, physical GB/s: H on every target bit; '

@@ -1086,3 +1086,15 @@ def check_transforms_random(dq, device=None, n=10, seed=0, ngates=40, dtype=torc
         assert (tf.jacrev(tf.jacrev(fs))(x) - hes).abs().max().item() < 20 * tol, ('jacrev(jacrev)', seed)
         assert (tf.hessian(fs)(x) - hes).abs().max().item() < 40 * tol, ('hessian = jacfwd(jacrev)', seed)
         assert (tf.jacfwd(fvec)(x) - jac).abs().max().item() < 20 * tol, ('jacfwd', seed)
+
+
+def pick_transport(world, device_count=None):
+    """Transport of a sharded GPU test with ``world`` ranks: ``('nccl', one device per rank)`` -- RCCL over xGMI, the
+    reference's own transport (communication.py:9-35, README.md:223-255) -- as soon as the box shows at least ``world``
+    devices (a multi-GPU lease, or an MI355X in CPX mode: 8 devices), else ``('gloo', every rank on device 0)`` with
+    host-staged exchanges.  Returns (backend, [device index of rank r])."""
+    if device_count is None:
+        device_count = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if world > 1 and device_count >= world and os.environ.get('DQ_TEST_TRANSPORT', '') != 'gloo':
+        return 'nccl', list(range(world))
+    return 'gloo', [0] * world

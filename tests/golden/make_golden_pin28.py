@@ -6,6 +6,10 @@ the squared norm, <Z_q> for every wire q from the reference's own ``expectation(
 Only outputs are stored (tests/golden/pin28.npz).
 
 usage: nohup python tests/golden/make_golden_pin28.py > /tmp/pin28.log 2>&1 &     (1-2 hours on 8 cores, ~10 GiB)
+
+``--sample K`` (round 6; K in 1 .. 15): batch element K of the same timed workload instead -- its angles are row K of
+bench.py's data matrix (``torch.rand(16, n_rx, generator=manual_seed(1234)) * 2 pi`` in float32, the reference's vmap
+semantics, circuit.py:232-240: H / CNOT shared, Rx angles per sample) -> tests/golden/pin28_s{K}.npz.
 """
 
 import math
@@ -42,6 +46,12 @@ def main():
     if c128:
         cir.to(torch.double)
     data = torch.tensor(angles, dtype=torch.float64 if c128 else torch.float32)
+    sample = int(sys.argv[sys.argv.index('--sample') + 1]) if '--sample' in sys.argv else 0
+    if sample:
+        assert 0 < sample < 16 and not c128
+        g = torch.Generator().manual_seed(1234)                 # bench.build_circuit, shard 0
+        rows = torch.rand(16, len(angles), generator=g, dtype=torch.float32) * 2 * math.pi
+        data = rows[sample].clone()
     t0 = time.perf_counter()
     with torch.no_grad():
         state = cir(data)          # QubitCircuit.forward, circuit.py:180-263
@@ -54,7 +64,7 @@ def main():
         idx = torch.randint(0, 2**n, (4096,), generator=torch.Generator().manual_seed(28))
         p = (flat.real.double() ** 2 + flat.imag.double() ** 2)
         out = {
-            'nqubit': np.array(n), 'depth': np.array(depth), 'seed': np.array(1234),
+            'nqubit': np.array(n), 'depth': np.array(depth), 'seed': np.array(1234), 'sample': np.array(sample),
             'angles_f32': data.numpy(),
             'indices': idx.numpy(),
             'amplitudes': to_np(flat[idx]),
@@ -66,6 +76,8 @@ def main():
         out['marginal_wires_0_4'] = pt.reshape(32, -1).sum(-1).numpy()
         out['marginal_wires_last5'] = pt.reshape(-1, 32).sum(0).numpy()
     name = 'pin28.npz' if (n, depth, c128) == (28, 40, False) else f'pin{n}_d{depth}{"_c128" if c128 else ""}.npz'
+    if sample:
+        name = name[:-4] + f'_s{sample}.npz'
     np.savez_compressed(os.path.join(HERE, name), **out)
     print('norm2', out['norm2'], 'Z0', out['expectation_z'][0], 'wrote', name, flush=True)
 

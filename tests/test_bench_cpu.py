@@ -115,3 +115,25 @@ def test_rehearsal_of_one_rank_of_a_world_that_is_not_there():
         assert line['schedule']['remaps'] > line['schedule']['virtual_remaps'] > 0
         # rank 0 starts from |0..0>, the others from zeros: no pass before the first exchange
         assert (line['schedule']['zero_shard_stretches'] > 0) == (r != 0)
+
+
+def test_transport_selector_of_the_sharded_gpu_tests():
+    """``_helpers.pick_transport``: RCCL (one device per rank) as soon as the box shows enough devices, gloo with every
+    rank on device 0 otherwise; a world of one never needs it; DQ_TEST_TRANSPORT=gloo pins the fallback."""
+    import os
+
+    from _helpers import pick_transport
+
+    assert pick_transport(2, device_count=1) == ('gloo', [0, 0])
+    assert pick_transport(4, device_count=2) == ('gloo', [0, 0, 0, 0])
+    assert pick_transport(2, device_count=2) == ('nccl', [0, 1])
+    assert pick_transport(4, device_count=8) == ('nccl', [0, 1, 2, 3])
+    assert pick_transport(8, device_count=8) == ('nccl', list(range(8)))
+    assert pick_transport(1, device_count=8) == ('gloo', [0])
+    assert pick_transport(2, device_count=0) == ('gloo', [0, 0])
+    os.environ['DQ_TEST_TRANSPORT'] = 'gloo'
+    try:
+        assert pick_transport(2, device_count=8) == ('gloo', [0, 0])
+    finally:
+        del os.environ['DQ_TEST_TRANSPORT']
+    assert pick_transport(2)[0] in ('gloo', 'nccl')        # (whatever this box shows)

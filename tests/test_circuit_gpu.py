@@ -732,8 +732,12 @@ def test_config3_pin_n28_complex64_batch16():
     assert dq.executor.LAST_RUN['passes'] > 0 and dq.executor.LAST_RUN['gates'] < len(spec)   # merged, fused
     state = cir.state.reshape(batch, 1 << n)[:1].contiguous()
     idx = torch.from_numpy(pin['indices']).to(state.device)
-    assert np.abs(state[0, idx].cpu().numpy() - pin['amplitudes']).max() < 1e-4
-    assert np.abs(state[0, idx].cpu().numpy() - pin['amplitudes']).max() < 1e-2 * np.abs(pin['amplitudes']).max()
+    got = state[0, idx].cpu().numpy()
+    assert np.abs(got - pin['amplitudes']).max() < 1e-4
+    # the criteria that bite at n = 28 (amplitudes ~ 1.6e-4: the absolute 1e-4 is vacuous there) are RELATIVE: the largest
+    # deviation against the largest pinned amplitude and l2 against l2, both at 1e-4 (measured: 5.4e-6 / 5.5e-6)
+    assert np.abs(got - pin['amplitudes']).max() < 1e-4 * np.abs(pin['amplitudes']).max()
+    assert np.linalg.norm(got - pin['amplitudes']) < 1e-4 * np.linalg.norm(pin['amplitudes'])
     assert abs(float(backend.expect_pauli(state, 0, 0)[0]) - float(pin['norm2'])) < 1e-4
     ez = np.array([float(backend.expect_pauli(state, 0, 1 << (n - 1 - q))[0]) for q in range(n)])
     assert np.abs(ez - pin['expectation_z']).max() < 1e-4
@@ -746,6 +750,34 @@ def test_config3_pin_n28_complex64_batch16():
     full = cir.state.reshape(batch, 1 << n)
     norms = backend.expect_pauli(full, 0, 0).cpu().numpy()
     assert np.abs(norms - 1).max() < 1e-4
+    evb = ev.reshape(batch, -1)[:, 0].cpu().numpy().copy()
+    # a second sample of the timed batch against the REAL reference (make_golden_pin28.py --sample 7: row 7 of the same
+    # data matrix through the reference's un-batched forward; vmap semantics circuit.py:232-240)
+    for name in sorted(os.listdir(os.path.join(root, 'tests', 'golden'))):
+        if not (name.startswith('pin28_s') and name.endswith('.npz')):
+            continue
+        pk = np.load(os.path.join(root, 'tests', 'golden', name))
+        k = int(pk['sample'])
+        assert np.array_equal(data[k].cpu().numpy(), pk['angles_f32'])
+        gk = full[k, torch.from_numpy(pk['indices']).to(full.device)].cpu().numpy()
+        assert np.abs(gk - pk['amplitudes']).max() < 1e-4 * np.abs(pk['amplitudes']).max(), name
+        assert np.linalg.norm(gk - pk['amplitudes']) < 1e-4 * np.linalg.norm(pk['amplitudes']), name
+        assert abs(float(norms[k]) - float(pk['norm2'])) < 1e-4
+        assert abs(float(evb[k]) - float(pk['expectation_z'][0])) < 1e-4
+    # samples 1 .. 15 against UN-BATCHED runs of the same angles through the same circuit (shared matrices, no per-sample
+    # stride): the whole 2^28 amplitudes of each, relative to the largest one and in l2
+    single, _ = bench.build_circuit(dq, n, spec, None, torch.complex64, dev())
+    for k in range(1, batch):
+        with torch.no_grad():
+            single(data[k])
+            e1 = single.expectation()
+        one = single.state.reshape(-1)
+        diff = (one - full[k])
+        scale = one.abs().max().item()
+        assert diff.abs().max().item() < 1e-4 * scale, k
+        assert torch.linalg.vector_norm(diff).item() < 1e-4 * torch.linalg.vector_norm(one).item(), k
+        assert abs(float(e1.reshape(-1)[0]) - float(evb[k])) < 1e-5, k
+        del diff, one
 
 
 def test_pin_n26_complex128_batch4():

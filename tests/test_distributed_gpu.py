@@ -7,6 +7,7 @@ ranks by ``bench.py --gpus N`` only."""
 import os
 import socket
 import sys
+import time
 import traceback
 
 import pytest
@@ -25,16 +26,16 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, case, ret, backend='gloo'):
+def _worker(rank, world, port, case, ret, backend='gloo', local=0):
     try:
         sys.path.insert(0, os.path.dirname(HERE))
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.join(HERE, 'golden'))
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          LOCAL_RANK='0')
+                          LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY='0')
         import deepquantum_amd as dq
 
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(local)
         dq.setup_distributed(backend)
         globals()['_case_' + case](dq, rank, world)
         dq.cleanup_distributed()
@@ -43,11 +44,29 @@ def _worker(rank, world, port, case, ret, backend='gloo'):
         ret[rank] = traceback.format_exc()
 
 
-def _run(case, world, backend='gloo'):
+def _spawn_one(rank, world, port, case, ret, backend, devices):
+    _worker(rank, world, port, case, ret, backend, devices[rank])
+
+
+def _run(case, world, backend=None):
+    """``backend`` None: RCCL with one device per rank when the box shows >= ``world`` devices, else gloo with every rank
+    on device 0 (``_helpers.pick_transport``; the selector has a CPU test)."""
+    sys.path.insert(0, HERE)
+    from _helpers import pick_transport
+
+    devices = [0] * world
+    if backend is None:
+        backend, devices = pick_transport(world)
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, case, ret, backend), nprocs=world, join=True)
+    ctx = mp.spawn(_spawn_one, args=(world, port, case, ret, backend, devices), nprocs=world, join=False)
+    deadline = time.monotonic() + float(os.environ.get('DQ_TEST_RANKS_TIMEOUT', 600))
+    while not ctx.join(timeout=5):
+        if time.monotonic() > deadline:                 # a stalled exchange must not hang the suite (or the box)
+            for pr in ctx.processes:
+                pr.kill()
+            pytest.fail(f'{case}: {world} ranks over {backend} did not finish in time; finished: {dict(ret)}')
     for r in range(world):
         assert ret.get(r) == 'ok', f'rank {r}: {ret.get(r)}'
 
@@ -131,7 +150,7 @@ def _case_zero_state(dq, rank, world):
     to be zero, the other ranks -- all zeros -- run no pass at all (tests/test_distributed_cpu.py, _zero_state_check)."""
     from test_distributed_cpu import _zero_state_check
 
-    dev = torch.device('cuda', 0)
+    dev = torch.device('cuda', torch.cuda.current_device())
     _zero_state_check(dq, rank, world, 21, 3, device=dev, depth=10)
     _zero_state_check(dq, rank, world, 20, None, dtype=torch.complex128, device=dev, depth=10)
 
@@ -303,7 +322,7 @@ def _case_rccl(dq, rank, world):
     from deepquantum_amd import distributed as D
 
     assert dist.get_backend() == 'nccl' and world == 1
-    dev = torch.device('cuda', 0)
+    dev = torch.device('cuda', torch.cuda.current_device())
     for dtype in (torch.complex64, torch.complex128):
         g = torch.Generator().manual_seed(3)
         send = torch.randn(1 << 16, generator=g, dtype=torch.float64).to(dtype).to(dev) * (1 + 2j)

@@ -31,7 +31,12 @@ def _bench(*args, need_gib, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    pr = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--backend', 'gloo', '--steps', '1', '--warmup', '0',
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from _helpers import pick_transport
+
+    world = int(args[args.index('--gpus') + 1])
+    transport, _devices = pick_transport(world)       # RCCL, one device per rank, when the box shows enough devices
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--backend', transport, '--steps', '1', '--warmup', '0',
                          '--functional', '--no-cpu-baseline'] + [str(a) for a in args],
                         capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
     assert pr.returncode == 0, pr.stderr[-3000:]
@@ -45,7 +50,7 @@ def _check(line, n, world):
     par = line['parity']
     assert line['parity_checked'] is True, par
     assert par['amplitudes_checked_per_rank_sum'] == 4096
-    assert par['max_amplitude_error_relative_to_largest_amplitude'] < 1e-3 and par['l2_error_relative'] < 1e-3
+    assert par['max_amplitude_error_relative_to_largest_amplitude'] < 1e-4 and par['l2_error_relative'] < 1e-4
     assert par['max_expectation_z_error'] < 1e-4 and abs(par['norm2'] - par['norm2_reference']) < 1e-4
     assert abs(line['config']['norm2_sample0'] - par['norm2_reference']) < 1e-4
 
