@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
         double* const grow = grads + (uint64_t)sample * (uint64_t)grad_bstride;
         for (unsigned i = tid; i < nrec * 8u; i += 256u) {
             const unsigned id = rw[8u * (i >> 3)];
-            if (id >= (unsigned)W::ID_GRAD && id <= (unsigned)W::ID_EXPZ) {      // (an expectation value fills component 0 only)
+            // (an expectation value fills component 0 only: one atomic per workgroup instead of eight)
+            if ((id >= (unsigned)W::ID_GRAD && id < (unsigned)W::ID_EXPZ) || (id == (unsigned)W::ID_EXPZ && (i & 7u) == 0u)) {
                 const typename W::acc_t v = *(__attribute__((address_space(3))) typename W::acc_t*)(uintptr_t)(4u * W::LDS_PER_WAVE + (unsigned)sizeof(typename W::acc_t) * i);
                 atomicAdd(grow + (uint64_t)rw[8u * (i >> 3) + 6] * 8u + (i & 7u), (double)v);
             }
@@ -618,7 +619,13 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
         // on the caller's sums but leave a longer tail: training step n = 28 (32 sweep passes) 89.3 ms at a cap of 64 (rounds
         // 3-4), 87.8 at 8, 87.4 at 2, 86.5 at 1 (profiles/r05/exp_grad_tpw.txt).  DQ_WAVE_GRAD_TPW overrides the cap
         static const int gcap = [] { const char* e = getenv("DQ_WAVE_GRAD_TPW"); return e ? atoi(e) : 2; }();
-        while (tpw < gcap && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
+        // a forward pass that only takes <Z..Z> from its registers (DQ_FG_EXPZ records, no DQ_FG_GRAD): its own cap
+        static const int zcap = [] { const char* e = getenv("DQ_WAVE_EXPZ_TPW"); return e ? atoi(e) : 2; }();
+        bool only_expz = !ext_rec;
+        for (unsigned r = 0; only_expz && r < kp.nrec_bytes / 32u; ++r)
+            only_expz = !(kp.rec[r].w[0] >= (uint32_t)W::ID_GRAD && kp.rec[r].w[0] < (uint32_t)W::ID_EXPZ);
+        const int cap = only_expz ? zcap : gcap;
+        while (tpw < cap && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
     } else {
         static const int tpw_env = [] { const char* e = getenv("DQ_WAVE_TPW"); return e ? atoi(e) : 1; }();
         while (tpw < tpw_env && (tiles * (uint64_t)batch) / (8ull * (uint64_t)tpw) >= 2048) tpw *= 2;
@@ -642,7 +649,9 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
     // runs of 2 .. 512 groups per XCD give the same within 0.2 %).  DQ_WAVE_XCD: 0 off, 1 contiguous eighths, C = 2, 4, ..:
     // runs of C tile groups per XCD
     int xcd = 0;
-    if (xcd_env && in_bstride != 0 && tpw == 1) {
+    // (several tiles per wave: the tile numbers of a wave lie a whole grid apart, the mapping of the workgroup holds for all)
+    static const int xcd_tpw = [] { const char* e = getenv("DQ_WAVE_XCD_TPW"); return e ? atoi(e) : 0; }();
+    if (xcd_env && in_bstride != 0 && (tpw == 1 || xcd_tpw)) {
         if (xcd_env == 1 && (grid.x & 7u) == 0) xcd = 31;
         else if (xcd_env > 1 && (xcd_env & (xcd_env - 1)) == 0 && grid.x % (8u * (unsigned)xcd_env) == 0)
             xcd = 32 - __builtin_clz((unsigned)xcd_env);       // log2(C) + 1
