@@ -159,9 +159,20 @@ def apply_gate(
 KERNARG_RECORDS = 112
 #: Device tensors that launches of a HIP graph UNDER CAPTURE read and that a plan or a cache owns -- the kernel matrix buffer
 #: of a circuit with fixed gates, the offsets of its deferred Rx blocks, the records of a long pass: the graph has their
-#: addresses baked in, so they must outlive the plan cache's evictions.  (What a capture allocates itself comes from the
-#: graph's own pool and lives with it.)  Never shrinks: a few KiB per captured circuit.
+#: addresses baked in, so they must outlive the plan cache's evictions.  Only tensors a cache OWNS are pinned (`own`):
+#: what a capture allocates itself -- the matrix buffer of a trainable circuit, built anew inside the capture -- comes
+#: from the graph's private pool and lives with the graph; pinning it would keep pool blocks from ever being reused.
+#: Pins of a capture made by `utils.CapturedGraph` belong to that object (`_PIN_SINK`) and die with it; those of a raw
+#: ``torch.cuda.graph`` capture stay here: a few KiB per captured circuit.
 _CAPTURE_PINS: dict = {}
+_PIN_SINK: list = []          # the innermost CapturedGraph under construction keeps its pins in _PIN_SINK[-1]
+
+
+def own(t: torch.Tensor | None) -> torch.Tensor | None:
+    """Mark a device tensor as owned by a plan / steady-state cache (what `pin_if_capturing` keeps alive)."""
+    if t is not None:
+        t._dq_owned = True
+    return t
 
 
 def pin_if_capturing(*tensors: torch.Tensor | None) -> None:
@@ -169,8 +180,11 @@ def pin_if_capturing(*tensors: torch.Tensor | None) -> None:
     if first is None or not first.is_cuda or not torch.cuda.is_current_stream_capturing():
         return
     for t in tensors:
-        if t is not None:
-            _CAPTURE_PINS.setdefault(id(t), t)
+        if t is not None and getattr(t, '_dq_owned', False):
+            if _PIN_SINK:
+                _PIN_SINK[-1].setdefault(id(t), t)
+            else:
+                _CAPTURE_PINS.setdefault(id(t), t)
 
 
 def _device_records(desc: _lib.DqFusedPass, n: int, device: torch.device) -> torch.Tensor | None:
@@ -197,7 +211,7 @@ def _device_records(desc: _lib.DqFusedPass, n: int, device: torch.device) -> tor
             host = torch.empty(int(nbytes), dtype=torch.uint8)
             got = lib.dq_wave_records(C.byref(desc), n, host.data_ptr(), int(nbytes))
             assert got == nbytes
-            hit = host.to(device)
+            hit = own(host.to(device))
         cache[key] = hit
     return hit
 
@@ -592,6 +606,8 @@ def interleave(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     if not _use_hip(a) or (a.numel() & 1):
         return torch.stack([a, b], dim=-1).reshape(a.shape[0], -1)
     a, b = a.contiguous(), b.contiguous()
+    if (a.data_ptr() | b.data_ptr()) & 15:      # a view at an odd complex64 offset: the kernels read 16-byte pieces
+        return torch.stack([a, b], dim=-1).reshape(a.shape[0], -1)
     out = torch.empty(a.shape[0], 2 * a.shape[1], dtype=a.dtype, device=a.device)
     lib = _lib.load()
     fn = getattr(lib, f'dq_interleave_{_suffix(a)}')
@@ -604,7 +620,7 @@ def deinterleave(pair: torch.Tensor, which: int) -> torch.Tensor:
     if pair.ndim != 2 or pair.shape[1] & 1 or which not in (0, 1):
         raise ValueError('deinterleave: a (batch, 2 N) tensor, which = 0 or 1')
     half = pair.shape[1] // 2
-    if not _use_hip(pair) or not pair.is_contiguous() or ((pair.shape[0] * half) & 1):
+    if not _use_hip(pair) or not pair.is_contiguous() or ((pair.shape[0] * half) & 1) or (pair.data_ptr() & 15):
         return pair.reshape(pair.shape[0], -1, 2)[:, :, which].contiguous()
     out = torch.empty(pair.shape[0], half, dtype=pair.dtype, device=pair.device)
     lib = _lib.load()

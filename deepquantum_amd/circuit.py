@@ -24,7 +24,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import executor, ops, qmath
+from . import _functorch, executor, ops, qmath
 from .gate import (
     CNOT, Barrier, Fredkin, Hadamard, HamiltonianGate, ImaginarySwap, LatentGate, PauliX, PauliY, PauliZ,
     PhaseShift, ProjectionJ, ReconfigurableBeamSplitter, Reset, Rx, Rxx, Rxy, Ry, Ryy, Rz, Rzz, SDaggerGate, SGate, Swap,
@@ -286,7 +286,7 @@ class QubitCircuit(Operation):
         # angle gradients in one kernel -- instead of a slice per layer and a slice per gate, whose backwards are a zero
         # fill, a copy and an add EACH (the reference's gradient benchmark at n = 8, 4 layers: 207 of a gradient's 365
         # launches).  Same views, same shapes, same values.
-        if data.requires_grad and torch.is_grad_enabled() and not torch._C._functorch.is_functorch_wrapped_tensor(data):
+        if data.requires_grad and torch.is_grad_enabled() and not _functorch.is_wrapped_tensor(data):
             # The angles of the previous call are views into ITS autograd graph.  While one of them lives, so does the
             # AccumulateGrad node of the caller's leaf -- and the new graph made below would reuse that node, stream and all:
             # after eager steps on the default stream a capture of the step on another stream then dies in
@@ -298,7 +298,7 @@ class QubitCircuit(Operation):
                         for name in getattr(gate, '_param_names', ()):
                             t = bufs.get(name)
                             # (plain autograd only: a wrapper that a torch.func transform left behind is not touched)
-                            if t is not None and not torch._C._functorch.is_functorch_wrapped_tensor(t) and t.grad_fn is not None:
+                            if t is not None and not _functorch.is_wrapped_tensor(t) and t.grad_fn is not None:
                                 bufs[name] = t.detach()
                                 gate.__dict__['_matrix_key'] = None        # (it names the old tensors; `init_para` drops it anyway)
                             t = None                                        # (this frame must not be the last holder either)

@@ -369,6 +369,10 @@ static int interleave_impl(const void* a, const void* b, void* out, int64_t coun
         set_error("dq_interleave: bad argument (count = %lld amplitudes per input: even, >= 2; out of place)", (long long)count);
         return DQ_ERR_ARG;
     }
+    if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15u) {
+        set_error("dq_interleave: the buffers must be 16-byte aligned (the kernel moves 16-byte pieces)");
+        return DQ_ERR_ARG;
+    }
     uint64_t nb = ((uint64_t)count / (16 / sizeof(cx<T>)) + 255) / 256;
     if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(interleave_kernel<T>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), static_cast<const cx<T>*>(a),
@@ -380,6 +384,10 @@ template <typename T>
 static int deinterleave_impl(const void* in, void* out, int64_t count, int which, dq_stream_t stream) {
     if (!in || !out || count < 2 || (count & 1) || in == out || which < 0 || which > 1) {
         set_error("dq_deinterleave: bad argument (count = %lld amplitudes per output: even, >= 2; which = %d)", (long long)count, which);
+        return DQ_ERR_ARG;
+    }
+    if ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) {
+        set_error("dq_deinterleave: the buffers must be 16-byte aligned (the kernel moves 16-byte pieces)");
         return DQ_ERR_ARG;
     }
     uint64_t nb = ((uint64_t)count / (16 / sizeof(cx<T>)) + 255) / 256;

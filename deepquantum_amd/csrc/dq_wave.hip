@@ -649,8 +649,10 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
     // runs of 2 .. 512 groups per XCD give the same within 0.2 %).  DQ_WAVE_XCD: 0 off, 1 contiguous eighths, C = 2, 4, ..:
     // runs of C tile groups per XCD
     int xcd = 0;
-    // (several tiles per wave: the tile numbers of a wave lie a whole grid apart, the mapping of the workgroup holds for all)
-    static const int xcd_tpw = [] { const char* e = getenv("DQ_WAVE_XCD_TPW"); return e ? atoi(e) : 0; }();
+    // (several tiles per wave -- the reducing instantiation: the tile numbers of a wave lie a whole grid apart and the mapping
+    // of the workgroup holds for each of them.  Round 6: the last pass of the headline, <Z0> + canonical restore, 15.35 ->
+    // 13.98 ms with it, profiles/r06/last_pass_knobs.txt; DQ_WAVE_XCD_TPW=0 restores round 5's behaviour)
+    static const int xcd_tpw = [] { const char* e = getenv("DQ_WAVE_XCD_TPW"); return e ? atoi(e) : 1; }();
     if (xcd_env && in_bstride != 0 && (tpw == 1 || xcd_tpw)) {
         if (xcd_env == 1 && (grid.x & 7u) == 0) xcd = 31;
         else if (xcd_env > 1 && (xcd_env & (xcd_env - 1)) == 0 && grid.x % (8u * (unsigned)xcd_env) == 0)

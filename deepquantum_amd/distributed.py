@@ -836,9 +836,33 @@ def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int,
 _PLACEMENTS: dict = {}
 
 
-def _dry_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, lr: int, v: int) -> tuple[int, float]:
+def _dry_canonicalize(ph: list[int], n: int, L: int) -> tuple[int, float]:
+    """(exchanges, volume in shards) that `_canonicalize` would need from placement ``ph`` (no data; ``ph`` is updated):
+    the same rounds -- every misplaced rank bit trades with its owner, or with a filler while the owner itself sits on
+    another rank bit."""
+    steps, vol = 0, 0.0
+    for _ in range(4):
+        misplaced = [q for q in range(n) if ph[q] >= L and ph[q] != q]
+        if not misplaced:
+            break
+        used: set = set()
+        pairs = []
+        for lq in misplaced:
+            owner = ph[lq]
+            pick = owner if (ph[owner] < L and owner not in used) else next(q for q in range(L) if ph[q] < L and q not in used)
+            used.add(pick)
+            pairs.append((lq, pick))
+        for lq, pick in pairs:
+            ph[lq], ph[pick] = ph[pick], ph[lq]
+        steps += 1
+        vol += 1 - 0.5 ** len(pairs)
+    return steps, vol
+
+
+def _dry_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, lr: int, v: int, restore: bool = False) -> tuple[int, float]:
     """(exchanges of real rank bits, their volume in shards) of the remap schedule started from placement ``ph0`` -- the
-    loop of `count_exchange_steps` without the statistics."""
+    loop of `count_exchange_steps` without the statistics.  ``restore``: plus what the canonicalisation at the end of a
+    drop-in forward (``keep_layout=False``) costs from where the schedule leaves the qubits."""
     L = lr + v
     ph = list(ph0)
     order = _order_for_remaps(prims, ph, n, lr, v)
@@ -861,10 +885,13 @@ def _dry_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, lr: int, v: i
                 vol += 1 - 0.5**k
             continue
         i += 1
+    if restore:
+        cs, cv = _dry_canonicalize(ph, n, L)
+        steps, vol = steps + cs, vol + cv
     return steps, vol
 
 
-def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0) -> list[int]:
+def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0, restore: bool = False) -> list[int]:
     """Where the qubits of a circuit that starts from |0..0> should sit at the start: |0..0> is the same vector under
     every permutation of the qubits (rank 0 holds the one non-zero amplitude at local index 0 in any of them), so the
     FIRST placement costs nothing -- no exchange, not even a re-labelling pass.  Candidates: the reference layout
@@ -874,21 +901,26 @@ def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0) -> list
     (`_dry_remaps`, ~10 ms) and the one with the fewest exchanges wins -- the reference layout unless another one saves a
     whole exchange.  Never worse than the reference start, typically one exchange and one stretch boundary less (n = 34 on 8 ranks:
     5 -> 4 exchanges, 35 -> 33 passes).  A pure function of the gate list, cached by its structure: every rank computes
-    the same placement.  ``canonicalize`` restores the reference's order whenever somebody asks for it."""
+    the same placement.  ``canonicalize`` restores the reference's order whenever somebody asks for it; ``restore`` (a
+    drop-in forward, ``keep_layout=False``) charges every candidate the exchanges of that canonicalisation too, so that
+    "never worse than the reference start" holds for the step as it runs."""
     from itertools import combinations
 
     g = n - L
     canonical = list(range(n))
     if g <= 0 or not prims:
         return canonical
-    key = (n, L, v, hash(tuple((p.kind, tuple(p.targets), tuple(p.controls)) for p in prims)))
+    # (the tuple itself: a hash of strings is randomised per process, and a collision on one rank only would give the
+    # ranks different placements)
+    key = (n, L, v, bool(restore), CONFIG['horizon'], CONFIG['reorder'],
+           tuple((p.kind, tuple(p.targets), tuple(p.controls)) for p in prims))
     hit = _PLACEMENTS.get(key)
     if hit is not None:
         return list(hit)
     nxt = _next_use(prims, 0, n)
     order = sorted(range(n), key=lambda q: (-nxt[q], 0 if q >= L else 1, -q))
     lr = L - v
-    best = (_dry_remaps(prims, canonical, n, lr, v), 0, canonical)
+    best = (_dry_remaps(prims, canonical, n, lr, v, restore), 0, canonical)
     for ci, pick in enumerate(combinations(order[:g + 3], g)):
         ph = list(canonical)
         rest = [q for q in order if q not in pick]
@@ -898,7 +930,7 @@ def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0) -> list
             entering = [q for q in want if q not in have]
             for lq, eq in zip(leaving, entering):
                 ph[lq], ph[eq] = ph[eq], ph[lq]
-        cand = (_dry_remaps(prims, ph, n, lr, v), ci + 1, ph)
+        cand = (_dry_remaps(prims, ph, n, lr, v, restore), ci + 1, ph)
         # (fewer EXCHANGES, not merely less volume: a placement that only trims the volume was measured to cost more in
         # passes and un-folded re-labellings than it saves on the wire -- rehearsal of n = 34 / 8 ranks with virtual bits)
         if cand[0][0] < best[0][0] or (cand[0][0] == best[0][0] and best[1] > 0 and cand[0] < best[0]):
@@ -1072,7 +1104,8 @@ def _dist_apply_loop(state: DistributedQubitState, prims: Sequence[Prim], mode: 
     if (mode == 'remap' and CONFIG['initial_placement'] and state.__dict__.get('_fresh_zero') and _is_canonical(state)
             and state.world_size > 1):
         # behind reset(): the first placement is free (see `initial_placement`)
-        state.__dict__['_phys'] = initial_placement(prims, state.nqubit, state.log_num_amps_per_node, vb)
+        state.__dict__['_phys'] = initial_placement(prims, state.nqubit, state.log_num_amps_per_node, vb,
+                                                    restore=not keep_layout)
     if mode == 'remap' and CONFIG['reorder']:
         prims = _order_for_remaps(prims, _phys(state), state.nqubit, state.log_num_amps_per_node - vb, vb)
     pending: list[Prim] = []

@@ -22,7 +22,7 @@ from typing import Any, Sequence
 
 import torch
 
-from . import backend, fusion, ops
+from . import _functorch, backend, fusion, ops
 
 
 @dataclass
@@ -620,10 +620,10 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
             if plan.rx_defer:       # uncontrolled Rx-like gates of complex64 passes: the deferred form (fusion.defer_rx)
                 idx = plan._rx_index.get(x.device)
                 if idx is None:
-                    idx = plan._rx_index[x.device] = torch.tensor(plan.rx_defer, dtype=torch.long, device=x.device)
+                    idx = plan._rx_index[x.device] = backend.own(torch.tensor(plan.rx_defer, dtype=torch.long, device=x.device))
                 backend.defer_rx(flat, idx)
             if steady is not None:
-                steady['flat'] = {fkey: (plan, flat, stride)}       # (one buffer per entry: the latest shape)
+                steady['flat'] = {fkey: (plan, backend.own(flat), stride)}       # (one buffer per entry: the latest shape)
         stats = {'passes': 0, 'singles': 0, 'gates': len(prims), 'rounds': 0, 'transposes': 0, 'zero_passes': 0}
         spare = scratch                      # the caller's second buffer (if any)
         other = spare if permute else None
@@ -1230,7 +1230,7 @@ class _AdjointCircuit(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        if torch._C._functorch.is_legacy_batchedtensor(gy) or ops._is_wrapped(gy):
+        if _functorch.is_legacy_batched(gy) or ops._is_wrapped(gy):
             raise RuntimeError('deepquantum_amd: a batch of cotangents reached the circuit node (is_grads_batched / '
                                'torch.autograd.functional.*(vectorize=True)): its sweep runs on raw buffers.  Use '
                                'torch.func.jacrev / torch.func.vmap over the function instead -- inside those transforms '
@@ -1459,7 +1459,7 @@ class _AdjointCircuit(torch.autograd.Function):
                     for k, si in enumerate(sc):
                         if rank[si] < rank[pi]:
                             bmat[r, k] = 1.0
-                before = bmat.to(work.device)
+                before = backend.own(bmat.to(work.device))
                 if plan._scale_cache is None:
                     plan._scale_cache = {}
                 plan._scale_cache[(key, work.device)] = before

@@ -20,33 +20,24 @@ import torch
 
 from torch.autograd import forward_ad as _fwad
 
-from . import backend
+from . import _functorch, backend
 
 
 def _is_batched(t: torch.Tensor) -> bool:
     """True inside a ``torch.vmap`` transform (the tensor is a functorch BatchedTensor)."""
-    return torch._C._functorch.is_batchedtensor(t)
+    return _functorch.is_batched(t)
 
 
 #: PyTorch releases the probes below were checked against (tests/test_api_cpu.py::test_functorch_probes_are_guarded names
 #: them too).  They read functorch's interpreter stack through private modules; on a release where those moved, the
 #: probes answer "unknown" and every caller takes its conservative route (per-gate nodes, no refusal).
-FUNCTORCH_PROBES_CHECKED_ON = ('2.10',)
+FUNCTORCH_PROBES_CHECKED_ON = _functorch.CHECKED_ON
 
 
 def transform_stack() -> list[str] | None:
     """The ``torch.func`` transforms this call runs under, outermost first, as 'Vmap' / 'Grad' / 'Jvp' / ... -- or None
     when this PyTorch does not let us look (the private interpreter stack moved)."""
-    try:
-        from torch._functorch.pyfunctorch import retrieve_all_functorch_interpreters
-
-        out = []
-        for it in retrieve_all_functorch_interpreters():
-            key = str(it.key())
-            out.append(key.rsplit('.', 1)[-1])
-        return out
-    except Exception:           # noqa: BLE001  (ImportError, AttributeError, a changed signature ...)
-        return None
+    return _functorch.transform_stack()
 
 
 def forward_ad_active() -> bool | None:
@@ -82,7 +73,7 @@ def _is_wrapped(t: torch.Tensor | None) -> bool:
     True for a dual tensor of plain forward-mode AD (``torch.autograd.forward_ad``): a raw kernel would drop its tangent."""
     if t is None:
         return False
-    if torch._C._functorch.is_functorch_wrapped_tensor(t):
+    if _functorch.is_wrapped_tensor(t):
         return True
     if forward_ad_active() is False:
         return False
@@ -282,9 +273,9 @@ class _ExpectPauli(torch.autograd.Function):
         # of a complex tensor is grad = 2 * dL/d(conj psi).
         # (P psi through the differentiable gate applications, so that a second derivative sees it)
         # (under create_graph only; a first-order backward takes all factors in one fused pass)
-        legacy = torch._C._functorch.is_legacy_batchedtensor
+        legacy = _functorch.is_legacy_batched
         if (not torch.is_grad_enabled() and state.ndim == 2 and not _is_batched(state) and not _is_wrapped(g)
-                and not _is_wrapped(state) and not legacy(g) and not legacy(state) and not transform_stack()):
+                and not _is_wrapped(state) and not legacy(g) and not legacy(state) and _functorch.no_transforms()):
             return apply_pauli(state, ctx.xmask, ctx.zmask, scale=2.0 * g), None, None
         ppsi = apply_pauli(state, ctx.xmask, ctx.zmask, differentiable=torch.is_grad_enabled())
         return (2.0 * g).to(state.real.dtype).unsqueeze(-1) * ppsi, None, None

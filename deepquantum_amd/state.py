@@ -8,6 +8,7 @@ from typing import Any
 import torch
 from torch import nn
 
+from . import _functorch
 from .bitmath import is_power_of_2, log_base2, power_of_2
 from .communication import comm_get_rank, comm_get_world_size
 from .qmath import amplitude_encoding, is_density_matrix
@@ -17,6 +18,25 @@ from .utils import complex_apply
 def tensor_version(t: torch.Tensor):
     """``t._version``, or None for a tensor that has none (inference tensors)."""
     return None if torch.is_inference(t) else t._version
+
+
+_PRIVATE_REFCOUNT: list = []
+
+
+def _refcount_of_a_private_tensor() -> int:
+    """``sys.getrefcount`` of a tensor held by a dict and one local only -- the situation `_rearm` tests for -- measured
+    once on a throwaway tensor instead of assuming CPython's "3" (interpreters with borrowed stack references count
+    differently)."""
+    if not _PRIVATE_REFCOUNT:
+        import sys
+
+        def probe() -> int:
+            bufs = {'state': torch.zeros(1)}
+            t = dict.get(bufs, 'state')
+            return sys.getrefcount(t)
+
+        _PRIVATE_REFCOUNT.append(probe())
+    return _PRIVATE_REFCOUNT[0]
 
 
 class _ComplexBuffers(nn.Module):
@@ -88,7 +108,7 @@ class QubitState(_ComplexBuffers):
 
         bufs = self.__dict__['_buffers']
         t = dict.get(bufs, 'state')
-        if t is None or torch._C._functorch.is_functorch_wrapped_tensor(t):      # (made inside a torch.func transform)
+        if t is None or _functorch.is_wrapped_tensor(t):      # (made inside a torch.func transform)
             bufs.zero_mark = None
             return
         bufs.zero_mark = (weakref.ref(t), tensor_version(t), t.data_ptr())
@@ -124,10 +144,12 @@ class QubitState(_ComplexBuffers):
         t = dict.get(bufs, 'state')
         use_count = getattr(torch._C, '_storage_Use_Count', None)
         if (t is None or use_count is None or t.numel() == 0 or not t.is_complex() or torch.is_inference(t)
-                or torch._C._functorch.is_functorch_wrapped_tensor(t) or t.requires_grad):
+                or _functorch.is_wrapped_tensor(t) or t.requires_grad):
             bufs.rearm = False
             return
-        if sys.getrefcount(t) != 3:                  # the dict, ``t`` and the argument of getrefcount: somebody else holds it
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            return                                   # (stays pending: the look at the memory is a host synchronisation)
+        if sys.getrefcount(t) != _refcount_of_a_private_tensor():      # the dict, ``t`` and the argument: somebody else holds it
             return                                   # (stays pending: cheap, no device work)
         storage = t.untyped_storage()
         if use_count(storage._cdata) != 2:           # the tensor and ``storage``: a view / .data / numpy alias is alive

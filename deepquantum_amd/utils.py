@@ -6,6 +6,8 @@ from typing import Any, Callable
 
 import torch
 
+from . import _functorch
+
 # real dtype requested through nn.Module.to(...) -> complex dtype the buffers must take
 dtype_map = {torch.float: torch.cfloat, torch.double: torch.cdouble}
 
@@ -44,7 +46,7 @@ class BulkMove:
         for mod in root.modules():
             for t in mod._buffers.values() if type(mod._buffers) is dict else ():
                 if (t is not None and t.device.type == 'cpu' and 0 < t.numel() <= self.LIMIT and id(t) not in self.bulk
-                        and not torch._C._functorch.is_functorch_wrapped_tensor(t)):
+                        and not _functorch.is_wrapped_tensor(t)):
                     groups.setdefault(t.dtype, []).append(t)
                     self.bulk[id(t)] = t
         self.bulk.clear()
@@ -99,8 +101,16 @@ class CapturedGraph:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.output = fn()
+        # cache-owned device tensors the captured launches read (backend.pin_if_capturing): they live as long as this object
+        from . import backend
+
+        self._pins: dict = {}
+        backend._PIN_SINK.append(self._pins)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.output = fn()
+        finally:
+            backend._PIN_SINK.pop()
 
     def replay(self):
         self.graph.replay()

@@ -438,7 +438,8 @@ int dq_permute_bits_c128(const void* in, void* out, int nl, const int* src_of_ds
 /* ABI 24.  Two arrays of `count` amplitudes side by side along a NEW index bit 0: out[2 i] = a[i], out[2 i + 1] = b[i] --
  * how a fused reverse sweep (dq_apply_fused_grad_*) wants psi and the cotangent lambda, i.e. the final state of
  * circuit.py:261 and the gradient autograd hands back for it -- and the way back: out[i] = in[2 i + which].  `count`
- * even (all samples of a batch at once: count = batch * 2^n); out of place; full coalesced lines both ways. */
+ * even (all samples of a batch at once: count = batch * 2^n); out of place; full coalesced lines both ways.  All
+ * buffers 16-byte aligned (a complex64 view at an odd element offset is not: DQ_ERR_ARG). */
 int dq_interleave_c64(const void* a, const void* b, void* out, int64_t count, dq_stream_t stream);
 int dq_interleave_c128(const void* a, const void* b, void* out, int64_t count, dq_stream_t stream);
 int dq_deinterleave_c64(const void* in, void* out, int64_t count, int which, dq_stream_t stream);

@@ -876,8 +876,50 @@ def test_functorch_probes_are_guarded(monkeypatch):
     import torch._functorch.pyfunctorch as pf
 
     monkeypatch.delattr(pf, 'retrieve_all_functorch_interpreters')
-    assert ops.transform_stack() is None
+    with pytest.warns(RuntimeWarning, match='retrieve_all_functorch_interpreters'):
+        assert ops.transform_stack() is None
     ops._single_forward_level()          # (no refusal without the probe: it goes ahead)
+    from deepquantum_amd import _functorch as fx
+
+    assert fx.no_transforms() is False                      # ("unknown" is not "none": the conservative route)
+
+
+def test_every_functorch_probe_goes_through_the_one_guarded_helper(monkeypatch):
+    """VERDICT r5 (weak 10): no module but ``_functorch.py`` touches ``torch._C._functorch`` or functorch's interpreter
+    stack, and with the private probes gone the helper still tells a wrapper from a plain tensor (public fallback) and says
+    so in a warning instead of silently dropping the fused batching."""
+    import glob
+    import os
+    import re
+
+    import torch.func as tf
+
+    import deepquantum_amd
+    from deepquantum_amd import _functorch as fx
+
+    pkg = os.path.dirname(deepquantum_amd.__file__)
+    for path in glob.glob(os.path.join(pkg, '*.py')):
+        if os.path.basename(path) == '_functorch.py':
+            continue
+        code = '\n'.join(ln.split('#', 1)[0] for ln in open(path).read().splitlines())
+        assert not re.search(r'torch\._C\._functorch|retrieve_all_functorch_interpreters', code), path
+    seen = []
+
+    def f(x):
+        seen.append((fx.is_wrapped_tensor(x), fx.is_batched(x), fx.is_legacy_batched(x)))
+        return x.sum()
+
+    tf.vmap(f)(torch.ones(2, 3))
+    tf.grad(f)(torch.ones(3))
+    assert seen == [(True, True, False), (True, False, False)]
+    assert not fx.is_wrapped_tensor(torch.ones(2)) and fx.no_transforms()
+    monkeypatch.setattr(fx, '_C', None)
+    monkeypatch.setattr(fx, '_WARNED', set())
+    seen.clear()
+    with pytest.warns(RuntimeWarning, match='is_functorch_wrapped_tensor'):
+        tf.vmap(f)(torch.ones(2, 3))
+    assert seen == [(True, True, False)]                     # (data_ptr() refuses on a wrapper: the public fallback)
+    assert not fx.is_wrapped_tensor(torch.ones(2))
 
 
 def test_a_circuit_moves_its_small_buffers_in_bulk():

@@ -525,7 +525,10 @@ def test_captured_training_step_keeps_the_device_records_of_its_long_sweep_passe
     held = [t for st in dq.executor.LAST_RUN['plan'].steps if hasattr(st, 'desc')
             for t in st.desc.__dict__.get('_dev_records', {}).values() if t is not None]
     assert held, 'no pass of the captured sweep kept its records in device memory'
-    assert all(id(t) in dq.backend._CAPTURE_PINS for t in held)
+    # (the pins of a capture belong to ITS CapturedGraph and die with it; nothing the capture allocated itself --
+    # the matrix buffer of this trainable circuit -- is pinned)
+    assert all(id(t) in graph._pins for t in held)
+    assert all(getattr(t, '_dq_owned', False) for t in graph._pins.values())
     del held
     first = graph.replay().clone()
     dq.executor._PLAN_CACHE.clear()         # the plans (and with them the descriptors' own references) go away ...
