@@ -582,6 +582,30 @@ def main():
     if args.no_fold_permute:
         dq.distributed.CONFIG['fold_permute'] = False
 
+    # What the FIRST step of a fresh process pays before anything is timed (round 5's driver run: 11.7 s on a fresh box for
+    # a 0.2-s step): taken apart here, each piece forced and timed on its own -- the HIP runtime + torch's device set-up,
+    # this library's code object (2 MB, loaded at the first launch of one of its kernels), the first touch of the two
+    # state buffers (afterwards torch's caching allocator hands the same blocks to the step) -- and the planner below.
+    cold = None
+    if have_gpu and not args.functional and args.rehearse_rank is None and not multi:
+        cold = {}
+        t_c = time.perf_counter()
+        torch.zeros(1, device=device)
+        torch.cuda.synchronize(device)
+        cold['hip_runtime_and_torch_device_init_s'] = time.perf_counter() - t_c
+        t_c = time.perf_counter()
+        probe = torch.zeros(1, 4, dtype=dtype, device=device)
+        probe[0, 0] = 1
+        dq.backend.apply_gate(probe, torch.eye(2, dtype=dtype, device=device).reshape(1, 2, 2), [0], [], out=probe)
+        torch.cuda.synchronize(device)
+        cold['library_load_and_first_kernel_s'] = time.perf_counter() - t_c
+        t_c = time.perf_counter()
+        touch = [torch.empty(nbatch << n, dtype=dtype, device=device).zero_() for _ in range(2)]
+        torch.cuda.synchronize(device)
+        cold['allocate_and_first_touch_of_two_state_buffers_s'] = time.perf_counter() - t_c
+        cold['state_buffer_GiB_each'] = (nbatch << n) * amp_bytes / 2**30
+        del touch, probe
+
     spec = random_circuit_spec(n, args.depth, args.seed)
     extra = []
     if args.config in (4, 5):       # global control / local target, and local control / GLOBAL target
@@ -860,6 +884,9 @@ def main():
                 # structure, cached afterwards) and the whole first step including it and the allocations
                 'plan_seconds': plan_s,
                 'first_step_seconds': setup_s,
+                # (the pieces before it, each forced and timed on its own in this process; `first_step_seconds` is what is
+                # left: the planner -- `plan_seconds` -- matrix buffers, descriptors, the first launches)
+                'cold_start_seconds': cold,
                 'ms_per_step_hip_events_median': statistics.median(step_ms) if step_ms else None,
                 'ms_per_step_hip_events_min': min(step_ms) if step_ms else None,
             },

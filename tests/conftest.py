@@ -11,6 +11,38 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'gpu_slow: GPU parametrisations that repeat a representative which stays in `-m gpu` '
+                                       '(run them too with DQ_GPU_SLOW=1 or -m "gpu or gpu_slow")')
+
+
+#: Round 6: `pytest -m gpu` had grown to 643-656 s of the driver's 1200-s limit.  The parametrisations
+#: below are the expensive twins of cases that stay in the default run (named behind each); they run with DQ_GPU_SLOW=1 or
+#: when the -m expression mentions gpu_slow.  Durations: profiles/r06/gpu_suite_first_run.txt.
+GPU_SLOW = (
+    # 59.5 s (the oracle in complex128 at n = 20, 400 gates); stays: [20-400-7-c64], [18-300-6-c128], in_place[19-400-5-c128]
+    'test_wave_gpu.py::test_wave_passes_with_permuted_stores[20-400-7-c128]',
+    # 39 s; stays: test_config4_n32_on_four_ranks[0] (v = 0 is what the dry-run model picks), virtual_bits-2 / -4 at small n
+    'test_fullsize_gpu.py::test_config4_n32_on_four_ranks[2]',
+    # 12 + 10 s; stay: the n = 12, 14, 17 cases of the same test in both precisions
+    'test_wave_gpu.py::test_z_string_expectations_from_the_registers_on_gpu[21-3-c128]',
+    'test_wave_gpu.py::test_z_string_expectations_from_the_registers_on_gpu[21-3-c64]',
+    # 17.8 s; stay: golden-2 and golden-8 (the same reference-made shards, the smallest and the largest world)
+    'test_distributed_gpu.py::test_sharded_on_gpu[golden-4]',
+    # 11.3 s; stays: folded_permute-2
+    'test_distributed_gpu.py::test_sharded_on_gpu[folded_permute-4]',
+)
+
+
+def pytest_collection_modifyitems(config, items):
+    expr = config.getoption('-m') or ''
+    if 'gpu_slow' in expr or os.environ.get('DQ_GPU_SLOW'):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if any(it.nodeid.endswith(s) for s in GPU_SLOW) else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 @pytest.fixture()
