@@ -89,7 +89,11 @@ def parse_args():
     ap.add_argument('--overlap-groups', type=int, default=None, help='N > 1: sample groups of the overlapped remap')
     ap.add_argument('--virtual-bits', type=int, default=None,
                     help='N > 1, un-batched shards (--strong, --config 4 | 5): top local index bits treated as rank bits of '
-                         'a virtual world, so that the rows of a shard overlap exchange and compute (default: 2 there)')
+                         'a virtual world, so that the rows of a shard overlap exchange and compute (default: chosen per '
+                         'circuit by the library\'s dry-run model, distributed.choose_virtual_bits -- never worse than 0 by it)')
+    ap.add_argument('--no-local-first-exchange', action='store_true',
+                    help='N > 1, A/B: the first exchange behind reset() over the wire (round 5) instead of every rank '
+                         'computing rank 0\'s first stretch itself')
     ap.add_argument('--no-fold-permute', action='store_true',
                     help='N > 1, A/B: the re-labelling before an exchange as a pass of its own')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
@@ -494,8 +498,10 @@ def rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed
         'fused_launch_ms_sum_per_step': sum(kernel_ms) / args.steps if kernel_ms else None,
         'fused_launch_GBs': (sum(kernel_bytes) / (sum(kernel_ms) * 1e-3) / 1e9) if kernel_ms else None,
         'virtual_rank_bits': vb,
+        'virtual_bits_model': (D.virtual_bits_table([p_ for op_ in cir.operators for p_ in op_.prims(decompose=True)], n, per_gpu,
+                                                    fresh=True, restore=False) if nbatch == 1 else None),
         'schedule': {k_: st[k_] for k_ in ('remaps', 'virtual_remaps', 'folded_permutes', 'permute_passes', 'local_flushes',
-                                           'zero_shard_stretches', 'known_zero_stretches')},
+                                           'zero_shard_stretches', 'known_zero_stretches', 'local_first_exchanges')},
         'wire_model': {'peak_GBs_per_link': XGMI_LINK_GBS, 'remaps': wire,
                        'wire_ms_per_step_all_exposed': sum(w['wire_ms_at_peak_link_rate'] for w in wire),
                        'wire_ms_per_step_exposed_model': sum(w['exposed_ms_model'] for w in wire)},
@@ -575,10 +581,12 @@ def main():
         dq.executor.CONFIG['free_low'] = False
     if args.overlap_groups is not None:
         dq.distributed.CONFIG['overlap_groups'] = args.overlap_groups
-    if distributed and (args.virtual_bits is not None or rehearse):
-        # an un-batched shard has no samples to overlap its exchanges with: its rows take their place (the library's
-        # default under RCCL: 2; a rehearsal runs what the RCCL job would)
-        dq.distributed.CONFIG['virtual_bits'] = 2 if args.virtual_bits is None else args.virtual_bits
+    if distributed and args.virtual_bits is not None:
+        # an un-batched shard has no samples to overlap its exchanges with: its rows can take their place.  Default (None):
+        # the library chooses v per circuit from its dry-run model (a rehearsal runs what the RCCL job would choose)
+        dq.distributed.CONFIG['virtual_bits'] = args.virtual_bits
+    if args.no_local_first_exchange:
+        dq.distributed.CONFIG['first_exchange_local'] = False
     if args.no_fold_permute:
         dq.distributed.CONFIG['fold_permute'] = False
 
@@ -952,6 +960,10 @@ def main():
             prims_ = [p_ for op_ in cir.operators for p_ in op_.prims(decompose=True)]
             g_ = int(math.log2(world))
             line['config']['virtual_rank_bits'] = vb_
+            if batch is None:
+                line['config']['virtual_bits_model'] = dq.distributed.virtual_bits_table(
+                    prims_, n, n - g_, fresh=True, restore=not cir.lazy_layout)
+            line['config']['local_first_exchanges_per_step'] = dstats.get('local_first_exchanges')
             line['config']['exchange_plan'] = {
                 'with_virtual_bits': dq.distributed.count_exchange_steps(prims_, n, g_, virtual_bits=vb_, reorder=True),
                 'without': dq.distributed.count_exchange_steps(prims_, n, g_, virtual_bits=0, reorder=True) if vb_ else None}

@@ -71,7 +71,12 @@ CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_gr
           'elide_exchange': False,
           # a circuit that starts from reset() picks its FIRST qubit placement freely (`initial_placement`: |0..0> is the
           # same vector under every permutation of the qubits): the qubits needed last start on the rank bits.  A/B switch
-          'initial_placement': True}
+          'initial_placement': True,
+          # the FIRST exchange behind reset() without the wire (round 6): only rank 0 holds anything before it, so every
+          # rank computes rank 0's first stretch itself (same |0..0>, same gates as rank 0 sees them, the known-zero
+          # masks make it cheap) and keeps the chunk the all-to-all would have brought it; the other chunk slots are the
+          # zeros the other ranks would have sent.  No collective, no bytes on the links.  A/B switch
+          'first_exchange_local': True}
 
 #: the accumulator of the DQ_FG_GRAD reductions while a fused reverse sweep runs on a sharded (psi, lambda) pair
 #: (adjoint._sweep_fused_sharded): every local stretch hands its rows to the passes
@@ -80,7 +85,7 @@ _SWEEP: dict = {'grads': None}
 #: statistics of the last ``dist_apply_prims`` call (bench / tests)
 LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_permutes': 0, 'permute_passes': 0,
             'wire_bytes': 0, 'groups': 1, 'virtual_bits': 0, 'virtual_remaps': 0, 'zero_shard_stretches': 0,
-            'known_zero_stretches': 0}
+            'known_zero_stretches': 0, 'local_first_exchanges': 0}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -141,7 +146,8 @@ def _localize(state: DistributedQubitState, p: Prim) -> Prim | None | str:
     (the identity on the rows it does not act on)."""
     vb = _vbits(state)
     if vb == 0:
-        return _localize_at(state.log_num_amps_per_node, state.rank, p)
+        # (the first stretch behind reset() with CONFIG['first_exchange_local']: every rank computes what RANK 0 holds)
+        return _localize_at(state.log_num_amps_per_node, 0 if state.__dict__.get('_as_rank0') else state.rank, p)
     L = state.log_num_amps_per_node
     lr = L - vb
     if p.kind != 'diag' and any(t >= lr for t in p.targets):
@@ -343,6 +349,7 @@ def _flush(state: DistributedQubitState, pending: list[Prim], expect_z: dict | N
     _settle(state)
     fresh = state.__dict__.pop('_fresh_zero', False)
     state.__dict__.pop('_zero_shard', None)      # (a shard of zeros runs its passes here like anybody: zeros in, zeros out)
+    state.__dict__.pop('_as_rank0', None)        # (no exchange came: ranks != 0 ran rank 0's gates on zeros -- zeros out)
     kz = state.__dict__.pop('_known_zero_local', 0)
     if not pending:
         return
@@ -579,10 +586,16 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     # (with virtual rank bits the rows of rank 0's shard are |0..0> and zeros: the masks hold for both; the other ranks
     # have skipped every stretch since reset() -- `_remap_virtual` -- and receive their first amplitudes now)
     fresh = state.__dict__.pop('_fresh_zero', False)
+    as0 = state.__dict__.pop('_as_rank0', False)
     zeros = state.rank != 0 and (fresh or state.__dict__.pop('_zero_shard', False))
     state.__dict__.pop('_zero_shard', None)
     kz = state.__dict__.pop('_known_zero_local', 0)
     first_exchange = state.__dict__.pop('_behind_reset', False)
+    if as0 and fresh and first_exchange and vb == 0 and _live(state):
+        _first_exchange_local(state, pairs, rbits, pending, out_perm, identity, k, chunk)
+        _remap_bookkeeping(ph, pairs, rbits, out_perm, L)
+        state.__dict__['_known_zero_local'] = ((1 << k) - 1) << (L - k)
+        return
     if zeros:
         LAST_RUN['zero_shard_stretches'] += 1
     elif pending:
@@ -656,6 +669,44 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
         state.__dict__['_known_zero_local'] = ((1 << k) - 1) << (L - k)
 
 
+def _first_exchange_local(state: DistributedQubitState, pairs, rbits, pending: list[Prim], out_perm, identity: bool,
+                          k: int, chunk: int) -> None:
+    """The first exchange behind reset() without the wire (CONFIG['first_exchange_local']).  Before it only rank 0 holds
+    anything: the all-to-all would bring rank r chunk c(r) of RANK 0's shard (c(r) = r's bits on the exchanged rank bits),
+    landing in chunk slot 0 (the sender's code), and zeros from everybody else.  ``pending`` was localized as rank 0 sees
+    the gates (`_localize`, ``_as_rank0``), so every rank of rank 0's group computes that shard itself -- |0..0> in, the
+    known-zero masks on: a fraction of a pass -- keeps its chunk and zeroes the other slots.  Ranks of a group without
+    rank 0 (k < log2 W) would receive zeros only: they keep their zeros and run nothing."""
+    _settle(state)
+    leader = state.rank
+    code = 0
+    for i, r in enumerate(rbits):
+        code |= ((state.rank >> r) & 1) << i
+        leader &= ~(1 << r)
+    LAST_RUN['local_first_exchanges'] += 1
+    if leader != 0:
+        LAST_RUN['zero_shard_stretches'] += 1
+        pending.clear()
+        return
+    a, b = _view(state), _bview(state)
+    rows = slice(0, a.shape[0])
+    if state.rank != 0:
+        a[:, 0] = 1                       # rank 0's input: |0..0> (the rest of the shard is the zeros reset() left)
+    if pending:
+        LAST_RUN['local_flushes'] += 1
+    in_b = (_run_rows(a, b, pending, rows, None if identity else out_perm, zero=True)
+            if (pending or not identity) else False)
+    src, dst = (b, a) if in_b else (a, b)
+    dst[:, :chunk].copy_(src[:, code * chunk:(code + 1) * chunk])
+    dst[:, chunk:].zero_()
+    if not in_b:                          # the new shard lies in the receive buffer
+        state.amps, state.buffer = state.buffer, state.amps
+    pending.clear()
+    if not identity:
+        LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
+    LAST_RUN['groups'] = 1
+
+
 def _remap_bookkeeping(ph: list[int], pairs, rbits, out_perm, L: int) -> None:
     """Local qubits moved with the permutation; entering qubit i now is rank bit rbits[i]; leaving qubit i is local bit
     L - k + i."""
@@ -709,6 +760,11 @@ def _remap_virtual(state: DistributedQubitState, pairs, pending: list[Prim]) -> 
         state.__dict__['_vbits'] = vb
 
 
+#: index bits below this are the contiguous low bits of a complex64 tile (fusion.default_geometry: min_low = 4; 3 for
+#: complex128 -- the stricter bound serves both): `fusion._place_writes` folds a final permutation only if it fixes them
+_UNFOLDABLE_BELOW = 4
+
+
 def _next_use(prims: Sequence[Prim], start: int, n: int) -> list[int]:
     """Index of the next gate (>= start) acting NON-diagonally on each logical qubit (inf if none soon)."""
     inf = 1 << 60
@@ -749,8 +805,11 @@ def _plan_remap(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int, v:
     frozen = [ph[q] >= L and not mine(ph[q]) for q in range(n)]       # the other class: stays where it is
     # farthest next use first; ties: keep what already is global (less traffic), then qubits above the contiguous run
     # of a tile (moving a lower bit cannot ride on a fused pass's permuted store), then canonical order
+    # (a local qubit on the contiguous low bits of a tile cannot be moved by a fused pass's permuted store -- its remap
+    # would cost a re-labelling pass of its own: with CONFIG['evict_foldable'] such a qubit is evicted only when nothing else is left)
+    low = _UNFOLDABLE_BELOW if CONFIG.get('evict_foldable', True) else 0
     order = sorted((q for q in range(n) if not frozen[q]),
-                   key=lambda q: (-nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
+                   key=lambda q: (1 if (not is_glob[q] and ph[q] < low) else 0, -nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
     new_global = set(order[:g])
     assert not ({t for t in needed if not frozen[t]} & new_global), 'gate needs more local qubits than a shard has'
     leaving = [q for q in range(n) if is_glob[q] and q not in new_global]
@@ -766,7 +825,29 @@ def _plan_remap(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int, v:
     return pairs
 
 
-def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int, v: int = 0) -> list[Prim]:
+_ORDERS: dict = {}
+
+
+def _structure(prims: Sequence[Prim]) -> tuple:
+    """What the exchange schedule of a gate list depends on (no matrices): the key of the schedule caches."""
+    return tuple((p.kind, tuple(p.targets), tuple(p.controls), p.mode, tuple(p.order)) for p in prims)
+
+
+def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int, v: int = 0,
+                      structure: tuple | None = None) -> list[Prim]:
+    """`_order_indices` applied; the order is cached by the gate list's structure and the starting placement (round 6: it
+    is 10 ms of host time for the 1360 gates of the n = 34 benchmark circuit, in front of the step's first launch)."""
+    key = (structure if structure is not None else _structure(prims), tuple(ph0), n, L, v)
+    order = _ORDERS.get(key)
+    if order is None:
+        order = _order_indices(prims, ph0, n, L, v)
+        if len(_ORDERS) >= 16:
+            _ORDERS.pop(next(iter(_ORDERS)))
+        _ORDERS[key] = order
+    return [prims[i] for i in order]
+
+
+def _order_indices(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int, v: int = 0) -> list[int]:
     """The gate list in an order that needs far fewer exchanges: list scheduling over the commutation DAG of the
     circuit (`fusion._Dag`: two gates commute when on every shared qubit both act diagonally, or both as functions of
     X) -- every gate that is ready and local under the current placement runs; only when ALL ready gates wait for a
@@ -817,8 +898,9 @@ def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int,
             mine = lambda p_: p_ >= L             # noqa: E731
         is_glob = [mine(ph[q]) for q in range(n)]
         frozen = [ph[q] >= L and not mine(ph[q]) for q in range(n)]
+        low = _UNFOLDABLE_BELOW if CONFIG.get('evict_foldable', True) else 0
         cand = sorted((q for q in range(n) if not frozen[q]),
-                      key=lambda q: (-nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
+                      key=lambda q: (1 if (not is_glob[q] and ph[q] < low) else 0, -nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
         new_global = set(cand[:sum(is_glob)])
         leaving = [q for q in range(n) if is_glob[q] and q not in new_global]
         entering = [q for q in new_global if not is_glob[q]]
@@ -830,7 +912,7 @@ def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int,
             continue
         for lq, eq in zip(leaving, entering):
             ph[lq], ph[eq] = ph[eq], ph[lq]
-    return [prims[i] for i in order]
+    return order
 
 
 _PLACEMENTS: dict = {}
@@ -859,10 +941,12 @@ def _dry_canonicalize(ph: list[int], n: int, L: int) -> tuple[int, float]:
     return steps, vol
 
 
-def _dry_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, lr: int, v: int, restore: bool = False) -> tuple[int, float]:
+def _dry_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, lr: int, v: int, restore: bool = False,
+                trace: list | None = None) -> tuple[int, float]:
     """(exchanges of real rank bits, their volume in shards) of the remap schedule started from placement ``ph0`` -- the
     loop of `count_exchange_steps` without the statistics.  ``restore``: plus what the canonicalisation at the end of a
-    drop-in forward (``keep_layout=False``) costs from where the schedule leaves the qubits."""
+    drop-in forward (``keep_layout=False``) costs from where the schedule leaves the qubits.  ``trace``: a list that
+    receives one (k, trades real rank bits) per remap of the gate schedule, in order."""
     L = lr + v
     ph = list(ph0)
     order = _order_for_remaps(prims, ph, n, lr, v)
@@ -880,6 +964,8 @@ def _dry_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, lr: int, v: i
                     ph[q] = new_local[ph[q]]
             for j, (lq, eq) in enumerate(pairs):
                 ph[eq], ph[lq] = rb[j], lr - k + j
+            if trace is not None:
+                trace.append((k, rb[0] >= L))
             if rb[0] >= L:
                 steps += 1
                 vol += 1 - 0.5**k
@@ -891,7 +977,8 @@ def _dry_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, lr: int, v: i
     return steps, vol
 
 
-def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0, restore: bool = False) -> list[int]:
+def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0, restore: bool = False,
+                      structure: tuple | None = None) -> list[int]:
     """Where the qubits of a circuit that starts from |0..0> should sit at the start: |0..0> is the same vector under
     every permutation of the qubits (rank 0 holds the one non-zero amplitude at local index 0 in any of them), so the
     FIRST placement costs nothing -- no exchange, not even a re-labelling pass.  Candidates: the reference layout
@@ -913,7 +1000,7 @@ def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0, restore
     # (the tuple itself: a hash of strings is randomised per process, and a collision on one rank only would give the
     # ranks different placements)
     key = (n, L, v, bool(restore), CONFIG['horizon'], CONFIG['reorder'],
-           tuple((p.kind, tuple(p.targets), tuple(p.controls)) for p in prims))
+           structure if structure is not None else _structure(prims))
     hit = _PLACEMENTS.get(key)
     if hit is not None:
         return list(hit)
@@ -939,6 +1026,72 @@ def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0, restore
         _PLACEMENTS.pop(next(iter(_PLACEMENTS)))
     _PLACEMENTS[key] = list(best[2])
     return list(best[2])
+
+
+#: The dry-run cost model behind `choose_virtual_bits`, in units of ONE PASS over the shard (read + write at the rate the
+#: pass kernel reaches on a shard, 5.5 TB/s: profiles/r05/strong_rehearsal.txt).  A stretch boundary -- every remap, real
+#: or virtual -- costs `boundary_passes` under-filled passes (measured: 35 passes in 6 stretches against 28 for the
+#: unsharded plan of the same circuit); the wire of a k-qubit exchange of real rank bits takes shard / 2^k per link at
+#: `link_GBs`, of which only the first row's share 2^-v is exposed with v virtual bits (all of it with v = 0).
+MODEL = {'pass_GBs': 5500.0, 'link_GBs': 153.0, 'boundary_passes': 1.7}
+
+_VBITS: dict = {}
+
+
+def modelled_cost(trace: Sequence[tuple[int, bool]], v: int, first_is_local: bool) -> float:
+    """Cost of a remap schedule (`_dry_remaps(trace=...)`) in passes over the shard: see `MODEL`."""
+    wire_pass = MODEL['pass_GBs'] / (2.0 * MODEL['link_GBs'])       # one shard over ONE link, in passes
+    cost, first = 0.0, first_is_local and v == 0
+    for k, real in trace:
+        cost += MODEL['boundary_passes']
+        if real:
+            if first:               # the first exchange behind reset() without the wire: a copy of 2^-k and a memset
+                cost += 0.5
+            else:
+                cost += wire_pass / (1 << k) * (0.5 ** v)
+            first = False
+    return cost
+
+
+def choose_virtual_bits(prims: Sequence[Prim], n: int, L: int, candidates: Sequence[int] = (0, 1, 2), fresh: bool = False,
+                        restore: bool = False, structure: tuple | None = None) -> int:
+    """CONFIG['virtual_bits'] = None: v from the dry-run model (`modelled_cost`), never one the model puts behind v = 0
+    (round 5 defaulted to 2 under RCCL; its own rehearsal of n = 34 on 8 ranks had v = 2 SLOWER than v = 0 for the slowest
+    rank: the hidden wire was paid for with three times the launches and 60-70 ms of compute).  Every candidate's schedule
+    is dry-run from the placement it would start from; ties go to the smaller v.  A pure function of the gate list and
+    CONFIG: every rank chooses alike."""
+    return _choose_virtual_bits(prims, n, L, candidates, fresh, restore, structure)[0]
+
+
+def _choose_virtual_bits(prims, n, L, candidates=(0, 1, 2), fresh=False, restore=False, structure=None) -> tuple[int, dict]:
+    key = (n, L, tuple(candidates), fresh, restore, CONFIG['first_exchange_local'], CONFIG['initial_placement'],
+           tuple(sorted(MODEL.items())), structure if structure is not None else _structure(prims))
+    hit = _VBITS.get(key)
+    if hit is not None:
+        return hit
+    best, table = None, {}
+    for v in candidates:
+        if L - v < 1:
+            continue
+        ph = (initial_placement(prims, n, L, v, restore=restore, structure=structure)
+              if (fresh and CONFIG['initial_placement']) else list(range(n)))
+        trace: list = []
+        _dry_remaps(prims, ph, n, L - v, v, trace=trace)
+        cost = modelled_cost(trace, v, fresh and CONFIG['first_exchange_local'])
+        table[v] = {'cost_in_passes': cost, 'remaps_real': sum(1 for _, r in trace if r),
+                    'remaps_virtual': sum(1 for _, r in trace if not r)}
+        if best is None or cost < best[1] - 1e-9:
+            best = (v, cost)
+    if len(_VBITS) >= 16:
+        _VBITS.pop(next(iter(_VBITS)))
+    _VBITS[key] = (best[0] if best else 0, table)
+    return _VBITS[key]
+
+
+def virtual_bits_table(prims: Sequence[Prim], n: int, L: int, **kw) -> dict:
+    """The model's table behind `choose_virtual_bits` (bench.py prints it): {v: cost in passes, remaps}, and the choice."""
+    v, table = _choose_virtual_bits(prims, n, L, **kw)
+    return {'chosen': v, 'candidates': table, 'model': dict(MODEL)}
 
 
 def _remap_for(state: DistributedQubitState, prims: Sequence[Prim], i: int, pending: list[Prim]) -> None:
@@ -1077,11 +1230,19 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
         canonicalize(state)
     # virtual rank bits: an un-batched shard of a forward circuit, rows of at least one tile
     vb = CONFIG['virtual_bits']
+    tile = executor._geometry(state.amps.dtype == torch.complex128).m
+    eligible = mode == 'remap' and state.batch is None and _SWEEP['grads'] is None and state.amps.ndim == 1
     if vb is None:
-        vb = 2 if (state.amps.is_cuda and dist.is_initialized() and dist.get_backend() == 'nccl') else 0
+        # from the dry-run model, and only where an exchange can overlap with compute at all -- RCCL on device shards
+        # (asynchronous, on the group's own stream), or the rehearsal of such a job; gloo is synchronous and host-staged
+        overlaps = state.amps.is_cuda and (CONFIG['elide_exchange'] or (dist.is_initialized() and dist.get_backend() == 'nccl'))
+        vb = 0
+        if overlaps and eligible:
+            cands = [v for v in (0, 1, 2) if state.log_num_amps_per_node - v >= tile]
+            vb = choose_virtual_bits(prims, state.nqubit, state.log_num_amps_per_node, cands,
+                                     fresh=bool(state.__dict__.get('_fresh_zero')), restore=not keep_layout)
     vb = int(vb or 0)
-    if vb and not (mode == 'remap' and state.batch is None and _SWEEP['grads'] is None and state.amps.ndim == 1
-                   and state.log_num_amps_per_node - vb >= executor._geometry(state.amps.dtype == torch.complex128).m):
+    if vb and not (eligible and state.log_num_amps_per_node - vb >= tile):
         vb = 0
     LAST_RUN['virtual_bits'] = vb
     if mode != 'remap':
@@ -1090,9 +1251,13 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
     if vb:
         _settle(state)
         state.__dict__['_vbits'] = vb
+    if (mode == 'remap' and vb == 0 and CONFIG['first_exchange_local'] and state.__dict__.get('_fresh_zero')
+            and state.world_size > 1):
+        state.__dict__['_as_rank0'] = True       # (until the first exchange: `_remap` / `_flush` take it off)
     try:
         return _dist_apply_loop(state, prims, mode, keep_layout, expect_z)
     finally:
+        state.__dict__.pop('_as_rank0', None)
         if vb:
             _settle(state)
             state.__dict__.pop('_vbits', None)
@@ -1101,13 +1266,14 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
 def _dist_apply_loop(state: DistributedQubitState, prims: Sequence[Prim], mode: str, keep_layout: bool,
                      expect_z: Sequence[int] | None) -> DistributedQubitState:
     vb = _vbits(state)
+    structure = _structure(prims) if mode == 'remap' else None
     if (mode == 'remap' and CONFIG['initial_placement'] and state.__dict__.get('_fresh_zero') and _is_canonical(state)
             and state.world_size > 1):
         # behind reset(): the first placement is free (see `initial_placement`)
         state.__dict__['_phys'] = initial_placement(prims, state.nqubit, state.log_num_amps_per_node, vb,
-                                                    restore=not keep_layout)
+                                                    restore=not keep_layout, structure=structure)
     if mode == 'remap' and CONFIG['reorder']:
-        prims = _order_for_remaps(prims, _phys(state), state.nqubit, state.log_num_amps_per_node - vb, vb)
+        prims = _order_for_remaps(prims, _phys(state), state.nqubit, state.log_num_amps_per_node - vb, vb, structure)
     pending: list[Prim] = []
     i, nprims = 0, len(prims)
     while i < nprims:

@@ -359,9 +359,12 @@ def _virtual_bits_check(dq, rank, world, n, double):
     assert stats[(0, True)]['virtual_bits'] == 0 and stats[(0, True)]['virtual_remaps'] == 0
     # behind reset() every rank but the first holds zeros until the first exchange of REAL rank bits: it runs none of the
     # stretches before it, however many re-labellings of virtual bits come first
+    # (v = 0: the first exchange takes no wire since round 6 -- every rank computes rank 0's first stretch itself)
     for key, st_ in stats.items():
-        if st_['remaps'] > st_['virtual_remaps']:
+        if st_['remaps'] > st_['virtual_remaps'] and not st_['local_first_exchanges']:
             assert (st_['zero_shard_stretches'] >= 1) == (rank != 0), (key, rank, st_)
+        if key[0] == 0 and st_['remaps'] > 0:
+            assert st_['local_first_exchanges'] == 1, (key, rank, st_)
 
 
 def _case_virtual_bits_w2(dq, rank, world):
@@ -434,8 +437,11 @@ def _zero_state_check(dq, rank, world, n, batch, dtype=torch.complex64, device=N
     executor.CONFIG['permute_min_bits'] = 12
     try:
         out = {}
-        for on in (True, False):
+        # (zero-state masks on / off; with them: the first exchange without the wire -- every rank computes rank 0's first
+        # stretch and keeps its chunk, round 6 -- and over the wire as before)
+        for on, local_first in ((True, True), (True, False), (False, True)):
             executor.CONFIG['zero_state'] = on
+            D.CONFIG['first_exchange_local'] = local_first
             calls['zext'] = 0
             cir, _ = bench.build_circuit(dq, n, spec, batch, dtype, device or 'cpu', distributed=True)
             cir.lazy_layout = False
@@ -444,9 +450,18 @@ def _zero_state_check(dq, rank, world, n, batch, dtype=torch.complex64, device=N
                 ev = cir.expectation()
             stats = dict(D.LAST_RUN)
             amps = st.amps.reshape(-1, per).clone()
-            out[on] = (amps, ev.clone())
+            out[(on, local_first)] = (amps, ev.clone())
             assert stats['remaps'] >= 1, stats
-            if on:
+            if on and local_first:
+                # no rank sat the first stretch out (unless its exchange group does not hold rank 0: k < log2 W), nothing of
+                # the first exchange went over the wire, and EVERY rank ran masked passes
+                assert stats['local_first_exchanges'] == 1, (rank, stats)
+                assert stats['zero_shard_stretches'] in ((0,) if world == 2 else (0, 1)), (rank, stats)
+                assert stats['known_zero_stretches'] >= 1, (rank, stats)
+                if be is not None and device is None and stats['zero_shard_stretches'] == 0:
+                    assert calls['zext'] >= 1, (rank, calls)
+            elif on:
+                assert stats['local_first_exchanges'] == 0
                 assert stats['zero_shard_stretches'] == (1 if rank else 0), (rank, stats)
                 # ... and behind the first exchange EVERY rank knows that the qubits that came from the rank bits are still
                 # |0>: the stretch after it starts with their mask
@@ -462,9 +477,11 @@ def _zero_state_check(dq, rank, world, n, batch, dtype=torch.complex64, device=N
             err = (amps - ref[:, rank * per:(rank + 1) * per].to(amps.device)).abs().max().item()
             assert err < tol, f'rank {rank}, zero_state {on}: shard error {err}'
             assert (ev.reshape(-1) - ref_ev.reshape(-1).to(ev.device)).abs().max().item() < 10 * tol
-        assert torch.equal(out[True][0], out[False][0]) or (out[True][0] - out[False][0]).abs().max().item() < 1e-6
+        for key in ((True, True), (True, False)):
+            assert torch.equal(out[key][0], out[(False, True)][0]) or (out[key][0] - out[(False, True)][0]).abs().max().item() < 1e-6
     finally:
         executor.CONFIG.update(old)
+        D.CONFIG['first_exchange_local'] = True
         if be is not None and device is None:
             be.apply_fused = inner
 
@@ -630,7 +647,8 @@ def _case_folded_permute_w2(dq, rank, world):
                     assert D.LAST_RUN['folded_permutes'] > 0, D.LAST_RUN
                 else:
                     assert D.LAST_RUN['folded_permutes'] == 0 and D.LAST_RUN['permute_passes'] > 0, D.LAST_RUN
-            assert D.LAST_RUN['wire_bytes'] > 0
+            # (round 6: the first exchange behind reset() takes no wire -- `first_exchange_local` -- and may be the only one)
+            assert D.LAST_RUN['wire_bytes'] > 0 or D.LAST_RUN['local_first_exchanges'] > 0
         assert remaps[True] < remaps[False], remaps      # gates re-ordered along the commutation DAG: fewer exchanges
         assert lazy > 0, 'no run ended in a non-canonical qubit order: the lazy restore was not exercised'
     finally:
