@@ -787,7 +787,7 @@ class DistributedQubitCircuit(QubitCircuit):
             if self.init_state.batch != batch:
                 old = self.init_state._buffers['amps']
                 self.init_state = DistributedQubitState(self.nqubit, batch, device=old.device, dtype=old.dtype)
-            self.init_state.reset()
+            self.init_state.reset(lazy=True)       # (the shard is cleared only if the passes behind |0..0> cannot do without)
             fresh = True
         else:
             self.init_state = state

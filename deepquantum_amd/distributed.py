@@ -76,7 +76,11 @@ CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_gr
           # rank computes rank 0's first stretch itself (same |0..0>, same gates as rank 0 sees them, the known-zero
           # masks make it cheap) and keeps the chunk the all-to-all would have brought it; the other chunk slots are the
           # zeros the other ranks would have sent.  No collective, no bytes on the links.  A/B switch
-          'first_exchange_local': True}
+          'first_exchange_local': True,
+          # remaps evict to the rank bits only qubits whose move can ride on a fused pass (not on the contiguous low bits of
+          # a tile) while others are left: saves the re-labelling pass in front of such an exchange, at times for one more
+          # exchange.  None = per circuit, whichever the dry-run model prices lower (`choose_eviction`)
+          'evict_foldable': None}
 
 #: the accumulator of the DQ_FG_GRAD reductions while a fused reverse sweep runs on a sharded (psi, lambda) pair
 #: (adjoint._sweep_fused_sharded): every local stretch hands its rows to the passes
@@ -85,7 +89,7 @@ _SWEEP: dict = {'grads': None}
 #: statistics of the last ``dist_apply_prims`` call (bench / tests)
 LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_permutes': 0, 'permute_passes': 0,
             'wire_bytes': 0, 'groups': 1, 'virtual_bits': 0, 'virtual_remaps': 0, 'zero_shard_stretches': 0,
-            'known_zero_stretches': 0, 'local_first_exchanges': 0}
+            'known_zero_stretches': 0, 'local_first_exchanges': 0, 'zero_fills': 0}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -130,6 +134,24 @@ def _all_reduce(t: torch.Tensor) -> None:
     """Sum over the ranks (left out in a rehearsal: this rank's share stands for the whole)."""
     if not CONFIG['elide_exchange']:
         dist.all_reduce(t, dist.ReduceOp.SUM)
+
+
+def _materialize_zeros(state: DistributedQubitState) -> None:
+    """Real zeros where the shard is only LOGICALLY zero (``_lazy_zero`` of `DistributedQubitState.reset(lazy=True)`:
+    everything behind the first LAZY_HEAD amplitudes of every row; ``_zeros_owed = ('top', k)`` behind the first
+    exchange without the wire: chunk slots 1 .. 2^k - 1).  Called by whoever is about to read the shard without the
+    known-zero masks that make the garbage unreachable."""
+    d = state.__dict__
+    fresh = d.pop('_lazy_zero', False)
+    owed = d.pop('_zeros_owed', None)
+    if not fresh and owed is None:
+        return
+    rows = state._buffers['amps'].view(-1, state.num_amps_per_node)
+    if fresh or owed[0] == 'fresh':
+        rows[:, state.LAZY_HEAD:].zero_()
+    else:
+        rows[:, state.num_amps_per_node >> owed[1]:].zero_()
+    LAST_RUN['zero_fills'] += 1
 
 
 def _rank_controls_ok(state: DistributedQubitState, controls: Sequence[int]) -> bool:
@@ -319,19 +341,25 @@ def _rows_of(pending: Sequence[Prim], rows: slice, total: int) -> list[Prim]:
 
 
 def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: slice,
-              out_perm: Sequence[int] | None = None, expect_z: dict | None = None, zero: bool = False) -> bool:
+              out_perm: Sequence[int] | None = None, expect_z: dict | None = None, zero: bool = False,
+              need_zeros=None) -> bool:
     """Fused local passes on rows ``rows`` of the shard ``a`` with the receive buffer ``b`` as the second buffer of the
     permuted stores; afterwards local bit q sits at position out_perm[q].  Returns True if the result lives in ``b``.
     ``zero``: the rows are |0..0> (rank 0's shard right after ``reset()``): the first passes skip what is still known to be
     zero (executor.CONFIG['zero_state'])."""
     total = a.shape[0]
     x, y = a[rows], b[rows]
+    if need_zeros is not None and (_SWEEP['grads'] is not None or not (CONFIG['fold_permute'] or out_perm is None)):
+        need_zeros()                              # (routes below that take no masks)
+        need_zeros = None
     if _SWEEP['grads'] is not None:               # a stretch of a fused reverse sweep: reductions inside the passes
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel(),
                            grads=_SWEEP['grads'][rows])
     elif CONFIG['fold_permute'] or out_perm is None:
+        # (``need_zeros``: the shard holds garbage where it is logically zero; the executor calls it before anything reads
+        # there -- i.e. unless the known-zero masks of ``zero`` apply to this schedule from its first pass to its last)
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel(),
-                           expect_z=expect_z, zero_state=zero)
+                           expect_z=expect_z, zero_state=zero, need_zeros=need_zeros)
     else:                                         # A/B: the re-labelling as a pass of its own
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y)
         if out.data_ptr() not in (x.data_ptr(), y.data_ptr()):
@@ -351,13 +379,21 @@ def _flush(state: DistributedQubitState, pending: list[Prim], expect_z: dict | N
     state.__dict__.pop('_zero_shard', None)      # (a shard of zeros runs its passes here like anybody: zeros in, zeros out)
     state.__dict__.pop('_as_rank0', None)        # (no exchange came: ranks != 0 ran rank 0's gates on zeros -- zeros out)
     kz = state.__dict__.pop('_known_zero_local', 0)
+    zero = (fresh and state.rank == 0) or kz
+    lazy = bool(state.__dict__.get('_lazy_zero') or state.__dict__.get('_zeros_owed'))
+    if lazy and not (pending and zero):
+        _materialize_zeros(state)                # (nothing runs, or it runs unmasked: the logical zeros become real ones)
+        lazy = False
     if not pending:
         return
     LAST_RUN['local_flushes'] += 1
     LAST_RUN['known_zero_stretches'] += bool(kz)
     a, b = _view(state), _bview(state)
-    if _run_rows(a, b, pending, slice(0, a.shape[0]), expect_z=expect_z, zero=(fresh and state.rank == 0) or kz):
+    if _run_rows(a, b, pending, slice(0, a.shape[0]), expect_z=expect_z, zero=zero,
+                 need_zeros=(lambda: _materialize_zeros(state)) if lazy else None):
         state.amps, state.buffer = state.buffer, state.amps
+    state.__dict__.pop('_lazy_zero', None)       # (masked passes that ran through have written everything)
+    state.__dict__.pop('_zeros_owed', None)
     pending.clear()
 
 
@@ -600,6 +636,14 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
         LAST_RUN['zero_shard_stretches'] += 1
     elif pending:
         LAST_RUN['known_zero_stretches'] += bool(kz)
+    # logical zeros (a lazy reset, the first exchange without the wire): the masked passes of ONE group of rows may run on
+    # them -- the executor clears them itself if the masks do not apply; every other case gets real zeros first
+    lazy = bool(state.__dict__.get('_lazy_zero') or state.__dict__.get('_zeros_owed'))
+    if lazy and not (len(groups) == 1 and not zeros and (pending or not identity) and (fresh and state.rank == 0 or kz)
+                     and not (state.__dict__.get('_lazy_zero') and not fresh)):
+        _materialize_zeros(state)
+        lazy = False
+    need_zeros = (lambda: _materialize_zeros(state)) if lazy else None
     inflight_prev = {id(st): (st, works) for st, works in state.__dict__.pop('_inflight', [])}
     inflight, landed_in_a = [], []
     if pending:
@@ -612,8 +656,10 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
             if zeros:
                 in_b = False
             else:
-                in_b = (_run_rows(a, b, pending, rows, None if identity else out_perm, zero=fresh or kz)
+                in_b = (_run_rows(a, b, pending, rows, None if identity else out_perm, zero=fresh or kz, need_zeros=need_zeros)
                         if (pending or not identity) else False)
+                state.__dict__.pop('_lazy_zero', None)      # (ran through masked -- or were cleared: all is written)
+                state.__dict__.pop('_zeros_owed', None)
             src, dst = (b, a) if in_b else (a, b)
             works = []
             if _live(state):
@@ -686,21 +732,34 @@ def _first_exchange_local(state: DistributedQubitState, pairs, rbits, pending: l
     LAST_RUN['local_first_exchanges'] += 1
     if leader != 0:
         LAST_RUN['zero_shard_stretches'] += 1
+        _materialize_zeros(state)         # (a shard of zeros from here on: real ones)
         pending.clear()
         return
     a, b = _view(state), _bview(state)
     rows = slice(0, a.shape[0])
     if state.rank != 0:
-        a[:, 0] = 1                       # rank 0's input: |0..0> (the rest of the shard is the zeros reset() left)
+        a[:, 0] = 1                       # rank 0's input: |0..0> (the rest of the shard is zero -- really, or logically)
     if pending:
         LAST_RUN['local_flushes'] += 1
-    in_b = (_run_rows(a, b, pending, rows, None if identity else out_perm, zero=True)
-            if (pending or not identity) else False)
+    lazy = bool(state.__dict__.get('_lazy_zero'))
+    if pending or not identity:
+        in_b = _run_rows(a, b, pending, rows, None if identity else out_perm, zero=True,
+                         need_zeros=(lambda: _materialize_zeros(state)) if lazy else None)
+    else:
+        _materialize_zeros(state)
+        in_b = False
+    was_lazy = lazy and state.__dict__.pop('_lazy_zero', False)     # (still set: the masked passes ran through, all is written)
     src, dst = (b, a) if in_b else (a, b)
     dst[:, :chunk].copy_(src[:, code * chunk:(code + 1) * chunk])
-    dst[:, chunk:].zero_()
     if not in_b:                          # the new shard lies in the receive buffer
         state.amps, state.buffer = state.buffer, state.amps
+    if was_lazy:
+        # the other chunk slots -- the zeros the other ranks would have sent -- stay un-cleared: the next stretch starts
+        # with the known-zero mask of the k qubits that came from the rank bits and reads nothing there; whoever cannot
+        # vouch for that clears them first (`_materialize_zeros`)
+        state.__dict__['_zeros_owed'] = ('top', k)
+    else:
+        dst[:, chunk:].zero_()
     pending.clear()
     if not identity:
         LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
@@ -728,6 +787,7 @@ def _remap_virtual(state: DistributedQubitState, pairs, pending: list[Prim]) -> 
     vb = state.__dict__.pop('_vbits')
     try:
         _settle(state)
+        _materialize_zeros(state)
         L = state.log_num_amps_per_node
         ph = _phys(state)
         out_perm = list(range(L))
@@ -758,6 +818,11 @@ def _remap_virtual(state: DistributedQubitState, pairs, pending: list[Prim]) -> 
         LAST_RUN['virtual_remaps'] += 1
     finally:
         state.__dict__['_vbits'] = vb
+
+
+#: the eviction policy in force (set per call by `_dist_apply_prims` from CONFIG['evict_foldable']; None there = whichever
+#: the dry-run model prefers for the circuit at hand, `choose_eviction`)
+_EVICT = [True]
 
 
 #: index bits below this are the contiguous low bits of a complex64 tile (fusion.default_geometry: min_low = 4; 3 for
@@ -807,7 +872,7 @@ def _plan_remap(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int, v:
     # of a tile (moving a lower bit cannot ride on a fused pass's permuted store), then canonical order
     # (a local qubit on the contiguous low bits of a tile cannot be moved by a fused pass's permuted store -- its remap
     # would cost a re-labelling pass of its own: with CONFIG['evict_foldable'] such a qubit is evicted only when nothing else is left)
-    low = _UNFOLDABLE_BELOW if CONFIG.get('evict_foldable', True) else 0
+    low = _UNFOLDABLE_BELOW if (_EVICT[0] and L >= 12) else 0      # (shards of at least a tile)
     order = sorted((q for q in range(n) if not frozen[q]),
                    key=lambda q: (1 if (not is_glob[q] and ph[q] < low) else 0, -nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
     new_global = set(order[:g])
@@ -837,7 +902,7 @@ def _order_for_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int,
                       structure: tuple | None = None) -> list[Prim]:
     """`_order_indices` applied; the order is cached by the gate list's structure and the starting placement (round 6: it
     is 10 ms of host time for the 1360 gates of the n = 34 benchmark circuit, in front of the step's first launch)."""
-    key = (structure if structure is not None else _structure(prims), tuple(ph0), n, L, v)
+    key = (structure if structure is not None else _structure(prims), tuple(ph0), n, L, v, _EVICT[0])
     order = _ORDERS.get(key)
     if order is None:
         order = _order_indices(prims, ph0, n, L, v)
@@ -898,7 +963,7 @@ def _order_indices(prims: Sequence[Prim], ph0: Sequence[int], n: int, L: int, v:
             mine = lambda p_: p_ >= L             # noqa: E731
         is_glob = [mine(ph[q]) for q in range(n)]
         frozen = [ph[q] >= L and not mine(ph[q]) for q in range(n)]
-        low = _UNFOLDABLE_BELOW if CONFIG.get('evict_foldable', True) else 0
+        low = _UNFOLDABLE_BELOW if (_EVICT[0] and L >= 12) else 0
         cand = sorted((q for q in range(n) if not frozen[q]),
                       key=lambda q: (1 if (not is_glob[q] and ph[q] < low) else 0, -nxt[q], 0 if is_glob[q] else 1, 0 if ph[q] >= 4 else 1, -q))
         new_global = set(cand[:sum(is_glob)])
@@ -965,7 +1030,9 @@ def _dry_remaps(prims: Sequence[Prim], ph0: Sequence[int], n: int, lr: int, v: i
             for j, (lq, eq) in enumerate(pairs):
                 ph[eq], ph[lq] = rb[j], lr - k + j
             if trace is not None:
-                trace.append((k, rb[0] >= L))
+                # (k, trades real rank bits, the re-labelling in front of it can ride on a pass: no entering qubit on the
+                # contiguous low bits of a tile)
+                trace.append((k, rb[0] >= L, all(e >= _UNFOLDABLE_BELOW for e in ent) or lr < 12))
             if rb[0] >= L:
                 steps += 1
                 vol += 1 - 0.5**k
@@ -999,7 +1066,7 @@ def initial_placement(prims: Sequence[Prim], n: int, L: int, v: int = 0, restore
         return canonical
     # (the tuple itself: a hash of strings is randomised per process, and a collision on one rank only would give the
     # ranks different placements)
-    key = (n, L, v, bool(restore), CONFIG['horizon'], CONFIG['reorder'],
+    key = (n, L, v, bool(restore), CONFIG['horizon'], CONFIG['reorder'], _EVICT[0],
            structure if structure is not None else _structure(prims))
     hit = _PLACEMENTS.get(key)
     if hit is not None:
@@ -1042,8 +1109,10 @@ def modelled_cost(trace: Sequence[tuple[int, bool]], v: int, first_is_local: boo
     """Cost of a remap schedule (`_dry_remaps(trace=...)`) in passes over the shard: see `MODEL`."""
     wire_pass = MODEL['pass_GBs'] / (2.0 * MODEL['link_GBs'])       # one shard over ONE link, in passes
     cost, first = 0.0, first_is_local and v == 0
-    for k, real in trace:
+    for k, real, *rest in trace:
         cost += MODEL['boundary_passes']
+        if rest and not rest[0]:
+            cost += 1.0             # a re-labelling pass of its own in front of the exchange
         if real:
             if first:               # the first exchange behind reset() without the wire: a copy of 2^-k and a memset
                 cost += 0.5
@@ -1051,6 +1120,36 @@ def modelled_cost(trace: Sequence[tuple[int, bool]], v: int, first_is_local: boo
                 cost += wire_pass / (1 << k) * (0.5 ** v)
             first = False
     return cost
+
+
+_EVICTIONS: dict = {}
+
+
+def choose_eviction(prims: Sequence[Prim], n: int, L: int, v: int = 0, fresh: bool = False, restore: bool = False,
+                    structure: tuple | None = None) -> bool:
+    """CONFIG['evict_foldable'] = None: both eviction rules dry-run through the whole schedule, the cheaper one by
+    `modelled_cost` wins (ties: the foldable rule).  A pure function of the gate list: every rank chooses alike."""
+    key = (n, L, v, fresh, restore, CONFIG['first_exchange_local'], CONFIG['initial_placement'], tuple(sorted(MODEL.items())),
+           structure if structure is not None else _structure(prims))
+    hit = _EVICTIONS.get(key)
+    if hit is not None:
+        return hit
+    keep = _EVICT[0]
+    costs = {}
+    try:
+        for rule in (True, False):
+            _EVICT[0] = rule
+            ph = (initial_placement(prims, n, L, v, restore=restore, structure=structure)
+                  if (fresh and CONFIG['initial_placement']) else list(range(n)))
+            trace: list = []
+            _dry_remaps(prims, ph, n, L - v, v, trace=trace)
+            costs[rule] = modelled_cost(trace, v, fresh and CONFIG['first_exchange_local'])
+    finally:
+        _EVICT[0] = keep
+    if len(_EVICTIONS) >= 16:
+        _EVICTIONS.pop(next(iter(_EVICTIONS)))
+    _EVICTIONS[key] = costs[True] <= costs[False] + 1e-9
+    return _EVICTIONS[key]
 
 
 def choose_virtual_bits(prims: Sequence[Prim], n: int, L: int, candidates: Sequence[int] = (0, 1, 2), fresh: bool = False,
@@ -1064,7 +1163,7 @@ def choose_virtual_bits(prims: Sequence[Prim], n: int, L: int, candidates: Seque
 
 
 def _choose_virtual_bits(prims, n, L, candidates=(0, 1, 2), fresh=False, restore=False, structure=None) -> tuple[int, dict]:
-    key = (n, L, tuple(candidates), fresh, restore, CONFIG['first_exchange_local'], CONFIG['initial_placement'],
+    key = (n, L, tuple(candidates), fresh, restore, CONFIG['first_exchange_local'], CONFIG['initial_placement'], _EVICT[0],
            tuple(sorted(MODEL.items())), structure if structure is not None else _structure(prims))
     hit = _VBITS.get(key)
     if hit is not None:
@@ -1078,8 +1177,9 @@ def _choose_virtual_bits(prims, n, L, candidates=(0, 1, 2), fresh=False, restore
         trace: list = []
         _dry_remaps(prims, ph, n, L - v, v, trace=trace)
         cost = modelled_cost(trace, v, fresh and CONFIG['first_exchange_local'])
-        table[v] = {'cost_in_passes': cost, 'remaps_real': sum(1 for _, r in trace if r),
-                    'remaps_virtual': sum(1 for _, r in trace if not r)}
+        table[v] = {'cost_in_passes': cost, 'remaps_real': sum(1 for t_ in trace if t_[1]),
+                    'remaps_virtual': sum(1 for t_ in trace if not t_[1]),
+                    'relabelling_passes': sum(1 for t_ in trace if not t_[2])}
         if best is None or cost < best[1] - 1e-9:
             best = (v, cost)
     if len(_VBITS) >= 16:
@@ -1211,9 +1311,12 @@ def dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode: 
         if fresh_zero and executor.CONFIG['zero_state'] and _SWEEP['grads'] is None and _is_canonical(state):
             state.__dict__['_fresh_zero'] = True
             state.__dict__['_behind_reset'] = True      # (until the first exchange of real rank bits)
+        elif state.__dict__.get('_lazy_zero'):
+            _materialize_zeros(state)                   # (a lazy reset() nobody takes up: real zeros)
         try:
             return _dist_apply_prims(state, prims, mode, keep_layout, force_mode, expect_z)
         finally:
+            _materialize_zeros(state)                   # (a no-op unless logical zeros are left: nobody outside sees them)
             for key in ('_fresh_zero', '_zero_shard', '_behind_reset', '_known_zero_local'):
                 state.__dict__.pop(key, None)
 
@@ -1229,6 +1332,7 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
     if mode == 'pairwise' and not _is_canonical(state):
         canonicalize(state)
     # virtual rank bits: an un-batched shard of a forward circuit, rows of at least one tile
+    _EVICT[0] = True if CONFIG['evict_foldable'] is None else bool(CONFIG['evict_foldable'])
     vb = CONFIG['virtual_bits']
     tile = executor._geometry(state.amps.dtype == torch.complex128).m
     eligible = mode == 'remap' and state.batch is None and _SWEEP['grads'] is None and state.amps.ndim == 1
@@ -1244,6 +1348,9 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
     vb = int(vb or 0)
     if vb and not (eligible and state.log_num_amps_per_node - vb >= tile):
         vb = 0
+    if CONFIG['evict_foldable'] is None and mode == 'remap' and state.world_size > 1 and state.log_num_amps_per_node - vb >= 12:
+        _EVICT[0] = choose_eviction(prims, state.nqubit, state.log_num_amps_per_node, vb,
+                                    fresh=bool(state.__dict__.get('_fresh_zero')), restore=not keep_layout)
     LAST_RUN['virtual_bits'] = vb
     if mode != 'remap':
         state.__dict__.pop('_fresh_zero', None)       # (gate-by-gate exchanges: not for them)
@@ -1254,6 +1361,10 @@ def _dist_apply_prims(state: DistributedQubitState, prims: Sequence[Prim], mode:
     if (mode == 'remap' and vb == 0 and CONFIG['first_exchange_local'] and state.__dict__.get('_fresh_zero')
             and state.world_size > 1):
         state.__dict__['_as_rank0'] = True       # (until the first exchange: `_remap` / `_flush` take it off)
+    elif state.__dict__.get('_lazy_zero') and not (state.rank == 0 and state.__dict__.get('_fresh_zero') and mode == 'remap' and vb == 0):
+        # a lazily reset shard somebody will read unmasked: the ranks that hold zeros and send them over the wire, rows of
+        # virtual rank bits, gate-by-gate exchanges
+        _materialize_zeros(state)
     try:
         return _dist_apply_loop(state, prims, mode, keep_layout, expect_z)
     finally:

@@ -276,7 +276,7 @@ def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
 
 def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
         out_perm: Sequence[int] | None = None, amps: int | None = None, grads: torch.Tensor | None = None,
-        expect_z: dict | None = None, zero_state: bool | int = False) -> torch.Tensor:
+        expect_z: dict | None = None, zero_state: bool | int = False, need_zeros=None) -> torch.Tensor:
     """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state.
 
     ``zero_state``: the caller vouches that ``state`` is |0..0> (every row; ``QubitState.is_zero_state``) -- the first
@@ -289,14 +289,23 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
     ``scratch``, whichever the last pass wrote.  ``out_perm``: afterwards index bit b sits at position out_perm[b]
     (the re-labelling a shard exchange needs); the last pass writes it if it can, else one extra permute pass.
     ``amps``: amplitudes the plan will be run on in total when ``state`` is only a slice of them (the sample groups of
-    the sharded state): the planner's effort goes by the whole."""
+    the sharded state): the planner's effort goes by the whole.
+    ``need_zeros`` (the sharded state, round 6): ``state`` holds garbage where ``zero_state`` says it is zero; the callable
+    clears it and is called before anything could read there -- i.e. unless the known-zero masks apply to this schedule
+    from its first pass to its last (`fusion.zero_state_masks` vouches that the result is then written completely)."""
     if len(prims) == 0 and out_perm is None:
+        if need_zeros is not None:
+            need_zeros()
         return state
     if state.ndim != 2:
         raise ValueError('state must be (batch, 2**n)')
     if grads is not None:       # a stretch of a reverse sweep ('grad' prims reduce into ``grads``; the sharded state's)
+        if need_zeros is not None:
+            need_zeros()
         return _run_nograd(state, prims, inplace=inplace, scratch=scratch, out_perm=out_perm, grads=grads, amps=amps)
     if needs_autograd(state, prims):
+        if need_zeros is not None:
+            need_zeros()
         assert scratch is None and out_perm is None, 'scratch / out_perm are for no-grad runs'
         # (inside a torch.func transform -- vmap, grad, jacrev -- only the per-gate nodes compose)
         vmapped = ops._is_wrapped(state) or any(ops._is_wrapped(p.matrix) for p in prims)
@@ -350,10 +359,11 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
                     e['extra'][mkey] = both
             nextra = len(expect_z['masks'])
             acc = torch.zeros(state.shape[0], nextra, 8, dtype=torch.float64, device=state.device)
-            out = _run_nograd(state, both, inplace, scratch, out_perm, grads=acc, amps=amps, zero_state=zero_state)
+            out = _run_nograd(state, both, inplace, scratch, out_perm, grads=acc, amps=amps, zero_state=zero_state,
+                              need_zeros=need_zeros)
             expect_z['values'] = acc[:, :, 0]
             return out
-    return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps, zero_state=zero_state)
+    return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps, zero_state=zero_state, need_zeros=need_zeros)
 
 
 class _Meta(tuple):
@@ -544,7 +554,7 @@ def _permute_after(x: torch.Tensor, out_perm: Sequence[int], scratch: torch.Tens
 
 def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
                 out_perm: Sequence[int] | None = None, grads: torch.Tensor | None = None,
-                amps: int | None = None, zero_state: bool | int = False) -> torch.Tensor:
+                amps: int | None = None, zero_state: bool | int = False, need_zeros=None) -> torch.Tensor:
     """``grads``: the accumulator of the 'grad' prims (the reverse sweep of ``_AdjointCircuit``; complex64, n >= a tile).
     ``zero_state``: ``state`` is |0..0> (see ``run``)."""
     n = state.shape[-1].bit_length() - 1
@@ -554,11 +564,15 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         m = g_.m                 # the tile a fused pass runs on
         if len(prims) == 0:
             LAST_RUN['permute_folded'] = False
+            if need_zeros is not None:
+                need_zeros()
             return _permute_after(state, out_perm, scratch)
         if grads is not None:
             assert n >= m and CONFIG['fuse'], 'the fused reverse sweep needs a state of at least one tile'
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):
+            if need_zeros is not None:
+                need_zeros()
             out = _run_small(state, prims, n, m)
             return out if out_perm is None else _permute_after(out, out_perm, scratch)
         permute = False
@@ -599,6 +613,9 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                     zk and any(plan.prim_ops[oi].kind in ('grad', 'expz') for oi in st.ops)
                     for zk, st in zip(zmasks, plan.steps) if isinstance(st, fusion.FusedStep)):
                 zmasks = None           # (a reducing pass sums over the whole buffer)
+        if need_zeros is not None and (zmasks is None or not (permute and plan.steps.applied_final_perm or out_perm is None)
+                                       or not all(isinstance(st_, fusion.FusedStep) for st_ in plan.steps)):
+            need_zeros()                # (the masks do not carry this schedule from its first pass to its last: real zeros)
         if (state.shape[0] > 1 and state.stride(0) == 0 and state.stride(1) == 1 and plan.steps
                 and isinstance(plan.steps[0], fusion.FusedStep)):
             shared_in = state.detach()[:1]

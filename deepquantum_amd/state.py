@@ -313,6 +313,10 @@ class DistributedQubitState(_ComplexBuffers):
                     d['_building'] = False
         if name == 'amps':
             d = self.__dict__
+            if (d.get('_lazy_zero') or d.get('_zeros_owed')) and not d.get('_raw', 0):
+                from .distributed import _materialize_zeros      # (somebody outside the sharded routines looks: real zeros)
+
+                _materialize_zeros(self)
             ph = d.get('_phys')
             if ph is not None and not d.get('_raw', 0) and any(p != q for q, p in enumerate(ph)):
                 from .distributed import canonicalize
@@ -341,14 +345,35 @@ class DistributedQubitState(_ComplexBuffers):
         _ = self.amps          # (a saved shard is in the reference's qubit order)
         return super().state_dict(*args, **kwargs)
 
-    def reset(self) -> None:
+    #: amplitudes at the start of every row that a LAZY reset really zeroes (a complex64 tile; more than any first pass
+    #: reads of |0..0> -- one 16-byte piece)
+    LAZY_HEAD = 1 << 12
+    #: tests: a lazy reset fills what it leaves un-zeroed with NaN, so that a read of it cannot go unnoticed
+    POISON_LAZY = False
+
+    def reset(self, lazy: bool = False) -> None:
+        """|0..0>: rank 0 holds a single 1, everybody else zeros (reference: state.py:358-383, circuit.py:1655-1675).
+
+        ``lazy`` (round 6; only ``DistributedQubitCircuit.forward``, which hands the state to ``dist_run(fresh_zero=True)``
+        right away): the shard is NOT cleared -- a 16-GiB memset per step -- beyond its first `LAZY_HEAD` amplitudes; the
+        flag ``_lazy_zero`` tells `distributed.dist_apply_prims` that the rest is logically zero but holds whatever the
+        last step left.  The passes behind |0..0> neither read nor keep it (known-zero masks); whoever cannot vouch for
+        that clears it first (`distributed._materialize_zeros`)."""
         self.__dict__.pop('_phys', None)   # canonical qubit order (first: ``amps`` below must not trigger an exchange)
         self.__dict__.pop('_expz', None)   # (expectation values cached by a circuit's last pass)
+        self.__dict__.pop('_lazy_zero', None)
+        self.__dict__.pop('_zeros_owed', None)
         cur = self._buffers['amps']       # (read past the lazy-build hook of __getattr__: it calls us)
         if tuple(cur.shape) != tuple(self._shape):
             self.amps = torch.zeros(self._shape, dtype=cur.dtype, device=cur.device)
             self.buffer = torch.zeros_like(self._buffers['amps'])
+        elif lazy and self.num_amps_per_node > self.LAZY_HEAD:
+            rows = cur.view(-1, self.num_amps_per_node)
+            if self.POISON_LAZY:
+                rows[:, self.LAZY_HEAD:] = float('nan')
+            rows[:, :self.LAZY_HEAD] = 0
+            self.__dict__['_lazy_zero'] = True
         else:
             cur.zero_()             # (the receive buffer is scratch: every use writes all of what it then reads)
         if self.rank == 0:
-            self.amps[..., 0] = 1.0
+            self._buffers['amps'][..., 0] = 1.0
