@@ -94,6 +94,9 @@ def parse_args():
     ap.add_argument('--no-local-first-exchange', action='store_true',
                     help='N > 1, A/B: the first exchange behind reset() over the wire (round 5) instead of every rank '
                          'computing rank 0\'s first stretch itself')
+    ap.add_argument('--slice-exchange', type=int, default=None,
+                    help='N > 1, un-batched shards: bits the last pass in front of an exchange and the first pass behind it are '
+                         'sliced by (0 = off; default: 2 under RCCL and in a rehearsal, distributed.CONFIG[\'slice_exchange\'])')
     ap.add_argument('--no-fold-permute', action='store_true',
                     help='N > 1, A/B: the re-labelling before an exchange as a pass of its own')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')
@@ -476,14 +479,29 @@ def rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed
     per_step = len(kernel_ms) / args.steps
     vb = st.get('virtual_bits', 0)
     wire = []
+    # one pass over the whole shard on this rank (read + write at the rate its fused launches reached)
+    full_pass_ms = (2 * shard_bytes / (sum(kernel_bytes) / (sum(kernel_ms) * 1e-3)) * 1e3) if kernel_ms else None
+    contention_ms = 0.0
     for row in remap_rows or []:
         k = row['qubits_exchanged']
         # a k-qubit remap: 2^k - 1 peers, one chunk of shard / 2^k to each over its own link, both directions at once
         t_ms = shard_bytes / (1 << k) / (XGMI_LINK_GBS * 1e9) * 1e3
+        exposed = t_ms / (1 << vb) if vb else t_ms
+        sl, sf, nsl = row.get('slices_last') or 0, row.get('slices_first') or 0, row.get('slices') or 0
+        if nsl and full_pass_ms:
+            # a sliced exchange: the last pass in `sl` launches, the first pass behind it in `sf`; the wire of
+            # slice j runs while slice j + 1 computes / while slice j - 1 is already computed on: what stays exposed is the
+            # wire less the (1 - 1/S) of either pass it runs beside, and never less than one protocol slice's share
+            hidden = full_pass_ms * ((1 - 1 / sl) if sl > 1 else 0.0) + full_pass_ms * ((1 - 1 / sf) if sf > 1 else 0.0)
+            exposed = max(t_ms - hidden, t_ms / nsl)
+            # ... and the hidden part is not free: its bytes cross this GPU's HBM (read to send, written on arrival) while
+            # the passes want all of it
+            contention_ms += (t_ms - exposed) / t_ms * 2 * (1 - 0.5 ** k) * shard_bytes / (sum(kernel_bytes) / (sum(kernel_ms) * 1e-3)) * 1e3
         wire.append({'remap': row['remap'], 'qubits_exchanged': k, 'links': (1 << k) - 1,
                      'wire_ms_at_peak_link_rate': t_ms,
                      # with 2^v rows of the shard in flight one after the other only the first row's share is not hidden
-                     'exposed_ms_model': t_ms / (1 << vb) if vb else t_ms,
+                     'exposed_ms_model': exposed,
+                     'protocol_slices': nsl or None, 'launches_of_the_last_pass': sl or None, 'launches_of_the_first_pass_behind': sf or None,
                      'local_passes_ms_median_per_row_group': row['local_passes_ms_median'], 'row_groups': row['samples'] // args.steps})
     ms = elapsed / args.steps * 1e3
     return {
@@ -501,11 +519,16 @@ def rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed
         'virtual_bits_model': (D.virtual_bits_table([p_ for op_ in cir.operators for p_ in op_.prims(decompose=True)], n, per_gpu,
                                                     fresh=True, restore=False) if nbatch == 1 else None),
         'schedule': {k_: st[k_] for k_ in ('remaps', 'virtual_remaps', 'folded_permutes', 'permute_passes', 'local_flushes',
-                                           'zero_shard_stretches', 'known_zero_stretches', 'local_first_exchanges')},
+                                           'zero_shard_stretches', 'known_zero_stretches', 'local_first_exchanges',
+                                           'sliced_remaps', 'slice_launches_last', 'slice_launches_first', 'zero_fills')},
         'wire_model': {'peak_GBs_per_link': XGMI_LINK_GBS, 'remaps': wire,
                        'wire_ms_per_step_all_exposed': sum(w['wire_ms_at_peak_link_rate'] for w in wire),
                        'wire_ms_per_step_exposed_model': sum(w['exposed_ms_model'] for w in wire)},
         'modelled_step_ms': ms + sum(w['exposed_ms_model'] for w in wire),
+        'full_pass_ms_on_this_shard': full_pass_ms,
+        'hbm_contention_ms_of_the_hidden_wire_model': contention_ms,
+        'modelled_step_ms_with_hbm_contention': ms + sum(w['exposed_ms_model'] for w in wire) + contention_ms,
+        'slice_exchange_bits': D.slice_bits_wanted(cir.init_state) if hasattr(cir, 'init_state') else None,
         'plan_seconds': plan_s, 'first_step_seconds': setup_s,
     }
 
@@ -587,6 +610,8 @@ def main():
         dq.distributed.CONFIG['virtual_bits'] = args.virtual_bits
     if args.no_local_first_exchange:
         dq.distributed.CONFIG['first_exchange_local'] = False
+    if args.slice_exchange is not None:
+        dq.distributed.CONFIG['slice_exchange'] = args.slice_exchange
     if args.no_fold_permute:
         dq.distributed.CONFIG['fold_permute'] = False
 
@@ -686,7 +711,8 @@ def main():
             med = lambda key: (sorted(x[key] for x in rows_ if key in x) or [None])[len([x for x in rows_ if key in x]) // 2]   # noqa: E731
             remap_rows.append({'remap': r_, 'qubits_exchanged': rows_[0]['k'], 'bytes_each_way_per_group': rows_[0]['bytes'],
                                'local_passes_ms_median': med('local_ms'), 'issue_to_wait_passed_ms_median': med('wire_ms'),
-                               'samples': len(rows_)})
+                               'samples': len(rows_), 'slices': rows_[0].get('slices'),
+                               'slices_last': med('slices_last'), 'slices_first': med('slices_first')})
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DQHIP_LIBRARY') or os.path.join(_HERE, 'libdqhip.so')
 
 DQ_OK = 0
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 # enum DqFusedKind / DqBitLoc (include/dq_hip.h)
 FG_GEN1, FG_X1, FG_DIAG1, FG_GEN2, FG_DIAG2, FG_RESERVED5, FG_GRAD, FG_EXPZ = range(8)
@@ -107,6 +107,7 @@ _SIGNATURES = {
     'dq_apply_fused_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp]),
     'dq_apply_fused_bcast_{s}': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp]),
     'dq_apply_fused_zext_{s}': (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _u64, _vp]),
+    'dq_apply_fused_slice_{s}': (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _u64, _u64, _u64, _vp]),
     'dq_defer_rx_c64': (_i, [_vp, _i64, _vp, _i64, _i64, _vp]),
     'dq_apply_fused_grad_c64': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp, _i64, _vp]),
     'dq_apply_fused_grad_c128': (_i, [_vp, _vp, _vp, _i64, _i, _i64, C.POINTER(DqFusedPass), _vp, _i64, _vp]),

@@ -224,19 +224,24 @@ def apply_fused(
     out: torch.Tensor | None = None,
     grads: torch.Tensor | None = None,
     known_zero: int = 0,
+    slice_bits: tuple[int, int] | None = None,
 ) -> torch.Tensor:
     """Run one fused pass (see fusion.py).  ``mats``: flat complex buffer (Bm * stride or stride).
     ``state`` with ONE row and ``out`` with B rows: the single input state is shared by all outputs.
     ``grads`` (float64, (B, rows, 8), added to): a pass of the adjoint method's reverse sweep -- its DQ_FG_GRAD
     records reduce into it (include/dq_hip.h, dq_apply_fused_grad_c64 / _c128).
     ``known_zero``: index bits (read side) known to be |0> in ``state`` -- it is not read where one of them is 1, and
-    ``out`` is not written where such a bit outside the tile is 1 (include/dq_hip.h, dq_apply_fused_zext_*)."""
+    ``out`` is not written where such a bit outside the tile is 1 (include/dq_hip.h, dq_apply_fused_zext_*).
+    ``slice_bits = (mask, value)``: ONE SLICE of the pass -- only the tiles whose index bits ``mask`` (read side, outside the
+    tile) equal ``value`` run (include/dq_hip.h, dq_apply_fused_slice_*)."""
     n = _nqubit(state)
     if out is None:
         out = state
     broadcast = state.shape[0] == 1 and out.shape[0] > 1
     if known_zero and grads is not None:
         raise ValueError('a reducing pass takes no known-zero bits')
+    if slice_bits is not None and (grads is not None or out.shape[0] > MAX_BATCH):
+        raise ValueError('a slice of a pass: no reducing pass, at most MAX_BATCH samples')
     if mats.dtype != state.dtype or mats.device != state.device or not mats.is_contiguous():
         raise ValueError('mats must be a contiguous buffer in the dtype/device of the state')
     if grads is not None:
@@ -247,6 +252,8 @@ def apply_fused(
         src = state.expand(out.shape[0], -1) if broadcast else state
         if grads is not None:
             return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out, grads=grads)
+        if slice_bits is not None:
+            return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out, known_zero=known_zero, slice_bits=slice_bits)
         if known_zero:
             return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out, known_zero=known_zero)
         return _test_backend.apply_fused(src, mats, mat_batch_stride, desc, out)
@@ -276,6 +283,12 @@ def apply_fused(
         return out
     lib = _lib.load()
     pin_if_capturing(mats)
+    if slice_bits is not None:
+        fn = lib.dq_apply_fused_slice_c128 if state.dtype == torch.complex128 else lib.dq_apply_fused_slice_c64
+        rc = fn(_ptr(state), 0 if broadcast else 1 << n, _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0],
+                C.byref(desc), int(known_zero), int(slice_bits[0]), int(slice_bits[1]), _stream(state))
+        _lib.check(rc, 'dq_apply_fused_slice')
+        return out
     if known_zero:
         fn = lib.dq_apply_fused_zext_c128 if state.dtype == torch.complex128 else lib.dq_apply_fused_zext_c64
         rc = fn(_ptr(state), 0 if broadcast else 1 << n, _ptr(out), _ptr(mats), int(mat_batch_stride), n, out.shape[0],

@@ -216,6 +216,46 @@ def exchange_chunks(recv: torch.Tensor, send: torch.Tensor, peers: list[int], ch
     return ex
 
 
+def exchange_pieces(recv: list[torch.Tensor], send: list[torch.Tensor], peers: list[int], what: str,
+                    async_op: bool = False) -> Exchange | None:
+    """One SLICE of a k-qubit remap (round 6; `distributed._remap` with the last pass in slices): piece c of ``send`` goes
+    to rank ``peers[c]`` and what that rank sends back lands in piece c of ``recv`` -- real, contiguous tensors, one per
+    member of the 2^k group (this rank's own piece is copied locally).  One coalesced batch of point-to-point operations
+    (RCCL: one group call); gloo with device memory (ranks sharing a GPU in the test-suite): staged through the host.
+    Returns the handle to wait on (``async_op``) or None when everything has completed."""
+    me = dist.get_rank()
+    assert len(send) == len(recv) == len(peers)
+    staged = send[0].is_cuda and dist.get_backend() == 'gloo'
+    ops, back = [], []
+    for c, peer in enumerate(peers):
+        ps, pr = send[c], recv[c]
+        assert ps.is_contiguous() and pr.is_contiguous() and ps.shape == pr.shape
+        if peer == me:
+            pr.copy_(ps)
+            continue
+        if staged:
+            hs, hr = ps.cpu(), torch.empty(pr.shape, dtype=pr.dtype)
+            back.append((pr, hr))
+            ps, pr = hs, hr
+        ops.append(dist.P2POp(dist.isend, ps, peer))
+        ops.append(dist.P2POp(dist.irecv, pr, peer))
+    if not ops:
+        return None
+    works = dist.batch_isend_irecv(ops)
+    COMM_STATS['collectives'] += 1
+    COMM_STATS['p2p_ops'] += len(ops)
+    COMM_STATS['staged'] += int(staged)
+    ex = Exchange(list(works), what, send[0].device)
+    _watch(ex)
+    if staged or not async_op:
+        ex.wait()
+        for pr, hr in back:
+            pr.copy_(hr)
+        if staged or not send[0].is_cuda:
+            return None
+    return ex
+
+
 def comm_exchange_arrays(send_data: torch.Tensor, recv_data: torch.Tensor, pair_rank: int | None) -> None:
     """Pairwise exchange with ``pair_rank``.  Every rank of the group must call it for every exchange
     step (ranks with nothing to move pass ``pair_rank=None``): it is expressed as one

@@ -82,7 +82,7 @@ inline hipStream_t as_stream(dq_stream_t s) { return reinterpret_cast<hipStream_
 // The wave-tile geometry of complex64 passes (csrc/dq_wave.hip); `pass` has been validated by dq_pass.hip.
 // (`known_zero`: index bits, read side, known to be |0> in the input -- dq_apply_fused_zext_*; 0 = none)
 int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                    const DqFusedPass* pass, hipStream_t s, uint64_t known_zero = 0);
+                    const DqFusedPass* pass, hipStream_t s, uint64_t known_zero = 0, uint64_t slice_mask = 0, uint64_t slice_value = 0);
 int wave_launch_grad_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads, const void* ext_rec = nullptr,
                          int64_t ext_bytes = 0);
@@ -90,7 +90,7 @@ int wave_launch_grad_c128(const void* in, void* out, const void* mats, int64_t m
                           const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads, const void* ext_rec = nullptr,
                           int64_t ext_bytes = 0);
 int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                     const DqFusedPass* pass, hipStream_t s, uint64_t known_zero = 0);
+                     const DqFusedPass* pass, hipStream_t s, uint64_t known_zero = 0, uint64_t slice_mask = 0, uint64_t slice_value = 0);
 
 // Validate target/control bit lists: in range, pairwise distinct.
 int validate_bits(int n, const int* targets, int k, const int* controls, int nc);

@@ -220,7 +220,8 @@ static int validate_pass(const DqFusedPass* p, int n, int slots, int logt, int64
 template <typename T>
 static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_bstride, int n, int64_t batch,
                       const DqFusedPass* pass, dq_stream_t stream, bool broadcast_in = false, double* grads = nullptr,
-                      int64_t ngrads = -1, uint64_t known_zero = 0, const void* ext_rec = nullptr, int64_t ext_bytes = 0) {
+                      int64_t ngrads = -1, uint64_t known_zero = 0, const void* ext_rec = nullptr, int64_t ext_bytes = 0,
+                      uint64_t slice_mask = 0, uint64_t slice_value = 0) {
     const int64_t in_bstride = broadcast_in ? 0 : (int64_t)1 << n;
     if (broadcast_in && in == out) {
         set_error("dq_apply_fused_bcast: the shared input state cannot be the output buffer");
@@ -274,14 +275,26 @@ static int fused_impl(const void* in, void* out, const void* mats, int64_t mat_b
             return DQ_ERR_ARG;
         }
     }
+    if (slice_mask) {
+        // a slice of the pass: index bits (read side) outside the tile, not known zero, held at slice_value
+        uint64_t tilemask = (1ull << pass->L) - 1ull;
+        for (int i = 0; i < pass->h; ++i) tilemask |= 1ull << pass->high_pos[i];
+        if ((n < 64 && (slice_mask >> n)) || (slice_mask & tilemask) || (slice_mask & known_zero) || (slice_value & ~slice_mask) ||
+            ngrads >= 0) {
+            set_error("dq_apply_fused_slice: slice_mask = 0x%llx must name index bits < n = %d outside the tile of the pass and outside "
+                      "known_zero, slice_value = 0x%llx a subset of it (and the pass no reverse-sweep pass)",
+                      (unsigned long long)slice_mask, n, (unsigned long long)slice_value);
+            return DQ_ERR_ARG;
+        }
+    }
     hipStream_t s = as_stream(stream);
     // one wavefront per tile: csrc/dq_wave.hip
     if (ngrads >= 0) {
         if constexpr (is128) return wave_launch_grad_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads, ext_rec, ext_bytes);
         else return wave_launch_grad_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads, ext_rec, ext_bytes);
     }
-    if constexpr (is128) return wave_launch_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, known_zero);
-    else return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, known_zero);
+    if constexpr (is128) return wave_launch_c128(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, known_zero, slice_mask, slice_value);
+    else return wave_launch_c64(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, known_zero, slice_mask, slice_value);
 }
 
 }  // namespace dq
@@ -381,6 +394,31 @@ extern "C" int dq_apply_fused_zext_c128(const void* in, int64_t in_batch_stride,
         return DQ_ERR_ARG;
     }
     return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, in_batch_stride == 0, nullptr, -1, known_zero);
+}
+
+// ABI 25.  ONE SLICE of a pass: only the tiles whose index bits `slice_mask` (read side; outside the tile, not in
+// known_zero) equal `slice_value` run -- 2^popcount(slice_mask) such launches are the whole pass.  The sharded state
+// launches the last pass in front of an exchange and the first pass behind it slice by slice, so that the wire can start
+// after the first slice and the next stretch with the first slice that has arrived.
+extern "C" int dq_apply_fused_slice_c64(const void* in, int64_t in_batch_stride, void* out, const void* mats, int64_t mat_batch_stride,
+                                        int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, uint64_t slice_mask,
+                                        uint64_t slice_value, dq_stream_t stream) {
+    if (in_batch_stride != 0 && (n < 0 || n > 62 || in_batch_stride != (int64_t)1 << n)) {
+        dq::set_error("dq_apply_fused_slice_c64: in_batch_stride is 0 (one shared input state) or 2^n");
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<float>(in, out, mats, mat_batch_stride, n, batch, pass, stream, in_batch_stride == 0, nullptr, -1, known_zero,
+                                 nullptr, 0, slice_mask, slice_value);
+}
+extern "C" int dq_apply_fused_slice_c128(const void* in, int64_t in_batch_stride, void* out, const void* mats, int64_t mat_batch_stride,
+                                         int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, uint64_t slice_mask,
+                                         uint64_t slice_value, dq_stream_t stream) {
+    if (in_batch_stride != 0 && (n < 0 || n > 62 || in_batch_stride != (int64_t)1 << n)) {
+        dq::set_error("dq_apply_fused_slice_c128: in_batch_stride is 0 (one shared input state) or 2^n");
+        return DQ_ERR_ARG;
+    }
+    return dq::fused_impl<double>(in, out, mats, mat_batch_stride, n, batch, pass, stream, in_batch_stride == 0, nullptr, -1, known_zero,
+                                  nullptr, 0, slice_mask, slice_value);
 }
 
 // ---- the deferred-Rx form of a pass's matrix buffer (DQ_MODE_RX, include/dq_hip.h) ----------------------------------

@@ -91,7 +91,10 @@ struct WaveKernPass {
     // in the input: dq_apply_fused_zext_*); bits 8..13 / 16..21: the physical register slots / lane bits of the load
     // layout that hold such bits (nothing is loaded where one of them is 1: the registers are zero)
     uint32_t zext;
-    uint32_t reserved[7];
+    // dq_apply_fused_slice_*: index bits outside the tile that are NOT bits of the tile number either but held at a value --
+    // OR-ed into every tile's read / write base (64 bits each, low word first); zero for a whole pass
+    uint32_t fix_read[2], fix_write[2];
+    uint32_t reserved[3];
     WaveRec rec[WAVE_MAX_REC];
 };
 static_assert(offsetof(WaveKernPass, store_off) == 40 && offsetof(WaveKernPass, load_lane_shift) == 80 &&
@@ -180,6 +183,11 @@ __global__ __launch_bounds__(256) void wave_pass_kernel(const vec2<typename W::r
             tg |= bit << ((rw >> (8 * k)) & 0x3fu);
             tw |= bit << ((sw >> (8 * k)) & 0x3fu);
         }
+    }
+    {   // a slice of a pass (dq_apply_fused_slice_*): the index bits it holds fixed
+        const uint32_t fo = offsetof(WaveKernPass, fix_read) / 4;
+        tg |= (uint64_t)hw[fo] | ((uint64_t)hw[fo + 1] << 32);
+        tw |= (uint64_t)hw[fo + 2] | ((uint64_t)hw[fo + 3] << 32);
     }
     // (the kernel's own arguments too, through the laundered pointer: re-read per tile instead of held across the assembly)
     typedef const __attribute__((address_space(4))) uint64_t* KQuads;
@@ -343,8 +351,11 @@ struct Xlate {
 // `dead`: index bits (read side) known to be |0> in the input (dq_apply_fused_zext_*; 0 = none).  Outside the tile they
 // drop out of the tile number -- the tiles in which one of them is 1 are all zero: neither read nor written --, inside
 // the tile the loads leave the registers of their 1-halves zero.
+// `fixm` / `fixv` (dq_apply_fused_slice_*): index bits outside the tile (read side) held at the value `fixv` gives them: they
+// drop out of the tile number too, and every tile's read and write bases get them OR-ed in (fix_read / fix_write).
 template <class W>
-static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k, uint64_t dead = 0, WaveRec* ext = nullptr, int ext_cap = 0) {
+static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k, uint64_t dead = 0, WaveRec* ext = nullptr, int ext_cap = 0,
+                          uint64_t fixm = 0, uint64_t fixv = 0) {
     memset(k, 0, sizeof(*k));
     const int L = p->L, h = p->h;
     auto rpos = [&](int tl) { return tl < L ? tl : (int)p->high_pos[tl - L]; };
@@ -367,15 +378,25 @@ static int wave_translate(const DqFusedPass* p, int n, WaveKernPass* k, uint64_t
         uint64_t tilemask = (1ull << L) - 1ull;
         for (int i = 0; i < h; ++i) tilemask |= 1ull << p->high_pos[i];
         int nb = 0;
+        uint64_t fix_r = 0, fix_w = 0;
         for (int j = 0, q = 0; j < n - W::M; ++j, ++q) {
             while (q < 64 && ((tilemask >> q) & 1ull)) ++q;
             if ((dead >> q) & 1ull) continue;       // (known |0>: not a bit of the tile number)
+            if ((fixm >> q) & 1ull) {               // (held fixed by this slice of the pass)
+                if ((fixv >> q) & 1ull) {
+                    fix_r |= 1ull << q;
+                    fix_w |= 1ull << p->store_blk_pos[j];
+                }
+                continue;
+            }
             k->read_blk_pos[nb] = (uint8_t)q;
             k->store_blk_pos[nb] = p->store_blk_pos[j];
             ++nb;
         }
         for (int j = nb; j < DQ_FUSED_MAX_BLK; ++j) k->read_blk_pos[j] = k->store_blk_pos[j] = 63;
         k->zext = (uint32_t)nb;
+        k->fix_read[0] = (uint32_t)fix_r, k->fix_read[1] = (uint32_t)(fix_r >> 32);
+        k->fix_write[0] = (uint32_t)fix_w, k->fix_write[1] = (uint32_t)(fix_w >> 32);
         // ... re-ordered by where they land on the WRITE side: tiles that run at the same time (neighbours in the tile
         // number) then write neighbouring runs, i.e. whole DRAM pages between them, while the read side does not care
         // (a tile reads one contiguous 32 KiB block wherever it lies).  DQ_WAVE_TILE_ORDER=read keeps the read order.
@@ -598,7 +619,7 @@ fail:
 template <class W, bool GRAD = false>
 static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                        const DqFusedPass* pass, hipStream_t s, double* grads = nullptr, int64_t ngrads = 0, uint64_t dead = 0,
-                       const void* ext_rec = nullptr, int64_t ext_bytes = 0) {
+                       const void* ext_rec = nullptr, int64_t ext_bytes = 0, uint64_t fixm = 0, uint64_t fixv = 0) {
     WaveKernPass kp;
     int rc;
     if (ext_rec) {      // the records lie in device memory (dq_wave_records wrote them, the caller copied them there): translate
@@ -610,7 +631,7 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
             return DQ_ERR_ARG;
         }
     } else {
-        rc = wave_translate<W>(pass, n, &kp, dead);
+        rc = wave_translate<W>(pass, n, &kp, dead, nullptr, 0, fixm, fixv);
     }
     if (rc) return rc;
     const uint64_t tiles = 1ull << (kp.zext & 63u);
@@ -666,8 +687,8 @@ static int wave_launch(const void* in, void* out, const void* mats, int64_t mat_
 }
 
 int wave_launch_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                    const DqFusedPass* pass, hipStream_t s, uint64_t dead) {
-    return wave_launch<WaveC64>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, nullptr, 0, dead);
+                    const DqFusedPass* pass, hipStream_t s, uint64_t dead, uint64_t fixm, uint64_t fixv) {
+    return wave_launch<WaveC64>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, nullptr, 0, dead, nullptr, 0, fixm, fixv);
 }
 int wave_launch_grad_c64(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
                          const DqFusedPass* pass, hipStream_t s, double* grads, int64_t ngrads, const void* ext_rec, int64_t ext_bytes) {
@@ -678,8 +699,8 @@ int wave_launch_grad_c128(const void* in, void* out, const void* mats, int64_t m
     return wave_launch<WaveC128, true>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, grads, ngrads, 0, ext_rec, ext_bytes);
 }
 int wave_launch_c128(const void* in, void* out, const void* mats, int64_t mat_bstride, int64_t in_bstride, int n, int64_t batch,
-                     const DqFusedPass* pass, hipStream_t s, uint64_t dead) {
-    return wave_launch<WaveC128>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, nullptr, 0, dead);
+                     const DqFusedPass* pass, hipStream_t s, uint64_t dead, uint64_t fixm, uint64_t fixv) {
+    return wave_launch<WaveC128>(in, out, mats, mat_bstride, in_bstride, n, batch, pass, s, nullptr, 0, dead, nullptr, 0, fixm, fixv);
 }
 
 }  // namespace dq

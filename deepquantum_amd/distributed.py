@@ -43,7 +43,7 @@ import torch.distributed as dist
 
 from . import backend, executor
 from .bitmath import get_bit
-from .communication import comm_exchange_arrays, exchange_chunks
+from .communication import comm_exchange_arrays, exchange_chunks, exchange_pieces
 from .executor import Prim
 from .qmath import block_sample, measure
 from .state import DistributedQubitState
@@ -80,7 +80,16 @@ CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_gr
           # remaps evict to the rank bits only qubits whose move can ride on a fused pass (not on the contiguous low bits of
           # a tile) while others are left: saves the re-labelling pass in front of such an exchange, at times for one more
           # exchange.  None = per circuit, whichever the dry-run model prices lower (`choose_eviction`)
-          'evict_foldable': None}
+          'evict_foldable': None,
+          # EXCHANGE OVERLAP FOR AN UN-BATCHED SHARD WITHOUT EXTRA STRETCHES (round 6): the last pass in front of a remap and
+          # the first pass behind it run in 2^B slices by B index bits right below the chunk bits (`_remap_sliced`,
+          # dq_apply_fused_slice_*): slice j of every chunk leaves for its peer while slice j + 1 computes, and the next
+          # stretch starts on slice j as soon as it has arrived.  The B qubits are the local ones needed last after the
+          # evicted ones -- outside the tiles of both passes on (nearly) every rank; where one is not, that rank launches
+          # fewer, bigger slices and the protocol stays the same.  Costs a third shard-sized buffer (the first pass behind
+          # the exchange must not write where slices are still being sent from).  None = 2 where an exchange can overlap
+          # with compute at all (RCCL on device shards, or the rehearsal of such a job), 0 elsewhere; an int forces it
+          'slice_exchange': None}
 
 #: the accumulator of the DQ_FG_GRAD reductions while a fused reverse sweep runs on a sharded (psi, lambda) pair
 #: (adjoint._sweep_fused_sharded): every local stretch hands its rows to the passes
@@ -89,7 +98,8 @@ _SWEEP: dict = {'grads': None}
 #: statistics of the last ``dist_apply_prims`` call (bench / tests)
 LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_permutes': 0, 'permute_passes': 0,
             'wire_bytes': 0, 'groups': 1, 'virtual_bits': 0, 'virtual_remaps': 0, 'zero_shard_stretches': 0,
-            'known_zero_stretches': 0, 'local_first_exchanges': 0, 'zero_fills': 0}
+            'known_zero_stretches': 0, 'local_first_exchanges': 0, 'zero_fills': 0, 'sliced_remaps': 0,
+            'slice_launches_last': 0, 'slice_launches_first': 0}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -303,6 +313,9 @@ def remap_timings() -> list[dict]:
     out = []
     for rec in TIMING['remaps']:
         row = {k: rec[k] for k in ('remap', 'rows', 'k', 'bytes')}
+        for k_ in ('slices', 'slices_last', 'slices_first'):       # (a sliced exchange: protocol slices, launches of the two passes)
+            if k_ in rec:
+                row[k_] = rec[k_]
         if rec.get('start') is not None and rec.get('issued') is not None:
             row['local_ms'] = rec['start'].elapsed_time(rec['issued'])
         if rec.get('issued') is not None and rec.get('done') is not None:
@@ -314,6 +327,7 @@ def remap_timings() -> list[dict]:
 def _settle(state: DistributedQubitState) -> None:
     """Join the group streams: everything in flight for this state (exchanges included) is ordered before whatever the
     current stream does next."""
+    _arrivals_done(state, state.__dict__.pop('_arrivals', None))
     keep = state.__dict__.pop('_inflight_keep', None)
     for stream, works in state.__dict__.pop('_inflight', []):
         if stream is not None:
@@ -325,6 +339,35 @@ def _settle(state: DistributedQubitState) -> None:
             for w in works:
                 _wait(w, None)
     del keep        # (the matrices the group streams were reading: only now may their memory be reused)
+
+
+def _arrivals_done(state: DistributedQubitState, arr: dict | None) -> None:
+    """Join a sliced exchange (`_remap_sliced`): every slice is ordered before what the current stream does next, and the
+    buffer the slices were sent from becomes the state's spare third buffer again."""
+    if arr is None:
+        return
+    for j, w in enumerate(arr['works']):
+        if w is not None:
+            w.wait()
+            arr['works'][j] = None
+    if TIMING['enabled'] and arr.get('timing') is not None and 'done' not in arr['timing']:
+        arr['timing']['done'] = _mark(None)
+    state.__dict__['_spare'] = arr.pop('src', None)
+
+
+def _first_slicing(state: DistributedQubitState, arr: dict | None) -> dict | None:
+    """``executor.run(slicing=...)`` for the first pass behind a sliced exchange: slice j is waited for right before the
+    first launch that reads it."""
+    if arr is None:
+        return None
+
+    def before(j: int) -> None:
+        w = arr['works'][j]
+        if w is not None:
+            w.wait()
+            arr['works'][j] = None
+
+    return {'first': (arr['bits'], before)}
 
 
 def _rows_of(pending: Sequence[Prim], rows: slice, total: int) -> list[Prim]:
@@ -342,7 +385,7 @@ def _rows_of(pending: Sequence[Prim], rows: slice, total: int) -> list[Prim]:
 
 def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: slice,
               out_perm: Sequence[int] | None = None, expect_z: dict | None = None, zero: bool = False,
-              need_zeros=None) -> bool:
+              need_zeros=None, slicing: dict | None = None) -> bool:
     """Fused local passes on rows ``rows`` of the shard ``a`` with the receive buffer ``b`` as the second buffer of the
     permuted stores; afterwards local bit q sits at position out_perm[q].  Returns True if the result lives in ``b``.
     ``zero``: the rows are |0..0> (rank 0's shard right after ``reset()``): the first passes skip what is still known to be
@@ -352,6 +395,13 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
     if need_zeros is not None and (_SWEEP['grads'] is not None or not (CONFIG['fold_permute'] or out_perm is None)):
         need_zeros()                              # (routes below that take no masks)
         need_zeros = None
+    if slicing is not None and (_SWEEP['grads'] is not None or not (CONFIG['fold_permute'] or out_perm is None)):
+        executor._slicing_all(slicing, 'first')   # (routes below that take no slices: everything has to be there first)
+        slicing = {k_: v_ for k_, v_ in slicing.items() if k_ != 'first'}
+        post = slicing
+        slicing = None
+    else:
+        post = None
     if _SWEEP['grads'] is not None:               # a stretch of a fused reverse sweep: reductions inside the passes
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel(),
                            grads=_SWEEP['grads'][rows])
@@ -359,13 +409,15 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
         # (``need_zeros``: the shard holds garbage where it is logically zero; the executor calls it before anything reads
         # there -- i.e. unless the known-zero masks of ``zero`` apply to this schedule from its first pass to its last)
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y, out_perm=out_perm, amps=a.numel(),
-                           expect_z=expect_z, zero_state=zero, need_zeros=need_zeros)
+                           expect_z=expect_z, zero_state=zero, need_zeros=need_zeros, slicing=slicing)
     else:                                         # A/B: the re-labelling as a pass of its own
         out = executor.run(x, _rows_of(pending, rows, total), inplace=True, scratch=y)
         if out.data_ptr() not in (x.data_ptr(), y.data_ptr()):
             x.copy_(out)
             out = x
         out = executor.run(out, [], inplace=True, scratch=y if out.data_ptr() == x.data_ptr() else x, out_perm=out_perm)
+    if post is not None:
+        executor._slicing_all(post, 'last', out)
     if out.data_ptr() == y.data_ptr():
         return True
     if out.data_ptr() != x.data_ptr():        # (states smaller than a tile come back in a fresh tensor)
@@ -374,6 +426,10 @@ def _run_rows(a: torch.Tensor, b: torch.Tensor, pending: Sequence[Prim], rows: s
 
 
 def _flush(state: DistributedQubitState, pending: list[Prim], expect_z: dict | None = None) -> None:
+    arr = state.__dict__.pop('_arrivals', None)      # (a sliced exchange in flight: the first pass below takes it slice by slice)
+    if arr is not None and not pending:
+        _arrivals_done(state, arr)
+        arr = None
     _settle(state)
     fresh = state.__dict__.pop('_fresh_zero', False)
     state.__dict__.pop('_zero_shard', None)      # (a shard of zeros runs its passes here like anybody: zeros in, zeros out)
@@ -389,9 +445,15 @@ def _flush(state: DistributedQubitState, pending: list[Prim], expect_z: dict | N
     LAST_RUN['local_flushes'] += 1
     LAST_RUN['known_zero_stretches'] += bool(kz)
     a, b = _view(state), _bview(state)
+    slicing = _first_slicing(state, arr)
     if _run_rows(a, b, pending, slice(0, a.shape[0]), expect_z=expect_z, zero=zero,
-                 need_zeros=(lambda: _materialize_zeros(state)) if lazy else None):
+                 need_zeros=(lambda: _materialize_zeros(state)) if lazy else None, slicing=slicing):
         state.amps, state.buffer = state.buffer, state.amps
+    if arr is not None:
+        LAST_RUN['slice_launches_first'] += slicing.get('done', {}).get('first', 0)
+        if TIMING['enabled'] and arr.get('timing') is not None:
+            arr['timing']['slices_first'] = slicing.get('done', {}).get('first', 0)
+        _arrivals_done(state, arr)
     state.__dict__.pop('_lazy_zero', None)       # (masked passes that ran through have written everything)
     state.__dict__.pop('_zeros_owed', None)
     pending.clear()
@@ -576,7 +638,8 @@ def _exchange_qubits(state: DistributedQubitState, pairs: list[tuple[int, int]])
     _settle(state)
 
 
-def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: list[Prim]) -> None:
+def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: list[Prim],
+           slice_qubits: Sequence[int] = ()) -> None:
     """The local gates ``pending`` (physical positions), then the exchange ``pairs``.  Per group of samples
     (CONFIG['overlap_groups']; each on its own stream): fused passes whose LAST one also moves the entering qubits to
     the top k local bits (executor ``out_perm``), then one all-to-all per sample among the 2^k ranks of the group --
@@ -590,10 +653,20 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     k = len(pairs)
     rbits = [ph[lq] - L for lq, _ in pairs]                 # bits of the (virtual) world's rank: the low vb are rows
     assert all(0 <= r < state.log_num_nodes + vb for r in rbits) and all(ph[eq] < L for _, eq in pairs)
+    # a sliced exchange in flight (`_remap_sliced`): the first pass of THIS stretch takes it slice by slice
+    arr = state.__dict__.pop('_arrivals', None)
     # 1. the entering qubits go to the top k local bits (chunk index = their joint value): destination bit d takes
     #    source bit src_of_dst[d]
     ent_bits = [ph[eq] for _, eq in pairs]
-    src_of_dst = [b for b in range(L) if b not in ent_bits] + ent_bits
+    sq = [q for q in slice_qubits if ph[q] < L and ph[q] not in ent_bits]
+    sliced = (len(sq) > 0 and vb == 0 and _view(state).shape[0] == 1 and _live(state) and L - k - len(sq) >= 12
+              and _SWEEP['grads'] is None and CONFIG['fold_permute'] and not state.__dict__.get('_as_rank0')
+              and not state.__dict__.get('_behind_reset'))
+    if not sliced:
+        sq = []
+    sbits = [ph[q] for q in sq]
+    #    (with slices: the slice qubits right below them -- protocol bit i on local bit L - k - B + i)
+    src_of_dst = [b for b in range(L) if b not in ent_bits and b not in sbits] + sbits + ent_bits
     out_perm = [0] * L
     for d, sp in enumerate(src_of_dst):
         out_perm[sp] = d
@@ -617,6 +690,11 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
     a, b = _view(state), _bview(state)
     groups = _row_groups(state)
     streams = _group_streams(state, len(groups))
+    if sliced or arr is not None:
+        if _remap_sliced(state, pairs, rbits, pending, out_perm, identity, k, chunk, peers, len(sq), arr):
+            _remap_bookkeeping(ph, pairs, rbits, out_perm, L)
+            return
+        a, b = _view(state), _bview(state)        # (the stretch may have run and changed the buffers' roles)
     # the first stretch behind reset(): rank 0 holds |0..0> -- its first passes skip what is still known to be zero --
     # and every other rank holds nothing but zeros, which stay zeros under any gates and in any layout: no pass at all
     # (with virtual rank bits the rows of rank 0's shard are |0..0> and zeros: the masks hold for both; the other ranks
@@ -713,6 +791,134 @@ def _remap(state: DistributedQubitState, pairs: list[tuple[int, int]], pending: 
         # the rank bits, now on the top k local bits, are still |0>, and the next stretch starts with their mask
         # (executor.run(zero_state=mask): its first passes move 2^-k of the shard)
         state.__dict__['_known_zero_local'] = ((1 << k) - 1) << (L - k)
+
+
+def _remap_sliced(state: DistributedQubitState, pairs, rbits, pending: list[Prim], out_perm, identity: bool, k: int,
+                  chunk: int, peers: list[int], nb: int, arr: dict | None) -> bool:
+    """A remap of an un-batched shard with its exchange in 2^nb slices (CONFIG['slice_exchange']; ``nb`` = 0: an ordinary
+    exchange, but the first pass of this stretch takes the PREVIOUS sliced exchange ``arr`` slice by slice).
+
+    The last pass of ``pending`` -- which also writes the re-labelling ``out_perm``: entering qubits on the top k local
+    bits, the nb slice qubits right below them -- is launched slice by slice (`executor.run(slicing=...)`); behind every
+    protocol slice j (the value of the nb bits) its part of every chunk -- contiguous: chunk c, slice j -- leaves for peer c
+    on the exchange stream while the next launch computes.  Nothing waits here: the next stretch's first pass waits for
+    slice j right before it reads it (`_first_slicing`), `_settle` for everything.  The pass behind the exchange must not
+    write where slices are still being sent from, so the state's buffers rotate through a THIRD one: received -> ``amps``,
+    spare -> ``buffer``, and the buffer the slices leave from becomes the spare when the last slice has gone.
+    Returns False when there is nothing sliced to do (the caller's ordinary route runs)."""
+    if nb == 0 and (arr is None or not pending):
+        _arrivals_done(state, arr)
+        return False
+    for key in ('_fresh_zero', '_zero_shard', '_behind_reset'):
+        state.__dict__.pop(key, None)
+    kz = state.__dict__.pop('_known_zero_local', 0)
+    lazy = bool(state.__dict__.get('_lazy_zero') or state.__dict__.get('_zeros_owed'))
+    if lazy and not (kz and (pending or not identity)):
+        _materialize_zeros(state)
+        lazy = False
+    if nb == 0:
+        # an ordinary exchange behind a sliced one: run the stretch here (its first pass in slices), then fall back
+        a, b = _view(state), _bview(state)
+        slicing = _first_slicing(state, arr)
+        LAST_RUN['local_flushes'] += 1
+        LAST_RUN['known_zero_stretches'] += bool(kz)
+        if _run_rows(a, b, pending, slice(0, 1), zero=kz, need_zeros=(lambda: _materialize_zeros(state)) if lazy else None,
+                     slicing=slicing):
+            state.amps, state.buffer = state.buffer, state.amps
+        state.__dict__.pop('_lazy_zero', None)
+        state.__dict__.pop('_zeros_owed', None)
+        LAST_RUN['slice_launches_first'] += slicing.get('done', {}).get('first', 0)
+        if TIMING['enabled'] and arr.get('timing') is not None:
+            arr['timing']['slices_first'] = slicing.get('done', {}).get('first', 0)
+        _arrivals_done(state, arr)
+        pending.clear()
+        return False
+    _settle(state)
+    L = state.log_num_amps_per_node
+    nsl = 1 << nb
+    sub = chunk >> nb
+    a, b = _view(state), _bview(state)
+    spare = state.__dict__.pop('_spare', None)
+    if spare is None or spare.shape != state.amps.shape or spare.dtype != state.amps.dtype or spare.device != state.amps.device:
+        spare = torch.empty_like(state.amps)
+    on_gpu = a.is_cuda
+    xs = _group_streams(state, 2)[1] if on_gpu else None          # the exchange stream
+    works: list = [None] * nsl
+    bufs: dict = {}
+    rec = None
+    if TIMING['enabled']:
+        rec = {'remap': LAST_RUN['remaps'] + 1, 'rows': (0, 1), 'k': k, 'bytes': ((1 << k) - 1) * chunk * a.element_size(),
+               'start': _mark(None), 'issued': None, 'exchange': None, 'stream': None, 'slices': nsl}
+        TIMING['remaps'].append(rec)
+
+    def pieces(t: torch.Tensor, j: int) -> list[torch.Tensor]:
+        v = torch.view_as_real(t[0]).reshape(1 << k, nsl, sub * 2)
+        return [v[c, j] for c in range(1 << k)]
+
+    ready: set = set()
+    nxt = [0]
+
+    def after(j: int, where: torch.Tensor) -> None:
+        # (the executor calls this behind the last launch that writes protocol slice j, with the buffer it wrote to.  A rank
+        # whose last pass could be cut by fewer bits finishes the slices in another order than its peers: point-to-point
+        # operations between two ranks match BY ORDER, so every rank issues the slices in protocol order, 0, 1, 2, ..)
+        bufs['src'] = where
+        ready.add(j)
+        while nxt[0] in ready:
+            issue(nxt[0], where)
+            nxt[0] += 1
+
+    def issue(j: int, where: torch.Tensor) -> None:
+        src, dst = where, bufs['dst']
+        nbytes = ((1 << k) - 1) * sub * a.element_size()
+        LAST_RUN['wire_bytes'] += nbytes
+        if rec is not None and rec['issued'] is None:
+            rec['issued'] = _mark(None)
+        if CONFIG['elide_exchange']:
+            return
+        what = (f'slice {j} of {nsl} of the shard exchange of remap {LAST_RUN["remaps"] + 1} (logical qubits leaving / entering '
+                f'{pairs}, rank bits {rbits}, peers {sorted(set(peers) - {state.rank})}, {nbytes} bytes each way)')
+        if xs is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(xs):
+                xs.wait_event(ev)
+                works[j] = exchange_pieces(pieces(dst, j), pieces(src, j), peers, what, async_op=True)
+        else:
+            works[j] = exchange_pieces(pieces(dst, j), pieces(src, j), peers, what, async_op=False)
+
+    slicing = {'last': ([L - k - nb + i for i in range(nb)], after)}
+    if arr is not None:
+        slicing.update(_first_slicing(state, arr))
+    bufs['src'], bufs['dst'] = None, spare.view(a.shape)
+    LAST_RUN['known_zero_stretches'] += bool(kz)
+    if pending:
+        LAST_RUN['local_flushes'] += 1
+    in_b = _run_rows(a, b, pending, slice(0, 1), None if identity else out_perm, zero=kz,
+                     need_zeros=(lambda: _materialize_zeros(state)) if lazy else None, slicing=slicing)
+    assert bufs['src'] is not None and (bufs['src'].data_ptr() == b.data_ptr()) == in_b, 'slices left from the wrong buffer'
+    state.__dict__.pop('_lazy_zero', None)
+    state.__dict__.pop('_zeros_owed', None)
+    done = slicing.get('done', {})
+    LAST_RUN['sliced_remaps'] += 1
+    LAST_RUN['slice_launches_last'] += done.get('last', 0)
+    LAST_RUN['slice_launches_first'] += done.get('first', 0)
+    if arr is not None:
+        if TIMING['enabled'] and arr.get('timing') is not None:
+            arr['timing']['slices_first'] = done.get('first', 0)
+        _arrivals_done(state, arr)
+    if rec is not None:
+        rec['slices_last'] = done.get('last', 0)
+    # received -> amps, the old spare's place is taken by the buffer that was NOT the source, the source stays out of
+    # reach until its slices have gone
+    src_t, other_t = (state.buffer, state.amps) if in_b else (state.amps, state.buffer)
+    state.amps, state.buffer = spare, other_t
+    state.__dict__['_arrivals'] = {'bits': [L - k - nb + i for i in range(nb)], 'works': works, 'src': src_t, 'timing': rec}
+    pending.clear()
+    if not identity:
+        LAST_RUN['folded_permutes' if executor.LAST_RUN.get('permute_folded') else 'permute_passes'] += 1
+    LAST_RUN['groups'] = 1
+    return True
 
 
 def _first_exchange_local(state: DistributedQubitState, pairs, rbits, pending: list[Prim], out_perm, identity: bool,
@@ -1194,9 +1400,33 @@ def virtual_bits_table(prims: Sequence[Prim], n: int, L: int, **kw) -> dict:
     return {'chosen': v, 'candidates': table, 'model': dict(MODEL)}
 
 
+def slice_bits_wanted(state: DistributedQubitState) -> int:
+    """CONFIG['slice_exchange'] resolved: how many bits the passes around an exchange are sliced by (0 = off)."""
+    nb = CONFIG['slice_exchange']
+    if nb is None:
+        overlaps = state.amps.is_cuda and (CONFIG['elide_exchange'] or (dist.is_initialized() and dist.get_backend() == 'nccl'))
+        nb = 2 if overlaps else 0
+    return int(nb) if (state.batch is None and _vbits(state) == 0) else 0
+
+
+def _slice_qubits(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int, pairs, nbits: int) -> list[int]:
+    """The qubits the passes around the exchange ``pairs`` are sliced by: local, staying local, movable by a permuted store,
+    and -- after the evicted ones -- needed LAST (farthest next non-diagonal use from gate ``i`` on): neither the gates
+    left for the last pass in front of the exchange nor the first ones behind it have any business with them.  A pure
+    function of the gate list and the placement: every rank picks the same."""
+    if nbits <= 0:
+        return []
+    nxt = _next_use(prims, i, n)
+    leaving_local = {eq for _, eq in pairs}
+    cand = sorted((q for q in range(n) if _UNFOLDABLE_BELOW <= ph[q] < L and q not in leaving_local), key=lambda q: (-nxt[q], -q))
+    return cand[:nbits]
+
+
 def _remap_for(state: DistributedQubitState, prims: Sequence[Prim], i: int, pending: list[Prim]) -> None:
-    pairs = _plan_remap(_phys(state), prims, i, state.nqubit, state.log_num_amps_per_node - _vbits(state), _vbits(state))
-    _remap(state, pairs, pending)
+    L = state.log_num_amps_per_node - _vbits(state)
+    pairs = _plan_remap(_phys(state), prims, i, state.nqubit, L, _vbits(state))
+    nb = slice_bits_wanted(state)
+    _remap(state, pairs, pending, _slice_qubits(_phys(state), prims, i, state.nqubit, L, pairs, nb) if nb else ())
 
 
 def count_exchange_steps(prims: Sequence[Prim], n: int, g: int, virtual_bits: int = 0, reorder: bool = False,

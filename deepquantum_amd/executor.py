@@ -276,7 +276,8 @@ def needs_autograd(state: torch.Tensor, prims: Sequence[Prim]) -> bool:
 
 def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
         out_perm: Sequence[int] | None = None, amps: int | None = None, grads: torch.Tensor | None = None,
-        expect_z: dict | None = None, zero_state: bool | int = False, need_zeros=None) -> torch.Tensor:
+        expect_z: dict | None = None, zero_state: bool | int = False, need_zeros=None,
+        slicing: dict | None = None) -> torch.Tensor:
     """Apply ``prims`` in order to ``state`` (B, 2**n) and return the new (B, 2**n) state.
 
     ``zero_state``: the caller vouches that ``state`` is |0..0> (every row; ``QubitState.is_zero_state``) -- the first
@@ -292,10 +293,20 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
     the sharded state): the planner's effort goes by the whole.
     ``need_zeros`` (the sharded state, round 6): ``state`` holds garbage where ``zero_state`` says it is zero; the callable
     clears it and is called before anything could read there -- i.e. unless the known-zero masks apply to this schedule
-    from its first pass to its last (`fusion.zero_state_masks` vouches that the result is then written completely)."""
+    from its first pass to its last (`fusion.zero_state_masks` vouches that the result is then written completely).
+    ``slicing`` (the sharded state's exchange overlap, round 6; in-place runs with ``scratch``): the FIRST and / or the LAST
+    pass in slices by index bits outside its tile (`backend.apply_fused(slice_bits=...)`), with a callback per PROTOCOL
+    slice -- the 2^B values of B agreed bits: ``{'first': (read positions of the B bits, before(j)), 'last': (positions of
+    the B bits AFTER the run, after(j, where))}``.  ``before(j)`` is called once for every j before the first launch that
+    reads slice j, ``after(j, where)`` once for every j behind the last launch that writes it (``where``: the buffer the
+    result is written to -- ``state`` or ``scratch``); a bit that lies inside the pass's tile
+    (or is known zero) is not sliced by: the launches then cover several protocol slices each (none sliceable: ``before``
+    for all j, the whole pass, ``after`` for all j).  ``slicing['done']`` reports what happened."""
     if len(prims) == 0 and out_perm is None:
         if need_zeros is not None:
             need_zeros()
+        _slicing_all(slicing, 'first')
+        _slicing_all(slicing, 'last', state)
         return state
     if state.ndim != 2:
         raise ValueError('state must be (batch, 2**n)')
@@ -360,10 +371,11 @@ def run(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scrat
             nextra = len(expect_z['masks'])
             acc = torch.zeros(state.shape[0], nextra, 8, dtype=torch.float64, device=state.device)
             out = _run_nograd(state, both, inplace, scratch, out_perm, grads=acc, amps=amps, zero_state=zero_state,
-                              need_zeros=need_zeros)
+                              need_zeros=need_zeros, slicing=slicing)
             expect_z['values'] = acc[:, :, 0]
             return out
-    return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps, zero_state=zero_state, need_zeros=need_zeros)
+    return _run_nograd(state, prims, inplace, scratch, out_perm, amps=amps, zero_state=zero_state, need_zeros=need_zeros,
+                       slicing=slicing)
 
 
 class _Meta(tuple):
@@ -552,9 +564,38 @@ def _permute_after(x: torch.Tensor, out_perm: Sequence[int], scratch: torch.Tens
     return backend.permute_bits(x, src_of_dst, out=dst)
 
 
+def _slicing_all(slicing: dict | None, which: str, where: torch.Tensor | None = None) -> None:
+    """Every protocol slice's callback of ``slicing[which]`` (a run, or a pass, that is not sliced); ``where``: the buffer
+    that holds the result (``after`` callbacks)."""
+    if slicing and which in slicing:
+        bits, cb = slicing[which]
+        for j in range(1 << len(bits)):
+            if which == 'last':
+                cb(j, where)
+            else:
+                cb(j)
+
+
+def _slice_launches(desc, kz: int, proto_reads: Sequence[int | None]) -> list[tuple[int, int, list[int]]]:
+    """The launches of ONE pass cut by the protocol bits that lie outside its tile: [(mask, value, protocol slices the
+    launch covers)] -- ``proto_reads[i]`` = READ position of protocol bit i (None: not a tile-number bit on the side that
+    matters).  No bit available: one launch, mask 0, covering every protocol slice."""
+    tile = set(range(desc.L)) | {desc.high_pos[i] for i in range(desc.h)}
+    avail = [(i, r) for i, r in enumerate(proto_reads) if r is not None and r not in tile and not (kz >> r) & 1]
+    nb = len(proto_reads)
+    mask = sum(1 << r for _, r in avail)
+    out = []
+    for a in range(1 << len(avail)):
+        value = sum(((a >> t) & 1) << r for t, (_, r) in enumerate(avail))
+        covered = [j for j in range(1 << nb) if all(((j >> i) & 1) == ((a >> t) & 1) for t, (i, _) in enumerate(avail))]
+        out.append((mask, value, covered))
+    return out
+
+
 def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = False, scratch: torch.Tensor | None = None,
                 out_perm: Sequence[int] | None = None, grads: torch.Tensor | None = None,
-                amps: int | None = None, zero_state: bool | int = False, need_zeros=None) -> torch.Tensor:
+                amps: int | None = None, zero_state: bool | int = False, need_zeros=None,
+                slicing: dict | None = None) -> torch.Tensor:
     """``grads``: the accumulator of the 'grad' prims (the reverse sweep of ``_AdjointCircuit``; complex64, n >= a tile).
     ``zero_state``: ``state`` is |0..0> (see ``run``)."""
     n = state.shape[-1].bit_length() - 1
@@ -566,15 +607,21 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
             LAST_RUN['permute_folded'] = False
             if need_zeros is not None:
                 need_zeros()
-            return _permute_after(state, out_perm, scratch)
+            _slicing_all(slicing, 'first')
+            res = _permute_after(state, out_perm, scratch)
+            _slicing_all(slicing, 'last', res)
+            return res
         if grads is not None:
             assert n >= m and CONFIG['fuse'], 'the fused reverse sweep needs a state of at least one tile'
         if (n < m and CONFIG['fuse'] and len(prims) >= CONFIG['small_fuse_min_gates']
                 and all(len(p.targets) <= 2 for p in prims)):
             if need_zeros is not None:
                 need_zeros()
+            _slicing_all(slicing, 'first')
             out = _run_small(state, prims, n, m)
-            return out if out_perm is None else _permute_after(out, out_perm, scratch)
+            out = out if out_perm is None else _permute_after(out, out_perm, scratch)
+            _slicing_all(slicing, 'last', out)
+            return out
         permute = False
         if scratch is not None:
             assert scratch.shape == state.shape and scratch.dtype == state.dtype and scratch.is_contiguous()
@@ -645,6 +692,13 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         spare = scratch                      # the caller's second buffer (if any)
         other = spare if permute else None
         scratch = None
+        # the first / last pass in slices (``slicing``): decided per pass below; whatever cannot be sliced still gets its
+        # callbacks -- all ``before`` in front of the pass, all ``after`` behind it
+        last_si = len(plan.steps) - 1
+        fold_ok = out_perm is None or (permute and plan.steps.applied_final_perm)
+        sliced = {'first': 0, 'last': 0}
+        if slicing is not None and plan.steps and not isinstance(plan.steps[0], fusion.FusedStep):
+            _slicing_all(slicing, 'first')
         for si, st in enumerate(plan.steps):
             if isinstance(st, fusion.FusedStep):
                 src, shared_in = (shared_in, None) if shared_in is not None else (x, None)
@@ -660,18 +714,53 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                     src = x
                 if kz:
                     stats['zero_passes'] += 1
-                if PROFILE['enabled'] and x.is_cuda:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr, known_zero=kz)
-                    e1.record()
-                    # bytes the pass has to move: what it reads (not where a known-zero bit is 1) + what it writes (not
-                    # the tiles in which such a bit outside the tile is 1)
-                    nz = bin(kz).count('1')
-                    nzo = nz - sum(1 for i in range(st.desc.h) if (kz >> st.desc.high_pos[i]) & 1)
-                    PROFILE['events'].append((e0, e1, len(st.ops), ((src.numel() >> nz) + (dst.numel() >> nzo)) * x.element_size()))
-                else:
-                    backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr, known_zero=kz)
+                launches = [(0, 0, None)]
+                before = after = None
+                if slicing is not None and (si == 0 or si == last_si):
+                    want_first = si == 0 and 'first' in slicing
+                    want_last = si == last_si and 'last' in slicing and fold_ok
+                    can = gr is None and src is x and x.shape[0] <= backend.MAX_BATCH
+                    d = st.desc
+                    if want_last:           # the bits are given where they lie AFTER the run: the write side of this pass
+                        tile_r = set(range(d.L)) | {d.high_pos[i] for i in range(d.h)}
+                        blk = [p_ for p_ in range(d.L, n) if p_ not in tile_r]
+                        read_of_write = {d.store_blk_pos[j]: p_ for j, p_ in enumerate(blk)}
+                        after = slicing['last'][1]
+                        if can:
+                            launches = _slice_launches(d, kz, [read_of_write.get(w) for w in slicing['last'][0]])
+                            sliced['last'] = len(launches)
+                        else:
+                            launches = [(0, 0, list(range(1 << len(slicing['last'][0]))))]
+                        if want_first:      # (a stretch of ONE pass: everything has to be there before it starts)
+                            _slicing_all(slicing, 'first')
+                    elif want_first:
+                        before = slicing['first'][1]
+                        if can:
+                            launches = _slice_launches(d, kz, list(slicing['first'][0]))
+                            sliced['first'] = len(launches)
+                        else:
+                            launches = [(0, 0, list(range(1 << len(slicing['first'][0]))))]
+                for smask, svalue, covered in launches:
+                    if before is not None:
+                        for j in covered:
+                            before(j)
+                    sb = (smask, svalue) if smask else None
+                    if PROFILE['enabled'] and x.is_cuda:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr, known_zero=kz, slice_bits=sb)
+                        e1.record()
+                        # bytes the pass has to move: what it reads (not where a known-zero bit is 1) + what it writes (not
+                        # the tiles in which such a bit outside the tile is 1); a slice: its share
+                        nz = bin(kz).count('1')
+                        nzo = nz - sum(1 for i in range(st.desc.h) if (kz >> st.desc.high_pos[i]) & 1)
+                        ns = bin(smask).count('1')
+                        PROFILE['events'].append((e0, e1, len(st.ops), (((src.numel() >> nz) + (dst.numel() >> nzo)) >> ns) * x.element_size()))
+                    else:
+                        backend.apply_fused(src, flat, stride, st.desc, out=dst, grads=gr, known_zero=kz, slice_bits=sb)
+                    if after is not None:
+                        for j in covered:
+                            after(j, dst)
                 if dst is not x:
                     x, other = dst, x
                 stats['passes'] += 1
@@ -695,6 +784,10 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
         LAST_RUN.update(stats)
         if out_perm is not None and not (permute and plan.steps.applied_final_perm):
             x = _permute_after(x, out_perm, other if other is not None else spare)
+        if slicing is not None:
+            if 'last' in slicing and not (plan.steps and isinstance(plan.steps[-1], fusion.FusedStep) and fold_ok):
+                _slicing_all(slicing, 'last', x)     # (the last step was no fused pass, or the re-labelling a pass of its own)
+            slicing['done'] = sliced
         return x
 
 

@@ -45,7 +45,7 @@ typedef enum {
     DQ_ERR_UNSUPPORTED = -3  /* valid request outside what this build implements */
 } DqStatus;
 
-#define DQ_ABI_VERSION 24
+#define DQ_ABI_VERSION 25
 
 int dq_abi_version(void);
 /* Thread-local, never NULL. */
@@ -268,7 +268,8 @@ int dq_defer_rx_c64(void* mats, int64_t mat_batch_stride, const int64_t* index, 
  * words (byte shift of every lane bit on the load side / the store side, what it adds to the thread's tile-local base),
  * record bytes, matrix base, 24 + 24 index positions of the tile number's bits (read, write), one word for
  * dq_apply_fused_zext_* (`known_zero`; bits 0..5: how many bits the tile number has, 8..13 / 16..21: register slots /
- * lane bits that are not loaded) + 7 reserved words, then the 32-byte records (word 0 = handler id, csrc/dq_wave_asm.inc).  At most `max_bytes` are copied to `out` (may be NULL); returns the size,
+ * lane bits that are not loaded), 2 + 2 words for dq_apply_fused_slice_* (index bits held fixed, OR-ed into every tile's
+ * read / write base; zero here) + 3 reserved words, then the 32-byte records (word 0 = handler id, csrc/dq_wave_asm.inc).  At most `max_bytes` are copied to `out` (may be NULL); returns the size,
  * or a negative DqStatus.  tests/_wave_emulator.py executes such a descriptor on the CPU. */
 int dq_wave_descriptor(const DqFusedPass* pass, int n, uint64_t known_zero, void* out, int max_bytes);
 /* `pass` is a HOST pointer; it is copied into the kernel argument segment.  in == out allowed.
@@ -302,6 +303,20 @@ int dq_apply_fused_zext_c64(const void* in, int64_t in_batch_stride, void* out, 
                             int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, dq_stream_t stream);
 int dq_apply_fused_zext_c128(const void* in, int64_t in_batch_stride, void* out, const void* mats, int64_t mat_batch_stride,
                              int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, dq_stream_t stream);
+
+/* ABI 25.  ONE SLICE of a pass: only the tiles whose index bits `slice_mask` (read side) equal `slice_value` run;
+ * 2^popcount(slice_mask) such launches are the whole pass, bit for bit.  `slice_mask` names index bits < n OUTSIDE the
+ * tile of the pass (not its contiguous low bits, not its gathered bits) and outside `known_zero`; `slice_value` is a subset
+ * of it.  Gates controlled by such a bit see its value.  For the index-bit-sharded state (distributed.py:57-202 of the
+ * reference exchanges whole shards gate by gate): the last pass in front of a k-qubit exchange is launched slice by
+ * slice -- each slice's part of every chunk leaves for its peer while the next slice computes -- and the first pass
+ * behind it starts with the first slice that has arrived. */
+int dq_apply_fused_slice_c64(const void* in, int64_t in_batch_stride, void* out, const void* mats, int64_t mat_batch_stride,
+                             int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, uint64_t slice_mask,
+                             uint64_t slice_value, dq_stream_t stream);
+int dq_apply_fused_slice_c128(const void* in, int64_t in_batch_stride, void* out, const void* mats, int64_t mat_batch_stride,
+                              int n, int64_t batch, const DqFusedPass* pass, uint64_t known_zero, uint64_t slice_mask,
+                              uint64_t slice_value, dq_stream_t stream);
 
 /* Reverse sweep of the adjoint method in fused passes (replaces the backward of autograd through circuit.py:261, one
  * matmul backward per gate -- qmath.py:504 -- with one saved state per gate).  `in` / `out` hold, per sample, psi and

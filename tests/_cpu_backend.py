@@ -40,7 +40,7 @@ class CpuTestBackend:
         return table[(bool(is_c128), variant)]
 
     # ---- fused pass interpreter --------------------------------------------------------------------
-    def apply_fused(self, state, mats, mat_batch_stride, desc, out, grads=None, known_zero=0):
+    def apply_fused(self, state, mats, mat_batch_stride, desc, out, grads=None, known_zero=0, slice_bits=None):
         self.fused_calls += 1
         n = state.shape[-1].bit_length() - 1
         bsz = state.shape[0]
@@ -117,6 +117,13 @@ class CpuTestBackend:
             assert grads is None and known_zero >> n == 0 and known_zero & ((1 << L) - 1) == 0
             x[:, (np.arange(1 << n, dtype=np.int64) & known_zero) != 0] = 0
             live_rows = (tiles & known_zero) == 0
+        if slice_bits is not None:
+            # include/dq_hip.h, dq_apply_fused_slice_*: only the tiles whose index bits `mask` (read side, outside the tile,
+            # not known zero) equal `value` run; what the other slices wrote (or will write) in `out` is not touched
+            smask, svalue = int(slice_bits[0]), int(slice_bits[1])
+            tile_bits = ((1 << L) - 1) | sum(1 << p for p in high_pos)
+            assert grads is None and smask >> n == 0 and smask & tile_bits == 0 and smask & known_zero == 0 and svalue & ~smask == 0
+            live_rows = live_rows & ((tiles & smask) == svalue)
         flat_m = mats.detach().numpy().reshape(-1)
         for b in range(bsz):
             t = x[b][idx]                               # (ntiles, 2^m)
@@ -263,7 +270,13 @@ class CpuTestBackend:
                         ok = tile_ok[:, None] & el_ok[None, :]
                         t = np.where(ok, ph * t, t)
             x[b][idxw] = t          # (every index is written exactly once: idxw partitions the state)
-        if known_zero:
+        if slice_bits is not None:
+            keep = out.detach().numpy().copy()
+            assert out.data_ptr() != state.data_ptr() or np.array_equal(idx, idxw)
+            for b in range(bsz):
+                keep[b][idxw[live_rows].reshape(-1)] = x[b][idxw[live_rows].reshape(-1)]
+            x = keep
+        elif known_zero:
             # (what the kernel leaves untouched is poisoned here: a later pass that reads it -- a wrong mask -- shows)
             keep = np.full_like(x, complex(float('nan'), float('nan')))
             for b in range(bsz):

@@ -49,7 +49,8 @@ class WaveKernPass(C.Structure):
     _fields_ = [('load_off', C.c_uint64 * 5), ('store_off', C.c_uint64 * 5), ('load_lane_shift', C.c_uint32 * 6),
                 ('store_lane_shift', C.c_uint32 * 6), ('tb_contrib', C.c_uint32 * 6), ('nrec_bytes', C.c_uint32),
                 ('mat_base_bytes', C.c_uint32), ('read_blk_pos', C.c_uint8 * 24), ('store_blk_pos', C.c_uint8 * 24),
-                ('zext', C.c_uint32), ('reserved', C.c_uint32 * 7), ('rec', (C.c_uint32 * 8) * 256)]     # (WAVE_EXT_REC: the test hook's cap)
+                ('zext', C.c_uint32), ('fix_read', C.c_uint32 * 2), ('fix_write', C.c_uint32 * 2), ('reserved', C.c_uint32 * 3),
+                ('rec', (C.c_uint32 * 8) * 256)]     # (WAVE_EXT_REC: the test hook's cap)
 
 
 def descriptor(desc, n, known_zero: int = 0) -> WaveKernPass:
@@ -156,8 +157,8 @@ def run_pass(desc, n, state, mats, mat_batch_stride, grads=None, known_zero: int
         flat_in = state[b]
         mb = flat_m[b * mat_batch_stride:] if mat_batch_stride else flat_m
         for tile in range(ntiles):
-            tg = sum(((tile >> j) & 1) << kp.read_blk_pos[j] for j in range(24))
-            tw = sum(((tile >> j) & 1) << kp.store_blk_pos[j] for j in range(24))
+            tg = sum(((tile >> j) & 1) << kp.read_blk_pos[j] for j in range(24)) | kp.fix_read[0] | (kp.fix_read[1] << 32)
+            tw = sum(((tile >> j) & 1) << kp.store_blk_pos[j] for j in range(24)) | kp.fix_write[0] | (kp.fix_write[1] << 32)
             a = np.zeros((64, NA), dtype=state.dtype)
             for piece in range(32):
                 # (zero-extended loads: a piece whose slot pattern has a known-zero bit set is not loaded, nor are the

@@ -368,6 +368,64 @@ def _virtual_bits_check(dq, rank, world, n, double):
             assert st_['local_first_exchanges'] == 1, (key, rank, st_)
 
 
+def _sliced_exchange_check(dq, rank, world, n, double, device='cpu'):
+    """CONFIG['slice_exchange'] (round 6): the last pass in front of a remap and the first pass behind it in slices by two
+    index bits below the chunk bits, the exchange slice by slice through a third buffer -- against the dense circuit and
+    against the unsliced run, lazy and canonical layout; some remap must really have been cut (more launches than remaps)."""
+    import bench
+    from deepquantum_amd import distributed as D
+    from deepquantum_amd import executor
+
+    dtype = torch.complex128 if double else torch.complex64
+    spec = bench.random_circuit_spec(n, 24, seed=77)
+    dense, data = bench.build_circuit(dq, n, spec, None, dtype, device)
+    with torch.no_grad():
+        ref = dense(data).reshape(-1)
+        ref_ev = dense.expectation()
+    per = (1 << n) // world
+    old = dict(executor.CONFIG)
+    executor.CONFIG['permute_min_bits'] = 11
+    tol = 1e-10 if double else 2e-5
+    try:
+        got = {}
+        for nb in (2, 1, 0):
+            D.CONFIG['slice_exchange'] = nb
+            for lazy in (True, False):
+                cir, _ = bench.build_circuit(dq, n, spec, None, dtype, device, distributed=True)
+                cir.lazy_layout = lazy
+                with torch.no_grad():
+                    for _rep in range(2):           # (the second forward starts from whatever the first left in all three buffers)
+                        st = cir(data)
+                        stats = dict(D.LAST_RUN)
+                        ev = cir.expectation()
+                amps = st.amps.reshape(-1).clone()
+                err = (amps - ref[rank * per:(rank + 1) * per]).abs().max().item()
+                assert err < tol, f'rank {rank}: slice_exchange {nb} lazy {lazy}: shard error {err}; {stats}'
+                assert (ev.reshape(-1) - ref_ev.reshape(-1)).abs().max().item() < 10 * tol
+                got[(nb, lazy)] = (amps, stats)
+                if nb:
+                    assert stats['sliced_remaps'] >= 1, stats
+                    assert max(stats['slice_launches_last'], stats['slice_launches_first']) >= 2, stats     # (a pass really was cut)
+                else:
+                    assert stats['sliced_remaps'] == 0
+        for key, (amps, _) in got.items():
+            assert (amps - got[(0, key[1])][0]).abs().max().item() < tol
+        if os.environ.get('DQ_TEST_VERBOSE') and rank == 0:
+            print({k_: {s_: v_[1][s_] for s_ in ('remaps', 'sliced_remaps', 'slice_launches_last', 'slice_launches_first', 'wire_bytes')} for k_, v_ in got.items()}, flush=True)
+    finally:
+        executor.CONFIG.update(old)
+        D.CONFIG['slice_exchange'] = None
+
+
+def _case_sliced_exchange_w2(dq, rank, world):
+    _sliced_exchange_check(dq, rank, world, 17, double=True)
+    _sliced_exchange_check(dq, rank, world, 18, double=False)
+
+
+def _case_sliced_exchange_w4(dq, rank, world):
+    _sliced_exchange_check(dq, rank, world, 18, double=False)
+
+
 def _case_virtual_bits_w2(dq, rank, world):
     _virtual_bits_check(dq, rank, world, 14, double=True)       # complex128: rows of 2^11 amplitudes = one tile
 
@@ -710,7 +768,7 @@ def _case_sampled_expectation_w4(dq, rank, world):
                                         ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4), ('folded_permute_w2', 2),
                                         ('golden_w2', 2), ('golden_w4', 4), ('golden_w8', 8),
                                         ('fused_sweep_w2', 2), ('fused_sweep_w4', 4), ('grouped_exchange_w4', 4), ('virtual_bits_w2', 2), ('virtual_bits_w4', 4), ('initial_placement_w4', 4),
-                                        ('zero_state_w2', 2), ('zero_state_w4', 4)])
+                                        ('zero_state_w2', 2), ('zero_state_w4', 4), ('sliced_exchange_w2', 2), ('sliced_exchange_w4', 4)])
 def test_sharded_circuit(case, world):
     _run(case, world)
 

@@ -145,6 +145,16 @@ def _case_virtual_bits(dq, rank, world):
             D.CONFIG['virtual_bits'] = 0
 
 
+def _case_sliced_exchange(dq, rank, world):
+    """CONFIG['slice_exchange'] with the real kernels (dq_apply_fused_slice_*): the passes around a remap in slices, the
+    exchange slice by slice through the third buffer (tests/test_distributed_cpu.py, _sliced_exchange_check)."""
+    from test_distributed_cpu import _sliced_exchange_check
+
+    dev = torch.device('cuda', torch.cuda.current_device())
+    _sliced_exchange_check(dq, rank, world, 19 + (world > 2), False, device=dev)
+    _sliced_exchange_check(dq, rank, world, 18 + (world > 2), True, device=dev)
+
+
 def _case_zero_state(dq, rank, world):
     """The first local stretch behind ``reset()`` with the real kernels: rank 0's first passes skip what is still known
     to be zero, the other ranks -- all zeros -- run no pass at all (tests/test_distributed_cpu.py, _zero_state_check)."""
@@ -404,6 +414,6 @@ def test_reference_dist_tests_on_gpu_world_of_one():
 @pytest.mark.parametrize('case,world', [('golden', 2), ('golden', 4), ('golden', 8), ('random_c64', 2), ('random_c64', 4), ('batched_c128', 4), ('adjoint_grad', 2),
                                         ('measure', 2), ('measure', 4), ('folded_permute', 2), ('folded_permute', 4),
                                         ('fused_sweep', 2), ('fused_sweep', 4), ('virtual_bits', 2), ('virtual_bits', 4),
-                                        ('zero_state', 2), ('zero_state', 4)])
+                                        ('zero_state', 2), ('zero_state', 4), ('sliced_exchange', 2), ('sliced_exchange', 4)])
 def test_sharded_on_gpu(case, world):
     _run(case, world)

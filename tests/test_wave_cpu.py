@@ -311,3 +311,31 @@ def test_two_target_dense_gates_on_the_wave_tile_kernel(cpu_backend, n, seed, is
     tol = 1e-12 if is128 else 1e-5
     assert (cur_d - ref).abs().max().item() < tol
     assert np.abs(cur_e - ref.numpy()).max() < tol
+
+
+def test_the_cpu_double_runs_a_pass_in_slices():
+    """The test double's reading of dq_apply_fused_slice_* (tests/_cpu_backend.py): the slices of a pass by index bits outside
+    its tile are the pass -- what the sharded state's sliced passes rely on in the CPU suite."""
+    from _cpu_backend import CpuTestBackend
+
+    be = CpuTestBackend()
+    n = 15
+    ops, mats = random_ops(n, 150, 21)
+    geom = fusion.default_geometry(False)
+    geom.permute_store = True
+    geom.plan_min_bits = 11
+    steps = fusion.schedule(ops, n, geom)
+    g = torch.Generator().manual_seed(5)
+    cur = torch.randn(2, 1 << n, generator=g, dtype=torch.complex64)
+    km = fusion.kernel_matrices(steps, ops, mats.to(torch.complex64))
+    for st in steps:
+        whole = torch.empty_like(cur)
+        be.apply_fused(cur, km, 0, st.desc, whole)
+        tile = set(range(st.desc.L)) | {st.desc.high_pos[i] for i in range(st.desc.h)}
+        bits = [p for p in range(n - 1, -1, -1) if p not in tile][:2]
+        mask = sum(1 << p for p in bits)
+        parts = torch.full_like(cur, float('nan'))
+        for v in range(4):
+            be.apply_fused(cur, km, 0, st.desc, parts, slice_bits=(mask, sum(((v >> i) & 1) << bits[i] for i in range(2))))
+        assert torch.equal(torch.view_as_real(parts), torch.view_as_real(whole))
+        cur = whole

@@ -219,3 +219,42 @@ def test_interleave_and_back_on_gpu(b, n, is128):
     pair = backend.interleave(x, y)
     assert torch.equal(pair, torch.stack([x, y], dim=-1).reshape(b, -1))
     assert torch.equal(backend.deinterleave(pair, 0), x) and torch.equal(backend.deinterleave(pair, 1), y)
+
+
+def slice_choices(desc, n, nbits):
+    """``nbits`` index bits (read side) outside the tile of ``desc`` -- the highest ones -- as a mask."""
+    tile = set(range(desc.L)) | {desc.high_pos[i] for i in range(desc.h)}
+    free = [p for p in range(n - 1, -1, -1) if p not in tile]
+    return sum(1 << p for p in free[:nbits]), free[:nbits]
+
+
+@PREC
+@pytest.mark.parametrize('n,ngates,seed,nbits', [(15, 200, 11, 1), (17, 300, 12, 2), (19, 300, 13, 2)])
+def test_a_pass_in_slices_is_the_pass(n, ngates, seed, nbits, is128):
+    """dq_apply_fused_slice_* (ABI 25): the 2^b launches that hold b index bits outside the tile at every value are the
+    whole pass, bit for bit -- out-of-place passes with permuted stores (the held bits land elsewhere on the write side),
+    gates controlled by a held bit included -- and a single slice writes nothing outside its own tiles."""
+    ops, mats = random_ops(n, ngates, seed)
+    mats = mats.to(cdtype(is128))
+    steps = wave_steps(ops, n, permute=True, is128=is128)
+    x = rand_state(2, n, 30 + seed, is128)
+    cur, md = x.to(dev()), fusion.kernel_matrices(steps, ops, mats).to(dev())
+    controlled = 0
+    for st in steps:
+        whole = torch.empty_like(cur)
+        backend.apply_fused(cur, md, 0, st.desc, out=whole)
+        mask, bits = slice_choices(st.desc, n, nbits)
+        controlled += sum(1 for gi in range(st.desc.rounds[st.desc.nrounds - 1].gate_end)
+                          if st.desc.gates[gi].out_cmask & mask)
+        parts = torch.full_like(cur, float('nan'))
+        for v in range(1 << nbits):
+            value = sum(((v >> i) & 1) << bits[i] for i in range(nbits))
+            before = parts.clone()
+            backend.apply_fused(cur, md, 0, st.desc, out=parts, slice_bits=(mask, value))
+            changed = (torch.view_as_real(parts) != torch.view_as_real(before)) & ~(torch.isnan(torch.view_as_real(parts)) & torch.isnan(torch.view_as_real(before)))
+            assert int(changed.any(dim=-1).sum()) <= parts.numel() >> nbits            # (only its own tiles)
+        assert torch.equal(torch.view_as_real(parts), torch.view_as_real(whole))
+        cur = whole
+    assert controlled > 0, 'no gate of any pass was controlled by a held bit: the case the kernel change is for'
+    with pytest.raises(RuntimeError):           # a held bit inside the tile is refused
+        backend.apply_fused(x.to(dev()), md, 0, steps[0].desc, out=torch.empty_like(cur), slice_bits=(1 << steps[0].desc.high_pos[0], 0))
