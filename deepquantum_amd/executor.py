@@ -182,7 +182,8 @@ def _steady(prims: Sequence[Prim]) -> dict | None:
 
 
 def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
-              out_perm: Sequence[int] | None = None, amps: int = 0, steady: dict | None = None) -> Plan:
+              out_perm: Sequence[int] | None = None, amps: int = 0, steady: dict | None = None,
+              final_free: tuple = ()) -> Plan:
     """``amps`` = amplitudes the plan will be run on (batch included): from ``CONFIG['plan_big_amps']`` on a step
     takes long enough (>= 0.1 s) for a wider search of the pass planner to pay for itself within a few steps
     (measured on the headline: 21 -> 20 passes, -2.7 %, 4.6 s of planning once per circuit structure)."""
@@ -200,8 +201,10 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
         if CONFIG['plan_restarts'] is None:
             geom.plan_restarts = 6
     geom.permute_store = permute
+    geom.final_free = tuple(final_free) if permute else ()
     head = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
-            geom.plan_branch, geom.plan_restarts, geom.free_low, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm))
+            geom.plan_branch, geom.plan_restarts, geom.free_low, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
+            geom.final_free)
     if steady is not None:
         plan = steady['plans'].get(head)
         if plan is not None and _PLAN_CACHE.get(plan[0]) is plan[1]:     # (still the plan the global cache would give)
@@ -637,7 +640,7 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 permute = 2 * nbytes <= CONFIG['permute_mem_frac'] * total and 2.05 * nbytes <= free
         steady = _steady(prims)
         plan = make_plan(prims, n, is128, permute, out_perm if permute else None, amps=max(state.numel(), amps or 0),
-                         steady=steady)
+                         steady=steady, final_free=tuple(slicing['last'][0]) if (slicing and 'last' in slicing) else ())
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies
         shared_in = None

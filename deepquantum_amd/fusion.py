@@ -90,6 +90,10 @@ class Geometry:
     plan_min_bits: int = 20   # states below 2^plan_min_bits amplitudes: greedy (width 1) -- planning time matters there
     far_bit: int = 19         # index bits >= far_bit are "far": every one gathered doubles the number of
     max_far: int | None = None  # distant address streams of a tile; None = no limit
+    # positions (in the layout the LAST pass leaves, i.e. after ``final_perm``) whose qubits that pass keeps out of its tile
+    # unless a gate needs them: the sharded state launches it in slices by exactly these bits (executor.run(slicing=...)),
+    # and a bit that merely PADS the tile would cost a factor two in slices for nothing
+    final_free: tuple = ()
 
     @property
     def logt(self) -> int:
@@ -665,8 +669,10 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
             for b in sorted((b for b in range(n) if wphys[b] is None), key=lambda b: phys[b]):
                 wphys[b] = rest.pop(0)
         inv = {phys[b]: b for b in range(n)}                          # physical (read side) -> logical
+        avoid = ({phys[b] for b in range(n) if wphys[b] in geom.final_free}
+                 if (geom.final_free and k == len(pending) - 1) else None)
         try:
-            step = _finalize(tops, n, geom, thigh, trounds, [wphys[inv[p_]] for p_ in range(n)])
+            step = _finalize(tops, n, geom, thigh, trounds, [wphys[inv[p_]] for p_ in range(n)], avoid)
         except _Infeasible:
             return None
         step.permutes = wphys != phys
@@ -677,8 +683,9 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
 
 
 def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rounds: list[_Round],
-              wpos: Sequence[int] | None = None) -> FusedStep:
-    """``wpos[p]`` = index bit the pass WRITES what it reads at index bit p to (None: where it was)."""
+              wpos: Sequence[int] | None = None, avoid_pad: set[int] | None = None) -> FusedStep:
+    """``wpos[p]`` = index bit the pass WRITES what it reads at index bit p to (None: where it was).  ``avoid_pad``: read
+    positions the tile is not PADDED with (``Geometry.final_free``) while others are left."""
     m, R, vb = geom.m, geom.slots, geom.vb
     rounds = [r for r in rounds if r.ops]
     L = geom.min_low
@@ -686,6 +693,11 @@ def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rou
     # gathered bits: the ones gates need, then the lowest free bits above the contiguous part
     highs = set(high)
     p = L
+    if avoid_pad and n - L - len(avoid_pad - highs) >= h:      # (enough other bits to pad with)
+        while len(highs) < h:
+            if p not in highs and p not in avoid_pad:
+                highs.add(p)
+            p += 1
     while len(highs) < h:
         if p not in highs:
             highs.add(p)

@@ -377,7 +377,7 @@ def _sliced_exchange_check(dq, rank, world, n, double, device='cpu'):
     from deepquantum_amd import executor
 
     dtype = torch.complex128 if double else torch.complex64
-    spec = bench.random_circuit_spec(n, 24, seed=77)
+    spec = bench.random_circuit_spec(n, 24 if device == 'cpu' else 40, seed=77)      # (several exchanges behind the first, local one)
     dense, data = bench.build_circuit(dq, n, spec, None, dtype, device)
     with torch.no_grad():
         ref = dense(data).reshape(-1)
@@ -405,11 +405,12 @@ def _sliced_exchange_check(dq, rank, world, n, double, device='cpu'):
                 got[(nb, lazy)] = (amps, stats)
                 if nb:
                     assert stats['sliced_remaps'] >= 1, stats
-                    assert max(stats['slice_launches_last'], stats['slice_launches_first']) >= 2, stats     # (a pass really was cut)
                 else:
                     assert stats['sliced_remaps'] == 0
         for key, (amps, _) in got.items():
             assert (amps - got[(0, key[1])][0]).abs().max().item() < tol
+        # (... and passes really were cut, on the send side or behind an exchange)
+        assert any(max(st_['slice_launches_last'], st_['slice_launches_first']) >= 2 for (nb_, _), (_, st_) in got.items() if nb_), got
         if os.environ.get('DQ_TEST_VERBOSE') and rank == 0:
             print({k_: {s_: v_[1][s_] for s_ in ('remaps', 'sliced_remaps', 'slice_launches_last', 'slice_launches_first', 'wire_bytes')} for k_, v_ in got.items()}, flush=True)
     finally:
