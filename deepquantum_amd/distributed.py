@@ -341,6 +341,18 @@ def _settle(state: DistributedQubitState) -> None:
     del keep        # (the matrices the group streams were reading: only now may their memory be reused)
 
 
+class _EventWait:
+    """``wait()``: the current stream waits for an event of the exchange stream (a slice that has arrived)."""
+
+    __slots__ = ('event',)
+
+    def __init__(self, event) -> None:
+        self.event = event
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 def _arrivals_done(state: DistributedQubitState, arr: dict | None) -> None:
     """Join a sliced exchange (`_remap_sliced`): every slice is ordered before what the current stream does next, and the
     buffer the slices were sent from becomes the state's spare third buffer again."""
@@ -879,11 +891,19 @@ def _remap_sliced(state: DistributedQubitState, pairs, rbits, pending: list[Prim
         what = (f'slice {j} of {nsl} of the shard exchange of remap {LAST_RUN["remaps"] + 1} (logical qubits leaving / entering '
                 f'{pairs}, rank bits {rbits}, peers {sorted(set(peers) - {state.rank})}, {nbytes} bytes each way)')
         if xs is not None:
+            # on the exchange stream, behind the launch that finished the slice; whoever needs the slice later waits for
+            # `done` -- recorded on that stream behind the exchange's own completion (RCCL: a stream-ordered wait, no host
+            # block; gloo on device memory: the staged copies back run on this stream) -- never for the handle itself
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(xs):
                 xs.wait_event(ev)
-                works[j] = exchange_pieces(pieces(dst, j), pieces(src, j), peers, what, async_op=True)
+                ex = exchange_pieces(pieces(dst, j), pieces(src, j), peers, what, async_op=True)
+                if ex is not None:
+                    ex.wait()
+                done = torch.cuda.Event()
+                done.record(xs)
+            works[j] = _EventWait(done)
         else:
             works[j] = exchange_pieces(pieces(dst, j), pieces(src, j), peers, what, async_op=False)
 
