@@ -2,7 +2,7 @@
 # Everything profiles/<tag>/ holds, in one go on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
 # then copy gpurun_out/prof/<tag>/{summary.txt,kernel_stats.csv,traffic_*.json,bench_*.json,*.txt} to profiles/<tag>/.
 cd "$(dirname "$0")/.."
-tag=${1:-r05}
+tag=${1:-r06}
 root=$PWD/gpurun_out/prof/$tag
 bash tools/profile.sh "$tag" > /dev/null 2>&1
 cp "$root/traffic.json" "$root/traffic_n28_b16_c64.json" 2>/dev/null
