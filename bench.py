@@ -94,6 +94,10 @@ def parse_args():
     ap.add_argument('--no-local-first-exchange', action='store_true',
                     help='N > 1, A/B: the first exchange behind reset() over the wire (round 5) instead of every rank '
                          'computing rank 0\'s first stretch itself')
+    ap.add_argument('--rehearse-loopback', action='store_true',
+                    help='with --rehearse-rank: the slices of a sliced exchange are copied send buffer -> receive buffer on the '
+                         'exchange stream instead of being left out, so that the bytes of the hidden wire cross this GPU\'s HBM '
+                         'beside the passes as they would with peers (measures the contention the model otherwise adds)')
     ap.add_argument('--slice-exchange', type=int, default=None,
                     help='N > 1, un-batched shards: bits the last pass in front of an exchange and the first pass behind it are '
                          'sliced by (0 = off; default: 2 under RCCL and in a rehearsal, distributed.CONFIG[\'slice_exchange\'])')
@@ -496,7 +500,8 @@ def rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed
             exposed = max(t_ms - hidden, t_ms / nsl)
             # ... and the hidden part is not free: its bytes cross this GPU's HBM (read to send, written on arrival) while
             # the passes want all of it
-            contention_ms += (t_ms - exposed) / t_ms * 2 * (1 - 0.5 ** k) * shard_bytes / (sum(kernel_bytes) / (sum(kernel_ms) * 1e-3)) * 1e3
+            if D.CONFIG['elide_exchange'] != 'loopback':     # (with --rehearse-loopback it is IN the measured compute)
+                contention_ms += (t_ms - exposed) / t_ms * 2 * (1 - 0.5 ** k) * shard_bytes / (sum(kernel_bytes) / (sum(kernel_ms) * 1e-3)) * 1e3
         wire.append({'remap': row['remap'], 'qubits_exchanged': k, 'links': (1 << k) - 1,
                      'wire_ms_at_peak_link_rate': t_ms,
                      # with 2^v rows of the shard in flight one after the other only the first row's share is not hidden
@@ -529,6 +534,7 @@ def rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed
         'hbm_contention_ms_of_the_hidden_wire_model': contention_ms,
         'modelled_step_ms_with_hbm_contention': ms + sum(w['exposed_ms_model'] for w in wire) + contention_ms,
         'slice_exchange_bits': D.slice_bits_wanted(cir.init_state) if hasattr(cir, 'init_state') else None,
+        'loopback_copies_for_the_hidden_wire': D.CONFIG['elide_exchange'] == 'loopback',
         'plan_seconds': plan_s, 'first_step_seconds': setup_s,
     }
 
@@ -564,7 +570,7 @@ def main():
     if rehearse:
         assert args.gpus > 1 and 0 <= args.rehearse_rank < args.gpus
         dq.DistributedQubitState.REHEARSE = (args.gpus, args.rehearse_rank)
-        dq.distributed.CONFIG['elide_exchange'] = True
+        dq.distributed.CONFIG['elide_exchange'] = 'loopback' if args.rehearse_loopback else True
     nshards = args.gpus if rehearse else world        # ranks the index bits are sharded over
 
     # ---- which workload -------------------------------------------------------------------------------------

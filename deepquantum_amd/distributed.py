@@ -69,6 +69,10 @@ CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_gr
           # are meaningless -- while schedule, passes, re-labellings and streams are exactly this rank's: the timing of the
           # kernels does not depend on the data, so the compute half of a multi-GPU step can be MEASURED on one GPU
           'elide_exchange': False,
+          # ... and with 'loopback' as its value the slices of a sliced exchange (`_remap_sliced`) are COPIED from the send
+          # buffer to the receive buffer on the exchange stream instead of being left out: the same bytes cross this GPU's HBM
+          # as when they leave for / arrive from the peers (only faster than any link), so the rehearsal measures what the
+          # hidden wire costs the passes it runs beside (amplitudes still meaningless)
           # a circuit that starts from reset() picks its FIRST qubit placement freely (`initial_placement`: |0..0> is the
           # same vector under every permutation of the qubits): the qubits needed last start on the rank bits.  A/B switch
           'initial_placement': True,
@@ -887,6 +891,17 @@ def _remap_sliced(state: DistributedQubitState, pairs, rbits, pending: list[Prim
         if rec is not None and rec['issued'] is None:
             rec['issued'] = _mark(None)
         if CONFIG['elide_exchange']:
+            if CONFIG['elide_exchange'] == 'loopback' and xs is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(xs):
+                    xs.wait_event(ev)
+                    for c, (pr, ps) in enumerate(zip(pieces(dst, j), pieces(src, j))):
+                        if peers[c] != state.rank:
+                            pr.copy_(ps)
+                    done = torch.cuda.Event()
+                    done.record(xs)
+                works[j] = _EventWait(done)
             return
         what = (f'slice {j} of {nsl} of the shard exchange of remap {LAST_RUN["remaps"] + 1} (logical qubits leaving / entering '
                 f'{pairs}, rank bits {rbits}, peers {sorted(set(peers) - {state.rank})}, {nbytes} bytes each way)')
