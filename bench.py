@@ -100,7 +100,7 @@ def parse_args():
                          'beside the passes as they would with peers (measures the contention the model otherwise adds)')
     ap.add_argument('--slice-exchange', type=int, default=None,
                     help='N > 1, un-batched shards: bits the last pass in front of an exchange and the first pass behind it are '
-                         'sliced by (0 = off; default: 2 under RCCL and in a rehearsal, distributed.CONFIG[\'slice_exchange\'])')
+                         'sliced by (0 = off; default: 3 under RCCL and in a rehearsal, distributed.CONFIG[\'slice_exchange\'])')
     ap.add_argument('--no-fold-permute', action='store_true',
                     help='N > 1, A/B: the re-labelling before an exchange as a pass of its own')
     ap.add_argument('--traffic-json', default=None, help='file with PMC-measured HBM bytes per launch')

@@ -91,7 +91,7 @@ CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_gr
           # stretch starts on slice j as soon as it has arrived.  The B qubits are the local ones needed last after the
           # evicted ones -- outside the tiles of both passes on (nearly) every rank; where one is not, that rank launches
           # fewer, bigger slices and the protocol stays the same.  Costs a third shard-sized buffer (the first pass behind
-          # the exchange must not write where slices are still being sent from).  None = 2 where an exchange can overlap
+          # the exchange must not write where slices are still being sent from).  None = 3 where an exchange can overlap
           # with compute at all (RCCL on device shards, or the rehearsal of such a job), 0 elsewhere; an int forces it
           'slice_exchange': None}
 
@@ -1440,7 +1440,7 @@ def slice_bits_wanted(state: DistributedQubitState) -> int:
     nb = CONFIG['slice_exchange']
     if nb is None:
         overlaps = state.amps.is_cuda and (CONFIG['elide_exchange'] or (dist.is_initialized() and dist.get_backend() == 'nccl'))
-        nb = 2 if overlaps else 0
+        nb = 3 if overlaps else 0           # (three bits against two, rehearsal of n = 34 / 8 ranks: −4 .. −7 ms per step)
     return int(nb) if (state.batch is None and _vbits(state) == 0) else 0
 
 
