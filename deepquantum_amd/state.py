@@ -330,13 +330,15 @@ class DistributedQubitState(_ComplexBuffers):
         # expectation values, stream hand-offs) is not inherited
         from copy import deepcopy
 
-        from .distributed import _settle
+        from .distributed import _materialize_zeros, _settle
 
         _settle(self)
+        _materialize_zeros(self)       # (a copy is read by whoever made it: logical zeros become real ones first)
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for key, value in self.__dict__.items():
-            if key in ('_raw', '_inflight', '_inflight_keep', '_expz', '_building'):
+            if key in ('_raw', '_inflight', '_inflight_keep', '_expz', '_building', '_spare', '_arrivals'):      # (the third buffer of a
+                #  sliced exchange is scratch: a copy gets its own when it needs one)
                 continue
             new.__dict__[key] = deepcopy(value, memo)
         return new
