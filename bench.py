@@ -996,6 +996,14 @@ def main():
                 line['config']['virtual_bits_model'] = dq.distributed.virtual_bits_table(
                     prims_, n, n - g_, fresh=True, restore=not cir.lazy_layout)
             line['config']['local_first_exchanges_per_step'] = dstats.get('local_first_exchanges')
+            # the passes around an exchange in slices (un-batched shards): protocol bits, remaps that were sliced,
+            # launches of the last pass in front of them / of the first pass behind them (this rank), memsets the step needed
+            line['config']['slice_exchange'] = {
+                'bits': dq.distributed.slice_bits_wanted(cir.init_state) if batch is None else 0,
+                'sliced_remaps_per_step': dstats.get('sliced_remaps'),
+                'launches_of_the_last_passes': dstats.get('slice_launches_last'),
+                'launches_of_the_first_passes_behind': dstats.get('slice_launches_first'),
+                'zero_fills_per_step': dstats.get('zero_fills')}
             line['config']['exchange_plan'] = {
                 'with_virtual_bits': dq.distributed.count_exchange_steps(prims_, n, g_, virtual_bits=vb_, reorder=True),
                 'without': dq.distributed.count_exchange_steps(prims_, n, g_, virtual_bits=0, reorder=True) if vb_ else None}
