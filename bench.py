@@ -98,6 +98,8 @@ def parse_args():
                     help='with --rehearse-rank: the slices of a sliced exchange are copied send buffer -> receive buffer on the '
                          'exchange stream instead of being left out, so that the bytes of the hidden wire cross this GPU\'s HBM '
                          'beside the passes as they would with peers (measures the contention the model otherwise adds)')
+    ap.add_argument('--no-defer-tail', action='store_true',
+                    help='N > 1, A/B: run the under-filled last pass of a stretch instead of moving its gates behind the exchange')
     ap.add_argument('--slice-exchange', type=int, default=None,
                     help='N > 1, un-batched shards: bits the last pass in front of an exchange and the first pass behind it are '
                          'sliced by (0 = off; default: 3 under RCCL and in a rehearsal, distributed.CONFIG[\'slice_exchange\'])')
@@ -525,7 +527,8 @@ def rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed
                                                     fresh=True, restore=False) if nbatch == 1 else None),
         'schedule': {k_: st[k_] for k_ in ('remaps', 'virtual_remaps', 'folded_permutes', 'permute_passes', 'local_flushes',
                                            'zero_shard_stretches', 'known_zero_stretches', 'local_first_exchanges',
-                                           'sliced_remaps', 'slice_launches_last', 'slice_launches_first', 'zero_fills')},
+                                           'sliced_remaps', 'slice_launches_last', 'slice_launches_first', 'zero_fills',
+                                           'deferred_tails', 'deferred_gates')},
         'wire_model': {'peak_GBs_per_link': XGMI_LINK_GBS, 'remaps': wire,
                        'wire_ms_per_step_all_exposed': sum(w['wire_ms_at_peak_link_rate'] for w in wire),
                        'wire_ms_per_step_exposed_model': sum(w['exposed_ms_model'] for w in wire)},
@@ -618,6 +621,8 @@ def main():
         dq.distributed.CONFIG['first_exchange_local'] = False
     if args.slice_exchange is not None:
         dq.distributed.CONFIG['slice_exchange'] = args.slice_exchange
+    if args.no_defer_tail:
+        dq.distributed.CONFIG['defer_tail'] = 0
     if args.no_fold_permute:
         dq.distributed.CONFIG['fold_permute'] = False
 
@@ -1003,7 +1008,8 @@ def main():
                 'sliced_remaps_per_step': dstats.get('sliced_remaps'),
                 'launches_of_the_last_passes': dstats.get('slice_launches_last'),
                 'launches_of_the_first_passes_behind': dstats.get('slice_launches_first'),
-                'zero_fills_per_step': dstats.get('zero_fills')}
+                'zero_fills_per_step': dstats.get('zero_fills'),
+                'deferred_tails_per_step': dstats.get('deferred_tails'), 'deferred_gates_per_step': dstats.get('deferred_gates')}
             line['config']['exchange_plan'] = {
                 'with_virtual_bits': dq.distributed.count_exchange_steps(prims_, n, g_, virtual_bits=vb_, reorder=True),
                 'without': dq.distributed.count_exchange_steps(prims_, n, g_, virtual_bits=0, reorder=True) if vb_ else None}

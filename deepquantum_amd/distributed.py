@@ -93,7 +93,12 @@ CONFIG = {'mode': 'remap', 'remap_min_prims': 8, 'horizon': 1 << 14, 'overlap_gr
           # fewer, bigger slices and the protocol stays the same.  Costs a third shard-sized buffer (the first pass behind
           # the exchange must not write where slices are still being sent from).  None = 3 where an exchange can overlap
           # with compute at all (RCCL on device shards, or the rehearsal of such a job), 0 elsewhere; an int forces it
-          'slice_exchange': None}
+          'slice_exchange': None,
+          # an under-filled LAST pass of a stretch (at most this many kernel gates) is not run at all: its gates move behind
+          # the exchange, where the next stretch's first passes take them in (legal when none of them targets a qubit that
+          # leaves for the rank bits; `_defer_tail`).  A pass of 3-7 gates costs a whole read and write of the shard; dry run of
+          # the n = 34 / 8-rank step: 33 -> 32 passes.  0 = off
+          'defer_tail': 12}
 
 #: the accumulator of the DQ_FG_GRAD reductions while a fused reverse sweep runs on a sharded (psi, lambda) pair
 #: (adjoint._sweep_fused_sharded): every local stretch hands its rows to the passes
@@ -103,7 +108,7 @@ _SWEEP: dict = {'grads': None}
 LAST_RUN = {'remaps': 0, 'pairwise_exchanges': 0, 'local_flushes': 0, 'folded_permutes': 0, 'permute_passes': 0,
             'wire_bytes': 0, 'groups': 1, 'virtual_bits': 0, 'virtual_remaps': 0, 'zero_shard_stretches': 0,
             'known_zero_stretches': 0, 'local_first_exchanges': 0, 'zero_fills': 0, 'sliced_remaps': 0,
-            'slice_launches_last': 0, 'slice_launches_first': 0}
+            'slice_launches_last': 0, 'slice_launches_first': 0, 'deferred_tails': 0, 'deferred_gates': 0}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1457,11 +1462,88 @@ def _slice_qubits(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int, 
     return cand[:nbits]
 
 
-def _remap_for(state: DistributedQubitState, prims: Sequence[Prim], i: int, pending: list[Prim]) -> None:
+class _Pending(list):
+    """The local gates of the stretch under way (physical positions, localized) with, beside each, the LOGICAL primitive it
+    was made from (``src``), and ALL logical primitives of the stretch in order (``every``: also those that are nothing on
+    this rank -- a control on a 0 rank bit) -- what `_defer_tail` decides on and re-queues behind the exchange.  ``src`` is
+    None once the list has been rewritten wholesale (virtual rank bits re-localize it): nothing is deferred then."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.src: list | None = []
+        self.every: list = []
+
+    def add(self, local: Prim | None, logical: Prim) -> None:
+        self.every.append(logical)
+        if local is not None:
+            super().append(local)
+            if self.src is not None:
+                self.src.append(logical)
+
+    def clear(self) -> None:
+        super().clear()
+        self.src = []
+        self.every = []
+
+    def __setitem__(self, key, value) -> None:
+        super().__setitem__(key, value)
+        self.src = None
+
+
+def _defer_tail(state: DistributedQubitState, pending: list[Prim], pairs) -> list[Prim]:
+    """CONFIG['defer_tail']: if the last pass of the stretch would be under-filled and none of its gates targets a qubit that
+    is about to leave for the rank bits (``pairs``), take those gates out of ``pending`` and return their logical primitives:
+    the caller queues them again behind the exchange.
+
+    EVERY RANK MUST DEFER THE SAME GATES -- a gate one rank applies before the exchange and its peer behind it is applied
+    twice to some chunks and never to others -- while the plans differ between ranks (a control on a rank bit makes a gate
+    nothing on half of them).  So the decision is taken on the stretch as the rank with ALL rank bits set sees it (every
+    rank-controlled gate present: a superset of everybody's gates; `executor.tail_of_last_pass` on that list), from
+    quantities every rank has alike: the logical gate list, the placement, the number of exchanges so far.  The tail of a
+    superset's schedule is closed under "comes later and does not commute" for every subset, so the move is legal on
+    every rank whether or not the gates form ITS last pass."""
+    cap = int(CONFIG['defer_tail'] or 0)
+    if (not cap or not isinstance(pending, _Pending) or pending.src is None or len(pending.every) < 32
+            or _vbits(state) or _SWEEP['grads'] is not None or _view(state).shape[0] != 1
+            or LAST_RUN['remaps'] < 2):         # (the first two stretches run behind |0..0> / with known-zero masks: cheap anyway)
+        return []
+    ph = _phys(state)
+    L = state.log_num_amps_per_node
+    leaving = {ph[eq] for _, eq in pairs}
+    ones = state.world_size - 1
+    canon, index = [], []
+    for m, q in enumerate(pending.every):
+        loc = _localize_at(L, ones, _translate(q, ph))
+        if isinstance(loc, Prim):
+            canon.append(loc)
+            index.append(m)
+    x = _view(state)
+    tail = executor.tail_of_last_pass(x, canon, amps=x.numel(), max_gates=cap)
+    if not tail or any(set(canon[m].targets) & leaving for m in tail):
+        return []
+    carry = [pending.every[index[m]] for m in tail]
+    gone = {id(q) for q in carry}
+    rest = [(p_, s_) for p_, s_ in zip(pending, pending.src) if id(s_) not in gone]
+    every = [q for q in pending.every if id(q) not in gone]
+    pending.clear()
+    for p_, s_ in rest:
+        list.append(pending, p_)
+        pending.src.append(s_)
+    pending.every = every
+    LAST_RUN['deferred_tails'] += 1
+    LAST_RUN['deferred_gates'] += len(carry)
+    return carry
+
+
+def _remap_for(state: DistributedQubitState, prims: Sequence[Prim], i: int, pending: list[Prim]) -> list[Prim]:
+    """The remap that makes gate ``i`` local, behind the local gates ``pending``.  Returns the logical primitives of a
+    deferred tail (`_defer_tail`): the caller localizes them under the new layout before anything else."""
     L = state.log_num_amps_per_node - _vbits(state)
     pairs = _plan_remap(_phys(state), prims, i, state.nqubit, L, _vbits(state))
+    carry = _defer_tail(state, pending, pairs)
     nb = slice_bits_wanted(state)
     _remap(state, pairs, pending, _slice_qubits(_phys(state), prims, i, state.nqubit, L, pairs, nb) if nb else ())
+    return carry
 
 
 def count_exchange_steps(prims: Sequence[Prim], n: int, g: int, virtual_bits: int = 0, reorder: bool = False,
@@ -1650,7 +1732,7 @@ def _dist_apply_loop(state: DistributedQubitState, prims: Sequence[Prim], mode: 
                                                     restore=not keep_layout, structure=structure)
     if mode == 'remap' and CONFIG['reorder']:
         prims = _order_for_remaps(prims, _phys(state), state.nqubit, state.log_num_amps_per_node - vb, vb, structure)
-    pending: list[Prim] = []
+    pending = _Pending()
     i, nprims = 0, len(prims)
     while i < nprims:
         p = prims[i] if mode == 'pairwise' else _translate(prims[i], _phys(state))
@@ -1660,15 +1742,16 @@ def _dist_apply_loop(state: DistributedQubitState, prims: Sequence[Prim], mode: 
             if p.kind != 'diag' and any(t >= state.log_num_amps_per_node - vb for t in p.targets):
                 _remap_for(state, prims, i, pending)
             else:
-                pending.append(p)
+                pending.add(p, prims[i])
                 i += 1
             continue
         local = _localize(state, p)
         if local is None:
+            pending.add(None, prims[i])      # (nothing on this rank -- but part of the stretch: `_defer_tail`)
             i += 1
             continue
         if isinstance(local, Prim):
-            pending.append(local)
+            pending.add(local, prims[i])
             i += 1
             continue
         if mode == 'pairwise':
@@ -1676,7 +1759,11 @@ def _dist_apply_loop(state: DistributedQubitState, prims: Sequence[Prim], mode: 
             _exchange_prim(state, p)
             i += 1
         else:
-            _remap_for(state, prims, i, pending)     # local gates so far + exchange; then gate i under the new layout
+            carry = _remap_for(state, prims, i, pending)     # local gates so far + exchange; then gate i under the new layout
+            for q in carry:                                  # (a deferred tail: first in line behind the exchange)
+                loc = _localize(state, _translate(q, _phys(state)))
+                assert loc != 'exchange', 'a deferred gate targets a qubit that left for the rank bits'
+                pending.add(loc if isinstance(loc, Prim) else None, q)
     if vb:                        # back to ONE shard of 2^L amplitudes (the rows are its top local index bits): the last
         _settle(state)            # stretch runs on the whole shard
         state.__dict__.pop('_vbits', None)

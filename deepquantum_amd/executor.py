@@ -567,6 +567,42 @@ def _permute_after(x: torch.Tensor, out_perm: Sequence[int], scratch: torch.Tens
     return backend.permute_bits(x, src_of_dst, out=dst)
 
 
+def tail_of_last_pass(state: torch.Tensor, prims: Sequence[Prim], amps: int, max_gates: int) -> list[int] | None:
+    """The indices (into ``prims``) of the gates the LAST fused pass of `run(state, prims, scratch=...)` would hold, if that
+    pass is under-filled -- at most ``max_gates`` kernel gates -- and not the only one; None otherwise.  Structure only (no
+    matrices are touched): the same merge of one-qubit runs and the same planner as the run itself.  The sharded state moves
+    such a tail behind the exchange that follows the stretch (`distributed._defer_tail`): a pass of 3-7 gates costs a whole
+    read and write of the shard."""
+    n = state.shape[-1].bit_length() - 1
+    is128 = state.dtype == torch.complex128
+    if not CONFIG['fuse'] or n < _geometry(is128).m or len(prims) < 2:
+        return None
+    members = [[i] for i in range(len(prims))]
+    struct = list(prims)
+    if CONFIG['merge_min_amps'] is not None and state.numel() >= CONFIG['merge_min_amps']:
+        groups, order, _multi, _levels = _merge_structure(prims)
+        riders: dict = {}                   # carrier group -> the factors of the scalar products that ride on its matrix
+        for kind, idx in order:
+            if kind == 's':                 # (c I commutes with everything: its factors go wherever their carrier goes)
+                riders.setdefault(groups[idx][3], []).extend(groups[idx][0])
+        members, struct = [], []
+        for kind, idx in order:
+            if kind == 's':
+                continue
+            if kind == 'p':
+                members.append([idx])
+                struct.append(prims[idx])
+            else:
+                members.append(list(groups[idx][0]) + riders.get(idx, []))
+                struct.append(Prim('gen', None, prims[groups[idx][0][0]].targets, (), groups[idx][1]))
+    permute = CONFIG['permute_store'] and n >= CONFIG['permute_min_bits']
+    plan = make_plan(struct, n, is128, permute, None, amps=max(state.numel(), amps or 0))
+    fused = [st for st in plan.steps if isinstance(st, fusion.FusedStep)]
+    if len(fused) < 2 or not isinstance(plan.steps[-1], fusion.FusedStep) or len(fused[-1].ops) > max_gates:
+        return None
+    return sorted(m for oi in fused[-1].ops for m in members[oi])
+
+
 def _slicing_all(slicing: dict | None, which: str, where: torch.Tensor | None = None) -> None:
     """Every protocol slice's callback of ``slicing[which]`` (a run, or a pass, that is not sliced); ``where``: the buffer
     that holds the result (``after`` callbacks)."""

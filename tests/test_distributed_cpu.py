@@ -418,6 +418,65 @@ def _sliced_exchange_check(dq, rank, world, n, double, device='cpu'):
         D.CONFIG['slice_exchange'] = None
 
 
+def _deferred_tail_check(dq, rank, world, n, double):
+    """CONFIG['defer_tail'] (round 6): an under-filled last pass of a stretch is not run, its gates move behind the exchange.
+    Every rank must defer the SAME gates (decided on the stretch as the rank with all rank bits set sees it): the counts are
+    compared across the ranks, the shards with the dense circuit and with the run that defers nothing -- with and without the
+    exchanges in slices."""
+    import bench
+    import torch.distributed as dist
+    from deepquantum_amd import distributed as D
+    from deepquantum_amd import executor
+
+    dtype = torch.complex128 if double else torch.complex64
+    per = (1 << n) // world
+    old = dict(executor.CONFIG)
+    executor.CONFIG['permute_min_bits'] = 11
+    tol = 1e-10 if double else 3e-5
+    deferred = 0
+    try:
+        for ci, (seed, depth) in enumerate(((1505, 22), (3, 30), (11, 30), (29, 40), (31, 22), (47, 40), (53, 30), (61, 40))):
+            if ci >= 2 and deferred:        # (at least two circuits, and on until some stretch had its tail deferred)
+                break
+            spec = bench.random_circuit_spec(n, depth, seed=seed)
+            dense, data = bench.build_circuit(dq, n, spec, None, dtype, 'cpu')
+            with torch.no_grad():
+                ref = dense(data).reshape(-1)
+            got = {}
+            for cap, nb in ((0, 0), (40, 0), (40, 2)):
+                D.CONFIG['defer_tail'], D.CONFIG['slice_exchange'] = cap, nb
+                cir, _ = bench.build_circuit(dq, n, spec, None, dtype, 'cpu', distributed=True)
+                cir.lazy_layout = False
+                with torch.no_grad():
+                    st = cir(data)
+                    stats = dict(D.LAST_RUN)
+                amps = st.amps.reshape(-1).clone()
+                err = (amps - ref[rank * per:(rank + 1) * per]).abs().max().item()
+                assert err < tol, f'rank {rank} seed {seed} defer_tail {cap} slices {nb}: shard error {err}; {stats}'
+                got[(cap, nb)] = amps
+                counts = torch.tensor([stats['deferred_tails'], stats['deferred_gates']], dtype=torch.int64)
+                every = [torch.zeros_like(counts) for _ in range(world)]
+                dist.all_gather(every, counts)
+                assert all(torch.equal(c, counts) for c in every), f'the ranks deferred different gates: {every}'
+                assert (cap > 0) or stats['deferred_tails'] == 0
+                if cap:
+                    deferred += stats['deferred_tails']
+            for amps in got.values():
+                assert (amps - got[(0, 0)]).abs().max().item() < tol
+        assert deferred > 0, 'no stretch of any circuit had its tail deferred'
+    finally:
+        executor.CONFIG.update(old)
+        D.CONFIG['defer_tail'], D.CONFIG['slice_exchange'] = 12, None
+
+
+def _case_deferred_tail_w2(dq, rank, world):
+    _deferred_tail_check(dq, rank, world, 17, double=True)
+
+
+def _case_deferred_tail_w4(dq, rank, world):
+    _deferred_tail_check(dq, rank, world, 18, double=False)
+
+
 def _case_sliced_exchange_w2(dq, rank, world):
     _sliced_exchange_check(dq, rank, world, 17, double=True)
     _sliced_exchange_check(dq, rank, world, 18, double=False)
@@ -769,7 +828,7 @@ def _case_sampled_expectation_w4(dq, rank, world):
                                         ('expectation_grad_w4', 4), ('measure_w2', 2), ('batched_w4', 4), ('folded_permute_w2', 2),
                                         ('golden_w2', 2), ('golden_w4', 4), ('golden_w8', 8),
                                         ('fused_sweep_w2', 2), ('fused_sweep_w4', 4), ('grouped_exchange_w4', 4), ('virtual_bits_w2', 2), ('virtual_bits_w4', 4), ('initial_placement_w4', 4),
-                                        ('zero_state_w2', 2), ('zero_state_w4', 4), ('sliced_exchange_w2', 2), ('sliced_exchange_w4', 4)])
+                                        ('zero_state_w2', 2), ('zero_state_w4', 4), ('sliced_exchange_w2', 2), ('sliced_exchange_w4', 4), ('deferred_tail_w2', 2), ('deferred_tail_w4', 4)])
 def test_sharded_circuit(case, world):
     _run(case, world)
 

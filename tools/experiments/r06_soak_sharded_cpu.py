@@ -1,7 +1,7 @@
 """Round 6 soak of the sharded state WITHOUT a GPU: gloo worlds of 2 and 4 on the CPU test double (NaN wherever a masked pass
 leaves its output untouched AND wherever a lazy reset() did not clear), random benchmark-generator circuits deep enough for
 several exchanges, un-batched and batched shards, the round's switches drawn per seed -- slice_exchange 0 .. 3,
-first_exchange_local, evict_foldable, virtual bits -- two forwards each (the second starts from dirty buffers), shards and <Z0>
+first_exchange_local, evict_foldable, defer_tail, virtual bits -- two forwards each (the second starts from dirty buffers), shards and <Z0>
 against the dense circuit.  usage: python tools/experiments/r06_soak_sharded_cpu.py [first_seed] [count]
 DQ_SOAK_DEVICE=cuda: the same with the REAL kernels, the ranks sharing the GPU (gloo, host-staged exchanges), states 3 qubits bigger."""
 import os
@@ -55,7 +55,7 @@ def worker(rank, world, port, first, count, ret):
             depth = rng.choice((8, 14, 22, 30))
             nb = rng.choice((0, 1, 2, 3))
             cfg = {'slice_exchange': nb, 'first_exchange_local': rng.random() < 0.8, 'evict_foldable': rng.choice((None, True, False)),
-                   'virtual_bits': 0 if (nb or batch is not None) else rng.choice((0, 0, 1, 2))}
+                   'virtual_bits': 0 if (nb or batch is not None) else rng.choice((0, 0, 1, 2)), 'defer_tail': rng.choice((0, 12, 12, 40))}
             spec = bench.random_circuit_spec(n, depth, seed=1000 + seed)
             dense, data = bench.build_circuit(dq, n, spec, batch, dtype, device)
             with torch.no_grad():
@@ -80,8 +80,8 @@ def worker(rank, world, port, first, count, ret):
             if rank == 0:
                 print(f'seed {seed}: world {world} n {n} batch {batch} depth {depth} {str(dtype)[-9:]} {cfg}: ok (remaps {stats["remaps"]}, sliced '
                       f'{stats["sliced_remaps"]}: launches {stats["slice_launches_last"]} / {stats["slice_launches_first"]}, local first '
-                      f'{stats["local_first_exchanges"]}, zero fills {stats["zero_fills"]})', flush=True)
-        D.CONFIG.update({'slice_exchange': None, 'first_exchange_local': True, 'evict_foldable': None, 'virtual_bits': None})
+                      f'{stats["local_first_exchanges"]}, zero fills {stats["zero_fills"]}, deferred tails {stats["deferred_tails"]} ({stats["deferred_gates"]} gates))', flush=True)
+        D.CONFIG.update({'slice_exchange': None, 'first_exchange_local': True, 'evict_foldable': None, 'virtual_bits': None, 'defer_tail': 12})
         dq.cleanup_distributed()
         ret[rank] = 'ok' if sliced or count < 4 else 'no remap was ever sliced'
     except Exception:  # noqa: BLE001
