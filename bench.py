@@ -536,7 +536,7 @@ def rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed
         'full_pass_ms_on_this_shard': full_pass_ms,
         'hbm_contention_ms_of_the_hidden_wire_model': contention_ms,
         'modelled_step_ms_with_hbm_contention': ms + sum(w['exposed_ms_model'] for w in wire) + contention_ms,
-        'slice_exchange_bits': D.slice_bits_wanted(cir.init_state) if hasattr(cir, 'init_state') else None,
+        'slice_exchange_bits': D.slice_bits_wanted(cir.init_state) if getattr(cir, 'init_state', None) is not None else None,
         'loopback_copies_for_the_hidden_wire': D.CONFIG['elide_exchange'] == 'loopback',
         'plan_seconds': plan_s, 'first_step_seconds': setup_s,
     }
@@ -1004,7 +1004,8 @@ def main():
             # the passes around an exchange in slices (un-batched shards): protocol bits, remaps that were sliced,
             # launches of the last pass in front of them / of the first pass behind them (this rank), memsets the step needed
             line['config']['slice_exchange'] = {
-                'bits': dq.distributed.slice_bits_wanted(cir.init_state) if batch is None else 0,
+                'bits': (dq.distributed.slice_bits_wanted(cir.init_state)
+                         if (batch is None and getattr(cir, 'init_state', None) is not None) else (0 if batch is not None else None)),
                 'sliced_remaps_per_step': dstats.get('sliced_remaps'),
                 'launches_of_the_last_passes': dstats.get('slice_launches_last'),
                 'launches_of_the_first_passes_behind': dstats.get('slice_launches_first'),
