@@ -183,7 +183,7 @@ def _steady(prims: Sequence[Prim]) -> dict | None:
 
 def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
               out_perm: Sequence[int] | None = None, amps: int = 0, steady: dict | None = None,
-              final_free: tuple = ()) -> Plan:
+              final_free: tuple = (), pad_untouched: bool = False, known_zero: int | None = None) -> Plan:
     """``amps`` = amplitudes the plan will be run on (batch included): from ``CONFIG['plan_big_amps']`` on a step
     takes long enough (>= 0.1 s) for a wider search of the pass planner to pay for itself within a few steps
     (measured on the headline: 21 -> 20 passes, -2.7 %, 4.6 s of planning once per circuit structure)."""
@@ -202,9 +202,11 @@ def make_plan(prims: Sequence[Prim], n: int, is128: bool, permute: bool = False,
             geom.plan_restarts = 6
     geom.permute_store = permute
     geom.final_free = tuple(final_free) if permute else ()
+    geom.pad_last_with_untouched = bool(pad_untouched)
+    geom.known_zero = known_zero
     head = (n, is128, geom.m, geom.slots, geom.min_low, geom.max_gates, geom.max_far, geom.far_bit, geom.plan_width,
             geom.plan_branch, geom.plan_restarts, geom.free_low, permute, CONFIG['fuse'], None if out_perm is None else tuple(out_perm),
-            geom.final_free)
+            geom.final_free, geom.pad_last_with_untouched, geom.known_zero)
     if steady is not None:
         plan = steady['plans'].get(head)
         if plan is not None and _PLAN_CACHE.get(plan[0]) is plan[1]:     # (still the plan the global cache would give)
@@ -676,7 +678,9 @@ def _run_nograd(state: torch.Tensor, prims: Sequence[Prim], inplace: bool = Fals
                 permute = 2 * nbytes <= CONFIG['permute_mem_frac'] * total and 2.05 * nbytes <= free
         steady = _steady(prims)
         plan = make_plan(prims, n, is128, permute, out_perm if permute else None, amps=max(state.numel(), amps or 0),
-                         steady=steady, final_free=tuple(slicing['last'][0]) if (slicing and 'last' in slicing) else ())
+                         steady=steady, final_free=tuple(slicing['last'][0]) if (slicing and 'last' in slicing) else (),
+                         pad_untouched=bool(zero_state) and bool(CONFIG['zero_state']),
+                         known_zero=int(zero_state) if (zero_state is not True and zero_state and CONFIG['zero_state']) else None)
         # one initial state expanded over the batch (stride 0) and a fused first step: that pass reads the single
         # state directly and writes the B results -- no B materialised copies
         shared_in = None

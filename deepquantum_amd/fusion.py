@@ -94,6 +94,16 @@ class Geometry:
     # unless a gate needs them: the sharded state launches it in slices by exactly these bits (executor.run(slicing=...)),
     # and a bit that merely PADS the tile would cost a factor two in slices for nothing
     final_free: tuple = ()
+    # a run behind |0..0> (or on a state with index bits known to be |0>): the LAST pass pads its tile with the index bits
+    # that no pass has had in its tile so far, while it has room -- a bit left outside every tile makes `zero_state_masks`
+    # give up on the whole schedule (the result would keep uninitialised memory), and which bits are left is a matter of
+    # the plan: on three of eight ranks of the n = 34 job one of the three qubits that came from the rank bits was, and
+    # their second stretch ran 8 full passes instead of 6.25 (44 ms against 34)
+    pad_last_with_untouched: bool = False
+    # the index bits the run's input is known to be |0> on (a shard behind its first exchange: the qubits that came from the
+    # rank bits; None: a circuit's own |0..0>, i.e. all of them): among schedules of as many passes the planner keeps the
+    # one that moves the least behind THAT state (`zero_state_cost`)
+    known_zero: int | None = None
 
     @property
     def logt(self) -> int:
@@ -451,7 +461,7 @@ def _schedule(ops: Sequence[PrimOp], n: int, geom: Geometry, width: int,
         if out is not None:
             # among schedules of as many passes: the one that moves the least behind |0..0> (most circuits start there:
             # `zero_state_masks`), then the one with the fewest layout changes
-            key = (len(out), zero_state_cost(out, n), sum(s_.ntranspose for s_ in out if isinstance(s_, FusedStep)))
+            key = (len(out), zero_state_cost(out, n, geom.known_zero), sum(s_.ntranspose for s_ in out if isinstance(s_, FusedStep)))
             if best is None or key < best[0]:
                 best = (key, out)
         if len(seen) >= 4 and best is not None or len(seen) >= 8:
@@ -625,6 +635,7 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
     phys = list(range(n))
     out = Steps()
     final = list(range(n))
+    touched: set[int] = set()           # logical index bits some pass has had in its tile so far
     if (permute and final_perm is not None and pending and not isinstance(pending[-1], SingleStep)
             and all(final_perm[b] == b for b in range(pending[-1][0].min_low))):
         final = list(final_perm)
@@ -671,8 +682,12 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
         inv = {phys[b]: b for b in range(n)}                          # physical (read side) -> logical
         avoid = ({phys[b] for b in range(n) if wphys[b] in geom.final_free}
                  if (geom.final_free and k == len(pending) - 1) else None)
+        touched |= set(low_list) | set(high)
+        prefer = None
+        if geom.pad_last_with_untouched and k == len(pending) - 1:
+            prefer = [phys[b] for b in range(n) if b not in touched]      # (read positions, ascending logical bit)
         try:
-            step = _finalize(tops, n, geom, thigh, trounds, [wphys[inv[p_]] for p_ in range(n)], avoid)
+            step = _finalize(tops, n, geom, thigh, trounds, [wphys[inv[p_]] for p_ in range(n)], avoid, prefer)
         except _Infeasible:
             return None
         step.permutes = wphys != phys
@@ -683,15 +698,22 @@ def _place_writes(ops: Sequence[PrimOp], n: int, pending: list, permute: bool,
 
 
 def _finalize(ops: Sequence[PrimOp], n: int, geom: Geometry, high: set[int], rounds: list[_Round],
-              wpos: Sequence[int] | None = None, avoid_pad: set[int] | None = None) -> FusedStep:
+              wpos: Sequence[int] | None = None, avoid_pad: set[int] | None = None,
+              prefer_pad: Sequence[int] | None = None) -> FusedStep:
     """``wpos[p]`` = index bit the pass WRITES what it reads at index bit p to (None: where it was).  ``avoid_pad``: read
-    positions the tile is not PADDED with (``Geometry.final_free``) while others are left."""
+    positions the tile is not PADDED with (``Geometry.final_free``) while others are left; ``prefer_pad``: read positions
+    it is padded with FIRST (``Geometry.pad_last_with_untouched``)."""
     m, R, vb = geom.m, geom.slots, geom.vb
     rounds = [r for r in rounds if r.ops]
     L = geom.min_low
     h = m - L
     # gathered bits: the ones gates need, then the lowest free bits above the contiguous part
     highs = set(high)
+    for q in (prefer_pad or ()):
+        if len(highs) >= h:
+            break
+        if q >= L and q not in highs and not (avoid_pad and q in avoid_pad):
+            highs.add(q)
     p = L
     if avoid_pad and n - L - len(avoid_pad - highs) >= h:      # (enough other bits to pad with)
         while len(highs) < h:
@@ -935,10 +957,11 @@ def zero_state_masks(steps: Sequence, n: int, known_zero: int | None = None) -> 
     return masks if any(masks) else None
 
 
-def zero_state_cost(steps: Sequence, n: int) -> float:
-    """What the passes of a schedule move when the circuit starts from |0..0>, in units of a full pass (one read + one write
-    of the state): `zero_state_masks` says which index bits are still known to be zero at every pass."""
-    masks = zero_state_masks(steps, n)
+def zero_state_cost(steps: Sequence, n: int, known_zero: int | None = None) -> float:
+    """What the passes of a schedule move when the circuit starts from |0..0> (``known_zero``: from a state with THESE index
+    bits known to be |0>), in units of a full pass (one read + one write of the state): `zero_state_masks` says which index
+    bits are still known to be zero at every pass."""
+    masks = zero_state_masks(steps, n, known_zero)
     if masks is None:
         return float(len(steps))
     cost = 0.0
