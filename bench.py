@@ -493,6 +493,12 @@ def rehearsal_line(dq, args, cir, n, per_gpu, nbatch, amp_bytes, ngates, elapsed
         # a k-qubit remap: 2^k - 1 peers, one chunk of shard / 2^k to each over its own link, both directions at once
         t_ms = shard_bytes / (1 << k) / (XGMI_LINK_GBS * 1e9) * 1e3
         exposed = t_ms / (1 << vb) if vb else t_ms
+        groups = max(1, row['samples'] // args.steps)
+        if not vb and groups > 1:
+            # a batched shard moves through a remap in `groups` sample groups on their own streams: a group's amplitudes are on
+            # the links while the next group computes, and a group starts its next stretch as soon as ITS exchange is back --
+            # what can stay exposed is the last group's share
+            exposed = t_ms / groups
         sl, sf, nsl = row.get('slices_last') or 0, row.get('slices_first') or 0, row.get('slices') or 0
         if nsl and full_pass_ms:
             # a sliced exchange: the last pass in `sl` launches, the first pass behind it in `sf`; the wire of
