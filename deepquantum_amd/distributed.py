@@ -1504,7 +1504,7 @@ def _defer_tail(state: DistributedQubitState, pending: list[Prim], pairs) -> lis
     every rank whether or not the gates form ITS last pass."""
     cap = int(CONFIG['defer_tail'] or 0)
     if (not cap or not isinstance(pending, _Pending) or pending.src is None or len(pending.every) < 32
-            or _vbits(state) or _SWEEP['grads'] is not None or _view(state).shape[0] != 1
+            or _vbits(state) or _SWEEP['grads'] is not None
             or LAST_RUN['remaps'] < 2):         # (the first two stretches run behind |0..0> / with known-zero masks: cheap anyway)
         return []
     ph = _phys(state)
@@ -1518,7 +1518,8 @@ def _defer_tail(state: DistributedQubitState, pending: list[Prim], pairs) -> lis
             canon.append(loc)
             index.append(m)
     x = _view(state)
-    tail = executor.tail_of_last_pass(x, canon, amps=x.numel(), max_gates=cap)
+    x = x[_row_groups(state)[0]]            # (a batched shard runs its stretches group by group: the plan is the group's)
+    tail = executor.tail_of_last_pass(x, canon, amps=_view(state).numel(), max_gates=cap)
     if not tail or any(set(canon[m].targets) & leaving for m in tail):
         return []
     carry = [pending.every[index[m]] for m in tail]
