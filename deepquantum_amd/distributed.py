@@ -1505,6 +1505,7 @@ def _defer_tail(state: DistributedQubitState, pending: list[Prim], pairs) -> lis
     cap = int(CONFIG['defer_tail'] or 0)
     if (not cap or not isinstance(pending, _Pending) or pending.src is None or len(pending.every) < 32
             or _vbits(state) or _SWEEP['grads'] is not None
+            or _view(state).shape[0] != 1      # (batched shards: measured neutral -- weak series n = 31: 350 / 365 ms with, 350 / 357 without)
             or LAST_RUN['remaps'] < 2):         # (the first two stretches run behind |0..0> / with known-zero masks: cheap anyway)
         return []
     ph = _phys(state)
