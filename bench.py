@@ -878,6 +878,13 @@ def main():
         qaoa['matches_closed_form'] = qaoa['max_relative_error_vs_closed_form'] < 1e-3
         if parity_ok is not None:
             parity_ok = bool(parity_ok) and qaoa['matches_closed_form']
+        # what this run is against the STATED size of BASELINE config 5 -- QubitCircuit(34) on eight MI355X, 31 local qubits:
+        # 16 + 16 GiB per rank for the forward, eight shard-sized buffers per rank for the sharded adjoint (128 GiB) -- which
+        # needs one GPU per rank; ranks that share a GPU (the full-size test of the one-GPU box) stop at n = 33 / n = 31
+        qaoa['stated_size'] = {'forward_nqubit': 34, 'qaoa_nqubit': 34, 'ranks': 8,
+                               'this_run': {'forward_nqubit': n, 'qaoa_nqubit': nq, 'ranks': world},
+                               'at_stated_size': bool(n == 34 and nq == 34 and world == 8),
+                               'pin_for_the_stated_size': 'tests/golden/pin_n34_cx.npz (consumed by this harness when n = 34)'}
 
     if rank == 0:
         total_gate_applies = ngates * nbatch * args.steps * (world if multi and not distributed else 1)
