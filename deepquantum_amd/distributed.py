@@ -1458,13 +1458,7 @@ def _slice_qubits(ph: list[int], prims: Sequence[Prim], i: int, n: int, L: int, 
         return []
     nxt = _next_use(prims, i, n)
     leaving_local = {eq for _, eq in pairs}
-    # (the gates right in front of the exchange are the ones the last pass is likeliest to hold: qubits they target come last)
-    recent: set = set()
-    for p in prims[max(0, i - int(CONFIG.get('slice_recent_gates', 48))):i]:
-        if p.kind != 'diag':
-            recent.update(p.targets)
-    cand = sorted((q for q in range(n) if _UNFOLDABLE_BELOW <= ph[q] < L and q not in leaving_local),
-                  key=lambda q: (q in recent, -nxt[q], -q))
+    cand = sorted((q for q in range(n) if _UNFOLDABLE_BELOW <= ph[q] < L and q not in leaving_local), key=lambda q: (-nxt[q], -q))
     return cand[:nbits]
 
 
