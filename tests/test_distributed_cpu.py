@@ -478,8 +478,8 @@ def _case_deferred_tail_w4(dq, rank, world):
 
 
 def _case_sliced_exchange_w2(dq, rank, world):
-    _sliced_exchange_check(dq, rank, world, 17, double=True)
-    _sliced_exchange_check(dq, rank, world, 18, double=False)
+    _sliced_exchange_check(dq, rank, world, 16, double=True)
+    _sliced_exchange_check(dq, rank, world, 17, double=False)
 
 
 def _case_sliced_exchange_w4(dq, rank, world):
