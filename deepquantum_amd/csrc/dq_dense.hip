@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __re
     }
 
     // ---- scatter: lane holds column (lane & 15) of each block, four rows per block ------------------------------
+    const uint64_t off_rowlane = target_offset(M::row(lane, 0), g);
 #pragma unroll
     for (int b = 0; b < BN; ++b) {
         const uint64_t c = col0 + (uint64_t)(wn * BN * 16 + b * 16 + l15);
@@ -233,12 +234,19 @@ __global__ __launch_bounds__(256) void apply_dense_mfma_kernel(const cx<T>* __re
         const uint64_t sample = col_sample_shift >= 0 ? (c >> col_sample_shift) : (uint64_t)zb;
         const uint64_t within = col_sample_shift >= 0 ? (c & ((1ull << col_sample_shift) - 1ull)) : c;
         cx<T>* po = out + (sample << g.n) + (insert_zeros(within, g.sorted) | g.cmask);
+        // row = (row0 + 16 (wm BM + a)) + (lane part) + (reg part): three disjoint bit fields of the row pattern, and the offset
+        // of a pattern is bitwise linear in it -- the lane part once per thread, the rest per WAVE in scalar registers
+        // (round 6: the 16 full `target_offset(r)` per tile, ~60 64-bit vector operations each, were the fixed per-tile cost
+        // that kept k = 6 / 7 at 0.50 / 0.61 of the MFMA peak: profiles/r06/exp_dense_ustat.txt)
 #pragma unroll
         for (int a = 0; a < BM; ++a)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int r = row0 + wm * BM * 16 + a * 16 + M::row(lane, reg);
-                st_amp<T, NT>(po + target_offset(r, g), cr[a][b][reg], ci[a][b][reg]);
+                const int ru = __builtin_amdgcn_readfirstlane(row0 + wm * BM * 16 + a * 16) + (M::row(0, reg) - M::row(0, 0));
+                const uint64_t ou = target_offset(ru, g);
+                const uint64_t ous = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ou >> 32)) << 32) |
+                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ou);
+                st_amp<T, NT>(po + (ous | off_rowlane), cr[a][b][reg], ci[a][b][reg]);
             }
     }
 }
@@ -296,6 +304,7 @@ void apply_dense56_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
         }
     };
     const int row0 = (wave % H) * 32;
+    const uint64_t off_rowlane56 = target_offset(M::row(lane, 0), g);
     const uint64_t stride = (uint64_t)gridDim.x * (4u / H);
     uint64_t grp = (uint64_t)blockIdx.x * (4u / H) + (uint64_t)(wave / H);
     V b[KS], bn[PREFETCH ? KS : 1];
@@ -341,14 +350,18 @@ void apply_dense56_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out,
         for (int a = 0; a < RB; ++a)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int r = row0 + a * 16 + M::row(lane, reg);
                 V v;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     v[2 * c] = cr[a][c][reg];
                     v[2 * c + 1] = ci[a][c][reg];
                 }
-                V* p = reinterpret_cast<V*>(out + base + target_offset(r, g));
+                // (the row pattern's offset: uniform part per wave in scalar registers, lane part once per thread -- see the
+                // staged kernel's scatter)
+                const uint64_t ou = target_offset(__builtin_amdgcn_readfirstlane(row0 + a * 16) + (M::row(0, reg) - M::row(0, 0)), g);
+                const uint64_t ous = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ou >> 32)) << 32) |
+                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ou);
+                V* p = reinterpret_cast<V*>(out + base + (ous | off_rowlane56));
                 if constexpr (NT) __builtin_nontemporal_store(v, p);
                 else *p = v;
             }
